@@ -1,0 +1,164 @@
+// ORACLE - TEST INFRASTRUCTURE ONLY (see frizbee_oracle.hpp header).
+// C ABI over the CPU restatement so pytest (ctypes) and bench.py's cpu_baseline leg can call it.
+#include "frizbee_oracle.hpp"
+
+using namespace fzo;
+
+template <int L>
+static Window pf_run(const std::string& needle, const u8* h, size_t hlen, int max_typos, bool cs, bool unicode) {
+    Prefilter<L> p(needle, cs);
+    if (unicode) {
+        if (max_typos == 0) return p.match_haystack_unicode(h, hlen);
+        if (max_typos == 1) return p.match_haystack_unicode_1_typo(h, hlen);
+        if (max_typos == 2) return p.match_haystack_unicode_2_typos(h, hlen);
+        return p.match_haystack_unicode_many_typos(h, hlen, (size_t)max_typos);
+    }
+    if (max_typos == 0) return p.match_haystack(h, hlen);
+    if (max_typos == 1) return p.match_haystack_1_typo(h, hlen);
+    if (max_typos == 2) return p.match_haystack_2_typos(h, hlen);
+    return p.match_haystack_many_typos(h, hlen, (size_t)max_typos);
+}
+
+template <int L, typename T>
+static u16 sw_run(const std::string& n, const Scoring& sc, bool cs, const u8* h, size_t hlen, bool include_prefix, bool unicode) {
+    SmithWaterman<L, T> sw(n, sc, cs);
+    return unicode ? sw.score_haystack_unicode(h, hlen, include_prefix) : sw.score_haystack(h, hlen, include_prefix);
+}
+
+extern "C" {
+
+struct fzo_config {
+    int32_t max_typos;  // -1 == None
+    int32_t casing, unicode, sort;
+    uint16_t scoring[9];  // match, mismatch, gap_open, gap_extend, prefix, capitalization, matching_case, exact_match, delimiter
+};
+
+static thread_local std::string g_err;
+const char* fzo_last_error() { return g_err.c_str(); }
+
+static Scoring scoring_from(const uint16_t s[9]) {
+    Scoring r;
+    r.match_score = s[0]; r.mismatch_penalty = s[1]; r.gap_open_penalty = s[2]; r.gap_extend_penalty = s[3];
+    r.prefix_bonus = s[4]; r.capitalization_bonus = s[5]; r.matching_case_bonus = s[6]; r.exact_match_bonus = s[7]; r.delimiter_bonus = s[8];
+    return r;
+}
+static Config config_from(const fzo_config* c) {
+    Config r;
+    r.max_typos = c->max_typos; r.casing = c->casing; r.unicode = c->unicode; r.sort = c->sort;
+    r.scoring = scoring_from(c->scoring);
+    return r;
+}
+
+// out = {matched, start, end}.  Returns 0 on success.
+int fzo_prefilter(const uint8_t* needle, size_t nlen, const uint8_t* hay, size_t hlen, int max_typos, int case_sensitive, int unicode, int lanes, uint64_t out[3]) {
+    try {
+        std::string n((const char*)needle, nlen);
+        Window w;
+        switch (lanes) {
+            case 16: w = pf_run<16>(n, hay, hlen, max_typos, case_sensitive, unicode); break;
+            case 32: w = pf_run<32>(n, hay, hlen, max_typos, case_sensitive, unicode); break;
+            case 64: w = pf_run<64>(n, hay, hlen, max_typos, case_sensitive, unicode); break;
+            default: g_err = "bad lanes"; return 1;
+        }
+        out[0] = w.matched; out[1] = w.start; out[2] = w.end;
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// Raw `score_haystack[_unicode]` (no prefilter / trim / exact bonus).  Returns score, or -1 on error.
+int fzo_sw_score(const uint8_t* needle, size_t nlen, const uint8_t* hay, size_t hlen, const uint16_t scoring[9], int case_sensitive, int include_prefix, int unicode, int lanes, int is_u8) {
+    try {
+        std::string n((const char*)needle, nlen);
+        Scoring sc = scoring_from(scoring);
+#define RUN(L) (is_u8 ? sw_run<L, u8>(n, sc, case_sensitive, hay, hlen, include_prefix, unicode) : sw_run<L, u16>(n, sc, case_sensitive, hay, hlen, include_prefix, unicode))
+        switch (lanes) {
+            case 8: return RUN(8);
+            case 16: return RUN(16);
+            case 32: return RUN(32);
+            case 64: return RUN(64);
+            default: g_err = "bad lanes"; return -1;
+        }
+#undef RUN
+    } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// match_greedy: returns score or -1 for None
+int fzo_greedy(const uint8_t* needle, size_t nlen, const uint8_t* hay, size_t hlen, const uint16_t scoring[9], int case_sensitive, int include_prefix) {
+    u16 s;
+    return match_greedy(std::string((const char*)needle, nlen), hay, hlen, scoring_from(scoring), case_sensitive, include_prefix, s) ? (int)s : -1;
+}
+
+int fzo_score_fits_in_u8(size_t needle_len, const uint16_t scoring[9]) { return score_fits_in_u8(needle_len, scoring_from(scoring)); }
+int fzo_max_needle_len(const uint16_t scoring[9]) {  // lib.rs:482-484
+    Scoring s = scoring_from(scoring);
+    return (int)(sat_sub16(0xFFFF, max_one_time_bonus(s)) / max_per_char_bonus(s));
+}
+
+void* fzo_matcher_create(const fzo_config* cfg, const uint8_t* needle, size_t nlen, int pf_lanes, int sw_lanes_u8, int sw_lanes_u16) {
+    try {
+        return new Matcher(std::string((const char*)needle, nlen), config_from(cfg), pf_lanes, sw_lanes_u8, sw_lanes_u16);
+    } catch (std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void fzo_matcher_free(void* m) { delete (Matcher*)m; }
+int fzo_matcher_info(void* m, int out[3]) {
+    Matcher* mm = (Matcher*)m;
+    out[0] = mm->pf_lanes; out[1] = mm->sw_lanes; out[2] = mm->use_u8;
+    return 0;
+}
+
+// threads < 0 -> match_list, else match_list_parallel(threads). Result is malloc'd; free with fzo_free.
+int fzo_match_list(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, long threads, Match** out, size_t* out_len) {
+    try {
+        HaystackList hs{bytes, ends, n};
+        Matcher* mm = (Matcher*)m;
+        std::vector<Match> r = threads < 0 ? mm->match_list(hs) : mm->match_list_parallel(hs, (size_t)threads);
+        *out_len = r.size();
+        *out = (Match*)malloc(std::max<size_t>(r.size(), 1) * sizeof(Match));
+        if (!r.empty()) memcpy(*out, r.data(), r.size() * sizeof(Match));
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+// Same as fzo_match_list but discards the result (timing leg): returns number of matches via out_len.
+int fzo_match_list_count(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, long threads, size_t* out_len) {
+    try {
+        HaystackList hs{bytes, ends, n};
+        Matcher* mm = (Matcher*)m;
+        std::vector<Match> r = threads < 0 ? mm->match_list(hs) : mm->match_list_parallel(hs, (size_t)threads);
+        *out_len = r.size();
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+void fzo_free(void* p) { free(p); }
+
+void fzo_radix_sort(Match* matches, size_t n) {
+    std::vector<Match> v(matches, matches + n);
+    radix_sort_matches(v);
+    if (n) memcpy(matches, v.data(), n * sizeof(Match));
+}
+// runs: concatenated, run_lens[k] entries each; out must hold the total.
+void fzo_k_merge(int order, const Match* runs, const size_t* run_lens, size_t nruns, Match* out) {
+    std::vector<std::vector<Match>> rs;
+    size_t off = 0;
+    for (size_t k = 0; k < nruns; k++) { rs.emplace_back(runs + off, runs + off + run_lens[k]); off += run_lens[k]; }
+    auto merged = k_merge_matches_by(order, rs);
+    if (!merged.empty()) memcpy(out, merged.data(), merged.size() * sizeof(Match));
+}
+
+// Needle preparation probes (for host-logic tests)
+int fzo_respects_case_for(int casing, const uint8_t* needle, size_t nlen) {
+    try { return respects_case_for(casing, std::string((const char*)needle, nlen)); } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
+// out: per scalar 9 bytes: chars[4], flipped[4], len. Returns scalar count or -1.
+int fzo_case_needle_unicode(const uint8_t* needle, size_t nlen, int case_sensitive, uint8_t* out, size_t cap) {
+    try {
+        auto v = case_needle_unicode(std::string((const char*)needle, nlen), case_sensitive);
+        for (size_t i = 0; i < v.size() && i < cap; i++) {
+            memcpy(out + 9 * i, v[i].chars, 4);
+            memcpy(out + 9 * i + 4, v[i].flipped, 4);
+            out[9 * i + 8] = (uint8_t)v[i].len;
+        }
+        return (int)v.size();
+    } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
+
+}  // extern "C"

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/*.json: known-answer vectors transcribed BY HAND from the reference's own
+tests (the reference is Rust and cannot be executed in the build image, so these are the values its
+test-suite asserts, not values produced by running it).  Each vector carries the reference
+file:line of the assertion it comes from.  Re-run to regenerate the JSON after editing."""
+import json, os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CHAR = 16  # MATCH_SCORE 12 + MATCHING_CASE_BONUS 4 (src/smith_waterman/mod.rs:159)
+PREFIX, DELIM, CAP, GOP, GEX, MATCH = 12, 4, 4, 5, 1, 12
+
+# ---- score_haystack(needle, haystack, include_prefix=true), case-insensitive, default Scoring,
+#      asserted on BackendScalar8 (LANES=8, u16): src/smith_waterman/mod.rs:163-166 ----
+sw_ascii = [
+    ("b", "abc", CHAR, "src/smith_waterman/mod.rs:209"),
+    ("c", "abc", CHAR, "src/smith_waterman/mod.rs:210"),
+    ("a", "abc", CHAR + PREFIX, "src/smith_waterman/mod.rs:215"),
+    ("a", "aabc", CHAR + PREFIX, "src/smith_waterman/mod.rs:216"),
+    ("a", "babc", CHAR, "src/smith_waterman/mod.rs:217"),
+    ("a", "a", CHAR + PREFIX, "src/smith_waterman/mod.rs:222"),
+    ("abc", "abc", 3 * CHAR + PREFIX, "src/smith_waterman/mod.rs:223"),
+    ("-", "a--bc", CHAR, "src/smith_waterman/mod.rs:256"),
+    ("b", "a-b", CHAR + DELIM, "src/smith_waterman/mod.rs:257"),
+    ("a", "a-b-c", CHAR + PREFIX, "src/smith_waterman/mod.rs:258"),
+    ("b", "a--b", CHAR + DELIM, "src/smith_waterman/mod.rs:259"),
+    ("c", "a--bc", CHAR, "src/smith_waterman/mod.rs:260"),
+    ("a", "-a--bc", CHAR + DELIM, "src/smith_waterman/mod.rs:261"),
+    ("-", "a-bc", CHAR, "src/smith_waterman/mod.rs:266"),
+    ("-", "a--bc", CHAR, "src/smith_waterman/mod.rs:267"),
+    ("test", "Uteost", CHAR * 4 - GOP, "src/smith_waterman/mod.rs:273-276"),
+    ("test", "Uteoost", CHAR * 4 - GOP - GEX, "src/smith_waterman/mod.rs:277-280"),
+    ("test", "Utooooeoooosoooot", CHAR * 4 - GOP * 3 - GEX * 9, "src/smith_waterman/mod.rs:281-284"),
+    ("test", "Utooooooeoooooosoooooot", CHAR * 4 - GOP * 3 - GEX * 15, "src/smith_waterman/mod.rs:285-288"),
+    ("a", "A", MATCH + PREFIX, "src/smith_waterman/mod.rs:293"),
+    ("A", "Aa", CHAR + PREFIX, "src/smith_waterman/mod.rs:294"),
+    ("D", "forDist", CHAR + CAP, "src/smith_waterman/mod.rs:295"),
+    ("D", "foRDist", CHAR, "src/smith_waterman/mod.rs:296"),
+    ("D", "FOR_DIST", CHAR + DELIM, "src/smith_waterman/mod.rs:297"),
+    ("foo", "Ufooo", CHAR * 3, "src/smith_waterman/mod.rs:422"),
+    ("foo", "Ufo", CHAR * 2 - GOP, "src/smith_waterman/mod.rs:424-431"),
+    ("foo", "Uf", CHAR - GOP - GEX, "src/smith_waterman/mod.rs:433-436"),
+    ("foo", "U", 0, "src/smith_waterman/mod.rs:438-439"),
+]
+# long-haystack boundary incl. the greedy fallback at 1025 (src/smith_waterman/mod.rs:508-520)
+sw_long = [("abc", L, 3 * CHAR, "src/smith_waterman/mod.rs:510-513") for L in (1023, 1024, 1025)]
+# case-sensitive scorer (src/smith_waterman/mod.rs:351-362)
+sw_case = [
+    ("A", "A", True, CHAR + PREFIX, "src/smith_waterman/mod.rs:353-356"),
+    ("A", "a", False, MATCH + PREFIX, "src/smith_waterman/mod.rs:358-361"),
+]
+# ordering assertions: score(a) > score(b)  (src/smith_waterman/mod.rs:268, 300-349)
+sw_greater = [
+    (("a_b", "a_bb"), ("a_b", "a__b"), "src/smith_waterman/mod.rs:268"),
+    (("swap", "swap(test)"), ("swap", "iter_swap(test)"), "src/smith_waterman/mod.rs:302"),
+    (("_", "_private_member"), ("_", "public_member"), "src/smith_waterman/mod.rs:303"),
+    (("H", "HELLO"), ("H", "fooHello"), "src/smith_waterman/mod.rs:308"),
+    (("foo", "fooo"), ("foo", "f_o_o_o"), "src/smith_waterman/mod.rs:313"),
+    (("fo", "foo"), ("fo", "faOo"), "src/smith_waterman/mod.rs:318"),
+    (("abc", "a111bc"), ("abc", "a1b1c"), "src/smith_waterman/mod.rs:341"),
+    (("b", "b"), ("b", "a-b"), "src/smith_waterman/mod.rs:346"),
+    (("b", "a-b"), ("b", "ab"), "src/smith_waterman/mod.rs:347"),
+    (("B", "aB"), ("b", "aB"), "src/smith_waterman/mod.rs:348"),
+]
+# score_haystack_unicode (src/smith_waterman/mod.rs:227-252)
+sw_unicode = [
+    ("é", "é", CHAR + PREFIX, "src/smith_waterman/mod.rs:229"),
+    ("😀", "😀", CHAR + PREFIX, "src/smith_waterman/mod.rs:230"),
+    ("éx", "éx", 2 * CHAR + PREFIX, "src/smith_waterman/mod.rs:231"),
+    ("ab", "aéb", 2 * CHAR + PREFIX - GOP, "src/smith_waterman/mod.rs:240-243"),
+    ("ab", "aé😀b", 2 * CHAR + PREFIX - GOP - GEX, "src/smith_waterman/mod.rs:248-251"),
+]
+sw_unicode_equal = [(("éx", "ébx"), ("éx", "é😀x"), "src/smith_waterman/mod.rs:236-239")]
+# fixed corpus that every backend width must score identically (src/smith_waterman/backend/tests/parity.rs:95-124)
+sw_cross_width = [
+    ("a", "abc"), ("abc", "abc"), ("foo", "fooBar"), ("foo", "012345foo"), ("foo", "01234567foo"),
+    ("foo", "0123456789foo"), ("foo", "0123456789012345foo"), ("foo", "0123456789012345678901234567foo"),
+    ("test", "Utooooeoooosoooot"), ("test", "Utooooooeoooooosoooooot"), ("foo", "Ufooo"), ("foo", "Ufo"),
+    ("hw", "hello_world"), ("fBr", "fooBar"), ("D", "FOR_DIST"), ("needle", "____________needle____________"),
+    ("abcdefghij", "abcdefghij"), ("abcdefghijklmnopqrst", "abcdefghijklmnopqrst"),
+]
+# match_greedy(needle, haystack, default, case_sensitive=false, include_prefix=true) (src/smith_waterman/greedy.rs:100-192)
+greedy = [
+    ("b", "abc", CHAR, "src/smith_waterman/greedy.rs:114"), ("c", "abc", CHAR, "src/smith_waterman/greedy.rs:115"),
+    ("fbb", "barbazfoobarbaz", CHAR - GOP - GEX + CHAR - GOP - GEX + CHAR, "src/smith_waterman/greedy.rs:116-122"),
+    ("a", "b", 0, "src/smith_waterman/greedy.rs:127"), ("ab", "ba", 0, "src/smith_waterman/greedy.rs:128"), ("abc", "ab", 0, "src/smith_waterman/greedy.rs:129"),
+    ("a", "abc", CHAR + PREFIX, "src/smith_waterman/greedy.rs:134"), ("a", "aabc", CHAR + PREFIX, "src/smith_waterman/greedy.rs:135"), ("a", "babc", CHAR, "src/smith_waterman/greedy.rs:136"),
+    ("-", "a--bc", CHAR, "src/smith_waterman/greedy.rs:141"), ("b", "a-b", CHAR + DELIM, "src/smith_waterman/greedy.rs:142"), ("a", "a-b-c", CHAR + PREFIX, "src/smith_waterman/greedy.rs:143"),
+    ("b", "a--b", CHAR + DELIM, "src/smith_waterman/greedy.rs:144"), ("c", "a--bc", CHAR, "src/smith_waterman/greedy.rs:145"), ("a", "-a--bc", CHAR, "src/smith_waterman/greedy.rs:146"),
+    ("-", "a-bc", CHAR, "src/smith_waterman/greedy.rs:151"), ("test", "Uterst", CHAR * 4 - GOP, "src/smith_waterman/greedy.rs:165-168"),
+    ("test", "Uterrst", CHAR * 4 - GOP - GEX, "src/smith_waterman/greedy.rs:169-172"),
+    ("a", "A", MATCH + PREFIX, "src/smith_waterman/greedy.rs:177"), ("A", "Aa", CHAR + PREFIX, "src/smith_waterman/greedy.rs:178"),
+    ("d", "forDist", MATCH + CAP, "src/smith_waterman/greedy.rs:179-182"), ("D", "forDist", CHAR + CAP, "src/smith_waterman/greedy.rs:183"),
+    ("D", "foRDist", CHAR, "src/smith_waterman/greedy.rs:184"), ("D", "FOR_DIST", CHAR + DELIM, "src/smith_waterman/greedy.rs:185"),
+]
+json.dump({
+    "greedy": [dict(needle=n, haystack=h, score=s, ref=r) for n, h, s, r in greedy],
+    "greedy_huge_gap": dict(needle="ab", x_count=70000, score=4, ref="src/smith_waterman/greedy.rs:157-161"),
+    "default_scoring": [12, 6, 5, 1, 12, 4, 4, 8, 4],
+    "sw_ascii": [dict(needle=n, haystack=h, score=s, ref=r) for n, h, s, r in sw_ascii],
+    "sw_long": [dict(needle=n, haystack_len=L, score=s, ref=r) for n, L, s, r in sw_long],
+    "sw_case": [dict(needle=n, haystack=h, case_sensitive=cs, score=s, ref=r) for n, h, cs, s, r in sw_case],
+    "sw_greater": [dict(a=list(a), b=list(b), ref=r) for a, b, r in sw_greater],
+    "sw_unicode": [dict(needle=n, haystack=h, score=s, ref=r) for n, h, s, r in sw_unicode],
+    "sw_unicode_equal": [dict(a=list(a), b=list(b), ref=r) for a, b, r in sw_unicode_equal],
+    "sw_cross_width": [dict(needle=n, haystack=h, ref="src/smith_waterman/backend/tests/parity.rs:95-124,184-190") for n, h in sw_cross_width],
+}, open(os.path.join(HERE, "smith_waterman.json"), "w"), ensure_ascii=False, indent=1)
+
+# ---- prefilter (src/prefilter/mod.rs:187-404) ----
+U = "_"
+pf_bool = [  # (needle, haystack, max_typos, case_sensitive, want)
+    ("foo", "foo", 0, False, True), ("foo", "f_o_o", 0, False, True), ("foo", "FOO", 0, False, True),
+    ("abc", "xaxbxcx", 0, False, True), ("fo", U * 15 + "fo", 0, False, True),
+    ("foo", "f" + U * 15 + "o" + U * 15 + "o", 0, False, True), ("foo", "oof", 0, False, False),
+    ("abc", "cba", 0, False, False), ("foo", "fo", 0, False, False),
+    ("foo", "f" + U * 25 + "o" + U * 6, 0, False, False), ("a", "", 0, False, False),
+    ("\0", "abc", 0, False, False), ("aa", "a", 0, False, False),
+    # typo_matching_cases :212-248
+    ("abc", "", 2, False, False), ("abc", "", 3, False, True), ("abc", "bc", 1, False, True),
+    ("abc", "ac", 1, False, True), ("abc", "ab", 1, False, True), ("bar", "ba", 1, False, True),
+    ("bar", "ar", 1, False, True), ("hello", "hll", 2, False, True), ("abcdef", "abdf", 2, False, True),
+    ("TeSt", "ES", 2, False, True), ("abc", "c", 2, False, True), ("a\0b", "ab", 1, False, True),
+    ("foo", "fo", 5, False, True), ("abc", "a" + U * 15 + "b", 1, False, True),
+    ("test", "t" + U * 15 + "s" + U * 15 + "t", 1, False, True),
+    ("d63NacaDJaaaa", "63aeeaaaeeaaaaaaaNacaDJaaAa", 1, False, True), ("bar", "rb", 1, False, False),
+    ("abcdef", "fcda", 2, False, False), ("TeSt", "ES", 1, False, False), ("abc", "cba", 1, False, False),
+    ("abc", "cba", 2, False, True), ("aaa", "aa", 0, False, False), ("aaa", "aa", 1, False, True),
+    ("aba", "aa", 1, False, True), ("aaba", "aba", 1, False, True),
+    # case_sensitive_matching_cases :250-270
+    ("foo", "foo", 0, True, True), ("foo", "FOO", 0, True, False), ("FoO", "xxFoOxx", 0, True, True),
+    ("abc", "xaxbxcx", 0, True, True), ("abc", "xAxBxCx", 0, True, False), ("TeSt", "eS", 2, True, True),
+    ("TeSt", "ES", 2, True, False), ("Ab", "b", 1, True, True), ("Ab", "ab", 0, True, False), ("Ab", "ab", 1, True, True),
+]
+pf_window = [  # (needle, haystack, max_typos, case_sensitive, unicode, [matched,start,end], ref)
+    ("foo", "xxfooxfoo", 0, False, False, [True, 2, 9], "src/prefilter/mod.rs:274"),
+    ("abc", "xxaybzczz", 0, False, False, [True, 2, 7], "src/prefilter/mod.rs:275"),
+    ("abcd", "xxaydz", 2, False, False, [True, 2, 5], "src/prefilter/mod.rs:276"),
+    ("abc", "xyz", 3, False, False, [True, 0, 3], "src/prefilter/mod.rs:277"),
+    ("إن", "xxإنyy", 0, False, True, [True, 2, 6], "src/prefilter/mod.rs:283"),
+    ("니다", "xx니__다yy", 0, False, True, [True, 2, 10], "src/prefilter/mod.rs:284"),
+    ("😀", "xx😀yy", 0, False, True, [True, 2, 6], "src/prefilter/mod.rs:285"),
+    ("é", "٩É", 0, False, True, [True, 2, 4], "src/prefilter/mod.rs:322"),
+    ("É", "é", 0, False, True, [True, 0, 2], "src/prefilter/mod.rs:401"),
+    ("إن", "ن", 1, False, True, [True, 0, 2], "src/prefilter/mod.rs:352-355"),
+    ("éन😀", "😀", 2, False, True, [True, 0, 4], "src/prefilter/mod.rs:361-364"),
+    ("😀éनZ", "Z", 3, False, True, [True, 0, 1], "src/prefilter/mod.rs:370-373"),
+]
+pf_unicode_bool = [  # (needle, haystack, max_typos, case_sensitive, want, ref)
+    ("إن", "ۥ؆", 0, False, False, "src/prefilter/mod.rs:305-308"),
+    ("é", "٩É", 0, True, False, "src/prefilter/mod.rs:323"),
+    ("éé", "٩É٩É٩É", 1, False, True, "src/prefilter/mod.rs:324"),
+    ("إن", "ن", 0, False, False, "src/prefilter/mod.rs:356"),
+    ("éन😀", "😀", 1, False, False, "src/prefilter/mod.rs:365"),
+    ("😀éनZ", "Z", 2, False, False, "src/prefilter/mod.rs:374"),
+    ("إن", "ۥ", 1, False, False, "src/prefilter/mod.rs:386"),
+    ("إن", "؆", 1, False, False, "src/prefilter/mod.rs:387"),
+    ("É", "é", 0, True, False, "src/prefilter/mod.rs:402"),
+]
+json.dump({
+    "pf_bool": [dict(needle=n, haystack=h, max_typos=t, case_sensitive=cs, matched=w, ref="src/prefilter/mod.rs:187-270") for n, h, t, cs, w in pf_bool],
+    "pf_window": [dict(needle=n, haystack=h, max_typos=t, case_sensitive=cs, unicode=u, window=w, ref=r) for n, h, t, cs, u, w, r in pf_window],
+    "pf_unicode_bool": [dict(needle=n, haystack=h, max_typos=t, case_sensitive=cs, matched=w, ref=r) for n, h, t, cs, w, r in pf_unicode_bool],
+    # sweeps: expected window computed from the rule the reference asserts
+    "pf_unicode_prefix_sweep": dict(needle="إن", prefix_lens=[0, 1, 7, 14, 15, 16, 31, 32, 63, 64], ref="src/prefilter/mod.rs:326-336"),
+    "pf_ascii_chunk_sweep": dict(prefix_lens=[0, 1, 7, 8, 15, 16, 31, 32, 63, 64],
+                                 cases=[["abc", 0, True], ["ac", 0, True], ["abcd", 0, False], ["abcd", 1, True]], ref="src/prefilter/mod.rs:472-503"),
+}, open(os.path.join(HERE, "prefilter.json"), "w"), ensure_ascii=False, indent=1)
+
+# ---- end-to-end Matcher (src/matcher/mod.rs:532-654, src/matcher/algo.rs:344-456, tests/api_properties.rs) ----
+D4 = ["deadbeef", "deadbf", "deadbeefg", "deadbe"]
+def hs_with(n, items):
+    # expanded by the test as: ["nomatch-%d" % i ...] with the listed overrides (tests/api_properties.rs haystacks_with)
+    return {"haystacks_with": [n, [list(x) for x in items]]}
+matcher = [
+    dict(name="test_basic", needle="deadbe", haystacks=D4, config=dict(max_typos=None), expect_indices=[3, 0, 2, 1], ref="src/matcher/mod.rs:533-547"),
+    dict(name="test_no_typos", needle="deadbe", haystacks=D4, config=dict(max_typos=0), expect_len=3, ref="src/matcher/mod.rs:550-557"),
+    dict(name="test_exact_match", needle="deadbe", haystacks=D4, config=dict(), expect_exact_indices=[3], ref="src/matcher/mod.rs:560-572"),
+    dict(name="test_exact_matches", needle="deadbe", haystacks=["deadbe", "deadbeef", "deadbe", "deadbf", "deadbe", "deadbeefg", "deadbe"], config=dict(),
+         expect_exact_indices=[0, 2, 4, 6], ref="src/matcher/mod.rs:575-594"),
+    dict(name="test_small_needle", needle="1", haystacks=["1"], config=dict(max_typos=2), expect_indices=[0], expect_exact_indices=[0], ref="src/matcher/mod.rs:597-603"),
+    dict(name="case_smart_lower", needle="foo", haystacks=["foo", "FOO", "fOo", "xxfooxx"], config=dict(sort="IndexAsc"), expect_indices=[0, 1, 2, 3], ref="src/matcher/mod.rs:620-628"),
+    dict(name="case_respect", needle="foo", haystacks=["foo", "FOO", "fOo", "xxfooxx"], config=dict(sort="IndexAsc", casing="Respect"), expect_indices=[0, 3], ref="src/matcher/mod.rs:630-638"),
+    dict(name="case_smart_upper", needle="FoO", haystacks=["foo", "FOO", "FoO", "xxFoOxx"], config=dict(sort="IndexAsc", casing="Smart"), expect_indices=[2, 3], ref="src/matcher/mod.rs:646-654"),
+    dict(name="zero_gap_capitalization", needle="BBBB", haystacks=["aBaBaBaB"],
+         config=dict(scoring=[40, 0, 0, 0, 0, 40, 0, 0, 0]), expect_scores=[320], ref="src/matcher/algo.rs:424-440"),
+    dict(name="unsorted_preserves_order", needle="foo", haystacks=["foo", "nomatch", "xfoo", "f_o_o", "bar"], config=dict(sort="IndexAsc"), expect_indices=[0, 2, 3], ref="src/matcher/algo.rs:443-456"),
+    dict(name="empty_needle", needle="", haystacks=["foo", "bar"], config=dict(), expect_indices=[0, 1], expect_scores=[0, 0], ref="tests/api_properties.rs:420-428"),
+    dict(name="exact_flag_tracks", needle="deadbe", haystacks=["deadbe", "deadbeef", "deadbe", "deadbf", "xxdeadbexx"], config=dict(),
+         expect_exact_map={"0": True, "1": False, "2": True, "4": False}, ref="tests/api_properties.rs:437-449"),
+    dict(name="unicode_zero_typo", needle="إن", haystacks=["xxإنyy", "إن", "ۥ؆", "nomatch", "x" * 65], config=dict(max_typos=0, sort="IndexAsc"),
+         expect_indices=[0, 1], expect_exact_list=[False, True], ref="tests/api_properties.rs:452-476"),
+    dict(name="parallel_tie_chunks", needle="abc", haystacks=hs_with(4097, [(2047, "abc"), (2048, "abc"), (4096, "abc")]), config=dict(),
+         expect_indices=[2047, 2048, 4096], ref="tests/api_properties.rs:656-665"),
+    dict(name="greedy_fallback_membership", needle="abc", haystacks=["a" + "z" * 1100 + "b"], config=dict(max_typos=1), expect_len=1, ref="src/matcher/algo.rs:396-408"),
+    dict(name="readme_smoke_fBr", needle="fBr", haystacks=["fooBar", "foo_bar", "barfoo", "prelude", "println!"], config=dict(), expect_indices=[0],
+         ref="README.md usage example; BASELINE.json configs[0] (score 53 is hand-derived in SURVEY.md, not reference-pinned)"),
+]
+json.dump({"cases": matcher,
+           "panics": [dict(needle="f", scoring=[12, 6, 5, 1, 12, 60000, 40000, 8, 4], message_contains="needle too long", ref="src/matcher/algo.rs:372-380")],
+           "max_needle_len_default": 10922, "max_needle_len_ref": "src/lib.rs:545-547",
+           "score_fits_in_u8": [dict(needle_len=4, scoring=[12, 6, 5, 1, 12, 4, 4, 8, 4], fits=True, ref="src/smith_waterman/mod.rs:523"),
+                                dict(needle_len=4, scoring=[12, 6, 5, 8, 12, 4, 4, 8, 4], fits=False, ref="src/smith_waterman/mod.rs:526-530")]},
+          open(os.path.join(HERE, "matcher.json"), "w"), ensure_ascii=False, indent=1)
+print("golden written")

@@ -1,0 +1,190 @@
+"""ctypes loader for oracle/libfrizbee_oracle.so (TEST INFRASTRUCTURE: the CPU restatement of the
+reference).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+DEFAULT_SCORING = [12, 6, 5, 1, 12, 4, 4, 8, 4]
+CASING = {"Ignore": 0, "Smart": 1, "Respect": 2}
+UNICODE = {"Ignore": 0, "Smart": 1, "Always": 2}
+SORT = {"ScoreThenIndexAsc": 0, "ScoreThenIndexDesc": 1, "IndexAsc": 2, "IndexDesc": 3}
+
+MATCH_DTYPE = np.dtype([("index", "<u4"), ("score", "<u2"), ("exact", "u1"), ("_pad", "u1")])
+
+
+class FzoConfig(C.Structure):
+    _fields_ = [("max_typos", C.c_int32), ("casing", C.c_int32), ("unicode", C.c_int32), ("sort", C.c_int32), ("scoring", C.c_uint16 * 9)]
+
+
+def build(native=False):
+    so = os.path.join(ORACLE_DIR, "libfrizbee_oracle.so")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "frizbee_oracle.hpp", "unicode_case_table.inc", "Makefile")]
+    if native or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        cmd = ["make", "-C", ORACLE_DIR] + (["-B", "NATIVE=1"] if native else [])
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = C.CDLL(build())
+        l.fzo_last_error.restype = C.c_char_p
+        l.fzo_prefilter.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        l.fzo_sw_score.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.fzo_greedy.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int]
+        l.fzo_score_fits_in_u8.argtypes = [C.c_size_t, C.POINTER(C.c_uint16)]
+        l.fzo_max_needle_len.argtypes = [C.POINTER(C.c_uint16)]
+        l.fzo_matcher_create.restype = C.c_void_p
+        l.fzo_matcher_create.argtypes = [C.POINTER(FzoConfig), C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        l.fzo_matcher_free.argtypes = [C.c_void_p]
+        l.fzo_matcher_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        l.fzo_match_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzo_match_list_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_size_t)]
+        l.fzo_free.argtypes = [C.c_void_p]
+        l.fzo_radix_sort.argtypes = [C.c_void_p, C.c_size_t]
+        l.fzo_k_merge.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.fzo_respects_case_for.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        l.fzo_case_needle_unicode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
+        _lib = l
+    return _lib
+
+
+def _b(s):
+    return s if isinstance(s, (bytes, bytearray)) else s.encode("utf-8")
+
+
+def _scoring(s):
+    return (C.c_uint16 * 9)(*(s or DEFAULT_SCORING))
+
+
+def prefilter(needle, haystack, max_typos=0, case_sensitive=False, unicode=False, lanes=64):
+    out = (C.c_uint64 * 3)()
+    n, h = _b(needle), _b(haystack)
+    rc = lib().fzo_prefilter(n, len(n), h, len(h), max_typos, int(case_sensitive), int(unicode), lanes, out)
+    if rc:
+        raise RuntimeError(lib().fzo_last_error().decode())
+    return (bool(out[0]), int(out[1]), int(out[2]))
+
+
+def sw_score(needle, haystack, scoring=None, case_sensitive=False, include_prefix=True, unicode=False, lanes=8, is_u8=False):
+    n, h = _b(needle), _b(haystack)
+    r = lib().fzo_sw_score(n, len(n), h, len(h), _scoring(scoring), int(case_sensitive), int(include_prefix), int(unicode), lanes, int(is_u8))
+    if r < 0:
+        raise RuntimeError(lib().fzo_last_error().decode())
+    return r
+
+
+def greedy(needle, haystack, scoring=None, case_sensitive=False, include_prefix=True):
+    n, h = _b(needle), _b(haystack)
+    return lib().fzo_greedy(n, len(n), h, len(h), _scoring(scoring), int(case_sensitive), int(include_prefix))
+
+
+def score_fits_in_u8(needle_len, scoring=None):
+    return bool(lib().fzo_score_fits_in_u8(needle_len, _scoring(scoring)))
+
+
+def max_needle_len(scoring=None):
+    return lib().fzo_max_needle_len(_scoring(scoring))
+
+
+def pack(haystacks):
+    """list[str|bytes] -> (uint8 bytes array (padded 64 zero bytes), uint64 exclusive end offsets)"""
+    bs = [_b(h) for h in haystacks]
+    ends = np.cumsum(np.fromiter((len(b) for b in bs), dtype=np.uint64, count=len(bs)), dtype=np.uint64) if bs else np.zeros(0, np.uint64)
+    data = np.frombuffer(b"".join(bs) + b"\0" * 64, dtype=np.uint8).copy()
+    return data, ends
+
+
+def make_config(max_typos=0, casing="Smart", unicode="Smart", sort="ScoreThenIndexAsc", scoring=None):
+    cfg = FzoConfig()
+    cfg.max_typos = -1 if max_typos is None else int(max_typos)
+    cfg.casing = CASING[casing] if isinstance(casing, str) else int(casing)
+    cfg.unicode = UNICODE[unicode] if isinstance(unicode, str) else int(unicode)
+    cfg.sort = SORT[sort] if isinstance(sort, str) else int(sort)
+    for i, v in enumerate(scoring or DEFAULT_SCORING):
+        cfg.scoring[i] = v
+    return cfg
+
+
+class Matcher:
+    """Oracle `Matcher` emulating the backend pair an ISA would select (matcher/mod.rs:448-498):
+    (pf_lanes, sw_lanes_u8, sw_lanes_u16) = (64,64,32) AVX-512+VBMI, (32,32,16) AVX2, (16,16,8) SSE/NEON/scalar."""
+
+    def __init__(self, needle, lanes=(64, 64, 32), **cfg):
+        self.cfg = make_config(**cfg)
+        n = _b(needle)
+        self.h = lib().fzo_matcher_create(C.byref(self.cfg), n, len(n), *lanes)
+        if not self.h:
+            raise RuntimeError(lib().fzo_last_error().decode())
+
+    def info(self):
+        out = (C.c_int * 3)()
+        lib().fzo_matcher_info(self.h, out)
+        return dict(pf_lanes=out[0], sw_lanes=out[1], use_u8=bool(out[2]))
+
+    def match_packed(self, data, ends, threads=-1):
+        out = C.c_void_p()
+        n = C.c_size_t()
+        rc = lib().fzo_match_list(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(out), C.byref(n))
+        if rc:
+            raise RuntimeError(lib().fzo_last_error().decode())
+        arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 8,))[: n.value * 8].view(MATCH_DTYPE).copy()
+        lib().fzo_free(out)
+        return arr
+
+    def count_packed(self, data, ends, threads=-1):
+        n = C.c_size_t()
+        rc = lib().fzo_match_list_count(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(n))
+        if rc:
+            raise RuntimeError(lib().fzo_last_error().decode())
+        return n.value
+
+    def match_list(self, haystacks):
+        return self.match_packed(*pack(haystacks))
+
+    def match_list_parallel(self, haystacks, threads):
+        return self.match_packed(*pack(haystacks), threads=threads)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().fzo_matcher_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def radix_sort(arr):
+    a = np.ascontiguousarray(arr.copy())
+    lib().fzo_radix_sort(a.ctypes.data, len(a))
+    return a
+
+
+def k_merge(order, runs):
+    lens = np.array([len(r) for r in runs], dtype=np.uint64)
+    cat = np.concatenate(runs) if runs else np.zeros(0, MATCH_DTYPE)
+    cat = np.ascontiguousarray(cat)
+    out = np.zeros(len(cat), MATCH_DTYPE)
+    lib().fzo_k_merge(SORT[order] if isinstance(order, str) else order, cat.ctypes.data, lens.ctypes.data, len(runs), out.ctypes.data)
+    return out
+
+
+def respects_case_for(casing, needle):
+    n = _b(needle)
+    return bool(lib().fzo_respects_case_for(CASING[casing], n, len(n)))
+
+
+def case_needle_unicode(needle, case_sensitive):
+    n = _b(needle)
+    buf = C.create_string_buffer(9 * (len(n) + 1))
+    k = lib().fzo_case_needle_unicode(n, len(n), int(case_sensitive), buf, len(n) + 1)
+    raw = buf.raw
+    return [(raw[9 * i : 9 * i + 4], raw[9 * i + 4 : 9 * i + 8], raw[9 * i + 8]) for i in range(k)]
