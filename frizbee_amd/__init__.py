@@ -1,0 +1,276 @@
+"""frizbee_amd - MI355X (gfx950) backend for saghen/frizbee's batched fuzzy-scoring path.
+
+A thin ctypes mirror of the reference's public surface for this path (`Matcher::new`, `match_list`,
+`match_list_parallel`, `Config`, `Scoring`, `Match`, `radix_sort_matches`; reference src/lib.rs:110-138,
+src/matcher/mod.rs:86-222, src/matcher/parallel.rs:18-89) over the C ABI in include/frizbee_hip.h.
+All scoring runs in hand-written HIP kernels (frizbee_amd/csrc); there is no CPU fallback: importing
+works anywhere, but every scoring call raises unless libfrizbee_hip.so is built and a GPU is present.
+"""
+import ctypes as C
+import enum
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfrizbee_hip.so")
+
+MATCH_DTYPE = np.dtype([("index", "<u4"), ("score", "<u2"), ("exact", "u1"), ("_pad", "u1")])
+
+
+class FrizbeeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class PanicError(FrizbeeError):
+    """The reference would `panic!` here; the message is the reference's panic text."""
+
+
+class CaseMatching(enum.IntEnum):  # src/lib.rs:357-368
+    Ignore = 0
+    Smart = 1
+    Respect = 2
+
+
+class UnicodeMatching(enum.IntEnum):  # src/lib.rs:379-392
+    Ignore = 0
+    Smart = 1
+    Always = 2
+
+
+class SortStrategy(enum.IntEnum):  # src/lib.rs:311-326
+    ScoreThenIndexAsc = 0
+    ScoreThenIndexDesc = 1
+    IndexAsc = 2
+    IndexDesc = 3
+
+
+@dataclass
+class Scoring:  # src/lib.rs:439-478, defaults src/const.rs:1-10
+    match_score: int = 12
+    mismatch_penalty: int = 6
+    gap_open_penalty: int = 5
+    gap_extend_penalty: int = 1
+    prefix_bonus: int = 12
+    capitalization_bonus: int = 4
+    matching_case_bonus: int = 4
+    exact_match_bonus: int = 8
+    delimiter_bonus: int = 4
+
+    def as_list(self):
+        return [self.match_score, self.mismatch_penalty, self.gap_open_penalty, self.gap_extend_penalty, self.prefix_bonus,
+                self.capitalization_bonus, self.matching_case_bonus, self.exact_match_bonus, self.delimiter_bonus]
+
+
+@dataclass
+class Config:  # src/lib.rs:236-271
+    max_typos: "int | None" = 0
+    casing: CaseMatching = CaseMatching.Smart
+    unicode: UnicodeMatching = UnicodeMatching.Smart
+    sort: SortStrategy = SortStrategy.ScoreThenIndexAsc
+    scoring: Scoring = field(default_factory=Scoring)
+    # which reference CPU backend to be bit-exact against; (0, 0) = what frizbee would pick on this host
+    pf_lanes: int = 0
+    sw_lanes: int = 0
+
+
+class _CScoring(C.Structure):
+    _fields_ = [(n, C.c_uint16) for n in ("match_score", "mismatch_penalty", "gap_open_penalty", "gap_extend_penalty", "prefix_bonus",
+                                          "capitalization_bonus", "matching_case_bonus", "exact_match_bonus", "delimiter_bonus")]
+
+
+class _CConfig(C.Structure):
+    _fields_ = [("max_typos", C.c_int32), ("casing", C.c_int32), ("unicode", C.c_int32), ("sort", C.c_int32), ("scoring", _CScoring),
+                ("pf_lanes", C.c_uint16), ("sw_lanes", C.c_uint16)]
+
+
+_lib = None
+
+SYMBOLS = [
+    "fzb_last_error", "fzb_config_default", "fzb_matcher_create", "fzb_matcher_clone", "fzb_matcher_free", "fzb_matcher_info",
+    "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
+    "fzb_match_list_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
+    "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
+]
+
+
+def lib():
+    """Loads libfrizbee_hip.so (raises if it has not been built: there is no fallback path)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise FrizbeeError(4, f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` (make -C frizbee_amd/csrc)")
+        l = C.CDLL(_LIB_PATH)
+        l.fzb_last_error.restype = C.c_char_p
+        l.fzb_config_default.argtypes = [C.POINTER(_CConfig)]
+        l.fzb_matcher_create.argtypes = [C.POINTER(_CConfig), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        l.fzb_matcher_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        l.fzb_matcher_free.argtypes = [C.c_void_p]
+        l.fzb_matcher_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        l.fzb_corpus_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        l.fzb_corpus_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.POINTER(C.c_void_p)]
+        l.fzb_corpus_free.argtypes = [C.c_void_p]
+        l.fzb_corpus_len.argtypes = [C.c_void_p]
+        l.fzb_corpus_len.restype = C.c_size_t
+        l.fzb_match_list.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_match_list_into.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_match_list_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        l.fzb_match_list_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_matches_free.argtypes = [C.c_void_p]
+        l.fzb_radix_sort_matches.argtypes = [C.c_void_p, C.c_size_t]
+        l.fzb_k_merge_matches.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        l.fzb_set_profiling.argtypes = [C.c_void_p, C.c_int]
+        l.fzb_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        l.fzb_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        _lib = l
+    return _lib
+
+
+def _check(rc):
+    if rc:
+        msg = lib().fzb_last_error().decode("utf-8", "replace")
+        raise (PanicError if rc == 2 else FrizbeeError)(rc, msg)
+
+
+def _b(s):
+    return s if isinstance(s, (bytes, bytearray)) else s.encode("utf-8")
+
+
+def pack(haystacks):
+    """list[str|bytes] -> (uint8 array of the concatenated bytes, uint64 exclusive end offsets) - the upload format."""
+    bs = [_b(h) for h in haystacks]
+    ends = np.cumsum(np.fromiter((len(b) for b in bs), dtype=np.uint64, count=len(bs)), dtype=np.uint64) if bs else np.zeros(0, np.uint64)
+    data = np.frombuffer(b"".join(bs) + b"\0", dtype=np.uint8).copy()
+    return data, ends
+
+
+def _take(out, n):
+    arr = np.zeros(n.value, MATCH_DTYPE)
+    if n.value:
+        C.memmove(arr.ctypes.data, out, n.value * 8)
+    lib().fzb_matches_free(out)
+    return arr
+
+
+class Corpus:
+    """A haystack list packed and resident in HBM (what `match_list(&haystacks)` borrows, uploaded once)."""
+
+    def __init__(self, haystacks=None, *, packed=None):
+        data, ends = packed if packed is not None else pack(haystacks)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        ends = np.ascontiguousarray(ends, dtype=np.uint64)
+        self.h = C.c_void_p()
+        self._keep = None
+        _check(lib().fzb_corpus_upload(data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), C.byref(self.h)))
+
+    @classmethod
+    def from_device(cls, dev_bytes_ptr, dev_ends_ptr, n, total_bytes, ends_are_u64=False, keep=None):
+        """Borrow device memory already in the padded-16 layout (see include/frizbee_hip.h)."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        self._keep = keep
+        _check(lib().fzb_corpus_from_device(dev_bytes_ptr, dev_ends_ptr, int(ends_are_u64), n, total_bytes, C.byref(self.h)))
+        return self
+
+    def __len__(self):
+        return lib().fzb_corpus_len(self.h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().fzb_corpus_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Matcher:
+    """`frizbee::Matcher` for one (non-negated, fuzzy) pattern: `Matcher::new(needle, &config)` (src/matcher/mod.rs:90-92)."""
+
+    def __init__(self, needle, config=None):
+        self.config = config or Config()
+        c = _CConfig()
+        c.max_typos = -1 if self.config.max_typos is None else int(self.config.max_typos)
+        c.casing, c.unicode, c.sort = int(self.config.casing), int(self.config.unicode), int(self.config.sort)
+        for name, v in zip([f[0] for f in _CScoring._fields_], self.config.scoring.as_list()):
+            setattr(c.scoring, name, v)
+        c.pf_lanes, c.sw_lanes = self.config.pf_lanes, self.config.sw_lanes
+        n = _b(needle)
+        self.needle = n
+        self.h = C.c_void_p()
+        _check(lib().fzb_matcher_create(C.byref(c), n, len(n), C.byref(self.h)))
+
+    def info(self):
+        out = (C.c_int32 * 6)()
+        _check(lib().fzb_matcher_info(self.h, out))
+        return dict(pf_lanes=out[0], sw_lanes=out[1], use_u8=bool(out[2]), case_sensitive=bool(out[3]), unicode=bool(out[4]), rows=out[5])
+
+    def _corpus(self, haystacks):
+        return haystacks if isinstance(haystacks, Corpus) else Corpus(haystacks)
+
+    def match_list(self, haystacks):
+        """`Matcher::match_list` (src/matcher/mod.rs:212-222). `haystacks` is a list of str/bytes or a resident `Corpus`."""
+        cp = self._corpus(haystacks)
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_match_list(self.h, cp.h, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
+    def match_list_parallel(self, haystacks, threads):
+        """`Matcher::match_list_parallel` (src/matcher/parallel.rs:18-89); identical result for every thread count."""
+        cp = self._corpus(haystacks)
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_match_list_parallel(self.h, cp.h, threads, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
+    def match_list_into(self, haystacks, first=0, count=None, index_offset=0):
+        """`Specialized::match_list(haystacks, haystack_index_offset, &mut matches)` (src/matcher/algo.rs:78-103): unsorted, input order."""
+        cp = self._corpus(haystacks)
+        count = len(cp) - first if count is None else count
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_match_list_into(self.h, cp.h, first, count, index_offset, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
+    def match_list_device(self, corpus, dev_out_ptr, capacity, dev_count_ptr, stream=0, first=0, count=None, index_offset=0):
+        """Device-resident form: records + count stay in HBM, asynchronous on `stream` (a hipStream_t handle)."""
+        count = len(corpus) - first if count is None else count
+        _check(lib().fzb_match_list_device(self.h, corpus.h, first, count, index_offset, dev_out_ptr, capacity, dev_count_ptr, stream))
+
+    def set_profiling(self, on=True):
+        _check(lib().fzb_set_profiling(self.h, int(on)))
+
+    def last_timings_ms(self):
+        out = (C.c_float * 4)()
+        _check(lib().fzb_last_timings(self.h, out))
+        return dict(filter=out[0], total=out[1])
+
+    def last_counters(self):
+        out = (C.c_uint32 * 4)()
+        _check(lib().fzb_last_counters(self.h, out))
+        return dict(filter_survivors=out[0], kept_by_exact_prefilter=out[1], generic_scored=out[3])
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().fzb_matcher_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+def radix_sort_matches(matches):
+    """`radix_sort_matches(&mut [Match])` (src/sort.rs:6-40): stable, descending score. Returns a sorted copy."""
+    a = np.ascontiguousarray(matches.copy())
+    lib().fzb_radix_sort_matches(a.ctypes.data, len(a))
+    return a
+
+
+def k_merge_matches(sort, runs):
+    """`k_merge_matches_by_*` (src/k_merge.rs:56-132): merge per-shard runs, each already ordered per `sort`."""
+    lens = np.array([len(r) for r in runs], dtype=np.uint64)
+    cat = np.ascontiguousarray(np.concatenate(runs)) if runs else np.zeros(0, MATCH_DTYPE)
+    out = np.zeros(len(cat), MATCH_DTYPE)
+    _check(lib().fzb_k_merge_matches(int(sort), cat.ctypes.data, lens.ctypes.data, len(runs), out.ctypes.data))
+    return out

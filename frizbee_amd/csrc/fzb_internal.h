@@ -1,0 +1,106 @@
+// Internal structures shared by the host side (host.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define FZB_MAX_ROWS 63        // needle rows handled on the GPU (bytes on the ASCII path, scalars on the unicode path)
+#define FZB_MAX_NEEDLE_BYTES 64
+#define FZB_MAX_HAYSTACK_LEN 1024  // reference: src/smith_waterman/algo/mod.rs:18 (beyond this the greedy fallback scores)
+#define FZB_TILE 1024          // haystacks per filter tile (one bitmap group + one count)
+
+// Needle + scoring constants, passed BY VALUE as a kernel argument (wave-uniform -> SGPR loads).
+// Mirrors what `Prefilter::new` / `SmithWaterman::new` precompute (src/prefilter/algo/mod.rs:30-42,
+// src/smith_waterman/algo/mod.rs:21-42) and the constants block of `score_haystack`
+// (src/smith_waterman/algo/ascii.rs:33-46).
+struct NeedleDev {
+    int32_t rows;          // DP rows: needle bytes (ASCII path) or needle scalars (unicode path)
+    int32_t nbytes;        // needle byte length (exact-match compare)
+    int32_t max_typos;     // -1 = None
+    int32_t min_haystack_len;  // chars - max_typos (src/matcher/algo.rs:62-65)
+    int32_t unicode;       // 1 = unicode path
+    int32_t lane_mask;     // 0xFF (u8 score class) or 0xFFFF (u16 class): lane type of the emulated CPU backend
+    // scoring constants, already combined as the reference combines them
+    u16 match_plus_mismatch;  // match_score.saturating_add(mismatch_penalty)
+    u16 mismatch;
+    u16 gex;               // gap_extend_penalty
+    u16 gopm;              // gap_open_penalty.saturating_sub(gap_extend_penalty)
+    u16 prefix, capitalization, matching_case, exact_bonus, delimiter;
+    u16 match_score, gap_open;  // raw values (greedy fallback, src/smith_waterman/greedy.rs)
+    u16 _pad;
+    u8 raw[FZB_MAX_NEEDLE_BYTES];  // needle bytes as given
+    u8 c[FZB_MAX_NEEDLE_BYTES];    // ASCII rows: byte            (case_needle, src/prefilter/mod.rs:49-65)
+    u8 f[FZB_MAX_NEEDLE_BYTES];    //            its case flip
+    u8 uc[FZB_MAX_ROWS + 1][4];    // unicode rows: scalar bytes  (case_needle_unicode, src/prefilter/mod.rs:71-96)
+    u8 uf[FZB_MAX_ROWS + 1][4];    //               flipped scalar bytes
+    u8 ulen[FZB_MAX_ROWS + 1];     //               UTF-8 length
+};
+
+// One haystack list resident in HBM.  Layout ("padded-16"): every haystack starts on a 16-byte boundary of
+// `bytes`, gaps are zero, `ends[i]` is the exclusive byte end of haystack i inside `bytes`;
+// start(i) = i ? roundup16(ends[i-1]) : 0.  >= 80 zero bytes follow the last haystack.
+struct CorpusDev {
+    const u8* bytes;
+    const void* ends;  // u32[n] or u64[n]
+    u64 n;
+    u64 total_bytes;   // padded size
+    int ends_u64;
+};
+
+struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between kernels (0 in final output)
+    u32 index;
+    u16 score;
+    u8 exact;
+    u8 valid;
+};
+
+// Per-call device workspace (owned by the matcher, grown on demand)
+struct Workspace {
+    u64* bitmap;        // count/64 words: filter decisions
+    u32* tile_counts;   // ntiles
+    u32* tile_prefix;   // ntiles + 1
+    u32* surv_idx;      // local haystack index of survivor j
+    u32* win;           // 2 * survivors: (start, end) windows from the lane-exact prefilter; start=0xFFFFFFFF => rejected
+    u32* overflow;      // survivor ids needing the generic scorer
+    u64* bitmap2;       // second-level keep bits (after the lane-exact prefilter)
+    u32* tile_counts2;
+    u32* tile_prefix2;
+    u32* items2;        // local haystack index of kept survivor
+    u32* win2;          // its window
+    u32* counters;      // [0]=filter survivors [1]=kept by the lane-exact prefilter [3]=sent to the generic scorer
+    u64* table;         // 256 x u64 filter table (device)
+    size_t cap_items;   // capacity (in haystacks) of the first-level arrays
+    size_t cap_level2;  // capacity of the second-level arrays (0 = not allocated)
+};
+
+struct LaunchCfg {
+    int pf_lanes, sw_lanes;
+    int filter_mode;    // 0 = none (all pass), 1 = ordered subsequence (exact for ASCII 0 typos), 2 = LCS >= rows-k (superset)
+    int filter_exact;   // 1 if the filter decision is exactly the reference's accept decision
+    int window_mode;    // 0 = from the lane-exact prefilter kernel, 1 = inline first/last occurrence (ASCII 0 typos), 2 = full haystack
+    int bias_ok;        // DP gap propagation may run in the biased domain (no u16 overflow possible)
+    int num_cus;
+};
+
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>
+// kernels_filter.hip
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, int rows, int mode, int need, u32 min_len,
+                       u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
+void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, hipStream_t st);
+void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,
+                    const u32* in_idx, const u32* in_win, u32* out_win, int grid, hipStream_t st);
+// kernels_window.hip
+void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
+                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st);
+// kernels_dp.hip
+void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
+                   int sw_lanes, int bias_ok, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32* counters, int grid, hipStream_t st);
+// kernels_generic.hip
+void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st);
+#endif

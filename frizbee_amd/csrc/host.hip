@@ -1,0 +1,615 @@
+// Host side of the MI355X frizbee backend: the C ABI of include/frizbee_hip.h.
+//
+// Mirrors, in C++ (the reference is compiled Rust and no Rust toolchain exists in the build image):
+//   Matcher::new / compile / get_backend      src/matcher/mod.rs:90-111, 178-204, 448-498
+//   MatcherImpl::new                          src/matcher/algo.rs:57-71, 311-325
+//   case_needle / case_needle_unicode         src/prefilter/mod.rs:49-96
+//   score_fits_in_u8 / Scoring guards         src/smith_waterman/mod.rs:92-116, src/lib.rs:480-538
+//   match_list / match_list_parallel post-steps  src/matcher/mod.rs:212-222, src/matcher/parallel.rs:18-89
+//   radix_sort_matches / k_merge              src/sort.rs:6-40, src/k_merge.rs:56-170
+// All scoring work happens in the gfx950 kernels; there is NO CPU fallback - without a HIP device every
+// scoring entry point fails with FZB_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/frizbee_hip.h"
+#include "fzb_internal.h"
+
+namespace {
+#include "unicode_case_table.inc"
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+// ---- UTF-8 / case helpers ---------------------------------------------------------------------------
+bool decode_utf8(const u8* s, size_t n, std::vector<u32>& out) {
+    size_t i = 0;
+    while (i < n) {
+        u8 b = s[i];
+        u32 cp;
+        int len;
+        if (b < 0x80) { cp = b; len = 1; }
+        else if ((b & 0xE0) == 0xC0) { cp = b & 0x1F; len = 2; }
+        else if ((b & 0xF0) == 0xE0) { cp = b & 0x0F; len = 3; }
+        else if ((b & 0xF8) == 0xF0) { cp = b & 0x07; len = 4; }
+        else return false;
+        if (i + len > n) return false;
+        for (int k = 1; k < len; k++) {
+            if ((s[i + k] & 0xC0) != 0x80) return false;
+            cp = (cp << 6) | (s[i + k] & 0x3F);
+        }
+        out.push_back(cp);
+        i += len;
+    }
+    return true;
+}
+int encode_utf8(u32 cp, u8 out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    if (cp < 0x80) { out[0] = (u8)cp; return 1; }
+    if (cp < 0x800) { out[0] = (u8)(0xC0 | (cp >> 6)); out[1] = (u8)(0x80 | (cp & 0x3F)); return 2; }
+    if (cp < 0x10000) { out[0] = (u8)(0xE0 | (cp >> 12)); out[1] = (u8)(0x80 | ((cp >> 6) & 0x3F)); out[2] = (u8)(0x80 | (cp & 0x3F)); return 3; }
+    out[0] = (u8)(0xF0 | (cp >> 18)); out[1] = (u8)(0x80 | ((cp >> 12) & 0x3F)); out[2] = (u8)(0x80 | ((cp >> 6) & 0x3F)); out[3] = (u8)(0x80 | (cp & 0x3F));
+    return 4;
+}
+bool is_uppercase(u32 cp) {  // char::is_uppercase
+    if (cp < 0x80) return cp >= 'A' && cp <= 'Z';
+    const auto* end = FZB_UPPER_RANGES + FZB_UPPER_RANGES_LEN;
+    const auto* it = std::upper_bound(FZB_UPPER_RANGES, end, cp, [](u32 v, const unsigned int (&r)[2]) { return v < r[0]; });
+    if (it == FZB_UPPER_RANGES) return false;
+    --it;
+    return cp >= (*it)[0] && cp <= (*it)[1];
+}
+u32 flip_same_width(u32 cp) {  // the flip `case_needle_unicode` keeps (single scalar, same UTF-8 width), else cp
+    if (cp < 0x80) return (cp >= 'A' && cp <= 'Z') ? cp + 32 : (cp >= 'a' && cp <= 'z') ? cp - 32 : cp;
+    const auto* end = FZB_CASE_FLIP + FZB_CASE_FLIP_LEN;
+    const auto* it = std::lower_bound(FZB_CASE_FLIP, end, cp, [](const unsigned int (&r)[2], u32 v) { return r[0] < v; });
+    return (it != end && (*it)[0] == cp) ? (*it)[1] : cp;
+}
+
+// ---- Scoring guards (src/lib.rs:480-538, src/smith_waterman/mod.rs:92-116) --------------------------------
+u16 sadd16(u32 a, u32 b) { return (u16)std::min<u32>(a + b, 0xFFFF); }
+u16 ssub16(u32 a, u32 b) { return (u16)(a > b ? a - b : 0); }
+u16 max_per_char_bonus(const fzb_scoring& s) {
+    u16 bonus = std::max(s.delimiter_bonus, s.capitalization_bonus);
+    u16 amortized = std::max<u16>((u16)((bonus + 1) / 2), ssub16(bonus, s.gap_open_penalty));
+    return sadd16(amortized, s.matching_case_bonus);
+}
+u16 max_one_time_bonus(const fzb_scoring& s) {
+    u16 bonus = std::max(s.delimiter_bonus, s.capitalization_bonus);
+    u16 amortized = std::max<u16>((u16)((bonus + 1) / 2), ssub16(bonus, s.gap_open_penalty));
+    return (u16)(bonus - amortized);
+}
+std::string overflow_guard(const fzb_scoring& s, size_t rows) {
+    u16 max_per_char = sadd16(s.match_score, max_per_char_bonus(s));
+    if (max_per_char == 0) return "";
+    u16 headroom = ssub16(ssub16(ssub16(ssub16(0xFFFF, s.prefix_bonus), s.exact_match_bonus), s.mismatch_penalty), max_one_time_bonus(s));
+    u16 max_needle_len = (u16)(headroom / max_per_char);
+    if (rows > (size_t)max_needle_len)
+        return "needle too long and could overflow the u16 score: " + std::to_string(rows) + " > " + std::to_string(max_needle_len);
+    size_t max_gap = 32 * (size_t)s.gap_extend_penalty + (size_t)s.gap_open_penalty;
+    if (max_gap > 0xFFFF) return "gap penalties too large and could overflow the u16 score: " + std::to_string(max_gap) + " > 65535";
+    return "";
+}
+size_t max_matrix_score(const fzb_scoring& s, size_t needle_len) {
+    size_t max_per_char = (size_t)s.match_score + (size_t)max_per_char_bonus(s);
+    return max_per_char * needle_len + (size_t)max_one_time_bonus(s) + (size_t)s.prefix_bonus;
+}
+bool fits_in_u8(size_t needle_len, const fzb_scoring& s) {
+    size_t max_constant = std::max<size_t>({(size_t)s.match_score + (size_t)s.mismatch_penalty, s.gap_open_penalty, s.gap_extend_penalty,
+                                            s.matching_case_bonus, s.capitalization_bonus, s.delimiter_bonus, s.prefix_bonus});
+    if (max_constant > 255) return false;
+    if (64 * (size_t)s.gap_extend_penalty + (size_t)s.gap_open_penalty > 255) return false;
+    return max_matrix_score(s, needle_len) + (size_t)s.mismatch_penalty <= 255;
+}
+
+// Which (prefilter lanes, score lanes) pair `Matcher::get_backend` picks on this host (src/matcher/mod.rs:448-498)
+void detect_host_lanes(bool use_u8, int& pf, int& sw) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_cpu_init();
+    const bool avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw");
+    const bool bmi = __builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2");
+    const bool vbmi = __builtin_cpu_supports("avx512vbmi");
+    const bool avx2 = __builtin_cpu_supports("avx2");
+    const bool sse = __builtin_cpu_supports("sse2") && __builtin_cpu_supports("ssse3") && __builtin_cpu_supports("sse4.1");
+    if (use_u8) {
+        if (avx512 && bmi && vbmi) { pf = 64; sw = 64; return; }
+        if (avx2) { pf = 32; sw = 32; return; }
+        if (sse) { pf = 16; sw = 16; return; }
+        pf = 16; sw = 16;  // scalar u8
+    } else {
+        if (avx512 && bmi) { pf = 64; sw = 32; return; }
+        if (avx2) { pf = 32; sw = 16; return; }
+        if (sse) { pf = 16; sw = 8; return; }
+        pf = 16; sw = 8;  // scalar
+    }
+#else
+    pf = 16;
+    sw = use_u8 ? 16 : 8;  // NEON / scalar
+#endif
+}
+
+hipError_t dev_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16); }
+
+}  // namespace
+
+struct fzb_corpus {
+    CorpusDev dev{};
+    void* own_bytes = nullptr;
+    void* own_ends = nullptr;
+};
+
+struct fzb_matcher {
+    fzb_config config{};
+    std::string needle;
+    bool empty = false, case_sensitive = false, unicode = false, use_u8 = false;
+    int rows = 0;
+    NeedleDev nd{};
+    LaunchCfg lc{};
+    std::vector<u64> table;  // host copy of the filter table
+    Workspace ws{};
+    int device = -1;
+    bool profiling = false;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    u32 last_counters[4] = {0, 0, 0, 0};
+    // staging for the synchronous API
+    fzb_match_rec* out_dev = nullptr;
+    size_t out_cap = 0;
+    u32* count_dev = nullptr;
+};
+
+extern "C" {
+
+const char* fzb_last_error(void) { return g_err.c_str(); }
+
+void fzb_config_default(fzb_config* out) {
+    if (!out) return;
+    memset(out, 0, sizeof(*out));
+    out->max_typos = 0;
+    out->casing = FZB_CASE_SMART;
+    out->unicode = FZB_UNICODE_SMART;
+    out->sort = FZB_SORT_SCORE_THEN_INDEX_ASC;
+    out->scoring = fzb_scoring{12, 6, 5, 1, 12, 4, 4, 8, 4};  // src/const.rs:1-10
+}
+
+static void free_workspace(Workspace& w) {
+    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    w = Workspace{};
+}
+
+int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, size_t needle_len, fzb_matcher** out) {
+    if (!config || !out || (!needle_utf8 && needle_len)) return fail(FZB_ERR_INVALID, "null argument");
+    if (config->casing < 0 || config->casing > 2 || config->unicode < 0 || config->unicode > 2 || config->sort < 0 || config->sort > 3 || config->max_typos < -1 ||
+        config->max_typos > 0xFFFF)
+        return fail(FZB_ERR_INVALID, "config enum/range out of bounds");
+    std::vector<u32> cps;
+    if (!decode_utf8(needle_utf8, needle_len, cps)) return fail(FZB_ERR_INVALID, "needle is not valid UTF-8");
+    auto m = new fzb_matcher();
+    m->config = *config;
+    m->needle.assign((const char*)needle_utf8, needle_len);
+    m->empty = needle_len == 0;
+    const fzb_scoring& sc = config->scoring;
+    m->use_u8 = fits_in_u8(needle_len, sc);  // byte length (src/matcher/mod.rs:453)
+    int pf = config->pf_lanes, sw = config->sw_lanes;
+    if (pf == 0 && sw == 0) detect_host_lanes(m->use_u8, pf, sw);
+    if (!(pf == 16 || pf == 32 || pf == 64) || !(sw == 8 || sw == 16 || sw == 32 || sw == 64)) {
+        delete m;
+        return fail(FZB_ERR_INVALID, "pf_lanes must be 16/32/64 and sw_lanes 8/16/32/64 (or both 0 = auto)");
+    }
+    m->lc.pf_lanes = pf;
+    m->lc.sw_lanes = sw;
+    if (m->empty) {  // CompiledPatterns::Empty (src/matcher/mod.rs:194-196)
+        *out = m;
+        return FZB_OK;
+    }
+    // CaseMatching::respects_case_for (src/lib.rs:370-376), UnicodeMatching::respects_unicode_for (:394-400)
+    bool any_upper = false, ascii = true;
+    for (u32 cp : cps) { any_upper |= is_uppercase(cp); ascii &= cp < 0x80; }
+    m->case_sensitive = config->casing == FZB_CASE_RESPECT || (config->casing == FZB_CASE_SMART && any_upper);
+    m->unicode = config->unicode == FZB_UNICODE_ALWAYS || (config->unicode == FZB_UNICODE_SMART && !ascii);
+    m->rows = (int)(m->unicode ? cps.size() : needle_len);
+    // guard_against_score_overflow (src/matcher/algo.rs:311-325)
+    std::string perr = overflow_guard(sc, (size_t)m->rows);
+    if (!perr.empty()) { delete m; return fail(FZB_ERR_PANIC, perr); }
+    if (needle_len > FZB_MAX_NEEDLE_BYTES || m->rows > FZB_MAX_ROWS) {
+        delete m;
+        return fail(FZB_ERR_UNSUPPORTED, "needles longer than 64 bytes / 63 rows are not handled by the HIP backend");
+    }
+    NeedleDev& nd = m->nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.rows = m->rows;
+    nd.nbytes = (int)needle_len;
+    nd.max_typos = config->max_typos;
+    nd.min_haystack_len = config->max_typos < 0 ? 0 : (int)(cps.size() > (size_t)config->max_typos ? cps.size() - (size_t)config->max_typos : 0);  // algo.rs:62-65
+    nd.unicode = m->unicode;
+    nd.lane_mask = m->use_u8 ? 0xFF : 0xFFFF;
+    nd.match_plus_mismatch = sadd16(sc.match_score, sc.mismatch_penalty);
+    nd.mismatch = sc.mismatch_penalty;
+    nd.gex = sc.gap_extend_penalty;
+    nd.gopm = ssub16(sc.gap_open_penalty, sc.gap_extend_penalty);
+    nd.prefix = sc.prefix_bonus;
+    nd.capitalization = sc.capitalization_bonus;
+    nd.matching_case = sc.matching_case_bonus;
+    nd.exact_bonus = sc.exact_match_bonus;
+    nd.delimiter = sc.delimiter_bonus;
+    nd.match_score = sc.match_score;
+    nd.gap_open = sc.gap_open_penalty;
+    for (size_t i = 0; i < needle_len; i++) {  // case_needle (src/prefilter/mod.rs:49-65)
+        u8 c = needle_utf8[i];
+        nd.raw[i] = c;
+        nd.c[i] = c;
+        nd.f[i] = m->case_sensitive ? c : (c >= 'a' && c <= 'z') ? (u8)(c - 32) : (c >= 'A' && c <= 'Z') ? (u8)(c + 32) : c;
+    }
+    if (cps.size() <= FZB_MAX_ROWS) {
+        for (size_t i = 0; i < cps.size(); i++) {  // case_needle_unicode (src/prefilter/mod.rs:71-96)
+            nd.ulen[i] = (u8)encode_utf8(cps[i], nd.uc[i]);
+            encode_utf8(m->case_sensitive ? cps[i] : flip_same_width(cps[i]), nd.uf[i]);
+        }
+    }
+    // ---- filter-stage configuration --------------------------------------------------------------
+    const int k = config->max_typos;
+    LaunchCfg& lc = m->lc;
+    if (k < 0 || k >= m->rows) {        // NO_PREFILTER, or `needle_len <= max_typos => (true, 0, len)`
+        lc.filter_mode = 0; lc.filter_exact = 1; lc.window_mode = 2;
+    } else if (!m->unicode && k == 0) { // exact: ordered subsequence; window = first/last occurrence
+        lc.filter_mode = 1; lc.filter_exact = 1; lc.window_mode = 1;
+    } else {                            // superset filter, lane-exact prefilter re-decides
+        lc.filter_mode = k == 0 ? 1 : 2; lc.filter_exact = 0; lc.window_mode = 0;
+    }
+    m->table.assign(256, 0);
+    for (int r = 0; r < m->rows; r++) {
+        if (m->unicode) {  // a scalar can only match where its LAST byte matches (either case): conservative
+            m->table[nd.uc[r][nd.ulen[r] - 1]] |= (u64)1 << r;
+            m->table[nd.uf[r][nd.ulen[r] - 1]] |= (u64)1 << r;
+        } else {
+            m->table[nd.c[r]] |= (u64)1 << r;
+            m->table[nd.f[r]] |= (u64)1 << r;
+        }
+    }
+    // biased gap propagation needs max cell value + lanes*gex (+ headroom) to stay below 2^16
+    lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
+    *out = m;
+    return FZB_OK;
+}
+
+int fzb_matcher_clone(const fzb_matcher* src, fzb_matcher** out) {
+    if (!src || !out) return fail(FZB_ERR_INVALID, "null argument");
+    fzb_config cfg = src->config;
+    cfg.pf_lanes = (uint16_t)src->lc.pf_lanes;
+    cfg.sw_lanes = (uint16_t)src->lc.sw_lanes;
+    return fzb_matcher_create(&cfg, (const uint8_t*)src->needle.data(), src->needle.size(), out);
+}
+
+void fzb_matcher_free(fzb_matcher* m) {
+    if (!m) return;
+    free_workspace(m->ws);
+    if (m->out_dev) (void)hipFree(m->out_dev);
+    if (m->count_dev) (void)hipFree(m->count_dev);
+    for (auto& e : m->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete m;
+}
+
+int fzb_matcher_info(const fzb_matcher* m, int32_t out[6]) {
+    if (!m || !out) return fail(FZB_ERR_INVALID, "null argument");
+    out[0] = m->lc.pf_lanes; out[1] = m->lc.sw_lanes; out[2] = m->use_u8; out[3] = m->case_sensitive; out[4] = m->unicode; out[5] = m->rows;
+    return FZB_OK;
+}
+
+// ---- corpus -----------------------------------------------------------------------------------------
+int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t n, fzb_corpus** out) {
+    if (!out || (n && (!bytes || !end_offsets))) return fail(FZB_ERR_INVALID, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(n) + " > 4294967295 (index offset: 0)");
+    // repack into the padded-16 device layout
+    std::vector<u64> pends(n);
+    u64 pos = 0, prev = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (end_offsets[i] < prev) return fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
+        const u64 len = end_offsets[i] - prev;
+        pos = (pos + 15) & ~(u64)15;
+        pos += len;
+        pends[i] = pos;
+        prev = end_offsets[i];
+    }
+    const u64 total = ((pos + 15) & ~(u64)15) + 96;
+    std::vector<u8> packed(total, 0);
+    prev = 0;
+    u64 ppos = 0;
+    for (size_t i = 0; i < n; i++) {
+        const u64 len = end_offsets[i] - prev;
+        ppos = (ppos + 15) & ~(u64)15;
+        memcpy(packed.data() + ppos, bytes + prev, len);
+        ppos += len;
+        prev = end_offsets[i];
+    }
+    auto c = new fzb_corpus();
+    c->dev.n = n;
+    c->dev.total_bytes = total;
+    c->dev.ends_u64 = total > 0xFFFFFFF0ull;
+    hipError_t e = dev_alloc(&c->own_bytes, total);
+    if (e == hipSuccess) e = hipMemcpy(c->own_bytes, packed.data(), total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (c->dev.ends_u64) {
+            e = dev_alloc(&c->own_ends, n * 8);
+            if (e == hipSuccess && n) e = hipMemcpy(c->own_ends, pends.data(), n * 8, hipMemcpyHostToDevice);
+        } else {
+            std::vector<u32> e32(n);
+            for (size_t i = 0; i < n; i++) e32[i] = (u32)pends[i];
+            e = dev_alloc(&c->own_ends, n * 4);
+            if (e == hipSuccess && n) e = hipMemcpy(c->own_ends, e32.data(), n * 4, hipMemcpyHostToDevice);
+        }
+    }
+    if (e != hipSuccess) {
+        fzb_corpus_free(c);
+        return fail(FZB_ERR_HIP, std::string("corpus upload: ") + hipGetErrorString(e));
+    }
+    c->dev.bytes = (const u8*)c->own_bytes;
+    c->dev.ends = c->own_ends;
+    *out = c;
+    return FZB_OK;
+}
+
+int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends_are_u64, size_t n, uint64_t total_bytes, fzb_corpus** out) {
+    if (!out || (n && (!dev_bytes || !dev_ends))) return fail(FZB_ERR_INVALID, "null argument");
+    if (((uintptr_t)dev_bytes & 15) != 0) return fail(FZB_ERR_INVALID, "dev_bytes must be 16-byte aligned");
+    if (n > 0xFFFFFFFFull) return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(n) + " > 4294967295 (index offset: 0)");
+    auto c = new fzb_corpus();
+    c->dev.bytes = (const u8*)dev_bytes;
+    c->dev.ends = dev_ends;
+    c->dev.ends_u64 = ends_are_u64 != 0;
+    c->dev.n = n;
+    c->dev.total_bytes = total_bytes;
+    *out = c;
+    return FZB_OK;
+}
+
+void fzb_corpus_free(fzb_corpus* c) {
+    if (!c) return;
+    if (c->own_bytes) (void)hipFree(c->own_bytes);
+    if (c->own_ends) (void)hipFree(c->own_ends);
+    delete c;
+}
+size_t fzb_corpus_len(const fzb_corpus* c) { return c ? (size_t)c->dev.n : 0; }
+
+// ---- pipeline -------------------------------------------------------------------------------------------
+static int ensure_workspace(fzb_matcher* m, size_t count) {
+    Workspace& w = m->ws;
+    const bool need_l2 = !m->lc.filter_exact;
+    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && w.counters) return FZB_OK;
+    hipStream_t st = nullptr;
+    (void)st;
+    free_workspace(w);
+    const size_t cap = count + count / 8 + 4096;
+    const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 1;
+    HIPCHK(dev_alloc((void**)&w.bitmap, (cap / 64 + 17) * 8));
+    HIPCHK(dev_alloc((void**)&w.tile_counts, ntiles * 4));
+    HIPCHK(dev_alloc((void**)&w.tile_prefix, (ntiles + 1) * 4));
+    HIPCHK(dev_alloc((void**)&w.surv_idx, cap * 4));
+    HIPCHK(dev_alloc((void**)&w.overflow, cap * 12));
+    HIPCHK(dev_alloc((void**)&w.counters, 64));
+    HIPCHK(dev_alloc((void**)&w.table, 256 * 8));
+    HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
+    w.cap_items = cap;
+    if (need_l2) {
+        HIPCHK(dev_alloc((void**)&w.win, cap * 8));
+        HIPCHK(dev_alloc((void**)&w.bitmap2, (cap / 64 + 17) * 8));
+        HIPCHK(dev_alloc((void**)&w.tile_counts2, ntiles * 4));
+        HIPCHK(dev_alloc((void**)&w.tile_prefix2, (ntiles + 1) * 4));
+        HIPCHK(dev_alloc((void**)&w.items2, cap * 4));
+        HIPCHK(dev_alloc((void**)&w.win2, cap * 8));
+        w.cap_level2 = cap;
+    }
+    return FZB_OK;
+}
+
+int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity,
+                          uint32_t* dev_count, void* stream) {
+    if (!m || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
+    if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
+    // guard_against_haystack_overflow (src/matcher/mod.rs:438-446)
+    if ((u64)count + (u64)index_offset > 0xFFFFFFFFull)
+        return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
+    if (m->empty) return fail(FZB_ERR_INVALID, "empty needle: handled on the host by fzb_match_list / fzb_match_list_into");
+    hipStream_t st = (hipStream_t)stream;
+    if (m->device < 0) {
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        m->device = dev;
+        m->lc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    int rc = ensure_workspace(m, count);
+    if (rc) return rc;
+    Workspace& w = m->ws;
+    const LaunchCfg& lc = m->lc;
+    const NeedleDev& nd = m->nd;
+    const CorpusDev& cd = c->dev;
+    const u32 cnt = (u32)count;
+    const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
+    if (m->profiling && !m->ev[0])
+        for (auto& e : m->ev) HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
+    if (count == 0) {
+        HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
+        return FZB_OK;
+    }
+    const int cus = lc.num_cus;
+    if (m->profiling) HIPCHK(hipEventRecord(m->ev[0], st));
+    const u32* items = nullptr;
+    const u32* win = nullptr;
+    const u32* n_items_ptr = &w.counters[0];
+    int wmode = lc.window_mode;
+    if (lc.filter_mode == 0) {
+        // nothing filtered: survivors are the identity list
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&w.counters[0], (int)cnt, 1, st));
+        if (m->profiling) HIPCHK(hipEventRecord(m->ev[1], st));
+    } else {
+        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
+        fzb_launch_filter(cd, first, cnt, w.table, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 8, st);
+        if (m->profiling) HIPCHK(hipEventRecord(m->ev[1], st));
+        fzb_launch_scan(w.tile_counts, w.tile_prefix, nullptr, cnt, &w.counters[0], st);
+        fzb_launch_map(1, w.bitmap, w.tile_prefix, nullptr, cnt, w.surv_idx, nullptr, nullptr, nullptr, cus * 4, st);
+        items = w.surv_idx;
+    }
+    if (!lc.filter_exact) {
+        fzb_launch_window(cd, first, items, &w.counters[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, w.counters, cus * 4, st);
+        fzb_launch_scan(w.tile_counts2, w.tile_prefix2, &w.counters[0], 0, &w.counters[1], st);
+        fzb_launch_map(2, w.bitmap2, w.tile_prefix2, &w.counters[0], 0, w.items2, items, w.win, w.win2, cus * 4, st);
+        items = w.items2;
+        win = w.win2;
+        n_items_ptr = &w.counters[1];
+        wmode = 0;
+    }
+    fzb_match_rec* outp = (fzb_match_rec*)dev_out;
+    if (nd.unicode) {
+        fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, w.counters, cus * 4, st);
+    } else {
+        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, outp, cap32, dev_count, w.overflow, w.counters, cus * 8, st);
+        // windows wider than one chunk were queued (item, start, end) in w.overflow by the DP kernel
+        fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &w.counters[3], nd, lc.sw_lanes, 0, outp, cap32, dev_count, w.counters, cus * 2, st);
+    }
+    if (m->profiling) HIPCHK(hipEventRecord(m->ev[2], st));
+    HIPCHK(hipGetLastError());
+    return FZB_OK;
+}
+
+int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len) {
+    if (!m || !c || !out || !out_len) return fail(FZB_ERR_INVALID, "null argument");
+    if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
+    if ((u64)count + (u64)index_offset > 0xFFFFFFFFull)
+        return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
+    *out = nullptr;
+    *out_len = 0;
+    if (m->empty) {  // src/matcher/mod.rs:381-384
+        fzb_match* r = (fzb_match*)malloc(std::max<size_t>(count, 1) * sizeof(fzb_match));
+        for (size_t i = 0; i < count; i++) r[i] = fzb_match{(uint32_t)(index_offset + i), 0, 0, 0};
+        *out = r;
+        *out_len = count;
+        return FZB_OK;
+    }
+    if (m->out_cap < count || !m->count_dev) {
+        if (m->out_dev) (void)hipFree(m->out_dev);
+        m->out_dev = nullptr;
+        m->out_cap = 0;
+        HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
+        m->out_cap = count;
+        if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
+    }
+    int rc = fzb_match_list_device(m, c, first, count, index_offset, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
+    if (rc) return rc;
+    u32 n = 0;
+    HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));  // synchronises the default stream
+    if (count) HIPCHK(hipMemcpy(m->last_counters, m->ws.counters, 16, hipMemcpyDeviceToHost));
+    fzb_match* r = (fzb_match*)malloc(std::max<size_t>(n, 1) * sizeof(fzb_match));
+    if (n) HIPCHK(hipMemcpy(r, m->out_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost));
+    *out = r;
+    *out_len = n;
+    return FZB_OK;
+}
+
+void fzb_radix_sort_matches(fzb_match* matches, size_t n) {  // src/sort.rs:6-40
+    if (n < 2) return;
+    std::vector<fzb_match> tmp(n);
+    size_t hist[256];
+    for (int pass = 0; pass < 2; pass++) {
+        const int shift = pass * 8;
+        fzb_match* src = pass == 0 ? matches : tmp.data();
+        fzb_match* dst = pass == 0 ? tmp.data() : matches;
+        memset(hist, 0, sizeof(hist));
+        for (size_t i = 0; i < n; i++) hist[(src[i].score >> shift) & 0xFF]++;
+        size_t off[256];
+        size_t run = 0;
+        for (int b = 255; b >= 0; b--) { off[b] = run; run += hist[b]; }  // descending buckets
+        for (size_t i = 0; i < n; i++) dst[off[(src[i].score >> shift) & 0xFF]++] = src[i];
+    }
+}
+
+int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t* out_len) {
+    if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
+    int rc = fzb_match_list_into(m, c, 0, c->dev.n, 0, out, out_len);
+    if (rc) return rc;
+    const int sort = m->config.sort;
+    if (sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC) std::reverse(*out, *out + *out_len);              // mod.rs:215-217
+    if (!m->empty && (sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC)) fzb_radix_sort_matches(*out, *out_len);  // :218-220
+    return FZB_OK;
+}
+
+int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads, fzb_match** out, size_t* out_len) {
+    if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
+    if (threads == 0) return fail(FZB_ERR_PANIC, "threads must be positive");  // parallel.rs:24
+    return fzb_match_list(m, c, out, out_len);
+}
+
+void fzb_matches_free(fzb_match* p) { free(p); }
+
+static bool merge_less(int order, const fzb_match& l, const fzb_match& r) {  // src/k_merge.rs:14-53
+    switch (order) {
+        case FZB_SORT_SCORE_THEN_INDEX_ASC: return l.score > r.score || (l.score == r.score && l.index < r.index);
+        case FZB_SORT_SCORE_THEN_INDEX_DESC: return l.score > r.score || (l.score == r.score && l.index > r.index);
+        case FZB_SORT_INDEX_ASC: return l.index < r.index;
+        default: return l.index > r.index;
+    }
+}
+
+int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_lens, size_t nruns, fzb_match* out) {
+    if (sort < 0 || sort > 3 || (nruns && (!run_lens))) return fail(FZB_ERR_INVALID, "bad argument");
+    // tournament over run heads (any correct k-way merge of runs sorted under a TOTAL order yields the same sequence)
+    std::vector<size_t> start(nruns), pos(nruns, 0);
+    size_t off = 0;
+    for (size_t k = 0; k < nruns; k++) { start[k] = off; off += run_lens[k]; }
+    std::vector<size_t> heap;
+    auto less_run = [&](size_t a, size_t b) { return merge_less(sort, runs[start[a] + pos[a]], runs[start[b] + pos[b]]); };
+    auto cmp = [&](size_t a, size_t b) { return less_run(b, a); };  // std heap is a max-heap
+    for (size_t k = 0; k < nruns; k++)
+        if (run_lens[k]) heap.push_back(k);
+    std::make_heap(heap.begin(), heap.end(), cmp);
+    size_t o = 0;
+    while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const size_t k = heap.back();
+        out[o++] = runs[start[k] + pos[k]];
+        if (++pos[k] < run_lens[k]) std::push_heap(heap.begin(), heap.end(), cmp);
+        else heap.pop_back();
+    }
+    return FZB_OK;
+}
+
+int fzb_set_profiling(fzb_matcher* m, int enabled) {
+    if (!m) return fail(FZB_ERR_INVALID, "null argument");
+    m->profiling = enabled != 0;
+    return FZB_OK;
+}
+
+int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
+    if (!m || !out_ms) return fail(FZB_ERR_INVALID, "null argument");
+    if (!m->profiling || !m->ev[0]) return fail(FZB_ERR_INVALID, "profiling not enabled");
+    HIPCHK(hipEventSynchronize(m->ev[2]));
+    HIPCHK(hipEventElapsedTime(&out_ms[0], m->ev[0], m->ev[1]));
+    HIPCHK(hipEventElapsedTime(&out_ms[1], m->ev[0], m->ev[2]));
+    out_ms[2] = out_ms[3] = 0;
+    return FZB_OK;
+}
+
+int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {
+    if (!m || !out) return fail(FZB_ERR_INVALID, "null argument");
+    if (m->ws.counters) HIPCHK(hipMemcpy(m->last_counters, m->ws.counters, 16, hipMemcpyDeviceToHost));
+    memcpy(out, m->last_counters, 16);
+    return FZB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+// gfx950 kernels, stage 1: the streaming filter over the whole haystack list (HBM-bound) and the small
+// order-preserving compaction kernels (scan / map) that turn its bitmap into a dense survivor list.
+//
+// Reference semantics being implemented:
+//   * `match_list_into_impl` outer loop: length check + prefilter accept (src/matcher/algo.rs:78-103)
+//   * 0-typo ASCII accept  == needle is a case-folded ordered subsequence (src/prefilter/algo/ascii.rs:6-54)
+//   * k-typo accept        is implied by LCS(needle, haystack) + k >= rows (src/prefilter/mod.rs:1013-1084);
+//     the converse does not hold at every lane width (oracle/selfcheck.cpp), so with typos - and on the unicode
+//     path, where this stage only looks at each scalar's LAST byte - this stage is a conservative superset
+//     and the lane-exact prefilter (kernels_window.hip) re-decides every survivor.
+#include "kernels_common.h"
+
+// ---------------------------------------------------------------------------------------------------
+// K1: one thread per haystack.  Bytes are streamed from HBM as aligned 16-byte vectors (padded-16 layout),
+// each byte indexes a 256-entry table in LDS whose entry is the bitmask of needle rows that byte can
+// match (either case); the per-thread state is one machine word:
+//   MODE 1 (ordered subsequence): st is one-hot at the next row to match; `st += st & T[b]` advances it.
+//   MODE 2 (bit-vector LCS, Allison-Dix/Hyyro): V' = (V + (V & M)) | (V & ~M); LCS = #zero bits.
+// Output: 1 bit per haystack (wave ballot -> one u64 store per wave) + a count per 1024-haystack tile.
+// ---------------------------------------------------------------------------------------------------
+template <typename TW, int MODE>
+__device__ __forceinline__ void filter_step(TW& st, u32 b, const TW* T) {
+    TW t = T[b];
+    if (MODE == 1) {
+        st += st & t;
+    } else {
+        TW u = st & t;
+        st = (st + u) | (st & ~t);
+    }
+}
+
+template <typename TW, int MODE>
+__device__ __forceinline__ void filter_word(TW& st, u32 w, u32 nbytes, const TW* T) {
+    if (nbytes >= 4) {
+        filter_step<TW, MODE>(st, w & 0xFF, T);
+        filter_step<TW, MODE>(st, (w >> 8) & 0xFF, T);
+        filter_step<TW, MODE>(st, (w >> 16) & 0xFF, T);
+        filter_step<TW, MODE>(st, w >> 24, T);
+    } else {
+        for (u32 k = 0; k < nbytes; k++) filter_step<TW, MODE>(st, (w >> (8 * k)) & 0xFF, T);
+    }
+}
+
+template <typename TW, int MODE, typename ET>
+__global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
+                                                 const u64* __restrict__ Tg, int rows, int need, u32 min_len,
+                                                 u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
+    __shared__ TW T[256];
+    __shared__ u32 s_cnt;
+    const int tid = threadIdx.x;
+    T[tid] = (TW)Tg[tid];
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        u32 cnt = 0;
+#pragma unroll 1
+        for (int p = 0; p < FZB_TILE / 256; p++) {
+            const u32 li = tile * FZB_TILE + p * 256 + tid;
+            bool matched = false;
+            if (li < count) {
+                u64 s;
+                u32 L;
+                haystack_span(ends, first + li, s, L);
+                if (L >= min_len) {
+                    const uint4* vp = (const uint4*)(bytes + s);
+                    TW st = (MODE == 1) ? (TW)1 : (TW)~(TW)0;
+                    const u32 nvec = (L + 15) >> 4;
+                    for (u32 v = 0; v < nvec; v++) {
+                        const uint4 q = vp[v];
+                        const u32 rem = L - 16 * v;
+                        filter_word<TW, MODE>(st, q.x, rem, T);
+                        if (rem > 4) filter_word<TW, MODE>(st, q.y, rem - 4, T);
+                        if (rem > 8) filter_word<TW, MODE>(st, q.z, rem - 8, T);
+                        if (rem > 12) filter_word<TW, MODE>(st, q.w, rem - 12, T);
+                    }
+                    if (MODE == 1) {
+                        matched = (st >> rows) & 1;
+                    } else {
+                        const TW low = rows >= (int)(8 * sizeof(TW)) ? (TW)~(TW)0 : (((TW)1 << rows) - 1);
+                        const TW z = ~st & low;
+                        const int lcs = sizeof(TW) == 8 ? __popcll((u64)z) : __popc((u32)z);
+                        matched = lcs >= need;
+                    }
+                }
+            }
+            const u64 b = __ballot(matched);
+            if (lane_id() == 0) {
+                bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
+                cnt += __popcll(b);
+            }
+        }
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// Used when nothing is filtered (max_typos = None, or max_typos >= rows): every haystack survives.
+__global__ __launch_bounds__(256) void k1_all_pass(u32 count, u32 min_len_unused, u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
+    const u32 nwords = (count + 63) / 64;
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    for (u32 w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+        const u32 rem = count - w * 64;
+        bitmap[w] = rem >= 64 ? ~(u64)0 : (((u64)1 << rem) - 1);
+    }
+    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
+        const u32 rem = count - t * FZB_TILE;
+        tile_counts[t] = rem >= FZB_TILE ? FZB_TILE : rem;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Exclusive scan of the per-tile counts (one 1024-thread block; the list has count/1024 entries).
+// `n_items_ptr` (device) holds the number of ITEMS the tiles cover, so the same kernel serves both the
+// first-level (haystacks) and second-level (survivors) compaction without a host round trip.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_tiles(const u32* __restrict__ counts, u32* __restrict__ prefix, const u32* __restrict__ n_items_ptr,
+                                                     u32 n_items_host, u32* __restrict__ total_out) {
+    __shared__ u32 wsum[16];
+    const u32 n_items = n_items_ptr ? *n_items_ptr : n_items_host;
+    const u32 ntiles = (n_items + FZB_TILE - 1) / FZB_TILE;
+    const u32 per = (ntiles + 1023) / 1024;
+    const u32 lo = threadIdx.x * per, hi = min(lo + per, ntiles);
+    u32 sum = 0;
+    for (u32 t = lo; t < hi; t++) sum += counts[t];
+    // block exclusive scan of `sum`
+    u32 incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        u32 v = __shfl_up(incl, off);
+        if (lane_id() >= off) incl += v;
+    }
+    const int wave = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 wbase = 0;
+    for (int w = 0; w < wave; w++) wbase += wsum[w];
+    u32 run = wbase + incl - sum;
+    for (u32 t = lo; t < hi; t++) {
+        prefix[t] = run;
+        run += counts[t];
+    }
+    if (threadIdx.x == 1023) {
+        prefix[ntiles] = wbase + incl;
+        *total_out = wbase + incl;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Bitmap -> dense, index-ordered list.  One thread per bitmap word.  LEVEL 1: out_idx[j] = bit position.
+// LEVEL 2 (after the lane-exact prefilter re-decided the survivors): gathers payloads of the kept items.
+// ---------------------------------------------------------------------------------------------------
+template <int LEVEL>
+__global__ __launch_bounds__(256) void k_map(const u64* __restrict__ bitmap, const u32* __restrict__ prefix, const u32* __restrict__ n_items_ptr, u32 n_items_host,
+                                             u32* __restrict__ out_idx, const u32* __restrict__ in_idx, const u32* __restrict__ in_win, u32* __restrict__ out_win) {
+    const u32 n_items = n_items_ptr ? *n_items_ptr : n_items_host;
+    const u32 nwords = (n_items + 63) / 64;
+    for (u32 w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+        u64 bits = bitmap[w];
+        if (!bits) continue;
+        const u32 tile = w / (FZB_TILE / 64);
+        u32 pos = prefix[tile];
+        for (u32 k = tile * (FZB_TILE / 64); k < w; k++) pos += __popcll(bitmap[k]);
+        while (bits) {
+            const int b = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const u32 item = w * 64 + b;
+            if (LEVEL == 1) {
+                out_idx[pos] = item;
+            } else {
+                out_idx[pos] = in_idx[item];
+                out_win[2 * pos] = in_win[2 * item];
+                out_win[2 * pos + 1] = in_win[2 * item + 1];
+            }
+            pos++;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host-side launch wrappers (called from pipeline.hip)
+// ---------------------------------------------------------------------------------------------------
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, int rows, int mode, int need, u32 min_len,
+                       u64* bitmap, u32* tile_counts, int grid, hipStream_t st) {
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    if (grid > (int)ntiles) grid = ntiles;
+    if (grid < 1) grid = 1;
+    if (mode == 0) {
+        hipLaunchKernelGGL(k1_all_pass, dim3(grid), dim3(256), 0, st, count, min_len, bitmap, tile_counts);
+        return;
+    }
+    const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
+#define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts)
+    if (c.ends_u64) {
+        if (mode == 1) { if (w64) FZB_K1(u64, 1, u64); else FZB_K1(u32, 1, u64); }
+        else           { if (w64) FZB_K1(u64, 2, u64); else FZB_K1(u32, 2, u64); }
+    } else {
+        if (mode == 1) { if (w64) FZB_K1(u64, 1, u32); else FZB_K1(u32, 1, u32); }
+        else           { if (w64) FZB_K1(u64, 2, u32); else FZB_K1(u32, 2, u32); }
+    }
+#undef FZB_K1
+}
+
+void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, counts, prefix, n_items_ptr, n_items_host, total_out);
+}
+
+void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,
+                    const u32* in_idx, const u32* in_win, u32* out_win, int grid, hipStream_t st) {
+    if (level == 1)
+        hipLaunchKernelGGL((k_map<1>), dim3(grid), dim3(256), 0, st, bitmap, prefix, n_items_ptr, n_items_host, out_idx, in_idx, in_win, out_win);
+    else
+        hipLaunchKernelGGL((k_map<2>), dim3(grid), dim3(256), 0, st, bitmap, prefix, n_items_ptr, n_items_host, out_idx, in_idx, in_win, out_win);
+}

@@ -1,0 +1,284 @@
+// gfx950 kernels, stage 2c: the generic scorer.  One WAVE per haystack, one DP column per lane, so a wave64
+// IS the reference's 64-lane score vector (AVX-512/u8 class); narrower classes use the low SWL lanes.
+// `shift_right_padded::<L>` is a wave shuffle whose low L lanes are refilled from the previous chunk's row,
+// kept per needle row in LDS (the reference's score_matrix column, src/smith_waterman/matrix.rs).
+// Handles everything the single-chunk thread-per-haystack kernel does not:
+//   * ASCII windows wider than one chunk               src/smith_waterman/algo/ascii.rs:10-158
+//   * the unicode scorer (any width)                   src/smith_waterman/algo/unicode.rs:10-273,
+//                                                      src/smith_waterman/algo/unicode_gap.rs:110-236
+//   * the greedy fallback beyond 1024 bytes            src/smith_waterman/greedy.rs:7-91
+// Arithmetic is done per lane in 32-bit registers and wrapped to the emulated lane type (u8 / u16) after
+// every add, so it follows the reference's wrapping add / saturating sub literally.
+#include "kernels_common.h"
+
+#define GEN_WAVES 4
+
+__device__ __forceinline__ u32 subs(u32 a, u32 b) { return a > b ? a - b : 0; }
+
+// shift right by k lanes; lanes < k take adj[SWL - k + lane] (adj = previous chunk's vector in LDS, or nullptr => 0)
+template <int SWL>
+__device__ __forceinline__ u32 shift_pad(u32 v, int k, const u16* adj, int lane) {
+    u32 t = __shfl_up(v, k);
+    if (lane < k) t = adj ? (u32)adj[SWL - k + lane] : 0u;
+    return t;
+}
+// same with the adjacent vector held in registers of the same wave (lane l holds adjv[l])
+template <int SWL>
+__device__ __forceinline__ u32 shift_pad_reg(u32 v, int k, u32 adjv, int lane) {
+    u32 t = __shfl_up(v, k);
+    u32 a = __shfl(adjv, (SWL - k + lane) & 63);
+    return lane < k ? a : t;
+}
+
+// match_greedy (src/smith_waterman/greedy.rs:7-91), run by one lane
+__device__ u32 greedy_score(const NeedleDev& nd, const u8* __restrict__ h, u32 hlen, bool include_prefix) {
+    const u32 n = (u32)nd.nbytes;
+    if (n > hlen) return 0;
+    u32 score = 0, hi = 0;
+    bool dben = false, prev_lower = false, prev_delim = false;
+    auto sadd = [](u32 a, u32 b) { u32 s = a + b; return s > 0xFFFFu ? 0xFFFFu : s; };
+    for (u32 ni = 0; ni < n; ni++) {
+        const u32 nc = nd.c[ni], fc = nd.f[ni];
+        const u32 hstart = hi;
+        bool found = false;
+        while (hi <= hlen - n + ni) {
+            const u32 hc = h[hi];
+            const bool digit = hc >= '0' && hc <= '9', upper = hc >= 'A' && hc <= 'Z', lower = hc >= 'a' && hc <= 'z';
+            const bool delim = hc < 128 && !(lower || upper || digit);
+            if (!delim) dben = true;
+            if (nc != hc && fc != hc) {
+                prev_delim = dben && delim;
+                prev_lower = lower;
+                hi++;
+                continue;
+            }
+            score = sadd(score, nd.match_score);
+            if (hi != hstart && ni != 0) {
+                u32 gl = hi - hstart;
+                gl = gl > 0 ? gl - 1 : 0;
+                if (gl > 0xFFFF) gl = 0xFFFF;
+                u32 ext = (u32)nd.gex * gl;
+                if (ext > 0xFFFF) ext = 0xFFFF;
+                score = subs(score, sadd((u32)nd.gap_open, ext));
+            }
+            if (nc == hc) score = sadd(score, nd.matching_case);
+            if (upper && prev_lower) score = sadd(score, nd.capitalization);
+            if (include_prefix && hi == 0) score = sadd(score, nd.prefix);
+            if (prev_delim && !delim) score = sadd(score, nd.delimiter);
+            prev_delim = dben && delim;
+            prev_lower = lower;
+            hi++;
+            found = true;
+            break;
+        }
+        if (!found) return 0;
+    }
+    return score;
+}
+
+template <int SWL, bool UNICODE, typename ET>
+__global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+                                                              const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
+                                                              const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
+                                                              fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters) {
+    // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row
+    __shared__ u16 s_adj_row[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
+    __shared__ u16 s_adj_aux[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
+    const int lane = lane_id();
+    const int wv = threadIdx.x >> 6;
+    const u32 nlist = *n_list_ptr;
+    if (UNICODE && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = nlist < capacity ? nlist : capacity;
+    const u32 LM = (u32)nd.lane_mask;
+    const u32 rows = (u32)nd.rows;
+    const u32 Mc = nd.match_plus_mismatch & LM, X = nd.mismatch & LM, gex = nd.gex & LM, gopm = nd.gopm & LM;
+    const u32 caseb = nd.matching_case & LM, capb = nd.capitalization & LM, delimb = nd.delimiter & LM, prefixb = nd.prefix & LM;
+    const bool active = lane < SWL;
+
+    for (u32 q = blockIdx.x * GEN_WAVES + wv; q < nlist; q += gridDim.x * GEN_WAVES) {
+        const u32 j = list ? list[3 * q] : q;  // list entries: (item, window start, window end) queued by the single-chunk kernel
+        if (j >= capacity) continue;
+        const u32 li = items ? items[j] : j;
+        u64 s;
+        u32 L;
+        haystack_span(ends, first + li, s, L);
+        const u8* hay = bytes + s;
+        u32 ws, we;
+        if (list) { ws = list[3 * q + 1]; we = list[3 * q + 2]; }
+        else if (wmode == 2) { ws = 0; we = L; }
+        else { ws = win[2 * j]; we = win[2 * j + 1]; }
+        const u32 sp = ws ? ws - 1 : 0;
+        const bool include_exact = sp == 0 && we == L;
+        const bool include_prefix = sp == 0;
+        const u32 m = we - sp;
+        const u8* th = hay + sp;  // trimmed haystack
+        u32 score = 0;
+        if (m > FZB_MAX_HAYSTACK_LEN) {
+            if (lane == 0) score = greedy_score(nd, th, m, include_prefix);
+            score = __shfl(score, 0);
+        } else if (m > 0 && rows > 0) {
+            const u32 nchunks = (m + SWL - 1) / SWL;
+            u32 maxs = 0;
+            bool prev_last_lower = false, prev_last_delim = false;  // previous chunk's last lane (ascii.rs:55-56, 78, 95)
+            u32 prev_cont = 0, prev_sm = 0;                         // unicode: previous chunk's continuation-gex / scalar-start vectors
+            for (u32 ch = 0; ch < nchunks; ch++) {
+                const u32 base = ch * SWL;
+                const u32 pos = base + lane;
+                const u32 b0 = (active && pos < m) ? th[pos] : 0;
+                const bool lower = b0 >= 'a' && b0 <= 'z', upper = b0 >= 'A' && b0 <= 'Z', digit = b0 >= '0' && b0 <= '9';
+                const bool delim = !(lower || upper || digit || b0 > 127);
+                bool pl = __shfl_up((int)lower, 1), pd = __shfl_up((int)delim, 1);
+                if (lane == 0) { pl = prev_last_lower; pd = prev_last_delim; }
+                const u32 cap = (upper && pl) ? capb : 0, dl = (pd && !delim) ? delimb : 0;
+                u32 bonus = (dl + cap) & LM;
+                bonus = (bonus + ((ch == 0 && lane == 0 && include_prefix) ? prefixb : 0)) & LM;
+                bonus = (bonus + Mc) & LM;
+                prev_last_lower = __shfl((int)lower, SWL - 1);
+                prev_last_delim = __shfl((int)delim, SWL - 1);
+
+                // unicode per-chunk vectors (unicode.rs:81-89, 244-273)
+                u32 b1 = 0, b2 = 0, b3 = 0;
+                bool sstart = false;
+                u32 contgex = 0, smask = 0;
+                u32 cont_k[6], sm_k[6];
+                if (UNICODE) {
+                    b1 = (active && pos + 1 < m) ? th[pos + 1] : 0;
+                    b2 = (active && pos + 2 < m) ? th[pos + 2] : 0;
+                    b3 = (active && pos + 3 < m) ? th[pos + 3] : 0;
+                    const bool valid = active && pos < m;
+                    const bool cont = b0 > 0x7f && b0 < 0xc0 && valid;
+                    sstart = !cont && valid;
+                    contgex = cont ? gex : 0;
+                    smask = sstart ? LM : 0;
+                    // the per-step (continuation count, scalar-start-crossed) vectors do not depend on the needle
+                    // row: unicode_gap.rs:141-166 `prepare_next_unicode_gap_step`, evaluated once per chunk
+                    u32 c = contgex, ac = prev_cont, sm = smask, asm_ = prev_sm;
+                    int k = 0;
+                    for (int sh = 1; sh < SWL; sh *= 2, k++) {
+                        cont_k[k] = c;
+                        sm_k[k] = sm;
+                        if (sh * 2 < SWL) {
+                            const u32 sc = shift_pad_reg<SWL>(c, sh, ac, lane);
+                            c = (c + sc) & LM;
+                            u32 sac = __shfl_up(ac, sh);
+                            if (lane < sh) sac = 0;
+                            ac = (ac + sac) & LM;
+                            const u32 ssm = shift_pad_reg<SWL>(sm, sh, asm_, lane);
+                            sm = max(sm, ssm);
+                            u32 sasm = __shfl_up(asm_, sh);
+                            if (lane < sh) sasm = 0;
+                            asm_ = max(asm_, sasm);
+                        }
+                    }
+                }
+
+                u32 prev_row = 0, up_mm = 0;
+                u32 carry_last = 0;  // S(row-1, previous chunk)[SWL-1], captured before that vector is overwritten
+                u32 row = 0;
+                for (u32 r = 1; r <= rows; r++) {
+                    bool mm, ex;
+                    if (UNICODE) {
+                        const u32 cl = nd.ulen[r - 1];
+                        const u8* uc = nd.uc[r - 1];
+                        const u8* uf = nd.uf[r - 1];
+                        const u32 lastb = cl == 1 ? b0 : cl == 2 ? b1 : cl == 3 ? b2 : b3;
+                        bool e = sstart && lastb == uc[cl - 1];
+                        bool fl = sstart && lastb == uf[cl - 1];
+                        if (cl > 1) { e = e && b0 == uc[0]; fl = fl && b0 == uf[0]; }
+                        if (cl > 2) { e = e && b1 == uc[1]; fl = fl && b1 == uf[1]; }
+                        if (cl > 3) { e = e && b2 == uc[2]; fl = fl && b2 == uf[2]; }
+                        ex = e;
+                        mm = e || fl;
+                    } else {
+                        ex = b0 == nd.c[r - 1];
+                        mm = ex || b0 == nd.f[r - 1];
+                    }
+                    // diagonal (ascii.rs:118-127 / unicode.rs:165-175)
+                    u32 dsrc = __shfl_up(prev_row, 1);
+                    if (lane == 0) dsrc = carry_last;
+                    u32 diag = (dsrc + (mm ? bonus : 0)) & LM;
+                    diag = subs(diag, X);
+                    diag = (diag + (ex ? caseb : 0)) & LM;
+                    // up (ascii.rs:130-133 / unicode.rs:178-182)
+                    u32 up = subs(subs(prev_row, gex), up_mm ? gopm : 0);
+                    if (UNICODE) {
+                        if (!sstart) { diag = 0; up = 0; }
+                    }
+                    row = max(diag, up);
+                    const u16* adj = ch ? s_adj_row[wv][r] : nullptr;
+                    const u16* adja = ch ? s_adj_aux[wv][r] : nullptr;
+                    // capture S(r, prev chunk)[SWL-1] for the next row's diagonal before overwriting
+                    const u32 next_carry = ch ? (u32)s_adj_row[wv][r][SWL - 1] : 0u;
+                    u32 aux;  // ASCII: this row's match mask (0 / LM); unicode: pending gap-open mask
+                    if (!UNICODE) {
+                        // propagate_horizontal_gaps (ascii_gap.rs:11-105)
+                        const u32 mmv = mm ? LM : 0;
+                        u32 kg = gex;
+                        for (int sh = 1; sh < SWL; sh *= 2) {
+                            const u32 srow = shift_pad<SWL>(row, sh, adj, lane);
+                            const u32 smm = shift_pad<SWL>(mmv, sh, adja, lane);
+                            const u32 pen = (kg + (gopm & smm)) & LM;
+                            row = max(row, subs(srow, pen));
+                            kg = (kg + kg) & LM;
+                        }
+                        aux = mmv;
+                    } else {
+                        // propagate_horizontal_unicode_gaps (unicode_gap.rs:110-236)
+                        u32 pending = mm ? LM : 0;
+                        u32 tot = gex;
+                        int k = 0;
+                        for (int sh = 1; sh < SWL; sh *= 2, k++) {
+                            const u32 srow = shift_pad<SWL>(row, sh, adj, lane);
+                            const u32 spend = shift_pad<SWL>(pending, sh, adja, lane);
+                            const u32 sgex = subs(tot, cont_k[k]);
+                            const u32 crossed = spend & sm_k[k];
+                            const u32 pen = (sgex + (gopm & crossed)) & LM;
+                            row = max(row, subs(srow, pen));
+                            pending = max(pending, subs(spend, sm_k[k]));
+                            tot = (tot + tot) & LM;
+                        }
+                        aux = pending;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (active && ch + 1 < nchunks) {
+                        s_adj_row[wv][r][lane] = (u16)row;
+                        s_adj_aux[wv][r][lane] = (u16)aux;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    carry_last = next_carry;
+                    prev_row = row;
+                    up_mm = mm ? 1 : 0;
+                }
+                if (active) maxs = max(maxs, row);
+                if (UNICODE) { prev_cont = contgex; prev_sm = smask; }
+            }
+            // horizontal max
+            for (int off = 32; off > 0; off >>= 1) maxs = max(maxs, (u32)__shfl_xor(maxs, off));
+            score = maxs;
+        }
+        if (lane == 0) {
+            bool exact = include_exact && m == (u32)nd.nbytes;
+            if (exact)
+                for (u32 k = 0; k < m; k++) exact = exact && th[k] == nd.raw[k];
+            if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+            fzb_match_rec rec;
+            rec.index = index_offset + li;
+            rec.score = (u16)score;
+            rec.exact = exact ? 1 : 0;
+            rec.valid = 0;
+            out[j] = rec;
+        }
+    }
+}
+
+void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st) {
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters)
+#define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
+#define FZB_K2C_U(SWL) do { if (unicode) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2C_U(64); break;
+        case 32: FZB_K2C_U(32); break;
+        case 16: FZB_K2C_U(16); break;
+        default: FZB_K2C_U(8); break;
+    }
+}

@@ -1,0 +1,461 @@
+// gfx950 kernels, stage 2a: the LANE-EXACT prefilter.  One thread per survivor of the streaming filter
+// re-runs the reference's chunked multi-path algorithm with the same chunk width (PFL = 16/32/64 "lanes")
+// the emulated CPU backend uses, because both the accept decision (with typos) and the returned window
+// depend on it.  Chunk occurrence masks are 64-bit integers exactly like AVX-512's __mmask64
+// (src/prefilter/backend/avx512.rs:9-57); movemask/tzcnt/lzcnt become SWAR compares + ffs/clz.
+//
+//   ASCII  1 / 2 / N typos : src/prefilter/algo/ascii_typos.rs:15-110, 113-251, 254-360, end scan :375-397
+//   unicode 0 typos        : src/prefilter/algo/unicode.rs:119-219, back scan :222-276
+//   unicode 1 / 2 / N typos: src/prefilter/algo/unicode_typos.rs:15-141, 144-330, 333-466, end scan :479-508
+//
+// Output per survivor: win[2j] = start, win[2j+1] = end (start = 0xFFFFFFFF if rejected) and a keep-bit
+// (wave ballot) + per-tile keep counts for the second-level compaction.
+#include "kernels_common.h"
+
+template <int PFL>
+struct Chunk {
+    static constexpr int NW = PFL / 4;
+    u32 w[NW];
+};
+
+template <int PFL>
+__device__ __forceinline__ u64 m_all() { return PFL == 64 ? ~(u64)0 : (((u64)1 << PFL) - 1); }
+template <int PFL>
+__device__ __forceinline__ u64 m_first_n(u32 n) { return n >= (u32)PFL ? m_all<PFL>() : (((u64)1 << n) - 1); }
+template <int PFL>
+__device__ __forceinline__ u32 m_lz(u64 m) { return (u32)__builtin_clzll(m) - (64 - PFL); }  // m != 0
+__device__ __forceinline__ u32 m_tz(u64 m) { return (u32)__builtin_ctzll(m); }                 // m != 0
+template <int PFL>
+__device__ __forceinline__ u64 m_clear_through_lowest(u64 self, u64 hit) { return self & ~(hit ^ (hit - 1)) & m_all<PFL>(); }
+
+// PFL bytes of the haystack starting at byte `pos` (haystack-relative), zero beyond `len`.
+template <int PFL>
+__device__ __forceinline__ void load_chunk(Chunk<PFL>& c, const u8* __restrict__ hay, u32 pos, u32 len) {
+#pragma unroll
+    for (int k = 0; k < Chunk<PFL>::NW; k++) {
+        const u32 p = pos + 4 * k;
+        u32 v = 0;
+        if (p < len) {
+            v = load_u32_unaligned(hay, p);
+            const u32 rem = len - p;
+            if (rem < 4) v &= (1u << (8 * rem)) - 1;
+        }
+        c.w[k] = v;
+    }
+}
+
+// 4-bit mask of the bytes of x that are zero (exact, no borrow artefacts)
+__device__ __forceinline__ u32 zero_bytes4(u32 x) {
+    u32 y = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;  // bit7 set in every non-zero byte
+    y = ~y & 0x80808080u;
+    return ((y >> 7) * 0x00204081u >> 21) & 0xF;
+}
+template <int PFL>
+__device__ __forceinline__ u64 eq_mask(const Chunk<PFL>& c, u32 v) {
+    const u32 sp = v * 0x01010101u;
+    u64 m = 0;
+#pragma unroll
+    for (int k = 0; k < Chunk<PFL>::NW; k++) m |= (u64)zero_bytes4(c.w[k] ^ sp) << (4 * k);
+    return m;
+}
+template <int PFL>
+__device__ __forceinline__ u64 occ_mask(const Chunk<PFL>& c, u32 a, u32 b) {
+    u64 m = eq_mask<PFL>(c, a);
+    if (b != a) m |= eq_mask<PFL>(c, b);
+    return m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Occurrence sources: what `B::occ(chunk, needle[idx])` / `unicode_char_mask(start, .., needle[idx])` return
+// ------------------------------------------------------------------------------------------------
+template <int PFL>
+struct AsciiSrc {
+    const NeedleDev& nd;
+    const u8* hay;
+    u32 len;
+    Chunk<PFL> chunk;
+    u64 valid;  // chunk_mask from load_window
+    __device__ AsciiSrc(const NeedleDev& n, const u8* h, u32 l) : nd(n), hay(h), len(l) {}
+    __device__ __forceinline__ void load(u32 start) {
+        load_chunk<PFL>(chunk, hay, start, len);
+        valid = m_first_n<PFL>(len - start);
+    }
+    __device__ __forceinline__ u64 mask(u32 idx) const { return occ_mask<PFL>(chunk, nd.c[idx], nd.f[idx]); }
+    __device__ __forceinline__ u64 init_mask() const { return valid; }  // ASCII path masks start as chunk_mask
+    __device__ __forceinline__ u32 rows() const { return (u32)nd.rows; }
+};
+
+template <int PFL>
+struct UnicodeSrc {
+    const NeedleDev& nd;
+    const u8* hay;
+    u32 len;
+    u32 start;
+    Chunk<PFL> ch[4];  // windows at start+0 .. start+3
+    __device__ UnicodeSrc(const NeedleDev& n, const u8* h, u32 l) : nd(n), hay(h), len(l), start(0) {}
+    __device__ __forceinline__ void load(u32 s) {
+        start = s;
+#pragma unroll
+        for (int o = 0; o < 4; o++) load_chunk<PFL>(ch[o], hay, s + o, len);
+    }
+    // match_unicode_char_prefix + char_variant_mask (unicode.rs:9-72) for one case variant
+    __device__ __forceinline__ u64 variant(const u8 chars[4], u32 cl, u64 chunk_mask) const {
+        u64 m = eq_mask<PFL>(ch[cl - 1], chars[cl - 1]) & chunk_mask;
+        if (m != 0 && cl > 1) {
+            m &= eq_mask<PFL>(ch[0], chars[0]);
+            if (cl > 2) m &= eq_mask<PFL>(ch[1], chars[1]);
+            if (cl > 3) m &= eq_mask<PFL>(ch[2], chars[2]);
+        }
+        return m;
+    }
+    // unicode_char_mask (unicode.rs:74-117)
+    __device__ __forceinline__ u64 mask(u32 idx) const {
+        const u32 cl = nd.ulen[idx];
+        if (start + cl > len) return 0;
+        const u64 valid = m_first_n<PFL>(len - (start + cl - 1));
+        return variant(nd.uc[idx], cl, valid) | variant(nd.uf[idx], cl, valid);
+    }
+    __device__ __forceinline__ u64 init_mask() const { return m_all<PFL>(); }  // unicode path masks start as all()
+    __device__ __forceinline__ u32 rows() const { return (u32)nd.rows; }
+};
+
+struct Win {
+    bool matched;
+    u32 start, end;
+};
+
+// ---- end scans --------------------------------------------------------------------------------
+// find_end_pos_with_typos (ascii_typos.rs:375-397)
+template <int PFL>
+__device__ u32 ascii_end_pos(AsciiSrc<PFL>& src, u32 max_typos) {
+    const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
+    u32 start = (len - 1) / PFL * PFL;
+    for (;;) {
+        src.load(start);
+        u64 mask = 0;
+        for (u32 i = first; i < n; i++) mask |= src.mask(i);
+        mask &= src.valid;
+        if (mask != 0) return start + PFL - m_lz<PFL>(mask);
+        if (start == 0) break;
+        start -= PFL;
+    }
+    return len;
+}
+// find_end_pos_with_unicode_typos (unicode_typos.rs:479-508)
+template <int PFL>
+__device__ u32 unicode_end_pos(UnicodeSrc<PFL>& src, u32 max_typos) {
+    const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
+    u32 start = len >= (u32)PFL ? len - PFL : 0;
+    for (;;) {
+        src.load(start);
+        u32 end_pos = 0;
+        for (u32 i = first; i < n; i++) {
+            const u64 mask = src.mask(i);
+            if (mask != 0) end_pos = max(end_pos, start + PFL - m_lz<PFL>(mask) + src.nd.ulen[i] - 1);
+        }
+        if (end_pos != 0) return end_pos;
+        if (start == 0) break;
+        start = start >= (u32)PFL ? start - PFL : 0;
+    }
+    return len;
+}
+template <int PFL>
+__device__ __forceinline__ u32 end_pos(AsciiSrc<PFL>& s, u32 k) { return ascii_end_pos<PFL>(s, k); }
+template <int PFL>
+__device__ __forceinline__ u32 end_pos(UnicodeSrc<PFL>& s, u32 k) { return unicode_end_pos<PFL>(s, k); }
+
+// ---- 1 typo (ascii_typos.rs:15-110 / unicode_typos.rs:15-141) -----------------------------------
+template <int PFL, typename Src>
+__device__ Win prefilter_1_typo(Src& src) {
+    const u32 n = src.rows(), len = src.len;
+    if (n <= 1) return {true, 0, len};
+    if (len == 0) return {false, 0, 0};
+    u32 i1 = 0, i2 = 1, msp = 0xFFFFFFFFu;
+    for (u32 start = 0; start < len; start += PFL) {
+        src.load(start);
+        u64 m1 = src.mask(i1), m2 = src.mask(i2);
+        u64 c1 = src.init_mask(), c2 = c1;
+        for (;;) {
+            bool advanced = false;
+            const u32 cand = i1 + 1;
+            if (cand > i2) {
+                if (cand == n) return {true, msp, end_pos<PFL>(src, 1)};
+                i2 = cand; c2 = c1; m2 = src.mask(i2);
+            } else if (cand == i2 && c1 > c2) {
+                c2 = c1;
+            }
+            const u64 h1 = m1 & c1;
+            if (h1 != 0) {
+                msp = min(msp, start + m_tz(h1));
+                i1 += 1;
+                c1 = m_clear_through_lowest<PFL>(c1, h1);
+                m1 = src.mask(i1);
+                advanced = true;
+            }
+            const u64 h2 = m2 & c2;
+            if (h2 != 0) {
+                msp = min(msp, start + m_tz(h2));
+                i2 += 1;
+                if (i2 >= n) return {true, msp, end_pos<PFL>(src, 1)};
+                c2 = m_clear_through_lowest<PFL>(c2, h2);
+                m2 = src.mask(i2);
+                advanced = true;
+            }
+            if (!advanced) break;
+        }
+    }
+    return {false, 0, len};
+}
+
+// ---- 2 typos (ascii_typos.rs:113-251 / unicode_typos.rs:144-330) --------------------------------
+template <int PFL, typename Src>
+__device__ Win prefilter_2_typos(Src& src) {
+    const u32 n = src.rows(), len = src.len;
+    if (n <= 2) return {true, 0, len};
+    if (len == 0) return {false, 0, 0};
+    u32 i1 = 0, i2 = 1, i3 = 2, msp = 0xFFFFFFFFu;
+    for (u32 start = 0; start < len; start += PFL) {
+        src.load(start);
+        u64 m1 = src.mask(i1), m2 = src.mask(i2), m3 = src.mask(i3);
+        u64 c1 = src.init_mask(), c2 = c1, c3 = c1;
+        for (;;) {
+            bool advanced = false;
+            const u32 cand2 = i1 + 1;
+            if (cand2 > i2) {
+                if (cand2 == n) return {true, msp, end_pos<PFL>(src, 2)};
+                i2 = cand2; c2 = c1; m2 = src.mask(i2);
+            } else if (cand2 == i2 && c1 > c2) {
+                c2 = c1;
+            }
+            const u32 cand3 = i2 + 1;
+            if (cand3 > i3) {
+                if (cand3 == n) return {true, msp, end_pos<PFL>(src, 2)};
+                i3 = cand3; c3 = c2; m3 = src.mask(i3);
+            } else if (cand3 == i3 && c2 > c3) {
+                c3 = c2;
+            }
+            const u64 h1 = m1 & c1;
+            if (h1 != 0) {
+                msp = min(msp, start + m_tz(h1));
+                i1 += 1;
+                c1 = m_clear_through_lowest<PFL>(c1, h1);
+                m1 = src.mask(i1);
+                advanced = true;
+            }
+            const u64 h2 = m2 & c2;
+            if (h2 != 0) {
+                msp = min(msp, start + m_tz(h2));
+                i2 += 1;
+                if (i2 >= n) return {true, msp, end_pos<PFL>(src, 2)};
+                c2 = m_clear_through_lowest<PFL>(c2, h2);
+                m2 = src.mask(i2);
+                advanced = true;
+            }
+            const u64 h3 = m3 & c3;
+            if (h3 != 0) {
+                msp = min(msp, start + m_tz(h3));
+                i3 += 1;
+                if (i3 >= n) return {true, msp, end_pos<PFL>(src, 2)};
+                c3 = m_clear_through_lowest<PFL>(c3, h3);
+                m3 = src.mask(i3);
+                advanced = true;
+            }
+            if (!advanced) break;
+        }
+    }
+    return {false, 0, len};
+}
+
+// ---- N typos (ascii_typos.rs:254-360 / unicode_typos.rs:333-466) --------------------------------
+template <int PFL, typename Src>
+__device__ Win prefilter_many_typos(Src& src, u32 max_typos) {
+    const u32 n = src.rows(), len = src.len;
+    if (n <= max_typos) return {true, 0, len};
+    if (len == 0) return {false, 0, 0};
+    const u32 path_count = max_typos + 1;  // <= rows <= 63
+    u8 idx[FZB_MAX_ROWS + 1];
+    u64 nmask[FZB_MAX_ROWS + 1];
+    for (u32 p = 0; p < path_count; p++) idx[p] = 0;
+    u32 msp = 0xFFFFFFFFu;
+    for (u32 start = 0; start < len; start += PFL) {
+        src.load(start);
+        u64 chunk_mask = src.init_mask();
+        for (u32 p = 0; p < path_count; p++) nmask[p] = src.mask(idx[p]);
+        for (;;) {
+            for (u32 p = 1; p < path_count; p++) {
+                const u32 cand = idx[p - 1] + 1;
+                if (cand > idx[p]) {
+                    if (cand == n) return {true, msp, end_pos<PFL>(src, max_typos)};
+                    idx[p] = (u8)cand;
+                    nmask[p] = src.mask(cand);
+                }
+            }
+            u64 match_mask = 0;
+            for (u32 p = 0; p < path_count; p++) match_mask |= nmask[p];
+            const u64 matches = match_mask & chunk_mask;
+            if (matches == 0) break;
+            const u32 hit_pos = m_tz(matches);
+            const u64 hit = matches & m_first_n<PFL>(hit_pos + 1);
+            msp = min(msp, start + hit_pos);
+            for (u32 p = 0; p < path_count; p++) {
+                if ((nmask[p] & hit) == 0) continue;
+                idx[p] += 1;
+                if (idx[p] == n) return {true, msp, end_pos<PFL>(src, max_typos)};
+                nmask[p] = src.mask(idx[p]);
+            }
+            chunk_mask = m_clear_through_lowest<PFL>(chunk_mask, hit);
+        }
+    }
+    return {false, 0, len};
+}
+
+// ---- unicode 0 typos (unicode.rs:119-219) + back scan (unicode.rs:222-276) -----------------------
+template <int PFL>
+__device__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL>& src, u32 row, u32 sub_start) {
+    // operates on haystack[sub_start..]; positions returned are relative to sub_start
+    const NeedleDev& nd = src.nd;
+    const u32 cl = nd.ulen[row];
+    const u32 len = src.len - sub_start;
+    const u32 back = PFL + cl - 1;
+    u32 start = len >= back ? len - back : 0;
+    UnicodeSrc<PFL> sub(nd, src.hay + sub_start, len);
+    for (;;) {
+        sub.load(start);
+        // load_window(start + cl - 1): valid lanes are those whose last byte lies inside the haystack
+        const u64 valid = m_first_n<PFL>(len - (start + cl - 1));
+        u64 mask = (eq_mask<PFL>(sub.ch[cl - 1], nd.uc[row][cl - 1]) | eq_mask<PFL>(sub.ch[cl - 1], nd.uf[row][cl - 1])) & valid;
+        if (mask != 0 && cl > 1) {
+            u64 pa = eq_mask<PFL>(sub.ch[0], nd.uc[row][0]), pb = eq_mask<PFL>(sub.ch[0], nd.uf[row][0]);
+            if (cl > 2) { pa &= eq_mask<PFL>(sub.ch[1], nd.uc[row][1]); pb &= eq_mask<PFL>(sub.ch[1], nd.uf[row][1]); }
+            if (cl > 3) { pa &= eq_mask<PFL>(sub.ch[2], nd.uc[row][2]); pb &= eq_mask<PFL>(sub.ch[2], nd.uf[row][2]); }
+            mask &= (pa | pb);
+        }
+        if (mask != 0) return start + PFL - m_lz<PFL>(mask) + cl - 1;
+        if (start == 0) break;
+        start = start >= (u32)PFL ? start - PFL : 0;
+    }
+    return len;
+}
+
+template <int PFL>
+__device__ Win prefilter_unicode_0(UnicodeSrc<PFL>& src) {
+    const NeedleDev& nd = src.nd;
+    const u32 len = src.len, n = src.rows();
+    if (len == 0) return {false, 0, 0};
+    bool can_skip = true;
+    u32 msp = 0;
+    u32 row = 0;  // current needle scalar
+    u32 start = 0;
+    while (start + nd.ulen[row] <= len) {
+        u32 char_len = nd.ulen[row];
+        src.load(start);
+        u64 valid = m_first_n<PFL>(len - (start + char_len - 1));
+        u64 available = m_all<PFL>();
+        for (;;) {
+            const u64 chunk_mask = available & valid;
+            // NOTE: the window (`chunk`) is the one loaded for `char_len`; the prefix compares use needle_char.len
+            const u32 ncl = nd.ulen[row];
+            u64 mask;
+            {
+                // char_variant_mask with chunk = window at start+char_len-1, prefixes for a scalar of ncl bytes
+                u64 a = eq_mask<PFL>(src.ch[char_len - 1], nd.uc[row][ncl - 1]) & chunk_mask;
+                if (a != 0 && ncl > 1) {
+                    a &= eq_mask<PFL>(src.ch[0], nd.uc[row][0]);
+                    if (ncl > 2) a &= eq_mask<PFL>(src.ch[1], nd.uc[row][1]);
+                    if (ncl > 3) a &= eq_mask<PFL>(src.ch[2], nd.uc[row][2]);
+                }
+                u64 b = eq_mask<PFL>(src.ch[char_len - 1], nd.uf[row][ncl - 1]) & chunk_mask;
+                if (b != 0 && ncl > 1) {
+                    b &= eq_mask<PFL>(src.ch[0], nd.uf[row][0]);
+                    if (ncl > 2) b &= eq_mask<PFL>(src.ch[1], nd.uf[row][1]);
+                    if (ncl > 3) b &= eq_mask<PFL>(src.ch[2], nd.uf[row][2]);
+                }
+                mask = a | b;
+            }
+            if (mask == 0) break;
+            available = m_clear_through_lowest<PFL>(available, mask);
+            if (can_skip) { msp = start + m_tz(mask); can_skip = false; }
+            if (row + 1 < n) {
+                row += 1;
+                if (nd.ulen[row] != char_len) {
+                    if (start + nd.ulen[row] > len) break;
+                    char_len = nd.ulen[row];
+                    valid = m_first_n<PFL>(len - (start + char_len - 1));
+                }
+            } else if (start + nd.ulen[row] - 1 + PFL >= len) {
+                return {true, msp, start + PFL - m_lz<PFL>(mask) + nd.ulen[row] - 1};
+            } else {
+                return {true, msp, start + find_last_unicode_char_pos<PFL>(src, row, start)};
+            }
+        }
+        start += PFL;
+    }
+    return {false, 0, len};
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a kernel
+// ------------------------------------------------------------------------------------------------
+template <int PFL, typename ET>
+__global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ surv_idx,
+                                                  const u32* __restrict__ n_surv_ptr, const NeedleDev nd, u32* __restrict__ win,
+                                                  u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32* __restrict__ counters) {
+    __shared__ u32 s_cnt;
+    const u32 M = *n_surv_ptr;
+    const u32 ntiles = (M + FZB_TILE - 1) / FZB_TILE;
+    const int tid = threadIdx.x;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        u32 cnt = 0;
+#pragma unroll 1
+        for (int p = 0; p < FZB_TILE / 256; p++) {
+            const u32 j = tile * FZB_TILE + p * 256 + tid;
+            bool keep = false;
+            if (j < M) {
+                const u32 li = surv_idx[j];
+                u64 s;
+                u32 L;
+                haystack_span(ends, first + li, s, L);
+                const u8* hay = bytes + s;
+                Win w;
+                const u32 k = (u32)nd.max_typos;
+                if (nd.unicode) {
+                    UnicodeSrc<PFL> src(nd, hay, L);
+                    if (k == 0) w = prefilter_unicode_0<PFL>(src);
+                    else if (k == 1) w = prefilter_1_typo<PFL>(src);
+                    else if (k == 2) w = prefilter_2_typos<PFL>(src);
+                    else w = prefilter_many_typos<PFL>(src, k);
+                } else {
+                    AsciiSrc<PFL> src(nd, hay, L);
+                    if (k == 1) w = prefilter_1_typo<PFL>(src);
+                    else if (k == 2) w = prefilter_2_typos<PFL>(src);
+                    else w = prefilter_many_typos<PFL>(src, k);
+                }
+                keep = w.matched;
+                win[2 * j] = keep ? w.start : 0xFFFFFFFFu;
+                win[2 * j + 1] = w.end;
+            }
+            const u64 b = __ballot(keep);
+            if (lane_id() == 0) {
+                bitmap2[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
+                cnt += __popcll(b);
+            }
+        }
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) tile_counts2[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
+                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st) {
+#define FZB_K2A(PFL, ET) hipLaunchKernelGGL((k2a_window<PFL, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, counters)
+    if (c.ends_u64) {
+        if (pf_lanes == 64) FZB_K2A(64, u64); else if (pf_lanes == 32) FZB_K2A(32, u64); else FZB_K2A(16, u64);
+    } else {
+        if (pf_lanes == 64) FZB_K2A(64, u32); else if (pf_lanes == 32) FZB_K2A(32, u32); else FZB_K2A(16, u32);
+    }
+#undef FZB_K2A
+}

@@ -1,0 +1,142 @@
+/*
+ * frizbee_hip.h - C ABI of the MI355X (gfx950) backend for saghen/frizbee's batched fuzzy-scoring path.
+ *
+ * This is the drop-in boundary: a Rust `MatcherBackend::Hip` variant binds exactly
+ * these entry points.  Each one names the reference interface it replaces (paths relative to the
+ * reference crate root).  Plain pointers and sizes only; nothing here depends on torch or HIP types
+ * (`void* stream` is a `hipStream_t`, NULL = the default stream).
+ *
+ * All functions return FZB_OK (0) or an error code; fzb_last_error() returns the message for the
+ * calling thread.  Where the reference panics, the message text is the reference's panic text.
+ * No function ever unwinds across the boundary.
+ */
+#ifndef FRIZBEE_HIP_H
+#define FRIZBEE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    FZB_OK = 0,
+    FZB_ERR_INVALID = 1,      /* bad argument (NULL, bad enum, invalid UTF-8 needle)                      */
+    FZB_ERR_PANIC = 2,        /* the reference would panic (message = its panic text)                     */
+    FZB_ERR_UNSUPPORTED = 3,  /* valid for the reference but not handled by this backend (stated limit)   */
+    FZB_ERR_HIP = 4,          /* HIP runtime error / no device                                            */
+    FZB_ERR_CAPACITY = 5      /* caller-provided device buffer too small                                  */
+};
+
+/* src/lib.rs:357-368 CaseMatching, :379-392 UnicodeMatching, :311-326 SortStrategy */
+enum { FZB_CASE_IGNORE = 0, FZB_CASE_SMART = 1, FZB_CASE_RESPECT = 2 };
+enum { FZB_UNICODE_IGNORE = 0, FZB_UNICODE_SMART = 1, FZB_UNICODE_ALWAYS = 2 };
+enum { FZB_SORT_SCORE_THEN_INDEX_ASC = 0, FZB_SORT_SCORE_THEN_INDEX_DESC = 1, FZB_SORT_INDEX_ASC = 2, FZB_SORT_INDEX_DESC = 3 };
+
+/* src/lib.rs:439-478 `Scoring` (same field order as the Rust struct declaration) */
+typedef struct fzb_scoring {
+    uint16_t match_score, mismatch_penalty, gap_open_penalty, gap_extend_penalty;
+    uint16_t prefix_bonus, capitalization_bonus, matching_case_bonus, exact_match_bonus, delimiter_bonus;
+} fzb_scoring;
+
+/* src/lib.rs:236-258 `Config` (+ per-pattern overrides already resolved, src/pattern.rs:250-262).
+ * `matching` must be Fuzzy: the literal modes (src/literal) are outside this backend.
+ * pf_lanes / sw_lanes select WHICH reference CPU backend the results are bit-exact against, because
+ * frizbee's scores, windows and typo-prefilter decisions depend on the SIMD lane count: both 0 = pick the
+ * pair the reference's `Matcher::get_backend` (src/matcher/mod.rs:448-498) would pick on THIS host CPU
+ * (`is_x86_feature_detected!` predicates) for the needle's score class: AVX-512(+VBMI for the u8 class):
+ * prefilter 64, score 64 (u8) / 32 (u16); AVX2: 32, 32 / 16; SSE4.1 or scalar: 16, 16 / 8.
+ * Non-zero values force a pair (pf_lanes in {16,32,64}, sw_lanes in {8,16,32,64}). */
+typedef struct fzb_config {
+    int32_t max_typos; /* Option<u16>: -1 = None (no prefilter) */
+    int32_t casing;    /* FZB_CASE_*    */
+    int32_t unicode;   /* FZB_UNICODE_* */
+    int32_t sort;      /* FZB_SORT_*    */
+    fzb_scoring scoring;
+    uint16_t pf_lanes, sw_lanes;
+} fzb_config;
+
+/* src/lib.rs:141-153 `Match` with an explicit layout (Rust's is unspecified; the shim copies field-wise) */
+typedef struct fzb_match {
+    uint32_t index;
+    uint16_t score;
+    uint8_t exact;
+    uint8_t _pad;
+} fzb_match;
+
+typedef struct fzb_matcher fzb_matcher; /* replaces `Matcher` / `MatcherImpl<P,S>` (src/matcher/mod.rs:77-82, algo.rs:47-54) */
+typedef struct fzb_corpus fzb_corpus;   /* the `&[S: AsRef<str>]` haystack list, packed and resident in HBM           */
+
+const char* fzb_last_error(void);
+
+/* `Config::default()` (src/lib.rs:260-271) / `Scoring::default()` (src/lib.rs:463-478), lanes = 0 (auto) */
+void fzb_config_default(fzb_config* out);
+
+/* `Matcher::new(needle, &config)` (src/matcher/mod.rs:90-111, 178-204) -> `MatcherImpl::new` (algo.rs:57-71):
+ * resolves Smart casing/unicode, picks the u8/u16 score class (smith_waterman/mod.rs:92-116), runs
+ * `guard_against_score_overflow` (lib.rs:506-537; FZB_ERR_PANIC with the reference's text), builds the
+ * device-side needle tables.  An empty needle is valid (matches everything with score 0, mod.rs:381-384). */
+int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, size_t needle_len, fzb_matcher** out);
+int fzb_matcher_clone(const fzb_matcher* m, fzb_matcher** out); /* `impl Clone for Matcher` (parallel.rs:46) */
+void fzb_matcher_free(fzb_matcher* m);
+/* introspection: out[0]=pf_lanes out[1]=sw_lanes out[2]=u8 class? out[3]=case_sensitive out[4]=unicode path? out[5]=rows */
+int fzb_matcher_info(const fzb_matcher* m, int32_t out[6]);
+
+/* Packs what `match_list(&haystacks)` borrows (src/matcher/mod.rs:212) into device memory:
+ * `bytes` = all haystacks concatenated, `end_offsets[i]` = exclusive end of haystack i (n entries).
+ * The copy is owned by the library and outlives calls, so repeated queries amortise the upload. */
+int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t n, fzb_corpus** out);
+/* Same, but the data already lives in HBM (e.g. a torch tensor's data_ptr()) in the library's device layout
+ * ("padded-16"): haystack i starts at start(i) = i ? roundup16(dev_ends[i-1]) : 0 and ends (exclusive) at
+ * dev_ends[i]; bytes between haystacks are zero; dev_bytes is 16-byte aligned and has >= 80 readable zero
+ * bytes after the last haystack.  dev_ends has n entries (uint32 if ends_are_u64 == 0).  Borrowed, not copied.
+ * (A list of 32-byte haystacks stored back to back already has this layout.) */
+int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends_are_u64, size_t n, uint64_t total_bytes, fzb_corpus** out);
+void fzb_corpus_free(fzb_corpus* c);
+size_t fzb_corpus_len(const fzb_corpus* c);
+
+/* `Matcher::match_list(&haystacks)` (src/matcher/mod.rs:212-222) = `match_list_into(.., offset 0)` ->
+ * `Specialized::match_list::<TYPOS,UNICODE,_>` (src/matcher/algo.rs:78-103) on the GPU, then the reverse /
+ * `radix_sort_matches` post-step (src/sort.rs:6-40) on the host.  `*out` is malloc'd by the library
+ * (free with fzb_matches_free) and holds exactly the Vec<Match> the reference returns, in its order. */
+int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t* out_len);
+
+/* `Specialized::match_list(&mut self, haystacks, haystack_index_offset, &mut matches)`
+ * (src/matcher/algo.rs:17-22, backend.rs:95-107): appends, in input order, one Match per prefilter-passing
+ * haystack of the sub-range [first, first+count) with `index = index_offset + (i - first)`; no sorting.
+ * This is the seam `MatcherBackend::Hip` implements and what `match_list_parallel`'s per-shard workers call. */
+int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len);
+
+/* Device-resident form of the above for callers that keep results in HBM (benchmarks, multi-GPU gather):
+ * writes the index-ordered records to dev_out (capacity records) and the record count to dev_count
+ * (one uint32 in device memory), asynchronously on `stream`.  No host synchronisation. */
+int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset,
+                          fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);
+
+/* `Matcher::match_list_parallel(&haystacks, threads)` (src/matcher/parallel.rs:18-89).  The GPU processes the
+ * whole list in one pass, so `threads` only keeps the reference's contract: 0 => FZB_ERR_PANIC
+ * "threads must be positive"; the result equals fzb_match_list for every thread count (parallel.rs:104-130). */
+int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads, fzb_match** out, size_t* out_len);
+
+void fzb_matches_free(fzb_match* p);
+
+/* `radix_sort_matches(&mut [Match])` (src/sort.rs:6-40): stable, descending score, host side */
+void fzb_radix_sort_matches(fzb_match* matches, size_t n);
+/* `k_merge_matches_by_*` (src/k_merge.rs:56-132): merges per-shard runs (each sorted per `sort`) - the
+ * host-side combine after the multi-GPU gather.  runs = concatenated runs, run_lens[k] records each. */
+int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_lens, size_t nruns, fzb_match* out);
+
+/* Measurement hooks (bench.py): per-stage device time of the most recent fzb_match_list_device call on
+ * this matcher, measured with HIP events on the launch stream.  out_ms[0]=filter kernel, [1]=whole pipeline.
+ * Requires fzb_set_profiling(m, 1) beforehand (adds event records only). */
+int fzb_set_profiling(fzb_matcher* m, int enabled);
+int fzb_last_timings(fzb_matcher* m, float out_ms[4]);
+/* counters of the last call: out[0]=survivors of the filter stage, [1]=records emitted,
+ * [2]=survivors rejected by the lane-exact prefilter, [3]=haystacks scored by the generic (multi-chunk) kernel */
+int fzb_last_counters(fzb_matcher* m, uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRIZBEE_HIP_H */

@@ -1,0 +1,105 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/frizbee_hip.h declares,
+and the host logic (class selection, Smart casing/unicode, guards, needle tables, sort/merge helpers) agrees with the oracle.
+No compute entry point is exercised here (no GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import frizbee_amd as F
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "frizbee_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(fzb_[a-z0-9_]+)\s*\(", hdr)))
+    assert set(declared) == set(F.SYMBOLS), (declared, F.SYMBOLS)
+    l = F.lib()
+    for s in declared:
+        assert hasattr(l, s), s
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(F._CScoring) == 18 and C.sizeof(F._CConfig) == 4 * 4 + 18 + 4 + 2  # padded to 4-byte alignment
+    assert F.MATCH_DTYPE.itemsize == 8 and O.MATCH_DTYPE == F.MATCH_DTYPE
+    c = F._CConfig()
+    F.lib().fzb_config_default(C.byref(c))
+    assert (c.max_typos, c.casing, c.unicode, c.sort) == (0, 1, 1, 0)
+    assert [getattr(c.scoring, f[0]) for f in F._CScoring._fields_] == O.DEFAULT_SCORING
+
+
+@pytest.mark.parametrize("needle,cfg", [
+    ("deadbe", {}), ("fBr", {}), ("a" * 13, {}), ("a" * 14, {}), ("إنما", {}), ("é", dict(unicode="Ignore")), ("abc", dict(unicode="Always")),
+    ("FoO", dict(casing="Ignore")), ("foo", dict(casing="Respect")), ("Éa", {}), ("ßx", {}), ("x", dict(scoring=[12, 260, 5, 1, 12, 4, 4, 8, 4])),
+    ("BBBB", dict(scoring=[40, 0, 0, 0, 0, 40, 0, 0, 0])), ("abcd", dict(scoring=[12, 6, 5, 8, 12, 4, 4, 8, 4])),
+])
+def test_matcher_new_resolution_matches_oracle(needle, cfg):
+    kw = dict(cfg)
+    fc = F.Config(casing=F.CaseMatching[kw.pop("casing", "Smart")], unicode=F.UnicodeMatching[kw.pop("unicode", "Smart")],
+                  scoring=F.Scoring(*kw.pop("scoring", O.DEFAULT_SCORING)), pf_lanes=64, sw_lanes=0)
+    # explicit lanes: ask for the AVX-512 pair of the needle's class
+    u8 = O.score_fits_in_u8(len(needle.encode()), fc.scoring.as_list())
+    fc.sw_lanes = 64 if u8 else 32
+    info = F.Matcher(needle, fc).info()
+    want = O.Matcher(needle, lanes=(64, 64, 32), **cfg).info()
+    assert (info["pf_lanes"], info["sw_lanes"], info["use_u8"]) == (want["pf_lanes"], want["sw_lanes"], want["use_u8"])
+    casing = cfg.get("casing", "Smart")
+    assert info["case_sensitive"] == O.respects_case_for(casing, needle)
+    uni = cfg.get("unicode", "Smart")
+    assert info["unicode"] == (uni == "Always" or (uni == "Smart" and not needle.isascii()))
+    assert info["rows"] == (len(needle) if info["unicode"] else len(needle.encode()))
+
+
+def test_auto_lanes_follow_host_cpu():
+    flags = open("/proc/cpuinfo").read()
+    info8 = F.Matcher("deadbe").info()
+    info16 = F.Matcher("a" * 20).info()
+    has = lambda f: re.search(r"\b%s\b" % f, flags) is not None
+    if has("avx512f") and has("avx512bw") and has("bmi1") and has("bmi2"):
+        assert (info16["pf_lanes"], info16["sw_lanes"]) == (64, 32)
+        if has("avx512vbmi"):
+            assert (info8["pf_lanes"], info8["sw_lanes"]) == (64, 64)
+    elif has("avx2"):
+        assert (info8["pf_lanes"], info8["sw_lanes"], info16["sw_lanes"]) == (32, 32, 16)
+
+
+def test_guards_raise_with_reference_panic_text():
+    with pytest.raises(F.PanicError, match="needle too long and could overflow the u16 score"):
+        F.Matcher("f", F.Config(scoring=F.Scoring(capitalization_bonus=60000, matching_case_bonus=40000)))
+    with pytest.raises(F.FrizbeeError):
+        F.Matcher(b"\xff\xfe")  # not UTF-8 (a Rust &str cannot hold this)
+    with pytest.raises(F.FrizbeeError, match="not handled by the HIP backend"):
+        F.Matcher("a" * 65)
+    # unicode rows are counted in chars for the guard (src/matcher/algo.rs:383-393)
+    F.Matcher("一二三四五六七八", F.Config(scoring=F.Scoring(capitalization_bonus=4000)))
+
+
+def test_radix_sort_and_k_merge_match_oracle():
+    rng = np.random.default_rng(42)
+    n = 1 << 16
+    arr = np.zeros(n, F.MATCH_DTYPE)
+    arr["index"] = np.arange(n)
+    arr["score"] = rng.integers(0, 1 << 16, n)
+    assert F.radix_sort_matches(arr).tolist() == O.radix_sort(arr).tolist()
+    for order in ("ScoreThenIndexAsc", "ScoreThenIndexDesc", "IndexAsc", "IndexDesc"):
+        runs = []
+        for k in range(5):
+            a = np.zeros(1000 + k, F.MATCH_DTYPE)
+            a["index"] = rng.choice(1 << 20, len(a), replace=False) * 5 + k
+            a["score"] = rng.integers(0, 300, len(a))
+            key = {"ScoreThenIndexAsc": (a["index"], -a["score"].astype(np.int64)), "ScoreThenIndexDesc": (-a["index"].astype(np.int64), -a["score"].astype(np.int64)),
+                   "IndexAsc": (a["index"],), "IndexDesc": (-a["index"].astype(np.int64),)}[order]
+            runs.append(a[np.lexsort(key)])
+        assert F.k_merge_matches(F.SortStrategy[order], runs).tolist() == O.k_merge(order, runs).tolist(), order
+
+
+def test_scoring_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(F.FrizbeeError):
+        F.Matcher("abc").match_list(["abc"])
