@@ -14,7 +14,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfrizbee_hip.so")
+_LIB_PATH = os.environ.get("FRIZBEE_HIP_LIB", os.path.join(_HERE, "libfrizbee_hip.so"))
 
 MATCH_DTYPE = np.dtype([("index", "<u4"), ("score", "<u2"), ("exact", "u1"), ("_pad", "u1")])
 

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -449,6 +450,15 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
         return FZB_OK;
     }
     const int cus = lc.num_cus;
+    static const bool dbg = getenv("FZB_DEBUG_SYNC") != nullptr;  // debugging aid: synchronise and report after every stage
+#define FZB_STAGE(name)                                                                  \
+    do {                                                                                 \
+        if (dbg) {                                                                       \
+            hipError_t e_ = hipStreamSynchronize(st);                                    \
+            fprintf(stderr, "[fzb] stage %s: %s\n", name, hipGetErrorString(e_));        \
+            if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
+        }                                                                                \
+    } while (0)
     if (m->profiling) HIPCHK(hipEventRecord(m->ev[0], st));
     const u32* items = nullptr;
     const u32* win = nullptr;
@@ -462,14 +472,20 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         fzb_launch_filter(cd, first, cnt, w.table, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 8, st);
         if (m->profiling) HIPCHK(hipEventRecord(m->ev[1], st));
+        FZB_STAGE("filter");
         fzb_launch_scan(w.tile_counts, w.tile_prefix, nullptr, cnt, &w.counters[0], st);
+        FZB_STAGE("scan1");
         fzb_launch_map(1, w.bitmap, w.tile_prefix, nullptr, cnt, w.surv_idx, nullptr, nullptr, nullptr, cus * 4, st);
+        FZB_STAGE("map1");
         items = w.surv_idx;
     }
     if (!lc.filter_exact) {
         fzb_launch_window(cd, first, items, &w.counters[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, w.counters, cus * 4, st);
+        FZB_STAGE("window");
         fzb_launch_scan(w.tile_counts2, w.tile_prefix2, &w.counters[0], 0, &w.counters[1], st);
+        FZB_STAGE("scan2");
         fzb_launch_map(2, w.bitmap2, w.tile_prefix2, &w.counters[0], 0, w.items2, items, w.win, w.win2, cus * 4, st);
+        FZB_STAGE("map2");
         items = w.items2;
         win = w.win2;
         n_items_ptr = &w.counters[1];
@@ -478,10 +494,13 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     fzb_match_rec* outp = (fzb_match_rec*)dev_out;
     if (nd.unicode) {
         fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, w.counters, cus * 4, st);
+        FZB_STAGE("generic(unicode)");
     } else {
         fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, outp, cap32, dev_count, w.overflow, w.counters, cus * 8, st);
+        FZB_STAGE("dp");
         // windows wider than one chunk were queued (item, start, end) in w.overflow by the DP kernel
         fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &w.counters[3], nd, lc.sw_lanes, 0, outp, cap32, dev_count, w.counters, cus * 2, st);
+        FZB_STAGE("generic(overflow)");
     }
     if (m->profiling) HIPCHK(hipEventRecord(m->ev[2], st));
     HIPCHK(hipGetLastError());

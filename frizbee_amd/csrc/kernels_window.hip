@@ -394,12 +394,16 @@ __device__ Win prefilter_unicode_0(UnicodeSrc<PFL>& src) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2a kernel
+// K2a kernel.  One instantiation per (chunk width, algorithm) keeps each kernel small: the all-in-one
+// version (7 algorithms inlined, 134 SGPR spills) was miscompiled by hipcc -O3 (ROCm 7.2) into an endless
+// loop for PFL=64 / unicode / 2 typos while -O1 and the same source built for the host ran correctly.
 // ------------------------------------------------------------------------------------------------
-template <int PFL, typename ET>
-__global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ surv_idx,
-                                                  const u32* __restrict__ n_surv_ptr, const NeedleDev nd, u32* __restrict__ win,
-                                                  u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32* __restrict__ counters) {
+enum { ALG_ASCII_1 = 0, ALG_ASCII_2 = 1, ALG_ASCII_N = 2, ALG_UNI_0 = 3, ALG_UNI_1 = 4, ALG_UNI_2 = 5, ALG_UNI_N = 6 };
+
+template <int PFL, int ALG>
+__global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
+                                                  const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
+                                                  u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2) {
     __shared__ u32 s_cnt;
     const u32 M = *n_surv_ptr;
     const u32 ntiles = (M + FZB_TILE - 1) / FZB_TILE;
@@ -413,24 +417,24 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
             const u32 j = tile * FZB_TILE + p * 256 + tid;
             bool keep = false;
             if (j < M) {
-                const u32 li = surv_idx[j];
+                const u32 li = surv_idx ? surv_idx[j] : j;
                 u64 s;
                 u32 L;
-                haystack_span(ends, first + li, s, L);
+                if (ends_u64) haystack_span((const u64*)ends_v, first + li, s, L);
+                else haystack_span((const u32*)ends_v, first + li, s, L);
                 const u8* hay = bytes + s;
                 Win w;
-                const u32 k = (u32)nd.max_typos;
-                if (nd.unicode) {
+                if (ALG >= ALG_UNI_0) {
                     UnicodeSrc<PFL> src(nd, hay, L);
-                    if (k == 0) w = prefilter_unicode_0<PFL>(src);
-                    else if (k == 1) w = prefilter_1_typo<PFL>(src);
-                    else if (k == 2) w = prefilter_2_typos<PFL>(src);
-                    else w = prefilter_many_typos<PFL>(src, k);
+                    if (ALG == ALG_UNI_0) w = prefilter_unicode_0<PFL>(src);
+                    else if (ALG == ALG_UNI_1) w = prefilter_1_typo<PFL>(src);
+                    else if (ALG == ALG_UNI_2) w = prefilter_2_typos<PFL>(src);
+                    else w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos);
                 } else {
                     AsciiSrc<PFL> src(nd, hay, L);
-                    if (k == 1) w = prefilter_1_typo<PFL>(src);
-                    else if (k == 2) w = prefilter_2_typos<PFL>(src);
-                    else w = prefilter_many_typos<PFL>(src, k);
+                    if (ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
+                    else if (ALG == ALG_ASCII_2) w = prefilter_2_typos<PFL>(src);
+                    else w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos);
                 }
                 keep = w.matched;
                 win[2 * j] = keep ? w.start : 0xFFFFFFFFu;
@@ -449,13 +453,27 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
     }
 }
 
-void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
-                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2A(PFL, ET) hipLaunchKernelGGL((k2a_window<PFL, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, counters)
-    if (c.ends_u64) {
-        if (pf_lanes == 64) FZB_K2A(64, u64); else if (pf_lanes == 32) FZB_K2A(32, u64); else FZB_K2A(16, u64);
-    } else {
-        if (pf_lanes == 64) FZB_K2A(64, u32); else if (pf_lanes == 32) FZB_K2A(32, u32); else FZB_K2A(16, u32);
+template <int PFL>
+static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, u32* win, u64* bitmap2,
+                              u32* tile_counts2, int grid, hipStream_t st) {
+    const int k = nd.max_typos;
+    const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
+#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), 0, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2)
+    switch (alg) {
+        case ALG_ASCII_1: FZB_K2A(ALG_ASCII_1); break;
+        case ALG_ASCII_2: FZB_K2A(ALG_ASCII_2); break;
+        case ALG_ASCII_N: FZB_K2A(ALG_ASCII_N); break;
+        case ALG_UNI_0: FZB_K2A(ALG_UNI_0); break;
+        case ALG_UNI_1: FZB_K2A(ALG_UNI_1); break;
+        case ALG_UNI_2: FZB_K2A(ALG_UNI_2); break;
+        default: FZB_K2A(ALG_UNI_N); break;
     }
 #undef FZB_K2A
+}
+
+void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
+                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st) {
+    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st);
+    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st);
+    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st);
 }

@@ -116,7 +116,7 @@ def test_random_long_needles_u16_class(pf):
     rng = np.random.default_rng(4242 + pf)
     for it in range(8):
         needle, hs = rand_case(rng, nmax=40, hmax=300, nh=200)
-        needle = (needle * 3)[: int(rng.integers(14, 41))]
+        needle = (needle * 41)[: int(rng.integers(14, 41))]
         for k in (0, 2, None):
             got, want, fm = both(needle, hs, pf=pf, max_typos=k)
             assert not fm.info()["use_u8"]
