@@ -163,7 +163,10 @@ struct fzb_matcher {
     Workspace ws{};
     int device = -1;
     bool profiling = false;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    static constexpr int PROF_SLOTS = 64;  // ring of per-call event triples: pipeline start, filter end, pipeline end
+    hipEvent_t evring[PROF_SLOTS][3] = {};
+    hipEvent_t* ev = evring[0];
+    u64 prof_calls = 0;
     u32 last_counters[4] = {0, 0, 0, 0};
     // staging for the synchronous API
     fzb_match_rec* out_dev = nullptr;
@@ -300,8 +303,9 @@ void fzb_matcher_free(fzb_matcher* m) {
     free_workspace(m->ws);
     if (m->out_dev) (void)hipFree(m->out_dev);
     if (m->count_dev) (void)hipFree(m->count_dev);
-    for (auto& e : m->ev)
-        if (e) (void)hipEventDestroy(e);
+    for (auto& tr : m->evring)
+        for (auto& e : tr)
+            if (e) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -442,8 +446,12 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     const CorpusDev& cd = c->dev;
     const u32 cnt = (u32)count;
     const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
-    if (m->profiling && !m->ev[0])
-        for (auto& e : m->ev) HIPCHK(hipEventCreate(&e));
+    if (m->profiling) {
+        m->ev = m->evring[m->prof_calls % fzb_matcher::PROF_SLOTS];
+        m->prof_calls++;
+        if (!m->ev[0])
+            for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&m->ev[i]));
+    }
     HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
     if (count == 0) {
         HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
@@ -611,16 +619,32 @@ int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_l
 int fzb_set_profiling(fzb_matcher* m, int enabled) {
     if (!m) return fail(FZB_ERR_INVALID, "null argument");
     m->profiling = enabled != 0;
+    m->prof_calls = 0;
     return FZB_OK;
 }
 
+// Averages over the calls made since fzb_set_profiling(m, 1) (at most the last 64):
+// out_ms[0] = filter kernel, [1] = whole pipeline, [2] = number of calls averaged, [3] = last call's pipeline time
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
     if (!m || !out_ms) return fail(FZB_ERR_INVALID, "null argument");
-    if (!m->profiling || !m->ev[0]) return fail(FZB_ERR_INVALID, "profiling not enabled");
-    HIPCHK(hipEventSynchronize(m->ev[2]));
-    HIPCHK(hipEventElapsedTime(&out_ms[0], m->ev[0], m->ev[1]));
-    HIPCHK(hipEventElapsedTime(&out_ms[1], m->ev[0], m->ev[2]));
-    out_ms[2] = out_ms[3] = 0;
+    if (!m->profiling || m->prof_calls == 0) return fail(FZB_ERR_INVALID, "profiling not enabled or no call recorded");
+    const u64 n = std::min<u64>(m->prof_calls, fzb_matcher::PROF_SLOTS);
+    double f = 0, t = 0;
+    float last = 0;
+    for (u64 i = 0; i < n; i++) {
+        hipEvent_t* e = m->evring[(m->prof_calls - 1 - i) % fzb_matcher::PROF_SLOTS];
+        HIPCHK(hipEventSynchronize(e[2]));
+        float a = 0, b = 0;
+        HIPCHK(hipEventElapsedTime(&a, e[0], e[1]));
+        HIPCHK(hipEventElapsedTime(&b, e[0], e[2]));
+        f += a;
+        t += b;
+        if (i == 0) last = b;
+    }
+    out_ms[0] = (float)(f / n);
+    out_ms[1] = (float)(t / n);
+    out_ms[2] = (float)n;
+    out_ms[3] = last;
     return FZB_OK;
 }
 

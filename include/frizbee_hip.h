@@ -127,9 +127,10 @@ void fzb_radix_sort_matches(fzb_match* matches, size_t n);
  * host-side combine after the multi-GPU gather.  runs = concatenated runs, run_lens[k] records each. */
 int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_lens, size_t nruns, fzb_match* out);
 
-/* Measurement hooks (bench.py): per-stage device time of the most recent fzb_match_list_device call on
- * this matcher, measured with HIP events on the launch stream.  out_ms[0]=filter kernel, [1]=whole pipeline.
- * Requires fzb_set_profiling(m, 1) beforehand (adds event records only). */
+/* Measurement hooks (bench.py): device time of the fzb_match_list_device calls made on this matcher since
+ * fzb_set_profiling(m, 1), measured with HIP events recorded on the launch stream (event records only, no
+ * synchronisation until read).  fzb_last_timings averages over those calls (at most the last 64):
+ * out_ms[0]=filter kernel, [1]=whole pipeline, [2]=calls averaged, [3]=last call's pipeline time. */
 int fzb_set_profiling(fzb_matcher* m, int enabled);
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]);
 /* counters of the last call: out[0]=survivors of the filter stage, [1]=records emitted,

@@ -1,0 +1,76 @@
+"""world_size-2 gloo test of the multi-GPU composition (shard ranges, all-gather-v of per-shard match lists,
+host merge).  No GPU: each rank's shard is scored by the CPU oracle (the checker standing in for the GPU stage),
+and the gathered + merged result must equal the single-list `match_list` for every sort strategy."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle_lib as O
+    import synth
+    from frizbee_amd import SortStrategy
+    from frizbee_amd.distributed import all_gather_matches, merge_shard_runs, shard_range
+
+    n = 30_001
+    rows, ends = synth.fixed_corpus(b"deadbe", n, 32)
+    data = np.concatenate([rows.numpy().reshape(-1), np.zeros(64, np.uint8)])
+    ok = True
+    for sort in ("ScoreThenIndexAsc", "ScoreThenIndexDesc", "IndexAsc", "IndexDesc"):
+        for k in (0, 2):
+            lo, hi = shard_range(n, rank, world)
+            # shard scored with a global index offset: IndexAsc + offset == `match_list_into(chunk, start as u32)`
+            m = O.Matcher("deadbe", max_typos=k, sort="IndexAsc")
+            local = m.match_packed(data[lo * 32 :], ends[lo:hi] - np.uint64(lo * 32))
+            local["index"] += lo
+            rec = torch.from_numpy(local.view(np.uint8).copy()) if len(local) else torch.zeros(8, dtype=torch.uint8)
+            runs = all_gather_matches(rec, len(local))
+            merged = merge_shard_runs(runs, SortStrategy[sort])
+            want = O.Matcher("deadbe", max_typos=k, sort=sort).match_packed(data, ends)
+            ok = ok and merged.tolist() == want.tolist()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_gather_merge_equals_single_list():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_shard_ranges_partition_the_list():
+    from frizbee_amd.distributed import shard_range
+    for n in (0, 1, 7, 8, 9, 100_000_000):
+        for w in (1, 2, 4, 8):
+            r = [shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
