@@ -244,7 +244,7 @@ class Matcher:
     def last_timings_ms(self):
         out = (C.c_float * 4)()
         _check(lib().fzb_last_timings(self.h, out))
-        return dict(filter=out[0], total=out[1], calls=int(out[2]), last_total=out[3])
+        return dict(filter=out[0], total=out[1], calls=int(out[2]), filter_launches=int(out[3]))
 
     def last_counters(self):
         out = (C.c_uint32 * 4)()

@@ -1,0 +1,212 @@
+// Thread-per-haystack single-chunk Smith-Waterman body shared by the standalone DP kernel (kernels_dp.hip) and the
+// fused filter+score kernel (kernels_fused.hip).  See kernels_dp.hip for the reference mapping and DESIGN.md for the
+// biased-domain gap propagation.
+#pragma once
+#include "kernels_common.h"
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2 as_us2(u32 x) { return __builtin_bit_cast(us2, x); }
+__device__ __forceinline__ u32 as_u32(us2 x) { return __builtin_bit_cast(u32, x); }
+__device__ __forceinline__ u32 p_add(u32 a, u32 b) { return as_u32(as_us2(a) + as_us2(b)); }
+__device__ __forceinline__ u32 p_sub(u32 a, u32 b) { return as_u32(as_us2(a) - as_us2(b)); }
+__device__ __forceinline__ u32 p_subs(u32 a, u32 b) { return as_u32(__builtin_elementwise_sub_sat(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ u32 p_max(u32 a, u32 b) { return as_u32(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ u32 p_mul(u32 a, u32 b) { return as_u32(as_us2(a) * as_us2(b)); }
+__device__ __forceinline__ u32 splat16(u32 v) { return (v & 0xFFFF) * 0x00010001u; }
+
+__device__ __forceinline__ u32 zero_bytes4_dp(u32 x) {
+    u32 y = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+    y = ~y & 0x80808080u;
+    return ((y >> 7) * 0x00204081u >> 21) & 0xF;
+}
+
+// byte class table (ascii.rs:65-89): bit0 lower, bit1 upper, bit2 delimiter
+__device__ __forceinline__ void build_cls_table(u8* cls) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) {
+        const bool lower = b >= 'a' && b <= 'z', upper = b >= 'A' && b <= 'Z', digit = b >= '0' && b <= '9';
+        const bool delim = !(lower || upper || digit || b > 127);
+        cls[b] = (u8)((lower ? 1 : 0) | (upper ? 2 : 0) | (delim ? 4 : 0));
+    }
+}
+
+// 0-typo ASCII window: first occurrence of needle[0] (either case), 1 + last occurrence of needle[rows-1]
+// (what src/prefilter/algo/ascii.rs:6-72 returns; lane-width independent)
+__device__ __forceinline__ void window_first_last(const NeedleDev& nd, const u8* __restrict__ hay, u32 L, u32& ws, u32& we) {
+    const u32 rows = (u32)nd.rows;
+    const u32 a0 = nd.c[0] * 0x01010101u, a1 = nd.f[0] * 0x01010101u;
+    const u32 z0 = nd.c[rows - 1] * 0x01010101u, z1 = nd.f[rows - 1] * 0x01010101u;
+    ws = 0xFFFFFFFFu;
+    we = 0;
+    const uint4* vp = (const uint4*)hay;
+    const u32 nvec = (L + 15) >> 4;
+    for (u32 v = 0; v < nvec; v++) {
+        const uint4 q = vp[v];
+        const u32 w4[4] = {q.x, q.y, q.z, q.w};
+        u32 mf = 0, ml = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            mf |= (zero_bytes4_dp(w4[k] ^ a0) | zero_bytes4_dp(w4[k] ^ a1)) << (4 * k);
+            ml |= (zero_bytes4_dp(w4[k] ^ z0) | zero_bytes4_dp(w4[k] ^ z1)) << (4 * k);
+        }
+        const u32 rem = L - 16 * v;
+        const u32 vm = rem >= 16 ? 0xFFFFu : ((1u << rem) - 1);
+        mf &= vm;
+        ml &= vm;
+        if (ws == 0xFFFFFFFFu && mf) ws = 16 * v + __builtin_ctz(mf);
+        if (ml) we = 16 * v + 32 - __builtin_clz(ml);
+    }
+    if (ws == 0xFFFFFFFFu) ws = 0;  // cannot happen for a survivor of the exact filter
+}
+
+// Scores the trimmed window th[0..m) (1 <= m <= SWL) as ONE chunk of SWL lanes.  hb receives the window bytes
+// (zero padded) for the caller's exact-match compare.  Returns S = max over all lanes of the last row.
+//
+// REAL = number of packed dwords (2 lanes each) that may hold haystack bytes: the caller guarantees m <= 2 * REAL.
+// Dwords >= REAL are zero padding, which the reference scores like any other lane (they enter the final max) but where,
+// for a needle without NUL bytes, nothing can match: match mask = 0, so the bonus / case / gap-open terms vanish and
+// the same recurrences reduce to `diag = S(i-1,j-1) (-) X`, `up = S(i-1,j) (-) gex`, and a gap step whose source lies in
+// the padding is a plain max.  REAL = NW is the fully general form.
+template <int SWL, bool BIAS, int REAL = SWL / 2>
+__device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls, u32 (&hb)[SWL / 4]) {
+    constexpr int NW = SWL / 2;  // packed score dwords
+    constexpr int NB = SWL / 4;  // haystack byte dwords
+    static_assert(REAL >= 1 && REAL <= NW, "REAL");
+    const u32 rows = (u32)nd.rows;
+    const u32 ONE = 0x00010001u;
+    const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
+    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const u32 p = 4 * k;
+        u32 v = 0;
+        if (p < m) {
+            v = load_u32_unaligned(th, p);
+            const u32 rem = m - p;
+            if (rem < 4) v &= (1u << (8 * rem)) - 1;
+        }
+        hb[k] = v;
+    }
+    // ---- haystack-side vectors (ascii.rs:59-101) ----------------------------------------------------
+    u32 hw[REAL], bonus[REAL];
+    {
+        u32 clsw_prev = 0;
+#pragma unroll
+        for (int d = 0; d < REAL; d++) {
+            const u32 w = hb[d / 2];
+            const u32 b0 = (d & 1) ? (w >> 16) & 0xFF : w & 0xFF;
+            const u32 b1 = (d & 1) ? w >> 24 : (w >> 8) & 0xFF;
+            hw[d] = b0 | (b1 << 16);
+            const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
+            const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);  // class of lane-1 (lane -1 of chunk 0: none)
+            const u32 cap01 = (clsw >> 1) & sh & ONE;                        // upper(j) & lower(j-1)
+            const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;                 // delim(j-1) & !delim(j)
+            bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+            clsw_prev = clsw;
+        }
+        if (include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);  // first_lane(prefix_bonus)
+    }
+    u32 prev[NW], gprev[REAL];
+#pragma unroll
+    for (int d = 0; d < NW; d++) prev[d] = 0;
+#pragma unroll
+    for (int d = 0; d < REAL; d++) gprev[d] = 0;
+#pragma unroll 1
+    for (u32 r = 0; r < rows; r++) {
+        const u32 c = nd.c[r], f = nd.f[r];
+        const bool ci = c != f;  // case-insensitive ASCII letter: (h | 0x20) == (c | 0x20) <=> h in {c, flip(c)}
+        const u32 orv = ci ? 0x00200020u : 0u;
+        const u32 cmpv = splat16(ci ? (c | 0x20) : c);
+        const u32 cv = splat16(c);
+        u32 row[NW], g[REAL];
+#pragma unroll
+        for (int d = 0; d < NW; d++) {
+            const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : 0u, 16);  // S(i-1, j-1)
+            if (d < REAL) {
+                const u32 mm = p_subs(ONE, (hw[d] | orv) ^ cmpv);      // match mask as 0/1 per lane
+                const u32 ex = ci ? p_subs(ONE, hw[d] ^ cv) : mm;      // exact-case match
+                u32 t = p_add(p_mul(mm, bonus[d]), sh);
+                t = p_subs(t, Xv);
+                const u32 diag = p_add(p_mul(ex, casev), t);
+                const u32 up = p_subs(p_subs(prev[d], gexv), gprev[d]);
+                row[d] = p_max(diag, up);
+                g[d] = p_mul(mm, gopmv);
+            } else {
+                row[d] = p_max(p_subs(sh, Xv), p_subs(prev[d], gexv));  // padding lanes: no match, no gap-open surcharge
+            }
+        }
+        // ---- propagate_horizontal_gaps: steps 1, 2, 4, ..., SWL/2 (ascii_gap.rs:11-105) ---------------
+        if (BIAS) {
+            u32 b[NW];
+#pragma unroll
+            for (int d = 0; d < NW; d++) b[d] = p_add(row[d], (u32)nd.gex * (u32)(2 * d + ((2 * d + 1) << 16)));
+            {
+                u32 nb[NW];
+#pragma unroll
+                for (int d = 0; d < NW; d++) {
+                    const u32 sb = __builtin_amdgcn_alignbit(b[d], d ? b[d - 1] : 0u, 16);
+                    if (d <= REAL) {  // source lanes 2d-1, 2d: at least one may be a real lane
+                        const u32 sg = __builtin_amdgcn_alignbit(d < REAL ? g[d] : 0u, (d && d - 1 < REAL) ? g[d - 1] : 0u, 16);
+                        nb[d] = p_max(b[d], p_subs(sb, sg));
+                    } else {
+                        nb[d] = p_max(b[d], sb);
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < NW; d++) b[d] = nb[d];
+            }
+#pragma unroll
+            for (int off = 1; off < NW; off *= 2) {
+                u32 nb[NW];
+#pragma unroll
+                for (int d = 0; d < NW; d++) nb[d] = d >= off ? ((d - off) < REAL ? p_max(b[d], p_subs(b[d - off], g[d - off])) : p_max(b[d], b[d - off])) : b[d];
+#pragma unroll
+                for (int d = 0; d < NW; d++) b[d] = nb[d];
+            }
+#pragma unroll
+            for (int d = 0; d < NW; d++) row[d] = p_sub(b[d], (u32)nd.gex * (u32)(2 * d + ((2 * d + 1) << 16)));
+        } else {
+            u32 kg = gexv;
+            {
+                u32 nb[NW];
+#pragma unroll
+                for (int d = 0; d < NW; d++) {
+                    const u32 sb = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : 0u, 16);
+                    const u32 sg = __builtin_amdgcn_alignbit(d < REAL ? g[d] : 0u, (d && d - 1 < REAL) ? g[d - 1] : 0u, 16);
+                    nb[d] = p_max(row[d], p_subs(sb, p_add(kg, sg)));
+                }
+#pragma unroll
+                for (int d = 0; d < NW; d++) row[d] = nb[d];
+            }
+#pragma unroll
+            for (int off = 1; off < NW; off *= 2) {
+                kg = p_add(kg, kg);
+                u32 nb[NW];
+#pragma unroll
+                for (int d = 0; d < NW; d++) nb[d] = d >= off ? p_max(row[d], p_subs(row[d - off], p_add(kg, (d - off) < REAL ? g[d - off] : 0u))) : row[d];
+#pragma unroll
+                for (int d = 0; d < NW; d++) row[d] = nb[d];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < NW; d++) prev[d] = row[d];
+#pragma unroll
+        for (int d = 0; d < REAL; d++) gprev[d] = g[d];
+    }
+    // ---- max over every lane of the last row (ascii.rs:152-156) -------------------------------------
+    u32 mx = prev[0];
+#pragma unroll
+    for (int d = 1; d < NW; d++) mx = p_max(mx, prev[d]);
+    return max(mx & 0xFFFF, mx >> 16);
+}
+
+// exact flag (matcher/algo.rs:245-248): window spans the whole haystack and equals the needle byte for byte
+template <int NB>
+__device__ __forceinline__ bool exact_match(const NeedleDev& nd, bool include_exact, u32 m, const u32 (&hb)[NB]) {
+    bool exact = include_exact && m == (u32)nd.nbytes;
+    if (exact) {
+        const u32* raw = (const u32*)nd.raw;
+#pragma unroll
+        for (int k = 0; k < NB && k < FZB_MAX_NEEDLE_BYTES / 4; k++) exact = exact && (hb[k] == raw[k]);
+    }
+    return exact;
+}

@@ -65,14 +65,15 @@ struct Workspace {
     u32* tile_prefix;   // ntiles + 1
     u32* surv_idx;      // local haystack index of survivor j
     u32* win;           // 2 * survivors: (start, end) windows from the lane-exact prefilter; start=0xFFFFFFFF => rejected
-    u32* overflow;      // survivor ids needing the generic scorer
+    u32* overflow;      // (output position, window start, window end, haystack) of items needing the generic scorer
     u64* bitmap2;       // second-level keep bits (after the lane-exact prefilter)
     u32* tile_counts2;
     u32* tile_prefix2;
     u32* items2;        // local haystack index of kept survivor
     u32* win2;          // its window
-    u32* counters;      // [0]=filter survivors [1]=kept by the lane-exact prefilter [3]=sent to the generic scorer
+    u32* counters;      // [0]=filter survivors [1]=kept by the lane-exact prefilter [2]=output base of the NEXT chunk [3]=sent to the generic scorer
     u64* table;         // 256 x u64 filter table (device)
+    u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
     size_t cap_level2;  // capacity of the second-level arrays (0 = not allocated)
 };
@@ -83,15 +84,16 @@ struct LaunchCfg {
     int filter_exact;   // 1 if the filter decision is exactly the reference's accept decision
     int window_mode;    // 0 = from the lane-exact prefilter kernel, 1 = inline first/last occurrence (ASCII 0 typos), 2 = full haystack
     int bias_ok;        // DP gap propagation may run in the biased domain (no u16 overflow possible)
+    int pad_ok;         // needle has no NUL byte: zero-padding lanes can never match (enables the padded-half DP form)
     int num_cus;
 };
 
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 // kernels_filter.hip
-void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, int rows, int mode, int need, u32 min_len,
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
-void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, hipStream_t st);
+void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, const u32* base_in, u32* base_out, hipStream_t st);
 void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,
                     const u32* in_idx, const u32* in_win, u32* out_win, int grid, hipStream_t st);
 // kernels_window.hip
@@ -99,8 +101,8 @@ void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const
                        u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st);
 // kernels_dp.hip
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int bias_ok, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32* counters, int grid, hipStream_t st);
+                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32* counters, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
-                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st);
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st);
 #endif

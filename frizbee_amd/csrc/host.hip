@@ -160,13 +160,18 @@ struct fzb_matcher {
     NeedleDev nd{};
     LaunchCfg lc{};
     std::vector<u64> table;  // host copy of the filter table
+    std::vector<u8> dfa;     // host copy of the subsequence DFA
     Workspace ws{};
     int device = -1;
     bool profiling = false;
-    static constexpr int PROF_SLOTS = 64;  // ring of per-call event triples: pipeline start, filter end, pipeline end
-    hipEvent_t evring[PROF_SLOTS][3] = {};
-    hipEvent_t* ev = evring[0];
+    static constexpr int MAX_CHUNKS = 8;
+    static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2+2c],[3+2c]=filter kernel of chunk c
+    hipEvent_t evring[PROF_SLOTS][2 + 2 * MAX_CHUNKS] = {};
+    int ev_chunks[PROF_SLOTS] = {};
     u64 prof_calls = 0;
+    // chunk pipelining: two internal streams forked from / joined to the caller's stream
+    hipStream_t streams[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_chain[MAX_CHUNKS] = {};
     u32 last_counters[4] = {0, 0, 0, 0};
     // staging for the synchronous API
     fzb_match_rec* out_dev = nullptr;
@@ -189,7 +194,7 @@ void fzb_config_default(fzb_config* out) {
 }
 
 static void free_workspace(Workspace& w) {
-    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table};
+    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table, w.dfa};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -284,6 +289,13 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
             m->table[nd.f[r]] |= (u64)1 << r;
         }
     }
+    // ordered-subsequence DFA: state s = rows matched so far; a byte that can match row s advances it
+    m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
+    for (int st = 0; st <= m->rows; st++)
+        for (int b = 0; b < 256; b++) m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && ((m->table[b] >> st) & 1)) ? st + 1 : st);
+    lc.pad_ok = 1;
+    for (size_t i = 0; i < needle_len; i++)
+        if (needle_utf8[i] == 0) lc.pad_ok = 0;
     // biased gap propagation needs max cell value + lanes*gex (+ headroom) to stay below 2^16
     lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
     *out = m;
@@ -306,6 +318,13 @@ void fzb_matcher_free(fzb_matcher* m) {
     for (auto& tr : m->evring)
         for (auto& e : tr)
             if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->ev_chain)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->ev_join)
+        if (e) (void)hipEventDestroy(e);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    for (auto& st : m->streams)
+        if (st) (void)hipStreamDestroy(st);
     delete m;
 }
 
@@ -399,15 +418,17 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     (void)st;
     free_workspace(w);
     const size_t cap = count + count / 8 + 4096;
-    const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 1;
+    const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 2 * fzb_matcher::MAX_CHUNKS + 2;
     HIPCHK(dev_alloc((void**)&w.bitmap, (cap / 64 + 17) * 8));
     HIPCHK(dev_alloc((void**)&w.tile_counts, ntiles * 4));
     HIPCHK(dev_alloc((void**)&w.tile_prefix, (ntiles + 1) * 4));
     HIPCHK(dev_alloc((void**)&w.surv_idx, cap * 4));
-    HIPCHK(dev_alloc((void**)&w.overflow, cap * 12));
-    HIPCHK(dev_alloc((void**)&w.counters, 64));
+    HIPCHK(dev_alloc((void**)&w.overflow, cap * 16));
+    HIPCHK(dev_alloc((void**)&w.counters, 64 * (fzb_matcher::MAX_CHUNKS + 1)));
     HIPCHK(dev_alloc((void**)&w.table, 256 * 8));
     HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
+    HIPCHK(dev_alloc((void**)&w.dfa, m->dfa.size() + 16));
+    if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
     w.cap_items = cap;
     if (need_l2) {
         HIPCHK(dev_alloc((void**)&w.win, cap * 8));
@@ -421,6 +442,90 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     return FZB_OK;
 }
 
+// One chunk [cfirst, cfirst + ccnt) of the range, issued on `st`.  `off` = chunk start relative to the range start
+// (a multiple of FZB_TILE) selects this chunk's slices of the workspace; cn = chunk number.
+static int run_chunk(fzb_matcher* m, const CorpusDev& cd, int cn, int nchunks, u64 cfirst, u32 ccnt, size_t off, u32 index_offset, fzb_match_rec* outp, u32 cap32,
+                     u32* dev_count, hipStream_t st, hipEvent_t* pev) {
+    Workspace& w = m->ws;
+    const LaunchCfg& lc = m->lc;
+    const NeedleDev& nd = m->nd;
+    const int cus = lc.num_cus;
+    static const bool dbg = getenv("FZB_DEBUG_SYNC") != nullptr;  // debugging aid: synchronise and report after every stage
+#define FZB_STAGE(name)                                                                                        \
+    do {                                                                                                       \
+        if (dbg) {                                                                                             \
+            hipError_t e_ = hipStreamSynchronize(st);                                                          \
+            fprintf(stderr, "[fzb] chunk %d stage %s: %s\n", cn, name, hipGetErrorString(e_));                 \
+            if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
+        }                                                                                                      \
+    } while (0)
+    u32* cnt_c = w.counters + 16 * cn;  // [0]=filter survivors [1]=kept by the lane-exact prefilter [2]=output base of the next chunk [3]=generic-scorer queue length
+    const u32* base_in = cn ? w.counters + 16 * (cn - 1) + 2 : nullptr;
+    u64* bitmap = w.bitmap + off / 64;
+    u32* tile_counts = w.tile_counts + off / FZB_TILE + cn;
+    u32* tile_prefix = w.tile_prefix + off / FZB_TILE + 2 * cn;
+    u32* surv_idx = w.surv_idx + off;
+    u32* overflow = w.overflow + 4 * off;
+    const bool last = cn == nchunks - 1;
+    const u32* items = nullptr;
+    const u32* win = nullptr;
+    const u32* n_items_ptr = &cnt_c[0];
+    int wmode = lc.window_mode;
+    if (lc.filter_mode == 0) {
+        // nothing filtered: the identity list; counts and bases are known on the host and were pre-set by the caller
+    } else {
+        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
+        if (pev) HIPCHK(hipEventRecord(pev[2 + 2 * cn], st));
+        fzb_launch_filter(cd, cfirst, ccnt, w.table, w.dfa, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, bitmap, tile_counts, cus * 8, st);
+        if (pev) HIPCHK(hipEventRecord(pev[3 + 2 * cn], st));
+        FZB_STAGE("filter");
+        if (lc.filter_exact) {  // this scan also chains the output base across chunks: it must follow the previous chunk's
+            if (cn) HIPCHK(hipStreamWaitEvent(st, m->ev_chain[cn - 1], 0));
+            fzb_launch_scan(tile_counts, tile_prefix, nullptr, ccnt, &cnt_c[0], base_in, &cnt_c[2], st);
+            HIPCHK(hipEventRecord(m->ev_chain[cn], st));
+        } else {
+            fzb_launch_scan(tile_counts, tile_prefix, nullptr, ccnt, &cnt_c[0], nullptr, nullptr, st);
+        }
+        FZB_STAGE("scan1");
+        fzb_launch_map(1, bitmap, tile_prefix, nullptr, ccnt, surv_idx, nullptr, nullptr, nullptr, cus * 2, st);
+        FZB_STAGE("map1");
+        items = surv_idx;
+    }
+    if (!lc.filter_exact) {
+        u32* winb = w.win + 2 * off;
+        u64* bitmap2 = w.bitmap2 + off / 64 + cn;
+        u32* tile_counts2 = w.tile_counts2 + off / FZB_TILE + cn;
+        u32* tile_prefix2 = w.tile_prefix2 + off / FZB_TILE + 2 * cn;
+        u32* items2 = w.items2 + off;
+        u32* win2 = w.win2 + 2 * off;
+        fzb_launch_window(cd, cfirst, items, &cnt_c[0], nd, lc.pf_lanes, winb, bitmap2, tile_counts2, cnt_c, cus * 4, st);
+        FZB_STAGE("window");
+        if (cn) HIPCHK(hipStreamWaitEvent(st, m->ev_chain[cn - 1], 0));
+        fzb_launch_scan(tile_counts2, tile_prefix2, &cnt_c[0], 0, &cnt_c[1], base_in, &cnt_c[2], st);
+        HIPCHK(hipEventRecord(m->ev_chain[cn], st));
+        FZB_STAGE("scan2");
+        fzb_launch_map(2, bitmap2, tile_prefix2, &cnt_c[0], 0, items2, items, winb, win2, cus * 2, st);
+        FZB_STAGE("map2");
+        items = items2;
+        win = win2;
+        n_items_ptr = &cnt_c[1];
+        wmode = 0;
+    }
+    u32* dc = last ? dev_count : nullptr;
+    if (nd.unicode) {
+        fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, base_in, dc, cnt_c, cus * 4, st);
+        FZB_STAGE("generic(unicode)");
+    } else {
+        fzb_launch_dp(cd, cfirst, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, base_in, dc, overflow, cnt_c, cus * 8, st);
+        FZB_STAGE("dp");
+        // windows wider than one chunk were queued (output position, start, end, haystack) by the DP kernel
+        fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow, &cnt_c[3], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c, cus / 2 + 1, st);
+        FZB_STAGE("generic(queued)");
+    }
+#undef FZB_STAGE
+    return FZB_OK;
+}
+
 int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity,
                           uint32_t* dev_count, void* stream) {
     if (!m || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
@@ -429,7 +534,7 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     if ((u64)count + (u64)index_offset > 0xFFFFFFFFull)
         return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
     if (m->empty) return fail(FZB_ERR_INVALID, "empty needle: handled on the host by fzb_match_list / fzb_match_list_into");
-    hipStream_t st = (hipStream_t)stream;
+    hipStream_t user = (hipStream_t)stream;
     if (m->device < 0) {
         int dev = 0;
         HIPCHK(hipGetDevice(&dev));
@@ -437,80 +542,68 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
         HIPCHK(hipGetDeviceProperties(&prop, dev));
         m->device = dev;
         m->lc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        for (auto& st : m->streams) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+        for (auto& e : m->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : m->ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     int rc = ensure_workspace(m, count);
     if (rc) return rc;
     Workspace& w = m->ws;
-    const LaunchCfg& lc = m->lc;
-    const NeedleDev& nd = m->nd;
     const CorpusDev& cd = c->dev;
-    const u32 cnt = (u32)count;
     const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
-    if (m->profiling) {
-        m->ev = m->evring[m->prof_calls % fzb_matcher::PROF_SLOTS];
-        m->prof_calls++;
-        if (!m->ev[0])
-            for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&m->ev[i]));
-    }
-    HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
+    HIPCHK(hipMemsetAsync(w.counters, 0, 64 * (fzb_matcher::MAX_CHUNKS + 1), user));
     if (count == 0) {
-        HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
+        HIPCHK(hipMemsetAsync(dev_count, 0, 4, user));
         return FZB_OK;
     }
-    const int cus = lc.num_cus;
-    static const bool dbg = getenv("FZB_DEBUG_SYNC") != nullptr;  // debugging aid: synchronise and report after every stage
-#define FZB_STAGE(name)                                                                  \
-    do {                                                                                 \
-        if (dbg) {                                                                       \
-            hipError_t e_ = hipStreamSynchronize(st);                                    \
-            fprintf(stderr, "[fzb] stage %s: %s\n", name, hipGetErrorString(e_));        \
-            if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
-        }                                                                                \
-    } while (0)
-    if (m->profiling) HIPCHK(hipEventRecord(m->ev[0], st));
-    const u32* items = nullptr;
-    const u32* win = nullptr;
-    const u32* n_items_ptr = &w.counters[0];
-    int wmode = lc.window_mode;
-    if (lc.filter_mode == 0) {
-        // nothing filtered: survivors are the identity list
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&w.counters[0], (int)cnt, 1, st));
-        if (m->profiling) HIPCHK(hipEventRecord(m->ev[1], st));
-    } else {
-        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
-        fzb_launch_filter(cd, first, cnt, w.table, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 8, st);
-        if (m->profiling) HIPCHK(hipEventRecord(m->ev[1], st));
-        FZB_STAGE("filter");
-        fzb_launch_scan(w.tile_counts, w.tile_prefix, nullptr, cnt, &w.counters[0], st);
-        FZB_STAGE("scan1");
-        fzb_launch_map(1, w.bitmap, w.tile_prefix, nullptr, cnt, w.surv_idx, nullptr, nullptr, nullptr, cus * 4, st);
-        FZB_STAGE("map1");
-        items = w.surv_idx;
+    // Chunking: the filter is HBM-bound and the scorer VALU-bound, so chunk c+1's filter is issued on the other stream
+    // and overlaps chunk c's scoring.  Chunks are tile-aligned; their records are laid out back to back through the
+    // device-side base chain (counters[16c + 2]).
+    static const int env_chunks = getenv("FZB_CHUNKS") ? atoi(getenv("FZB_CHUNKS")) : 0;
+    int nchunks = env_chunks > 0 ? env_chunks : (count >= (4u << 20) ? 4 : count >= (1u << 20) ? 2 : 1);
+    nchunks = std::min(nchunks, (int)fzb_matcher::MAX_CHUNKS);
+    size_t per = ((count + nchunks - 1) / nchunks + FZB_TILE - 1) / FZB_TILE * FZB_TILE;
+    nchunks = (int)((count + per - 1) / per);
+    hipEvent_t* pev = nullptr;
+    if (m->profiling) {
+        const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);
+        pev = m->evring[slot];
+        m->ev_chunks[slot] = m->lc.filter_mode ? nchunks : 0;
+        m->prof_calls++;
+        for (int i = 0; i < 2 + 2 * nchunks; i++)
+            if (!pev[i]) HIPCHK(hipEventCreate(&pev[i]));
+        HIPCHK(hipEventRecord(pev[0], user));
     }
-    if (!lc.filter_exact) {
-        fzb_launch_window(cd, first, items, &w.counters[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, w.counters, cus * 4, st);
-        FZB_STAGE("window");
-        fzb_launch_scan(w.tile_counts2, w.tile_prefix2, &w.counters[0], 0, &w.counters[1], st);
-        FZB_STAGE("scan2");
-        fzb_launch_map(2, w.bitmap2, w.tile_prefix2, &w.counters[0], 0, w.items2, items, w.win, w.win2, cus * 4, st);
-        FZB_STAGE("map2");
-        items = w.items2;
-        win = w.win2;
-        n_items_ptr = &w.counters[1];
-        wmode = 0;
+    if (m->lc.filter_mode == 0) {  // identity survivor lists: counts and output bases are host-known
+        size_t done = 0;
+        for (int cn = 0; cn < nchunks; cn++) {
+            const size_t ccnt = std::min(per, count - done);
+            done += ccnt;
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(w.counters + 16 * cn), (int)ccnt, 1, user));
+            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(w.counters + 16 * cn + 2), (int)done, 1, user));
+        }
     }
     fzb_match_rec* outp = (fzb_match_rec*)dev_out;
-    if (nd.unicode) {
-        fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, w.counters, cus * 4, st);
-        FZB_STAGE("generic(unicode)");
+    if (nchunks == 1) {
+        rc = run_chunk(m, cd, 0, 1, first, (u32)count, 0, index_offset, outp, cap32, dev_count, user, pev);
+        if (rc) return rc;
     } else {
-        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, outp, cap32, dev_count, w.overflow, w.counters, cus * 8, st);
-        FZB_STAGE("dp");
-        // windows wider than one chunk were queued (item, start, end) in w.overflow by the DP kernel
-        fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &w.counters[3], nd, lc.sw_lanes, 0, outp, cap32, dev_count, w.counters, cus * 2, st);
-        FZB_STAGE("generic(overflow)");
+        HIPCHK(hipEventRecord(m->ev_fork, user));
+        for (auto& st : m->streams) HIPCHK(hipStreamWaitEvent(st, m->ev_fork, 0));
+        size_t off = 0;
+        for (int cn = 0; cn < nchunks; cn++) {
+            const size_t ccnt = std::min(per, count - off);
+            rc = run_chunk(m, cd, cn, nchunks, first + off, (u32)ccnt, off, (u32)(index_offset + off), outp, cap32, dev_count, m->streams[cn & 1], pev);
+            if (rc) return rc;
+            off += ccnt;
+        }
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipEventRecord(m->ev_join[i], m->streams[i]));
+            HIPCHK(hipStreamWaitEvent(user, m->ev_join[i], 0));
+        }
     }
-    if (m->profiling) HIPCHK(hipEventRecord(m->ev[2], st));
+    if (pev) HIPCHK(hipEventRecord(pev[1], user));
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }
@@ -541,7 +634,6 @@ int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     if (rc) return rc;
     u32 n = 0;
     HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));  // synchronises the default stream
-    if (count) HIPCHK(hipMemcpy(m->last_counters, m->ws.counters, 16, hipMemcpyDeviceToHost));
     fzb_match* r = (fzb_match*)malloc(std::max<size_t>(n, 1) * sizeof(fzb_match));
     if (n) HIPCHK(hipMemcpy(r, m->out_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost));
     *out = r;
@@ -623,34 +715,47 @@ int fzb_set_profiling(fzb_matcher* m, int enabled) {
     return FZB_OK;
 }
 
-// Averages over the calls made since fzb_set_profiling(m, 1) (at most the last 64):
-// out_ms[0] = filter kernel, [1] = whole pipeline, [2] = number of calls averaged, [3] = last call's pipeline time
+// Averages over the calls made since fzb_set_profiling(m, 1) (at most the last 32):
+// out_ms[0] = filter kernel time (sum over the chunks' launches), [1] = whole pipeline, [2] = calls averaged, [3] = filter launches per call
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
     if (!m || !out_ms) return fail(FZB_ERR_INVALID, "null argument");
     if (!m->profiling || m->prof_calls == 0) return fail(FZB_ERR_INVALID, "profiling not enabled or no call recorded");
     const u64 n = std::min<u64>(m->prof_calls, fzb_matcher::PROF_SLOTS);
     double f = 0, t = 0;
-    float last = 0;
+    int chunks = 0;
     for (u64 i = 0; i < n; i++) {
-        hipEvent_t* e = m->evring[(m->prof_calls - 1 - i) % fzb_matcher::PROF_SLOTS];
-        HIPCHK(hipEventSynchronize(e[2]));
-        float a = 0, b = 0;
-        HIPCHK(hipEventElapsedTime(&a, e[0], e[1]));
-        HIPCHK(hipEventElapsedTime(&b, e[0], e[2]));
-        f += a;
+        const int slot = (int)((m->prof_calls - 1 - i) % fzb_matcher::PROF_SLOTS);
+        hipEvent_t* e = m->evring[slot];
+        HIPCHK(hipEventSynchronize(e[1]));
+        float b = 0;
+        HIPCHK(hipEventElapsedTime(&b, e[0], e[1]));
         t += b;
-        if (i == 0) last = b;
+        chunks = m->ev_chunks[slot];
+        for (int cn = 0; cn < chunks; cn++) {
+            float a = 0;
+            HIPCHK(hipEventElapsedTime(&a, e[2 + 2 * cn], e[3 + 2 * cn]));
+            f += a;
+        }
     }
     out_ms[0] = (float)(f / n);
     out_ms[1] = (float)(t / n);
     out_ms[2] = (float)n;
-    out_ms[3] = last;
+    out_ms[3] = (float)chunks;
     return FZB_OK;
 }
 
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {
     if (!m || !out) return fail(FZB_ERR_INVALID, "null argument");
-    if (m->ws.counters) HIPCHK(hipMemcpy(m->last_counters, m->ws.counters, 16, hipMemcpyDeviceToHost));
+    if (m->ws.counters) {
+        u32 all[16 * fzb_matcher::MAX_CHUNKS];
+        HIPCHK(hipMemcpy(all, m->ws.counters, sizeof(all), hipMemcpyDeviceToHost));
+        memset(m->last_counters, 0, 16);
+        for (int cn = 0; cn < fzb_matcher::MAX_CHUNKS; cn++) {
+            m->last_counters[0] += all[16 * cn];
+            m->last_counters[1] += all[16 * cn + 1];
+            m->last_counters[3] += all[16 * cn + 3];
+        }
+    }
     memcpy(out, m->last_counters, 16);
     return FZB_OK;
 }

@@ -97,6 +97,120 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K1-DFA: the ordered-subsequence test (MODE 1) as a table-driven DFA.  State s = number of needle rows
+// already matched; dfa[s * 256 + b] = s + 1 if byte b matches row s (either case), else s; state `rows`
+// is absorbing.  One step is ONE v_perm_b32 (builds the LDS address (s << 8) | byte) + ONE ds_read_u8,
+// instead of extract / lookup / and / add.  The lookup chain is serial per haystack, so every thread runs
+// the 4 haystacks it owns in a tile as 4 interleaved chains, with all their 16-byte vectors requested
+// from HBM up front.  The table has (rows + 1) * 256 bytes; 4 byte values share a dword, so the
+// alphanumerics of one state row spread over distinct LDS banks.
+// ---------------------------------------------------------------------------------------------------
+template <int K>
+__device__ __forceinline__ u32 dfa_step(u32 st, u32 w, const u8* dfa) {
+    // address = (st << 8) | byte K of w  (v_perm_b32: byte0 <- w.byteK, byte1 <- st.byte0, bytes 2,3 <- 0)
+    const u32 addr = __builtin_amdgcn_perm(st, w, 0x0c0c0400u | (u32)K);
+    return dfa[addr];
+}
+__device__ __forceinline__ void dfa_word4(u32 (&st)[4], const u32 (&w)[4], const u8* dfa) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<0>(st[p], w[p], dfa);
+#pragma unroll
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<1>(st[p], w[p], dfa);
+#pragma unroll
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<2>(st[p], w[p], dfa);
+#pragma unroll
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<3>(st[p], w[p], dfa);
+}
+__device__ __forceinline__ u32 dfa_partial(u32 st, const uint4& q, u32 nbytes, const u8* dfa) {
+    const u32 w4[4] = {q.x, q.y, q.z, q.w};
+    for (u32 k = 0; k < nbytes; k++) {
+        const u32 b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
+        st = dfa[(st << 8) | b];
+    }
+    return st;
+}
+
+template <typename ET>
+__global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
+                                              const u8* __restrict__ dfa_g, int rows, u32 min_len, u64* __restrict__ bitmap,
+                                              u32* __restrict__ tile_counts) {
+    extern __shared__ __attribute__((aligned(16))) u8 dfa[];
+    __shared__ u32 s_cnt;
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        u64 hs[4];
+        u32 hl[4];
+        uint4 v0[4], v1[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const u32 li = tile * FZB_TILE + p * 256 + tid;
+            hs[p] = 0;
+            hl[p] = 0;
+            if (li < count) haystack_span(ends, first + li, hs[p], hl[p]);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            v0[p] = make_uint4(0, 0, 0, 0);
+            v1[p] = make_uint4(0, 0, 0, 0);
+            const uint4* vp = (const uint4*)(bytes + hs[p]);
+            if (hl[p] > 0) v0[p] = vp[0];
+            if (hl[p] > 16) v1[p] = vp[1];
+        }
+        u32 st[4] = {0, 0, 0, 0};
+        const bool full0 = hl[0] >= 16 && hl[1] >= 16 && hl[2] >= 16 && hl[3] >= 16;
+        if (full0) {
+            { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4(st, w, dfa); }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++) st[p] = dfa_partial(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
+        }
+        const bool full1 = hl[0] >= 32 && hl[1] >= 32 && hl[2] >= 32 && hl[3] >= 32;
+        if (full1) {
+            { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4(st, w, dfa); }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (hl[p] > 16) st[p] = dfa_partial(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
+        }
+        u32 cnt = 0;
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            const u32 L = hl[p];
+            if (L > 32) {  // longer haystacks: remaining vectors on demand
+                const uint4* vp = (const uint4*)(bytes + hs[p]);
+                const u32 nvec = (L + 15) >> 4;
+                for (u32 v = 2; v < nvec; v++) {
+                    const uint4 qv = vp[v];
+                    const u32 rem = L - 16 * v;
+                    st[p] = dfa_partial(st[p], qv, rem >= 16 ? 16u : rem, dfa);
+                }
+            }
+            const u32 li = tile * FZB_TILE + p * 256 + tid;
+            const bool matched = li < count && L >= min_len && st[p] == (u32)rows;
+            const u64 b = __ballot(matched);
+            if (lane_id() == 0) {
+                bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
+                cnt += __popcll(b);
+            }
+        }
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
 // Used when nothing is filtered (max_typos = None, or max_typos >= rows): every haystack survives.
 __global__ __launch_bounds__(256) void k1_all_pass(u32 count, u32 min_len_unused, u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
     const u32 nwords = (count + 63) / 64;
@@ -117,14 +231,21 @@ __global__ __launch_bounds__(256) void k1_all_pass(u32 count, u32 min_len_unused
 // first-level (haystacks) and second-level (survivors) compaction without a host round trip.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan_tiles(const u32* __restrict__ counts, u32* __restrict__ prefix, const u32* __restrict__ n_items_ptr,
-                                                     u32 n_items_host, u32* __restrict__ total_out) {
+                                                     u32 n_items_host, u32* __restrict__ total_out, const u32* __restrict__ base_in, u32* __restrict__ base_out) {
     __shared__ u32 wsum[16];
     const u32 n_items = n_items_ptr ? *n_items_ptr : n_items_host;
     const u32 ntiles = (n_items + FZB_TILE - 1) / FZB_TILE;
     const u32 per = (ntiles + 1023) / 1024;
     const u32 lo = threadIdx.x * per, hi = min(lo + per, ntiles);
+    // thread-local sum with the loads batched 8 at a time (independent loads in flight instead of a serial chain)
     u32 sum = 0;
-    for (u32 t = lo; t < hi; t++) sum += counts[t];
+    for (u32 t = lo; t < hi; t += 8) {
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (t + k < hi) ? counts[t + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sum += v[k];
+    }
     // block exclusive scan of `sum`
     u32 incl = sum;
     for (int off = 1; off < 64; off <<= 1) {
@@ -137,13 +258,20 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(const u32* __restrict__ cou
     u32 wbase = 0;
     for (int w = 0; w < wave; w++) wbase += wsum[w];
     u32 run = wbase + incl - sum;
-    for (u32 t = lo; t < hi; t++) {
-        prefix[t] = run;
-        run += counts[t];
+    for (u32 t = lo; t < hi; t += 8) {
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (t + k < hi) ? counts[t + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (t + k < hi) prefix[t + k] = run;
+            run += v[k];
+        }
     }
     if (threadIdx.x == 1023) {
         prefix[ntiles] = wbase + incl;
         *total_out = wbase + incl;
+        if (base_out) *base_out = (base_in ? *base_in : 0u) + wbase + incl;  // chunk chaining: where the next chunk's records start
     }
 }
 
@@ -181,11 +309,17 @@ __global__ __launch_bounds__(256) void k_map(const u64* __restrict__ bitmap, con
 // ---------------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from pipeline.hip)
 // ---------------------------------------------------------------------------------------------------
-void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, int rows, int mode, int need, u32 min_len,
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, int grid, hipStream_t st) {
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
+    if (mode == 1) {
+        const size_t lds = (size_t)(rows + 1) * 256;
+        if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, bitmap, tile_counts);
+        else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, bitmap, tile_counts);
+        return;
+    }
     if (mode == 0) {
         hipLaunchKernelGGL(k1_all_pass, dim3(grid), dim3(256), 0, st, count, min_len, bitmap, tile_counts);
         return;
@@ -202,8 +336,8 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #undef FZB_K1
 }
 
-void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, counts, prefix, n_items_ptr, n_items_host, total_out);
+void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, const u32* base_in, u32* base_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, counts, prefix, n_items_ptr, n_items_host, total_out, base_in, base_out);
 }
 
 void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,

@@ -80,14 +80,15 @@ template <int SWL, bool UNICODE, typename ET>
 __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                               const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
                                                               const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
-                                                              fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters) {
+                                                              fzb_match_rec* __restrict__ out, u32 capacity, const u32* __restrict__ base_ptr, u32* __restrict__ dev_count, u32* __restrict__ counters) {
     // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row
     __shared__ u16 s_adj_row[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
     __shared__ u16 s_adj_aux[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
     const int lane = lane_id();
     const int wv = threadIdx.x >> 6;
     const u32 nlist = *n_list_ptr;
-    if (UNICODE && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = nlist < capacity ? nlist : capacity;
+    const u32 base = (!list && base_ptr) ? *base_ptr : 0u;  // list entries already carry absolute output positions
+    if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = (base + nlist) < capacity ? (base + nlist) : capacity;
     const u32 LM = (u32)nd.lane_mask;
     const u32 rows = (u32)nd.rows;
     const u32 Mc = nd.match_plus_mismatch & LM, X = nd.mismatch & LM, gex = nd.gex & LM, gopm = nd.gopm & LM;
@@ -95,15 +96,17 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
     const bool active = lane < SWL;
 
     for (u32 q = blockIdx.x * GEN_WAVES + wv; q < nlist; q += gridDim.x * GEN_WAVES) {
-        const u32 j = list ? list[3 * q] : q;  // list entries: (item, window start, window end) queued by the single-chunk kernel
-        if (j >= capacity) continue;
-        const u32 li = items ? items[j] : j;
+        // list entries: (output position, window start, window end, local haystack index) queued by the single-chunk kernels
+        const u32 j = list ? list[4 * q] : q;          // rank inside this chunk (direct mode) / absolute output position (list mode)
+        const u32 opos = list ? j : base + j;
+        if (opos >= capacity) continue;
+        const u32 li = list ? list[4 * q + 3] : (items ? items[j] : j);
         u64 s;
         u32 L;
         haystack_span(ends, first + li, s, L);
         const u8* hay = bytes + s;
         u32 ws, we;
-        if (list) { ws = list[3 * q + 1]; we = list[3 * q + 2]; }
+        if (list) { ws = list[4 * q + 1]; we = list[4 * q + 2]; }
         else if (wmode == 2) { ws = 0; we = L; }
         else { ws = win[2 * j]; we = win[2 * j + 1]; }
         const u32 sp = ws ? ws - 1 : 0;
@@ -265,14 +268,14 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
             rec.score = (u16)score;
             rec.exact = exact ? 1 : 0;
             rec.valid = 0;
-            out[j] = rec;
+            out[opos] = rec;
         }
     }
 }
 
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
-                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters)
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st) {
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, base_ptr, dev_count, counters)
 #define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
 #define FZB_K2C_U(SWL) do { if (unicode) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
     switch (sw_lanes) {
