@@ -91,7 +91,7 @@ _lib = None
 
 SYMBOLS = [
     "fzb_last_error", "fzb_config_default", "fzb_matcher_create", "fzb_matcher_clone", "fzb_matcher_free", "fzb_matcher_info",
-    "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
+    "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_set_max_len", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
     "fzb_match_list_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
 ]
@@ -112,6 +112,7 @@ def lib():
         l.fzb_matcher_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         l.fzb_corpus_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         l.fzb_corpus_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.POINTER(C.c_void_p)]
+        l.fzb_corpus_set_max_len.argtypes = [C.c_void_p, C.c_uint32]
         l.fzb_corpus_free.argtypes = [C.c_void_p]
         l.fzb_corpus_len.argtypes = [C.c_void_p]
         l.fzb_corpus_len.restype = C.c_size_t
@@ -167,12 +168,15 @@ class Corpus:
         _check(lib().fzb_corpus_upload(data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), C.byref(self.h)))
 
     @classmethod
-    def from_device(cls, dev_bytes_ptr, dev_ends_ptr, n, total_bytes, ends_are_u64=False, keep=None):
-        """Borrow device memory already in the padded-16 layout (see include/frizbee_hip.h)."""
+    def from_device(cls, dev_bytes_ptr, dev_ends_ptr, n, total_bytes, ends_are_u64=False, keep=None, max_len=0):
+        """Borrow device memory already in the padded-16 layout (see include/frizbee_hip.h).  max_len: optional upper bound
+        on the haystack length (0 = unknown)."""
         self = cls.__new__(cls)
         self.h = C.c_void_p()
         self._keep = keep
         _check(lib().fzb_corpus_from_device(dev_bytes_ptr, dev_ends_ptr, int(ends_are_u64), n, total_bytes, C.byref(self.h)))
+        if max_len:
+            _check(lib().fzb_corpus_set_max_len(self.h, max_len))
         return self
 
     def __len__(self):

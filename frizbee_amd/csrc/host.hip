@@ -172,6 +172,7 @@ struct fzb_matcher {
     // chunk pipelining: two internal streams forked from / joined to the caller's stream
     hipStream_t streams[2] = {nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_chain[MAX_CHUNKS] = {};
+
     u32 last_counters[4] = {0, 0, 0, 0};
     // staging for the synchronous API
     fzb_match_rec* out_dev = nullptr;
@@ -340,10 +341,11 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
     if (n > 0xFFFFFFFFull) return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(n) + " > 4294967295 (index offset: 0)");
     // repack into the padded-16 device layout
     std::vector<u64> pends(n);
-    u64 pos = 0, prev = 0;
+    u64 pos = 0, prev = 0, max_len = 0;
     for (size_t i = 0; i < n; i++) {
         if (end_offsets[i] < prev) return fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
         const u64 len = end_offsets[i] - prev;
+        max_len = std::max(max_len, len);
         pos = (pos + 15) & ~(u64)15;
         pos += len;
         pends[i] = pos;
@@ -364,6 +366,7 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
     c->dev.n = n;
     c->dev.total_bytes = total;
     c->dev.ends_u64 = total > 0xFFFFFFF0ull;
+    c->dev.max_len = (u32)std::min<u64>(max_len, 0xFFFFFFFFu);
     hipError_t e = dev_alloc(&c->own_bytes, total);
     if (e == hipSuccess) e = hipMemcpy(c->own_bytes, packed.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
@@ -408,6 +411,11 @@ void fzb_corpus_free(fzb_corpus* c) {
     delete c;
 }
 size_t fzb_corpus_len(const fzb_corpus* c) { return c ? (size_t)c->dev.n : 0; }
+int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
+    if (!c) return fail(FZB_ERR_INVALID, "null argument");
+    c->dev.max_len = max_len;
+    return FZB_OK;
+}
 
 // ---- pipeline -------------------------------------------------------------------------------------------
 static int ensure_workspace(fzb_matcher* m, size_t count) {
@@ -518,8 +526,10 @@ static int run_chunk(fzb_matcher* m, const CorpusDev& cd, int cn, int nchunks, u
     } else {
         fzb_launch_dp(cd, cfirst, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, base_in, dc, overflow, cnt_c, cus * 8, st);
         FZB_STAGE("dp");
-        // windows wider than one chunk were queued (output position, start, end, haystack) by the DP kernel
-        fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow, &cnt_c[3], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c, cus / 2 + 1, st);
+        // windows wider than one chunk were queued (output position, start, end, haystack) by the DP kernel;
+        // impossible (launch skipped) when no haystack of the corpus is longer than a chunk
+        if (!(cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes))
+            fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow, &cnt_c[3], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c, cus / 2 + 1, st);
         FZB_STAGE("generic(queued)");
     }
 #undef FZB_STAGE
@@ -552,19 +562,21 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     Workspace& w = m->ws;
     const CorpusDev& cd = c->dev;
     const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
-    HIPCHK(hipMemsetAsync(w.counters, 0, 64 * (fzb_matcher::MAX_CHUNKS + 1), user));
     if (count == 0) {
         HIPCHK(hipMemsetAsync(dev_count, 0, 4, user));
         return FZB_OK;
     }
-    // Chunking: the filter is HBM-bound and the scorer VALU-bound, so chunk c+1's filter is issued on the other stream
-    // and overlaps chunk c's scoring.  Chunks are tile-aligned; their records are laid out back to back through the
-    // device-side base chain (counters[16c + 2]).
+    // Optional chunking (FZB_CHUNKS=n, default 1): chunk c+1's HBM-bound filter is issued on a second stream so it can
+    // overlap chunk c's VALU-bound scoring; chunks are tile-aligned and their records are laid out back to back through
+    // the device-side base chain (counters[16c + 2]).  Measured on MI355X it does NOT pay for a single query (the extra
+    // launches, event waits and the fork/join cost more than the overlap wins, eagerly and as a replayed hipGraph), so it
+    // stays off by default; see DESIGN.md.
     static const int env_chunks = getenv("FZB_CHUNKS") ? atoi(getenv("FZB_CHUNKS")) : 0;
-    int nchunks = env_chunks > 0 ? env_chunks : (count >= (4u << 20) ? 4 : count >= (1u << 20) ? 2 : 1);
+    int nchunks = env_chunks > 0 ? env_chunks : 1;
     nchunks = std::min(nchunks, (int)fzb_matcher::MAX_CHUNKS);
     size_t per = ((count + nchunks - 1) / nchunks + FZB_TILE - 1) / FZB_TILE * FZB_TILE;
     nchunks = (int)((count + per - 1) / per);
+    HIPCHK(hipMemsetAsync(w.counters, 0, 64 * (fzb_matcher::MAX_CHUNKS + 1), user));
     hipEvent_t* pev = nullptr;
     if (m->profiling) {
         const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);

@@ -93,6 +93,9 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
  * bytes after the last haystack.  dev_ends has n entries (uint32 if ends_are_u64 == 0).  Borrowed, not copied.
  * (A list of 32-byte haystacks stored back to back already has this layout.) */
 int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends_are_u64, size_t n, uint64_t total_bytes, fzb_corpus** out);
+/* Optional hint for borrowed corpora: the longest haystack in bytes (fzb_corpus_upload computes it).  Must be an upper
+ * bound; 0 = unknown. */
+int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len);
 void fzb_corpus_free(fzb_corpus* c);
 size_t fzb_corpus_len(const fzb_corpus* c);
 

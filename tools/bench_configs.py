@@ -1,0 +1,44 @@
+"""Device-pipeline timing of the other BASELINE.json configurations (not the headline bench line):
+C3 = len-32 / max_typos=2, C4-shard = ragged 8..128 (one GPU's 12.5M-item shard of the 100M list), C5 = UTF-8 len-32.
+Prints one JSON object per config with the per-kernel-stage event timings measured by the library."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np, torch, synth, frizbee_amd as F
+dev = torch.device("cuda", 0)
+def run(name, needle, cfg, corpus, n, steps=10):
+    m = F.Matcher(needle, cfg)
+    out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev); cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    for _ in range(2): m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps): m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr())
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / steps
+    m.set_profiling(True)
+    for _ in range(steps): m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr())
+    torch.cuda.synchronize(); tm = m.last_timings_ms(); c = m.last_counters()
+    print(json.dumps(dict(config=name, haystacks=n, ms_per_step=wall * 1e3, haystacks_per_s=n / wall, filter_ms=tm["filter"], pipeline_ms=tm["total"], matches=int(cnt[0].item()), **c)), flush=True)
+which = sys.argv[1:] or ["C2", "C3", "C4", "C5"]
+n = 10_000_000
+if "C2" in which or "C3" in which:
+    flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
+    flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
+    ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+    if "C2" in which: run("C2 len32 typos0", "deadbe", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n)
+    if "C3" in which: run("C3 len32 typos2", "deadbe", F.Config(max_typos=2, pf_lanes=64, sw_lanes=64), cp, n)
+    if "C2none" in which: run("C2 len32 typosNone(all scored)", "deadbe", F.Config(max_typos=None, pf_lanes=64, sw_lanes=64), cp, n, steps=3)
+    del cp, flat, ends
+if "C4" in which:
+    n4 = 12_500_000 if "C4small" not in which else 2_000_000
+    data, ends = synth.ragged_corpus(b"deadbeef", n4, device=dev)
+    cp = F.Corpus(packed=(data, ends))
+    run("C4 shard ragged 8..128 typos0", "deadbeef", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n4)
+    del cp
+if "C5" in which:
+    n5 = 2_000_000
+    data, ends = synth.utf8_corpus(n5, 32)
+    reps = 5
+    data = np.tile(data, reps); ends = np.arange(1, n5 * reps + 1, dtype=np.uint64) * np.uint64(32)
+    cp = F.Corpus(packed=(data, ends))
+    run("C5 utf8 len32 typos0 (2M distinct x5)", "إنما", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n5 * reps)
