@@ -210,3 +210,171 @@ __device__ __forceinline__ bool exact_match(const NeedleDev& nd, bool include_ex
     }
     return exact;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Multi-chunk form: windows of SWL < m <= 1024 bytes, still one THREAD per haystack.  Chunks are processed left to
+// right; for every needle row the reference keeps the previous chunk's final row and match mask (score_matrix /
+// match_masks column, src/smith_waterman/matrix.rs) because (a) `shift_right_padded::<k>` refills the low k lanes from
+// the previous chunk's top k lanes (ascii.rs:136-143) and (b) lane 0's diagonal reads S(i-1, prev chunk)[last].
+// Only the top SWL/2 lanes can ever be shifted in, so per row the thread parks SWL/4 dwords of row values and SWL/4
+// dwords of gap-open charges in a global scratch slab laid out [row][dword][thread] (coalesced across the wave).
+// In the biased domain the adjacent lanes are simply positions -SWL/2..-1 of one longer vector (bias (p + SWL) * gex).
+// ---------------------------------------------------------------------------------------------------------------
+template <int SWL, bool BIAS>
+__device__ __forceinline__ u32 dp_multi_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls,
+                                              u32* __restrict__ scratch, u32 sstride, u32 sidx) {
+    constexpr int NW = SWL / 2;
+    constexpr int NB = SWL / 4;
+    constexpr int HT = NW / 2;  // parked dwords per vector (top half)
+    const u32 rows = (u32)nd.rows;
+    const u32 ONE = 0x00010001u;
+    const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
+    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+    const u32 nchunks = (m + SWL - 1) / SWL;
+    u32 maxs[NW];
+#pragma unroll
+    for (int d = 0; d < NW; d++) maxs[d] = 0;
+    u32 clsw_carry = 0;  // class of the previous chunk's last lane, in the HIGH half (what alignbit shifts in)
+#pragma unroll 1
+    for (u32 ch = 0; ch < nchunks; ch++) {
+        const u32 cbase = ch * SWL;
+        u32 hw[NW], bonus[NW];
+        {
+            u32 clsw_prev = clsw_carry;
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const u32 p = cbase + 4 * k;
+                u32 w = 0;
+                if (p < m) {
+                    w = load_u32_unaligned(th, p);
+                    const u32 rem = m - p;
+                    if (rem < 4) w &= (1u << (8 * rem)) - 1;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int d = 2 * k + h;
+                    const u32 b0 = h ? (w >> 16) & 0xFF : w & 0xFF;
+                    const u32 b1 = h ? w >> 24 : (w >> 8) & 0xFF;
+                    hw[d] = b0 | (b1 << 16);
+                    const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
+                    const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);
+                    const u32 cap01 = (clsw >> 1) & sh & ONE;
+                    const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;
+                    bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+                    clsw_prev = clsw;
+                }
+            }
+            clsw_carry = clsw_prev;
+            if (ch == 0 && include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
+        }
+        u32 prev[NW], gprev[NW];
+#pragma unroll
+        for (int d = 0; d < NW; d++) prev[d] = 0, gprev[d] = 0;
+        u32 carry = 0;  // S(r-1, previous chunk) top dword (its high half is the last lane), unbiased
+#pragma unroll 1
+        for (u32 r = 0; r < rows; r++) {
+            const u32 c = nd.c[r], f = nd.f[r];
+            const bool ci = c != f;
+            const u32 orv = ci ? 0x00200020u : 0u;
+            const u32 cmpv = splat16(ci ? (c | 0x20) : c);
+            const u32 cv = splat16(c);
+            // previous chunk's parked vectors for this row (zero for the first chunk)
+            u32 arow[HT], ag[HT];
+            u32* srow = scratch + (size_t)(r * NW) * sstride + sidx;
+#pragma unroll
+            for (int t = 0; t < HT; t++) {
+                arow[t] = ch ? srow[(size_t)t * sstride] : 0u;
+                ag[t] = ch ? srow[(size_t)(HT + t) * sstride] : 0u;
+            }
+            u32 row[NW], g[NW];
+#pragma unroll
+            for (int d = 0; d < NW; d++) {
+                const u32 mm = p_subs(ONE, (hw[d] | orv) ^ cmpv);
+                const u32 ex = ci ? p_subs(ONE, hw[d] ^ cv) : mm;
+                const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : carry, 16);
+                u32 t = p_add(p_mul(mm, bonus[d]), sh);
+                t = p_subs(t, Xv);
+                const u32 diag = p_add(p_mul(ex, casev), t);
+                const u32 up = p_subs(p_subs(prev[d], gexv), gprev[d]);
+                row[d] = p_max(diag, up);
+                g[d] = p_mul(mm, gopmv);
+            }
+            carry = arow[HT - 1];
+            // propagate over the concatenation [parked top half of the previous chunk | this chunk]
+            if (BIAS) {
+                u32 b[NW], ab[HT];
+#pragma unroll
+                for (int d = 0; d < NW; d++) b[d] = p_add(row[d], (u32)nd.gex * (u32)((2 * d + SWL) + ((2 * d + 1 + SWL) << 16)));
+#pragma unroll
+                for (int t = 0; t < HT; t++) ab[t] = p_add(arow[t], (u32)nd.gex * (u32)((2 * (HT + t)) + ((2 * (HT + t) + 1) << 16)));
+                {
+                    u32 nb[NW];
+#pragma unroll
+                    for (int d = 0; d < NW; d++) {
+                        const u32 sb = __builtin_amdgcn_alignbit(b[d], d ? b[d - 1] : ab[HT - 1], 16);
+                        const u32 sg = __builtin_amdgcn_alignbit(g[d], d ? g[d - 1] : ag[HT - 1], 16);
+                        nb[d] = p_max(b[d], p_subs(sb, sg));
+                    }
+#pragma unroll
+                    for (int d = 0; d < NW; d++) b[d] = nb[d];
+                }
+#pragma unroll
+                for (int off = 1; off < NW; off *= 2) {
+                    u32 nb[NW];
+#pragma unroll
+                    for (int d = 0; d < NW; d++) {
+                        const u32 sb = d >= off ? b[d - off] : ab[HT + d - off];
+                        const u32 sg = d >= off ? g[d - off] : ag[HT + d - off];
+                        nb[d] = p_max(b[d], p_subs(sb, sg));
+                    }
+#pragma unroll
+                    for (int d = 0; d < NW; d++) b[d] = nb[d];
+                }
+#pragma unroll
+                for (int d = 0; d < NW; d++) row[d] = p_sub(b[d], (u32)nd.gex * (u32)((2 * d + SWL) + ((2 * d + 1 + SWL) << 16)));
+            } else {
+                u32 kg = gexv;
+                {
+                    u32 nb[NW];
+#pragma unroll
+                    for (int d = 0; d < NW; d++) {
+                        const u32 sb = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : arow[HT - 1], 16);
+                        const u32 sg = __builtin_amdgcn_alignbit(g[d], d ? g[d - 1] : ag[HT - 1], 16);
+                        nb[d] = p_max(row[d], p_subs(sb, p_add(kg, sg)));
+                    }
+#pragma unroll
+                    for (int d = 0; d < NW; d++) row[d] = nb[d];
+                }
+#pragma unroll
+                for (int off = 1; off < NW; off *= 2) {
+                    kg = p_add(kg, kg);
+                    u32 nb[NW];
+#pragma unroll
+                    for (int d = 0; d < NW; d++) {
+                        const u32 sb = d >= off ? row[d - off] : arow[HT + d - off];
+                        const u32 sg = d >= off ? g[d - off] : ag[HT + d - off];
+                        nb[d] = p_max(row[d], p_subs(sb, p_add(kg, sg)));
+                    }
+#pragma unroll
+                    for (int d = 0; d < NW; d++) row[d] = nb[d];
+                }
+            }
+            // park this chunk's top half for the next chunk
+            if (ch + 1 < nchunks) {
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    srow[(size_t)t * sstride] = row[HT + t];
+                    srow[(size_t)(HT + t) * sstride] = g[HT + t];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NW; d++) prev[d] = row[d], gprev[d] = g[d];
+        }
+#pragma unroll
+        for (int d = 0; d < NW; d++) maxs[d] = p_max(maxs[d], prev[d]);
+    }
+    u32 mx = maxs[0];
+#pragma unroll
+    for (int d = 1; d < NW; d++) mx = p_max(mx, maxs[d]);
+    return max(mx & 0xFFFF, mx >> 16);
+}

@@ -66,13 +66,15 @@ struct Workspace {
     u32* tile_prefix;   // ntiles + 1
     u32* surv_idx;      // local haystack index of survivor j
     u32* win;           // 2 * survivors: (start, end) windows from the lane-exact prefilter; start=0xFFFFFFFF => rejected
-    u32* overflow;      // (output position, window start, window end, haystack) of items needing the generic scorer
+    u32* overflow;      // queue of (output position, window start, window end, haystack): multi-chunk windows from the front, > 1024-byte windows from the back
+    u32* dp_scratch;    // multi-chunk DP: parked row/gap vectors, [row][dword][thread]
+    size_t dp_scratch_words;
     u64* bitmap2;       // second-level keep bits (after the lane-exact prefilter)
     u32* tile_counts2;
     u32* tile_prefix2;
     u32* items2;        // local haystack index of kept survivor
     u32* win2;          // its window
-    u32* counters;      // [0]=filter survivors [1]=kept by the lane-exact prefilter [2]=output base of the NEXT chunk [3]=sent to the generic scorer
+    u32* counters;      // [0]=filter survivors [1]=kept by the lane-exact prefilter [2]=output base of the NEXT chunk [3]=multi-chunk queue length [4]=greedy (>1024 B) queue length
     u64* table;         // 256 x u64 filter table (device)
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
@@ -87,12 +89,13 @@ struct LaunchCfg {
     int bias_ok;        // DP gap propagation may run in the biased domain (no u16 overflow possible)
     int pad_ok;         // needle has no NUL byte: zero-padding lanes can never match (enables the padded-half DP form)
     int num_cus;
+    u32 dead_byte;      // a byte value no needle row can match (used to neutralise bytes past a haystack's end in the DFA filter)
 };
 
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 // kernels_filter.hip
-void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, int rows, int mode, int need, u32 min_len,
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
 void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, const u32* base_in, u32* base_out, hipStream_t st);
 void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,
@@ -102,7 +105,9 @@ void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const
                        u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st);
 // kernels_dp.hip
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32* counters, int grid, hipStream_t st);
+                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st);
+void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
+                         fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st);

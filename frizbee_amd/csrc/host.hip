@@ -195,7 +195,7 @@ void fzb_config_default(fzb_config* out) {
 }
 
 static void free_workspace(Workspace& w) {
-    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table, w.dfa};
+    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table, w.dfa};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -290,6 +290,9 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
             m->table[nd.f[r]] |= (u64)1 << r;
         }
     }
+    lc.dead_byte = 0;
+    for (int b = 255; b >= 0; b--)
+        if (m->table[b] == 0) { lc.dead_byte = (u32)b; break; }
     // ordered-subsequence DFA: state s = rows matched so far; a byte that can match row s advances it
     m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
     for (int st = 0; st <= m->rows; st++)
@@ -484,7 +487,7 @@ static int run_chunk(fzb_matcher* m, const CorpusDev& cd, int cn, int nchunks, u
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2 + 2 * cn], st));
-        fzb_launch_filter(cd, cfirst, ccnt, w.table, w.dfa, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, bitmap, tile_counts, cus * 8, st);
+        fzb_launch_filter(cd, cfirst, ccnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, bitmap, tile_counts, cus * 8, st);
         if (pev) HIPCHK(hipEventRecord(pev[3 + 2 * cn], st));
         FZB_STAGE("filter");
         if (lc.filter_exact) {  // this scan also chains the output base across chunks: it must follow the previous chunk's
@@ -524,13 +527,31 @@ static int run_chunk(fzb_matcher* m, const CorpusDev& cd, int cn, int nchunks, u
         fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, base_in, dc, cnt_c, cus * 4, st);
         FZB_STAGE("generic(unicode)");
     } else {
-        fzb_launch_dp(cd, cfirst, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, base_in, dc, overflow, cnt_c, cus * 8, st);
+        const u32 qcap = ccnt;  // this chunk's slice of the queue holds ccnt entries
+        fzb_launch_dp(cd, cfirst, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, base_in, dc, overflow, qcap, cnt_c, cus * 8, st);
         FZB_STAGE("dp");
-        // windows wider than one chunk were queued (output position, start, end, haystack) by the DP kernel;
-        // impossible (launch skipped) when no haystack of the corpus is longer than a chunk
-        if (!(cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes))
-            fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow, &cnt_c[3], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c, cus / 2 + 1, st);
-        FZB_STAGE("generic(queued)");
+        // windows wider than one chunk were queued by the DP kernel; impossible (launches skipped) when no haystack of
+        // the corpus is longer than a chunk
+        if (!(cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes)) {
+            const int mgrid = cus * 2;
+            const size_t words = (size_t)(nd.rows + 1) * (size_t)(lc.sw_lanes / 2) * (size_t)mgrid * 128;
+            if (w.dp_scratch_words < words) {
+                // (first use only; a synchronous allocation is acceptable here and never happens in steady state)
+                if (w.dp_scratch) HIPCHK(hipFree(w.dp_scratch));
+                w.dp_scratch = nullptr;
+                w.dp_scratch_words = 0;
+                HIPCHK(dev_alloc((void**)&w.dp_scratch, words * 4));
+                w.dp_scratch_words = words;
+            }
+            fzb_launch_dp_multi(cd, cfirst, index_offset, overflow, &cnt_c[3], nd, lc.sw_lanes, lc.bias_ok, outp, cap32, w.dp_scratch, mgrid, st);
+            FZB_STAGE("dp_multi");
+            if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {
+                // > 1024-byte windows (greedy fallback): queued from the back of the queue slice
+                fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c,
+                                   cus / 4 + 1, st);
+                FZB_STAGE("generic(greedy)");
+            }
+        }
     }
 #undef FZB_STAGE
     return FZB_OK;

@@ -20,7 +20,7 @@ template <int SWL, bool BIAS, typename ET>
 __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                               const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                               const NeedleDev nd, int wmode, int pad_ok, fzb_match_rec* __restrict__ out, u32 capacity, const u32* __restrict__ base_ptr, u32* __restrict__ dev_count,
-                                              u32* __restrict__ overflow, u32* __restrict__ counters) {
+                                              u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters) {
     __shared__ u8 cls[256];
     build_cls_table(cls);
     __syncthreads();
@@ -43,11 +43,20 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
         const bool include_exact = sp == 0 && we == L;
         const u32 m = we - sp;
         if (m > (u32)SWL) {
-            const u32 slot = atomicAdd(&counters[3], 1u);
-            overflow[4 * slot] = base + j;  // (output position, window start, window end, local haystack index)
-            overflow[4 * slot + 1] = ws;
-            overflow[4 * slot + 2] = we;
-            overflow[4 * slot + 3] = li;
+            // wider than one chunk: queued for the multi-chunk kernel (counters[3], front of `overflow`), or - beyond the
+            // reference's 1024-byte matrix limit - for the generic kernel's greedy scorer (counters[4], back of `overflow`)
+            u32* qe;
+            if (m > FZB_MAX_HAYSTACK_LEN) {
+                const u32 slot = atomicAdd(&counters[4], 1u);
+                qe = overflow + 4 * (size_t)(qcap - 1 - slot);
+            } else {
+                const u32 slot = atomicAdd(&counters[3], 1u);
+                qe = overflow + 4 * (size_t)slot;
+            }
+            qe[0] = base + j;  // (output position, window start, window end, local haystack index)
+            qe[1] = ws;
+            qe[2] = we;
+            qe[3] = li;
             continue;
         }
         u32 score = 0;
@@ -71,9 +80,58 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k2d: the queued windows of SWL < m <= 1024 bytes, one thread each, chunk by chunk (dp_multi_chunk).
+// ---------------------------------------------------------------------------------------------------------------
+template <int SWL, bool BIAS, typename ET>
+__global__ __launch_bounds__(128) void k2d_dp_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+                                                    const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
+                                                    fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
+    __shared__ u8 cls[256];
+    build_cls_table(cls);
+    __syncthreads();
+    const u32 nlist = *n_list_ptr;
+    const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u32 q = gtid; q < nlist; q += nthreads) {
+        const u32 opos = list[4 * q], ws = list[4 * q + 1], we = list[4 * q + 2], li = list[4 * q + 3];
+        if (opos >= capacity) continue;
+        u64 s;
+        u32 L;
+        haystack_span(ends, first + li, s, L);
+        const u8* hay = bytes + s;
+        const u32 sp = ws ? ws - 1 : 0;
+        const bool include_exact = sp == 0 && we == L;
+        const u32 m = we - sp;
+        u32 score = dp_multi_chunk<SWL, BIAS>(nd, hay + sp, m, sp == 0, cls, scratch, nthreads, gtid);
+        bool exact = include_exact && m == (u32)nd.nbytes;
+        if (exact)
+            for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+        if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+        fzb_match_rec rec;
+        rec.index = index_offset + li;
+        rec.score = (u16)score;
+        rec.exact = exact ? 1 : 0;
+        rec.valid = 0;
+        out[opos] = rec;
+    }
+}
+
+void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
+                         fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st) {
+#define FZB_K2D(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_multi<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch)
+#define FZB_K2D_ET(SWL, B) do { if (c.ends_u64) FZB_K2D(SWL, B, u64); else FZB_K2D(SWL, B, u32); } while (0)
+#define FZB_K2D_B(SWL) do { if (bias_ok) FZB_K2D_ET(SWL, true); else FZB_K2D_ET(SWL, false); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2D_B(64); break;
+        case 32: FZB_K2D_B(32); break;
+        case 16: FZB_K2D_B(16); break;
+        default: FZB_K2D_B(8); break;
+    }
+}
+
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2B(SWL, B, ET) hipLaunchKernelGGL((k2b_dp<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, base_ptr, dev_count, overflow, counters)
+                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st) {
+#define FZB_K2B(SWL, B, ET) hipLaunchKernelGGL((k2b_dp<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, base_ptr, dev_count, overflow, qcap, counters)
 #define FZB_K2B_ET(SWL, B) do { if (c.ends_u64) FZB_K2B(SWL, B, u64); else FZB_K2B(SWL, B, u32); } while (0)
 #define FZB_K2B_B(SWL) do { if (bias_ok) FZB_K2B_ET(SWL, true); else FZB_K2B_ET(SWL, false); } while (0)
     switch (sw_lanes) {

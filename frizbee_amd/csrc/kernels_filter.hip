@@ -131,9 +131,9 @@ __device__ __forceinline__ u32 dfa_partial(u32 st, const uint4& q, u32 nbytes, c
     return st;
 }
 
-template <typename ET>
+template <typename ET, bool SHORT>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                              const u8* __restrict__ dfa_g, int rows, u32 min_len, u64* __restrict__ bitmap,
+                                              const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
                                               u32* __restrict__ tile_counts) {
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     __shared__ u32 s_cnt;
@@ -162,40 +162,71 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
             if (hl[p] > 16) v1[p] = vp[1];
         }
         u32 st[4] = {0, 0, 0, 0};
-        const bool full0 = hl[0] >= 16 && hl[1] >= 16 && hl[2] >= 16 && hl[3] >= 16;
-        if (full0) {
-            { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4(st, w, dfa); }
-        } else {
+        u32 nvmax = 0;
 #pragma unroll
-            for (int p = 0; p < 4; p++) st[p] = dfa_partial(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
-        }
-        const bool full1 = hl[0] >= 32 && hl[1] >= 32 && hl[2] >= 32 && hl[3] >= 32;
-        if (full1) {
-            { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4(st, w, dfa); }
-        } else {
+        for (int p = 0; p < 4; p++) nvmax = max(nvmax, (hl[p] + 15) >> 4);
+        if (SHORT || nvmax <= 2) {
+            // short haystacks (<= 32 bytes): both vectors are already in flight
+            if (hl[0] >= 16 && hl[1] >= 16 && hl[2] >= 16 && hl[3] >= 16) {
+                { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4(st, w, dfa); }
+                { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4(st, w, dfa); }
+                { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4(st, w, dfa); }
+                { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4(st, w, dfa); }
+            } else {
 #pragma unroll
-            for (int p = 0; p < 4; p++)
-                if (hl[p] > 16) st[p] = dfa_partial(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
+                for (int p = 0; p < 4; p++) st[p] = dfa_partial(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
+            }
+            if (hl[0] >= 32 && hl[1] >= 32 && hl[2] >= 32 && hl[3] >= 32) {
+                { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4(st, w, dfa); }
+                { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4(st, w, dfa); }
+                { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4(st, w, dfa); }
+                { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4(st, w, dfa); }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    if (hl[p] > 16) st[p] = dfa_partial(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
+            }
+        } else {
+            // longer / ragged haystacks: vector by vector over the 4 interleaved chains, requesting two vectors ahead.
+            // Bytes past a haystack's end are replaced by `dead`, a byte value no needle row can match (the needle has at
+            // most 63 rows x 2 cases), so every vector runs the same branch-free unrolled steps.
+            const u32 deadv = dead * 0x01010101u;
+            uint4 cur[4], nxt[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) cur[p] = v0[p], nxt[p] = v1[p];
+            for (u32 v = 0; v < nvmax; v++) {
+                uint4 nn[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    nn[p] = make_uint4(0, 0, 0, 0);
+                    if (hl[p] > 16 * (v + 2)) nn[p] = ((const uint4*)(bytes + hs[p]))[v + 2];
+                }
+                u32 wx[4], wy[4], wz[4], ww[4];
+#pragma unroll
+                for (int p = 0; p < 4; p++) {
+                    const u32 rem = hl[p] > 16 * v ? hl[p] - 16 * v : 0u;  // valid bytes from this vector on
+                    auto san = [&](u32 w, u32 off) {
+                        const u32 nv = rem > off ? rem - off : 0u;
+                        const u32 mask = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1);
+                        return (w & mask) | (deadv & ~mask);
+                    };
+                    wx[p] = san(cur[p].x, 0);
+                    wy[p] = san(cur[p].y, 4);
+                    wz[p] = san(cur[p].z, 8);
+                    ww[p] = san(cur[p].w, 12);
+                }
+                dfa_word4(st, wx, dfa);
+                dfa_word4(st, wy, dfa);
+                dfa_word4(st, wz, dfa);
+                dfa_word4(st, ww, dfa);
+#pragma unroll
+                for (int p = 0; p < 4; p++) cur[p] = nxt[p], nxt[p] = nn[p];
+            }
         }
         u32 cnt = 0;
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const u32 L = hl[p];
-            if (L > 32) {  // longer haystacks: remaining vectors on demand
-                const uint4* vp = (const uint4*)(bytes + hs[p]);
-                const u32 nvec = (L + 15) >> 4;
-                for (u32 v = 2; v < nvec; v++) {
-                    const uint4 qv = vp[v];
-                    const u32 rem = L - 16 * v;
-                    st[p] = dfa_partial(st[p], qv, rem >= 16 ? 16u : rem, dfa);
-                }
-            }
             const u32 li = tile * FZB_TILE + p * 256 + tid;
             const bool matched = li < count && L >= min_len && st[p] == (u32)rows;
             const u64 b = __ballot(matched);
@@ -309,15 +340,18 @@ __global__ __launch_bounds__(256) void k_map(const u64* __restrict__ bitmap, con
 // ---------------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from pipeline.hip)
 // ---------------------------------------------------------------------------------------------------
-void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, int rows, int mode, int need, u32 min_len,
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, int grid, hipStream_t st) {
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     if (mode == 1) {
         const size_t lds = (size_t)(rows + 1) * 256;
-        if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, bitmap, tile_counts);
-        else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, bitmap, tile_counts);
+        const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
+#define FZB_K1D(ET, S) hipLaunchKernelGGL((k1_dfa<ET, S>), dim3(grid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts)
+        if (c.ends_u64) { if (shortc) FZB_K1D(u64, true); else FZB_K1D(u64, false); }
+        else            { if (shortc) FZB_K1D(u32, true); else FZB_K1D(u32, false); }
+#undef FZB_K1D
         return;
     }
     if (mode == 0) {

@@ -96,17 +96,19 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
     const bool active = lane < SWL;
 
     for (u32 q = blockIdx.x * GEN_WAVES + wv; q < nlist; q += gridDim.x * GEN_WAVES) {
-        // list entries: (output position, window start, window end, local haystack index) queued by the single-chunk kernels
-        const u32 j = list ? list[4 * q] : q;          // rank inside this chunk (direct mode) / absolute output position (list mode)
+        // list entries: (output position, window start, window end, local haystack index) queued by the single-chunk kernel
+        // list mode: the queue grows downwards from `list` (the end of the chunk's queue slice): entry q is at list - 4 (q + 1)
+        const u32* le = list ? list - 4 * (size_t)(q + 1) : nullptr;
+        const u32 j = list ? le[0] : q;          // rank inside this chunk (direct mode) / absolute output position (list mode)
         const u32 opos = list ? j : base + j;
         if (opos >= capacity) continue;
-        const u32 li = list ? list[4 * q + 3] : (items ? items[j] : j);
+        const u32 li = list ? le[3] : (items ? items[j] : j);
         u64 s;
         u32 L;
         haystack_span(ends, first + li, s, L);
         const u8* hay = bytes + s;
         u32 ws, we;
-        if (list) { ws = list[4 * q + 1]; we = list[4 * q + 2]; }
+        if (list) { ws = le[1]; we = le[2]; }
         else if (wmode == 2) { ws = 0; we = L; }
         else { ws = win[2 * j]; we = win[2 * j + 1]; }
         const u32 sp = ws ? ws - 1 : 0;
