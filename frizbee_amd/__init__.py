@@ -92,7 +92,7 @@ _lib = None
 SYMBOLS = [
     "fzb_last_error", "fzb_config_default", "fzb_matcher_create", "fzb_matcher_clone", "fzb_matcher_free", "fzb_matcher_info",
     "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_set_max_len", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
-    "fzb_match_list_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
+    "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
 ]
 
@@ -119,6 +119,7 @@ def lib():
         l.fzb_match_list.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzb_match_list_into.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzb_match_list_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        l.fzb_match_list_sorted_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         l.fzb_match_list_parallel.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzb_matches_free.argtypes = [C.c_void_p]
         l.fzb_radix_sort_matches.argtypes = [C.c_void_p, C.c_size_t]
@@ -241,6 +242,10 @@ class Matcher:
         """Device-resident form: records + count stay in HBM, asynchronous on `stream` (a hipStream_t handle)."""
         count = len(corpus) - first if count is None else count
         _check(lib().fzb_match_list_device(self.h, corpus.h, first, count, index_offset, dev_out_ptr, capacity, dev_count_ptr, stream))
+
+    def match_list_sorted_device(self, corpus, dev_out_ptr, capacity, dev_count_ptr, stream=0):
+        """`match_list` with the result left in HBM, already in `config.sort` order (device-side reverse + radix sort)."""
+        _check(lib().fzb_match_list_sorted_device(self.h, corpus.h, dev_out_ptr, capacity, dev_count_ptr, stream))
 
     def set_profiling(self, on=True):
         _check(lib().fzb_set_profiling(self.h, int(on)))

@@ -69,6 +69,9 @@ struct Workspace {
     u32* overflow;      // queue of (output position, window start, window end, haystack): multi-chunk windows from the front, > 1024-byte windows from the back
     u32* dp_scratch;    // multi-chunk DP: parked row/gap vectors, [row][dword][thread]
     size_t dp_scratch_words;
+    fzb_match_rec* sort_tmp;  // device radix sort: ping-pong buffer + digit-major tile histogram
+    u32* sort_hist;
+    size_t sort_cap;
     u64* bitmap2;       // second-level keep bits (after the lane-exact prefilter)
     u32* tile_counts2;
     u32* tile_prefix2;
@@ -108,6 +111,8 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
                    int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st);
 void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
+// kernels_sort.hip
+void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st);

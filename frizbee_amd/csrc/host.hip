@@ -195,7 +195,7 @@ void fzb_config_default(fzb_config* out) {
 }
 
 static void free_workspace(Workspace& w) {
-    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table, w.dfa};
+    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table, w.dfa};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -641,6 +641,29 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     return FZB_OK;
 }
 
+int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream) {
+    if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
+    int rc = fzb_match_list_device(m, c, 0, c->dev.n, 0, dev_out, capacity, dev_count, stream);
+    if (rc) return rc;
+    const int sort = m->config.sort;
+    const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;          // src/matcher/mod.rs:215-217
+    const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;  // :218-220
+    if ((!reversed && !by_score) || c->dev.n == 0) return FZB_OK;
+    Workspace& w = m->ws;
+    const size_t cap = std::min<size_t>(capacity, c->dev.n);
+    if (by_score && w.sort_cap < cap) {
+        if (w.sort_tmp) HIPCHK(hipFree(w.sort_tmp));
+        if (w.sort_hist) HIPCHK(hipFree(w.sort_hist));
+        w.sort_tmp = nullptr; w.sort_hist = nullptr; w.sort_cap = 0;
+        HIPCHK(dev_alloc((void**)&w.sort_tmp, (cap + 16) * sizeof(fzb_match_rec)));
+        HIPCHK(dev_alloc((void**)&w.sort_hist, (size_t)256 * (cap / 2048 + 2) * 4));
+        w.sort_cap = cap;
+    }
+    fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream);
+    HIPCHK(hipGetLastError());
+    return FZB_OK;
+}
+
 int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len) {
     if (!m || !c || !out || !out_len) return fail(FZB_ERR_INVALID, "null argument");
     if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
@@ -692,12 +715,34 @@ void fzb_radix_sort_matches(fzb_match* matches, size_t n) {  // src/sort.rs:6-40
 }
 
 int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t* out_len) {
-    if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
-    int rc = fzb_match_list_into(m, c, 0, c->dev.n, 0, out, out_len);
-    if (rc) return rc;
+    if (!m || !c || !out || !out_len) return fail(FZB_ERR_INVALID, "null argument");
     const int sort = m->config.sort;
-    if (sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC) std::reverse(*out, *out + *out_len);              // mod.rs:215-217
-    if (!m->empty && (sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC)) fzb_radix_sort_matches(*out, *out_len);  // :218-220
+    if (m->empty) {  // CompiledPatterns::Empty: every index, score 0, reversed if the strategy says so, never sorted (mod.rs:215-220, 381-384)
+        int rc = fzb_match_list_into(m, c, 0, c->dev.n, 0, out, out_len);
+        if (rc) return rc;
+        if (sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC) std::reverse(*out, *out + *out_len);
+        return FZB_OK;
+    }
+    const size_t count = c->dev.n;
+    *out = nullptr;
+    *out_len = 0;
+    if (m->out_cap < count || !m->count_dev) {
+        if (m->out_dev) (void)hipFree(m->out_dev);
+        m->out_dev = nullptr;
+        m->out_cap = 0;
+        HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
+        m->out_cap = count;
+        if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
+    }
+    // scoring AND the reverse / stable radix sort post-step run on the device; the host only receives the final list
+    int rc = fzb_match_list_sorted_device(m, c, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
+    if (rc) return rc;
+    u32 n = 0;
+    HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));
+    fzb_match* r = (fzb_match*)malloc(std::max<size_t>(n, 1) * sizeof(fzb_match));
+    if (n) HIPCHK(hipMemcpy(r, m->out_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost));
+    *out = r;
+    *out_len = n;
     return FZB_OK;
 }
 

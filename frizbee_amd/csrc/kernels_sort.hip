@@ -1,0 +1,146 @@
+// gfx950 kernels, stage 3 (ordering): `radix_sort_matches` on the device.
+//
+// Reference: src/sort.rs:6-40 - a STABLE least-significant-digit radix sort of the Match records by `score`,
+// descending, two passes of 8 bits; ties keep their input order (the input is index-ascending, or index-descending
+// after the reverse that `match_list` applies for the *Desc strategies, src/matcher/mod.rs:215-221).
+// Same algorithm here, each pass as histogram -> exclusive scan -> stable scatter:
+//   * a tile = 2048 consecutive records, processed in order by one workgroup, 256 at a time;
+//   * digit' = 255 - digit so ascending bucket order is descending score order;
+//   * inside a wave the rank among equal digits is found with 8 ballots (one per digit bit: lanes holding the same
+//     digit = AND of the matching ballot masks), waves of a 256-record slab are ordered through a per-wave histogram
+//     in LDS, slabs through a running per-digit counter - so equal keys never overtake each other.
+// The record count lives in device memory (no host round trip); grids are sized for the capacity.
+#include "kernels_common.h"
+
+#define SORT_TILE 2048
+
+__device__ __forceinline__ u32 sort_digit(const fzb_match_rec& r, int shift) { return 255u - ((r.score >> shift) & 0xFFu); }
+
+// hist[d * ntiles_cap + tile] = number of records of tile with digit' d
+__global__ __launch_bounds__(256) void k_sort_hist(const fzb_match_rec* __restrict__ in, const u32* __restrict__ n_ptr, int shift, u32* __restrict__ hist,
+                                                   u32 ntiles_cap) {
+    __shared__ u32 h[256];
+    const u32 n = *n_ptr;
+    const u32 ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const u32 lo = tile * SORT_TILE, hi = min(lo + SORT_TILE, n);
+        for (u32 i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[sort_digit(in[i], shift)], 1u);
+        __syncthreads();
+        hist[threadIdx.x * ntiles_cap + tile] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// exclusive scan, in place, of the digit-major histogram: 256 rows of `ntiles` live entries (row stride ntiles_cap)
+__global__ __launch_bounds__(1024) void k_sort_scan(u32* __restrict__ hist, const u32* __restrict__ n_ptr, u32 ntiles_cap) {
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry_s;
+    const u32 n = *n_ptr;
+    const u32 ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const u32 total = 256 * ntiles;  // logical element e -> hist[(e / ntiles) * ntiles_cap + e % ntiles]
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (u32 base = 0; base < total; base += 1024 * 8) {
+        u32 v[8];
+        u32 sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 e = base + threadIdx.x * 8 + k;
+            v[k] = e < total ? hist[(e / ntiles) * ntiles_cap + e % ntiles] : 0u;
+            sum += v[k];
+        }
+        u32 incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 t = __shfl_up(incl, off);
+            if (lane_id() >= off) incl += t;
+        }
+        const int wave = threadIdx.x >> 6;
+        if (lane_id() == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 wbase = carry_s;
+        for (int w = 0; w < wave; w++) wbase += wsum[w];
+        u32 run = wbase + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 e = base + threadIdx.x * 8 + k;
+            if (e < total) hist[(e / ntiles) * ntiles_cap + e % ntiles] = run;
+            run += v[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = run;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(const fzb_match_rec* __restrict__ in, fzb_match_rec* __restrict__ out, const u32* __restrict__ n_ptr,
+                                                      int shift, const u32* __restrict__ offs, u32 ntiles_cap) {
+    __shared__ u32 wave_hist[4][256];
+    __shared__ u32 run[256];
+    const u32 n = *n_ptr;
+    const u32 ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        run[tid] = offs[tid * ntiles_cap + tile];  // where this tile's records with digit' = tid start
+        const u32 lo = tile * SORT_TILE, hi = min(lo + SORT_TILE, n);
+        for (u32 base = lo; base < hi; base += 256) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) wave_hist[w][tid] = 0;
+            __syncthreads();
+            const u32 i = base + tid;
+            const bool valid = i < hi;
+            fzb_match_rec r;
+            u32 d = 0;
+            if (valid) {
+                r = in[i];
+                d = sort_digit(r, shift);
+            }
+            // lanes of this wave holding the same digit (and valid)
+            u64 peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const u64 bal = __ballot((d >> b) & 1);
+                peers &= ((d >> b) & 1) ? bal : ~bal;
+            }
+            const u32 rank = __popcll(peers & (((u64)1 << lane) - 1));
+            if (valid && rank == 0) wave_hist[wave][d] = __popcll(peers);
+            __syncthreads();
+            // digit tid: order the four waves, advance the running offset
+            const u32 c0 = wave_hist[0][tid], c1 = wave_hist[1][tid], c2 = wave_hist[2][tid], c3 = wave_hist[3][tid];
+            const u32 b0 = run[tid];
+            __syncthreads();
+            wave_hist[0][tid] = b0;
+            wave_hist[1][tid] = b0 + c0;
+            wave_hist[2][tid] = b0 + c0 + c1;
+            wave_hist[3][tid] = b0 + c0 + c1 + c2;
+            run[tid] = b0 + c0 + c1 + c2 + c3;
+            __syncthreads();
+            if (valid) out[wave_hist[wave][d] + rank] = r;
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reverse(fzb_match_rec* __restrict__ a, const u32* __restrict__ n_ptr) {
+    const u32 n = *n_ptr;
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n / 2; i += gridDim.x * blockDim.x) {
+        const fzb_match_rec x = a[i], y = a[n - 1 - i];
+        a[i] = y;
+        a[n - 1 - i] = x;
+    }
+}
+
+// records: `buf` (n = *n_ptr records, capacity cap) sorted in place; tmp >= cap records; hist >= 256 * ntiles_cap words
+void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st) {
+    if (reverse_first) hipLaunchKernelGGL(k_reverse, dim3(grid), dim3(256), 0, st, buf, n_ptr);
+    if (!by_score) return;
+    for (int pass = 0; pass < 2; pass++) {
+        const fzb_match_rec* src = pass == 0 ? buf : tmp;
+        fzb_match_rec* dst = pass == 0 ? tmp : buf;
+        const int shift = pass * 8;
+        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, src, n_ptr, shift, hist, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, hist, n_ptr, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, src, dst, n_ptr, shift, hist, ntiles_cap);
+    }
+}

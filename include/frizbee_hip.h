@@ -100,8 +100,8 @@ void fzb_corpus_free(fzb_corpus* c);
 size_t fzb_corpus_len(const fzb_corpus* c);
 
 /* `Matcher::match_list(&haystacks)` (src/matcher/mod.rs:212-222) = `match_list_into(.., offset 0)` ->
- * `Specialized::match_list::<TYPOS,UNICODE,_>` (src/matcher/algo.rs:78-103) on the GPU, then the reverse /
- * `radix_sort_matches` post-step (src/sort.rs:6-40) on the host.  `*out` is malloc'd by the library
+* `Specialized::match_list::<TYPOS,UNICODE,_>` (src/matcher/algo.rs:78-103) and the reverse / `radix_sort_matches`
+ * post-step (src/sort.rs:6-40), all on the GPU.  `*out` is malloc'd by the library
  * (free with fzb_matches_free) and holds exactly the Vec<Match> the reference returns, in its order. */
 int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t* out_len);
 
@@ -116,6 +116,11 @@ int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
  * (one uint32 in device memory), asynchronously on `stream`.  No host synchronisation. */
 int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset,
                           fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);
+
+/* `Matcher::match_list` entirely in HBM: the records of the WHOLE corpus in the order `config.sort` asks for
+ * (reverse for the *Desc strategies, then the stable descending radix sort of src/sort.rs:6-40 for the Score* strategies,
+ * both as device kernels).  fzb_match_list is this call + one device-to-host copy. */
+int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);
 
 /* `Matcher::match_list_parallel(&haystacks, threads)` (src/matcher/parallel.rs:18-89).  The GPU processes the
  * whole list in one pass, so `threads` only keeps the reference's contract: 0 => FZB_ERR_PANIC
