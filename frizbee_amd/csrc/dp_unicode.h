@@ -1,0 +1,188 @@
+// Thread-per-haystack single-chunk form of the reference's UNICODE Smith-Waterman (score_haystack_unicode,
+// src/smith_waterman/algo/unicode.rs:10-273, propagate_horizontal_unicode_gaps, src/smith_waterman/algo/unicode_gap.rs:110-236).
+// Rows are needle SCALARS, lanes are haystack BYTES; only the first byte lane of a haystack scalar can match, and
+// UTF-8 continuation bytes are zero-cost "transport" lanes for horizontal gaps.
+//
+// The reference carries, through its log-step gap scan, three per-step vectors that do not depend on the needle row:
+//   cont_s[L] = gex * #continuation lanes in (L-s, L]   (so  tot_s - cont_s = gex * #NON-continuation lanes crossed),
+//   sm_s[L]   = "a scalar start lies in (L-s, L]",       and the pending-gap-open mask that follows the match lanes.
+// Both windowed quantities are differences of prefix counts, so with
+//   Q[L] = #scalar-start lanes in [0, L]   and   P[L] = gex * #non-continuation lanes in [0, L]  (padding lanes count)
+// the step  cand = shift_s(row) (-) ((tot_s (-) cont_s) + (gop' & shift_s(pending) & sm_s))  becomes, in the biased domain
+// r'[L] = r[L] + P[L]:   cand'[L] = r'[L-s] (-) (gop' & pending[L-s] & (Q[L] != Q[L-s])).
+// Exactness of the bias is the same argument as in dp_body.h (row values are >= 0, so r'[L] >= P[L] >= P[L-s]).
+// Single chunk only: the adjacent chunk is the zero column.  Wider windows go to the generic wave-per-haystack kernel.
+#pragma once
+#include "dp_body.h"
+
+typedef short ss2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 p_neg_mask(u32 neg) {  // per 16-bit lane: 0xFFFF if the lane (as i16) is negative else 0
+    return __builtin_bit_cast(u32, __builtin_bit_cast(ss2, neg) >> 15);
+}
+// 0x80 in every byte of x that is zero (exact)
+__device__ __forceinline__ u32 zflag4(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }
+
+template <int SWL>
+__device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls) {
+    constexpr int NW = SWL / 2;
+    constexpr int NB = SWL / 4;
+    const u32 rows = (u32)nd.rows;
+    const u32 ONE = 0x00010001u;
+    const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
+    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+    // ---- bytes (+1 guard dword of zeros for the shifted views) ----
+    u32 hb[NB + 1];
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        const u32 p = 4 * k;
+        u32 v = 0;
+        if (p < m) {
+            v = load_u32_unaligned(th, p);
+            const u32 rem = m - p;
+            if (rem < 4) v &= (1u << (8 * rem)) - 1;
+        }
+        hb[k] = v;
+    }
+    hb[NB] = 0;
+    // ---- per-byte scalar-start flags (0x80 where valid && !continuation), prefix counts Q, bonus ----
+    u32 sflag[NB];
+    u32 Q[NW], bonus[NW];
+    {
+        u32 clsw_prev = 0;
+        u32 qrun = 0;  // running count, replicated in both halves
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const u32 w = hb[k];
+            // continuation byte: 0x80..0xBF  <=>  (b & 0xC0) == 0x80
+            const u32 contf = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u);
+            // valid lanes: position < m
+            const u32 p = 4 * k;
+            const u32 nv = m > p ? min(m - p, 4u) : 0u;
+            const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
+            sflag[k] = validf & ~contf;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int d = 2 * k + h;
+                const u32 b0 = h ? (w >> 16) & 0xFF : w & 0xFF;
+                const u32 b1 = h ? w >> 24 : (w >> 8) & 0xFF;
+                const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
+                const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);
+                const u32 cap01 = (clsw >> 1) & sh & ONE;
+                const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;
+                bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+                clsw_prev = clsw;
+                // scalar-start 0/1 for the two lanes of this dword
+                const u32 t = sflag[k] >> 7;
+                const u32 s0 = h ? (t >> 16) & 1 : t & 1;
+                const u32 s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
+                const u32 q0 = qrun + s0, q1 = q0 + s1;
+                Q[d] = q0 | (q1 << 16);
+                qrun = q1;
+            }
+        }
+        if (include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
+    }
+    const u32 mv = splat16(m);
+    // P[d] = gex * (Q[d] + #padding lanes up to and including the lane) ; padding lanes are non-continuation lanes too
+    auto Pof = [&](int d) {
+        const u32 lanepos1 = (u32)(2 * d + 1) | ((u32)(2 * d + 2) << 16);
+        return p_mul(p_add(Q[d], p_subs(lanepos1, mv)), gexv);
+    };
+    u32 prev[NW], upm[NW];
+#pragma unroll
+    for (int d = 0; d < NW; d++) prev[d] = 0, upm[d] = 0;
+#pragma unroll 1
+    for (u32 r = 0; r < rows; r++) {
+        const u32 cl = nd.ulen[r];
+        const u8* uc = nd.uc[r];
+        const u8* uf = nd.uf[r];
+        const bool two = (uc[0] != uf[0]) || (uc[1] != uf[1]) || (uc[2] != uf[2]) || (uc[3] != uf[3]);
+        // ---- byte-level match flags: scalar start && bytes [L, L+cl) equal the needle scalar (unicode.rs:221-241) ----
+        u32 row[NW], pend[NW], mmv[NW];
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const u32 w0 = hb[k];
+            const u32 w1 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 1);
+            const u32 w2 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 2);
+            const u32 w3 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 3);
+            const u32 wl = cl == 1 ? w0 : cl == 2 ? w1 : cl == 3 ? w2 : w3;  // view holding each lane's LAST scalar byte
+            u32 fe = zflag4(wl ^ (uc[cl - 1] * 0x01010101u)) & sflag[k];
+            if (cl > 1) fe &= zflag4(w0 ^ (uc[0] * 0x01010101u));
+            if (cl > 2) fe &= zflag4(w1 ^ (uc[1] * 0x01010101u));
+            if (cl > 3) fe &= zflag4(w2 ^ (uc[2] * 0x01010101u));
+            u32 fm = fe;
+            if (two) {
+                u32 ff = zflag4(wl ^ (uf[cl - 1] * 0x01010101u)) & sflag[k];
+                if (cl > 1) ff &= zflag4(w0 ^ (uf[0] * 0x01010101u));
+                if (cl > 2) ff &= zflag4(w1 ^ (uf[1] * 0x01010101u));
+                if (cl > 3) ff &= zflag4(w2 ^ (uf[2] * 0x01010101u));
+                fm |= ff;
+            }
+            // expand to per-lane 16-bit masks (two score dwords per byte dword)
+            const u32 te = fe >> 7, tm = fm >> 7;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int d = 2 * k + h;
+                const u32 sel = h ? 0x0c030c02u : 0x0c010c00u;
+                const u32 e01 = __builtin_amdgcn_perm(0u, te, sel) & ONE;
+                const u32 m01 = __builtin_amdgcn_perm(0u, tm, sel) & ONE;
+                const u32 exm = p_sub(0u, e01), mmk = p_sub(0u, m01);  // 0xFFFF where set
+                // scalar-start mask of the two lanes, from the prefix counts
+                const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : 0u, 16);
+                const u32 sst = p_neg_mask(p_sub(qs, Q[d]));
+                // diagonal / up (unicode.rs:165-182), both masked to scalar-start lanes
+                const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : 0u, 16);
+                u32 t = p_add(sh, mmk & bonus[d]);
+                t = p_subs(t, Xv);
+                const u32 diag = p_add(t, exm & casev);
+                const u32 up = p_subs(p_subs(prev[d], gexv), upm[d] & gopmv);
+                row[d] = p_max(diag, up) & sst;
+                pend[d] = mmk;
+                mmv[d] = mmk;
+            }
+        }
+        // ---- propagate_horizontal_unicode_gaps in the biased domain ----
+#pragma unroll
+        for (int d = 0; d < NW; d++) row[d] = p_add(row[d], Pof(d));
+        {
+            u32 nb[NW], np[NW];
+#pragma unroll
+            for (int d = 0; d < NW; d++) {
+                const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : 0u, 16);
+                const u32 ps = __builtin_amdgcn_alignbit(pend[d], d ? pend[d - 1] : 0u, 16);
+                const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : 0u, 16);
+                const u32 fl = p_neg_mask(p_sub(qs, Q[d]));  // a scalar start lies in (L-1, L]
+                nb[d] = p_max(row[d], p_subs(bs, ps & fl & gopmv));
+                np[d] = pend[d] | (ps & ~fl);
+            }
+#pragma unroll
+            for (int d = 0; d < NW; d++) row[d] = nb[d], pend[d] = np[d];
+        }
+#pragma unroll
+        for (int off = 1; off < NW; off *= 2) {
+            u32 nb[NW], np[NW];
+#pragma unroll
+            for (int d = 0; d < NW; d++) {
+                if (d >= off) {
+                    const u32 fl = p_neg_mask(p_sub(Q[d - off], Q[d]));
+                    nb[d] = p_max(row[d], p_subs(row[d - off], pend[d - off] & fl & gopmv));
+                    np[d] = pend[d] | (pend[d - off] & ~fl);
+                } else {
+                    nb[d] = row[d];
+                    np[d] = pend[d];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NW; d++) row[d] = nb[d], pend[d] = np[d];
+        }
+#pragma unroll
+        for (int d = 0; d < NW; d++) {
+            prev[d] = p_sub(row[d], Pof(d));
+            upm[d] = mmv[d];
+        }
+    }
+    u32 mx = prev[0];
+#pragma unroll
+    for (int d = 1; d < NW; d++) mx = p_max(mx, prev[d]);
+    return max(mx & 0xFFFF, mx >> 16);
+}

@@ -523,7 +523,17 @@ static int run_chunk(fzb_matcher* m, const CorpusDev& cd, int cn, int nchunks, u
         wmode = 0;
     }
     u32* dc = last ? dev_count : nullptr;
-    if (nd.unicode) {
+    if (nd.unicode && lc.bias_ok) {
+        // thread-per-haystack single-chunk unicode scorer; wider windows are queued (from the back) for the generic kernel
+        const u32 qcap = ccnt;
+        fzb_launch_dp_unicode(cd, cfirst, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, base_in, dc, overflow, qcap, cnt_c, cus * 8, st);
+        FZB_STAGE("dp(unicode)");
+        if (!(cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes)) {
+            fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, nullptr, cnt_c, cus * 2,
+                               st);
+            FZB_STAGE("generic(unicode, queued)");
+        }
+    } else if (nd.unicode) {
         fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, base_in, dc, cnt_c, cus * 4, st);
         FZB_STAGE("generic(unicode)");
     } else {
