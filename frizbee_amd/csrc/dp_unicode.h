@@ -45,7 +45,6 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
     }
     hb[NB] = 0;
     // ---- per-byte scalar-start flags (0x80 where valid && !continuation), prefix counts Q, bonus ----
-    u32 sflag[NB];
     u32 Q[NW], bonus[NW];
     {
         u32 clsw_prev = 0;
@@ -59,7 +58,7 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
             const u32 p = 4 * k;
             const u32 nv = m > p ? min(m - p, 4u) : 0u;
             const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
-            sflag[k] = validf & ~contf;
+            const u32 sflagk = validf & ~contf;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int d = 2 * k + h;
@@ -72,7 +71,7 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
                 bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
                 clsw_prev = clsw;
                 // scalar-start 0/1 for the two lanes of this dword
-                const u32 t = sflag[k] >> 7;
+                const u32 t = sflagk >> 7;
                 const u32 s0 = h ? (t >> 16) & 1 : t & 1;
                 const u32 s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
                 const u32 q0 = qrun + s0, q1 = q0 + s1;
@@ -98,7 +97,7 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
         const u8* uf = nd.uf[r];
         const bool two = (uc[0] != uf[0]) || (uc[1] != uf[1]) || (uc[2] != uf[2]) || (uc[3] != uf[3]);
         // ---- byte-level match flags: scalar start && bytes [L, L+cl) equal the needle scalar (unicode.rs:221-241) ----
-        u32 row[NW], pend[NW], mmv[NW];
+        u32 row[NW], pend[NW];
 #pragma unroll
         for (int k = 0; k < NB; k++) {
             const u32 w0 = hb[k];
@@ -106,13 +105,13 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
             const u32 w2 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 2);
             const u32 w3 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 3);
             const u32 wl = cl == 1 ? w0 : cl == 2 ? w1 : cl == 3 ? w2 : w3;  // view holding each lane's LAST scalar byte
-            u32 fe = zflag4(wl ^ (uc[cl - 1] * 0x01010101u)) & sflag[k];
+            u32 fe = zflag4(wl ^ (uc[cl - 1] * 0x01010101u));
             if (cl > 1) fe &= zflag4(w0 ^ (uc[0] * 0x01010101u));
             if (cl > 2) fe &= zflag4(w1 ^ (uc[1] * 0x01010101u));
             if (cl > 3) fe &= zflag4(w2 ^ (uc[2] * 0x01010101u));
             u32 fm = fe;
             if (two) {
-                u32 ff = zflag4(wl ^ (uf[cl - 1] * 0x01010101u)) & sflag[k];
+                u32 ff = zflag4(wl ^ (uf[cl - 1] * 0x01010101u));
                 if (cl > 1) ff &= zflag4(w0 ^ (uf[0] * 0x01010101u));
                 if (cl > 2) ff &= zflag4(w1 ^ (uf[1] * 0x01010101u));
                 if (cl > 3) ff &= zflag4(w2 ^ (uf[2] * 0x01010101u));
@@ -126,60 +125,46 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
                 const u32 sel = h ? 0x0c030c02u : 0x0c010c00u;
                 const u32 e01 = __builtin_amdgcn_perm(0u, te, sel) & ONE;
                 const u32 m01 = __builtin_amdgcn_perm(0u, tm, sel) & ONE;
-                const u32 exm = p_sub(0u, e01), mmk = p_sub(0u, m01);  // 0xFFFF where set
-                // scalar-start mask of the two lanes, from the prefix counts
+                // scalar-start mask of the two lanes, from the prefix counts; only scalar-start lanes can match
                 const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : 0u, 16);
                 const u32 sst = p_neg_mask(p_sub(qs, Q[d]));
+                const u32 exm = p_sub(0u, e01) & sst, mmk = p_sub(0u, m01) & sst;  // 0xFFFF where set
                 // diagonal / up (unicode.rs:165-182), both masked to scalar-start lanes
                 const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : 0u, 16);
                 u32 t = p_add(sh, mmk & bonus[d]);
                 t = p_subs(t, Xv);
                 const u32 diag = p_add(t, exm & casev);
-                const u32 up = p_subs(p_subs(prev[d], gexv), upm[d] & gopmv);
+                const u32 up = p_subs(p_subs(prev[d], gexv), upm[d] & gopmv);  // upm[d] still holds the PREVIOUS row's match mask
                 row[d] = p_max(diag, up) & sst;
                 pend[d] = mmk;
-                mmv[d] = mmk;
+                upm[d] = mmk;  // ... and from here on this row's (read again only by the next row)
             }
         }
         // ---- propagate_horizontal_unicode_gaps in the biased domain ----
 #pragma unroll
         for (int d = 0; d < NW; d++) row[d] = p_add(row[d], Pof(d));
-        {
-            u32 nb[NW], np[NW];
+        // every step updates in place from the highest dword down: entry d only reads entries <= d, which are still the
+        // values from before the step (keeps the live register set to one copy of row / pending)
 #pragma unroll
-            for (int d = 0; d < NW; d++) {
-                const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : 0u, 16);
-                const u32 ps = __builtin_amdgcn_alignbit(pend[d], d ? pend[d - 1] : 0u, 16);
-                const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : 0u, 16);
-                const u32 fl = p_neg_mask(p_sub(qs, Q[d]));  // a scalar start lies in (L-1, L]
-                nb[d] = p_max(row[d], p_subs(bs, ps & fl & gopmv));
-                np[d] = pend[d] | (ps & ~fl);
-            }
-#pragma unroll
-            for (int d = 0; d < NW; d++) row[d] = nb[d], pend[d] = np[d];
+        for (int d = NW - 1; d >= 0; d--) {
+            const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : 0u, 16);
+            const u32 ps = __builtin_amdgcn_alignbit(pend[d], d ? pend[d - 1] : 0u, 16);
+            const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : 0u, 16);
+            const u32 fl = p_neg_mask(p_sub(qs, Q[d]));  // a scalar start lies in (L-1, L]
+            row[d] = p_max(row[d], p_subs(bs, ps & fl & gopmv));
+            pend[d] = pend[d] | (ps & ~fl);
         }
 #pragma unroll
         for (int off = 1; off < NW; off *= 2) {
-            u32 nb[NW], np[NW];
 #pragma unroll
-            for (int d = 0; d < NW; d++) {
-                if (d >= off) {
-                    const u32 fl = p_neg_mask(p_sub(Q[d - off], Q[d]));
-                    nb[d] = p_max(row[d], p_subs(row[d - off], pend[d - off] & fl & gopmv));
-                    np[d] = pend[d] | (pend[d - off] & ~fl);
-                } else {
-                    nb[d] = row[d];
-                    np[d] = pend[d];
-                }
+            for (int d = NW - 1; d >= off; d--) {
+                const u32 fl = p_neg_mask(p_sub(Q[d - off], Q[d]));
+                row[d] = p_max(row[d], p_subs(row[d - off], pend[d - off] & fl & gopmv));
+                pend[d] = pend[d] | (pend[d - off] & ~fl);
             }
-#pragma unroll
-            for (int d = 0; d < NW; d++) row[d] = nb[d], pend[d] = np[d];
         }
 #pragma unroll
-        for (int d = 0; d < NW; d++) {
-            prev[d] = p_sub(row[d], Pof(d));
-            upm[d] = mmv[d];
-        }
+        for (int d = 0; d < NW; d++) prev[d] = p_sub(row[d], Pof(d));
     }
     u32 mx = prev[0];
 #pragma unroll

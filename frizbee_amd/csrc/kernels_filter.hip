@@ -314,25 +314,33 @@ template <int LEVEL>
 __global__ __launch_bounds__(256) void k_map(const u64* __restrict__ bitmap, const u32* __restrict__ prefix, const u32* __restrict__ n_items_ptr, u32 n_items_host,
                                              u32* __restrict__ out_idx, const u32* __restrict__ in_idx, const u32* __restrict__ in_win, u32* __restrict__ out_win) {
     const u32 n_items = n_items_ptr ? *n_items_ptr : n_items_host;
-    const u32 nwords = (n_items + 63) / 64;
-    for (u32 w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
-        u64 bits = bitmap[w];
-        if (!bits) continue;
-        const u32 tile = w / (FZB_TILE / 64);
-        u32 pos = prefix[tile];
-        for (u32 k = tile * (FZB_TILE / 64); k < w; k++) pos += __popcll(bitmap[k]);
-        while (bits) {
-            const int b = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            const u32 item = w * 64 + b;
-            if (LEVEL == 1) {
-                out_idx[pos] = item;
-            } else {
-                out_idx[pos] = in_idx[item];
-                out_win[2 * pos] = in_win[2 * item];
-                out_win[2 * pos + 1] = in_win[2 * item + 1];
+    if (LEVEL == 1) {
+        // sparse (a few set bits per word): one thread per bitmap word
+        const u32 nwords = (n_items + 63) / 64;
+        for (u32 w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
+            u64 bits = bitmap[w];
+            if (!bits) continue;
+            const u32 tile = w / (FZB_TILE / 64);
+            u32 pos = prefix[tile];
+            for (u32 k = tile * (FZB_TILE / 64); k < w; k++) pos += __popcll(bitmap[k]);
+            while (bits) {
+                const int b = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                out_idx[pos++] = w * 64 + b;
             }
-            pos++;
+        }
+    } else {
+        // dense (most survivors are kept): one thread per item, each computing its own rank, so the payload gather is coalesced
+        for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n_items; j += gridDim.x * blockDim.x) {
+            const u32 w = j >> 6;
+            const u64 bits = bitmap[w];
+            if (!((bits >> (j & 63)) & 1)) continue;
+            const u32 tile = j / FZB_TILE;
+            u32 pos = prefix[tile] + __popcll(bits & (((u64)1 << (j & 63)) - 1));
+            for (u32 k = tile * (FZB_TILE / 64); k < w; k++) pos += __popcll(bitmap[k]);
+            out_idx[pos] = in_idx ? in_idx[j] : j;
+            out_win[2 * pos] = in_win[2 * j];
+            out_win[2 * pos + 1] = in_win[2 * j + 1];
         }
     }
 }

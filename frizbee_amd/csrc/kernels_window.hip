@@ -31,6 +31,25 @@ __device__ __forceinline__ u64 m_clear_through_lowest(u64 self, u64 hit) { retur
 // PFL bytes of the haystack starting at byte `pos` (haystack-relative), zero beyond `len`.
 template <int PFL>
 __device__ __forceinline__ void load_chunk(Chunk<PFL>& c, const u8* __restrict__ hay, u32 pos, u32 len) {
+    if ((pos & 15) == 0) {
+        // `hay` is 16-byte aligned (padded-16 layout): whole-vector loads, zero beyond len (>= 80 readable bytes follow the corpus)
+#pragma unroll
+        for (int v = 0; v < Chunk<PFL>::NW / 4; v++) {
+            const u32 p = pos + 16 * v;
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (p < len) q = *(const uint4*)(hay + p);
+            const u32 w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 pk = p + 4 * k;
+                u32 x = w4[k];
+                if (pk >= len) x = 0;
+                else if (len - pk < 4) x &= (1u << (8 * (len - pk))) - 1;
+                c.w[4 * v + k] = x;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < Chunk<PFL>::NW; k++) {
         const u32 p = pos + 4 * k;
@@ -60,8 +79,12 @@ __device__ __forceinline__ u64 eq_mask(const Chunk<PFL>& c, u32 v) {
 }
 template <int PFL>
 __device__ __forceinline__ u64 occ_mask(const Chunk<PFL>& c, u32 a, u32 b) {
-    u64 m = eq_mask<PFL>(c, a);
-    if (b != a) m |= eq_mask<PFL>(c, b);
+    if (b == a) return eq_mask<PFL>(c, a);
+    // a / b are the two cases of one ASCII letter (they differ only in bit 5): (h | 0x20) == (a | 0x20)  <=>  h in {a, b}
+    const u32 sp = (a | 0x20u) * 0x01010101u;
+    u64 m = 0;
+#pragma unroll
+    for (int k = 0; k < Chunk<PFL>::NW; k++) m |= (u64)zero_bytes4((c.w[k] | 0x20202020u) ^ sp) << (4 * k);
     return m;
 }
 
@@ -95,8 +118,21 @@ struct UnicodeSrc {
     __device__ UnicodeSrc(const NeedleDev& n, const u8* h, u32 l) : nd(n), hay(h), len(l), start(0) {}
     __device__ __forceinline__ void load(u32 s) {
         start = s;
+        // one pass over memory: the window at +0 plus one guard dword; the +1..+3 windows are byte-shifts of it
+        load_chunk<PFL>(ch[0], hay, s, len);
+        u32 guard = 0;
+        {
+            const u32 p = s + PFL;
+            if (p < len) {
+                guard = load_u32_unaligned(hay, p);
+                if (len - p < 4) guard &= (1u << (8 * (len - p))) - 1;
+            }
+        }
 #pragma unroll
-        for (int o = 0; o < 4; o++) load_chunk<PFL>(ch[o], hay, s + o, len);
+        for (int o = 1; o < 4; o++)
+#pragma unroll
+            for (int k = 0; k < Chunk<PFL>::NW; k++)
+                ch[o].w[k] = __builtin_amdgcn_alignbyte(k + 1 < Chunk<PFL>::NW ? ch[0].w[k + 1] : guard, ch[0].w[k], o);
     }
     // match_unicode_char_prefix + char_variant_mask (unicode.rs:9-72) for one case variant
     __device__ __forceinline__ u64 variant(const u8 chars[4], u32 cl, u64 chunk_mask) const {
