@@ -9,7 +9,7 @@ owns a contiguous 10M-item shard of a 10M*N list (global index offset), scores i
 the per-shard match lists are exchanged with one RCCL all-gather-v (frizbee_amd/distributed.py) inside the step.
 
 Prints ONE JSON line on rank 0 (see the driver contract): value = haystacks scored per second, whole job.
-  roofline     : dominant HBM-bound kernel = the streaming filter (k1_filter); achieved = algorithmic bytes per launch
+  roofline     : dominant HBM-bound kernel = the streaming filter (k1_dfa); achieved = algorithmic bytes per launch
                  (sum len + 4 B end offset per haystack + 1 bit decision) / its average duration over the timed steps,
                  measured with HIP events recorded on the launch stream by the library (fzb_last_timings).
   cpu_baseline : the CPU oracle (a C++ port of the reference, oracle/) running match_list_parallel on all host cores over
@@ -172,8 +172,8 @@ def main():
                        "haystacks_per_gpu": n, "haystack_len": HAY_LEN, "max_typos": args.max_typos,
                        "emulated_reference_backend": "AVX-512 (prefilter 64 lanes, Smith-Waterman 64 x u8)",
                        "sharding": f"contiguous index ranges over {world} GPU(s), all-gather-v of match records" if world > 1 else "single GPU",
-                       "matches_per_shard": n_matches, "filter_survivors": counters["filter_survivors"], "generic_scored": counters["generic_scored"]},
-            "roofline": {"bound": "hbm", "kernel": "k1_filter", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "matches_per_shard": n_matches, "filter_survivors": counters["filter_survivors"]},
+            "roofline": {"bound": "hbm", "kernel": "k1_dfa", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": filt_bytes, "avg_kernel_ms": tm["filter"], "launches_averaged": tm["calls"]},
             "device_pipeline_ms": tm["total"],
             "pipeline_algorithmic_GBps": (n * HAY_LEN + 4 * n + 8 * n_matches) / (tm["total"] * 1e-3) / 1e9,

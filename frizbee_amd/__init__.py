@@ -253,12 +253,12 @@ class Matcher:
     def last_timings_ms(self):
         out = (C.c_float * 4)()
         _check(lib().fzb_last_timings(self.h, out))
-        return dict(filter=out[0], total=out[1], calls=int(out[2]), filter_launches=int(out[3]))
+        return dict(filter=out[0], total=out[1], calls=int(out[2]))
 
     def last_counters(self):
         out = (C.c_uint32 * 4)()
         _check(lib().fzb_last_counters(self.h, out))
-        return dict(filter_survivors=out[0], kept_by_exact_prefilter=out[1], generic_scored=out[3])
+        return dict(filter_survivors=out[0], kept_by_exact_prefilter=out[1], generic_scored=out[2], multi_chunk_scored=out[3])
 
     def __del__(self):
         try:

@@ -164,14 +164,10 @@ struct fzb_matcher {
     Workspace ws{};
     int device = -1;
     bool profiling = false;
-    static constexpr int MAX_CHUNKS = 8;
-    static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2+2c],[3+2c]=filter kernel of chunk c
-    hipEvent_t evring[PROF_SLOTS][2 + 2 * MAX_CHUNKS] = {};
-    int ev_chunks[PROF_SLOTS] = {};
+    static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2],[3]=around the filter kernel
+    hipEvent_t evring[PROF_SLOTS][4] = {};
+    int ev_filter[PROF_SLOTS] = {};
     u64 prof_calls = 0;
-    // chunk pipelining: two internal streams forked from / joined to the caller's stream
-    hipStream_t streams[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr}, ev_chain[MAX_CHUNKS] = {};
 
     u32 last_counters[4] = {0, 0, 0, 0};
     // staging for the synchronous API
@@ -322,13 +318,6 @@ void fzb_matcher_free(fzb_matcher* m) {
     for (auto& tr : m->evring)
         for (auto& e : tr)
             if (e) (void)hipEventDestroy(e);
-    for (auto& e : m->ev_chain)
-        if (e) (void)hipEventDestroy(e);
-    for (auto& e : m->ev_join)
-        if (e) (void)hipEventDestroy(e);
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    for (auto& st : m->streams)
-        if (st) (void)hipStreamDestroy(st);
     delete m;
 }
 
@@ -429,13 +418,13 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     (void)st;
     free_workspace(w);
     const size_t cap = count + count / 8 + 4096;
-    const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 2 * fzb_matcher::MAX_CHUNKS + 2;
+    const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 2;
     HIPCHK(dev_alloc((void**)&w.bitmap, (cap / 64 + 17) * 8));
     HIPCHK(dev_alloc((void**)&w.tile_counts, ntiles * 4));
     HIPCHK(dev_alloc((void**)&w.tile_prefix, (ntiles + 1) * 4));
     HIPCHK(dev_alloc((void**)&w.surv_idx, cap * 4));
     HIPCHK(dev_alloc((void**)&w.overflow, cap * 16));
-    HIPCHK(dev_alloc((void**)&w.counters, 64 * (fzb_matcher::MAX_CHUNKS + 1)));
+    HIPCHK(dev_alloc((void**)&w.counters, 64));
     HIPCHK(dev_alloc((void**)&w.table, 256 * 8));
     HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
     HIPCHK(dev_alloc((void**)&w.dfa, m->dfa.size() + 16));
@@ -453,120 +442,6 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     return FZB_OK;
 }
 
-// One chunk [cfirst, cfirst + ccnt) of the range, issued on `st`.  `off` = chunk start relative to the range start
-// (a multiple of FZB_TILE) selects this chunk's slices of the workspace; cn = chunk number.
-static int run_chunk(fzb_matcher* m, const CorpusDev& cd, int cn, int nchunks, u64 cfirst, u32 ccnt, size_t off, u32 index_offset, fzb_match_rec* outp, u32 cap32,
-                     u32* dev_count, hipStream_t st, hipEvent_t* pev) {
-    Workspace& w = m->ws;
-    const LaunchCfg& lc = m->lc;
-    const NeedleDev& nd = m->nd;
-    const int cus = lc.num_cus;
-    static const bool dbg = getenv("FZB_DEBUG_SYNC") != nullptr;  // debugging aid: synchronise and report after every stage
-#define FZB_STAGE(name)                                                                                        \
-    do {                                                                                                       \
-        if (dbg) {                                                                                             \
-            hipError_t e_ = hipStreamSynchronize(st);                                                          \
-            fprintf(stderr, "[fzb] chunk %d stage %s: %s\n", cn, name, hipGetErrorString(e_));                 \
-            if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
-        }                                                                                                      \
-    } while (0)
-    u32* cnt_c = w.counters + 16 * cn;  // [0]=filter survivors [1]=kept by the lane-exact prefilter [2]=output base of the next chunk [3]=generic-scorer queue length
-    const u32* base_in = cn ? w.counters + 16 * (cn - 1) + 2 : nullptr;
-    u64* bitmap = w.bitmap + off / 64;
-    u32* tile_counts = w.tile_counts + off / FZB_TILE + cn;
-    u32* tile_prefix = w.tile_prefix + off / FZB_TILE + 2 * cn;
-    u32* surv_idx = w.surv_idx + off;
-    u32* overflow = w.overflow + 4 * off;
-    const bool last = cn == nchunks - 1;
-    const u32* items = nullptr;
-    const u32* win = nullptr;
-    const u32* n_items_ptr = &cnt_c[0];
-    int wmode = lc.window_mode;
-    if (lc.filter_mode == 0) {
-        // nothing filtered: the identity list; counts and bases are known on the host and were pre-set by the caller
-    } else {
-        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
-        if (pev) HIPCHK(hipEventRecord(pev[2 + 2 * cn], st));
-        fzb_launch_filter(cd, cfirst, ccnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, bitmap, tile_counts, cus * 8, st);
-        if (pev) HIPCHK(hipEventRecord(pev[3 + 2 * cn], st));
-        FZB_STAGE("filter");
-        if (lc.filter_exact) {  // this scan also chains the output base across chunks: it must follow the previous chunk's
-            if (cn) HIPCHK(hipStreamWaitEvent(st, m->ev_chain[cn - 1], 0));
-            fzb_launch_scan(tile_counts, tile_prefix, nullptr, ccnt, &cnt_c[0], base_in, &cnt_c[2], st);
-            HIPCHK(hipEventRecord(m->ev_chain[cn], st));
-        } else {
-            fzb_launch_scan(tile_counts, tile_prefix, nullptr, ccnt, &cnt_c[0], nullptr, nullptr, st);
-        }
-        FZB_STAGE("scan1");
-        fzb_launch_map(1, bitmap, tile_prefix, nullptr, ccnt, surv_idx, nullptr, nullptr, nullptr, cus * 2, st);
-        FZB_STAGE("map1");
-        items = surv_idx;
-    }
-    if (!lc.filter_exact) {
-        u32* winb = w.win + 2 * off;
-        u64* bitmap2 = w.bitmap2 + off / 64 + cn;
-        u32* tile_counts2 = w.tile_counts2 + off / FZB_TILE + cn;
-        u32* tile_prefix2 = w.tile_prefix2 + off / FZB_TILE + 2 * cn;
-        u32* items2 = w.items2 + off;
-        u32* win2 = w.win2 + 2 * off;
-        fzb_launch_window(cd, cfirst, items, &cnt_c[0], nd, lc.pf_lanes, winb, bitmap2, tile_counts2, cnt_c, cus * 4, st);
-        FZB_STAGE("window");
-        if (cn) HIPCHK(hipStreamWaitEvent(st, m->ev_chain[cn - 1], 0));
-        fzb_launch_scan(tile_counts2, tile_prefix2, &cnt_c[0], 0, &cnt_c[1], base_in, &cnt_c[2], st);
-        HIPCHK(hipEventRecord(m->ev_chain[cn], st));
-        FZB_STAGE("scan2");
-        fzb_launch_map(2, bitmap2, tile_prefix2, &cnt_c[0], 0, items2, items, winb, win2, cus * 2, st);
-        FZB_STAGE("map2");
-        items = items2;
-        win = win2;
-        n_items_ptr = &cnt_c[1];
-        wmode = 0;
-    }
-    u32* dc = last ? dev_count : nullptr;
-    if (nd.unicode && lc.bias_ok) {
-        // thread-per-haystack single-chunk unicode scorer; wider windows are queued (from the back) for the generic kernel
-        const u32 qcap = ccnt;
-        fzb_launch_dp_unicode(cd, cfirst, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, base_in, dc, overflow, qcap, cnt_c, cus * 8, st);
-        FZB_STAGE("dp(unicode)");
-        if (!(cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes)) {
-            fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, nullptr, cnt_c, cus * 2,
-                               st);
-            FZB_STAGE("generic(unicode, queued)");
-        }
-    } else if (nd.unicode) {
-        fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, base_in, dc, cnt_c, cus * 4, st);
-        FZB_STAGE("generic(unicode)");
-    } else {
-        const u32 qcap = ccnt;  // this chunk's slice of the queue holds ccnt entries
-        fzb_launch_dp(cd, cfirst, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, base_in, dc, overflow, qcap, cnt_c, cus * 8, st);
-        FZB_STAGE("dp");
-        // windows wider than one chunk were queued by the DP kernel; impossible (launches skipped) when no haystack of
-        // the corpus is longer than a chunk
-        if (!(cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes)) {
-            const int mgrid = cus * 2;
-            const size_t words = (size_t)(nd.rows + 1) * (size_t)(lc.sw_lanes / 2) * (size_t)mgrid * 128;
-            if (w.dp_scratch_words < words) {
-                // (first use only; a synchronous allocation is acceptable here and never happens in steady state)
-                if (w.dp_scratch) HIPCHK(hipFree(w.dp_scratch));
-                w.dp_scratch = nullptr;
-                w.dp_scratch_words = 0;
-                HIPCHK(dev_alloc((void**)&w.dp_scratch, words * 4));
-                w.dp_scratch_words = words;
-            }
-            fzb_launch_dp_multi(cd, cfirst, index_offset, overflow, &cnt_c[3], nd, lc.sw_lanes, lc.bias_ok, outp, cap32, w.dp_scratch, mgrid, st);
-            FZB_STAGE("dp_multi");
-            if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {
-                // > 1024-byte windows (greedy fallback): queued from the back of the queue slice
-                fzb_launch_generic(cd, cfirst, index_offset, items, win, wmode, overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c,
-                                   cus / 4 + 1, st);
-                FZB_STAGE("generic(greedy)");
-            }
-        }
-    }
-#undef FZB_STAGE
-    return FZB_OK;
-}
-
 int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity,
                           uint32_t* dev_count, void* stream) {
     if (!m || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
@@ -575,7 +450,7 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     if ((u64)count + (u64)index_offset > 0xFFFFFFFFull)
         return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
     if (m->empty) return fail(FZB_ERR_INVALID, "empty needle: handled on the host by fzb_match_list / fzb_match_list_into");
-    hipStream_t user = (hipStream_t)stream;
+    hipStream_t st = (hipStream_t)stream;
     if (m->device < 0) {
         int dev = 0;
         HIPCHK(hipGetDevice(&dev));
@@ -583,70 +458,109 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
         HIPCHK(hipGetDeviceProperties(&prop, dev));
         m->device = dev;
         m->lc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        for (auto& st : m->streams) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-        for (auto& e : m->ev_join) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : m->ev_chain) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     int rc = ensure_workspace(m, count);
     if (rc) return rc;
     Workspace& w = m->ws;
+    const LaunchCfg& lc = m->lc;
+    const NeedleDev& nd = m->nd;
     const CorpusDev& cd = c->dev;
+    const int cus = lc.num_cus;
+    const u32 cnt = (u32)count;
     const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
+    static const bool dbg = getenv("FZB_DEBUG_SYNC") != nullptr;  // debugging aid: synchronise and report after every stage
+#define FZB_STAGE(name)                                                                                        \
+    do {                                                                                                       \
+        if (dbg) {                                                                                             \
+            hipError_t e_ = hipStreamSynchronize(st);                                                          \
+            fprintf(stderr, "[fzb] stage %s: %s\n", name, hipGetErrorString(e_));                              \
+            if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
+        }                                                                                                      \
+    } while (0)
+    HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
     if (count == 0) {
-        HIPCHK(hipMemsetAsync(dev_count, 0, 4, user));
+        HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
         return FZB_OK;
     }
-    // Optional chunking (FZB_CHUNKS=n, default 1): chunk c+1's HBM-bound filter is issued on a second stream so it can
-    // overlap chunk c's VALU-bound scoring; chunks are tile-aligned and their records are laid out back to back through
-    // the device-side base chain (counters[16c + 2]).  Measured on MI355X it does NOT pay for a single query (the extra
-    // launches, event waits and the fork/join cost more than the overlap wins, eagerly and as a replayed hipGraph), so it
-    // stays off by default; see DESIGN.md.
-    static const int env_chunks = getenv("FZB_CHUNKS") ? atoi(getenv("FZB_CHUNKS")) : 0;
-    int nchunks = env_chunks > 0 ? env_chunks : 1;
-    nchunks = std::min(nchunks, (int)fzb_matcher::MAX_CHUNKS);
-    size_t per = ((count + nchunks - 1) / nchunks + FZB_TILE - 1) / FZB_TILE * FZB_TILE;
-    nchunks = (int)((count + per - 1) / per);
-    HIPCHK(hipMemsetAsync(w.counters, 0, 64 * (fzb_matcher::MAX_CHUNKS + 1), user));
     hipEvent_t* pev = nullptr;
     if (m->profiling) {
         const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);
         pev = m->evring[slot];
-        m->ev_chunks[slot] = m->lc.filter_mode ? nchunks : 0;
+        m->ev_filter[slot] = lc.filter_mode ? 1 : 0;
         m->prof_calls++;
-        for (int i = 0; i < 2 + 2 * nchunks; i++)
+        for (int i = 0; i < 4; i++)
             if (!pev[i]) HIPCHK(hipEventCreate(&pev[i]));
-        HIPCHK(hipEventRecord(pev[0], user));
+        HIPCHK(hipEventRecord(pev[0], st));
     }
-    if (m->lc.filter_mode == 0) {  // identity survivor lists: counts and output bases are host-known
-        size_t done = 0;
-        for (int cn = 0; cn < nchunks; cn++) {
-            const size_t ccnt = std::min(per, count - done);
-            done += ccnt;
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(w.counters + 16 * cn), (int)ccnt, 1, user));
-            HIPCHK(hipMemsetD32Async((hipDeviceptr_t)(w.counters + 16 * cn + 2), (int)done, 1, user));
-        }
+    // counters: [0]=filter survivors [1]=kept by the lane-exact prefilter [3]=multi-chunk queue [4]=generic (greedy / wide unicode) queue
+    u32* cnt_c = w.counters;
+    const u32* items = nullptr;
+    const u32* win = nullptr;
+    const u32* n_items_ptr = &cnt_c[0];
+    int wmode = lc.window_mode;
+    if (lc.filter_mode == 0) {
+        // nothing filtered (max_typos = None or >= rows): the survivors are the identity list
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&cnt_c[0], (int)cnt, 1, st));
+    } else {
+        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
+        if (pev) HIPCHK(hipEventRecord(pev[2], st));
+        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 8, st);
+        if (pev) HIPCHK(hipEventRecord(pev[3], st));
+        FZB_STAGE("filter");
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, w.surv_idx, &cnt_c[0], cus * 2, st);
+        FZB_STAGE("compact1");
+        items = w.surv_idx;
+    }
+    if (!lc.filter_exact) {
+        // the stream stage was a superset: re-decide every survivor with the reference's chunked algorithm at its exact lane width
+        fzb_launch_window(cd, first, items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, cus * 4, st);
+        FZB_STAGE("window");
+        fzb_launch_scan(w.tile_counts2, w.tile_prefix2, &cnt_c[0], 0, &cnt_c[1], nullptr, nullptr, st);
+        FZB_STAGE("scan2");
+        fzb_launch_map(2, w.bitmap2, w.tile_prefix2, &cnt_c[0], 0, w.items2, items, w.win, w.win2, cus * 2, st);
+        FZB_STAGE("map2");
+        items = w.items2;
+        win = w.win2;
+        n_items_ptr = &cnt_c[1];
+        wmode = 0;
     }
     fzb_match_rec* outp = (fzb_match_rec*)dev_out;
-    if (nchunks == 1) {
-        rc = run_chunk(m, cd, 0, 1, first, (u32)count, 0, index_offset, outp, cap32, dev_count, user, pev);
-        if (rc) return rc;
-    } else {
-        HIPCHK(hipEventRecord(m->ev_fork, user));
-        for (auto& st : m->streams) HIPCHK(hipStreamWaitEvent(st, m->ev_fork, 0));
-        size_t off = 0;
-        for (int cn = 0; cn < nchunks; cn++) {
-            const size_t ccnt = std::min(per, count - off);
-            rc = run_chunk(m, cd, cn, nchunks, first + off, (u32)ccnt, off, (u32)(index_offset + off), outp, cap32, dev_count, m->streams[cn & 1], pev);
-            if (rc) return rc;
-            off += ccnt;
+    const u32 qcap = cnt;  // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back
+    const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
+    if (nd.unicode && lc.bias_ok) {
+        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus * 8, st);
+        FZB_STAGE("dp(unicode)");
+        if (!no_wide) {
+            fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, nullptr, cnt_c, cus * 2, st);
+            FZB_STAGE("generic(unicode, queued)");
         }
-        for (int i = 0; i < 2; i++) {
-            HIPCHK(hipEventRecord(m->ev_join[i], m->streams[i]));
-            HIPCHK(hipStreamWaitEvent(user, m->ev_join[i], 0));
+    } else if (nd.unicode) {
+        fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, nullptr, dev_count, cnt_c, cus * 4, st);
+        FZB_STAGE("generic(unicode)");
+    } else {
+        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus * 8, st);
+        FZB_STAGE("dp");
+        if (!no_wide) {
+            const int mgrid = cus * 2;
+            const size_t words = (size_t)(nd.rows + 1) * (size_t)(lc.sw_lanes / 2) * (size_t)mgrid * 128;
+            if (w.dp_scratch_words < words) {  // first use only
+                if (w.dp_scratch) HIPCHK(hipFree(w.dp_scratch));
+                w.dp_scratch = nullptr;
+                w.dp_scratch_words = 0;
+                HIPCHK(dev_alloc((void**)&w.dp_scratch, words * 4));
+                w.dp_scratch_words = words;
+            }
+            fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, lc.bias_ok, outp, cap32, w.dp_scratch, mgrid, st);
+            FZB_STAGE("dp_multi");
+            if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
+                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c,
+                                   cus / 4 + 1, st);
+                FZB_STAGE("generic(greedy)");
+            }
         }
     }
-    if (pev) HIPCHK(hipEventRecord(pev[1], user));
+#undef FZB_STAGE
+    if (pev) HIPCHK(hipEventRecord(pev[1], st));
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }
@@ -804,13 +718,13 @@ int fzb_set_profiling(fzb_matcher* m, int enabled) {
 }
 
 // Averages over the calls made since fzb_set_profiling(m, 1) (at most the last 32):
-// out_ms[0] = filter kernel time (sum over the chunks' launches), [1] = whole pipeline, [2] = calls averaged, [3] = filter launches per call
+// out_ms[0] = filter kernel, [1] = whole pipeline, [2] = calls averaged, [3] = 1 if a filter kernel ran
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
     if (!m || !out_ms) return fail(FZB_ERR_INVALID, "null argument");
     if (!m->profiling || m->prof_calls == 0) return fail(FZB_ERR_INVALID, "profiling not enabled or no call recorded");
     const u64 n = std::min<u64>(m->prof_calls, fzb_matcher::PROF_SLOTS);
     double f = 0, t = 0;
-    int chunks = 0;
+    int has_filter = 0;
     for (u64 i = 0; i < n; i++) {
         const int slot = (int)((m->prof_calls - 1 - i) % fzb_matcher::PROF_SLOTS);
         hipEvent_t* e = m->evring[slot];
@@ -818,31 +732,29 @@ int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
         float b = 0;
         HIPCHK(hipEventElapsedTime(&b, e[0], e[1]));
         t += b;
-        chunks = m->ev_chunks[slot];
-        for (int cn = 0; cn < chunks; cn++) {
+        has_filter = m->ev_filter[slot];
+        if (has_filter) {
             float a = 0;
-            HIPCHK(hipEventElapsedTime(&a, e[2 + 2 * cn], e[3 + 2 * cn]));
+            HIPCHK(hipEventElapsedTime(&a, e[2], e[3]));
             f += a;
         }
     }
     out_ms[0] = (float)(f / n);
     out_ms[1] = (float)(t / n);
     out_ms[2] = (float)n;
-    out_ms[3] = (float)chunks;
+    out_ms[3] = (float)has_filter;
     return FZB_OK;
 }
 
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {
     if (!m || !out) return fail(FZB_ERR_INVALID, "null argument");
     if (m->ws.counters) {
-        u32 all[16 * fzb_matcher::MAX_CHUNKS];
+        u32 all[8];
         HIPCHK(hipMemcpy(all, m->ws.counters, sizeof(all), hipMemcpyDeviceToHost));
-        memset(m->last_counters, 0, 16);
-        for (int cn = 0; cn < fzb_matcher::MAX_CHUNKS; cn++) {
-            m->last_counters[0] += all[16 * cn];
-            m->last_counters[1] += all[16 * cn + 1];
-            m->last_counters[3] += all[16 * cn + 3];
-        }
+        m->last_counters[0] = all[0];
+        m->last_counters[1] = all[1];
+        m->last_counters[2] = all[4];
+        m->last_counters[3] = all[3];
     }
     memcpy(out, m->last_counters, 16);
     return FZB_OK;

@@ -138,11 +138,11 @@ int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_l
 /* Measurement hooks (bench.py): device time of the fzb_match_list_device calls made on this matcher since
  * fzb_set_profiling(m, 1), measured with HIP events recorded on the launch stream (event records only, no
  * synchronisation until read).  fzb_last_timings averages over those calls (at most the last 64):
- * out_ms[0]=filter kernel, [1]=whole pipeline, [2]=calls averaged, [3]=last call's pipeline time. */
+ * out_ms[0]=filter kernel, [1]=whole pipeline, [2]=calls averaged, [3]=1 if a filter kernel ran. */
 int fzb_set_profiling(fzb_matcher* m, int enabled);
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]);
-/* counters of the last call: out[0]=survivors of the filter stage, [1]=records emitted,
- * [2]=survivors rejected by the lane-exact prefilter, [3]=haystacks scored by the generic (multi-chunk) kernel */
+/* counters of the last call: out[0]=survivors of the filter stage, [1]=kept by the lane-exact prefilter,
+ * [2]=windows scored by the generic wave-per-haystack kernel, [3]=windows scored by the multi-chunk kernel */
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]);
 
 #ifdef __cplusplus

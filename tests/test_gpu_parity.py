@@ -215,7 +215,7 @@ def test_bench_shape_ragged_8_128():
     data, ends = synth.ragged_corpus(b"deadbeef", 300_000)
     got, want, fm = both("deadbeef", None, packed=(data, ends), max_typos=0)
     assert_same(got, want, "ragged")
-    assert fm.last_counters()["generic_scored"] > 0  # some windows are wider than one chunk
+    assert fm.last_counters()["multi_chunk_scored"] > 0  # some windows are wider than one chunk
 
 
 def test_bench_shape_utf8():
@@ -253,23 +253,3 @@ def test_empty_inputs():
     got, want, _ = both("abc", ["", "a", ""], max_typos=3)
     assert_same(got, want)
 
-
-def test_chunked_two_stream_pipeline_matches_single_chunk():
-    # FZB_CHUNKS is read once per process: run the 1M len-32 parity case in a child with 3 chunks on two streams
-    import subprocess
-    code = (
-        "import sys, os, numpy as np\n"
-        "sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "import synth, frizbee_amd as F, oracle_lib as O\n"
-        "rows, ends = synth.fixed_corpus(b'deadbe', 300000, 32)\n"
-        "data = rows.numpy().reshape(-1)\n"
-        "for k in (0, 2):\n"
-        "    got = F.Matcher('deadbe', F.Config(max_typos=k, pf_lanes=64, sw_lanes=64)).match_list(F.Corpus(packed=(data, ends)))\n"
-        "    want = O.Matcher('deadbe', max_typos=k).match_packed(np.concatenate([data, np.zeros(64, np.uint8)]), ends)\n"
-        "    assert got.tolist() == want.tolist(), k\n"
-        "print('ok')\n"
-    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)),
-         os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    env = dict(os.environ, FZB_CHUNKS="3")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
-    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]
