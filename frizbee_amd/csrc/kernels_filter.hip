@@ -8,8 +8,6 @@
 //     the converse does not hold at every lane width (oracle/selfcheck.cpp), so with typos - and on the unicode
 //     path, where this stage only looks at each scalar's LAST byte - this stage is a conservative superset
 //     and the lane-exact prefilter (kernels_window.hip) re-decides every survivor.
-#include <cstdlib>
-
 #include "kernels_common.h"
 
 // ---------------------------------------------------------------------------------------------------
@@ -244,96 +242,6 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// K1-DFA, LDS-staged form for ragged / long haystacks.  With lengths of 8..128 bytes a thread-per-haystack
-// kernel reads 16 bytes per lane at ~80-byte strides, every 128-byte line is touched by several lanes at
-// different loop iterations, and the per-CU working set (hundreds of KB) thrashes L1/L2: measured 1.9 TB/s.
-// Here a workgroup copies the CONTIGUOUS byte range of 256 consecutive haystacks into LDS with fully
-// coalesced 16-byte loads (every byte leaves HBM once), then each thread walks its own haystack out of
-// LDS (aligned ds_read_b128: haystacks start on 16-byte boundaries).  Ranges larger than the LDS buffer
-// (very long haystacks) fall back to direct global reads for that group.
-// ---------------------------------------------------------------------------------------------------
-#define FZB_STAGE_CAP (40 * 1024)
-
-template <typename ET>
-__global__ __launch_bounds__(256) void k1_dfa_staged(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                     const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
-                                                     u32* __restrict__ tile_counts) {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    __shared__ u32 s_cnt;
-    const int tid = threadIdx.x;
-    const u32 dfa_bytes = ((u32)(rows + 1) * 256 + 15) & ~15u;
-    u8* dfa = smem;
-    u8* buf = smem + dfa_bytes;
-    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
-    const u32 deadv = dead * 0x01010101u;
-    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        u32 cnt = 0;
-#pragma unroll 1
-        for (int sub = 0; sub < FZB_TILE / 256; sub++) {
-            const u32 i0 = tile * FZB_TILE + sub * 256;
-            if (i0 >= count) break;  // uniform
-            const u32 nsub = min(256u, count - i0);
-            // contiguous byte range of this group: [S0, S1)
-            u64 S0;
-            u32 dummy;
-            haystack_span(ends, first + i0, S0, dummy);
-            const u64 S1 = (u64)ends[first + i0 + nsub - 1];
-            const u64 span = S1 - S0;
-            u64 hs = 0;
-            u32 L = 0;
-            if ((u32)tid < nsub) haystack_span(ends, first + i0 + tid, hs, L);
-            u32 st = 0;
-            if (span <= FZB_STAGE_CAP) {
-                for (u64 o = (u64)tid * 16; o < span; o += 256 * 16) *(uint4*)(buf + o) = *(const uint4*)(bytes + S0 + o);
-                __syncthreads();
-                const u8* hb = buf + (hs - S0);
-                const u32 nvec = (L + 15) >> 4;
-                for (u32 v = 0; v < nvec; v++) {
-                    uint4 q = *(const uint4*)(hb + 16 * v);
-                    const u32 rem = L - 16 * v;
-                    if (rem < 16) {
-                        u32 w4[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const u32 nv = rem > 4u * k ? rem - 4 * k : 0u;
-                            const u32 mask = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1);
-                            w4[k] = (w4[k] & mask) | (deadv & ~mask);
-                        }
-                        q = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                    }
-                    st = dfa_step<0>(st, q.x, dfa); st = dfa_step<1>(st, q.x, dfa); st = dfa_step<2>(st, q.x, dfa); st = dfa_step<3>(st, q.x, dfa);
-                    st = dfa_step<0>(st, q.y, dfa); st = dfa_step<1>(st, q.y, dfa); st = dfa_step<2>(st, q.y, dfa); st = dfa_step<3>(st, q.y, dfa);
-                    st = dfa_step<0>(st, q.z, dfa); st = dfa_step<1>(st, q.z, dfa); st = dfa_step<2>(st, q.z, dfa); st = dfa_step<3>(st, q.z, dfa);
-                    st = dfa_step<0>(st, q.w, dfa); st = dfa_step<1>(st, q.w, dfa); st = dfa_step<2>(st, q.w, dfa); st = dfa_step<3>(st, q.w, dfa);
-                }
-                __syncthreads();
-            } else {
-                const uint4* vp = (const uint4*)(bytes + hs);
-                const u32 nvec = (L + 15) >> 4;
-                for (u32 v = 0; v < nvec; v++) {
-                    const uint4 q = vp[v];
-                    const u32 rem = L - 16 * v;
-                    st = dfa_partial(st, q, rem >= 16 ? 16u : rem, dfa);
-                }
-            }
-            const bool matched = (u32)tid < nsub && L >= min_len && st == (u32)rows;
-            const u64 b = __ballot(matched);
-            if (lane_id() == 0) {
-                bitmap[i0 / 64 + (tid >> 6)] = b;
-                cnt += __popcll(b);
-            }
-        }
-        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
-        __syncthreads();
-        if (tid == 0) tile_counts[tile] = s_cnt;
-        __syncthreads();
-    }
-}
-
 // Used when nothing is filtered (max_typos = None, or max_typos >= rows): every haystack survives.
 __global__ __launch_bounds__(256) void k1_all_pass(u32 count, u32 min_len_unused, u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
     const u32 nwords = (count + 63) / 64;
@@ -508,13 +416,6 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
     if (mode == 1) {
         const size_t lds = (size_t)(rows + 1) * 256;
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
-        static const bool no_stage = getenv("FZB_NO_STAGE") != nullptr;
-        if (!shortc && !no_stage) {
-            const size_t lds2 = ((lds + 15) & ~(size_t)15) + FZB_STAGE_CAP + 16;
-            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa_staged<u64>), dim3(grid), dim3(256), lds2, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
-            else hipLaunchKernelGGL((k1_dfa_staged<u32>), dim3(grid), dim3(256), lds2, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
-            return;
-        }
 #define FZB_K1D(ET, S) hipLaunchKernelGGL((k1_dfa<ET, S>), dim3(grid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts)
         if (c.ends_u64) { if (shortc) FZB_K1D(u64, true); else FZB_K1D(u64, false); }
         else            { if (shortc) FZB_K1D(u32, true); else FZB_K1D(u32, false); }
