@@ -98,7 +98,7 @@ def main():
     m = F.Matcher(NEEDLE.decode(), cfg)
     out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev)
     cnt = torch.zeros(4, dtype=torch.int32, device=dev)
-    # a real (non-null) stream: the library captures its multi-stream chunk pipeline into a hipGraph on first use
+    # a real (non-null) stream: everything the library launches (and its profiling events) goes onto this stream
     side = torch.cuda.Stream(dev)
     torch.cuda.synchronize(dev)
     torch.cuda.set_stream(side)
@@ -124,9 +124,9 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    # Kernel-level timing: the SAME K steps again, immediately after, with per-kernel HIP events recorded by the library
-    # on the launch stream.  (Event records cannot sit inside the replayed graph, so this pass runs the plain
-    # single-stream pipeline; rocprofv3 --kernel-trace of this command covers both passes.)
+    # Kernel-level timing: the SAME K steps again, immediately after, with HIP events recorded by the library around the
+    # filter kernel on the launch stream (kept out of the timed region above so the events cost nothing there;
+    # rocprofv3 --kernel-trace of this command covers both passes).
     m.set_profiling(True)
     for _ in range(args.steps):
         step()
