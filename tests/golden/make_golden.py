@@ -190,11 +190,25 @@ matcher = [
          expect_indices=[0, 1], expect_exact_list=[False, True], ref="tests/api_properties.rs:452-476"),
     dict(name="parallel_tie_chunks", needle="abc", haystacks=hs_with(4097, [(2047, "abc"), (2048, "abc"), (4096, "abc")]), config=dict(),
          expect_indices=[2047, 2048, 4096], ref="tests/api_properties.rs:656-665"),
+    dict(name="unicode_typo_scalar_count_1", needle="إن", haystacks=["ن", "😀", "x"], config=dict(max_typos=1, sort="IndexAsc"), expect_indices=[0], ref="tests/api_properties.rs:559-567"),
+    dict(name="unicode_typo_scalar_count_2", needle="éन😀", haystacks=["ن", "😀", "x"], config=dict(max_typos=2, sort="IndexAsc"), expect_indices=[1], ref="tests/api_properties.rs:569-573"),
+    dict(name="parallel_chunk_boundaries", needle="abc", haystacks=hs_with(4101, [(0, "abc"), (2047, "xabc"), (2048, "abxc"), (2049, "alpha/beta/abc"), (4095, "ABC"), (4096, "a_b_c"), (4100, "zabc")]),
+         config=dict(), expect_len=7, ref="tests/api_properties.rs:627-654"),
+    dict(name="custom_scoring_within_guard", needle="abc", haystacks=["abc", "a_b_c"], config=dict(scoring=[8, 6, 5, 1, 12, 4, 1, 8, 4]), expect_len=2, ref="tests/api_properties.rs:770-778"),
     dict(name="greedy_fallback_membership", needle="abc", haystacks=["a" + "z" * 1100 + "b"], config=dict(max_typos=1), expect_len=1, ref="src/matcher/algo.rs:396-408"),
     dict(name="readme_smoke_fBr", needle="fBr", haystacks=["fooBar", "foo_bar", "barfoo", "prelude", "println!"], config=dict(), expect_indices=[0],
          ref="README.md usage example; BASELINE.json configs[0] (score 53 is hand-derived in SURVEY.md, not reference-pinned)"),
 ]
-json.dump({"cases": matcher,
+# pairs of configurations the reference asserts give identical match lists
+same = [
+    dict(name="long_prefiltered_fallback_ascii", needle="ab", haystacks=["xa" + "_" * 1200 + "b"],
+         config_a=dict(sort="IndexAsc", scoring=[12, 6, 0, 0, 12, 0, 4, 8, 0]), config_b=dict(sort="IndexAsc", scoring=[12, 6, 0, 0, 12, 0, 4, 8, 0], max_typos=None),
+         ref="tests/api_properties.rs:515-531"),
+    dict(name="long_prefiltered_fallback_unicode", needle="éb", haystacks=["xé" + "_" * 1200 + "b"],
+         config_a=dict(sort="IndexAsc", scoring=[12, 6, 0, 0, 12, 0, 4, 8, 0]), config_b=dict(sort="IndexAsc", scoring=[12, 6, 0, 0, 12, 0, 4, 8, 0], max_typos=None),
+         ref="tests/api_properties.rs:543-546"),
+]
+json.dump({"cases": matcher, "same_result": same,
            "panics": [dict(needle="f", scoring=[12, 6, 5, 1, 12, 60000, 40000, 8, 4], message_contains="needle too long", ref="src/matcher/algo.rs:372-380")],
            "max_needle_len_default": 10922, "max_needle_len_ref": "src/lib.rs:545-547",
            "score_fits_in_u8": [dict(needle_len=4, scoring=[12, 6, 5, 1, 12, 4, 4, 8, 4], fits=True, ref="src/smith_waterman/mod.rs:523"),

@@ -74,6 +74,16 @@ def test_reference_golden_cases_through_hip(case, pf):
         fm.match_list_parallel(hs, 0)
 
 
+@pytest.mark.parametrize("pf", [64, 32, 16])
+@pytest.mark.parametrize("case", MT["same_result"], ids=lambda c: c["name"])
+def test_configs_the_reference_asserts_equal_through_hip(case, pf):
+    ga, wa, _ = both(case["needle"], case["haystacks"], pf=pf, **case["config_a"])
+    gb, wb, _ = both(case["needle"], case["haystacks"], pf=pf, **case["config_b"])
+    assert_same(ga, wa, case["name"])
+    assert_same(gb, wb, case["name"])
+    assert len(ga) == 1 and ga.tolist() == gb.tolist(), case["ref"]
+
+
 def test_readme_smoke():
     got = F.Matcher("fBr").match_list(["fooBar", "foo_bar", "barfoo", "prelude", "println!"])
     assert got.tolist() == [(0, 53, 0, 0)]

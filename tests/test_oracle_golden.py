@@ -151,6 +151,14 @@ def test_matcher_end_to_end(case, lanes):
         assert rp.tolist() == r.tolist(), (t, case["ref"])
 
 
+@pytest.mark.parametrize("lanes", [(64, 64, 32), (32, 32, 16), (16, 16, 8)])
+@pytest.mark.parametrize("case", MT["same_result"], ids=lambda c: c["name"])
+def test_configs_the_reference_asserts_equal(case, lanes):
+    a = O.Matcher(case["needle"], lanes=lanes, **case["config_a"]).match_list(case["haystacks"])
+    b = O.Matcher(case["needle"], lanes=lanes, **case["config_b"]).match_list(case["haystacks"])
+    assert len(a) == 1 and a.tolist() == b.tolist(), case["ref"]
+
+
 def test_readme_smoke_score_is_53():
     # BASELINE.json configs[0]; 53 is hand-derived in SURVEY.md section 8 (not a reference-pinned value)
     r = O.Matcher("fBr").match_list(["fooBar", "foo_bar", "barfoo", "prelude", "println!"])
