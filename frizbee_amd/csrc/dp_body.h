@@ -58,23 +58,29 @@ __device__ __forceinline__ void window_first_last(const NeedleDev& nd, const u8*
     if (ws == 0xFFFFFFFFu) ws = 0;  // cannot happen for a survivor of the exact filter
 }
 
-// Scores the trimmed window th[0..m) (1 <= m <= SWL) as ONE chunk of SWL lanes.  hb receives the window bytes
-// (zero padded) for the caller's exact-match compare.  Returns S = max over all lanes of the last row.
-//
-// REAL = number of packed dwords (2 lanes each) that may hold haystack bytes: the caller guarantees m <= 2 * REAL.
-// Dwords >= REAL are zero padding, which the reference scores like any other lane (they enter the final max) but where,
-// for a needle without NUL bytes, nothing can match: match mask = 0, so the bonus / case / gap-open terms vanish and
-// the same recurrences reduce to `diag = S(i-1,j-1) (-) X`, `up = S(i-1,j) (-) gex`, and a gap step whose source lies in
-// the padding is a plain max.  REAL = NW is the fully general form.
-template <int SWL, bool BIAS, int REAL = SWL / 2>
-__device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls, u32 (&hb)[SWL / 4]) {
-    constexpr int NW = SWL / 2;  // packed score dwords
-    constexpr int NB = SWL / 4;  // haystack byte dwords
-    static_assert(REAL >= 1 && REAL <= NW, "REAL");
+// The same for a haystack of at most 32 bytes whose two 16-byte vectors are already in registers (the DP kernel's
+// software pipeline requested them one iteration ahead).
+__device__ __forceinline__ void window_first_last_regs(const NeedleDev& nd, const uint4& q0, const uint4& q1, u32 L, u32& ws, u32& we) {
     const u32 rows = (u32)nd.rows;
-    const u32 ONE = 0x00010001u;
-    const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
-    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+    const u32 a0 = nd.c[0] * 0x01010101u, a1 = nd.f[0] * 0x01010101u;
+    const u32 z0 = nd.c[rows - 1] * 0x01010101u, z1 = nd.f[rows - 1] * 0x01010101u;
+    const u32 w8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    u32 mf = 0, ml = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        mf |= (zero_bytes4_dp(w8[k] ^ a0) | zero_bytes4_dp(w8[k] ^ a1)) << (4 * k);
+        ml |= (zero_bytes4_dp(w8[k] ^ z0) | zero_bytes4_dp(w8[k] ^ z1)) << (4 * k);
+    }
+    const u32 vm = L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1);
+    mf &= vm;
+    ml &= vm;
+    ws = mf ? (u32)__builtin_ctz(mf) : 0u;  // (mf == 0 cannot happen for a survivor of the exact filter)
+    we = ml ? 32u - (u32)__builtin_clz(ml) : 0u;
+}
+
+// Window bytes th[0..m) -> hb (zero padded), from memory ...
+template <int NB>
+__device__ __forceinline__ void load_window_mem(const u8* __restrict__ th, u32 m, u32 (&hb)[NB]) {
 #pragma unroll
     for (int k = 0; k < NB; k++) {
         const u32 p = 4 * k;
@@ -86,6 +92,54 @@ __device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, const u8* __
         }
         hb[k] = v;
     }
+}
+// ... or from the 32 bytes of a short haystack held in registers: bytes [sp, sp + m), sp + m <= 32
+template <int NB>
+__device__ __forceinline__ void load_window_regs(const uint4& q0, const uint4& q1, u32 sp, u32 m, u32 (&hb)[NB]) {
+    u32 x[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, 0u};
+    const u32 ds = sp >> 2, bs = sp & 3;
+    if (ds & 4) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) x[i] = i + 4 < 9 ? x[i + 4] : 0u;
+    }
+    if (ds & 2) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) x[i] = i + 2 < 9 ? x[i + 2] : 0u;
+    }
+    if (ds & 1) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) x[i] = i + 1 < 9 ? x[i + 1] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        u32 v = 0;
+        if (k < 8) {
+            v = __builtin_amdgcn_alignbyte(x[k + 1], x[k], bs);
+            const u32 p = 4 * k;
+            const u32 rem = m > p ? m - p : 0u;
+            if (rem < 4) v &= (1u << (8 * rem)) - 1;
+        }
+        hb[k] = v;
+    }
+}
+
+// Scores the trimmed window (1 <= m <= SWL bytes, given zero padded in hb) as ONE chunk of SWL lanes.
+// Returns S = max over all lanes of the last row.
+//
+// REAL = number of packed dwords (2 lanes each) that may hold haystack bytes: the caller guarantees m <= 2 * REAL.
+// Dwords >= REAL are zero padding, which the reference scores like any other lane (they enter the final max) but where,
+// for a needle without NUL bytes, nothing can match: match mask = 0, so the bonus / case / gap-open terms vanish and
+// the same recurrences reduce to `diag = S(i-1,j-1) (-) X`, `up = S(i-1,j) (-) gex`, and a gap step whose source lies in
+// the padding is a plain max.  REAL = NW is the fully general form.
+template <int SWL, bool BIAS, int REAL = SWL / 2>
+__device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, u32 m, bool include_prefix, const u8* cls, const u32 (&hb)[SWL / 4]) {
+    constexpr int NW = SWL / 2;  // packed score dwords
+    constexpr int NB = SWL / 4;  // haystack byte dwords
+    static_assert(REAL >= 1 && REAL <= NW, "REAL");
+    const u32 rows = (u32)nd.rows;
+    const u32 ONE = 0x00010001u;
+    const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
+    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
     // ---- haystack-side vectors (ascii.rs:59-101) ----------------------------------------------------
     u32 hw[REAL], bonus[REAL];
     {

@@ -538,7 +538,7 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
         fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, nullptr, dev_count, cnt_c, cus * 4, st);
         FZB_STAGE("generic(unicode)");
     } else {
-        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus * 8, st);
+        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
         if (!no_wide) {
             const int mgrid = cus * 2;

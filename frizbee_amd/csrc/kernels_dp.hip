@@ -27,56 +27,107 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
     const u32 M = *n_items_ptr;
     const u32 base = base_ptr ? *base_ptr : 0u;  // records of earlier chunks precede this chunk's
     if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = (base + M) < capacity ? (base + M) : capacity;
-    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
-        if (base + j >= capacity) continue;
-        const u32 li = items ? items[j] : j;
-        u64 s;
-        u32 L;
-        haystack_span(ends, first + li, s, L);
-        const u8* hay = bytes + s;
-        u32 ws, we;
-        if (wmode == 0) { ws = win[2 * j]; we = win[2 * j + 1]; }
-        else if (wmode == 2) { ws = 0; we = L; }
-        else window_first_last(nd, hay, L, ws, we);
-        // ---- trim_haystack (matcher/algo.rs:332-338) --------------------------------------------------
-        const u32 sp = ws ? ws - 1 : 0;
-        const bool include_exact = sp == 0 && we == L;
-        const u32 m = we - sp;
-        if (m > (u32)SWL) {
-            // wider than one chunk: queued for the multi-chunk kernel (counters[3], front of `overflow`), or - beyond the
-            // reference's 1024-byte matrix limit - for the generic kernel's greedy scorer (counters[4], back of `overflow`)
-            u32* qe;
-            if (m > FZB_MAX_HAYSTACK_LEN) {
-                const u32 slot = atomicAdd(&counters[4], 1u);
-                qe = overflow + 4 * (size_t)(qcap - 1 - slot);
-            } else {
-                const u32 slot = atomicAdd(&counters[3], 1u);
-                qe = overflow + 4 * (size_t)slot;
+    // Persistent threads with a three-deep software pipeline over the dependent loads of one item
+    // (survivor index / window -> end offsets -> haystack vectors): each stage is requested one iteration before it is
+    // needed, so the ~7 us of integer DP of the current item cover the latency and only the prologue waits on memory.
+    // (With ~200 VGPRs only two waves fit a SIMD, and they run in phase: without this every iteration began with both
+    // of them stalled on a three-deep dependent load chain.)
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    auto load_item = [&](u64 j, u32& li, u32& ws, u32& we) {
+        li = 0; ws = 0; we = 0;
+        if (j < M) {
+            li = items ? items[j] : (u32)j;
+            if (wmode == 0) { const uint2 w = *(const uint2*)(win + 2 * j); ws = w.x; we = w.y; }
+        }
+    };
+    auto load_span = [&](u64 j, u32 li, u64& s, u32& L) {
+        s = 0; L = 0;
+        if (j < M) haystack_span(ends, first + li, s, L);
+    };
+    auto load_vecs = [&](u64 s, u32 L, uint4& q0, uint4& q1) {
+        q0 = make_uint4(0, 0, 0, 0);
+        q1 = make_uint4(0, 0, 0, 0);
+        const uint4* vp = (const uint4*)(bytes + s);
+        if (L > 0) q0 = vp[0];
+        if (L > 16) q1 = vp[1];
+    };
+    u32 li_c, ws_c, we_c, L_c, li_n, ws_n, we_n, L_n, li_m, ws_m, we_m;
+    u64 s_c, s_n;
+    uint4 q0_c, q1_c;
+    load_item(j0, li_c, ws_c, we_c);
+    load_item(j0 + stride, li_n, ws_n, we_n);
+    load_item(j0 + 2 * stride, li_m, ws_m, we_m);
+    load_span(j0, li_c, s_c, L_c);
+    load_span(j0 + stride, li_n, s_n, L_n);
+    load_vecs(s_c, L_c, q0_c, q1_c);
+    for (u64 j = j0; j < M; j += stride) {
+        // requests for the following iterations
+        uint4 q0_n, q1_n;
+        load_vecs(s_n, L_n, q0_n, q1_n);
+        u64 s_m;
+        u32 L_m;
+        load_span(j + 2 * stride, li_m, s_m, L_m);
+        u32 li_f, ws_f, we_f;
+        load_item(j + 3 * stride, li_f, ws_f, we_f);
+        // ---- this iteration's item ----------------------------------------------------------------------
+        do {
+            if (base + j >= capacity) break;
+            const u32 li = li_c, L = L_c;
+            const u8* hay = bytes + s_c;
+            const bool inreg = __all((int)(L <= 32));  // wave-uniform: the two prefetched vectors hold every haystack of the wave
+            u32 ws = ws_c, we = we_c;
+            if (wmode == 2) { ws = 0; we = L; }
+            else if (wmode == 1) {
+                if (inreg) window_first_last_regs(nd, q0_c, q1_c, L, ws, we);
+                else window_first_last(nd, hay, L, ws, we);
             }
-            qe[0] = base + j;  // (output position, window start, window end, local haystack index)
-            qe[1] = ws;
-            qe[2] = we;
-            qe[3] = li;
-            continue;
-        }
-        u32 score = 0;
-        u32 hb[SWL / 4];
+            // ---- trim_haystack (matcher/algo.rs:332-338) --------------------------------------------------
+            const u32 sp = ws ? ws - 1 : 0;
+            const bool include_exact = sp == 0 && we == L;
+            const u32 m = we - sp;
+            if (m > (u32)SWL) {
+                // wider than one chunk: queued for the multi-chunk kernel (counters[3], front of `overflow`), or - beyond the
+                // reference's 1024-byte matrix limit - for the generic kernel's greedy scorer (counters[4], back of `overflow`)
+                u32* qe;
+                if (m > FZB_MAX_HAYSTACK_LEN) {
+                    const u32 slot = atomicAdd(&counters[4], 1u);
+                    qe = overflow + 4 * (size_t)(qcap - 1 - slot);
+                } else {
+                    const u32 slot = atomicAdd(&counters[3], 1u);
+                    qe = overflow + 4 * (size_t)slot;
+                }
+                qe[0] = base + (u32)j;  // (output position, window start, window end, local haystack index)
+                qe[1] = ws;
+                qe[2] = we;
+                qe[3] = li;
+                break;
+            }
+            u32 score = 0;
+            u32 hb[SWL / 4];
 #pragma unroll
-        for (int k = 0; k < SWL / 4; k++) hb[k] = 0;
-        if (m > 0) {
-            // wave-uniform choice: if every window in this wave fits the low half of the chunk, the upper half is pure padding
-            const bool half = pad_ok && SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
-            if (half) score = dp_single_chunk<SWL, BIAS, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, hay + sp, m, sp == 0, cls, hb);
-            else score = dp_single_chunk<SWL, BIAS>(nd, hay + sp, m, sp == 0, cls, hb);
-        }
-        const bool exact = exact_match<SWL / 4>(nd, include_exact, m, hb);
-        if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
-        fzb_match_rec rec;
-        rec.index = index_offset + li;
-        rec.score = (u16)score;
-        rec.exact = exact ? 1 : 0;
-        rec.valid = 0;
-        out[base + j] = rec;
+            for (int k = 0; k < SWL / 4; k++) hb[k] = 0;
+            if (m > 0) {
+                if (inreg) load_window_regs<SWL / 4>(q0_c, q1_c, sp, m, hb);
+                else load_window_mem<SWL / 4>(hay + sp, m, hb);
+                // wave-uniform choice: if every window in this wave fits the low half of the chunk, the upper half is pure padding
+                const bool half = pad_ok && SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
+                if (half) score = dp_single_chunk<SWL, BIAS, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, sp == 0, cls, hb);
+                else score = dp_single_chunk<SWL, BIAS>(nd, m, sp == 0, cls, hb);
+            }
+            const bool exact = exact_match<SWL / 4>(nd, include_exact, m, hb);
+            if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+            fzb_match_rec rec;
+            rec.index = index_offset + li;
+            rec.score = (u16)score;
+            rec.exact = exact ? 1 : 0;
+            rec.valid = 0;
+            out[base + j] = rec;
+        } while (0);
+        // ---- rotate the pipeline ------------------------------------------------------------------------
+        li_c = li_n; ws_c = ws_n; we_c = we_n; s_c = s_n; L_c = L_n; q0_c = q0_n; q1_c = q1_n;
+        li_n = li_m; ws_n = ws_m; we_n = we_m; s_n = s_m; L_n = L_m;
+        li_m = li_f; ws_m = ws_f; we_m = we_f;
     }
 }
 
@@ -131,8 +182,13 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
 
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                    int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2B(SWL, B, ET) hipLaunchKernelGGL((k2b_dp<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, base_ptr, dev_count, overflow, qcap, counters)
-#define FZB_K2B_ET(SWL, B) do { if (c.ends_u64) FZB_K2B(SWL, B, u64); else FZB_K2B(SWL, B, u32); } while (0)
+    // `grid` = number of CUs here: the kernel is persistent, so launch exactly the workgroups that are resident at once
+#define FZB_K2B(SWL, B, ET)                                                                                              \
+    static int per_cu_##SWL##B##ET = 0;                                                                                  \
+    if (!per_cu_##SWL##B##ET && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_##SWL##B##ET, k2b_dp<SWL, B, ET>, 128, 0) != hipSuccess || per_cu_##SWL##B##ET < 1)) \
+        per_cu_##SWL##B##ET = 4;                                                                                         \
+    hipLaunchKernelGGL((k2b_dp<SWL, B, ET>), dim3(grid * per_cu_##SWL##B##ET), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, base_ptr, dev_count, overflow, qcap, counters)
+#define FZB_K2B_ET(SWL, B) do { if (c.ends_u64) { FZB_K2B(SWL, B, u64); } else { FZB_K2B(SWL, B, u32); } } while (0)
 #define FZB_K2B_B(SWL) do { if (bias_ok) FZB_K2B_ET(SWL, true); else FZB_K2B_ET(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2B_B(64); break;
