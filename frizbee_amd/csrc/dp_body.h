@@ -131,7 +131,9 @@ __device__ __forceinline__ void load_window_regs(const uint4& q0, const uint4& q
 // for a needle without NUL bytes, nothing can match: match mask = 0, so the bonus / case / gap-open terms vanish and
 // the same recurrences reduce to `diag = S(i-1,j-1) (-) X`, `up = S(i-1,j) (-) gex`, and a gap step whose source lies in
 // the padding is a plain max.  REAL = NW is the fully general form.
-template <int SWL, bool BIAS, int REAL = SWL / 2>
+// UPPER = the needle has an uppercase letter (decided on the host; keeps the rarely needed code path, and its
+// registers, out of the common instantiation).
+template <int SWL, bool BIAS, bool UPPER, int REAL = SWL / 2>
 __device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, u32 m, bool include_prefix, const u8* cls, const u32 (&hb)[SWL / 4]) {
     constexpr int NW = SWL / 2;  // packed score dwords
     constexpr int NB = SWL / 4;  // haystack byte dwords
@@ -141,7 +143,13 @@ __device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, u32 m, bool 
     const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
     const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
     // ---- haystack-side vectors (ascii.rs:59-101) ----------------------------------------------------
-    u32 hw[REAL], bonus[REAL];
+    // The matching-case bonus (ascii.rs:121-131) is folded into the per-lane match bonus: a needle byte c earns it on
+    // the lanes where h == c.  For a case-folded letter (match: h in {c, flip(c)}) those are the matching lanes that
+    // have c's case; for an exactly compared byte, all matching lanes - which then have c's case too, or are
+    // non-letters.  So the stored vector carries the case bonus on the lowercase lanes: right for a lowercase c and -
+    // plus the constant - for a non-letter c (non-matching lanes are multiplied by 0 either way).  A needle with an
+    // uppercase letter (UPPER, rare under smart case) keeps the literal form with a separate exact-case compare.
+    u32 hw[REAL], bonus_lo[REAL];
     {
         u32 clsw_prev = 0;
 #pragma unroll
@@ -154,10 +162,11 @@ __device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, u32 m, bool 
             const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);  // class of lane-1 (lane -1 of chunk 0: none)
             const u32 cap01 = (clsw >> 1) & sh & ONE;                        // upper(j) & lower(j-1)
             const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;                 // delim(j-1) & !delim(j)
-            bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+            u32 bonus = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+            if (d == 0 && include_prefix) bonus = p_add(bonus, (u32)nd.prefix);  // first_lane(prefix_bonus)
+            bonus_lo[d] = UPPER ? bonus : p_add(bonus, p_mul(clsw & ONE, casev));
             clsw_prev = clsw;
         }
-        if (include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);  // first_lane(prefix_bonus)
     }
     u32 prev[NW], gprev[REAL];
 #pragma unroll
@@ -166,27 +175,35 @@ __device__ __forceinline__ u32 dp_single_chunk(const NeedleDev& nd, u32 m, bool 
     for (int d = 0; d < REAL; d++) gprev[d] = 0;
 #pragma unroll 1
     for (u32 r = 0; r < rows; r++) {
-        const u32 c = nd.c[r], f = nd.f[r];
+        // needle bytes through aligned dword reads of the by-value argument: wave-uniform, so they are scalar loads
+        const u32 c = (((const u32*)nd.c)[r >> 2] >> (8 * (r & 3))) & 0xFF, f = (((const u32*)nd.f)[r >> 2] >> (8 * (r & 3))) & 0xFF;
         const bool ci = c != f;  // case-insensitive ASCII letter: (h | 0x20) == (c | 0x20) <=> h in {c, flip(c)}
         const u32 orv = ci ? 0x00200020u : 0u;
         const u32 cmpv = splat16(ci ? (c | 0x20) : c);
         const u32 cv = splat16(c);
+        const bool c_lower = c >= 'a' && c <= 'z';
+        const u32 extra = c_lower ? 0u : casev;  // a non-letter needle byte: every matching lane is an exact-case match
         u32 row[NW], g[REAL];
 #pragma unroll
-        for (int d = 0; d < NW; d++) {
+        for (int d = 0; d < REAL; d++) {
             const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : 0u, 16);  // S(i-1, j-1)
-            if (d < REAL) {
-                const u32 mm = p_subs(ONE, (hw[d] | orv) ^ cmpv);      // match mask as 0/1 per lane
-                const u32 ex = ci ? p_subs(ONE, hw[d] ^ cv) : mm;      // exact-case match
-                u32 t = p_add(p_mul(mm, bonus[d]), sh);
-                t = p_subs(t, Xv);
-                const u32 diag = p_add(p_mul(ex, casev), t);
-                const u32 up = p_subs(p_subs(prev[d], gexv), gprev[d]);
-                row[d] = p_max(diag, up);
-                g[d] = p_mul(mm, gopmv);
+            const u32 mm = p_subs(ONE, (hw[d] | orv) ^ cmpv);                             // match mask as 0/1 per lane
+            u32 diag;
+            if (UPPER) {
+                // literal form: separate exact-case compare (bonus_lo holds the bonus WITHOUT the case term here)
+                const u32 ex = ci ? p_subs(ONE, hw[d] ^ cv) : mm;
+                diag = p_add(p_mul(ex, casev), p_subs(p_add(p_mul(mm, bonus_lo[d]), sh), Xv));
             } else {
-                row[d] = p_max(p_subs(sh, Xv), p_subs(prev[d], gexv));  // padding lanes: no match, no gap-open surcharge
+                diag = p_subs(p_add(p_mul(mm, p_add(bonus_lo[d], extra)), sh), Xv);
             }
+            const u32 up = p_subs(p_subs(prev[d], gexv), gprev[d]);
+            row[d] = p_max(diag, up);
+            g[d] = p_mul(mm, gopmv);
+        }
+#pragma unroll
+        for (int d = REAL; d < NW; d++) {
+            const u32 sh = __builtin_amdgcn_alignbit(prev[d], prev[d - 1], 16);
+            row[d] = p_max(p_subs(sh, Xv), p_subs(prev[d], gexv));  // padding lanes: no match, no gap-open surcharge
         }
         // ---- propagate_horizontal_gaps: steps 1, 2, 4, ..., SWL/2 (ascii_gap.rs:11-105) ---------------
         if (BIAS) {

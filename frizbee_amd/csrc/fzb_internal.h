@@ -32,9 +32,9 @@ struct NeedleDev {
     u16 prefix, capitalization, matching_case, exact_bonus, delimiter;
     u16 match_score, gap_open;  // raw values (greedy fallback, src/smith_waterman/greedy.rs)
     u16 _pad;
-    u8 raw[FZB_MAX_NEEDLE_BYTES];  // needle bytes as given
-    u8 c[FZB_MAX_NEEDLE_BYTES];    // ASCII rows: byte            (case_needle, src/prefilter/mod.rs:49-65)
-    u8 f[FZB_MAX_NEEDLE_BYTES];    //            its case flip
+    alignas(4) u8 raw[FZB_MAX_NEEDLE_BYTES];  // needle bytes as given
+    alignas(4) u8 c[FZB_MAX_NEEDLE_BYTES];    // ASCII rows: byte            (case_needle, src/prefilter/mod.rs:49-65)
+    alignas(4) u8 f[FZB_MAX_NEEDLE_BYTES];    //            its case flip
     u8 uc[FZB_MAX_ROWS + 1][4];    // unicode rows: scalar bytes  (case_needle_unicode, src/prefilter/mod.rs:71-96)
     u8 uf[FZB_MAX_ROWS + 1][4];    //               flipped scalar bytes
     u8 ulen[FZB_MAX_ROWS + 1];     //               UTF-8 length

@@ -16,7 +16,7 @@
 // (see DESIGN.md).  BIAS=false keeps the literal 3-op form for scorings where the bias could overflow u16.
 #include "dp_body.h"
 
-template <int SWL, bool BIAS, typename ET>
+template <int SWL, bool BIAS, bool UPPER, typename ET>
 __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                               const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                               const NeedleDev nd, int wmode, int pad_ok, fzb_match_rec* __restrict__ out, u32 capacity, const u32* __restrict__ base_ptr, u32* __restrict__ dev_count,
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
                 else load_window_mem<SWL / 4>(hay + sp, m, hb);
                 // wave-uniform choice: if every window in this wave fits the low half of the chunk, the upper half is pure padding
                 const bool half = pad_ok && SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
-                if (half) score = dp_single_chunk<SWL, BIAS, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, sp == 0, cls, hb);
-                else score = dp_single_chunk<SWL, BIAS>(nd, m, sp == 0, cls, hb);
+                if (half) score = dp_single_chunk<SWL, BIAS, UPPER, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, sp == 0, cls, hb);
+                else score = dp_single_chunk<SWL, BIAS, UPPER>(nd, m, sp == 0, cls, hb);
             }
             const bool exact = exact_match<SWL / 4>(nd, include_exact, m, hb);
             if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
@@ -181,15 +181,19 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
 }
 
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st) {
-    // `grid` = number of CUs here: the kernel is persistent, so launch exactly the workgroups that are resident at once
-#define FZB_K2B(SWL, B, ET)                                                                                              \
-    static int per_cu_##SWL##B##ET = 0;                                                                                  \
-    if (!per_cu_##SWL##B##ET && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_##SWL##B##ET, k2b_dp<SWL, B, ET>, 128, 0) != hipSuccess || per_cu_##SWL##B##ET < 1)) \
-        per_cu_##SWL##B##ET = 4;                                                                                         \
-    hipLaunchKernelGGL((k2b_dp<SWL, B, ET>), dim3(grid * per_cu_##SWL##B##ET), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, base_ptr, dev_count, overflow, qcap, counters)
-#define FZB_K2B_ET(SWL, B) do { if (c.ends_u64) { FZB_K2B(SWL, B, u64); } else { FZB_K2B(SWL, B, u32); } } while (0)
-#define FZB_K2B_B(SWL) do { if (bias_ok) FZB_K2B_ET(SWL, true); else FZB_K2B_ET(SWL, false); } while (0)
+                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st) {
+    bool upper = false;  // an uppercase letter among the needle bytes as they are compared
+    for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+    // the kernel is persistent: launch exactly the workgroups that are resident at once
+#define FZB_K2B(SWL, B, U, ET)                                                                                                          \
+    do {                                                                                                                                \
+        static int per_cu = 0;                                                                                                          \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp<SWL, B, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
+        hipLaunchKernelGGL((k2b_dp<SWL, B, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, base_ptr, dev_count, overflow, qcap, counters); \
+    } while (0)
+#define FZB_K2B_ET(SWL, B, U) do { if (c.ends_u64) FZB_K2B(SWL, B, U, u64); else FZB_K2B(SWL, B, U, u32); } while (0)
+#define FZB_K2B_U(SWL, B) do { if (upper) FZB_K2B_ET(SWL, B, true); else FZB_K2B_ET(SWL, B, false); } while (0)
+#define FZB_K2B_B(SWL) do { if (bias_ok) FZB_K2B_U(SWL, true); else FZB_K2B_U(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2B_B(64); break;
         case 32: FZB_K2B_B(32); break;
