@@ -25,6 +25,11 @@
 #include <thread>
 #include <vector>
 
+#if defined(FZO_NATIVE_SIMD) && defined(__AVX512BW__) && defined(__AVX512VL__) && defined(__AVX512VBMI__)
+#define FZO_AVX512 1
+#include <immintrin.h>
+#endif
+
 namespace fzo {
 
 using u8 = uint8_t;
@@ -220,11 +225,46 @@ inline bool score_fits_in_u8(size_t needle_len, const Scoring& s) {  // smith_wa
 // =======================================================================================
 struct Window { bool matched; size_t start; size_t end; };
 
+// One LANES-byte load of the prefilter with its compare-to-bitmask ops (the `Vector` side of
+// prefilter/backend/mod.rs:116-172).  Lanes at or past `len` read as zero.
+template <int LANES>
+struct PfChunk {
+    u8 b[LANES];
+    static PfChunk load(const u8* h, size_t start, size_t len) {
+        PfChunk c;
+        for (int i = 0; i < LANES; i++) c.b[i] = (start + i < len) ? h[start + i] : 0;
+        return c;
+    }
+    u64 eq(u8 v) const { u64 m = 0; for (int i = 0; i < LANES; i++) if (b[i] == v) m |= (u64)1 << i; return m; }
+    u64 occ(std::pair<u8, u8> n) const { u64 m = 0; for (int i = 0; i < LANES; i++) if (b[i] == n.first || b[i] == n.second) m |= (u64)1 << i; return m; }
+};
+#if defined(FZO_AVX512)
+// The same three ops as the reference's AVX-512 backend computes them (prefilter/backend/avx512.rs): one masked
+// 64-byte load, byte compares straight into a 64-bit mask register.  Only compiled for the CPU-baseline build of the
+// oracle (oracle/Makefile NATIVE=1 on a CPU with AVX-512 BW+VBMI); tests/test_oracle_avx512.py checks it lane for
+// lane against the portable definitions above.
+template <>
+struct PfChunk<64> {
+    __m512i x;
+    static PfChunk load(const u8* h, size_t start, size_t len) {
+        PfChunk c;
+        const size_t take = len > start ? std::min<size_t>(len - start, 64) : 0;
+        const __mmask64 k = take >= 64 ? ~(__mmask64)0 : (((__mmask64)1 << take) - 1);
+        c.x = _mm512_maskz_loadu_epi8(k, h + start);
+        return c;
+    }
+    u64 eq(u8 v) const { return (u64)_mm512_cmpeq_epi8_mask(x, _mm512_set1_epi8((char)v)); }
+    u64 occ(std::pair<u8, u8> n) const {
+        return (u64)(_mm512_cmpeq_epi8_mask(x, _mm512_set1_epi8((char)n.first)) | _mm512_cmpeq_epi8_mask(x, _mm512_set1_epi8((char)n.second)));
+    }
+};
+#endif
+
 template <int LANES>
 struct Prefilter {
     static_assert(LANES == 16 || LANES == 32 || LANES == 64, "prefilter LANES");
     typedef u64 Mask;  // low LANES bits meaningful (u16/u32/u64 in the reference)
-    struct Chunk { u8 b[LANES]; };
+    typedef PfChunk<LANES> Chunk;
 
     std::vector<std::pair<u8, u8>> needle_ascii;
     std::vector<UnicodeChar> needle_unicode;
@@ -241,18 +281,14 @@ struct Prefilter {
 
     // ---- loads (prefilter/algo/load.rs:4-49).  Over-read bytes are never observable
     // (every use is ANDed with a validity mask), so lanes past `len` are zero here. ----
-    static Chunk load_raw(const u8* h, size_t start, size_t len) {
-        Chunk c;
-        for (int i = 0; i < LANES; i++) c.b[i] = (start + i < len) ? h[start + i] : 0;
-        return c;
-    }
+    static Chunk load_raw(const u8* h, size_t start, size_t len) { return Chunk::load(h, start, len); }
     static Chunk load_window(const u8* h, size_t start, size_t len, Mask& mask) {
         size_t remaining = len - start;
         mask = remaining >= (size_t)LANES ? m_all() : m_first_n(remaining);
         return load_raw(h, start, len);
     }
-    static Mask eq(const Chunk& c, u8 v) { Mask m = 0; for (int i = 0; i < LANES; i++) if (c.b[i] == v) m |= (u64)1 << i; return m; }
-    static Mask occ(const Chunk& c, std::pair<u8, u8> n) { Mask m = 0; for (int i = 0; i < LANES; i++) if (c.b[i] == n.first || c.b[i] == n.second) m |= (u64)1 << i; return m; }
+    static Mask eq(const Chunk& c, u8 v) { return c.eq(v); }
+    static Mask occ(const Chunk& c, std::pair<u8, u8> n) { return c.occ(n); }
 
     // ---- 0 typos, ASCII: prefilter/algo/ascii.rs:6-54 ----
     Window match_haystack(const u8* h, size_t len) const {
@@ -789,6 +825,9 @@ struct SV {
         for (int i = L; i < LANES; i++) r.v[i] = v[i - L];
         return r;
     }
+    // mask lanes (0xFF / 0x00 bytes) widened to score lanes (all-ones / zero): scalar.rs:18-42
+    template <typename BYTES>
+    static SV from_mask(const BYTES& m) { SV r; for (int i = 0; i < LANES; i++) r.v[i] = m.lane(i) ? (T)~(T)0 : (T)0; return r; }
 };
 // Byte/mask vector (ScalarBytes<LANES>, scalar.rs:8-145): mask lane = 0xFF / 0x00
 template <int LANES>
@@ -813,7 +852,122 @@ struct BV {
         for (int i = 1; i < LANES; i++) r.v[i] = v[i - 1];
         return r;
     }
+    static BV first_n(size_t n) { BV r = zero(); for (size_t i = 0; i < n && i < (size_t)LANES; i++) r.v[i] = 0xFF; return r; }
+    u8 lane(int i) const { return v[i]; }
 };
+
+#if defined(FZO_AVX512)
+// ---------------------------------------------------------------------------------------
+// AVX-512 forms of the two lane-vector types at the widths the reference's AVX-512 backend uses
+// (smith_waterman/backend/avx512.rs: 64 x u8 and 32 x u16 in one zmm).  Same operations, same
+// names, so SmithWaterman<64,u8> / <32,u16> below run the identical algorithm text on real
+// SIMD registers.  CPU-baseline build only; checked against the portable types by
+// tests/test_oracle_avx512.py.
+// ---------------------------------------------------------------------------------------
+template <>
+struct BV<64> {
+    __m512i x;
+    static BV zero() { BV r; r.x = _mm512_setzero_si512(); return r; }
+    static BV load_partial(const u8* data, size_t start, size_t len) {
+        const size_t take = len > start ? std::min<size_t>(len - start, 64) : 0;
+        const __mmask64 k = take >= 64 ? ~(__mmask64)0 : (((__mmask64)1 << take) - 1);
+        BV r; r.x = _mm512_maskz_loadu_epi8(k, data + start); return r;
+    }
+    static BV from_k(__mmask64 k) { BV r; r.x = _mm512_movm_epi8(k); return r; }
+    BV eq(u8 c) const { return from_k(_mm512_cmpeq_epi8_mask(x, _mm512_set1_epi8((char)c))); }
+    BV gt(u8 c) const { return from_k(_mm512_cmpgt_epu8_mask(x, _mm512_set1_epi8((char)c))); }
+    BV lt(u8 c) const { return from_k(_mm512_cmplt_epu8_mask(x, _mm512_set1_epi8((char)c))); }
+    BV and_(const BV& o) const { BV r; r.x = _mm512_and_si512(x, o.x); return r; }
+    BV or_(const BV& o) const { BV r; r.x = _mm512_or_si512(x, o.x); return r; }
+    BV not_() const { BV r; r.x = _mm512_xor_si512(x, _mm512_set1_epi8((char)0xFF)); return r; }
+    bool is_zero() const { return _mm512_test_epi8_mask(x, x) == 0; }
+    BV shift_right_padded_1(const BV& prev) const {
+        alignas(64) static const u8 idx[64] = {63,  64,  65,  66,  67,  68,  69,  70,  71,  72,  73,  74,  75,  76,  77,  78,  79,  80,  81,  82,  83,  84,
+                                               85,  86,  87,  88,  89,  90,  91,  92,  93,  94,  95,  96,  97,  98,  99,  100, 101, 102, 103, 104, 105, 106,
+                                               107, 108, 109, 110, 111, 112, 113, 114, 115, 116, 117, 118, 119, 120, 121, 122, 123, 124, 125, 126};
+        BV r; r.x = _mm512_permutex2var_epi8(prev.x, _mm512_load_si512((const void*)idx), x); return r;  // index < 64: prev, >= 64: this
+    }
+    static BV first_n(size_t n) { return from_k(n >= 64 ? ~(__mmask64)0 : (((__mmask64)1 << n) - 1)); }
+    u8 lane(int i) const { alignas(64) u8 t[64]; _mm512_store_si512((void*)t, x); return t[i]; }  // (only the mixed-width pairs, e.g. 64 x u16, go through this)
+};
+template <>
+struct SV<64, u8> {
+    __m512i x;
+    static SV zero() { SV r; r.x = _mm512_setzero_si512(); return r; }
+    static SV splat(u16 v) { SV r; r.x = _mm512_set1_epi8((char)(u8)v); return r; }  // `value as u8`
+    static SV first_lane(u16 v) { SV r; r.x = _mm512_zextsi128_si512(_mm_cvtsi32_si128((int)(u8)v)); return r; }
+    SV max(const SV& o) const { SV r; r.x = _mm512_max_epu8(x, o.x); return r; }
+    u16 horizontal_max() const {
+        __m256i a = _mm256_max_epu8(_mm512_castsi512_si256(x), _mm512_extracti64x4_epi64(x, 1));
+        __m128i b = _mm_max_epu8(_mm256_castsi256_si128(a), _mm256_extracti128_si256(a, 1));
+        b = _mm_max_epu8(b, _mm_srli_si128(b, 8));
+        b = _mm_max_epu8(b, _mm_srli_si128(b, 4));
+        b = _mm_max_epu8(b, _mm_srli_si128(b, 2));
+        b = _mm_max_epu8(b, _mm_srli_si128(b, 1));
+        return (u16)(u8)_mm_cvtsi128_si32(b);
+    }
+    SV add(const SV& o) const { SV r; r.x = _mm512_add_epi8(x, o.x); return r; }    // wrapping
+    SV subs(const SV& o) const { SV r; r.x = _mm512_subs_epu8(x, o.x); return r; }  // saturating at 0
+    SV and_(const SV& o) const { SV r; r.x = _mm512_and_si512(x, o.x); return r; }
+    SV shift_right_padded(int L, const SV& prev) const {
+        alignas(64) static const u8 iota[64] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21,
+                                                22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43,
+                                                44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63};
+        const __m512i idx = _mm512_add_epi8(_mm512_load_si512((const void*)iota), _mm512_set1_epi8((char)(64 - L)));  // lane i <- concat(prev, this)[64 - L + i]
+        SV r; r.x = _mm512_permutex2var_epi8(prev.x, idx, x); return r;
+    }
+    static SV from_mask(const BV<64>& m) { SV r; r.x = m.x; return r; }
+};
+template <>
+struct BV<32> {
+    __m256i x;
+    static BV zero() { BV r; r.x = _mm256_setzero_si256(); return r; }
+    static BV load_partial(const u8* data, size_t start, size_t len) {
+        const size_t take = len > start ? std::min<size_t>(len - start, 32) : 0;
+        const __mmask32 k = take >= 32 ? ~(__mmask32)0 : (((__mmask32)1 << take) - 1);
+        BV r; r.x = _mm256_maskz_loadu_epi8(k, data + start); return r;
+    }
+    static BV from_k(__mmask32 k) { BV r; r.x = _mm256_movm_epi8(k); return r; }
+    BV eq(u8 c) const { return from_k(_mm256_cmpeq_epi8_mask(x, _mm256_set1_epi8((char)c))); }
+    BV gt(u8 c) const { return from_k(_mm256_cmpgt_epu8_mask(x, _mm256_set1_epi8((char)c))); }
+    BV lt(u8 c) const { return from_k(_mm256_cmplt_epu8_mask(x, _mm256_set1_epi8((char)c))); }
+    BV and_(const BV& o) const { BV r; r.x = _mm256_and_si256(x, o.x); return r; }
+    BV or_(const BV& o) const { BV r; r.x = _mm256_or_si256(x, o.x); return r; }
+    BV not_() const { BV r; r.x = _mm256_xor_si256(x, _mm256_set1_epi8((char)0xFF)); return r; }
+    bool is_zero() const { return _mm256_testz_si256(x, x) != 0; }
+    BV shift_right_padded_1(const BV& prev) const {
+        alignas(32) static const u8 idx[32] = {31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62};
+        BV r; r.x = _mm256_permutex2var_epi8(prev.x, _mm256_load_si256((const __m256i*)idx), x); return r;
+    }
+    static BV first_n(size_t n) { return from_k(n >= 32 ? ~(__mmask32)0 : (((__mmask32)1 << n) - 1)); }
+    u8 lane(int i) const { alignas(32) u8 t[32]; _mm256_store_si256((__m256i*)t, x); return t[i]; }
+};
+template <>
+struct SV<32, u16> {
+    __m512i x;
+    static SV zero() { SV r; r.x = _mm512_setzero_si512(); return r; }
+    static SV splat(u16 v) { SV r; r.x = _mm512_set1_epi16((short)v); return r; }
+    static SV first_lane(u16 v) { SV r; r.x = _mm512_zextsi128_si512(_mm_cvtsi32_si128((int)v)); return r; }
+    SV max(const SV& o) const { SV r; r.x = _mm512_max_epu16(x, o.x); return r; }
+    u16 horizontal_max() const {
+        __m256i a = _mm256_max_epu16(_mm512_castsi512_si256(x), _mm512_extracti64x4_epi64(x, 1));
+        __m128i b = _mm_max_epu16(_mm256_castsi256_si128(a), _mm256_extracti128_si256(a, 1));
+        b = _mm_max_epu16(b, _mm_srli_si128(b, 8));
+        b = _mm_max_epu16(b, _mm_srli_si128(b, 4));
+        b = _mm_max_epu16(b, _mm_srli_si128(b, 2));
+        return (u16)_mm_cvtsi128_si32(b);
+    }
+    SV add(const SV& o) const { SV r; r.x = _mm512_add_epi16(x, o.x); return r; }
+    SV subs(const SV& o) const { SV r; r.x = _mm512_subs_epu16(x, o.x); return r; }
+    SV and_(const SV& o) const { SV r; r.x = _mm512_and_si512(x, o.x); return r; }
+    SV shift_right_padded(int L, const SV& prev) const {
+        alignas(64) static const u16 iota[32] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31};
+        const __m512i idx = _mm512_add_epi16(_mm512_load_si512((const void*)iota), _mm512_set1_epi16((short)(32 - L)));  // lane i <- concat(prev, this)[32 - L + i]
+        SV r; r.x = _mm512_permutex2var_epi16(prev.x, idx, x); return r;
+    }
+    static SV from_mask(const BV<32>& m) { SV r; r.x = _mm512_cvtepi8_epi16(m.x); return r; }  // 0xFF -> 0xFFFF (sign extension)
+};
+#endif
 
 template <int LANES, typename T>
 struct SmithWaterman {
@@ -839,7 +993,7 @@ struct SmithWaterman {
     S& sm(size_t r, size_t c) { return score_matrix[r * stride + c]; }
     S& mmx(size_t r, size_t c) { return match_masks[r * stride + c]; }
 
-    static S widen(const B& m) { S r; for (int i = 0; i < LANES; i++) r.v[i] = m.v[i] ? (T)~(T)0 : (T)0; return r; }  // scalar.rs:18-42
+    static S widen(const B& m) { return S::from_mask(m); }  // scalar.rs:18-42
 
     // smith_waterman/algo/ascii_gap.rs:11-105 (gap_step! + propagate_{8,16,32,64}_lane)
     static S propagate_horizontal_gaps(S row, const S& adj, const S& mm, const S& amm, const S& gop, S gex) {
@@ -959,9 +1113,7 @@ struct SmithWaterman {
     // smith_waterman/algo/unicode.rs:219-273
     static B valid_haystack_lanes(size_t hlen, size_t start) {
         size_t valid = hlen > start ? std::min<size_t>(hlen - start, LANES) : 0;
-        B r = B::zero();
-        for (size_t i = 0; i < valid; i++) r.v[i] = 0xFF;
-        return r;
+        return B::first_n(valid);
     }
     static B unicode_char_match_mask(const B chunks[4], const B& scalar_start_mask, int char_len, const u8 chars[4]) {
         B mask = chunks[4 - char_len].eq(chars[char_len - 1]).and_(scalar_start_mask);

@@ -27,6 +27,16 @@ static u16 sw_run(const std::string& n, const Scoring& sc, bool cs, const u8* h,
 
 extern "C" {
 
+// which lane-vector implementation this build of the oracle runs on
+const char* fzo_simd_kind(void) {
+#if defined(FZO_AVX512)
+    return "avx512";
+#else
+    return "portable";
+#endif
+}
+
+
 struct fzo_config {
     int32_t max_typos;  // -1 == None
     int32_t casing, unicode, sort;

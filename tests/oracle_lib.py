@@ -20,23 +20,27 @@ class FzoConfig(C.Structure):
     _fields_ = [("max_typos", C.c_int32), ("casing", C.c_int32), ("unicode", C.c_int32), ("sort", C.c_int32), ("scoring", C.c_uint16 * 9)]
 
 
-def build(native=False):
-    so = os.path.join(ORACLE_DIR, "libfrizbee_oracle.so")
+def build(native=False, force=False):
+    """Portable build (the parity checker): libfrizbee_oracle.so.  native=True: libfrizbee_oracle_native.so, compiled
+    -march=native with the AVX-512 lane-vector types when the host has them (the CPU-baseline build; host-specific, so
+    it is listed in .gpurunignore and bench.py rebuilds it with force=True on the machine it times)."""
+    name = "libfrizbee_oracle_native.so" if native else "libfrizbee_oracle.so"
+    so = os.path.join(ORACLE_DIR, name)
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "frizbee_oracle.hpp", "unicode_case_table.inc", "Makefile")]
-    if native or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        cmd = ["make", "-C", ORACLE_DIR] + (["-B", "NATIVE=1"] if native else [])
-        subprocess.check_call(cmd, stdout=subprocess.DEVNULL)
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORACLE_DIR] + (["-B"] if force else []) + [name], stdout=subprocess.DEVNULL)
     return so
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        l = C.CDLL(build())
+def lib(native=False):
+    l = _libs.get(bool(native))
+    if l is None:
+        l = C.CDLL(build(native))
         l.fzo_last_error.restype = C.c_char_p
+        l.fzo_simd_kind.restype = C.c_char_p
         l.fzo_prefilter.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         l.fzo_sw_score.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         l.fzo_greedy.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int]
@@ -53,8 +57,12 @@ def lib():
         l.fzo_k_merge.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.fzo_respects_case_for.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         l.fzo_case_needle_unicode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
-        _lib = l
-    return _lib
+        _libs[bool(native)] = l
+    return l
+
+
+def simd_kind(native=False):
+    return lib(native).fzo_simd_kind().decode()
 
 
 def _b(s):
@@ -65,18 +73,18 @@ def _scoring(s):
     return (C.c_uint16 * 9)(*(s or DEFAULT_SCORING))
 
 
-def prefilter(needle, haystack, max_typos=0, case_sensitive=False, unicode=False, lanes=64):
+def prefilter(needle, haystack, max_typos=0, case_sensitive=False, unicode=False, lanes=64, native=False):
     out = (C.c_uint64 * 3)()
     n, h = _b(needle), _b(haystack)
-    rc = lib().fzo_prefilter(n, len(n), h, len(h), max_typos, int(case_sensitive), int(unicode), lanes, out)
+    rc = lib(native).fzo_prefilter(n, len(n), h, len(h), max_typos, int(case_sensitive), int(unicode), lanes, out)
     if rc:
         raise RuntimeError(lib().fzo_last_error().decode())
     return (bool(out[0]), int(out[1]), int(out[2]))
 
 
-def sw_score(needle, haystack, scoring=None, case_sensitive=False, include_prefix=True, unicode=False, lanes=8, is_u8=False):
+def sw_score(needle, haystack, scoring=None, case_sensitive=False, include_prefix=True, unicode=False, lanes=8, is_u8=False, native=False):
     n, h = _b(needle), _b(haystack)
-    r = lib().fzo_sw_score(n, len(n), h, len(h), _scoring(scoring), int(case_sensitive), int(include_prefix), int(unicode), lanes, int(is_u8))
+    r = lib(native).fzo_sw_score(n, len(n), h, len(h), _scoring(scoring), int(case_sensitive), int(include_prefix), int(unicode), lanes, int(is_u8))
     if r < 0:
         raise RuntimeError(lib().fzo_last_error().decode())
     return r
@@ -118,33 +126,34 @@ class Matcher:
     """Oracle `Matcher` emulating the backend pair an ISA would select (matcher/mod.rs:448-498):
     (pf_lanes, sw_lanes_u8, sw_lanes_u16) = (64,64,32) AVX-512+VBMI, (32,32,16) AVX2, (16,16,8) SSE/NEON/scalar."""
 
-    def __init__(self, needle, lanes=(64, 64, 32), **cfg):
+    def __init__(self, needle, lanes=(64, 64, 32), native=False, **cfg):
         self.cfg = make_config(**cfg)
+        self.lib = lib(native)
         n = _b(needle)
-        self.h = lib().fzo_matcher_create(C.byref(self.cfg), n, len(n), *lanes)
+        self.h = self.lib.fzo_matcher_create(C.byref(self.cfg), n, len(n), *lanes)
         if not self.h:
-            raise RuntimeError(lib().fzo_last_error().decode())
+            raise RuntimeError(self.lib.fzo_last_error().decode())
 
     def info(self):
         out = (C.c_int * 3)()
-        lib().fzo_matcher_info(self.h, out)
+        self.lib.fzo_matcher_info(self.h, out)
         return dict(pf_lanes=out[0], sw_lanes=out[1], use_u8=bool(out[2]))
 
     def match_packed(self, data, ends, threads=-1):
         out = C.c_void_p()
         n = C.c_size_t()
-        rc = lib().fzo_match_list(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(out), C.byref(n))
+        rc = self.lib.fzo_match_list(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(out), C.byref(n))
         if rc:
-            raise RuntimeError(lib().fzo_last_error().decode())
+            raise RuntimeError(self.lib.fzo_last_error().decode())
         arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 8,))[: n.value * 8].view(MATCH_DTYPE).copy()
-        lib().fzo_free(out)
+        self.lib.fzo_free(out)
         return arr
 
     def count_packed(self, data, ends, threads=-1):
         n = C.c_size_t()
-        rc = lib().fzo_match_list_count(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(n))
+        rc = self.lib.fzo_match_list_count(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(n))
         if rc:
-            raise RuntimeError(lib().fzo_last_error().decode())
+            raise RuntimeError(self.lib.fzo_last_error().decode())
         return n.value
 
     def match_list(self, haystacks):
@@ -156,7 +165,7 @@ class Matcher:
     def __del__(self):
         try:
             if getattr(self, "h", None):
-                lib().fzo_matcher_free(self.h)
+                self.lib.fzo_matcher_free(self.h)
                 self.h = None
         except Exception:
             pass
