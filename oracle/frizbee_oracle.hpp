@@ -1447,6 +1447,35 @@ struct Matcher {
         for (auto& th : pool) th.join();
         return k_merge_matches_by(config.sort, runs);
     }
+
+    // Timing aid for bench.py's cpu_baseline (not part of the reference API): the worker loop of match_list_parallel
+    // WITHOUT the per-thread sort and the single-threaded k-way merge, i.e. the same scope as one step of the GPU
+    // pipeline (score every haystack, keep the records of the accepted ones).  Returns the number of matches.
+    size_t score_parallel_unordered(const HaystackList& hs, size_t threads) const {
+        if (threads == 0) throw std::runtime_error("threads must be positive");
+        threads = std::max<size_t>(std::min(threads, (hs.n + 1999) / 2000), 1);
+        if (hs.n == 0 || empty) return hs.n;
+        const size_t chunk_size = 2048;
+        size_t num_chunks = (hs.n + chunk_size - 1) / chunk_size;
+        std::atomic<size_t> next_chunk(0), total(0);
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < threads; t++) {
+            pool.emplace_back([&]() {
+                MatcherBase* local = impl->clone();
+                std::vector<Match> local_matches;
+                for (;;) {
+                    size_t chunk_idx = next_chunk.fetch_add(1, std::memory_order_relaxed);
+                    if (chunk_idx >= num_chunks) break;
+                    size_t start = chunk_idx * chunk_size, end = std::min(start + chunk_size, hs.n);
+                    match_list_into(local, hs, start, end, (u32)start, local_matches);
+                }
+                total.fetch_add(local_matches.size());
+                delete local;
+            });
+        }
+        for (auto& th : pool) th.join();
+        return total.load();
+    }
 };
 
 }  // namespace fzo

@@ -138,6 +138,14 @@ int fzo_match_list_count(void* m, const uint8_t* bytes, const uint64_t* ends, si
         return 0;
     } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
+// Timing leg: score every haystack on `threads` workers, no ordering step (Matcher::score_parallel_unordered).
+int fzo_score_count_unordered(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, long threads, size_t* out_len) {
+    try {
+        HaystackList hs{bytes, ends, n};
+        *out_len = ((Matcher*)m)->score_parallel_unordered(hs, (size_t)threads);
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
 void fzo_free(void* p) { free(p); }
 
 void fzo_radix_sort(Match* matches, size_t n) {

@@ -52,6 +52,7 @@ def lib(native=False):
         l.fzo_matcher_info.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         l.fzo_match_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzo_match_list_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_size_t)]
+        l.fzo_score_count_unordered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_size_t)]
         l.fzo_free.argtypes = [C.c_void_p]
         l.fzo_radix_sort.argtypes = [C.c_void_p, C.c_size_t]
         l.fzo_k_merge.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -152,6 +153,14 @@ class Matcher:
     def count_packed(self, data, ends, threads=-1):
         n = C.c_size_t()
         rc = self.lib.fzo_match_list_count(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(n))
+        if rc:
+            raise RuntimeError(self.lib.fzo_last_error().decode())
+        return n.value
+
+    def score_count_unordered(self, data, ends, threads):
+        """timing aid: the parallel scoring loop without the ordering step; returns the number of matches"""
+        n = C.c_size_t()
+        rc = self.lib.fzo_score_count_unordered(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), threads, C.byref(n))
         if rc:
             raise RuntimeError(self.lib.fzo_last_error().decode())
         return n.value
