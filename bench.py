@@ -6,7 +6,9 @@ records in HBM) over one synthetic haystack list that is already resident in HBM
 BASELINE.json configs[1] - needle "deadbe" (6 chars) vs 10,000,000 x 32-byte ASCII haystacks per GPU, max_typos=0,
 seed 12345, reference "Partial Match" mix (5 % full / 20 % partial / 75 % none).  N > 1 is weak scaling: each rank
 owns a contiguous 10M-item shard of a 10M*N list (global index offset), scores it with no data-path collective, then
-the per-shard match lists are exchanged with one RCCL all-gather-v (frizbee_amd/distributed.py) inside the step.
+each step's per-shard match list is gathered to rank 0 by RCCL (frizbee_amd/distributed.py ShardExchange: fixed-capacity
+buffers, asynchronous and double-buffered, so step i's gather overlaps step i+1's kernels; every gather has completed
+when the closing barrier + synchronize returns).
 
 Prints ONE JSON line on rank 0 (see the driver contract): value = haystacks scored per second, whole job.
   roofline     : dominant HBM-bound kernel = the streaming filter (k1_dfa); achieved = algorithmic bytes per launch
@@ -93,13 +95,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # FZB_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, exchange) with a single rank: a self-test of that
+    # path on a 1-GPU box, not a benchmark configuration
+    use_dist = world > 1 or os.environ.get("FZB_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import frizbee_amd as F
     import synth
-    from frizbee_amd.distributed import all_gather_matches
+    from frizbee_amd.distributed import ShardExchange, merge_shard_runs
 
     n = args.per_gpu
     # ---- synthetic shard, generated directly in HBM (padded-16 layout == back-to-back 32-byte rows) ----
@@ -119,14 +126,28 @@ def main():
     stream = side.cuda_stream
     index_offset = rank * n
 
-    def step():
+    ex = None
+    if use_dist:
+        # set-up (untimed): one synchronous pass sizes the exchange buffers every rank agrees on
         m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=stream, index_offset=index_offset)
-        if world > 1:
-            return all_gather_matches(out, cnt[0])
-        return None
+        torch.cuda.synchronize(dev)
+        ex = ShardExchange(ShardExchange.plan(int(cnt[0].item()), device=dev), dev)
+    step_no = [0]
+
+    def step():
+        if ex is None:
+            m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=stream, index_offset=index_offset)
+            return
+        # N > 1: count + records are written straight into this slot's exchange buffer, then gathered to rank 0 by RCCL
+        # on its own stream while the next step's kernels run (double-buffered; no host synchronisation in the loop)
+        slot = step_no[0] & 1
+        step_no[0] += 1
+        ex.wait(slot)
+        m.match_list_device(corpus, ex.records_ptr(slot), ex.cap, ex.count_ptr(slot), stream=stream, index_offset=index_offset)
+        ex.post(slot)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -147,14 +168,23 @@ def main():
     fence()
     tm = m.last_timings_ms()
     m.set_profiling(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
-    n_matches = int(cnt[0].item())
+    gathered = None
+    if ex is None:
+        n_matches = int(cnt[0].item())
+    else:
+        last = (step_no[0] - 1) & 1
+        runs = ex.collect(last)       # root: the per-shard runs of the last step; everyone: drains the exchange
+        ex.collect(last ^ 1)
+        n_matches = int(ex.send[last][:4].cpu().numpy().view(np.uint32)[0])
+        if rank == 0:
+            merged = merge_shard_runs(runs, F.SortStrategy.ScoreThenIndexAsc)  # the reference's combine step, once, outside the timed loop
+            gathered = {"matches_all_shards": int(sum(len(r) for r in runs)), "merged_len": int(len(merged)), "exchange_capacity_records": ex.cap}
     counters = m.last_counters()
-
     if rank == 0:
         total = n * world
         # algorithmic bytes of one filter launch (this rank's shard): payload once + u32 end offset + 1 decision bit per haystack
@@ -185,8 +215,8 @@ def main():
                                    "mix 5% full / 20% partial / 75% none, seed 12345 (BASELINE.json configs[1])",
                        "haystacks_per_gpu": n, "haystack_len": HAY_LEN, "max_typos": args.max_typos,
                        "emulated_reference_backend": "AVX-512 (prefilter 64 lanes, Smith-Waterman 64 x u8)",
-                       "sharding": f"contiguous index ranges over {world} GPU(s), all-gather-v of match records" if world > 1 else "single GPU",
-                       "matches_per_shard": n_matches, "filter_survivors": counters["filter_survivors"]},
+                       "sharding": f"contiguous index ranges over {world} GPU(s); per step an asynchronous, double-buffered RCCL gather of the match records to rank 0" if world > 1 else "single GPU",
+                       "matches_per_shard": n_matches, "filter_survivors": counters["filter_survivors"], "exchange": gathered},
             "roofline": {"bound": "hbm", "kernel": "k1_dfa", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "bytes_per_launch": filt_bytes, "avg_kernel_ms": tm["filter"], "launches_averaged": tm["calls"]},
             "device_pipeline_ms": tm["total"],
@@ -196,7 +226,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(rows, min(n, 10_000_000), args.max_typos)
             res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -40,6 +40,66 @@ def all_gather_matches(records_u8, count, group=None):
     return [host[r, : counts_h[r] * 8].copy().view(MATCH_DTYPE) for r in range(world)]
 
 
+class ShardExchange:
+    """Steady-state exchange of per-shard match lists with NO host synchronisation in the loop: a gather to the root
+    rank (the process whose host consumes the merged result) of fixed-capacity buffers, double-buffered and asynchronous.
+
+    Buffer layout per rank and slot: [u32 count | u32 0 | capacity x 8-byte records].  The scoring pipeline writes the
+    count and the records straight into it (`count_ptr` / `records_ptr` are what `fzb_match_list_device` takes), `post`
+    launches the gather on the backend's own stream (RCCL send/recv over the point-to-point xGMI links: the root
+    receives its world-1 peers' buffers on separate links in parallel), and the next step's kernels overlap it.
+    The capacity is agreed once, up front (`plan`), from a first measured count; a shard that later outgrows it is
+    reported by `collect`, never truncated silently."""
+
+    HEADER = 8
+
+    def __init__(self, capacity_records, device, group=None, root=0, slots=2):
+        self.group, self.root = group, root
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.cap = int(capacity_records)
+        nbytes = self.HEADER + self.cap * 8
+        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.rank == root else None for _ in range(slots)]
+        self.work = [None] * slots
+
+    @staticmethod
+    def plan(local_count, group=None, margin=1.25, device=None):
+        """Capacity every rank agrees on: max over ranks of the measured count, plus a margin (one collective, set-up only)."""
+        t = torch.tensor([int(local_count)], dtype=torch.int64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        return int(int(t.item()) * margin) + 4096
+
+    def count_ptr(self, slot):
+        return self.send[slot].data_ptr()
+
+    def records_ptr(self, slot):
+        return self.send[slot].data_ptr() + self.HEADER
+
+    def wait(self, slot):
+        """Order the caller's stream after the exchange that last used `slot` (no host block with RCCL)."""
+        if self.work[slot] is not None:
+            self.work[slot].wait()
+            self.work[slot] = None
+
+    def post(self, slot):
+        self.wait(slot)
+        self.work[slot] = dist.gather(self.send[slot], gather_list=self.recv[slot], dst=self.root, group=self.group, async_op=True)
+
+    def collect(self, slot):
+        """Root only, synchronising: the per-rank runs of the exchange posted on `slot` as numpy MATCH_DTYPE arrays."""
+        self.wait(slot)
+        if self.rank != self.root:
+            return None
+        runs = []
+        for r, buf in enumerate(self.recv[slot]):
+            host = buf.cpu().numpy()
+            cnt = int(host[:4].view(np.uint32)[0])
+            if cnt >= self.cap:
+                raise RuntimeError(f"shard {r} produced at least {cnt} matches, exchange capacity is {self.cap}: plan a larger capacity")
+            runs.append(host[self.HEADER : self.HEADER + cnt * 8].copy().view(MATCH_DTYPE))
+        return runs
+
+
 def merge_shard_runs(runs, sort):
     """Per-shard index-ordered runs -> the reference's final ordering (parallel.rs:66-87)."""
     sort = SortStrategy(int(sort))

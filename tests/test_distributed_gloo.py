@@ -32,7 +32,7 @@ def _worker(rank, world, port, q):
     import oracle_lib as O
     import synth
     from frizbee_amd import SortStrategy
-    from frizbee_amd.distributed import all_gather_matches, merge_shard_runs, shard_range
+    from frizbee_amd.distributed import ShardExchange, all_gather_matches, merge_shard_runs, shard_range
 
     n = 30_001
     rows, ends = synth.fixed_corpus(b"deadbe", n, 32)
@@ -50,6 +50,22 @@ def _worker(rank, world, port, q):
             merged = merge_shard_runs(runs, SortStrategy[sort])
             want = O.Matcher("deadbe", max_typos=k, sort=sort).match_packed(data, ends)
             ok = ok and merged.tolist() == want.tolist()
+            # the sync-free path bench.py uses at N > 1: fixed-capacity gather to the root, double-buffered, three rounds
+            cap = ShardExchange.plan(len(local))
+            ex = ShardExchange(cap, torch.device("cpu"))
+            for step in range(3):
+                slot = step % 2
+                ex.wait(slot)
+                buf = ex.send[slot].numpy()  # stands in for the device pipeline writing count + records in place
+                buf[:4] = np.array([len(local)], np.uint32).view(np.uint8)
+                buf[ex.HEADER : ex.HEADER + len(local) * 8] = local.view(np.uint8)
+                ex.post(slot)
+            runs2 = ex.collect(0)  # steps 0 and 2 used slot 0
+            if rank == 0:
+                ok = ok and merge_shard_runs(runs2, SortStrategy[sort]).tolist() == want.tolist()
+            else:
+                ok = ok and runs2 is None
+            ex.collect(1)
     q.put((rank, ok))
     dist.destroy_process_group()
 
