@@ -9,6 +9,8 @@
 //     path, where this stage only looks at each scalar's LAST byte - this stage is a conservative superset
 //     and the lane-exact prefilter (kernels_window.hip) re-decides every survivor.
 #include "kernels_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------
 // K1: one thread per haystack.  Bytes are streamed from HBM as aligned 16-byte vectors (padded-16 layout),
@@ -131,7 +133,7 @@ __device__ __forceinline__ u32 dfa_partial(u32 st, const uint4& q, u32 nbytes, c
     return st;
 }
 
-template <typename ET, bool SHORT>
+template <typename ET>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                               const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
                                               u32* __restrict__ tile_counts) {
@@ -162,66 +164,25 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
             if (hl[p] > 16) v1[p] = vp[1];
         }
         u32 st[4] = {0, 0, 0, 0};
-        u32 nvmax = 0;
-#pragma unroll
-        for (int p = 0; p < 4; p++) nvmax = max(nvmax, (hl[p] + 15) >> 4);
-        if (SHORT || nvmax <= 2) {
-            // short haystacks (<= 32 bytes): both vectors are already in flight
-            if (hl[0] >= 16 && hl[1] >= 16 && hl[2] >= 16 && hl[3] >= 16) {
-                { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4(st, w, dfa); }
-                { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4(st, w, dfa); }
-                { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4(st, w, dfa); }
-                { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4(st, w, dfa); }
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; p++) st[p] = dfa_partial(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
-            }
-            if (hl[0] >= 32 && hl[1] >= 32 && hl[2] >= 32 && hl[3] >= 32) {
-                { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4(st, w, dfa); }
-                { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4(st, w, dfa); }
-                { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4(st, w, dfa); }
-                { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4(st, w, dfa); }
-            } else {
-#pragma unroll
-                for (int p = 0; p < 4; p++)
-                    if (hl[p] > 16) st[p] = dfa_partial(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
-            }
+        // short haystacks (<= 32 bytes): both vectors are already in flight
+        if (hl[0] >= 16 && hl[1] >= 16 && hl[2] >= 16 && hl[3] >= 16) {
+            { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4(st, w, dfa); }
         } else {
-            // longer / ragged haystacks: vector by vector over the 4 interleaved chains, requesting two vectors ahead.
-            // Bytes past a haystack's end are replaced by `dead`, a byte value no needle row can match (the needle has at
-            // most 63 rows x 2 cases), so every vector runs the same branch-free unrolled steps.
-            const u32 deadv = dead * 0x01010101u;
-            uint4 cur[4], nxt[4];
 #pragma unroll
-            for (int p = 0; p < 4; p++) cur[p] = v0[p], nxt[p] = v1[p];
-            for (u32 v = 0; v < nvmax; v++) {
-                uint4 nn[4];
+            for (int p = 0; p < 4; p++) st[p] = dfa_partial(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
+        }
+        if (hl[0] >= 32 && hl[1] >= 32 && hl[2] >= 32 && hl[3] >= 32) {
+            { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4(st, w, dfa); }
+        } else {
 #pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    nn[p] = make_uint4(0, 0, 0, 0);
-                    if (hl[p] > 16 * (v + 2)) nn[p] = ((const uint4*)(bytes + hs[p]))[v + 2];
-                }
-                u32 wx[4], wy[4], wz[4], ww[4];
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const u32 rem = hl[p] > 16 * v ? hl[p] - 16 * v : 0u;  // valid bytes from this vector on
-                    auto san = [&](u32 w, u32 off) {
-                        const u32 nv = rem > off ? rem - off : 0u;
-                        const u32 mask = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1);
-                        return (w & mask) | (deadv & ~mask);
-                    };
-                    wx[p] = san(cur[p].x, 0);
-                    wy[p] = san(cur[p].y, 4);
-                    wz[p] = san(cur[p].z, 8);
-                    ww[p] = san(cur[p].w, 12);
-                }
-                dfa_word4(st, wx, dfa);
-                dfa_word4(st, wy, dfa);
-                dfa_word4(st, wz, dfa);
-                dfa_word4(st, ww, dfa);
-#pragma unroll
-                for (int p = 0; p < 4; p++) cur[p] = nxt[p], nxt[p] = nn[p];
-            }
+            for (int p = 0; p < 4; p++)
+                if (hl[p] > 16) st[p] = dfa_partial(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
         }
         u32 cnt = 0;
 #pragma unroll
@@ -233,6 +194,116 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
             if (lane_id() == 0) {
                 bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
                 cnt += __popcll(b);
+            }
+        }
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K1-DFA for ragged lists (haystacks longer than the two pre-requested vectors).  Same DFA; P = haystacks a
+// thread runs interleaved (a 1024-haystack tile takes 4 / P sub-passes).  With long haystacks the quantity to
+// control is the cache footprint, not memory-level parallelism: a wave's load touches 64 haystacks = a
+// contiguous ~5 KB of which only 16 B per haystack are consumed, and the rest of those lines must still be in
+// L2 when the lane comes back for its next vector.  Footprint per CU = resident waves x P x ~5 KB, so P and the
+// number of resident workgroups are launch parameters (fzb_launch_filter).
+// ---------------------------------------------------------------------------------------------------
+template <int P>
+__device__ __forceinline__ void dfa_wordP(u32 (&st)[P], const u32 (&w)[P], const u8* dfa) {
+#pragma unroll
+    for (int p = 0; p < P; p++) st[p] = dfa_step<0>(st[p], w[p], dfa);
+#pragma unroll
+    for (int p = 0; p < P; p++) st[p] = dfa_step<1>(st[p], w[p], dfa);
+#pragma unroll
+    for (int p = 0; p < P; p++) st[p] = dfa_step<2>(st[p], w[p], dfa);
+#pragma unroll
+    for (int p = 0; p < P; p++) st[p] = dfa_step<3>(st[p], w[p], dfa);
+}
+
+template <typename ET, int P>
+__global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
+                                                     const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                                     u32* __restrict__ tile_counts) {
+    extern __shared__ __attribute__((aligned(16))) u8 dfa[];
+    __shared__ u32 s_cnt;
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    const u32 deadv = dead * 0x01010101u;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        u32 cnt = 0;
+#pragma unroll 1
+        for (int sub = 0; sub < 4 / P; sub++) {
+            const u32 base = tile * FZB_TILE + sub * (256 * P);
+            u64 hs[P];
+            u32 hl[P];
+            uint4 cur[P], nxt[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const u32 li = base + p * 256 + tid;
+                hs[p] = 0;
+                hl[p] = 0;
+                if (li < count) haystack_span(ends, first + li, hs[p], hl[p]);
+            }
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                cur[p] = make_uint4(0, 0, 0, 0);
+                nxt[p] = make_uint4(0, 0, 0, 0);
+                const uint4* vp = (const uint4*)(bytes + hs[p]);
+                if (hl[p] > 0) cur[p] = vp[0];
+                if (hl[p] > 16) nxt[p] = vp[1];
+            }
+            u32 st[P];
+            u32 nvmax = 0;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                st[p] = 0;
+                nvmax = max(nvmax, (hl[p] + 15) >> 4);
+            }
+            // Bytes past a haystack's end are replaced by `dead`, a byte value no needle row can match, so every vector runs
+            // the same branch-free unrolled steps.
+            for (u32 v = 0; v < nvmax; v++) {
+                uint4 nn[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    nn[p] = make_uint4(0, 0, 0, 0);
+                    if (hl[p] > 16 * (v + 2)) nn[p] = ((const uint4*)(bytes + hs[p]))[v + 2];
+                }
+                u32 wx[P], wy[P], wz[P], ww[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const u32 rem = hl[p] > 16 * v ? hl[p] - 16 * v : 0u;  // valid bytes from this vector on
+                    auto san = [&](u32 w, u32 off) {
+                        const u32 nv = rem > off ? rem - off : 0u;
+                        const u32 mask = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1);
+                        return (w & mask) | (deadv & ~mask);
+                    };
+                    wx[p] = san(cur[p].x, 0);
+                    wy[p] = san(cur[p].y, 4);
+                    wz[p] = san(cur[p].z, 8);
+                    ww[p] = san(cur[p].w, 12);
+                }
+                dfa_wordP<P>(st, wx, dfa);
+                dfa_wordP<P>(st, wy, dfa);
+                dfa_wordP<P>(st, wz, dfa);
+                dfa_wordP<P>(st, ww, dfa);
+#pragma unroll
+                for (int p = 0; p < P; p++) cur[p] = nxt[p], nxt[p] = nn[p];
+            }
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const u32 li = base + p * 256 + tid;
+                const bool matched = li < count && hl[p] >= min_len && st[p] == (u32)rows;
+                const u64 b = __ballot(matched);
+                if (lane_id() == 0) {
+                    bitmap[(base + p * 256) / 64 + (tid >> 6)] = b;
+                    cnt += __popcll(b);
+                }
             }
         }
         if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
@@ -416,10 +487,17 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
     if (mode == 1) {
         const size_t lds = (size_t)(rows + 1) * 256;
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
-#define FZB_K1D(ET, S) hipLaunchKernelGGL((k1_dfa<ET, S>), dim3(grid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts)
-        if (c.ends_u64) { if (shortc) FZB_K1D(u64, true); else FZB_K1D(u64, false); }
-        else            { if (shortc) FZB_K1D(u32, true); else FZB_K1D(u32, false); }
-#undef FZB_K1D
+        if (shortc) {
+            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
+            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
+        } else {
+            // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
+            // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times)
+            int rgrid = std::min<int>((grid / 8) * 6, (int)ntiles);
+            if (rgrid < 1) rgrid = 1;
+            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa_ragged<u64, 1>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
+            else hipLaunchKernelGGL((k1_dfa_ragged<u32, 1>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
+        }
         return;
     }
     if (mode == 0) {
