@@ -344,7 +344,7 @@ __device__ __forceinline__ u32 dp_multi_chunk(const NeedleDev& nd, const u8* __r
         u32 carry = 0;  // S(r-1, previous chunk) top dword (its high half is the last lane), unbiased
 #pragma unroll 1
         for (u32 r = 0; r < rows; r++) {
-            const u32 c = nd.c[r], f = nd.f[r];
+            const u32 c = (((const u32*)nd.c)[r >> 2] >> (8 * (r & 3))) & 0xFF, f = (((const u32*)nd.f)[r >> 2] >> (8 * (r & 3))) & 0xFF;  // scalar loads
             const bool ci = c != f;
             const u32 orv = ci ? 0x00200020u : 0u;
             const u32 cmpv = splat16(ci ? (c | 0x20) : c);

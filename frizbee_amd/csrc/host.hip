@@ -541,7 +541,7 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
         fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
         if (!no_wide) {
-            const int mgrid = cus * 2;
+            const int mgrid = cus * 4;  // 2 waves per SIMD (the kernel is capped at 256 VGPRs)
             const size_t words = (size_t)(nd.rows + 1) * (size_t)(lc.sw_lanes / 2) * (size_t)mgrid * 128;
             if (w.dp_scratch_words < words) {  // first use only
                 if (w.dp_scratch) HIPCHK(hipFree(w.dp_scratch));

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
 // k2d: the queued windows of SWL < m <= 1024 bytes, one thread each, chunk by chunk (dp_multi_chunk).
 // ---------------------------------------------------------------------------------------------------------------
 template <int SWL, bool BIAS, typename ET>
-__global__ __launch_bounds__(128) void k2d_dp_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+__global__ __launch_bounds__(128, 2) void k2d_dp_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                     const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
                                                     fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
     __shared__ u8 cls[256];
