@@ -7,6 +7,7 @@ All scoring runs in hand-written HIP kernels (frizbee_amd/csrc); there is no CPU
 works anywhere, but every scoring call raises unless libfrizbee_hip.so is built and a GPU is present.
 """
 import ctypes as C
+import weakref
 import enum
 import os
 from dataclasses import dataclass, field
@@ -149,12 +150,18 @@ def pack(haystacks):
     return data, ends
 
 
-def _take(out, n):
-    arr = np.zeros(n.value, MATCH_DTYPE)
-    if n.value:
-        C.memmove(arr.ctypes.data, out, n.value * 8)
-    lib().fzb_matches_free(out)
-    return arr
+def _take(out, n, copy=True):
+    """Result list of the C ABI -> numpy.  copy=False wraps the library's (pinned, pooled) buffer without copying and
+    returns it to the pool when the array is garbage collected."""
+    if copy or not n.value:
+        arr = np.zeros(n.value, MATCH_DTYPE)
+        if n.value:
+            C.memmove(arr.ctypes.data, out, n.value * 8)
+        lib().fzb_matches_free(out)
+        return arr
+    base = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(n.value * 8,))
+    weakref.finalize(base, lib().fzb_matches_free, C.c_void_p(out.value))
+    return base.view(MATCH_DTYPE)
 
 
 class Corpus:
@@ -216,12 +223,12 @@ class Matcher:
     def _corpus(self, haystacks):
         return haystacks if isinstance(haystacks, Corpus) else Corpus(haystacks)
 
-    def match_list(self, haystacks):
+    def match_list(self, haystacks, copy=True):
         """`Matcher::match_list` (src/matcher/mod.rs:212-222). `haystacks` is a list of str/bytes or a resident `Corpus`."""
         cp = self._corpus(haystacks)
         out, n = C.c_void_p(), C.c_size_t()
         _check(lib().fzb_match_list(self.h, cp.h, C.byref(out), C.byref(n)))
-        return _take(out, n)
+        return _take(out, n, copy)
 
     def match_list_parallel(self, haystacks, threads):
         """`Matcher::match_list_parallel` (src/matcher/parallel.rs:18-89); identical result for every thread count."""

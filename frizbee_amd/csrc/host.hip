@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/frizbee_hip.h"
@@ -588,6 +590,68 @@ int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match*
     return FZB_OK;
 }
 
+// Result lists handed to the caller live in page-locked host memory so that the device-to-host copy of the records runs at
+// DMA speed (a pageable destination is staged through bounce buffers: ~3x slower for a 4 MB list).  Pinning is expensive, so
+// the buffers are pooled: fzb_matches_free returns a buffer to the pool and a steady stream of queries keeps reusing the same
+// few.  Lists that never were on the device (empty needle) come from malloc; fzb_matches_free tells the two apart.
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> live;             // handed out: pointer -> capacity in bytes
+    std::vector<std::pair<void*, size_t>> free_list;    // ready for reuse
+    static constexpr size_t kMaxFree = 8;
+    void* get(size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        size_t best = free_list.size();
+        for (size_t i = 0; i < free_list.size(); i++)
+            if (free_list[i].second >= bytes && (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+        void* p = nullptr;
+        size_t cap = 0;
+        if (best != free_list.size()) {
+            p = free_list[best].first;
+            cap = free_list[best].second;
+            free_list.erase(free_list.begin() + best);
+        } else {
+            cap = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 16);
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+        }
+        live[p] = cap;
+        return p;
+    }
+    bool put(void* p) {  // false: not one of ours
+        std::lock_guard<std::mutex> g(mu);
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        const size_t cap = it->second;
+        live.erase(it);
+        if (free_list.size() < kMaxFree) free_list.emplace_back(p, cap);
+        else (void)hipHostFree(p);
+        return true;
+    }
+};
+PinnedPool& pinned_pool() {
+    static PinnedPool* pool = new PinnedPool;  // never destroyed: the HIP runtime may already be gone at exit
+    return *pool;
+}
+// count (device) -> host, then the records into a pooled pinned buffer
+int fetch_records(const void* dev_records, const u32* dev_count, fzb_match** out, size_t* out_len) {
+    u32 n = 0;
+    HIPCHK(hipMemcpy(&n, dev_count, 4, hipMemcpyDeviceToHost));  // synchronises the default stream
+    fzb_match* r = (fzb_match*)pinned_pool().get(std::max<size_t>(n, 1) * sizeof(fzb_match));
+    if (!r) return fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
+    if (n) {
+        hipError_t e = hipMemcpy(r, dev_records, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            pinned_pool().put(r);
+            return fail(FZB_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        }
+    }
+    *out = r;
+    *out_len = n;
+    return FZB_OK;
+}
+}  // namespace
+
 int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len) {
     if (!m || !c || !out || !out_len) return fail(FZB_ERR_INVALID, "null argument");
     if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
@@ -612,13 +676,7 @@ int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     }
     int rc = fzb_match_list_device(m, c, first, count, index_offset, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
-    u32 n = 0;
-    HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));  // synchronises the default stream
-    fzb_match* r = (fzb_match*)malloc(std::max<size_t>(n, 1) * sizeof(fzb_match));
-    if (n) HIPCHK(hipMemcpy(r, m->out_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost));
-    *out = r;
-    *out_len = n;
-    return FZB_OK;
+    return fetch_records(m->out_dev, m->count_dev, out, out_len);
 }
 
 void fzb_radix_sort_matches(fzb_match* matches, size_t n) {  // src/sort.rs:6-40
@@ -661,13 +719,7 @@ int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t*
     // scoring AND the reverse / stable radix sort post-step run on the device; the host only receives the final list
     int rc = fzb_match_list_sorted_device(m, c, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
-    u32 n = 0;
-    HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));
-    fzb_match* r = (fzb_match*)malloc(std::max<size_t>(n, 1) * sizeof(fzb_match));
-    if (n) HIPCHK(hipMemcpy(r, m->out_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost));
-    *out = r;
-    *out_len = n;
-    return FZB_OK;
+    return fetch_records(m->out_dev, m->count_dev, out, out_len);
 }
 
 int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads, fzb_match** out, size_t* out_len) {
@@ -676,7 +728,9 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
     return fzb_match_list(m, c, out, out_len);
 }
 
-void fzb_matches_free(fzb_match* p) { free(p); }
+void fzb_matches_free(fzb_match* p) {
+    if (p && !pinned_pool().put(p)) free(p);
+}
 
 static bool merge_less(int order, const fzb_match& l, const fzb_match& r) {  // src/k_merge.rs:14-53
     switch (order) {

@@ -29,6 +29,30 @@ if "C2" in which or "C3" in which:
     if "C3" in which: run("C3 len32 typos2", "deadbe", F.Config(max_typos=2, pf_lanes=64, sw_lanes=64), cp, n)
     if "C2none" in which: run("C2 len32 typosNone(all scored)", "deadbe", F.Config(max_typos=None, pf_lanes=64, sw_lanes=64), cp, n, steps=3)
     del cp, flat, ends
+for mixname, full, partial in (("MIXALL", 1.0, 0.0), ("MIXNONE", 0.0, 0.0)):
+    # the other two mixes of the reference's benchmark (benches/lib.rs:60-64): All Match (VALU-bound ceiling), No Match (pure filter)
+    if mixname in which:
+        flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
+        flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev, full=full, partial=partial))
+        ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
+        cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+        run(f"C2 list with mix full={full} partial={partial}", "deadbe", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n, steps=5)
+        del cp, flat, ends
+if "E2E" in which:
+    # end to end from host memory: pack + upload once (fzb_corpus_upload), then the ordered query the caller sees
+    # (fzb_match_list: pipeline + device sort + D2H of the records)
+    rows, ends = synth.fixed_corpus(b"deadbe", n, 32, device=dev)
+    data = rows.cpu().numpy().reshape(-1)
+    t0 = time.perf_counter(); cp = F.Corpus(packed=(data, ends)); t_up = time.perf_counter() - t0
+    m = F.Matcher("deadbe", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64))
+    m.match_list(cp)
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter(); r = m.match_list(cp, copy=False); ts.append(time.perf_counter() - t0)
+    print(json.dumps(dict(config="C2 end to end", haystacks=n, corpus_upload_ms=t_up * 1e3, upload_GBps=data.nbytes / t_up / 1e9,
+                          match_list_ms_best=min(ts) * 1e3, match_list_ms_median=sorted(ts)[len(ts) // 2] * 1e3, matches=int(len(r)),
+                          haystacks_per_s_query=n / min(ts))), flush=True)
+    del cp
 if "C4" in which:
     n4 = 12_500_000 if "C4small" not in which else 2_000_000
     data, ends = synth.ragged_corpus(b"deadbeef", n4, device=dev)
