@@ -15,7 +15,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
+#include <new>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -333,47 +336,69 @@ int fzb_matcher_info(const fzb_matcher* m, int32_t out[6]) {
 int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t n, fzb_corpus** out) {
     if (!out || (n && (!bytes || !end_offsets))) return fail(FZB_ERR_INVALID, "null argument");
     if (n > 0xFFFFFFFFull) return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(n) + " > 4294967295 (index offset: 0)");
-    // repack into the padded-16 device layout
-    std::vector<u64> pends(n);
-    u64 pos = 0, prev = 0, max_len = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (end_offsets[i] < prev) return fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
-        const u64 len = end_offsets[i] - prev;
-        max_len = std::max(max_len, len);
-        pos = (pos + 15) & ~(u64)15;
-        pos += len;
-        pends[i] = pos;
-        prev = end_offsets[i];
+    // repack into the padded-16 device layout, on up to 32 host threads: per-range padded sizes, a serial prefix over the
+    // ranges, then every range copies its haystacks (and zeroes its own gaps: the buffer is not cleared as a whole)
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::thread::hardware_concurrency(), n / 65536 + 1}));
+    const size_t per = (n + nthreads - 1) / nthreads;
+    std::vector<u64> range_bytes(nthreads, 0), range_max(nthreads, 0);
+    std::vector<int> range_bad(nthreads, 0);
+    auto for_ranges = [&](auto fn) {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(fn, t);
+        fn((size_t)0);
+        for (auto& th : pool) th.join();
+    };
+    for_ranges([&](size_t t) {
+        const size_t lo = std::min(t * per, n), hi = std::min(lo + per, n);
+        u64 prev = lo ? end_offsets[lo - 1] : 0, bytes_padded = 0, mx = 0;
+        for (size_t i = lo; i < hi; i++) {
+            if (end_offsets[i] < prev) { range_bad[t] = 1; break; }
+            const u64 len = end_offsets[i] - prev;
+            mx = std::max(mx, len);
+            bytes_padded += (len + 15) & ~(u64)15;
+            prev = end_offsets[i];
+        }
+        range_bytes[t] = bytes_padded;
+        range_max[t] = mx;
+    });
+    u64 max_len = 0, total_padded = 0;
+    std::vector<u64> range_start(nthreads, 0);
+    for (size_t t = 0; t < nthreads; t++) {
+        if (range_bad[t]) return fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
+        range_start[t] = total_padded;
+        total_padded += range_bytes[t];
+        max_len = std::max(max_len, range_max[t]);
     }
-    const u64 total = ((pos + 15) & ~(u64)15) + 96;
-    std::vector<u8> packed(total, 0);
-    prev = 0;
-    u64 ppos = 0;
-    for (size_t i = 0; i < n; i++) {
-        const u64 len = end_offsets[i] - prev;
-        ppos = (ppos + 15) & ~(u64)15;
-        memcpy(packed.data() + ppos, bytes + prev, len);
-        ppos += len;
-        prev = end_offsets[i];
-    }
+    const u64 total = total_padded + 96;
+    const bool ends_u64 = total > 0xFFFFFFF0ull;
+    std::unique_ptr<u8[]> packed(new (std::nothrow) u8[total]);
+    std::unique_ptr<u8[]> pends(new (std::nothrow) u8[std::max<size_t>(n, 1) * (ends_u64 ? 8 : 4)]);
+    if (!packed || !pends) return fail(FZB_ERR_INVALID, "out of host memory while packing the corpus");
+    memset(packed.get() + total_padded, 0, 96);
+    for_ranges([&](size_t t) {
+        const size_t lo = std::min(t * per, n), hi = std::min(lo + per, n);
+        u64 prev = lo ? end_offsets[lo - 1] : 0, ppos = range_start[t];  // every haystack starts on a 16-byte boundary
+        u8* dst = packed.get();
+        for (size_t i = lo; i < hi; i++) {
+            const u64 len = end_offsets[i] - prev;
+            memcpy(dst + ppos, bytes + prev, len);
+            const u64 end = ppos + len, next = (end + 15) & ~(u64)15;
+            if (next != end) memset(dst + end, 0, next - end);
+            if (ends_u64) ((u64*)pends.get())[i] = end;
+            else ((u32*)pends.get())[i] = (u32)end;
+            ppos = next;
+            prev = end_offsets[i];
+        }
+    });
     auto c = new fzb_corpus();
     c->dev.n = n;
     c->dev.total_bytes = total;
-    c->dev.ends_u64 = total > 0xFFFFFFF0ull;
+    c->dev.ends_u64 = ends_u64;
     c->dev.max_len = (u32)std::min<u64>(max_len, 0xFFFFFFFFu);
     hipError_t e = dev_alloc(&c->own_bytes, total);
-    if (e == hipSuccess) e = hipMemcpy(c->own_bytes, packed.data(), total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        if (c->dev.ends_u64) {
-            e = dev_alloc(&c->own_ends, n * 8);
-            if (e == hipSuccess && n) e = hipMemcpy(c->own_ends, pends.data(), n * 8, hipMemcpyHostToDevice);
-        } else {
-            std::vector<u32> e32(n);
-            for (size_t i = 0; i < n; i++) e32[i] = (u32)pends[i];
-            e = dev_alloc(&c->own_ends, n * 4);
-            if (e == hipSuccess && n) e = hipMemcpy(c->own_ends, e32.data(), n * 4, hipMemcpyHostToDevice);
-        }
-    }
+    if (e == hipSuccess) e = hipMemcpy(c->own_bytes, packed.get(), total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = dev_alloc(&c->own_ends, std::max<size_t>(n, 1) * (ends_u64 ? 8 : 4));
+    if (e == hipSuccess && n) e = hipMemcpy(c->own_ends, pends.get(), n * (ends_u64 ? 8 : 4), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         fzb_corpus_free(c);
         return fail(FZB_ERR_HIP, std::string("corpus upload: ") + hipGetErrorString(e));
