@@ -1286,8 +1286,11 @@ struct HaystackList {  // packed bytes + exclusive end offsets (the boundary's c
     const u8* bytes;
     const u64* ends;
     size_t n;
-    const u8* ptr(size_t i) const { return bytes + (i ? ends[i - 1] : 0); }
-    size_t len(size_t i) const { return (size_t)(ends[i] - (i ? ends[i - 1] : 0)); }
+    // optional indirection: item i is haystack gather[i] of the packed list (the `gathered: Vec<&str>` of matcher/multi.rs:107-114)
+    const u32* gather = nullptr;
+    size_t at(size_t i) const { return gather ? (size_t)gather[i] : i; }
+    const u8* ptr(size_t i) const { size_t k = at(i); return bytes + (k ? ends[k - 1] : 0); }
+    size_t len(size_t i) const { size_t k = at(i); return (size_t)(ends[k] - (k ? ends[k - 1] : 0)); }
 };
 
 struct MatcherBase {
@@ -1475,6 +1478,125 @@ struct Matcher {
         }
         for (auto& th : pool) th.join();
         return total.load();
+    }
+};
+
+// =======================================================================================
+// MULTI-PATTERN COMPOSITION: src/matcher/multi.rs, fuzzy patterns only.
+// A pattern = needle + negation + per-pattern overrides resolved against the matcher's config
+// (PatternConfig::resolve, src/pattern.rs:250-262; Matcher::compile, src/matcher/mod.rs:192-204).
+// The literal matching modes (prefix / suffix / substring / exact, src/literal) are not restated.
+// =======================================================================================
+struct PatternSpec {
+    std::string needle;
+    bool negated = false;
+    bool has_max_typos = false;  // Some(k): overrides; None: inherits (even when the config says None)
+    int max_typos = 0;
+    int casing = -1, unicode = -1;  // -1: inherit
+    bool has_scoring = false;
+    Scoring scoring;
+};
+
+struct MultiMatcher {
+    Config config;
+    struct Compiled { bool negated; Matcher* m; };
+    std::vector<Compiled> patterns;  // empty needles are dropped (mod.rs:193-195)
+
+    MultiMatcher(const std::vector<PatternSpec>& specs, const Config& c, int pf_lanes, int sw_lanes_u8, int sw_lanes_u16) : config(c) {
+        for (const PatternSpec& sp : specs) {
+            if (sp.needle.empty()) continue;
+            Config rc = c;  // PatternConfig::resolve: sort is always the matcher's
+            if (sp.has_max_typos) rc.max_typos = sp.max_typos;
+            if (sp.casing >= 0) rc.casing = sp.casing;
+            if (sp.unicode >= 0) rc.unicode = sp.unicode;
+            if (sp.has_scoring) rc.scoring = sp.scoring;
+            rc.sort = SORT_INDEX_ASC;
+            patterns.push_back(Compiled{sp.negated, new Matcher(sp.needle, rc, pf_lanes, sw_lanes_u8, sw_lanes_u16)});
+        }
+    }
+    ~MultiMatcher() { for (auto& p : patterns) delete p.m; }
+    MultiMatcher(const MultiMatcher&) = delete;
+
+    // CompiledPatterns::{Empty, Single, Multi} (mod.rs:178-190): a single NEGATED pattern is Multi
+    bool is_empty() const { return patterns.empty(); }
+    bool is_single() const { return patterns.size() == 1 && !patterns[0].negated; }
+
+    // match_list_multi_into (multi.rs:84-152)
+    void match_list_multi_into(const HaystackList& hs, size_t lo, size_t hi, u32 index_offset, std::vector<Match>& out) const {
+        size_t base = patterns.size();
+        for (size_t i = 0; i < patterns.size(); i++) if (!patterns[i].negated) { base = i; break; }
+        std::vector<Match> candidates;
+        if (base != patterns.size()) patterns[base].m->match_list_into(patterns[base].m->impl, hs, lo, hi, index_offset, candidates);
+        else for (size_t i = lo; i < hi; i++) candidates.push_back(Match{(u32)(index_offset + (i - lo)), 0, 0, 0});
+        std::vector<u32> gathered;
+        std::vector<Match> hits;
+        for (size_t pi = 0; pi < patterns.size(); pi++) {
+            if (pi == base || candidates.empty()) continue;
+            gathered.clear();
+            for (const Match& m : candidates) gathered.push_back((u32)(lo + (m.index - index_offset)));
+            HaystackList sub{hs.bytes, hs.ends, gathered.size(), gathered.data()};
+            hits.clear();
+            patterns[pi].m->match_list_into(patterns[pi].m->impl, sub, 0, sub.n, 0, hits);
+            if (patterns[pi].negated) {
+                std::vector<Match> kept;
+                size_t h = 0;
+                for (size_t pos = 0; pos < candidates.size(); pos++) {
+                    bool matched = h < hits.size() && hits[h].index == pos;
+                    if (matched) h++;
+                    else kept.push_back(candidates[pos]);
+                }
+                candidates.swap(kept);
+            } else {
+                std::vector<Match> next;
+                for (Match hit : hits) {
+                    const Match& cand = candidates[hit.index];
+                    hit.index = cand.index;
+                    hit.score = sat_add16(hit.score, cand.score);
+                    hit.exact = (u8)(hit.exact | cand.exact);
+                    next.push_back(hit);
+                }
+                candidates.swap(next);
+            }
+        }
+        out.insert(out.end(), candidates.begin(), candidates.end());
+    }
+
+    void match_list_into(const HaystackList& hs, size_t lo, size_t hi, u32 index_offset, std::vector<Match>& out) const {  // mod.rs:373-392
+        std::string err = Matcher::guard_against_haystack_overflow(hi - lo, index_offset);
+        if (!err.empty()) throw std::runtime_error(err);
+        if (is_empty()) { for (size_t i = lo; i < hi; i++) out.push_back(Match{(u32)(index_offset + (i - lo)), 0, 0, 0}); return; }
+        if (is_single()) { patterns[0].m->match_list_into(patterns[0].m->impl, hs, lo, hi, index_offset, out); return; }
+        match_list_multi_into(hs, lo, hi, index_offset, out);
+    }
+
+    std::vector<Match> match_list(const HaystackList& hs) const {  // mod.rs:212-222
+        std::vector<Match> matches;
+        match_list_into(hs, 0, hs.n, 0, matches);
+        if (sort_is_reversed(config.sort)) std::reverse(matches.begin(), matches.end());
+        if (!is_empty() && sort_is_by_score(config.sort)) radix_sort_matches(matches);
+        return matches;
+    }
+
+    // The reference's own oracle for this composition (tests/api_properties.rs:316-361): match every pattern on its own,
+    // intersect the non-negated ones (scores add with saturation, exact flags OR), subtract the negated ones.  Index order.
+    std::vector<Match> reference_composition(const HaystackList& hs) const {
+        std::vector<std::vector<Match>> per(patterns.size());
+        for (size_t pi = 0; pi < patterns.size(); pi++) patterns[pi].m->match_list_into(patterns[pi].m->impl, hs, 0, hs.n, 0, per[pi]);
+        std::vector<size_t> cur(patterns.size(), 0);
+        std::vector<Match> out;
+        for (size_t i = 0; i < hs.n; i++) {
+            Match combined{(u32)i, 0, 0, 0};
+            bool keep = true;
+            for (size_t pi = 0; pi < patterns.size(); pi++) {
+                while (cur[pi] < per[pi].size() && per[pi][cur[pi]].index < i) cur[pi]++;
+                const Match* hit = (cur[pi] < per[pi].size() && per[pi][cur[pi]].index == i) ? &per[pi][cur[pi]] : nullptr;
+                if (patterns[pi].negated) { if (hit) keep = false; }
+                else if (!hit) keep = false;
+                else { combined.score = sat_add16(combined.score, hit->score); combined.exact = (u8)(combined.exact | hit->exact); }
+            }
+            if (keep) out.push_back(combined);
+        }
+        return out;
     }
 };
 

@@ -138,6 +138,49 @@ int fzo_match_list_count(void* m, const uint8_t* bytes, const uint64_t* ends, si
         return 0;
     } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
+// ---- multi-pattern composition (matcher/multi.rs; fuzzy patterns) ----
+struct fzo_pattern {
+    const uint8_t* needle;
+    size_t needle_len;
+    int32_t negated, has_max_typos, max_typos, casing, unicode, has_scoring;  // casing / unicode: -1 = inherit
+    uint16_t scoring[9];
+};
+void* fzo_multi_create(const fzo_config* cfg, const fzo_pattern* pats, size_t npats, int pf_lanes, int sw_lanes_u8, int sw_lanes_u16) {
+    try {
+        std::vector<PatternSpec> specs;
+        for (size_t i = 0; i < npats; i++) {
+            PatternSpec sp;
+            sp.needle.assign((const char*)pats[i].needle, pats[i].needle_len);
+            sp.negated = pats[i].negated != 0;
+            sp.has_max_typos = pats[i].has_max_typos != 0;
+            sp.max_typos = pats[i].max_typos;
+            sp.casing = pats[i].casing;
+            sp.unicode = pats[i].unicode;
+            sp.has_scoring = pats[i].has_scoring != 0;
+            if (sp.has_scoring) {
+                const uint16_t* v = pats[i].scoring;
+                sp.scoring = Scoring{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
+            }
+            specs.push_back(sp);
+        }
+        return new MultiMatcher(specs, config_from(cfg), pf_lanes, sw_lanes_u8, sw_lanes_u16);
+    } catch (std::exception& e) { g_err = e.what(); return nullptr; }
+}
+void fzo_multi_free(void* m) { delete (MultiMatcher*)m; }
+// mode 0: Matcher::match_list over CompiledPatterns (sequential narrowing, multi.rs:84-152, then the ordering step);
+// mode 1: the reference's test oracle for it (per-pattern lists composed per haystack, index order).
+int fzo_multi_match_list(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, int mode, Match** out, size_t* out_len) {
+    try {
+        HaystackList hs{bytes, ends, n};
+        MultiMatcher* mm = (MultiMatcher*)m;
+        std::vector<Match> r = mode == 0 ? mm->match_list(hs) : mm->reference_composition(hs);
+        *out_len = r.size();
+        *out = (Match*)malloc(std::max<size_t>(r.size(), 1) * sizeof(Match));
+        if (!r.empty()) memcpy(*out, r.data(), r.size() * sizeof(Match));
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
 // Timing leg: score every haystack on `threads` workers, no ordering step (Matcher::score_parallel_unordered).
 int fzo_score_count_unordered(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, long threads, size_t* out_len) {
     try {

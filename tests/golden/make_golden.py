@@ -214,4 +214,25 @@ json.dump({"cases": matcher, "same_result": same,
            "score_fits_in_u8": [dict(needle_len=4, scoring=[12, 6, 5, 1, 12, 4, 4, 8, 4], fits=True, ref="src/smith_waterman/mod.rs:523"),
                                 dict(needle_len=4, scoring=[12, 6, 5, 8, 12, 4, 4, 8, 4], fits=False, ref="src/smith_waterman/mod.rs:526-530")]},
           open(os.path.join(HERE, "matcher.json"), "w"), ensure_ascii=False, indent=1)
+# ---- multi-pattern composition, fuzzy patterns (src/matcher/multi.rs tests; patterns as (needle, negated, max_typos or "inherit")) ----
+multi = [
+    dict(name="scores_sum", patterns=[["foo", False, "inherit"], ["foo", False, "inherit"]], haystacks=["foo", "xfoox", "bar"], config=dict(sort="IndexAsc"),
+         expect_double_of_single="foo", ref="src/matcher/multi.rs:192-207"),
+    dict(name="score_sorted", patterns=[["foo", False, "inherit"], ["bar", False, "inherit"]], haystacks=["xfoobarx", "foobar", "zzz"], config=dict(),
+         expect_len=2, expect_first_index=1, expect_sorted=True, ref="src/matcher/multi.rs:230-237"),
+    dict(name="max_typos_override_beats_config", patterns=[["helloz", False, 1]], haystacks=["hello", "world"], config=dict(max_typos=0, sort="IndexAsc"),
+         expect_indices=[0], ref="src/matcher/multi.rs:338-349"),
+    dict(name="no_override_is_strict", patterns=[["helloz", False, "inherit"]], haystacks=["hello", "world"], config=dict(max_typos=0, sort="IndexAsc"),
+         expect_indices=[], ref="src/matcher/multi.rs:335-337"),
+    dict(name="max_typos_override_per_pattern", patterns=[["foo", False, "inherit"], ["barz", False, 1]], haystacks=["foo bar", "fox bar"],
+         config=dict(max_typos=0, sort="IndexAsc"), expect_indices=[0], ref="src/matcher/multi.rs:352-368"),
+    dict(name="smart_case_per_pattern", patterns=[["Foo", False, "inherit"], ["bar", False, "inherit"]], haystacks=["Foo BAR", "foo bar"],
+         config=dict(casing="Smart", sort="IndexAsc"), expect_indices=[0], ref="src/matcher/multi.rs:389-398"),
+    dict(name="unicode_per_pattern", patterns=[["다나", False, "inherit"], ["foo", False, "inherit"]], haystacks=["다나 foo", "dana foo", "다나"],
+         config=dict(sort="IndexAsc"), expect_indices=[0], ref="src/matcher/multi.rs:401-406"),
+    dict(name="empty_patterns_match_everything", patterns=[], haystacks=["foo", "bar"], config=dict(), expect_len=2, ref="src/matcher/multi.rs:409-413"),
+    dict(name="only_empty_needles_match_everything", patterns=[["", True, "inherit"], ["", False, "inherit"]], haystacks=["foo", "bar"], config=dict(), expect_len=2,
+         ref="src/matcher/multi.rs:415-416; src/matcher/mod.rs:193-195"),
+]
+json.dump({"cases": multi}, open(os.path.join(HERE, "multi.json"), "w"), ensure_ascii=False, indent=1)
 print("golden written")

@@ -16,6 +16,11 @@ SORT = {"ScoreThenIndexAsc": 0, "ScoreThenIndexDesc": 1, "IndexAsc": 2, "IndexDe
 MATCH_DTYPE = np.dtype([("index", "<u4"), ("score", "<u2"), ("exact", "u1"), ("_pad", "u1")])
 
 
+class FzoPattern(C.Structure):
+    _fields_ = [("needle", C.c_char_p), ("needle_len", C.c_size_t), ("negated", C.c_int32), ("has_max_typos", C.c_int32), ("max_typos", C.c_int32),
+                ("casing", C.c_int32), ("unicode", C.c_int32), ("has_scoring", C.c_int32), ("scoring", C.c_uint16 * 9)]
+
+
 class FzoConfig(C.Structure):
     _fields_ = [("max_typos", C.c_int32), ("casing", C.c_int32), ("unicode", C.c_int32), ("sort", C.c_int32), ("scoring", C.c_uint16 * 9)]
 
@@ -53,6 +58,10 @@ def lib(native=False):
         l.fzo_match_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzo_match_list_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_size_t)]
         l.fzo_score_count_unordered.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_long, C.POINTER(C.c_size_t)]
+        l.fzo_multi_create.restype = C.c_void_p
+        l.fzo_multi_create.argtypes = [C.POINTER(FzoConfig), C.POINTER(FzoPattern), C.c_size_t, C.c_int, C.c_int, C.c_int]
+        l.fzo_multi_free.argtypes = [C.c_void_p]
+        l.fzo_multi_match_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzo_free.argtypes = [C.c_void_p]
         l.fzo_radix_sort.argtypes = [C.c_void_p, C.c_size_t]
         l.fzo_k_merge.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -175,6 +184,66 @@ class Matcher:
         try:
             if getattr(self, "h", None):
                 self.lib.fzo_matcher_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+INHERIT = "inherit"
+
+
+def P(needle, negated=False, max_typos=INHERIT, casing=None, unicode=None, scoring=None):
+    """One pattern of a multi-pattern matcher (reference `Pattern` + `PatternConfig`, src/pattern.rs:9-18, 230-262; fuzzy matching
+    only).  max_typos=INHERIT is PatternConfig's `None`; an int is `Some(k)`."""
+    return dict(needle=needle, negated=negated, max_typos=max_typos, casing=casing, unicode=unicode, scoring=scoring)
+
+
+class MultiMatcher:
+    """Oracle `Matcher::from_patterns` (src/matcher/mod.rs:95-111, 178-204; src/matcher/multi.rs)."""
+
+    def __init__(self, patterns, lanes=(64, 64, 32), native=False, **cfg):
+        self.cfg = make_config(**cfg)
+        self.lib = lib(native)
+        arr = (FzoPattern * max(len(patterns), 1))()
+        self._keep = []
+        for i, p in enumerate(patterns):
+            n = _b(p["needle"])
+            self._keep.append(n)
+            arr[i].needle, arr[i].needle_len, arr[i].negated = n, len(n), int(p["negated"])
+            arr[i].has_max_typos = int(p["max_typos"] != INHERIT)
+            arr[i].max_typos = 0 if p["max_typos"] == INHERIT else int(p["max_typos"])
+            arr[i].casing = -1 if p["casing"] is None else CASING[p["casing"]]
+            arr[i].unicode = -1 if p["unicode"] is None else UNICODE[p["unicode"]]
+            arr[i].has_scoring = int(p["scoring"] is not None)
+            for k, v in enumerate(p["scoring"] or DEFAULT_SCORING):
+                arr[i].scoring[k] = v
+        self.h = self.lib.fzo_multi_create(C.byref(self.cfg), arr, len(patterns), *lanes)
+        if not self.h:
+            raise RuntimeError(self.lib.fzo_last_error().decode())
+
+    def _run(self, data, ends, mode):
+        out, n = C.c_void_p(), C.c_size_t()
+        rc = self.lib.fzo_multi_match_list(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), mode, C.byref(out), C.byref(n))
+        if rc:
+            raise RuntimeError(self.lib.fzo_last_error().decode())
+        arr = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 8,))[: n.value * 8].view(MATCH_DTYPE).copy()
+        self.lib.fzo_free(out)
+        return arr
+
+    def match_packed(self, data, ends):
+        return self._run(data, ends, 0)
+
+    def match_list(self, haystacks):
+        return self._run(*pack(haystacks), 0)
+
+    def reference_composition(self, haystacks):
+        """the reference's own test oracle for the composition (tests/api_properties.rs:316-361), index order"""
+        return self._run(*pack(haystacks), 1)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.fzo_multi_free(self.h)
                 self.h = None
         except Exception:
             pass
