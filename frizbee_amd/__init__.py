@@ -88,6 +88,11 @@ class _CConfig(C.Structure):
                 ("pf_lanes", C.c_uint16), ("sw_lanes", C.c_uint16)]
 
 
+class _CPattern(C.Structure):
+    _fields_ = [("needle_utf8", C.c_char_p), ("needle_len", C.c_size_t), ("negated", C.c_int32), ("has_max_typos", C.c_int32), ("max_typos", C.c_int32),
+                ("casing", C.c_int32), ("unicode", C.c_int32), ("has_scoring", C.c_int32), ("scoring", _CScoring)]
+
+
 _lib = None
 
 SYMBOLS = [
@@ -95,6 +100,7 @@ SYMBOLS = [
     "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_set_max_len", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
     "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
+    "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
 ]
 
 
@@ -128,6 +134,12 @@ def lib():
         l.fzb_set_profiling.argtypes = [C.c_void_p, C.c_int]
         l.fzb_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.fzb_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        l.fzb_multi_matcher_create.argtypes = [C.POINTER(_CConfig), C.POINTER(_CPattern), C.c_size_t, C.POINTER(C.c_void_p)]
+        l.fzb_multi_matcher_free.argtypes = [C.c_void_p]
+        l.fzb_multi_matcher_len.argtypes = [C.c_void_p]
+        l.fzb_multi_matcher_len.restype = C.c_size_t
+        l.fzb_multi_match_list.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_multi_match_list_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
 
@@ -199,17 +211,78 @@ class Corpus:
             pass
 
 
+def _c_config(config):
+    c = _CConfig()
+    c.max_typos = -1 if config.max_typos is None else int(config.max_typos)
+    c.casing, c.unicode, c.sort = int(config.casing), int(config.unicode), int(config.sort)
+    for name, v in zip([f[0] for f in _CScoring._fields_], config.scoring.as_list()):
+        setattr(c.scoring, name, v)
+    c.pf_lanes, c.sw_lanes = config.pf_lanes, config.sw_lanes
+    return c
+
+
+@dataclass
+class Pattern:
+    """Reference `Pattern` + `PatternConfig` (src/pattern.rs:9-18, 230-262), fuzzy matching only.  `None` fields inherit the
+    matcher's config; max_typos=k is `Some(k)` (there is no way to ask for unlimited typos per pattern, as in the reference)."""
+    needle: "str | bytes"
+    negated: bool = False
+    max_typos: "int | None" = None
+    casing: "CaseMatching | None" = None
+    unicode: "UnicodeMatching | None" = None
+    scoring: "Scoring | None" = None
+
+
+class MultiMatcher:
+    """`Matcher::from_patterns(&patterns, &config)` (src/matcher/mod.rs:95-111; composition src/matcher/multi.rs:84-152)."""
+
+    def __init__(self, patterns, config=None):
+        self.config = config or Config()
+        pats = [p if isinstance(p, Pattern) else Pattern(p) for p in patterns]
+        arr = (_CPattern * max(len(pats), 1))()
+        self._keep = []
+        for i, p in enumerate(pats):
+            n = _b(p.needle)
+            self._keep.append(n)
+            arr[i].needle_utf8, arr[i].needle_len, arr[i].negated = n, len(n), int(p.negated)
+            arr[i].has_max_typos, arr[i].max_typos = int(p.max_typos is not None), int(p.max_typos or 0)
+            arr[i].casing = -1 if p.casing is None else int(p.casing)
+            arr[i].unicode = -1 if p.unicode is None else int(p.unicode)
+            arr[i].has_scoring = int(p.scoring is not None)
+            for name, v in zip([f[0] for f in _CScoring._fields_], (p.scoring or Scoring()).as_list()):
+                setattr(arr[i].scoring, name, v)
+        c = _c_config(self.config)
+        self.h = C.c_void_p()
+        _check(lib().fzb_multi_matcher_create(C.byref(c), arr, len(pats), C.byref(self.h)))
+
+    def __len__(self):
+        return lib().fzb_multi_matcher_len(self.h)
+
+    def match_list(self, haystacks, copy=True):
+        cp = haystacks if isinstance(haystacks, Corpus) else Corpus(haystacks)
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_multi_match_list(self.h, cp.h, C.byref(out), C.byref(n)))
+        return _take(out, n, copy)
+
+    def match_list_device(self, corpus, dev_out_ptr, capacity, dev_count_ptr, stream=0, first=0, count=None, index_offset=0):
+        count = len(corpus) - first if count is None else count
+        _check(lib().fzb_multi_match_list_device(self.h, corpus.h, first, count, index_offset, dev_out_ptr, capacity, dev_count_ptr, stream))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().fzb_multi_matcher_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class Matcher:
     """`frizbee::Matcher` for one (non-negated, fuzzy) pattern: `Matcher::new(needle, &config)` (src/matcher/mod.rs:90-92)."""
 
     def __init__(self, needle, config=None):
         self.config = config or Config()
-        c = _CConfig()
-        c.max_typos = -1 if self.config.max_typos is None else int(self.config.max_typos)
-        c.casing, c.unicode, c.sort = int(self.config.casing), int(self.config.unicode), int(self.config.sort)
-        for name, v in zip([f[0] for f in _CScoring._fields_], self.config.scoring.as_list()):
-            setattr(c.scoring, name, v)
-        c.pf_lanes, c.sw_lanes = self.config.pf_lanes, self.config.sw_lanes
+        c = _c_config(self.config)
         n = _b(needle)
         self.needle = n
         self.h = C.c_void_p()

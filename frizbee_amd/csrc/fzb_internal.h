@@ -101,7 +101,9 @@ struct LaunchCfg {
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
 void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, const u32* base_in, u32* base_out, hipStream_t st);
-void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, u32* out_idx, u32* total_out, int grid, hipStream_t st);
+void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st);
+void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,
+                             u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
 void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,
                     const u32* in_idx, const u32* in_win, u32* out_win, int grid, hipStream_t st);
 // kernels_window.hip
@@ -118,6 +120,13 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
                            int grid, hipStream_t st);
 // kernels_sort.hip
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st);
+// kernels_multi.hip
+void fzb_launch_records_to_items(const fzb_match_rec* cand, const u32* n_ptr, u32 index_offset, u32* items, int grid, hipStream_t st);
+void fzb_launch_identity_records(fzb_match_rec* out, u32 n, u32 index_offset, u32* count_out, int grid, hipStream_t st);
+void fzb_launch_join_add(fzb_match_rec* hits, const u32* n_hits_ptr, const fzb_match_rec* cand, const u32* n_cand_ptr, int grid, hipStream_t st);
+void fzb_launch_remove_hits(const fzb_match_rec* cand, const u32* n_cand_ptr, const fzb_match_rec* hits, const u32* n_hits_ptr, u64* bitmap, u32* tile_counts,
+                            fzb_match_rec* out, u32* total_out, int grid, hipStream_t st);
+void fzb_launch_copy_records(const fzb_match_rec* in, const u32* n_ptr, fzb_match_rec* out, u32 capacity, u32* count_out, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st);

@@ -217,6 +217,7 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     m->use_u8 = fits_in_u8(needle_len, sc);  // byte length (src/matcher/mod.rs:453)
     int pf = config->pf_lanes, sw = config->sw_lanes;
     if (pf == 0 && sw == 0) detect_host_lanes(m->use_u8, pf, sw);
+    else if (sw == 0) sw = m->use_u8 ? pf : pf / 2;  // the score width of the ISA family whose prefilter has pf lanes (64: AVX-512, 32: AVX2, 16: SSE/scalar)
     if (!(pf == 16 || pf == 32 || pf == 64) || !(sw == 8 || sw == 16 || sw == 32 || sw == 64)) {
         delete m;
         return fail(FZB_ERR_INVALID, "pf_lanes must be 16/32/64 and sw_lanes 8/16/32/64 (or both 0 = auto)");
@@ -469,8 +470,11 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     return FZB_OK;
 }
 
-int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity,
-                          uint32_t* dev_count, void* stream) {
+// The pipeline.  items_in == nullptr: the haystacks are the contiguous range [first, first + count).  Otherwise they are the
+// listed ones, items_in[j] = index relative to `first`, *n_items_in of them (a device-side count <= count): the narrowing
+// step of the multi-pattern composition.
+static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, const u32* items_in, const u32* n_items_in,
+                        fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream) {
     if (!m || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
     if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
     // guard_against_haystack_overflow (src/matcher/mod.rs:438-446)
@@ -513,7 +517,7 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     if (m->profiling) {
         const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);
         pev = m->evring[slot];
-        m->ev_filter[slot] = lc.filter_mode ? 1 : 0;
+        m->ev_filter[slot] = (lc.filter_mode && !items_in) ? 1 : 0;
         m->prof_calls++;
         for (int i = 0; i < 4; i++)
             if (!pev[i]) HIPCHK(hipEventCreate(&pev[i]));
@@ -525,7 +529,19 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     const u32* win = nullptr;
     const u32* n_items_ptr = &cnt_c[0];
     int wmode = lc.window_mode;
-    if (lc.filter_mode == 0) {
+    if (items_in) {
+        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
+        if (lc.filter_mode == 0) {
+            HIPCHK(hipMemcpyAsync(&cnt_c[0], n_items_in, 4, hipMemcpyDeviceToDevice, st));
+            items = items_in;
+        } else {
+            fzb_launch_filter_items(cd, first, items_in, n_items_in, w.table, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 4, st);
+            FZB_STAGE("filter(items)");
+            fzb_launch_compact1(w.bitmap, w.tile_counts, 0, n_items_in, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
+            FZB_STAGE("compact1(items)");
+            items = w.surv_idx;
+        }
+    } else if (lc.filter_mode == 0) {
         // nothing filtered (max_typos = None or >= rows): the survivors are the identity list
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&cnt_c[0], (int)cnt, 1, st));
     } else {
@@ -534,7 +550,7 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
         fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 8, st);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, w.surv_idx, &cnt_c[0], cus * 2, st);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 2, st);
         FZB_STAGE("compact1");
         items = w.surv_idx;
     }
@@ -590,6 +606,11 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
     if (pev) HIPCHK(hipEventRecord(pev[1], st));
     HIPCHK(hipGetLastError());
     return FZB_OK;
+}
+
+int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity,
+                          uint32_t* dev_count, void* stream) {
+    return run_pipeline(m, c, first, count, index_offset, nullptr, nullptr, dev_out, capacity, dev_count, stream);
 }
 
 int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream) {
@@ -751,6 +772,186 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
     if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
     if (threads == 0) return fail(FZB_ERR_PANIC, "threads must be positive");  // parallel.rs:24
     return fzb_match_list(m, c, out, out_len);
+}
+
+// ---- multi-pattern composition (src/matcher/multi.rs) ---------------------------------------------------
+struct fzb_multi_matcher {
+    fzb_config config{};
+    struct Compiled { bool negated; fzb_matcher* m; };
+    std::vector<Compiled> patterns;  // empty needles dropped (src/matcher/mod.rs:193-195)
+    int num_cus = 0;
+    // device buffers, grown on demand: two candidate lists (ping-pong), their lengths, the item list handed to the next pattern,
+    // and the bitmap / per-tile counts of the negation's compaction
+    size_t cap = 0;
+    fzb_match_rec* cand[2] = {nullptr, nullptr};
+    u32* counts = nullptr;  // [0],[1] = lengths of cand[0], cand[1]
+    u32* items = nullptr;
+    u64* bitmap = nullptr;
+    u32* tile_counts = nullptr;
+    // ordering + staging for the synchronous API
+    fzb_match_rec* out_dev = nullptr;
+    size_t out_cap = 0;
+    u32* count_dev = nullptr;
+    fzb_match_rec* sort_tmp = nullptr;
+    u32* sort_hist = nullptr;
+    size_t sort_cap = 0;
+};
+
+static void multi_free_buffers(fzb_multi_matcher* mm) {
+    void* ptrs[] = {mm->cand[0], mm->cand[1], mm->counts, mm->items, mm->bitmap, mm->tile_counts};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    mm->cand[0] = mm->cand[1] = nullptr;
+    mm->counts = mm->items = nullptr;
+    mm->bitmap = nullptr;
+    mm->tile_counts = nullptr;
+    mm->cap = 0;
+}
+
+int fzb_multi_matcher_create(const fzb_config* config, const fzb_pattern* patterns, size_t n_patterns, fzb_multi_matcher** out) {
+    if (!config || !out || (n_patterns && !patterns)) return fail(FZB_ERR_INVALID, "null argument");
+    auto mm = new fzb_multi_matcher();
+    mm->config = *config;
+    for (size_t i = 0; i < n_patterns; i++) {
+        const fzb_pattern& p = patterns[i];
+        if (p.needle_len == 0) continue;  // Matcher::compile returns None for an empty needle
+        if (!p.needle_utf8) { fzb_multi_matcher_free(mm); return fail(FZB_ERR_INVALID, "null needle"); }
+        fzb_config rc = *config;  // PatternConfig::resolve (src/pattern.rs:250-262); `sort` is the matcher's and applies to the combined list only
+        if (p.has_max_typos) rc.max_typos = p.max_typos;
+        if (p.casing >= 0) rc.casing = p.casing;
+        if (p.unicode >= 0) rc.unicode = p.unicode;
+        if (p.has_scoring) rc.scoring = p.scoring;
+        rc.sort = FZB_SORT_INDEX_ASC;
+        fzb_matcher* m = nullptr;
+        int rc_create = fzb_matcher_create(&rc, p.needle_utf8, p.needle_len, &m);
+        if (rc_create) { fzb_multi_matcher_free(mm); return rc_create; }
+        mm->patterns.push_back({p.negated != 0, m});
+    }
+    *out = mm;
+    return FZB_OK;
+}
+
+void fzb_multi_matcher_free(fzb_multi_matcher* mm) {
+    if (!mm) return;
+    for (auto& p : mm->patterns) fzb_matcher_free(p.m);
+    multi_free_buffers(mm);
+    void* ptrs[] = {mm->out_dev, mm->count_dev, mm->sort_tmp, mm->sort_hist};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete mm;
+}
+
+size_t fzb_multi_matcher_len(const fzb_multi_matcher* mm) { return mm ? mm->patterns.size() : 0; }
+
+int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity,
+                                uint32_t* dev_count, void* stream) {
+    if (!mm || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
+    if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
+    if ((u64)count + (u64)index_offset > 0xFFFFFFFFull)
+        return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
+    hipStream_t st = (hipStream_t)stream;
+    if (!mm->num_cus) {
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        mm->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int cus = mm->num_cus;
+    const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
+    auto& ps = mm->patterns;
+    if (count == 0) {
+        HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
+        return FZB_OK;
+    }
+    // CompiledPatterns::{Empty, Single, Multi} (src/matcher/mod.rs:178-190; a single NEGATED pattern is Multi)
+    if (ps.empty()) {
+        if (count > capacity) return fail(FZB_ERR_CAPACITY, "output buffer smaller than the haystack list (no pattern: every haystack matches)");
+        fzb_launch_identity_records((fzb_match_rec*)dev_out, (u32)count, index_offset, dev_count, cus * 2, st);
+        HIPCHK(hipGetLastError());
+        return FZB_OK;
+    }
+    if (ps.size() == 1 && !ps[0].negated) return fzb_match_list_device(ps[0].m, c, first, count, index_offset, dev_out, capacity, dev_count, stream);
+    if (mm->cap < count) {
+        multi_free_buffers(mm);
+        const size_t cap = count + count / 8 + 4096;
+        HIPCHK(dev_alloc((void**)&mm->cand[0], (cap + 16) * sizeof(fzb_match_rec)));
+        HIPCHK(dev_alloc((void**)&mm->cand[1], (cap + 16) * sizeof(fzb_match_rec)));
+        HIPCHK(dev_alloc((void**)&mm->counts, 64));
+        HIPCHK(dev_alloc((void**)&mm->items, cap * 4));
+        HIPCHK(dev_alloc((void**)&mm->bitmap, (cap / 64 + 17) * 8));
+        HIPCHK(dev_alloc((void**)&mm->tile_counts, ((cap + FZB_TILE - 1) / FZB_TILE + 2) * 4));
+        mm->cap = cap;
+    }
+    // match_list_multi_into (src/matcher/multi.rs:84-152)
+    size_t base = ps.size();
+    for (size_t i = 0; i < ps.size(); i++)
+        if (!ps[i].negated) { base = i; break; }
+    int cur = 0;  // cand[cur] / counts[cur] = the candidates
+    int rc;
+    if (base != ps.size()) {
+        rc = fzb_match_list_device(ps[base].m, c, first, count, index_offset, (fzb_match*)mm->cand[0], mm->cap, &mm->counts[0], stream);
+        if (rc) return rc;
+    } else {
+        fzb_launch_identity_records(mm->cand[0], (u32)count, index_offset, &mm->counts[0], cus * 2, st);  // all patterns negated: every haystack is a candidate
+    }
+    for (size_t pi = 0; pi < ps.size(); pi++) {
+        if (pi == base) continue;
+        // (the reference skips the remaining patterns once no candidate is left; with the count on the device the kernels just find nothing to do)
+        fzb_launch_records_to_items(mm->cand[cur], &mm->counts[cur], index_offset, mm->items, cus * 2, st);
+        const int oth = cur ^ 1;
+        if (!ps[pi].negated) {
+            rc = run_pipeline(ps[pi].m, c, first, count, index_offset, mm->items, &mm->counts[cur], (fzb_match*)mm->cand[oth], mm->cap, &mm->counts[oth], stream);
+            if (rc) return rc;
+            fzb_launch_join_add(mm->cand[oth], &mm->counts[oth], mm->cand[cur], &mm->counts[cur], cus * 2, st);
+            cur = oth;
+        } else {
+            // the negated pattern's hits land in the other slot; k_flag_absent reads them, then k_compact_records (next in stream
+            // order) overwrites that same slot with the candidates that were not hit
+            fzb_match_rec* hits = mm->cand[oth];
+            rc = run_pipeline(ps[pi].m, c, first, count, index_offset, mm->items, &mm->counts[cur], (fzb_match*)hits, mm->cap, &mm->counts[2], stream);
+            if (rc) return rc;
+            fzb_launch_remove_hits(mm->cand[cur], &mm->counts[cur], hits, &mm->counts[2], mm->bitmap, mm->tile_counts, mm->cand[oth], &mm->counts[oth], cus * 2, st);
+            cur = oth;
+        }
+    }
+    fzb_launch_copy_records(mm->cand[cur], &mm->counts[cur], (fzb_match_rec*)dev_out, cap32, dev_count, cus * 2, st);
+    HIPCHK(hipGetLastError());
+    return FZB_OK;
+}
+
+int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match** out, size_t* out_len) {
+    if (!mm || !c || !out || !out_len) return fail(FZB_ERR_INVALID, "null argument");
+    const size_t count = c->dev.n;
+    *out = nullptr;
+    *out_len = 0;
+    if (mm->out_cap < count || !mm->count_dev) {
+        if (mm->out_dev) (void)hipFree(mm->out_dev);
+        mm->out_dev = nullptr;
+        mm->out_cap = 0;
+        HIPCHK(dev_alloc((void**)&mm->out_dev, (count + 16) * sizeof(fzb_match_rec)));
+        mm->out_cap = count;
+        if (!mm->count_dev) HIPCHK(dev_alloc((void**)&mm->count_dev, 16));
+    }
+    int rc = fzb_multi_match_list_device(mm, c, 0, count, 0, (fzb_match*)mm->out_dev, mm->out_cap, mm->count_dev, nullptr);
+    if (rc) return rc;
+    // Matcher::match_list (src/matcher/mod.rs:212-222): reverse, then the stable radix sort unless there is no pattern at all
+    const int sort = mm->config.sort;
+    const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;
+    const bool by_score = !mm->patterns.empty() && (sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC);
+    if ((reversed || by_score) && count) {
+        if (by_score && mm->sort_cap < count) {
+            if (mm->sort_tmp) (void)hipFree(mm->sort_tmp);
+            if (mm->sort_hist) (void)hipFree(mm->sort_hist);
+            mm->sort_tmp = nullptr; mm->sort_hist = nullptr; mm->sort_cap = 0;
+            HIPCHK(dev_alloc((void**)&mm->sort_tmp, (count + 16) * sizeof(fzb_match_rec)));
+            HIPCHK(dev_alloc((void**)&mm->sort_hist, (size_t)256 * (count / 2048 + 2) * 4));
+            mm->sort_cap = count;
+        }
+        fzb_launch_sort(mm->out_dev, mm->sort_tmp, mm->count_dev, mm->sort_hist, (u32)(mm->sort_cap / 2048 + 2), reversed, by_score, mm->num_cus * 2, nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    return fetch_records(mm->out_dev, mm->count_dev, out, out_len);
 }
 
 void fzb_matches_free(fzb_match* p) {

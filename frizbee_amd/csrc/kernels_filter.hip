@@ -423,10 +423,13 @@ __global__ __launch_bounds__(256) void k_map(const u64* __restrict__ bitmap, con
 // scans its own tiles' counts in LDS, and expands its bitmap words into the index-ordered survivor list.
 // The last workgroup also publishes the total.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap, const u32* __restrict__ counts, u32 n_items, u32* __restrict__ out_idx,
-                                                  u32* __restrict__ total_out) {
+__global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap, const u32* __restrict__ counts, u32 n_items_host, const u32* __restrict__ n_items_ptr,
+                                                  const u32* __restrict__ src, u32* __restrict__ out_idx, u32* __restrict__ total_out) {
+    // n_items_ptr (device) overrides the host count; src, if given, maps a bit position to the value that is listed
+    // (the item-list form of the filter: positions in a candidate list -> haystack indices)
     __shared__ u32 red[4];
     __shared__ u32 pre[256];
+    const u32 n_items = n_items_ptr ? *n_items_ptr : n_items_host;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u32 ntiles = (n_items + FZB_TILE - 1) / FZB_TILE;
     const u32 T = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -467,13 +470,91 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
             while (bits) {
                 const int b = __builtin_ctzll(bits);
                 bits &= bits - 1;
-                out_idx[pos++] = w * 64 + b;
+                out_idx[pos++] = src ? src[w * 64 + b] : w * 64 + b;
             }
         }
         base += batch_total;
         __syncthreads();
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *total_out = base;  // every earlier workgroup's tiles precede this one's
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same accept tests over an ITEM LIST (positions j -> haystack items[j]) whose length lives in device memory:
+// the narrowing step of the multi-pattern composition (src/matcher/multi.rs:102-118 re-matches each further pattern
+// against only the haystacks that survived the previous ones).  Candidates are a small, sparse subset, so this is
+// one plain thread per item; the decisions leave in the usual bitmap + per-1024 counts, indexed by list position.
+// ---------------------------------------------------------------------------------------------------
+template <typename TW, int MODE, typename ET>
+__global__ __launch_bounds__(256) void k1_items(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ items,
+                                                const u32* __restrict__ n_items_ptr, const u64* __restrict__ Tg, int rows, int need, u32 min_len,
+                                                u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
+    __shared__ TW T[256];
+    __shared__ u32 s_cnt;
+    const int tid = threadIdx.x;
+    T[tid] = (TW)Tg[tid];
+    const u32 count = *n_items_ptr;
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        u32 cnt = 0;
+#pragma unroll 1
+        for (int p = 0; p < FZB_TILE / 256; p++) {
+            const u32 j = tile * FZB_TILE + p * 256 + tid;
+            bool matched = false;
+            if (j < count) {
+                u64 s;
+                u32 L;
+                haystack_span(ends, first + items[j], s, L);
+                if (L >= min_len) {
+                    const uint4* vp = (const uint4*)(bytes + s);
+                    TW st = (MODE == 1) ? (TW)1 : (TW)~(TW)0;
+                    const u32 nvec = (L + 15) >> 4;
+                    for (u32 v = 0; v < nvec; v++) {
+                        const uint4 q = vp[v];
+                        const u32 rem = L - 16 * v;
+                        filter_word<TW, MODE>(st, q.x, rem, T);
+                        if (rem > 4) filter_word<TW, MODE>(st, q.y, rem - 4, T);
+                        if (rem > 8) filter_word<TW, MODE>(st, q.z, rem - 8, T);
+                        if (rem > 12) filter_word<TW, MODE>(st, q.w, rem - 12, T);
+                    }
+                    if (MODE == 1) {
+                        matched = (st >> rows) & 1;
+                    } else {
+                        const TW low = rows >= (int)(8 * sizeof(TW)) ? (TW)~(TW)0 : (((TW)1 << rows) - 1);
+                        const TW z = ~st & low;
+                        const int lcs = sizeof(TW) == 8 ? __popcll((u64)z) : __popc((u32)z);
+                        matched = lcs >= need;
+                    }
+                }
+            }
+            const u64 b = __ballot(matched);
+            if (lane_id() == 0) {
+                bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
+                cnt += __popcll(b);
+            }
+        }
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,
+                             u64* bitmap, u32* tile_counts, int grid, hipStream_t st) {
+    // MODE 1 with one-hot state needs rows + 1 bits, MODE 2 rows bits
+    const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
+#define FZB_K1I(TW, MODE, ET) hipLaunchKernelGGL((k1_items<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, n_items_ptr, table, rows, need, min_len, bitmap, tile_counts)
+    if (c.ends_u64) {
+        if (mode == 1) { if (w64) FZB_K1I(u64, 1, u64); else FZB_K1I(u32, 1, u64); }
+        else           { if (w64) FZB_K1I(u64, 2, u64); else FZB_K1I(u32, 2, u64); }
+    } else {
+        if (mode == 1) { if (w64) FZB_K1I(u64, 1, u32); else FZB_K1I(u32, 1, u32); }
+        else           { if (w64) FZB_K1I(u64, 2, u32); else FZB_K1I(u32, 2, u32); }
+    }
+#undef FZB_K1I
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -520,8 +601,8 @@ void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, counts, prefix, n_items_ptr, n_items_host, total_out, base_in, base_out);
 }
 
-void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, u32* out_idx, u32* total_out, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, out_idx, total_out);
+void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, n_items_ptr, src, out_idx, total_out);
 }
 
 void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,

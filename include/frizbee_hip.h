@@ -47,7 +47,8 @@ typedef struct fzb_scoring {
  * pair the reference's `Matcher::get_backend` (src/matcher/mod.rs:448-498) would pick on THIS host CPU
  * (`is_x86_feature_detected!` predicates) for the needle's score class: AVX-512(+VBMI for the u8 class):
  * prefilter 64, score 64 (u8) / 32 (u16); AVX2: 32, 32 / 16; SSE4.1 or scalar: 16, 16 / 8.
- * Non-zero values force a pair (pf_lanes in {16,32,64}, sw_lanes in {8,16,32,64}). */
+ * Non-zero values force a pair (pf_lanes in {16,32,64}, sw_lanes in {8,16,32,64}); pf_lanes set with sw_lanes 0 = that ISA
+ * family's score width for the needle's class (what a multi-pattern matcher needs: its patterns may differ in class). */
 typedef struct fzb_config {
     int32_t max_typos; /* Option<u16>: -1 = None (no prefilter) */
     int32_t casing;    /* FZB_CASE_*    */
@@ -134,6 +135,35 @@ void fzb_radix_sort_matches(fzb_match* matches, size_t n);
 /* `k_merge_matches_by_*` (src/k_merge.rs:56-132): merges per-shard runs (each sorted per `sort`) - the
  * host-side combine after the multi-GPU gather.  runs = concatenated runs, run_lens[k] records each. */
 int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_lens, size_t nruns, fzb_match* out);
+
+/* ---- multi-pattern composition ----------------------------------------------------------------------
+ * `Matcher::from_patterns(&[Pattern], &Config)` (src/matcher/mod.rs:95-111): a haystack matches when every non-negated
+ * pattern matches and no negated one does; score = saturating sum of the non-negated patterns' scores, exact = OR
+ * (src/matcher/multi.rs:84-152).  One `fzb_pattern` = reference `Pattern{needle, negated, config: PatternConfig}`
+ * (src/pattern.rs:9-18, 230-262); the per-pattern overrides are resolved against the matcher's config exactly like
+ * `PatternConfig::resolve`.  Only fuzzy matching: `PatternConfig::matching` / `Config::matching` other than Fuzzy (the
+ * literal modes of src/literal, and therefore `Pattern::parse`'s `!foo` = negated SUBSTRING) is outside this backend. */
+typedef struct fzb_pattern {
+    const uint8_t* needle_utf8;
+    size_t needle_len;      /* 0: the pattern is dropped (Matcher::compile, src/matcher/mod.rs:193-195) */
+    int32_t negated;
+    int32_t has_max_typos;  /* PatternConfig::max_typos = Some(max_typos); 0 = None = inherit the config's */
+    int32_t max_typos;
+    int32_t casing;         /* FZB_CASE_*, or -1 = inherit */
+    int32_t unicode;        /* FZB_UNICODE_*, or -1 = inherit */
+    int32_t has_scoring;    /* PatternConfig::scoring = Some(scoring) */
+    fzb_scoring scoring;
+} fzb_pattern;
+typedef struct fzb_multi_matcher fzb_multi_matcher;
+
+int fzb_multi_matcher_create(const fzb_config* config, const fzb_pattern* patterns, size_t n_patterns, fzb_multi_matcher** out);
+void fzb_multi_matcher_free(fzb_multi_matcher* mm);
+size_t fzb_multi_matcher_len(const fzb_multi_matcher* mm); /* compiled (non-empty) patterns */
+/* `Matcher::match_list` over CompiledPatterns::{Empty, Single, Multi} (src/matcher/mod.rs:212-222, 373-392): ordered per config.sort */
+int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match** out, size_t* out_len);
+/* `match_list_multi_into(patterns, haystacks, haystack_index_offset, matches)` (src/matcher/multi.rs:84-152): index order, result in HBM */
+int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset,
+                                fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);
 
 /* Measurement hooks (bench.py): device time of the fzb_match_list_device calls made on this matcher since
  * fzb_set_profiling(m, 1), measured with HIP events recorded on the launch stream (event records only, no
