@@ -50,12 +50,14 @@ enum CaseMatching { CASE_IGNORE = 0, CASE_SMART = 1, CASE_RESPECT = 2 };
 enum UnicodeMatching { UNI_IGNORE = 0, UNI_SMART = 1, UNI_ALWAYS = 2 };
 enum SortStrategy { SORT_SCORE_THEN_INDEX_ASC = 0, SORT_SCORE_THEN_INDEX_DESC = 1, SORT_INDEX_ASC = 2, SORT_INDEX_DESC = 3 };
 
+enum Matching { MATCH_FUZZY = 0, MATCH_EXACT = 1, MATCH_PREFIX = 2, MATCH_SUFFIX = 3, MATCH_SUBSTRING = 4 };  // lib.rs:414-427
 struct Config {
     int max_typos = 0;  // -1 == None
     int casing = CASE_SMART;
     int unicode = UNI_SMART;
     int sort = SORT_SCORE_THEN_INDEX_ASC;
     Scoring scoring;
+    int matching = MATCH_FUZZY;
 };
 
 struct Match {
@@ -197,10 +199,13 @@ inline u16 max_one_time_bonus(const Scoring& s) {  // lib.rs:497-503
     return (u16)(bonus - amortized);
 }
 // Returns "" if OK, else the panic message (lib.rs:506-537)
-inline std::string guard_against_score_overflow(const Scoring& s, size_t needle_len) {
-    u16 max_per_char = sat_add16(s.match_score, max_per_char_bonus(s));
+inline std::string guard_against_score_overflow(const Scoring& s, size_t needle_len, int max_bonus_per_char_in = -1, int max_one_time_in = -1) {
+    // fuzzy callers pass the amortised bonuses (matcher/algo.rs:311-325), the literal matcher its own (literal/algo.rs:314-322)
+    const u16 bonus_pc = max_bonus_per_char_in < 0 ? max_per_char_bonus(s) : (u16)max_bonus_per_char_in;
+    const u16 one_time = max_one_time_in < 0 ? max_one_time_bonus(s) : (u16)max_one_time_in;
+    u16 max_per_char = sat_add16(s.match_score, bonus_pc);
     if (max_per_char == 0) return "";
-    u16 headroom = sat_sub16(sat_sub16(sat_sub16(sat_sub16(0xFFFF, s.prefix_bonus), s.exact_match_bonus), s.mismatch_penalty), max_one_time_bonus(s));
+    u16 headroom = sat_sub16(sat_sub16(sat_sub16(sat_sub16(0xFFFF, s.prefix_bonus), s.exact_match_bonus), s.mismatch_penalty), one_time);
     u16 max_needle_len = (u16)(headroom / max_per_char);
     if (needle_len > (size_t)max_needle_len)
         return "needle too long and could overflow the u16 score: " + std::to_string(needle_len) + " > " + std::to_string(max_needle_len);
@@ -1353,6 +1358,97 @@ struct MatcherImpl : MatcherBase {
     }
 };
 
+// =======================================================================================
+// LITERAL MATCHING: exact / prefix / suffix / substring, src/literal/algo.rs.
+// The needle must occur as a contiguous run; scoring is the Smith-Waterman bonuses of a gap-free
+// alignment.  Independent of the SIMD width (the reference asserts all its backends agree,
+// src/literal/backend.rs:103-200), so the two-seed-byte scan is restated as a plain scan.
+// =======================================================================================
+inline bool literal_is_delimiter(u8 b) { return b <= 127 && !((b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z') || (b >= '0' && b <= '9')); }  // algo.rs:326-329
+
+struct LiteralMatcher : MatcherBase {
+    int mode;
+    Scoring scoring;
+    std::string needle;
+    bool unicode;
+    std::vector<std::pair<u8, u8>> needle_ascii;
+    std::vector<UnicodeChar> needle_unicode;
+
+    LiteralMatcher(const std::string& n, const Config& c, bool case_sensitive, bool unicode_)
+        : mode(c.matching), scoring(c.scoring), needle(n), unicode(unicode_), needle_ascii(case_needle(n, case_sensitive)), needle_unicode(case_needle_unicode(n, case_sensitive)) {}
+    MatcherBase* clone() const override { return new LiteralMatcher(*this); }
+
+    bool matches_at(const u8* h, size_t pos) const {  // algo.rs:157-176
+        if (unicode) {
+            size_t k = pos;
+            for (const UnicodeChar& c : needle_unicode) {
+                if (memcmp(h + k, c.chars, c.len) != 0 && memcmp(h + k, c.flipped, c.len) != 0) return false;
+                k += c.len;
+            }
+        } else {
+            for (size_t k = 0; k < needle_ascii.size(); k++) {
+                u8 b = h[pos + k];
+                if (b != needle_ascii[k].first && b != needle_ascii[k].second) return false;
+            }
+        }
+        return true;
+    }
+    u16 score_scalar(const u8* h, size_t start, bool matched_exact_case) const {  // algo.rs:180-200
+        u16 score = scoring.match_score;
+        if (matched_exact_case) score = (u16)(score + scoring.matching_case_bonus);
+        if (start == 0) {
+            score = (u16)(score + scoring.prefix_bonus);
+        } else {
+            u8 b = h[start], prev = h[start - 1];
+            if (b >= 'A' && b <= 'Z' && prev >= 'a' && prev <= 'z') score = (u16)(score + scoring.capitalization_bonus);
+            if (literal_is_delimiter(prev) && !literal_is_delimiter(b)) score = (u16)(score + scoring.delimiter_bonus);
+        }
+        return score;
+    }
+    u16 score_at(const u8* h, size_t hlen, size_t pos) const {  // algo.rs:204-225
+        u16 score = 0;
+        if (unicode) {
+            size_t start = pos;
+            for (const UnicodeChar& c : needle_unicode) {
+                score = (u16)(score + score_scalar(h, start, memcmp(h + start, c.chars, c.len) == 0));
+                start += c.len;
+            }
+        } else {
+            for (size_t k = 0; k < needle_ascii.size(); k++) score = (u16)(score + score_scalar(h, pos + k, h[pos + k] == needle_ascii[k].first));
+        }
+        if (pos == 0 && needle.size() == hlen) score = (u16)(score + scoring.exact_match_bonus);
+        return score;
+    }
+    bool find(const u8* h, size_t hlen, size_t& pos_out, u16& score_out) const {  // algo.rs:232-312
+        size_t nl = needle.size();
+        if (hlen < nl) return false;
+        auto hit = [&](size_t pos) { pos_out = pos; score_out = score_at(h, hlen, pos); return true; };
+        switch (mode) {
+            case MATCH_EXACT: return hlen == nl && matches_at(h, 0) && hit(0);
+            case MATCH_PREFIX: return matches_at(h, 0) && hit(0);
+            case MATCH_SUFFIX: return matches_at(h, hlen - nl) && hit(hlen - nl);
+            default: {  // substring: best score, earliest position on ties
+                bool found = false;
+                for (size_t pos = 0; pos + nl <= hlen; pos++) {
+                    if (!matches_at(h, pos)) continue;
+                    u16 sc = score_at(h, hlen, pos);
+                    if (!found || sc > score_out) { found = true; pos_out = pos; score_out = sc; }
+                }
+                return found;
+            }
+        }
+    }
+    void match_list_into(const HaystackList& hs, size_t lo, size_t hi, u32 index_offset, std::vector<Match>& out) override {  // algo.rs:95-127
+        for (size_t i = lo; i < hi; i++) {
+            size_t pos = 0;
+            u16 score = 0;
+            if (!find(hs.ptr(i), hs.len(i), pos, score)) continue;
+            bool exact = pos == 0 && needle.size() == hs.len(i);
+            out.push_back(Match{(u32)(index_offset + (i - lo)), score, (u8)(exact ? 1 : 0), 0});
+        }
+    }
+};
+
 struct Matcher {
     Config config;
     std::string needle;
@@ -1372,6 +1468,13 @@ struct Matcher {
         if (empty) return;
         bool case_sensitive = respects_case_for(c.casing, n);
         bool unicode = respects_unicode_for(c.unicode, n);
+        if (c.matching != MATCH_FUZZY) {  // get_literal_backend (mod.rs:449-451); LiteralImpl::new (literal/algo.rs:33-36, 314-322)
+            u16 bonus = sat_add16(std::max(c.scoring.capitalization_bonus, c.scoring.delimiter_bonus), c.scoring.matching_case_bonus);
+            std::string err = guard_against_score_overflow(c.scoring, n.size(), bonus, 0);
+            if (!err.empty()) throw std::runtime_error(err);
+            impl = new LiteralMatcher(n, c, case_sensitive, unicode);
+            return;
+        }
         // guard_against_score_overflow (algo.rs:311-325): rows = chars on the unicode path, bytes otherwise
         size_t rows = unicode ? utf8_decode((const u8*)n.data(), n.size()).size() : n.size();
         std::string err = guard_against_score_overflow(c.scoring, rows);
@@ -1482,10 +1585,9 @@ struct Matcher {
 };
 
 // =======================================================================================
-// MULTI-PATTERN COMPOSITION: src/matcher/multi.rs, fuzzy patterns only.
+// MULTI-PATTERN COMPOSITION: src/matcher/multi.rs.
 // A pattern = needle + negation + per-pattern overrides resolved against the matcher's config
 // (PatternConfig::resolve, src/pattern.rs:250-262; Matcher::compile, src/matcher/mod.rs:192-204).
-// The literal matching modes (prefix / suffix / substring / exact, src/literal) are not restated.
 // =======================================================================================
 struct PatternSpec {
     std::string needle;
@@ -1495,7 +1597,70 @@ struct PatternSpec {
     int casing = -1, unicode = -1;  // -1: inherit
     bool has_scoring = false;
     Scoring scoring;
+    int matching = -1;  // -1: inherit Config::matching
 };
+
+// Pattern::parse (src/pattern.rs:87-167): one query atom; `^foo` prefix, `foo$` suffix, `^foo$` exact, `'foo` substring, `!foo` negated
+// (a bare negated atom matches substrings), backslash escapes.
+inline PatternSpec parse_pattern(const std::string& atom) {
+    std::vector<u32> cps = utf8_decode((const u8*)atom.data(), atom.size());
+    std::vector<std::pair<u32, bool>> tokens;  // (char, escaped)
+    for (size_t i = 0; i < cps.size(); i++) {
+        if (cps[i] == '\\' && i + 1 < cps.size()) { tokens.push_back({cps[i + 1], true}); i++; }
+        else tokens.push_back({cps[i], false});
+    }
+    size_t lo = 0, hi = tokens.size();
+    auto strip_first = [&](u32 op) { if (lo < hi && !tokens[lo].second && tokens[lo].first == op) { lo++; return true; } return false; };
+    auto strip_last = [&](u32 op) { if (lo < hi && !tokens[hi - 1].second && tokens[hi - 1].first == op) { hi--; return true; } return false; };
+    bool negated = strip_first('!');
+    bool prefix = strip_first('^');
+    bool substring = !prefix && strip_first('\'');
+    bool suffix = strip_last('$');
+    auto is_ws = [](u32 c) {  // char::is_whitespace (Unicode White_Space)
+        return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+    };
+    auto is_special = [&](u32 c) { return c == '!' || c == '^' || c == '\'' || c == '$' || is_ws(c); };
+    PatternSpec sp;
+    for (size_t i = lo; i < hi; i++) {
+        if (tokens[i].second && !is_special(tokens[i].first)) sp.needle.push_back('\\');
+        u8 buf[4];
+        int n = utf8_encode(tokens[i].first, buf);
+        sp.needle.append((const char*)buf, n);
+    }
+    sp.negated = negated;
+    if (prefix && suffix) sp.matching = MATCH_EXACT;
+    else if (prefix) sp.matching = MATCH_PREFIX;
+    else if (suffix) sp.matching = MATCH_SUFFIX;
+    else if (substring) sp.matching = MATCH_SUBSTRING;
+    else if (negated) sp.matching = MATCH_SUBSTRING;
+    return sp;
+}
+// Pattern::parse_query (src/pattern.rs:186-222): whitespace separated atoms, backslash keeps the next char in the atom, empty needles dropped
+inline std::vector<PatternSpec> parse_query(const std::string& query) {
+    std::vector<PatternSpec> out;
+    std::vector<u32> cps = utf8_decode((const u8*)query.data(), query.size());
+    auto is_ws = [](u32 c) {
+        return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F || c == 0x205F || c == 0x3000;
+    };
+    std::string atom;
+    bool in_atom = false, escaped = false;
+    auto push = [&]() {
+        PatternSpec p = parse_pattern(atom);
+        if (!p.needle.empty()) out.push_back(p);
+        atom.clear();
+        in_atom = false;
+    };
+    for (u32 c : cps) {
+        u8 buf[4];
+        int n = utf8_encode(c, buf);
+        if (escaped) { escaped = false; atom.append((const char*)buf, n); }
+        else if (c == '\\') { in_atom = true; escaped = true; atom.append((const char*)buf, n); }
+        else if (is_ws(c)) { if (in_atom) push(); }
+        else { in_atom = true; atom.append((const char*)buf, n); }
+    }
+    if (in_atom) push();
+    return out;
+}
 
 struct MultiMatcher {
     Config config;
@@ -1510,6 +1675,7 @@ struct MultiMatcher {
             if (sp.casing >= 0) rc.casing = sp.casing;
             if (sp.unicode >= 0) rc.unicode = sp.unicode;
             if (sp.has_scoring) rc.scoring = sp.scoring;
+            if (sp.matching >= 0) rc.matching = sp.matching;
             rc.sort = SORT_INDEX_ASC;
             patterns.push_back(Compiled{sp.negated, new Matcher(sp.needle, rc, pf_lanes, sw_lanes_u8, sw_lanes_u16)});
         }

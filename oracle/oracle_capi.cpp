@@ -41,6 +41,7 @@ struct fzo_config {
     int32_t max_typos;  // -1 == None
     int32_t casing, unicode, sort;
     uint16_t scoring[9];  // match, mismatch, gap_open, gap_extend, prefix, capitalization, matching_case, exact_match, delimiter
+    int32_t matching;     // Matching: 0 fuzzy, 1 exact, 2 prefix, 3 suffix, 4 substring
 };
 
 static thread_local std::string g_err;
@@ -56,6 +57,7 @@ static Config config_from(const fzo_config* c) {
     Config r;
     r.max_typos = c->max_typos; r.casing = c->casing; r.unicode = c->unicode; r.sort = c->sort;
     r.scoring = scoring_from(c->scoring);
+    r.matching = c->matching;
     return r;
 }
 
@@ -144,6 +146,7 @@ struct fzo_pattern {
     size_t needle_len;
     int32_t negated, has_max_typos, max_typos, casing, unicode, has_scoring;  // casing / unicode: -1 = inherit
     uint16_t scoring[9];
+    int32_t matching;  // -1 = inherit
 };
 void* fzo_multi_create(const fzo_config* cfg, const fzo_pattern* pats, size_t npats, int pf_lanes, int sw_lanes_u8, int sw_lanes_u16) {
     try {
@@ -157,6 +160,7 @@ void* fzo_multi_create(const fzo_config* cfg, const fzo_pattern* pats, size_t np
             sp.casing = pats[i].casing;
             sp.unicode = pats[i].unicode;
             sp.has_scoring = pats[i].has_scoring != 0;
+            sp.matching = pats[i].matching;
             if (sp.has_scoring) {
                 const uint16_t* v = pats[i].scoring;
                 sp.scoring = Scoring{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]};
@@ -179,6 +183,23 @@ int fzo_multi_match_list(void* m, const uint8_t* bytes, const uint64_t* ends, si
         if (!r.empty()) memcpy(*out, r.data(), r.size() * sizeof(Match));
         return 0;
     } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// Pattern::parse_query -> flat text, one line per pattern: "<negated 0|1> <matching -1..4> <needle bytes as hex>\n"
+int fzo_parse_query(const uint8_t* query, size_t qlen, char* out, size_t out_cap) {
+    try {
+        std::vector<PatternSpec> ps = parse_query(std::string((const char*)query, qlen));
+        std::string r;
+        for (const PatternSpec& p : ps) {
+            r += std::to_string((int)p.negated) + " " + std::to_string(p.matching) + " ";
+            static const char* hex = "0123456789abcdef";
+            for (unsigned char c : p.needle) { r.push_back(hex[c >> 4]); r.push_back(hex[c & 15]); }
+            r.push_back('\n');
+        }
+        if (r.size() + 1 > out_cap) { g_err = "fzo_parse_query: output buffer too small"; return -1; }
+        memcpy(out, r.c_str(), r.size() + 1);
+        return (int)ps.size();
+    } catch (std::exception& e) { g_err = e.what(); return -1; }
 }
 
 // Timing leg: score every haystack on `threads` workers, no ordering step (Matcher::score_parallel_unordered).

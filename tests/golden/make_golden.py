@@ -235,4 +235,76 @@ multi = [
          ref="src/matcher/multi.rs:415-416; src/matcher/mod.rs:193-195"),
 ]
 json.dump({"cases": multi}, open(os.path.join(HERE, "multi.json"), "w"), ensure_ascii=False, indent=1)
+# ---- literal matching (src/literal/mod.rs tests): Substring scores with CaseMatching::Ignore unless stated ----
+EXACT = 8
+lit_scores = [  # (needle, haystack, casing, expected score or None, ref)
+    ("bar", "foobar", "Ignore", 3 * CHAR, "src/literal/mod.rs:121"),
+    ("bar", "foo_bar", "Ignore", 3 * CHAR + DELIM, "src/literal/mod.rs:123-126"),
+    ("ab", "ab_ab", "Ignore", 2 * CHAR + PREFIX, "src/literal/mod.rs:132"),
+    ("b", "abc", "Ignore", CHAR, "src/literal/mod.rs:212"), ("c", "abc", "Ignore", CHAR, "src/literal/mod.rs:213"),
+    ("a", "abc", "Ignore", CHAR + PREFIX, "src/literal/mod.rs:218"), ("a", "aabc", "Ignore", CHAR + PREFIX, "src/literal/mod.rs:219"), ("a", "babc", "Ignore", CHAR, "src/literal/mod.rs:220"),
+    ("a", "a", "Ignore", CHAR + PREFIX + EXACT, "src/literal/mod.rs:227-230"), ("abc", "abc", "Ignore", 3 * CHAR + PREFIX + EXACT, "src/literal/mod.rs:231-234"),
+    ("-", "a--bc", "Ignore", CHAR, "src/literal/mod.rs:239"), ("b", "a-b", "Ignore", CHAR + DELIM, "src/literal/mod.rs:240"), ("a", "a-b-c", "Ignore", CHAR + PREFIX, "src/literal/mod.rs:241"),
+    ("b", "a--b", "Ignore", CHAR + DELIM, "src/literal/mod.rs:242"), ("c", "a--bc", "Ignore", CHAR, "src/literal/mod.rs:243"), ("a", "-a--bc", "Ignore", CHAR + DELIM, "src/literal/mod.rs:244"),
+    ("-", "a-bc", "Ignore", CHAR, "src/literal/mod.rs:249"),
+    ("a", "Ab", "Ignore", MATCH + PREFIX, "src/literal/mod.rs:255"), ("A", "Aa", "Ignore", CHAR + PREFIX, "src/literal/mod.rs:256"),
+    ("D", "forDist", "Ignore", CHAR + CAP, "src/literal/mod.rs:257"), ("D", "foRDist", "Ignore", CHAR, "src/literal/mod.rs:258"), ("D", "FOR_DIST", "Ignore", CHAR + DELIM, "src/literal/mod.rs:259"),
+    ("A", "0A", "Respect", CHAR, "src/literal/mod.rs:284-287"), ("A", "0a", "Respect", None, "src/literal/mod.rs:288"), ("A", "0a", "Ignore", MATCH, "src/literal/mod.rs:289-292"),
+    ("é", "é", "Ignore", CHAR + PREFIX + EXACT, "src/literal/mod.rs:301-304"), ("éx", "éx", "Ignore", 2 * CHAR + PREFIX + EXACT, "src/literal/mod.rs:306-309"), ("é", "xé", "Ignore", CHAR, "src/literal/mod.rs:311"),
+    ("Ꭰ", "\u1b70", "Ignore", None, "src/literal/mod.rs:335-339"),
+    ("ß", "SS", "Ignore", None, "src/literal/mod.rs:352"), ("ß", "ss", "Ignore", None, "src/literal/mod.rs:353"),
+    ("é", "É", "Respect", None, "src/literal/mod.rs:323-327"), ("и", "И", "Respect", None, "src/literal/mod.rs:323-327"), ("α", "Α", "Respect", None, "src/literal/mod.rs:323-327"),
+]
+lit_matches = [  # (needle, haystack, casing): must match (score unspecified)
+    ("é", "É", "Ignore", "src/literal/mod.rs:319-322"), ("и", "И", "Ignore", "src/literal/mod.rs:319-322"), ("α", "Α", "Ignore", "src/literal/mod.rs:319-322"),
+    ("Ꭰ", "ꭰ", "Ignore", "src/literal/mod.rs:340-343"), ("ß", "ß", "Ignore", "src/literal/mod.rs:351"),
+]
+lit_greater = [  # substring score(a) > score(b), casing Ignore
+    (("swap", "swap(test)"), ("swap", "iter_swap(test)"), "src/literal/mod.rs:264"), (("_", "_private_member"), ("_", "public_member"), "src/literal/mod.rs:265"),
+    (("H", "HELLO"), ("H", "fooHello"), "src/literal/mod.rs:270"), (("b", "b"), ("b", "a-b"), "src/literal/mod.rs:275"), (("b", "a-b"), ("b", "ab"), "src/literal/mod.rs:276"),
+    (("B", "aB"), ("b", "aB"), "src/literal/mod.rs:277"),
+]
+lit_lists = [  # (matching, needle, haystacks, config extras, expected indices, expect all exact?, ref)
+    ("Exact", "foo", ["foo", "foobar", "xfoo", "FOO"], {}, [0, 3], True, "src/literal/mod.rs:55-61"),
+    ("Prefix", "foo", ["foobar", "barfoo", "foo", "xfoobar"], {}, [0, 2], None, "src/literal/mod.rs:66-72"),
+    ("Suffix", "foo", ["foobar", "barfoo", "foo", "xfoobar"], {}, [1, 2], None, "src/literal/mod.rs:73-79"),
+    ("Substring", "bar", ["xxbarxx", "bar", "nope", "foo_bar"], {}, [0, 1, 3], None, "src/literal/mod.rs:84-91"),
+    ("Prefix", "foo", ["foo", "FOO", "fOo"], {"casing": "Respect"}, [0], None, "src/literal/mod.rs:138-151"),
+    ("Prefix", "foo", ["foo", "FOO", "fOo"], {}, [0, 1, 2], None, "src/literal/mod.rs:153-159"),
+    ("Substring", "é다😀", ["é다😀", "xxé다😀yy", "é다", "plain"], {}, [0, 1], None, "src/literal/mod.rs:165-171"),
+    ("Exact", "é다😀", ["é다😀", "xxé다😀yy", "é다", "plain"], {}, [0], True, "src/literal/mod.rs:172-174"),
+    ("Substring", "abcd", ["abc"], {}, [], None, "src/literal/mod.rs:187"), ("Prefix", "abcd", ["abc"], {}, [], None, "src/literal/mod.rs:188"),
+    ("Suffix", "abcd", ["abc"], {}, [], None, "src/literal/mod.rs:189"), ("Exact", "abcd", ["abc"], {}, [], None, "src/literal/mod.rs:190"),
+] + [("Substring", "bar", ["x" * k + "bar"], {}, [0], None, "src/literal/mod.rs:196-201") for k in (0, 1, 7, 8, 15, 16, 31, 32, 63, 64, 65)]
+lit_prefix_equals_fuzzy = [("foo", "foo"), ("foo", "foobar"), ("fooBar", "fooBarBaz"), ("a", "abc")]  # src/literal/mod.rs:96-110 (+ exact == fuzzy for foo/foo :112-114)
+# cross-backend corpus: every backend must agree (src/literal/backend.rs:118-153) - used as extra oracle-vs-HIP cases
+lit_corpus = [("x", "y" * 200), ("needle", "xxneedlexxneedle_needle"), ("é다😀", "xxé다😀yyé다😀"), ("다", "가나다라마"), ("z", "abcdefghijklmnopqrstuvwxyz"), ("FoO", "prefix_FoO_FOO_foo"),
+              ("a", "a" * 35), ("ab", "ab" * 12), ("aa", "baaab"), ("aaaa", "xaaaaaaaax"), ("aaa", "aaaaa"), ("bar", "x" * 30 + "bar"), ("ba", "a" * 30 + "ba"),
+              ("foobar", "foobatefoobarfoobar"), ("é", "xÉyéZÉ"), ("café", "un CAFÉ, deux cafés"), ("Ꭰ", "\u1b70Ꭰꭰ\u1b70"), ("иха", "МУХА_ИХА_иха"), ("αβ", "ΑΒβα_αβ")]
+# Pattern::parse / parse_query (src/pattern.rs:307-382): atom -> (needle, matching or None, negated)
+parse_atoms = [
+    ("foo", "foo", None, False), ("^foo", "foo", "Prefix", False), ("foo$", "foo", "Suffix", False), ("'foo", "foo", "Substring", False), ("^foo$", "foo", "Exact", False),
+    ("!foo", "foo", "Substring", True), ("!^foo", "foo", "Prefix", True), ("!foo$", "foo", "Suffix", True), ("!'foo", "foo", "Substring", True), ("!^foo$", "foo", "Exact", True),
+    ("\\^foo", "^foo", None, False), ("foo\\$", "foo$", None, False), ("\\'foo", "'foo", None, False), ("\\!foo", "!foo", None, False), ("foo\\ bar", "foo bar", None, False),
+    ("!\\^foo", "^foo", "Substring", True), ("!\\!foo", "!foo", "Substring", True),
+    ("foo\\\\$", "foo\\\\", "Suffix", False), ("foo\\bar", "foo\\bar", None, False), ("foo\\", "foo\\", None, False), ("a\\\\\\ b", "a\\\\ b", None, False),
+]
+parse_queries = [  # query -> needles
+    ("foo !^bar", ["foo", "bar"], "src/pattern.rs:347-351"), ("  foo \t bar  ", ["foo", "bar"], "src/pattern.rs:353-356"), ("foo\\ bar baz", ["foo bar", "baz"], "src/pattern.rs:361-364"),
+    ("foo\\\\ bar", ["foo\\\\", "bar"], "src/pattern.rs:370-373"), ("", [], "src/pattern.rs:378"), ("   ", [], "src/pattern.rs:379"), ("! ^$ '", [], "src/pattern.rs:380"),
+]
+# multi-pattern queries with the literal negations (src/matcher/multi.rs:165-228, 409-417)
+multi_queries = [
+    ("foo !bar", ["foobar", "foo", "barfoo", "bar", "qux"], dict(sort="IndexAsc"), [1], "src/matcher/multi.rs:165-170"),
+    ("foo !^bar", ["foo/bar", "bar/foo", "foo", "foobar"], dict(sort="IndexAsc"), [0, 2, 3], "src/matcher/multi.rs:178-182"),
+    ("foo !bar$", ["foo/bar", "bar/foo", "foo", "foobar"], dict(sort="IndexAsc"), [1, 2], "src/matcher/multi.rs:185-189"),
+    ("!foo", ["foo", "bar", "xfoox", "qux"], dict(sort="IndexAsc"), [1, 3], "src/matcher/multi.rs:213-219"),
+    ("!foo !qux", ["foo", "bar", "xfoox", "qux"], dict(sort="IndexAsc"), [1], "src/matcher/multi.rs:222-223"),
+    ("foo !foo", ["foo", "foobar"], dict(), [], "src/matcher/multi.rs:226-230"),
+    ("! ^$", ["foo", "bar"], dict(sort="IndexAsc"), [0, 1], "src/matcher/multi.rs:415-416"),
+    ("^foo", ["fooX", "xfoo"], dict(sort="IndexAsc", max_typos=None), [0], "src/matcher/multi.rs:308-316"),
+]
+json.dump(dict(scores=lit_scores, matches=lit_matches, greater=lit_greater, lists=lit_lists, prefix_equals_fuzzy=lit_prefix_equals_fuzzy, corpus=lit_corpus,
+               parse_atoms=parse_atoms, parse_queries=parse_queries, multi_queries=multi_queries),
+          open(os.path.join(HERE, "literal.json"), "w"), ensure_ascii=False, indent=1)
 print("golden written")

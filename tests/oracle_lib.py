@@ -12,17 +12,18 @@ DEFAULT_SCORING = [12, 6, 5, 1, 12, 4, 4, 8, 4]
 CASING = {"Ignore": 0, "Smart": 1, "Respect": 2}
 UNICODE = {"Ignore": 0, "Smart": 1, "Always": 2}
 SORT = {"ScoreThenIndexAsc": 0, "ScoreThenIndexDesc": 1, "IndexAsc": 2, "IndexDesc": 3}
+MATCHING = {"Fuzzy": 0, "Exact": 1, "Prefix": 2, "Suffix": 3, "Substring": 4}
 
 MATCH_DTYPE = np.dtype([("index", "<u4"), ("score", "<u2"), ("exact", "u1"), ("_pad", "u1")])
 
 
 class FzoPattern(C.Structure):
     _fields_ = [("needle", C.c_char_p), ("needle_len", C.c_size_t), ("negated", C.c_int32), ("has_max_typos", C.c_int32), ("max_typos", C.c_int32),
-                ("casing", C.c_int32), ("unicode", C.c_int32), ("has_scoring", C.c_int32), ("scoring", C.c_uint16 * 9)]
+                ("casing", C.c_int32), ("unicode", C.c_int32), ("has_scoring", C.c_int32), ("scoring", C.c_uint16 * 9), ("matching", C.c_int32)]
 
 
 class FzoConfig(C.Structure):
-    _fields_ = [("max_typos", C.c_int32), ("casing", C.c_int32), ("unicode", C.c_int32), ("sort", C.c_int32), ("scoring", C.c_uint16 * 9)]
+    _fields_ = [("max_typos", C.c_int32), ("casing", C.c_int32), ("unicode", C.c_int32), ("sort", C.c_int32), ("scoring", C.c_uint16 * 9), ("matching", C.c_int32)]
 
 
 def build(native=False, force=False):
@@ -62,6 +63,7 @@ def lib(native=False):
         l.fzo_multi_create.argtypes = [C.POINTER(FzoConfig), C.POINTER(FzoPattern), C.c_size_t, C.c_int, C.c_int, C.c_int]
         l.fzo_multi_free.argtypes = [C.c_void_p]
         l.fzo_multi_match_list.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzo_parse_query.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]
         l.fzo_free.argtypes = [C.c_void_p]
         l.fzo_radix_sort.argtypes = [C.c_void_p, C.c_size_t]
         l.fzo_k_merge.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -121,7 +123,7 @@ def pack(haystacks):
     return data, ends
 
 
-def make_config(max_typos=0, casing="Smart", unicode="Smart", sort="ScoreThenIndexAsc", scoring=None):
+def make_config(max_typos=0, casing="Smart", unicode="Smart", sort="ScoreThenIndexAsc", scoring=None, matching="Fuzzy"):
     cfg = FzoConfig()
     cfg.max_typos = -1 if max_typos is None else int(max_typos)
     cfg.casing = CASING[casing] if isinstance(casing, str) else int(casing)
@@ -129,6 +131,7 @@ def make_config(max_typos=0, casing="Smart", unicode="Smart", sort="ScoreThenInd
     cfg.sort = SORT[sort] if isinstance(sort, str) else int(sort)
     for i, v in enumerate(scoring or DEFAULT_SCORING):
         cfg.scoring[i] = v
+    cfg.matching = MATCHING[matching] if isinstance(matching, str) else int(matching)
     return cfg
 
 
@@ -192,10 +195,10 @@ class Matcher:
 INHERIT = "inherit"
 
 
-def P(needle, negated=False, max_typos=INHERIT, casing=None, unicode=None, scoring=None):
+def P(needle, negated=False, max_typos=INHERIT, casing=None, unicode=None, scoring=None, matching=None):
     """One pattern of a multi-pattern matcher (reference `Pattern` + `PatternConfig`, src/pattern.rs:9-18, 230-262; fuzzy matching
     only).  max_typos=INHERIT is PatternConfig's `None`; an int is `Some(k)`."""
-    return dict(needle=needle, negated=negated, max_typos=max_typos, casing=casing, unicode=unicode, scoring=scoring)
+    return dict(needle=needle, negated=negated, max_typos=max_typos, casing=casing, unicode=unicode, scoring=scoring, matching=matching)
 
 
 class MultiMatcher:
@@ -215,6 +218,7 @@ class MultiMatcher:
             arr[i].casing = -1 if p["casing"] is None else CASING[p["casing"]]
             arr[i].unicode = -1 if p["unicode"] is None else UNICODE[p["unicode"]]
             arr[i].has_scoring = int(p["scoring"] is not None)
+            arr[i].matching = -1 if p.get("matching") is None else MATCHING[p["matching"]]
             for k, v in enumerate(p["scoring"] or DEFAULT_SCORING):
                 arr[i].scoring[k] = v
         self.h = self.lib.fzo_multi_create(C.byref(self.cfg), arr, len(patterns), *lanes)
@@ -247,6 +251,21 @@ class MultiMatcher:
                 self.h = None
         except Exception:
             pass
+
+
+def parse_query(query):
+    """Oracle `Pattern::parse_query` (src/pattern.rs:186-222) -> list of P(...) with the matching mode the syntax implies"""
+    q = _b(query)
+    buf = C.create_string_buffer(16 * len(q) + 256)
+    n = lib().fzo_parse_query(q, len(q), buf, len(buf))
+    if n < 0:
+        raise RuntimeError(lib().fzo_last_error().decode())
+    inv = {v: k for k, v in MATCHING.items()}
+    out = []
+    for line in buf.value.decode().splitlines():
+        neg, matching, hexs = (line.split(" ") + [""])[:3]
+        out.append(P(bytes.fromhex(hexs).decode("utf-8"), negated=neg == "1", matching=None if int(matching) < 0 else inv[int(matching)]))
+    return out
 
 
 def radix_sort(arr):
