@@ -49,6 +49,14 @@ class SortStrategy(enum.IntEnum):  # src/lib.rs:311-326
     IndexDesc = 3
 
 
+class Matching(enum.IntEnum):  # src/lib.rs:414-427
+    Fuzzy = 0
+    Exact = 1
+    Prefix = 2
+    Suffix = 3
+    Substring = 4
+
+
 @dataclass
 class Scoring:  # src/lib.rs:439-478, defaults src/const.rs:1-10
     match_score: int = 12
@@ -76,6 +84,7 @@ class Config:  # src/lib.rs:236-271
     # which reference CPU backend to be bit-exact against; (0, 0) = what frizbee would pick on this host
     pf_lanes: int = 0
     sw_lanes: int = 0
+    matching: Matching = Matching.Fuzzy
 
 
 class _CScoring(C.Structure):
@@ -85,12 +94,12 @@ class _CScoring(C.Structure):
 
 class _CConfig(C.Structure):
     _fields_ = [("max_typos", C.c_int32), ("casing", C.c_int32), ("unicode", C.c_int32), ("sort", C.c_int32), ("scoring", _CScoring),
-                ("pf_lanes", C.c_uint16), ("sw_lanes", C.c_uint16)]
+                ("pf_lanes", C.c_uint16), ("sw_lanes", C.c_uint16), ("matching", C.c_int32)]
 
 
 class _CPattern(C.Structure):
-    _fields_ = [("needle_utf8", C.c_char_p), ("needle_len", C.c_size_t), ("negated", C.c_int32), ("has_max_typos", C.c_int32), ("max_typos", C.c_int32),
-                ("casing", C.c_int32), ("unicode", C.c_int32), ("has_scoring", C.c_int32), ("scoring", _CScoring)]
+    _fields_ = [("needle_utf8", C.c_void_p), ("needle_len", C.c_size_t), ("negated", C.c_int32), ("has_max_typos", C.c_int32), ("max_typos", C.c_int32),
+                ("casing", C.c_int32), ("unicode", C.c_int32), ("has_scoring", C.c_int32), ("scoring", _CScoring), ("matching", C.c_int32)]
 
 
 _lib = None
@@ -101,6 +110,7 @@ SYMBOLS = [
     "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
     "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
+    "fzb_parse_query", "fzb_patterns_free",
 ]
 
 
@@ -136,6 +146,8 @@ def lib():
         l.fzb_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         l.fzb_multi_matcher_create.argtypes = [C.POINTER(_CConfig), C.POINTER(_CPattern), C.c_size_t, C.POINTER(C.c_void_p)]
         l.fzb_multi_matcher_free.argtypes = [C.c_void_p]
+        l.fzb_parse_query.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.POINTER(_CPattern)), C.POINTER(C.c_size_t)]
+        l.fzb_patterns_free.argtypes = [C.POINTER(_CPattern), C.c_size_t]
         l.fzb_multi_matcher_len.argtypes = [C.c_void_p]
         l.fzb_multi_matcher_len.restype = C.c_size_t
         l.fzb_multi_match_list.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
@@ -218,6 +230,7 @@ def _c_config(config):
     for name, v in zip([f[0] for f in _CScoring._fields_], config.scoring.as_list()):
         setattr(c.scoring, name, v)
     c.pf_lanes, c.sw_lanes = config.pf_lanes, config.sw_lanes
+    c.matching = int(config.matching)
     return c
 
 
@@ -231,6 +244,18 @@ class Pattern:
     casing: "CaseMatching | None" = None
     unicode: "UnicodeMatching | None" = None
     scoring: "Scoring | None" = None
+    matching: "Matching | None" = None
+
+
+def parse_query(query):
+    """`Pattern::parse_query` (src/pattern.rs:186-222) -> list[Pattern]"""
+    q = _b(query)
+    arr, n = C.POINTER(_CPattern)(), C.c_size_t()
+    _check(lib().fzb_parse_query(q, len(q), C.byref(arr), C.byref(n)))
+    out = [Pattern(C.string_at(arr[i].needle_utf8, arr[i].needle_len).decode("utf-8"), negated=bool(arr[i].negated),
+                   matching=None if arr[i].matching < 0 else Matching(arr[i].matching)) for i in range(n.value)]
+    lib().fzb_patterns_free(arr, n.value)
+    return out
 
 
 class MultiMatcher:
@@ -244,11 +269,12 @@ class MultiMatcher:
         for i, p in enumerate(pats):
             n = _b(p.needle)
             self._keep.append(n)
-            arr[i].needle_utf8, arr[i].needle_len, arr[i].negated = n, len(n), int(p.negated)
+            arr[i].needle_utf8, arr[i].needle_len, arr[i].negated = C.cast(C.c_char_p(n), C.c_void_p), len(n), int(p.negated)
             arr[i].has_max_typos, arr[i].max_typos = int(p.max_typos is not None), int(p.max_typos or 0)
             arr[i].casing = -1 if p.casing is None else int(p.casing)
             arr[i].unicode = -1 if p.unicode is None else int(p.unicode)
             arr[i].has_scoring = int(p.scoring is not None)
+            arr[i].matching = -1 if p.matching is None else int(p.matching)
             for name, v in zip([f[0] for f in _CScoring._fields_], (p.scoring or Scoring()).as_list()):
                 setattr(arr[i].scoring, name, v)
         c = _c_config(self.config)

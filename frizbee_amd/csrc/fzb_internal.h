@@ -127,6 +127,11 @@ void fzb_launch_join_add(fzb_match_rec* hits, const u32* n_hits_ptr, const fzb_m
 void fzb_launch_remove_hits(const fzb_match_rec* cand, const u32* n_cand_ptr, const fzb_match_rec* hits, const u32* n_hits_ptr, u64* bitmap, u32* tile_counts,
                             fzb_match_rec* out, u32* total_out, int grid, hipStream_t st);
 void fzb_launch_copy_records(const fzb_match_rec* in, const u32* n_ptr, fzb_match_rec* out, u32 capacity, u32* count_out, int grid, hipStream_t st);
+// kernels_literal.hip
+void fzb_launch_literal_filter(const CorpusDev& c, u64 first, u32 count, const u32* items, const u32* n_items_ptr, const NeedleDev& nd, int mode, u64* bitmap, u32* tile_counts,
+                               int grid, hipStream_t st);
+void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* n_items_ptr, const NeedleDev& nd, int mode, fzb_match_rec* out,
+                              u32 capacity, u32* dev_count, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st);

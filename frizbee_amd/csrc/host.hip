@@ -98,10 +98,14 @@ u16 max_one_time_bonus(const fzb_scoring& s) {
     u16 amortized = std::max<u16>((u16)((bonus + 1) / 2), ssub16(bonus, s.gap_open_penalty));
     return (u16)(bonus - amortized);
 }
-std::string overflow_guard(const fzb_scoring& s, size_t rows) {
-    u16 max_per_char = sadd16(s.match_score, max_per_char_bonus(s));
+// Scoring::guard_against_score_overflow (src/lib.rs:506-537).  Fuzzy callers pass the amortised bonuses (src/matcher/algo.rs:311-325),
+// the literal matcher its own (src/literal/algo.rs:314-322).
+std::string overflow_guard(const fzb_scoring& s, size_t rows, int bonus_per_char = -1, int one_time = -1) {
+    const u16 bpc = bonus_per_char < 0 ? max_per_char_bonus(s) : (u16)bonus_per_char;
+    const u16 ot = one_time < 0 ? max_one_time_bonus(s) : (u16)one_time;
+    u16 max_per_char = sadd16(s.match_score, bpc);
     if (max_per_char == 0) return "";
-    u16 headroom = ssub16(ssub16(ssub16(ssub16(0xFFFF, s.prefix_bonus), s.exact_match_bonus), s.mismatch_penalty), max_one_time_bonus(s));
+    u16 headroom = ssub16(ssub16(ssub16(ssub16(0xFFFF, s.prefix_bonus), s.exact_match_bonus), s.mismatch_penalty), ot);
     u16 max_needle_len = (u16)(headroom / max_per_char);
     if (rows > (size_t)max_needle_len)
         return "needle too long and could overflow the u16 score: " + std::to_string(rows) + " > " + std::to_string(max_needle_len);
@@ -161,6 +165,7 @@ struct fzb_matcher {
     fzb_config config{};
     std::string needle;
     bool empty = false, case_sensitive = false, unicode = false, use_u8 = false;
+    int literal_mode = 0;  // 0 = fuzzy; else FZB_MATCH_EXACT / PREFIX / SUFFIX / SUBSTRING (src/literal)
     int rows = 0;
     NeedleDev nd{};
     LaunchCfg lc{};
@@ -193,6 +198,7 @@ void fzb_config_default(fzb_config* out) {
     out->unicode = FZB_UNICODE_SMART;
     out->sort = FZB_SORT_SCORE_THEN_INDEX_ASC;
     out->scoring = fzb_scoring{12, 6, 5, 1, 12, 4, 4, 8, 4};  // src/const.rs:1-10
+    out->matching = FZB_MATCH_FUZZY;
 }
 
 static void free_workspace(Workspace& w) {
@@ -234,8 +240,11 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     m->case_sensitive = config->casing == FZB_CASE_RESPECT || (config->casing == FZB_CASE_SMART && any_upper);
     m->unicode = config->unicode == FZB_UNICODE_ALWAYS || (config->unicode == FZB_UNICODE_SMART && !ascii);
     m->rows = (int)(m->unicode ? cps.size() : needle_len);
-    // guard_against_score_overflow (src/matcher/algo.rs:311-325)
-    std::string perr = overflow_guard(sc, (size_t)m->rows);
+    if (config->matching < FZB_MATCH_FUZZY || config->matching > FZB_MATCH_SUBSTRING) { delete m; return fail(FZB_ERR_INVALID, "bad matching mode"); }
+    m->literal_mode = config->matching;
+    // guard_against_score_overflow: fuzzy src/matcher/algo.rs:311-325 (rows); literal src/literal/algo.rs:33, 314-322 (needle bytes, its own per-char bonus)
+    std::string perr = m->literal_mode ? overflow_guard(sc, needle_len, sadd16(std::max(sc.capitalization_bonus, sc.delimiter_bonus), sc.matching_case_bonus), 0)
+                                       : overflow_guard(sc, (size_t)m->rows);
     if (!perr.empty()) { delete m; return fail(FZB_ERR_PANIC, perr); }
     if (needle_len > FZB_MAX_NEEDLE_BYTES || m->rows > FZB_MAX_ROWS) {
         delete m;
@@ -513,6 +522,18 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
         return FZB_OK;
     }
+    if (m->literal_mode) {
+        // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
+        u32* cnt_c = w.counters;
+        fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
+        FZB_STAGE("literal filter");
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, items_in ? n_items_in : nullptr, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
+        FZB_STAGE("literal compact");
+        fzb_launch_literal_score(cd, first, index_offset, w.surv_idx, &cnt_c[0], nd, m->literal_mode, (fzb_match_rec*)dev_out, cap32, dev_count, cus * 4, st);
+        FZB_STAGE("literal score");
+        HIPCHK(hipGetLastError());
+        return FZB_OK;
+    }
     hipEvent_t* pev = nullptr;
     if (m->profiling) {
         const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);
@@ -774,6 +795,87 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
     return fzb_match_list(m, c, out, out_len);
 }
 
+// ---- query syntax: Pattern::parse / Pattern::parse_query (src/pattern.rs:87-222) ---------------------------------------------
+namespace {
+bool is_rust_whitespace(u32 c) {  // char::is_whitespace = Unicode White_Space
+    return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F ||
+           c == 0x205F || c == 0x3000;
+}
+void append_utf8(std::string& s, u32 cp) {
+    u8 buf[4];
+    const int n = encode_utf8(cp, buf);
+    s.append((const char*)buf, (size_t)n);
+}
+struct ParsedAtom { std::string needle; bool negated; int matching; };
+// one atom: `!` negates, `^` / `$` anchor, `'` asks for a substring, a bare negated atom is a substring too; `\x` escapes x
+ParsedAtom parse_atom(const std::vector<u32>& atom) {
+    std::vector<std::pair<u32, bool>> tok;  // (char, escaped)
+    for (size_t i = 0; i < atom.size(); i++) {
+        if (atom[i] == '\\' && i + 1 < atom.size()) { tok.push_back({atom[i + 1], true}); i++; }
+        else tok.push_back({atom[i], false});
+    }
+    size_t lo = 0, hi = tok.size();
+    auto first_is = [&](u32 op) { if (lo < hi && !tok[lo].second && tok[lo].first == op) { lo++; return true; } return false; };
+    auto last_is = [&](u32 op) { if (lo < hi && !tok[hi - 1].second && tok[hi - 1].first == op) { hi--; return true; } return false; };
+    ParsedAtom a;
+    a.negated = first_is('!');
+    const bool prefix = first_is('^');
+    const bool substring = !prefix && first_is('\'');
+    const bool suffix = last_is('$');
+    for (size_t i = lo; i < hi; i++) {
+        const u32 c = tok[i].first;
+        const bool special = c == '!' || c == '^' || c == '\'' || c == '$' || is_rust_whitespace(c);
+        if (tok[i].second && !special) a.needle.push_back('\\');  // a backslash before anything else stays literal
+        append_utf8(a.needle, c);
+    }
+    a.matching = prefix && suffix ? FZB_MATCH_EXACT : prefix ? FZB_MATCH_PREFIX : suffix ? FZB_MATCH_SUFFIX : (substring || a.negated) ? FZB_MATCH_SUBSTRING : -1;
+    return a;
+}
+}  // namespace
+
+int fzb_parse_query(const uint8_t* query_utf8, size_t query_len, fzb_pattern** out_patterns, size_t* out_n) {
+    if (!out_patterns || !out_n || (query_len && !query_utf8)) return fail(FZB_ERR_INVALID, "null argument");
+    std::vector<u32> cps;
+    if (!decode_utf8(query_utf8, query_len, cps)) return fail(FZB_ERR_INVALID, "query is not valid UTF-8");
+    std::vector<ParsedAtom> atoms;
+    std::vector<u32> cur;
+    bool in_atom = false, escaped = false;
+    auto flush = [&]() {
+        ParsedAtom a = parse_atom(cur);
+        if (!a.needle.empty()) atoms.push_back(a);  // atoms with an empty needle (`!`, `^$`) are dropped
+        cur.clear();
+        in_atom = false;
+    };
+    for (u32 c : cps) {
+        if (escaped) { escaped = false; cur.push_back(c); }
+        else if (c == '\\') { in_atom = true; escaped = true; cur.push_back(c); }
+        else if (is_rust_whitespace(c)) { if (in_atom) flush(); }
+        else { in_atom = true; cur.push_back(c); }
+    }
+    if (in_atom) flush();
+    fzb_pattern* arr = (fzb_pattern*)calloc(std::max<size_t>(atoms.size(), 1), sizeof(fzb_pattern));
+    for (size_t i = 0; i < atoms.size(); i++) {
+        u8* n = (u8*)malloc(atoms[i].needle.size() + 1);
+        memcpy(n, atoms[i].needle.data(), atoms[i].needle.size());
+        n[atoms[i].needle.size()] = 0;
+        arr[i].needle_utf8 = n;
+        arr[i].needle_len = atoms[i].needle.size();
+        arr[i].negated = atoms[i].negated;
+        arr[i].casing = -1;
+        arr[i].unicode = -1;
+        arr[i].matching = atoms[i].matching;
+    }
+    *out_patterns = arr;
+    *out_n = atoms.size();
+    return FZB_OK;
+}
+
+void fzb_patterns_free(fzb_pattern* patterns, size_t n) {
+    if (!patterns) return;
+    for (size_t i = 0; i < n; i++) free((void*)patterns[i].needle_utf8);
+    free(patterns);
+}
+
 // ---- multi-pattern composition (src/matcher/multi.rs) ---------------------------------------------------
 struct fzb_multi_matcher {
     fzb_config config{};
@@ -821,6 +923,7 @@ int fzb_multi_matcher_create(const fzb_config* config, const fzb_pattern* patter
         if (p.casing >= 0) rc.casing = p.casing;
         if (p.unicode >= 0) rc.unicode = p.unicode;
         if (p.has_scoring) rc.scoring = p.scoring;
+        if (p.matching >= 0) rc.matching = p.matching;
         rc.sort = FZB_SORT_INDEX_ASC;
         fzb_matcher* m = nullptr;
         int rc_create = fzb_matcher_create(&rc, p.needle_utf8, p.needle_len, &m);

@@ -33,6 +33,8 @@ enum {
 enum { FZB_CASE_IGNORE = 0, FZB_CASE_SMART = 1, FZB_CASE_RESPECT = 2 };
 enum { FZB_UNICODE_IGNORE = 0, FZB_UNICODE_SMART = 1, FZB_UNICODE_ALWAYS = 2 };
 enum { FZB_SORT_SCORE_THEN_INDEX_ASC = 0, FZB_SORT_SCORE_THEN_INDEX_DESC = 1, FZB_SORT_INDEX_ASC = 2, FZB_SORT_INDEX_DESC = 3 };
+/* src/lib.rs:414-427 Matching: fuzzy (Smith-Waterman) or one of the literal modes of src/literal (contiguous occurrence) */
+enum { FZB_MATCH_FUZZY = 0, FZB_MATCH_EXACT = 1, FZB_MATCH_PREFIX = 2, FZB_MATCH_SUFFIX = 3, FZB_MATCH_SUBSTRING = 4 };
 
 /* src/lib.rs:439-478 `Scoring` (same field order as the Rust struct declaration) */
 typedef struct fzb_scoring {
@@ -41,7 +43,7 @@ typedef struct fzb_scoring {
 } fzb_scoring;
 
 /* src/lib.rs:236-258 `Config` (+ per-pattern overrides already resolved, src/pattern.rs:250-262).
- * `matching` must be Fuzzy: the literal modes (src/literal) are outside this backend.
+ * `matching`: the literal modes (src/literal/algo.rs) ignore max_typos and do not depend on pf_lanes / sw_lanes.
  * pf_lanes / sw_lanes select WHICH reference CPU backend the results are bit-exact against, because
  * frizbee's scores, windows and typo-prefilter decisions depend on the SIMD lane count: both 0 = pick the
  * pair the reference's `Matcher::get_backend` (src/matcher/mod.rs:448-498) would pick on THIS host CPU
@@ -56,6 +58,7 @@ typedef struct fzb_config {
     int32_t sort;      /* FZB_SORT_*    */
     fzb_scoring scoring;
     uint16_t pf_lanes, sw_lanes;
+    int32_t matching;  /* FZB_MATCH_* */
 } fzb_config;
 
 /* src/lib.rs:141-153 `Match` with an explicit layout (Rust's is unspecified; the shim copies field-wise) */
@@ -141,8 +144,8 @@ int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_l
  * pattern matches and no negated one does; score = saturating sum of the non-negated patterns' scores, exact = OR
  * (src/matcher/multi.rs:84-152).  One `fzb_pattern` = reference `Pattern{needle, negated, config: PatternConfig}`
  * (src/pattern.rs:9-18, 230-262); the per-pattern overrides are resolved against the matcher's config exactly like
- * `PatternConfig::resolve`.  Only fuzzy matching: `PatternConfig::matching` / `Config::matching` other than Fuzzy (the
- * literal modes of src/literal, and therefore `Pattern::parse`'s `!foo` = negated SUBSTRING) is outside this backend. */
+ * `PatternConfig::resolve`, including the matching mode (`Pattern::parse`: `^foo` prefix, `foo$` suffix, `^foo$` exact,
+ * `'foo` substring, `!foo` negated substring). */
 typedef struct fzb_pattern {
     const uint8_t* needle_utf8;
     size_t needle_len;      /* 0: the pattern is dropped (Matcher::compile, src/matcher/mod.rs:193-195) */
@@ -153,8 +156,14 @@ typedef struct fzb_pattern {
     int32_t unicode;        /* FZB_UNICODE_*, or -1 = inherit */
     int32_t has_scoring;    /* PatternConfig::scoring = Some(scoring) */
     fzb_scoring scoring;
+    int32_t matching;       /* FZB_MATCH_*, or -1 = inherit Config::matching (what Pattern::parse leaves for a plain atom) */
 } fzb_pattern;
 typedef struct fzb_multi_matcher fzb_multi_matcher;
+
+/* `Pattern::parse_query(query)` (src/pattern.rs:186-222; atoms per `Pattern::parse`, :87-167): whitespace separated atoms, `\\` escapes,
+ * atoms with an empty needle dropped.  The array (and the needle strings it points to) is released with fzb_patterns_free. */
+int fzb_parse_query(const uint8_t* query_utf8, size_t query_len, fzb_pattern** out_patterns, size_t* out_n);
+void fzb_patterns_free(fzb_pattern* patterns, size_t n);
 
 int fzb_multi_matcher_create(const fzb_config* config, const fzb_pattern* patterns, size_t n_patterns, fzb_multi_matcher** out);
 void fzb_multi_matcher_free(fzb_multi_matcher* mm);

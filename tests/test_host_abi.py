@@ -24,11 +24,12 @@ def test_library_loads_and_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header():
-    assert C.sizeof(F._CScoring) == 18 and C.sizeof(F._CConfig) == 4 * 4 + 18 + 4 + 2  # padded to 4-byte alignment
+    assert C.sizeof(F._CScoring) == 18 and C.sizeof(F._CConfig) == 4 * 4 + 18 + 4 + 2 + 4  # 2 bytes of padding before the trailing int32 `matching`
+    assert F._CConfig.matching.offset == 40 and C.sizeof(F._CPattern) == 8 + 8 + 6 * 4 + 18 + 2 + 4
     assert F.MATCH_DTYPE.itemsize == 8 and O.MATCH_DTYPE == F.MATCH_DTYPE
     c = F._CConfig()
     F.lib().fzb_config_default(C.byref(c))
-    assert (c.max_typos, c.casing, c.unicode, c.sort) == (0, 1, 1, 0)
+    assert (c.max_typos, c.casing, c.unicode, c.sort, c.matching) == (0, 1, 1, 0, 0)
     assert [getattr(c.scoring, f[0]) for f in F._CScoring._fields_] == O.DEFAULT_SCORING
 
 
