@@ -308,6 +308,21 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
     for (int st = 0; st <= m->rows; st++)
         for (int b = 0; b < 256; b++) m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && ((m->table[b] >> st) & 1)) ? st + 1 : st);
+    if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) {
+        // Substring accept on the ASCII path = "the text drives the needle's Knuth-Morris-Pratt automaton into its final state":
+        // the same table shape, so the streaming DFA filter kernels run it unchanged.  Position k matches byte b iff b is
+        // needle[k] or its case flip; both case forms of a needle byte take the automaton to the same state (the flip is
+        // an involution on every position's byte set), so the usual single restart state works for the folded alphabet.
+        const int n = m->rows;
+        auto hit = [&](int k, int b) { return b == nd.c[k] || b == nd.f[k]; };
+        for (int b = 0; b < 256; b++) m->dfa[b] = (u8)(hit(0, b) ? 1 : 0);
+        int x = 0;  // restart state: where the automaton is after reading needle[1..k)
+        for (int k = 1; k < n; k++) {
+            for (int b = 0; b < 256; b++) m->dfa[(size_t)k * 256 + b] = (u8)(hit(k, b) ? k + 1 : m->dfa[(size_t)x * 256 + b]);
+            x = m->dfa[(size_t)x * 256 + nd.c[k]];
+        }
+        for (int b = 0; b < 256; b++) m->dfa[(size_t)n * 256 + b] = (u8)n;  // found: absorbing
+    }
     lc.pad_ok = 1;
     for (size_t i = 0; i < needle_len; i++)
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
@@ -525,7 +540,10 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     if (m->literal_mode) {
         // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
         u32* cnt_c = w.counters;
-        fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
+        if (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode && !items_in)  // the streaming DFA filter over the needle's KMP automaton
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, cus * 8, st);
+        else
+            fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
         FZB_STAGE("literal filter");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, items_in ? n_items_in : nullptr, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
         FZB_STAGE("literal compact");

@@ -52,6 +52,21 @@ if "MULTI" in which:
     torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 10
     print(json.dumps(dict(config="C2 list, patterns dead + be + !x", haystacks=n, ms_per_step=wall * 1e3, haystacks_per_s=n / wall, matches=int(cnt[0].item()))), flush=True)
     del cp, flat, ends
+if "LITERAL" in which:
+    # the literal modes on the C2 list (device pipeline: accept pass -> compaction -> scoring pass)
+    flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
+    flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
+    ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+    out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev); cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    for needle, matching in (("de", "Substring"), ("deadbe", "Substring"), ("d", "Prefix"), ("e", "Suffix")):
+        m = F.Matcher(needle, F.Config(matching=F.Matching[matching]))
+        for _ in range(2): m.match_list_device(cp, out.data_ptr(), n, cnt.data_ptr())
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): m.match_list_device(cp, out.data_ptr(), n, cnt.data_ptr())
+        torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 10
+        print(json.dumps(dict(config=f"C2 list, literal {matching} {needle!r}", haystacks=n, ms_per_step=wall * 1e3, haystacks_per_s=n / wall, matches=int(cnt[0].item()))), flush=True)
+    del cp, flat, ends
 if "E2E" in which:
     # end to end from host memory: pack + upload once (fzb_corpus_upload), then the ordered query the caller sees
     # (fzb_match_list: pipeline + device sort + D2H of the records)
