@@ -99,7 +99,7 @@ struct LaunchCfg {
 #include <hip/hip_runtime.h>
 // kernels_filter.hip
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
-                       u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
+                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st);
 void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, const u32* base_in, u32* base_out, hipStream_t st);
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st);
 void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,

@@ -532,7 +532,9 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
         }                                                                                                      \
     } while (0)
-    HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
+    // the streaming filter kernels clear the counter block themselves (one launch less on the hot path)
+    const bool filter_resets = count != 0 && !items_in && (m->literal_mode ? (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode) : lc.filter_mode != 0);
+    if (!filter_resets) HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
     if (count == 0) {
         HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
         return FZB_OK;
@@ -541,7 +543,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
         u32* cnt_c = w.counters;
         if (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode && !items_in)  // the streaming DFA filter over the needle's KMP automaton
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, cus * 8, st);
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
         else
             fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
         FZB_STAGE("literal filter");
@@ -586,7 +588,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 8, st);
+        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 2, st);

@@ -46,7 +46,10 @@ __device__ __forceinline__ void filter_word(TW& st, u32 w, u32 nbytes, const TW*
 template <typename TW, int MODE, typename ET>
 __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                                  const u64* __restrict__ Tg, int rows, int need, u32 min_len,
-                                                 u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
+                                                 u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+    // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
+    // compaction kernel reads it
+    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     __shared__ TW T[256];
     __shared__ u32 s_cnt;
     const int tid = threadIdx.x;
@@ -136,7 +139,10 @@ __device__ __forceinline__ u32 dfa_partial(u32 st, const uint4& q, u32 nbytes, c
 template <typename ET>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                               const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
-                                              u32* __restrict__ tile_counts) {
+                                              u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+    // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
+    // compaction kernel reads it
+    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     __shared__ u32 s_cnt;
     const int tid = threadIdx.x;
@@ -226,7 +232,10 @@ __device__ __forceinline__ void dfa_wordP(u32 (&st)[P], const u32 (&w)[P], const
 template <typename ET, int P>
 __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                                      const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
-                                                     u32* __restrict__ tile_counts) {
+                                                     u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+    // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
+    // compaction kernel reads it
+    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     __shared__ u32 s_cnt;
     const int tid = threadIdx.x;
@@ -458,15 +467,24 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
         pre[tid] = base + wb + incl - c;
         const u32 batch_total = red[0] + red[1] + red[2] + red[3];
         __syncthreads();
-        // expand the bitmap words of these tiles
+        // expand the bitmap words of these tiles: the 16 words of a tile sit in 16 consecutive lanes (w0 is a multiple of 16),
+        // so a word's offset inside its tile is a 16-lane segmented scan of the popcounts - no re-reading of the earlier words
         const u32 w0 = tb * (FZB_TILE / 64), w1 = (tb + nt) * (FZB_TILE / 64);
         const u32 nwords = (n_items + 63) / 64;
-        for (u32 w = w0 + tid; w < w1 && w < nwords; w += 256) {
-            u64 bits = bitmap[w];
+        for (u32 wb0 = w0; wb0 < w1; wb0 += 256) {  // uniform trip count: the shuffles below need every lane
+            const u32 w = wb0 + tid;
+            const bool live = w < w1 && w < nwords;
+            u64 bits = live ? bitmap[w] : 0ull;
+            const u32 c = (u32)__popcll(bits);
+            u32 incl = c;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const u32 v = __shfl_up(incl, off, 16);
+                if ((lane & 15) >= off) incl += v;
+            }
             if (!bits) continue;
             const u32 tile = w / (FZB_TILE / 64);
-            u32 pos = pre[tile - tb];
-            for (u32 k = tile * (FZB_TILE / 64); k < w; k++) pos += __popcll(bitmap[k]);
+            u32 pos = pre[tile - tb] + incl - c;
             while (bits) {
                 const int b = __builtin_ctzll(bits);
                 bits &= bits - 1;
@@ -561,7 +579,7 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // host-side launch wrappers (called from pipeline.hip)
 // ---------------------------------------------------------------------------------------------------
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
-                       u64* bitmap, u32* tile_counts, int grid, hipStream_t st) {
+                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st) {
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
@@ -569,15 +587,15 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         const size_t lds = (size_t)(rows + 1) * 256;
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
-            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
-            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
+            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);
+            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);
         } else {
             // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
             // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times)
             int rgrid = std::min<int>((grid / 8) * 6, (int)ntiles);
             if (rgrid < 1) rgrid = 1;
-            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa_ragged<u64, 1>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
-            else hipLaunchKernelGGL((k1_dfa_ragged<u32, 1>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts);
+            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa_ragged<u64, 1>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);
+            else hipLaunchKernelGGL((k1_dfa_ragged<u32, 1>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);
         }
         return;
     }
@@ -586,7 +604,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         return;
     }
     const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
-#define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts)
+#define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters)
     if (c.ends_u64) {
         if (mode == 1) { if (w64) FZB_K1(u64, 1, u64); else FZB_K1(u32, 1, u64); }
         else           { if (w64) FZB_K1(u64, 2, u64); else FZB_K1(u32, 2, u64); }
