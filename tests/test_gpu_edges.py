@@ -1,0 +1,70 @@
+"""Edge cases of the boundary on the GPU: 64-bit end offsets, NUL bytes in haystacks and needles, a result buffer smaller
+than the match list, one-item lists, every (fuzzy) kernel family on a device-built padded-16 corpus."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import frizbee_amd as F
+import oracle_lib as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def padded16(haystacks, dev, u64):
+    """Build the device layout by hand: every haystack on a 16-byte boundary, exclusive ends, >= 96 zero bytes of tail."""
+    ends, pos, chunks = [], 0, []
+    for h in haystacks:
+        pad = (-pos) % 16
+        chunks.append(b"\0" * pad + h)
+        pos += pad + len(h)
+        ends.append(pos)
+    blob = b"".join(chunks) + b"\0" * ((-pos) % 16 + 96)
+    data = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    e = torch.tensor(ends, dtype=torch.int64 if u64 else torch.int32, device=dev) if ends else torch.zeros(1, dtype=torch.int64 if u64 else torch.int32, device=dev)
+    return F.Corpus.from_device(data.data_ptr(), e.data_ptr(), len(haystacks), data.numel(), ends_are_u64=u64, keep=(data, e))
+
+
+@pytest.mark.parametrize("u64", [False, True])
+def test_device_layout_with_32_and_64_bit_ends(u64):
+    rng = np.random.default_rng(5)
+    alpha = b"abcdeDEF_-/ 01\0"
+    hs = [bytes(alpha[int(x)] for x in rng.integers(0, len(alpha), int(rng.choice([0, 1, 5, 16, 31, 32, 33, 64, 65, 100, 200, 1100])))) for _ in range(3000)]
+    cp = padded16(hs, torch.device("cuda", 0), u64)
+    for needle, cfg in (("deadbe", dict(max_typos=0)), ("dea", dict(max_typos=1)), ("ab_c", dict(max_typos=None)), ("a\0b", dict(max_typos=0)), ("é", dict(max_typos=0, unicode="Always"))):
+        for matching in ("Fuzzy", "Substring"):
+            want = O.Matcher(needle, matching=matching, **cfg).match_list(hs)
+            fc = F.Config(max_typos=cfg["max_typos"], unicode=F.UnicodeMatching[cfg.get("unicode", "Smart")], matching=F.Matching[matching], pf_lanes=64)
+            got = F.Matcher(needle, fc).match_list(cp)
+            assert got.tolist() == want.tolist(), (needle, cfg, matching, u64)
+
+
+def test_result_buffer_smaller_than_the_match_list_is_clamped_not_overrun():
+    rows, ends = synth.fixed_corpus(b"deadbe", 200_000, 32)
+    cp = F.Corpus(packed=(rows.numpy().reshape(-1), ends))
+    m = F.Matcher("deadbe", F.Config(sort=F.SortStrategy.IndexAsc, pf_lanes=64, sw_lanes=64))
+    whole = m.match_list(cp)
+    cap = len(whole) // 3
+    dev = torch.device("cuda", 0)
+    out = torch.full(((cap + 64) * 8,), 0xAB, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    m.match_list_device(cp, out.data_ptr(), cap, cnt.data_ptr())
+    torch.cuda.synchronize()
+    assert int(cnt[0].item()) == cap
+    host = out.cpu().numpy()
+    assert host[: cap * 8].view(F.MATCH_DTYPE).tolist() == whole[:cap].tolist()  # index order: the first `cap` matches
+    assert (host[cap * 8 :] == 0xAB).all()  # nothing written past the capacity
+
+
+def test_tiny_lists():
+    for hs in ([], [""], ["deadbe"], ["x"], ["", "deadbe", ""]):
+        for typos in (0, 1, None):
+            want = O.Matcher("deadbe", max_typos=typos).match_list(hs)
+            got = F.Matcher("deadbe", F.Config(max_typos=typos, pf_lanes=64)).match_list(hs)
+            assert got.tolist() == want.tolist(), (hs, typos)
+        assert F.MultiMatcher(F.parse_query("dead !x"), F.Config(pf_lanes=64)).match_list(hs).tolist() == O.MultiMatcher(O.parse_query("dead !x")).match_list(hs).tolist()

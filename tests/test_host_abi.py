@@ -104,3 +104,18 @@ def test_scoring_entry_points_fail_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(F.FrizbeeError):
         F.Matcher("abc").match_list(["abc"])
+
+
+def test_parse_query_matches_the_references_known_answers():
+    # Pattern::parse / parse_query (src/pattern.rs:307-382), host logic of the boundary (no GPU involved)
+    import json
+    lt = json.load(open(os.path.join(ROOT, "tests", "golden", "literal.json")))
+    for atom, needle, matching, negated in lt["parse_atoms"]:
+        got = F.parse_query(atom.replace(" ", "\\ ") if " " in atom and "\\ " not in atom else atom)
+        assert len(got) == 1
+        assert (got[0].needle, None if got[0].matching is None else got[0].matching.name, got[0].negated) == (needle, matching, negated), atom
+    for query, needles, ref in lt["parse_queries"]:
+        assert [p.needle for p in F.parse_query(query)] == needles, ref
+    for query in ("foo !^bar 'lit baz$ ^ex$ !neg a\\ b \\!x ! \\", "다나 !é$ ^\\^x"):
+        got, want = F.parse_query(query), O.parse_query(query)
+        assert [(p.needle, p.negated, None if p.matching is None else p.matching.name) for p in got] == [(p["needle"], p["negated"], p["matching"]) for p in want]
