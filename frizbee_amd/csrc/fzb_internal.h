@@ -63,7 +63,6 @@ struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between k
 struct Workspace {
     u64* bitmap;        // count/64 words: filter decisions
     u32* tile_counts;   // ntiles
-    u32* tile_prefix;   // ntiles + 1
     u32* surv_idx;      // local haystack index of survivor j
     u32* win;           // 2 * survivors: (start, end) windows from the lane-exact prefilter; start=0xFFFFFFFF => rejected
     u32* overflow;      // queue of (output position, window start, window end, haystack): multi-chunk windows from the front, > 1024-byte windows from the back
@@ -74,7 +73,6 @@ struct Workspace {
     size_t sort_cap;
     u64* bitmap2;       // second-level keep bits (after the lane-exact prefilter)
     u32* tile_counts2;
-    u32* tile_prefix2;
     u32* items2;        // local haystack index of kept survivor
     u32* win2;          // its window
     u32* counters;      // [0]=filter survivors [1]=kept by the lane-exact prefilter [2]=output base of the NEXT chunk [3]=multi-chunk queue length [4]=greedy (>1024 B) queue length
@@ -100,12 +98,11 @@ struct LaunchCfg {
 // kernels_filter.hip
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st);
-void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, const u32* base_in, u32* base_out, hipStream_t st);
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st);
 void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,
                              u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
-void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,
-                    const u32* in_idx, const u32* in_win, u32* out_win, int grid, hipStream_t st);
+void fzb_launch_compact2(const u64* bitmap, const u32* counts, const u32* n_items_ptr, const u32* in_idx, const u32* in_win, u32* out_idx, u32* out_win, u32* total_out,
+                         int grid, hipStream_t st);
 // kernels_window.hip
 void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
                        u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st);

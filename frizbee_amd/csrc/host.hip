@@ -202,7 +202,7 @@ void fzb_config_default(fzb_config* out) {
 }
 
 static void free_workspace(Workspace& w) {
-    void* ptrs[] = {w.bitmap, w.tile_counts, w.tile_prefix, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.tile_prefix2, w.items2, w.win2, w.counters, w.table, w.dfa};
+    void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -473,7 +473,6 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 2;
     HIPCHK(dev_alloc((void**)&w.bitmap, (cap / 64 + 17) * 8));
     HIPCHK(dev_alloc((void**)&w.tile_counts, ntiles * 4));
-    HIPCHK(dev_alloc((void**)&w.tile_prefix, (ntiles + 1) * 4));
     HIPCHK(dev_alloc((void**)&w.surv_idx, cap * 4));
     HIPCHK(dev_alloc((void**)&w.overflow, cap * 16));
     HIPCHK(dev_alloc((void**)&w.counters, 64));
@@ -486,7 +485,6 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
         HIPCHK(dev_alloc((void**)&w.win, cap * 8));
         HIPCHK(dev_alloc((void**)&w.bitmap2, (cap / 64 + 17) * 8));
         HIPCHK(dev_alloc((void**)&w.tile_counts2, ntiles * 4));
-        HIPCHK(dev_alloc((void**)&w.tile_prefix2, (ntiles + 1) * 4));
         HIPCHK(dev_alloc((void**)&w.items2, cap * 4));
         HIPCHK(dev_alloc((void**)&w.win2, cap * 8));
         w.cap_level2 = cap;
@@ -599,10 +597,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // the stream stage was a superset: re-decide every survivor with the reference's chunked algorithm at its exact lane width
         fzb_launch_window(cd, first, items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, cus * 4, st);
         FZB_STAGE("window");
-        fzb_launch_scan(w.tile_counts2, w.tile_prefix2, &cnt_c[0], 0, &cnt_c[1], nullptr, nullptr, st);
-        FZB_STAGE("scan2");
-        fzb_launch_map(2, w.bitmap2, w.tile_prefix2, &cnt_c[0], 0, w.items2, items, w.win, w.win2, cus * 2, st);
-        FZB_STAGE("map2");
+        fzb_launch_compact2(w.bitmap2, w.tile_counts2, &cnt_c[0], items, w.win, w.items2, w.win2, &cnt_c[1], cus * 2, st);
+        FZB_STAGE("compact2");
         items = w.items2;
         win = w.win2;
         n_items_ptr = &cnt_c[1];

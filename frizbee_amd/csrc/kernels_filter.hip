@@ -322,111 +322,8 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
     }
 }
 
-// Used when nothing is filtered (max_typos = None, or max_typos >= rows): every haystack survives.
-__global__ __launch_bounds__(256) void k1_all_pass(u32 count, u32 min_len_unused, u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
-    const u32 nwords = (count + 63) / 64;
-    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    for (u32 w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
-        const u32 rem = count - w * 64;
-        bitmap[w] = rem >= 64 ? ~(u64)0 : (((u64)1 << rem) - 1);
-    }
-    for (u32 t = blockIdx.x * blockDim.x + threadIdx.x; t < ntiles; t += gridDim.x * blockDim.x) {
-        const u32 rem = count - t * FZB_TILE;
-        tile_counts[t] = rem >= FZB_TILE ? FZB_TILE : rem;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------
-// Exclusive scan of the per-tile counts (one 1024-thread block; the list has count/1024 entries).
-// `n_items_ptr` (device) holds the number of ITEMS the tiles cover, so the same kernel serves both the
-// first-level (haystacks) and second-level (survivors) compaction without a host round trip.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_tiles(const u32* __restrict__ counts, u32* __restrict__ prefix, const u32* __restrict__ n_items_ptr,
-                                                     u32 n_items_host, u32* __restrict__ total_out, const u32* __restrict__ base_in, u32* __restrict__ base_out) {
-    __shared__ u32 wsum[16];
-    const u32 n_items = n_items_ptr ? *n_items_ptr : n_items_host;
-    const u32 ntiles = (n_items + FZB_TILE - 1) / FZB_TILE;
-    const u32 per = (ntiles + 1023) / 1024;
-    const u32 lo = threadIdx.x * per, hi = min(lo + per, ntiles);
-    // thread-local sum with the loads batched 8 at a time (independent loads in flight instead of a serial chain)
-    u32 sum = 0;
-    for (u32 t = lo; t < hi; t += 8) {
-        u32 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (t + k < hi) ? counts[t + k] : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; k++) sum += v[k];
-    }
-    // block exclusive scan of `sum`
-    u32 incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        u32 v = __shfl_up(incl, off);
-        if (lane_id() >= off) incl += v;
-    }
-    const int wave = threadIdx.x >> 6;
-    if (lane_id() == 63) wsum[wave] = incl;
-    __syncthreads();
-    u32 wbase = 0;
-    for (int w = 0; w < wave; w++) wbase += wsum[w];
-    u32 run = wbase + incl - sum;
-    for (u32 t = lo; t < hi; t += 8) {
-        u32 v[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (t + k < hi) ? counts[t + k] : 0u;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (t + k < hi) prefix[t + k] = run;
-            run += v[k];
-        }
-    }
-    if (threadIdx.x == 1023) {
-        prefix[ntiles] = wbase + incl;
-        *total_out = wbase + incl;
-        if (base_out) *base_out = (base_in ? *base_in : 0u) + wbase + incl;  // chunk chaining: where the next chunk's records start
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Bitmap -> dense, index-ordered list.  One thread per bitmap word.  LEVEL 1: out_idx[j] = bit position.
-// LEVEL 2 (after the lane-exact prefilter re-decided the survivors): gathers payloads of the kept items.
-// ---------------------------------------------------------------------------------------------------
-template <int LEVEL>
-__global__ __launch_bounds__(256) void k_map(const u64* __restrict__ bitmap, const u32* __restrict__ prefix, const u32* __restrict__ n_items_ptr, u32 n_items_host,
-                                             u32* __restrict__ out_idx, const u32* __restrict__ in_idx, const u32* __restrict__ in_win, u32* __restrict__ out_win) {
-    const u32 n_items = n_items_ptr ? *n_items_ptr : n_items_host;
-    if (LEVEL == 1) {
-        // sparse (a few set bits per word): one thread per bitmap word
-        const u32 nwords = (n_items + 63) / 64;
-        for (u32 w = blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += gridDim.x * blockDim.x) {
-            u64 bits = bitmap[w];
-            if (!bits) continue;
-            const u32 tile = w / (FZB_TILE / 64);
-            u32 pos = prefix[tile];
-            for (u32 k = tile * (FZB_TILE / 64); k < w; k++) pos += __popcll(bitmap[k]);
-            while (bits) {
-                const int b = __builtin_ctzll(bits);
-                bits &= bits - 1;
-                out_idx[pos++] = w * 64 + b;
-            }
-        }
-    } else {
-        // dense (most survivors are kept): one thread per item, each computing its own rank, so the payload gather is coalesced
-        for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n_items; j += gridDim.x * blockDim.x) {
-            const u32 w = j >> 6;
-            const u64 bits = bitmap[w];
-            if (!((bits >> (j & 63)) & 1)) continue;
-            const u32 tile = j / FZB_TILE;
-            u32 pos = prefix[tile] + __popcll(bits & (((u64)1 << (j & 63)) - 1));
-            for (u32 k = tile * (FZB_TILE / 64); k < w; k++) pos += __popcll(bitmap[k]);
-            out_idx[pos] = in_idx ? in_idx[j] : j;
-            out_win[2 * pos] = in_win[2 * j];
-            out_win[2 * pos + 1] = in_win[2 * j + 1];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Level-1 compaction in ONE kernel (replaces k_scan_tiles + k_map<1> on the hot path): every workgroup owns a
+// Level-1 compaction in ONE kernel: every workgroup owns a
 // contiguous run of tiles, obtains the number of survivors before its run by reducing the (small, L2-resident)
 // per-tile count array itself - redundant across workgroups but far cheaper than a dependent scan launch -
 // scans its own tiles' counts in LDS, and expands its bitmap words into the index-ordered survivor list.
@@ -495,6 +392,73 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
         __syncthreads();
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) *total_out = base;  // every earlier workgroup's tiles precede this one's
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Level-2 compaction (after the lane-exact prefilter re-decided the filter's survivors), same scheme, one kernel:
+// here most items are kept, so the work is laid out per ITEM - the gathers of the kept items' haystack index and
+// window are coalesced - with the per-word offsets of a batch of tiles prepared once in LDS.
+// ---------------------------------------------------------------------------------------------------
+#define FZB_C2_BATCH 64  // tiles per batch: 64 x 16 word offsets in LDS
+__global__ __launch_bounds__(256) void k_compact2(const u64* __restrict__ bitmap, const u32* __restrict__ counts, const u32* __restrict__ n_items_ptr,
+                                                  const u32* __restrict__ in_idx, const u32* __restrict__ in_win, u32* __restrict__ out_idx, u32* __restrict__ out_win,
+                                                  u32* __restrict__ total_out) {
+    __shared__ u32 red[4];
+    __shared__ u32 pre[FZB_C2_BATCH];
+    __shared__ u32 woff[FZB_C2_BATCH * (FZB_TILE / 64)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 n_items = *n_items_ptr;
+    const u32 ntiles = (n_items + FZB_TILE - 1) / FZB_TILE;
+    const u32 T = (ntiles + gridDim.x - 1) / gridDim.x;
+    const u32 t0 = min(blockIdx.x * T, ntiles), t1 = min(t0 + T, ntiles);
+    u32 part = 0;
+    for (u32 i = tid; i < t0; i += 256) part += counts[i];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    u32 base = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    const u32 nwords = (n_items + 63) / 64;
+    for (u32 tb = t0; tb < t1; tb += FZB_C2_BATCH) {
+        const u32 nt = min((u32)FZB_C2_BATCH, t1 - tb);
+        // exclusive scan of the batch's tile counts (nt <= 64: one wave)
+        if (wave == 0) {
+            const u32 c = (u32)lane < nt ? counts[tb + lane] : 0u;
+            u32 incl = c;
+            for (int off = 1; off < 64; off <<= 1) {
+                const u32 v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if ((u32)lane < nt) pre[lane] = base + incl - c;
+            if (lane == 63) red[0] = incl;
+        }
+        // offset of every bitmap word inside its tile: 16-lane segmented scan of the popcounts
+        const u32 w0 = tb * (FZB_TILE / 64), w1 = (tb + nt) * (FZB_TILE / 64);
+        for (u32 wb0 = w0; wb0 < w1; wb0 += 256) {
+            const u32 w = wb0 + tid;
+            const u32 c = (w < w1 && w < nwords) ? (u32)__popcll(bitmap[w]) : 0u;
+            u32 incl = c;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const u32 v = __shfl_up(incl, off, 16);
+                if ((lane & 15) >= off) incl += v;
+            }
+            if (w < w1) woff[w - w0] = incl - c;
+        }
+        __syncthreads();
+        const u32 j0 = tb * FZB_TILE, j1 = min((tb + nt) * FZB_TILE, n_items);
+        for (u32 j = j0 + tid; j < j1; j += 256) {
+            const u32 w = j >> 6;
+            const u64 bits = bitmap[w];
+            if (!((bits >> (j & 63)) & 1)) continue;
+            const u32 pos = pre[j / FZB_TILE - tb] + woff[w - w0] + (u32)__popcll(bits & (((u64)1 << (j & 63)) - 1));
+            out_idx[pos] = in_idx ? in_idx[j] : j;
+            *(uint2*)(out_win + 2 * (size_t)pos) = *(const uint2*)(in_win + 2 * (size_t)j);
+        }
+        base += red[0];
+        __syncthreads();
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) *total_out = base;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -599,10 +563,6 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         }
         return;
     }
-    if (mode == 0) {
-        hipLaunchKernelGGL(k1_all_pass, dim3(grid), dim3(256), 0, st, count, min_len, bitmap, tile_counts);
-        return;
-    }
     const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
 #define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters)
     if (c.ends_u64) {
@@ -615,18 +575,11 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #undef FZB_K1
 }
 
-void fzb_launch_scan(const u32* counts, u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* total_out, const u32* base_in, u32* base_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, counts, prefix, n_items_ptr, n_items_host, total_out, base_in, base_out);
-}
-
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st) {
     hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, n_items_ptr, src, out_idx, total_out);
 }
 
-void fzb_launch_map(int level, const u64* bitmap, const u32* prefix, const u32* n_items_ptr, u32 n_items_host, u32* out_idx,
-                    const u32* in_idx, const u32* in_win, u32* out_win, int grid, hipStream_t st) {
-    if (level == 1)
-        hipLaunchKernelGGL((k_map<1>), dim3(grid), dim3(256), 0, st, bitmap, prefix, n_items_ptr, n_items_host, out_idx, in_idx, in_win, out_win);
-    else
-        hipLaunchKernelGGL((k_map<2>), dim3(grid), dim3(256), 0, st, bitmap, prefix, n_items_ptr, n_items_host, out_idx, in_idx, in_win, out_win);
+void fzb_launch_compact2(const u64* bitmap, const u32* counts, const u32* n_items_ptr, const u32* in_idx, const u32* in_win, u32* out_idx, u32* out_win, u32* total_out,
+                         int grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_compact2, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items_ptr, in_idx, in_win, out_idx, out_win, total_out);
 }
