@@ -105,7 +105,7 @@ class _CPattern(C.Structure):
 _lib = None
 
 SYMBOLS = [
-    "fzb_last_error", "fzb_config_default", "fzb_matcher_create", "fzb_matcher_clone", "fzb_matcher_free", "fzb_matcher_info",
+    "fzb_last_error", "fzb_config_default", "fzb_matcher_create", "fzb_matcher_clone", "fzb_matcher_free", "fzb_matcher_info", "fzb_matcher_set_pattern", "fzb_matcher_set_config",
     "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_set_max_len", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
     "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
@@ -126,6 +126,8 @@ def lib():
         l.fzb_matcher_create.argtypes = [C.POINTER(_CConfig), C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
         l.fzb_matcher_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         l.fzb_matcher_free.argtypes = [C.c_void_p]
+        l.fzb_matcher_set_pattern.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        l.fzb_matcher_set_config.argtypes = [C.c_void_p, C.POINTER(_CConfig)]
         l.fzb_matcher_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         l.fzb_corpus_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         l.fzb_corpus_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.POINTER(C.c_void_p)]
@@ -313,6 +315,18 @@ class Matcher:
         self.needle = n
         self.h = C.c_void_p()
         _check(lib().fzb_matcher_create(C.byref(c), n, len(n), C.byref(self.h)))
+
+    def set_pattern(self, needle):
+        """`Matcher::set_pattern` (src/matcher/mod.rs:154-165): same matcher, new needle; the device workspace is kept."""
+        n = _b(needle)
+        _check(lib().fzb_matcher_set_pattern(self.h, n, len(n)))
+        self.needle = n
+
+    def set_config(self, config):
+        """`Matcher::set_config` (src/matcher/mod.rs:143-152)"""
+        c = _c_config(config)
+        _check(lib().fzb_matcher_set_config(self.h, C.byref(c)))
+        self.config = config
 
     def info(self):
         out = (C.c_int32 * 6)()

@@ -80,6 +80,7 @@ struct Workspace {
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
     size_t cap_level2;  // capacity of the second-level arrays (0 = not allocated)
+    bool tables_stale;  // the matcher's needle / config changed since `table` and `dfa` were uploaded
 };
 
 struct LaunchCfg {

@@ -332,6 +332,47 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     return FZB_OK;
 }
 
+// `Matcher::set_pattern` / `Matcher::set_config` (src/matcher/mod.rs:154-176): the matcher is rebuilt for the new needle or config
+// exactly as fzb_matcher_create would build it, but keeps its device workspace (sized by the corpus, not by the needle), so a
+// re-query after every keystroke costs two small table uploads instead of a round of device allocations.
+static int rebuild_matcher(fzb_matcher* m, const fzb_config* config, const uint8_t* needle_utf8, size_t needle_len) {
+    fzb_matcher* fresh = nullptr;
+    int rc = fzb_matcher_create(config, needle_utf8, needle_len, &fresh);
+    if (rc) return rc;  // m is left as it was
+    // device-side state moves over to the rebuilt matcher ...
+    std::swap(fresh->ws, m->ws);
+    fresh->ws.tables_stale = true;
+    std::swap(fresh->out_dev, m->out_dev);
+    std::swap(fresh->out_cap, m->out_cap);
+    std::swap(fresh->count_dev, m->count_dev);
+    fresh->device = m->device;
+    fresh->lc.num_cus = m->lc.num_cus;
+    fresh->profiling = m->profiling;
+    fresh->prof_calls = m->prof_calls;
+    for (int i = 0; i < fzb_matcher::PROF_SLOTS; i++) {
+        for (int k = 0; k < 4; k++) std::swap(fresh->evring[i][k], m->evring[i][k]);
+        fresh->ev_filter[i] = m->ev_filter[i];
+    }
+    // ... and then the handle the caller holds takes the rebuilt matcher's place
+    std::swap(*fresh, *m);
+    fzb_matcher_free(fresh);
+    return FZB_OK;
+}
+
+int fzb_matcher_set_pattern(fzb_matcher* m, const uint8_t* needle_utf8, size_t needle_len) {
+    if (!m || (!needle_utf8 && needle_len)) return fail(FZB_ERR_INVALID, "null argument");
+    if (m->needle.size() == needle_len && (needle_len == 0 || memcmp(m->needle.data(), needle_utf8, needle_len) == 0)) return FZB_OK;  // "skipped if the pattern is the same"
+    const fzb_config cfg = m->config;
+    return rebuild_matcher(m, &cfg, needle_utf8, needle_len);
+}
+
+int fzb_matcher_set_config(fzb_matcher* m, const fzb_config* config) {
+    if (!m || !config) return fail(FZB_ERR_INVALID, "null argument");
+    if (memcmp(&m->config, config, sizeof(fzb_config)) == 0) return FZB_OK;
+    const std::string needle = m->needle;
+    return rebuild_matcher(m, config, (const uint8_t*)needle.data(), needle.size());
+}
+
 int fzb_matcher_clone(const fzb_matcher* src, fzb_matcher** out) {
     if (!src || !out) return fail(FZB_ERR_INVALID, "null argument");
     fzb_config cfg = src->config;
@@ -465,9 +506,14 @@ int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
 static int ensure_workspace(fzb_matcher* m, size_t count) {
     Workspace& w = m->ws;
     const bool need_l2 = !m->lc.filter_exact;
-    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && w.counters) return FZB_OK;
-    hipStream_t st = nullptr;
-    (void)st;
+    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && w.counters) {
+        if (w.tables_stale) {  // fzb_matcher_set_pattern / set_config kept the device buffers: only the two small tables change
+            HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
+            if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
+            w.tables_stale = false;
+        }
+        return FZB_OK;
+    }
     free_workspace(w);
     const size_t cap = count + count / 8 + 4096;
     const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 2;
@@ -478,7 +524,7 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     HIPCHK(dev_alloc((void**)&w.counters, 64));
     HIPCHK(dev_alloc((void**)&w.table, 256 * 8));
     HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
-    HIPCHK(dev_alloc((void**)&w.dfa, m->dfa.size() + 16));
+    HIPCHK(dev_alloc((void**)&w.dfa, (size_t)(FZB_MAX_ROWS + 2) * 256 + 16));  // room for any needle: set_pattern re-uploads in place
     if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
     w.cap_items = cap;
     if (need_l2) {
@@ -608,7 +654,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     const u32 qcap = cnt;  // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back
     const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
     if (nd.unicode && lc.bias_ok) {
-        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus * 8, st);
+        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
             fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, nullptr, cnt_c, cus * 2, st);

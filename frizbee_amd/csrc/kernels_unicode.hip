@@ -15,46 +15,87 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
     const u32 M = *n_items_ptr;
     const u32 base = base_ptr ? *base_ptr : 0u;
     if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = (base + M) < capacity ? (base + M) : capacity;
-    for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < M; j += gridDim.x * blockDim.x) {
-        if (base + j >= capacity) continue;
-        const u32 li = items ? items[j] : j;
-        u64 s;
-        u32 L;
-        haystack_span(ends, first + li, s, L);
-        const u8* hay = bytes + s;
-        u32 ws, we;
-        if (wmode == 2) { ws = 0; we = L; } else { ws = win[2 * j]; we = win[2 * j + 1]; }
-        const u32 sp = ws ? ws - 1 : 0;
-        const bool include_exact = sp == 0 && we == L;
-        const u32 m = we - sp;
-        if (m > (u32)SWL) {
-            const u32 slot = atomicAdd(&counters[4], 1u);
-            u32* qe = overflow + 4 * (size_t)(qcap - 1 - slot);  // back of the queue slice: consumed by the generic kernel
-            qe[0] = base + j;
-            qe[1] = ws;
-            qe[2] = we;
-            qe[3] = li;
-            continue;
+    // Persistent threads with the same three-deep software pipeline as k2b_dp over the dependent loads (item / window -> end
+    // offsets -> haystack bytes).  This kernel needs nearly the whole register file (one wave per SIMD), so no second wave covers
+    // a stall: the stages are requested one iteration ahead, and the haystack's first line is touched one iteration ahead so that
+    // the scorer's own byte loads find it in L2.
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    auto load_item = [&](u64 j, u32& li, u32& ws, u32& we) {
+        li = 0; ws = 0; we = 0;
+        if (j < M) {
+            li = items ? items[j] : (u32)j;
+            if (wmode != 2) { const uint2 w = *(const uint2*)(win + 2 * j); ws = w.x; we = w.y; }
         }
-        u32 score = 0;
-        if (m > 0 && nd.rows > 0) score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
-        bool exact = include_exact && m == (u32)nd.nbytes;
-        if (exact)
-            for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
-        if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
-        fzb_match_rec rec;
-        rec.index = index_offset + li;
-        rec.score = (u16)score;
-        rec.exact = exact ? 1 : 0;
-        rec.valid = 0;
-        out[base + j] = rec;
+    };
+    auto load_span = [&](u64 j, u32 li, u64& s, u32& L) {
+        s = 0; L = 0;
+        if (j < M) haystack_span(ends, first + li, s, L);
+    };
+    u32 li_c, ws_c, we_c, L_c, li_n, ws_n, we_n, L_n, li_m, ws_m, we_m;
+    u64 s_c, s_n;
+    load_item(j0, li_c, ws_c, we_c);
+    load_item(j0 + stride, li_n, ws_n, we_n);
+    load_item(j0 + 2 * stride, li_m, ws_m, we_m);
+    load_span(j0, li_c, s_c, L_c);
+    load_span(j0 + stride, li_n, s_n, L_n);
+    u32 warm = 0;
+    for (u64 j = j0; j < M; j += stride) {
+        u32 warm_n = 0;
+        if (L_n > 0) warm_n = *(const u32*)(bytes + s_n + (ws_n & ~3u));  // the next item's window start: brings its line(s) into L2
+        u64 s_m;
+        u32 L_m;
+        load_span(j + 2 * stride, li_m, s_m, L_m);
+        u32 li_f, ws_f, we_f;
+        load_item(j + 3 * stride, li_f, ws_f, we_f);
+        do {
+            if (base + j >= capacity) break;
+            const u32 li = li_c, L = L_c;
+            const u8* hay = bytes + s_c;
+            u32 ws = ws_c, we = we_c;
+            if (wmode == 2) { ws = 0; we = L; }
+            const u32 sp = ws ? ws - 1 : 0;
+            const bool include_exact = sp == 0 && we == L;
+            const u32 m = we - sp;
+            if (m > (u32)SWL) {
+                const u32 slot = atomicAdd(&counters[4], 1u);
+                u32* qe = overflow + 4 * (size_t)(qcap - 1 - slot);  // back of the queue slice: consumed by the generic kernel
+                qe[0] = base + (u32)j;
+                qe[1] = ws;
+                qe[2] = we;
+                qe[3] = li;
+                break;
+            }
+            u32 score = 0;
+            if (m > 0 && nd.rows > 0) score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
+            bool exact = include_exact && m == (u32)nd.nbytes;
+            if (exact)
+                for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+            if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+            fzb_match_rec rec;
+            rec.index = index_offset + li;
+            rec.score = (u16)(score + (warm & 0u));  // keeps the warm-up load of the previous iteration alive until here
+            rec.exact = exact ? 1 : 0;
+            rec.valid = 0;
+            out[base + j] = rec;
+        } while (0);
+        li_c = li_n; ws_c = ws_n; we_c = we_n; s_c = s_n; L_c = L_n;
+        li_n = li_m; ws_n = ws_m; we_n = we_m; s_n = s_m; L_n = L_m;
+        li_m = li_f; ws_m = ws_f; we_m = we_f;
+        warm = warm_n;
     }
 }
 
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
                            int grid, hipStream_t st) {
-#define FZB_K2U(SWL, ET) hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, base_ptr, dev_count, overflow, qcap, counters)
+    // `grid` = number of CUs: the kernel is persistent, launch exactly the resident workgroups
+#define FZB_K2U(SWL, ET)                                                                                                               \
+    do {                                                                                                                               \
+        static int per_cu = 0;                                                                                                         \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
+        hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, base_ptr, dev_count, overflow, qcap, counters); \
+    } while (0)
 #define FZB_K2U_ET(SWL) do { if (c.ends_u64) FZB_K2U(SWL, u64); else FZB_K2U(SWL, u32); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2U_ET(64); break;

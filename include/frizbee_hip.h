@@ -83,6 +83,11 @@ void fzb_config_default(fzb_config* out);
  * device-side needle tables.  An empty needle is valid (matches everything with score 0, mod.rs:381-384). */
 int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, size_t needle_len, fzb_matcher** out);
 int fzb_matcher_clone(const fzb_matcher* m, fzb_matcher** out); /* `impl Clone for Matcher` (parallel.rs:46) */
+/* `Matcher::set_pattern` / `Matcher::set_config` (src/matcher/mod.rs:154-176): rebuild for a new needle / config; no-ops when nothing
+ * changed.  The device workspace (sized by the corpus) is kept: re-querying a resident corpus after every keystroke allocates nothing.
+ * On error the matcher is left unchanged. */
+int fzb_matcher_set_pattern(fzb_matcher* m, const uint8_t* needle_utf8, size_t needle_len);
+int fzb_matcher_set_config(fzb_matcher* m, const fzb_config* config);
 void fzb_matcher_free(fzb_matcher* m);
 /* introspection: out[0]=pf_lanes out[1]=sw_lanes out[2]=u8 class? out[3]=case_sensitive out[4]=unicode path? out[5]=rows */
 int fzb_matcher_info(const fzb_matcher* m, int32_t out[6]);

@@ -68,3 +68,24 @@ def test_tiny_lists():
             got = F.Matcher("deadbe", F.Config(max_typos=typos, pf_lanes=64)).match_list(hs)
             assert got.tolist() == want.tolist(), (hs, typos)
         assert F.MultiMatcher(F.parse_query("dead !x"), F.Config(pf_lanes=64)).match_list(hs).tolist() == O.MultiMatcher(O.parse_query("dead !x")).match_list(hs).tolist()
+
+
+def test_set_pattern_and_set_config_requery_a_resident_corpus():
+    # Matcher::set_pattern / set_config (src/matcher/mod.rs:143-176): typing "deadbeef" one key at a time against one resident list
+    rows, ends = synth.fixed_corpus(b"deadbeef", 200_000, 32)
+    data = rows.numpy().reshape(-1)
+    cp = F.Corpus(packed=(data, ends))
+    odata = np.concatenate([data, np.zeros(64, np.uint8)])
+    m = F.Matcher("d", F.Config(pf_lanes=64))
+    for needle in ("d", "de", "dea", "dead", "deadb", "deadbe", "deadbee", "deadbeef", "Dead", "é", ""):
+        m.set_pattern(needle)
+        assert m.match_list(cp).tolist() == O.Matcher(needle).match_packed(odata, ends).tolist(), needle
+    m.set_pattern("deadbe")
+    for cfg, ocfg in ((F.Config(max_typos=2, pf_lanes=64), dict(max_typos=2)), (F.Config(max_typos=None, sort=F.SortStrategy.IndexDesc, pf_lanes=64), dict(max_typos=None, sort="IndexDesc")),
+                      (F.Config(matching=F.Matching.Substring, pf_lanes=64), dict(matching="Substring")), (F.Config(pf_lanes=16), dict())):
+        m.set_config(cfg)
+        lanes = (16, 16, 8) if cfg.pf_lanes == 16 else (64, 64, 32)
+        assert m.match_list(cp).tolist() == O.Matcher("deadbe", lanes=lanes, **ocfg).match_packed(odata, ends).tolist(), ocfg
+    with pytest.raises(F.FrizbeeError):
+        m.set_pattern("a" * 65)  # refused: the matcher keeps working as it was
+    assert m.match_list(cp).tolist() == O.Matcher("deadbe", lanes=(16, 16, 8)).match_packed(odata, ends).tolist()
