@@ -24,3 +24,16 @@ __device__ __forceinline__ u32 load_u32_unaligned(const u8* __restrict__ base, u
     u32 lo = a[0], hi = a[1];
     return __builtin_amdgcn_alignbyte(hi, lo, (u32)(p & 3));
 }
+
+// Queue slots for the lanes of a wave that want one: ONE atomic per wave instead of one per lane.  Every currently active
+// lane must call it (with its own flag); the returned slot is meaningful where `want` is true.
+__device__ __forceinline__ u32 wave_alloc(u32* counter, bool want) {
+    const u64 mask = __ballot(want);
+    u32 base = 0;
+    if (mask) {
+        const int leader = __builtin_ctzll(mask);
+        if (lane_id() == leader) base = atomicAdd(counter, (u32)__popcll(mask));
+        base = __shfl(base, leader);
+    }
+    return base + (u32)__popcll(mask & (((u64)1 << lane_id()) - 1));
+}

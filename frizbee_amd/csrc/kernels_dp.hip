@@ -86,17 +86,13 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
             const u32 sp = ws ? ws - 1 : 0;
             const bool include_exact = sp == 0 && we == L;
             const u32 m = we - sp;
-            if (m > (u32)SWL) {
-                // wider than one chunk: queued for the multi-chunk kernel (counters[3], front of `overflow`), or - beyond the
-                // reference's 1024-byte matrix limit - for the generic kernel's greedy scorer (counters[4], back of `overflow`)
-                u32* qe;
-                if (m > FZB_MAX_HAYSTACK_LEN) {
-                    const u32 slot = atomicAdd(&counters[4], 1u);
-                    qe = overflow + 4 * (size_t)(qcap - 1 - slot);
-                } else {
-                    const u32 slot = atomicAdd(&counters[3], 1u);
-                    qe = overflow + 4 * (size_t)slot;
-                }
+            // wider than one chunk: queued for the multi-chunk kernel (counters[3], front of `overflow`), or - beyond the
+            // reference's 1024-byte matrix limit - for the generic kernel's greedy scorer (counters[4], back of `overflow`)
+            const bool wide = m > (u32)SWL, greedy = m > FZB_MAX_HAYSTACK_LEN;
+            const u32 slot_multi = wave_alloc(&counters[3], wide && !greedy);
+            const u32 slot_greedy = wave_alloc(&counters[4], greedy);
+            if (wide) {
+                u32* qe = greedy ? overflow + 4 * (size_t)(qcap - 1 - slot_greedy) : overflow + 4 * (size_t)slot_multi;
                 qe[0] = base + (u32)j;  // (output position, window start, window end, local haystack index)
                 qe[1] = ws;
                 qe[2] = we;
