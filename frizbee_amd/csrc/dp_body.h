@@ -1,6 +1,5 @@
-// Thread-per-haystack single-chunk Smith-Waterman body shared by the standalone DP kernel (kernels_dp.hip) and the
-// fused filter+score kernel (kernels_fused.hip).  See kernels_dp.hip for the reference mapping and DESIGN.md for the
-// biased-domain gap propagation.
+// Thread-per-haystack Smith-Waterman bodies of the DP kernels (kernels_dp.hip): single chunk and chunk-by-chunk.
+// See kernels_dp.hip for the reference mapping and DESIGN.md for the biased-domain gap propagation.
 #pragma once
 #include "kernels_common.h"
 

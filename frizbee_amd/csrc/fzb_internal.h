@@ -109,12 +109,12 @@ void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const
                        u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st);
 // kernels_dp.hip
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st);
+                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st);
 void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_unicode.hip
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                           int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
+                           int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
                            int grid, hipStream_t st);
 // kernels_sort.hip
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st);
@@ -132,5 +132,5 @@ void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, c
                               u32 capacity, u32* dev_count, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
-                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st);
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st);
 #endif

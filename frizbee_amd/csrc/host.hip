@@ -654,17 +654,17 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     const u32 qcap = cnt;  // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back
     const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
     if (nd.unicode && lc.bias_ok) {
-        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus, st);
+        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
-            fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, nullptr, cnt_c, cus * 2, st);
+            fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * 2, st);
             FZB_STAGE("generic(unicode, queued)");
         }
     } else if (nd.unicode) {
-        fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, nullptr, dev_count, cnt_c, cus * 4, st);
+        fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, cnt_c, cus * 4, st);
         FZB_STAGE("generic(unicode)");
     } else {
-        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, nullptr, dev_count, w.overflow, qcap, cnt_c, cus, st);
+        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
         if (!no_wide) {
             const int mgrid = cus * 4;  // 2 waves per SIMD (the kernel is capped at 256 VGPRs)
@@ -679,7 +679,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, lc.bias_ok, outp, cap32, w.dp_scratch, mgrid, st);
             FZB_STAGE("dp_multi");
             if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
-                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, nullptr, cnt_c,
+                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, cnt_c,
                                    cus / 4 + 1, st);
                 FZB_STAGE("generic(greedy)");
             }

@@ -19,14 +19,13 @@
 template <int SWL, bool BIAS, bool UPPER, typename ET>
 __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                               const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
-                                              const NeedleDev nd, int wmode, int pad_ok, fzb_match_rec* __restrict__ out, u32 capacity, const u32* __restrict__ base_ptr, u32* __restrict__ dev_count,
+                                              const NeedleDev nd, int wmode, int pad_ok, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count,
                                               u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters) {
     __shared__ u8 cls[256];
     build_cls_table(cls);
     __syncthreads();
     const u32 M = *n_items_ptr;
-    const u32 base = base_ptr ? *base_ptr : 0u;  // records of earlier chunks precede this chunk's
-    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = (base + M) < capacity ? (base + M) : capacity;
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
     // Persistent threads with a three-deep software pipeline over the dependent loads of one item
     // (survivor index / window -> end offsets -> haystack vectors): each stage is requested one iteration before it is
     // needed, so the ~7 us of integer DP of the current item cover the latency and only the prologue waits on memory.
@@ -72,7 +71,7 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
         load_item(j + 3 * stride, li_f, ws_f, we_f);
         // ---- this iteration's item ----------------------------------------------------------------------
         do {
-            if (base + j >= capacity) break;
+            if (j >= capacity) break;
             const u32 li = li_c, L = L_c;
             const u8* hay = bytes + s_c;
             const bool inreg = __all((int)(L <= 32));  // wave-uniform: the two prefetched vectors hold every haystack of the wave
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
             const u32 slot_greedy = wave_alloc(&counters[4], greedy);
             if (wide) {
                 u32* qe = greedy ? overflow + 4 * (size_t)(qcap - 1 - slot_greedy) : overflow + 4 * (size_t)slot_multi;
-                qe[0] = base + (u32)j;  // (output position, window start, window end, local haystack index)
+                qe[0] = (u32)j;  // (output position, window start, window end, local haystack index)
                 qe[1] = ws;
                 qe[2] = we;
                 qe[3] = li;
@@ -118,7 +117,7 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
             rec.score = (u16)score;
             rec.exact = exact ? 1 : 0;
             rec.valid = 0;
-            out[base + j] = rec;
+            out[j] = rec;
         } while (0);
         // ---- rotate the pipeline ------------------------------------------------------------------------
         li_c = li_n; ws_c = ws_n; we_c = we_n; s_c = s_n; L_c = L_n; q0_c = q0_n; q1_c = q1_n;
@@ -177,7 +176,7 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
 }
 
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st) {
+                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st) {
     bool upper = false;  // an uppercase letter among the needle bytes as they are compared
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     // the kernel is persistent: launch exactly the workgroups that are resident at once
@@ -185,7 +184,7 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
     do {                                                                                                                                \
         static int per_cu = 0;                                                                                                          \
         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp<SWL, B, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
-        hipLaunchKernelGGL((k2b_dp<SWL, B, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, base_ptr, dev_count, overflow, qcap, counters); \
+        hipLaunchKernelGGL((k2b_dp<SWL, B, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, dev_count, overflow, qcap, counters); \
     } while (0)
 #define FZB_K2B_ET(SWL, B, U) do { if (c.ends_u64) FZB_K2B(SWL, B, U, u64); else FZB_K2B(SWL, B, U, u32); } while (0)
 #define FZB_K2B_U(SWL, B) do { if (upper) FZB_K2B_ET(SWL, B, true); else FZB_K2B_ET(SWL, B, false); } while (0)

@@ -540,7 +540,7 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 }
 
 // ---------------------------------------------------------------------------------------------------
-// host-side launch wrappers (called from pipeline.hip)
+// host-side launch wrappers (called from host.hip)
 // ---------------------------------------------------------------------------------------------------
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st) {

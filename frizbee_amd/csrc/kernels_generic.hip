@@ -80,15 +80,14 @@ template <int SWL, bool UNICODE, typename ET>
 __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                               const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
                                                               const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
-                                                              fzb_match_rec* __restrict__ out, u32 capacity, const u32* __restrict__ base_ptr, u32* __restrict__ dev_count, u32* __restrict__ counters) {
+                                                              fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters) {
     // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row
     __shared__ u16 s_adj_row[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
     __shared__ u16 s_adj_aux[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
     const int lane = lane_id();
     const int wv = threadIdx.x >> 6;
     const u32 nlist = *n_list_ptr;
-    const u32 base = (!list && base_ptr) ? *base_ptr : 0u;  // list entries already carry absolute output positions
-    if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = (base + nlist) < capacity ? (base + nlist) : capacity;
+    if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = nlist < capacity ? nlist : capacity;
     const u32 LM = (u32)nd.lane_mask;
     const u32 rows = (u32)nd.rows;
     const u32 Mc = nd.match_plus_mismatch & LM, X = nd.mismatch & LM, gex = nd.gex & LM, gopm = nd.gopm & LM;
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
         // list mode: the queue grows downwards from `list` (the end of the chunk's queue slice): entry q is at list - 4 (q + 1)
         const u32* le = list ? list - 4 * (size_t)(q + 1) : nullptr;
         const u32 j = list ? le[0] : q;          // rank inside this chunk (direct mode) / absolute output position (list mode)
-        const u32 opos = list ? j : base + j;
+        const u32 opos = j;
         if (opos >= capacity) continue;
         const u32 li = list ? le[3] : (items ? items[j] : j);
         u64 s;
@@ -276,8 +275,8 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
 }
 
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
-                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, base_ptr, dev_count, counters)
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st) {
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters)
 #define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
 #define FZB_K2C_U(SWL) do { if (unicode) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
     switch (sw_lanes) {

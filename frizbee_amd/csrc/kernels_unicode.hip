@@ -7,14 +7,13 @@ template <int SWL, typename ET>
 __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                       const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                       const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                      const u32* __restrict__ base_ptr, u32* __restrict__ dev_count, u32* __restrict__ overflow, u32 qcap,
+                                                      u32* __restrict__ dev_count, u32* __restrict__ overflow, u32 qcap,
                                                       u32* __restrict__ counters) {
     __shared__ u8 cls[256];
     build_cls_table(cls);
     __syncthreads();
     const u32 M = *n_items_ptr;
-    const u32 base = base_ptr ? *base_ptr : 0u;
-    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = (base + M) < capacity ? (base + M) : capacity;
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
     // Persistent threads with the same three-deep software pipeline as k2b_dp over the dependent loads (item / window -> end
     // offsets -> haystack bytes).  This kernel needs nearly the whole register file (one wave per SIMD), so no second wave covers
     // a stall: the stages are requested one iteration ahead, and the haystack's first line is touched one iteration ahead so that
@@ -49,7 +48,7 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
         u32 li_f, ws_f, we_f;
         load_item(j + 3 * stride, li_f, ws_f, we_f);
         do {
-            if (base + j >= capacity) break;
+            if (j >= capacity) break;
             const u32 li = li_c, L = L_c;
             const u8* hay = bytes + s_c;
             u32 ws = ws_c, we = we_c;
@@ -60,7 +59,7 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
             if (m > (u32)SWL) {
                 const u32 slot = atomicAdd(&counters[4], 1u);
                 u32* qe = overflow + 4 * (size_t)(qcap - 1 - slot);  // back of the queue slice: consumed by the generic kernel
-                qe[0] = base + (u32)j;
+                qe[0] = (u32)j;
                 qe[1] = ws;
                 qe[2] = we;
                 qe[3] = li;
@@ -77,7 +76,7 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
             rec.score = (u16)(score + (warm & 0u));  // keeps the warm-up load of the previous iteration alive until here
             rec.exact = exact ? 1 : 0;
             rec.valid = 0;
-            out[base + j] = rec;
+            out[j] = rec;
         } while (0);
         li_c = li_n; ws_c = ws_n; we_c = we_n; s_c = s_n; L_c = L_n;
         li_n = li_m; ws_n = ws_m; we_n = we_m; s_n = s_m; L_n = L_m;
@@ -87,14 +86,14 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
 }
 
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                           int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, const u32* base_ptr, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
+                           int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
                            int grid, hipStream_t st) {
     // `grid` = number of CUs: the kernel is persistent, launch exactly the resident workgroups
 #define FZB_K2U(SWL, ET)                                                                                                               \
     do {                                                                                                                               \
         static int per_cu = 0;                                                                                                         \
         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
-        hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, base_ptr, dev_count, overflow, qcap, counters); \
+        hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters); \
     } while (0)
 #define FZB_K2U_ET(SWL) do { if (c.ends_u64) FZB_K2U(SWL, u64); else FZB_K2U(SWL, u32); } while (0)
     switch (sw_lanes) {
