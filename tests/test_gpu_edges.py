@@ -89,3 +89,38 @@ def test_set_pattern_and_set_config_requery_a_resident_corpus():
     with pytest.raises(F.FrizbeeError):
         m.set_pattern("a" * 65)  # refused: the matcher keeps working as it was
     assert m.match_list(cp).tolist() == O.Matcher("deadbe", lanes=(16, 16, 8)).match_packed(odata, ends).tolist()
+
+
+def test_corpus_beyond_4_gib_uses_64_bit_offsets():
+    # 41 M haystacks of 112 bytes = 4.59 GB: end offsets and byte addresses no longer fit 32 bits.  Built on the device
+    # (padded-16 layout = back-to-back rows since 112 % 16 == 0); checked against the oracle on three windows of the list,
+    # one of them entirely above the 4 GiB line, through sub-range calls and through the whole-list call.
+    dev = torch.device("cuda", 0)
+    n, L = 41_000_000, 112
+    needle = b"deadbeef"
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    flat = torch.empty(n * L + 256, dtype=torch.uint8, device=dev)
+    alpha = torch.tensor(list(b"abcdefghijklmnopqrstuvwxyz_-/0123456789"), dtype=torch.uint8, device=dev)
+    step = 1_000_000
+    for lo in range(0, n, step):
+        hi = min(lo + step, n)
+        idx = torch.randint(0, len(alpha), ((hi - lo) * L,), generator=g, device=dev)
+        flat[lo * L : hi * L] = alpha[idx]
+    flat[n * L :] = 0
+    ends = torch.arange(1, n + 1, dtype=torch.int64, device=dev) * L
+    assert int(ends[-1].item()) > (1 << 32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), ends_are_u64=True, keep=(flat, ends))
+    m = F.Matcher(needle.decode(), F.Config(max_typos=1, sort=F.SortStrategy.IndexAsc, pf_lanes=64, sw_lanes=64))
+    om = O.Matcher(needle.decode(), max_typos=1, sort="IndexAsc")
+    whole = m.match_list(cp)
+    assert len(whole) > 1000
+    for first in (0, 38_347_000, n - 200_000):  # 38_347_922 * 112 = 2^32: the second window straddles the line
+        cnt = 200_000
+        host = flat[first * L : (first + cnt) * L].cpu().numpy()
+        want = om.match_packed(np.concatenate([host, np.zeros(64, np.uint8)]), np.arange(1, cnt + 1, dtype=np.uint64) * np.uint64(L))
+        got = m.match_list_into(cp, first=first, count=cnt, index_offset=0)
+        assert got.tolist() == want.tolist(), first
+        sl = whole[(whole["index"] >= first) & (whole["index"] < first + cnt)].copy()
+        sl["index"] -= first
+        assert sl.tolist() == want.tolist(), first
