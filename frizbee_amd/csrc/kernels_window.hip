@@ -114,33 +114,34 @@ struct UnicodeSrc {
     const u8* hay;
     u32 len;
     u32 start;
-    Chunk<PFL> ch[4];  // windows at start+0 .. start+3
-    __device__ UnicodeSrc(const NeedleDev& n, const u8* h, u32 l) : nd(n), hay(h), len(l), start(0) {}
+    Chunk<PFL> w0;  // window at start+0
+    u32 guard;      // the 4 bytes after it: the windows at start+1 .. start+3 are byte shifts of (w0, guard), formed on demand
+                    // (keeping four chunks and indexing them with a per-thread scalar length put the whole set into scratch memory)
+    __device__ UnicodeSrc(const NeedleDev& n, const u8* h, u32 l) : nd(n), hay(h), len(l), start(0), guard(0) {}
     __device__ __forceinline__ void load(u32 s) {
         start = s;
-        // one pass over memory: the window at +0 plus one guard dword; the +1..+3 windows are byte-shifts of it
-        load_chunk<PFL>(ch[0], hay, s, len);
-        u32 guard = 0;
-        {
-            const u32 p = s + PFL;
-            if (p < len) {
-                guard = load_u32_unaligned(hay, p);
-                if (len - p < 4) guard &= (1u << (8 * (len - p))) - 1;
-            }
+        load_chunk<PFL>(w0, hay, s, len);
+        guard = 0;
+        const u32 p = s + PFL;
+        if (p < len) {
+            guard = load_u32_unaligned(hay, p);
+            if (len - p < 4) guard &= (1u << (8 * (len - p))) - 1;
         }
+    }
+    // window at start + o, o in 0..3 (v_alignbyte_b32 takes the shift from a register)
+    __device__ __forceinline__ Chunk<PFL> at(u32 o) const {
+        Chunk<PFL> r;
 #pragma unroll
-        for (int o = 1; o < 4; o++)
-#pragma unroll
-            for (int k = 0; k < Chunk<PFL>::NW; k++)
-                ch[o].w[k] = __builtin_amdgcn_alignbyte(k + 1 < Chunk<PFL>::NW ? ch[0].w[k + 1] : guard, ch[0].w[k], o);
+        for (int k = 0; k < Chunk<PFL>::NW; k++) r.w[k] = __builtin_amdgcn_alignbyte(k + 1 < Chunk<PFL>::NW ? w0.w[k + 1] : guard, w0.w[k], o);
+        return r;
     }
     // match_unicode_char_prefix + char_variant_mask (unicode.rs:9-72) for one case variant
     __device__ __forceinline__ u64 variant(const u8 chars[4], u32 cl, u64 chunk_mask) const {
-        u64 m = eq_mask<PFL>(ch[cl - 1], chars[cl - 1]) & chunk_mask;
+        u64 m = eq_mask<PFL>(at(cl - 1), chars[cl - 1]) & chunk_mask;
         if (m != 0 && cl > 1) {
-            m &= eq_mask<PFL>(ch[0], chars[0]);
-            if (cl > 2) m &= eq_mask<PFL>(ch[1], chars[1]);
-            if (cl > 3) m &= eq_mask<PFL>(ch[2], chars[2]);
+            m &= eq_mask<PFL>(at(0), chars[0]);
+            if (cl > 2) m &= eq_mask<PFL>(at(1), chars[1]);
+            if (cl > 3) m &= eq_mask<PFL>(at(2), chars[2]);
         }
         return m;
     }
@@ -359,11 +360,11 @@ __device__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL>& src, u32 row, u32 sub
         sub.load(start);
         // load_window(start + cl - 1): valid lanes are those whose last byte lies inside the haystack
         const u64 valid = m_first_n<PFL>(len - (start + cl - 1));
-        u64 mask = (eq_mask<PFL>(sub.ch[cl - 1], nd.uc[row][cl - 1]) | eq_mask<PFL>(sub.ch[cl - 1], nd.uf[row][cl - 1])) & valid;
+        u64 mask = (eq_mask<PFL>(sub.at(cl - 1), nd.uc[row][cl - 1]) | eq_mask<PFL>(sub.at(cl - 1), nd.uf[row][cl - 1])) & valid;
         if (mask != 0 && cl > 1) {
-            u64 pa = eq_mask<PFL>(sub.ch[0], nd.uc[row][0]), pb = eq_mask<PFL>(sub.ch[0], nd.uf[row][0]);
-            if (cl > 2) { pa &= eq_mask<PFL>(sub.ch[1], nd.uc[row][1]); pb &= eq_mask<PFL>(sub.ch[1], nd.uf[row][1]); }
-            if (cl > 3) { pa &= eq_mask<PFL>(sub.ch[2], nd.uc[row][2]); pb &= eq_mask<PFL>(sub.ch[2], nd.uf[row][2]); }
+            u64 pa = eq_mask<PFL>(sub.at(0), nd.uc[row][0]), pb = eq_mask<PFL>(sub.at(0), nd.uf[row][0]);
+            if (cl > 2) { pa &= eq_mask<PFL>(sub.at(1), nd.uc[row][1]); pb &= eq_mask<PFL>(sub.at(1), nd.uf[row][1]); }
+            if (cl > 3) { pa &= eq_mask<PFL>(sub.at(2), nd.uc[row][2]); pb &= eq_mask<PFL>(sub.at(2), nd.uf[row][2]); }
             mask &= (pa | pb);
         }
         if (mask != 0) return start + PFL - m_lz<PFL>(mask) + cl - 1;
@@ -394,17 +395,17 @@ __device__ Win prefilter_unicode_0(UnicodeSrc<PFL>& src) {
             u64 mask;
             {
                 // char_variant_mask with chunk = window at start+char_len-1, prefixes for a scalar of ncl bytes
-                u64 a = eq_mask<PFL>(src.ch[char_len - 1], nd.uc[row][ncl - 1]) & chunk_mask;
+                u64 a = eq_mask<PFL>(src.at(char_len - 1), nd.uc[row][ncl - 1]) & chunk_mask;
                 if (a != 0 && ncl > 1) {
-                    a &= eq_mask<PFL>(src.ch[0], nd.uc[row][0]);
-                    if (ncl > 2) a &= eq_mask<PFL>(src.ch[1], nd.uc[row][1]);
-                    if (ncl > 3) a &= eq_mask<PFL>(src.ch[2], nd.uc[row][2]);
+                    a &= eq_mask<PFL>(src.at(0), nd.uc[row][0]);
+                    if (ncl > 2) a &= eq_mask<PFL>(src.at(1), nd.uc[row][1]);
+                    if (ncl > 3) a &= eq_mask<PFL>(src.at(2), nd.uc[row][2]);
                 }
-                u64 b = eq_mask<PFL>(src.ch[char_len - 1], nd.uf[row][ncl - 1]) & chunk_mask;
+                u64 b = eq_mask<PFL>(src.at(char_len - 1), nd.uf[row][ncl - 1]) & chunk_mask;
                 if (b != 0 && ncl > 1) {
-                    b &= eq_mask<PFL>(src.ch[0], nd.uf[row][0]);
-                    if (ncl > 2) b &= eq_mask<PFL>(src.ch[1], nd.uf[row][1]);
-                    if (ncl > 3) b &= eq_mask<PFL>(src.ch[2], nd.uf[row][2]);
+                    b &= eq_mask<PFL>(src.at(0), nd.uf[row][0]);
+                    if (ncl > 2) b &= eq_mask<PFL>(src.at(1), nd.uf[row][1]);
+                    if (ncl > 3) b &= eq_mask<PFL>(src.at(2), nd.uf[row][2]);
                 }
                 mask = a | b;
             }
