@@ -22,18 +22,25 @@ __device__ __forceinline__ u32 p_neg_mask(u32 neg) {  // per 16-bit lane: 0xFFFF
 // 0x80 in every byte of x that is zero (exact)
 __device__ __forceinline__ u32 zflag4(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }
 
-template <int SWL>
+// REAL = packed dwords (2 lanes each) that may hold haystack bytes: the caller guarantees m <= 2 * REAL.  Lanes at or past m are
+// not valid, so they are never scalar starts: diag / up are masked to 0 there, their match / pending masks are 0, the prefix count
+// Q stays at its final value and a hop from padding to padding crosses no scalar start (no gap-open charge, pending irrelevant).
+// They still receive row values through the gap scan and enter the final max, so they are computed - but only the score row,
+// which is what REAL < NW saves in registers (no Q / bonus / pending / up-mask entries for them) and instructions.
+template <int SWL, int REAL = SWL / 2>
 __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls) {
     constexpr int NW = SWL / 2;
     constexpr int NB = SWL / 4;
+    constexpr int RB = (REAL + 1) / 2;  // byte dwords that may hold haystack bytes
+    static_assert(REAL >= 1 && REAL <= NW, "REAL");
     const u32 rows = (u32)nd.rows;
     const u32 ONE = 0x00010001u;
     const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
     const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
     // ---- bytes (+1 guard dword of zeros for the shifted views) ----
-    u32 hb[NB + 1];
+    u32 hb[RB + 1];
 #pragma unroll
-    for (int k = 0; k < NB; k++) {
+    for (int k = 0; k < RB; k++) {
         const u32 p = 4 * k;
         u32 v = 0;
         if (p < m) {
@@ -43,14 +50,15 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
         }
         hb[k] = v;
     }
-    hb[NB] = 0;
+    hb[RB] = 0;
     // ---- per-byte scalar-start flags (0x80 where valid && !continuation), prefix counts Q, bonus ----
-    u32 Q[NW], bonus[NW];
+    u32 Q[2 * RB], bonus[2 * RB];
+    u32 qtotv;  // the final count in both halves: Q of every padding dword
     {
         u32 clsw_prev = 0;
         u32 qrun = 0;  // running count, replicated in both halves
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
+        for (int k = 0; k < RB; k++) {
             const u32 w = hb[k];
             // continuation byte: 0x80..0xBF  <=>  (b & 0xC0) == 0x80
             const u32 contf = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u);
@@ -80,16 +88,20 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
             }
         }
         if (include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
+        qtotv = qrun | (qrun << 16);
     }
+    auto Qof = [&](int d) { return d < 2 * RB ? Q[d < 2 * RB ? d : 0] : qtotv; };
     const u32 mv = splat16(m);
     // P[d] = gex * (Q[d] + #padding lanes up to and including the lane) ; padding lanes are non-continuation lanes too
     auto Pof = [&](int d) {
         const u32 lanepos1 = (u32)(2 * d + 1) | ((u32)(2 * d + 2) << 16);
-        return p_mul(p_add(Q[d], p_subs(lanepos1, mv)), gexv);
+        return p_mul(p_add(Qof(d), p_subs(lanepos1, mv)), gexv);
     };
-    u32 prev[NW], upm[NW];
+    u32 prev[NW], upm[2 * RB];
 #pragma unroll
-    for (int d = 0; d < NW; d++) prev[d] = 0, upm[d] = 0;
+    for (int d = 0; d < NW; d++) prev[d] = 0;
+#pragma unroll
+    for (int d = 0; d < 2 * RB; d++) upm[d] = 0;
 #pragma unroll 1
     for (u32 r = 0; r < rows; r++) {
         const u32 cl = nd.ulen[r];
@@ -97,9 +109,11 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
         const u8* uf = nd.uf[r];
         const bool two = (uc[0] != uf[0]) || (uc[1] != uf[1]) || (uc[2] != uf[2]) || (uc[3] != uf[3]);
         // ---- byte-level match flags: scalar start && bytes [L, L+cl) equal the needle scalar (unicode.rs:221-241) ----
-        u32 row[NW], pend[NW];
+        u32 row[NW], pend[2 * RB];
 #pragma unroll
-        for (int k = 0; k < NB; k++) {
+        for (int d = 2 * RB; d < NW; d++) row[d] = 0;  // padding dwords: diag / up are masked to scalar-start lanes, and there are none
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
             const u32 w0 = hb[k];
             const u32 w1 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 1);
             const u32 w2 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 2);
@@ -148,19 +162,27 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
 #pragma unroll
         for (int d = NW - 1; d >= 0; d--) {
             const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : 0u, 16);
-            const u32 ps = __builtin_amdgcn_alignbit(pend[d], d ? pend[d - 1] : 0u, 16);
-            const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : 0u, 16);
-            const u32 fl = p_neg_mask(p_sub(qs, Q[d]));  // a scalar start lies in (L-1, L]
-            row[d] = p_max(row[d], p_subs(bs, ps & fl & gopmv));
-            pend[d] = pend[d] | (ps & ~fl);
+            if (d <= 2 * RB) {  // a source lane (2d-1 or 2d) may be a real lane
+                const u32 ps = __builtin_amdgcn_alignbit(d < 2 * RB ? pend[d < 2 * RB ? d : 0] : 0u, (d && d - 1 < 2 * RB) ? pend[d ? d - 1 : 0] : 0u, 16);
+                const u32 qs = __builtin_amdgcn_alignbit(Qof(d), d ? Qof(d - 1) : 0u, 16);
+                const u32 fl = p_neg_mask(p_sub(qs, Qof(d)));  // a scalar start lies in (L-1, L]
+                row[d] = p_max(row[d], p_subs(bs, ps & fl & gopmv));
+                if (d < 2 * RB) pend[d] = pend[d] | (ps & ~fl);
+            } else {
+                row[d] = p_max(row[d], bs);  // padding -> padding: no scalar start crossed, nothing pending can be charged
+            }
         }
 #pragma unroll
         for (int off = 1; off < NW; off *= 2) {
 #pragma unroll
             for (int d = NW - 1; d >= off; d--) {
-                const u32 fl = p_neg_mask(p_sub(Q[d - off], Q[d]));
-                row[d] = p_max(row[d], p_subs(row[d - off], pend[d - off] & fl & gopmv));
-                pend[d] = pend[d] | (pend[d - off] & ~fl);
+                if (d - off < 2 * RB) {
+                    const u32 fl = p_neg_mask(p_sub(Q[d - off < 2 * RB ? d - off : 0], Qof(d)));
+                    row[d] = p_max(row[d], p_subs(row[d - off], pend[d - off < 2 * RB ? d - off : 0] & fl & gopmv));
+                    if (d < 2 * RB) pend[d] = pend[d] | (pend[d - off < 2 * RB ? d - off : 0] & ~fl);
+                } else {
+                    row[d] = p_max(row[d], row[d - off]);
+                }
             }
         }
 #pragma unroll

@@ -66,7 +66,12 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
                 break;
             }
             u32 score = 0;
-            if (m > 0 && nd.rows > 0) score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
+            if (m > 0 && nd.rows > 0) {
+                // wave-uniform choice: if every window of the wave fits the low half of the chunk, the upper half is pure padding
+                const bool half = SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
+                if (half) score = dp_unicode_single_chunk<SWL, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, hay + sp, m, sp == 0, cls);
+                else score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
+            }
             bool exact = include_exact && m == (u32)nd.nbytes;
             if (exact)
                 for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
