@@ -3,8 +3,8 @@
 // generic wave-per-haystack kernel (kernels_generic.hip), exactly like the ASCII single-chunk kernel does.
 #include "dp_unicode.h"
 
-template <int SWL, typename ET>
-__global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+template <int SWL, bool HALFONLY, typename ET>
+__device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                       const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                       const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity,
                                                       u32* __restrict__ dev_count, u32* __restrict__ overflow, u32 qcap,
@@ -68,9 +68,9 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
             u32 score = 0;
             if (m > 0 && nd.rows > 0) {
                 // wave-uniform choice: if every window of the wave fits the low half of the chunk, the upper half is pure padding
-                const bool half = SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
+                const bool half = HALFONLY || (SWL >= 16 && __all((int)(m <= (u32)SWL / 2)));
                 if (half) score = dp_unicode_single_chunk<SWL, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, hay + sp, m, sp == 0, cls);
-                else score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
+                else if (!HALFONLY) score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
             }
             bool exact = include_exact && m == (u32)nd.nbytes;
             if (exact)
@@ -90,15 +90,32 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode(const u8* __restrict__ byt
     }
 }
 
+#define FZB_K2U_PARAMS const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win, \
+    const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ overflow, \
+    u32 qcap, u32* __restrict__ counters
+#define FZB_K2U_ARGS bytes, ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters
+template <int SWL, typename ET>
+__global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, ET>(FZB_K2U_ARGS); }
+// every haystack of the list fits the low half of a chunk (host-known: corpus max_len <= SWL / 2): the general form is compiled out,
+// which lets the kernel fit 256 VGPRs (a few spills outside the row loop) and run two waves per SIMD
+template <int SWL, typename ET>
+__global__ __launch_bounds__(128, 2) void k2u_dp_unicode_half(FZB_K2U_PARAMS) { k2u_body<SWL, true, ET>(FZB_K2U_ARGS); }
+
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
                            int grid, hipStream_t st) {
     // `grid` = number of CUs: the kernel is persistent, launch exactly the resident workgroups
+    const bool half_only = sw_lanes >= 16 && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2;
 #define FZB_K2U(SWL, ET)                                                                                                               \
     do {                                                                                                                               \
-        static int per_cu = 0;                                                                                                         \
-        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
-        hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters); \
+        static int per_cu = 0, per_cu_half = 0;                                                                                        \
+        if (half_only) {                                                                                                               \
+            if (!per_cu_half && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_half, k2u_dp_unicode_half<SWL, ET>, 128, 0) != hipSuccess || per_cu_half < 1)) per_cu_half = 4; \
+            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters); \
+        } else {                                                                                                                       \
+            if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
+            hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters); \
+        }                                                                                                                              \
     } while (0)
 #define FZB_K2U_ET(SWL) do { if (c.ends_u64) FZB_K2U(SWL, u64); else FZB_K2U(SWL, u32); } while (0)
     switch (sw_lanes) {
