@@ -98,12 +98,22 @@ struct AsciiSrc {
     u32 len;
     Chunk<PFL> chunk;
     u64 valid;  // chunk_mask from load_window
-    __device__ AsciiSrc(const NeedleDev& n, const u8* h, u32 l) : nd(n), hay(h), len(l) {}
+    // The typo algorithms ask for the occurrence mask of a needle row again every time a path advances (~20 times for a
+    // 6-row needle), each one a 16-dword SWAR compare plus two per-thread byte loads of the needle.  With a cache (LDS,
+    // [row][thread], this thread's column only - no barriers) every row's mask is computed once per chunk, rows in a
+    // wave-uniform loop (scalar needle loads), and a request is one ds_read_b64.
+    u64* cache;
+    u32 loaded;  // chunk start the cache / chunk belong to
+    __device__ AsciiSrc(const NeedleDev& n, const u8* h, u32 l, u64* cache_ = nullptr) : nd(n), hay(h), len(l), cache(cache_), loaded(0xFFFFFFFFu) {}
     __device__ __forceinline__ void load(u32 start) {
+        if (start == loaded) return;  // (the end scan of a one-chunk haystack asks for the chunk that is already here)
+        loaded = start;
         load_chunk<PFL>(chunk, hay, start, len);
         valid = m_first_n<PFL>(len - start);
+        if (cache)
+            for (int r = 0; r < nd.rows; r++) cache[r * 256 + threadIdx.x] = occ_mask<PFL>(chunk, nd.c[r], nd.f[r]);
     }
-    __device__ __forceinline__ u64 mask(u32 idx) const { return occ_mask<PFL>(chunk, nd.c[idx], nd.f[idx]); }
+    __device__ __forceinline__ u64 mask(u32 idx) const { return cache ? cache[idx * 256 + threadIdx.x] : occ_mask<PFL>(chunk, nd.c[idx], nd.f[idx]); }
     __device__ __forceinline__ u64 init_mask() const { return valid; }  // ASCII path masks start as chunk_mask
     __device__ __forceinline__ u32 rows() const { return (u32)nd.rows; }
 };
@@ -440,7 +450,8 @@ enum { ALG_ASCII_1 = 0, ALG_ASCII_2 = 1, ALG_ASCII_N = 2, ALG_UNI_0 = 3, ALG_UNI
 template <int PFL, int ALG>
 __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
                                                   const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
-                                                  u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2) {
+                                                  u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, int use_cache) {
+    extern __shared__ __attribute__((aligned(16))) u64 mask_cache[];  // rows x 256 occurrence masks (ASCII algorithms, use_cache)
     __shared__ u32 s_cnt;
     const u32 M = *n_surv_ptr;
     const u32 ntiles = (M + FZB_TILE - 1) / FZB_TILE;
@@ -468,7 +479,7 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
                     else if (ALG == ALG_UNI_2) w = prefilter_2_typos<PFL>(src);
                     else w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos);
                 } else {
-                    AsciiSrc<PFL> src(nd, hay, L);
+                    AsciiSrc<PFL> src(nd, hay, L, use_cache ? mask_cache : nullptr);
                     if (ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
                     else if (ALG == ALG_ASCII_2) w = prefilter_2_typos<PFL>(src);
                     else w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos);
@@ -495,7 +506,10 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
                               u32* tile_counts2, int grid, hipStream_t st) {
     const int k = nd.max_typos;
     const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
-#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), 0, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2)
+    // occurrence-mask cache in LDS for the ASCII algorithms: rows x 2 KB per workgroup, up to 16 rows
+    const int use_cache = !nd.unicode && nd.rows <= 16;
+    const size_t lds = use_cache ? (size_t)nd.rows * 256 * 8 : 0;
+#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache)
     switch (alg) {
         case ALG_ASCII_1: FZB_K2A(ALG_ASCII_1); break;
         case ALG_ASCII_2: FZB_K2A(ALG_ASCII_2); break;
