@@ -10,6 +10,7 @@ __device__ __forceinline__ u32 p_add(u32 a, u32 b) { return as_u32(as_us2(a) + a
 __device__ __forceinline__ u32 p_sub(u32 a, u32 b) { return as_u32(as_us2(a) - as_us2(b)); }
 __device__ __forceinline__ u32 p_subs(u32 a, u32 b) { return as_u32(__builtin_elementwise_sub_sat(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ u32 p_max(u32 a, u32 b) { return as_u32(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
+__device__ __forceinline__ u32 p_min(u32 a, u32 b) { return as_u32(__builtin_elementwise_min(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ u32 p_mul(u32 a, u32 b) { return as_u32(as_us2(a) * as_us2(b)); }
 __device__ __forceinline__ u32 splat16(u32 v) { return (v & 0xFFFF) * 0x00010001u; }
 
@@ -301,6 +302,7 @@ __device__ __forceinline__ u32 dp_multi_chunk(const NeedleDev& nd, const u8* __r
     const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
     const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
     const u32 nchunks = (m + SWL - 1) / SWL;
+    const bool u8class = nd.lane_mask == 0xFF;  // score values of the u8 class fit a byte (score_fits_in_u8)
     u32 maxs[NW];
 #pragma unroll
     for (int d = 0; d < NW; d++) maxs[d] = 0;
@@ -349,12 +351,28 @@ __device__ __forceinline__ u32 dp_multi_chunk(const NeedleDev& nd, const u8* __r
             const u32 cmpv = splat16(ci ? (c | 0x20) : c);
             const u32 cv = splat16(c);
             // previous chunk's parked vectors for this row (zero for the first chunk)
+            // Parked form (the slab traffic is what bounds this kernel): the gap-open charges are 0 or gop' per lane = ONE bit per
+            // lane, one dword for the whole top half; row values of the u8 score class fit a byte, four lanes per dword.
             u32 arow[HT], ag[HT];
             u32* srow = scratch + (size_t)(r * NW) * sstride + sidx;
+            if (ch) {
+                if (u8class) {
 #pragma unroll
-            for (int t = 0; t < HT; t++) {
-                arow[t] = ch ? srow[(size_t)t * sstride] : 0u;
-                ag[t] = ch ? srow[(size_t)(HT + t) * sstride] : 0u;
+                    for (int t = 0; t < HT / 2; t++) {
+                        const u32 pk = srow[(size_t)t * sstride];
+                        arow[2 * t] = __builtin_amdgcn_perm(0u, pk, 0x0c010c00u);
+                        arow[2 * t + 1] = __builtin_amdgcn_perm(0u, pk, 0x0c030c02u);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HT; t++) arow[t] = srow[(size_t)t * sstride];
+                }
+                const u32 bits = srow[(size_t)HT * sstride];
+#pragma unroll
+                for (int t = 0; t < HT; t++) ag[t] = p_mul(((bits >> (2 * t)) & 1u) | (((bits >> (2 * t + 1)) & 1u) << 16), gopmv);
+            } else {
+#pragma unroll
+                for (int t = 0; t < HT; t++) arow[t] = 0u, ag[t] = 0u;
             }
             u32 row[NW], g[NW];
 #pragma unroll
@@ -431,11 +449,20 @@ __device__ __forceinline__ u32 dp_multi_chunk(const NeedleDev& nd, const u8* __r
             }
             // park this chunk's top half for the next chunk
             if (ch + 1 < nchunks) {
+                if (u8class) {
+#pragma unroll
+                    for (int t = 0; t < HT / 2; t++) srow[(size_t)t * sstride] = __builtin_amdgcn_perm(row[HT + 2 * t + 1], row[HT + 2 * t], 0x06040200u);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HT; t++) srow[(size_t)t * sstride] = row[HT + t];
+                }
+                u32 bits = 0;
 #pragma unroll
                 for (int t = 0; t < HT; t++) {
-                    srow[(size_t)t * sstride] = row[HT + t];
-                    srow[(size_t)(HT + t) * sstride] = g[HT + t];
+                    const u32 m01 = p_min(g[HT + t], ONE);  // 1 where the lane is charged
+                    bits |= ((m01 & 1u) | ((m01 >> 15) & 2u)) << (2 * t);
                 }
+                srow[(size_t)HT * sstride] = bits;
             }
 #pragma unroll
             for (int d = 0; d < NW; d++) prev[d] = row[d], gprev[d] = g[d];
