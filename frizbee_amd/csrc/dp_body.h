@@ -39,21 +39,31 @@ __device__ __forceinline__ void window_first_last(const NeedleDev& nd, const u8*
     we = 0;
     const uint4* vp = (const uint4*)hay;
     const u32 nvec = (L + 15) >> 4;
-    for (u32 v = 0; v < nvec; v++) {
-        const uint4 q = vp[v];
-        const u32 w4[4] = {q.x, q.y, q.z, q.w};
-        u32 mf = 0, ml = 0;
+    // eight vectors are requested together and then examined: the scan needs every vector (last occurrence), and one load per
+    // loop trip would expose a full memory round trip per 16 bytes to a kernel that has only two waves per SIMD to cover it
+    for (u32 vb = 0; vb < nvec; vb += 8) {
+        uint4 qs[8];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            mf |= (zero_bytes4_dp(w4[k] ^ a0) | zero_bytes4_dp(w4[k] ^ a1)) << (4 * k);
-            ml |= (zero_bytes4_dp(w4[k] ^ z0) | zero_bytes4_dp(w4[k] ^ z1)) << (4 * k);
+        for (int k = 0; k < 8; k++) qs[k] = vb + k < nvec ? vp[vb + k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const u32 v = vb + k;
+            if (v >= nvec) break;
+            const uint4 q = qs[k];
+            const u32 w4[4] = {q.x, q.y, q.z, q.w};
+            u32 mf = 0, ml = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                mf |= (zero_bytes4_dp(w4[j] ^ a0) | zero_bytes4_dp(w4[j] ^ a1)) << (4 * j);
+                ml |= (zero_bytes4_dp(w4[j] ^ z0) | zero_bytes4_dp(w4[j] ^ z1)) << (4 * j);
+            }
+            const u32 rem = L - 16 * v;
+            const u32 vm = rem >= 16 ? 0xFFFFu : ((1u << rem) - 1);
+            mf &= vm;
+            ml &= vm;
+            if (ws == 0xFFFFFFFFu && mf) ws = 16 * v + __builtin_ctz(mf);
+            if (ml) we = 16 * v + 32 - __builtin_clz(ml);
         }
-        const u32 rem = L - 16 * v;
-        const u32 vm = rem >= 16 ? 0xFFFFu : ((1u << rem) - 1);
-        mf &= vm;
-        ml &= vm;
-        if (ws == 0xFFFFFFFFu && mf) ws = 16 * v + __builtin_ctz(mf);
-        if (ml) we = 16 * v + 32 - __builtin_clz(ml);
     }
     if (ws == 0xFFFFFFFFu) ws = 0;  // cannot happen for a survivor of the exact filter
 }
