@@ -762,7 +762,8 @@ struct Prefilter {
 static const size_t MAX_HAYSTACK_LEN = 1024;  // smith_waterman/algo/mod.rs:18
 
 // smith_waterman/greedy.rs:7-91.  Returns false for None.
-inline bool match_greedy(const std::string& needle_s, const u8* haystack, size_t hlen, const Scoring& scoring, bool case_sensitive, bool include_prefix, u16& score_out) {
+inline bool match_greedy(const std::string& needle_s, const u8* haystack, size_t hlen, const Scoring& scoring, bool case_sensitive, bool include_prefix, u16& score_out,
+                         std::vector<u32>* indices = nullptr) {
     auto needle = case_needle(needle_s, case_sensitive);
     if (needle.size() > hlen) return false;
     u16 score = 0;
@@ -800,6 +801,7 @@ inline bool match_greedy(const std::string& needle_s, const u8* haystack, size_t
             if (prev_is_delim && !is_delim) score = sat_add16(score, scoring.delimiter_bonus);
             prev_is_delim = delimiter_bonus_enabled && is_delim;
             prev_is_lower = is_lower;
+            if (indices) indices->push_back((u32)haystack_idx);
             haystack_idx += 1;
             found = true;
             break;
@@ -830,6 +832,7 @@ struct SV {
         for (int i = L; i < LANES; i++) r.v[i] = v[i - L];
         return r;
     }
+    T lane(int i) const { return v[i]; }
     // mask lanes (0xFF / 0x00 bytes) widened to score lanes (all-ones / zero): scalar.rs:18-42
     template <typename BYTES>
     static SV from_mask(const BYTES& m) { SV r; for (int i = 0; i < LANES; i++) r.v[i] = m.lane(i) ? (T)~(T)0 : (T)0; return r; }
@@ -922,6 +925,7 @@ struct SV<64, u8> {
         SV r; r.x = _mm512_permutex2var_epi8(prev.x, idx, x); return r;
     }
     static SV from_mask(const BV<64>& m) { SV r; r.x = m.x; return r; }
+    u8 lane(int i) const { alignas(64) u8 t[64]; _mm512_store_si512((void*)t, x); return t[i]; }
 };
 template <>
 struct BV<32> {
@@ -971,6 +975,7 @@ struct SV<32, u16> {
         SV r; r.x = _mm512_permutex2var_epi16(prev.x, idx, x); return r;
     }
     static SV from_mask(const BV<32>& m) { SV r; r.x = _mm512_cvtepi8_epi16(m.x); return r; }  // 0xFF -> 0xFFFF (sign extension)
+    u16 lane(int i) const { alignas(64) u16 t[32]; _mm512_store_si512((void*)t, x); return t[i]; }
 };
 #endif
 
@@ -986,6 +991,7 @@ struct SmithWaterman {
     Scoring scoring;
     // Matrix<B>: (needle_len+1) x (MAX_HAYSTACK_LEN/LANES + 1) (smith_waterman/matrix.rs:11-22)
     size_t stride;
+    size_t chunks_used = 0;  // `haystack_chunks` of the most recent scoring call (smith_waterman/mod.rs:131-134)
     std::vector<S> score_matrix, match_masks, unicode_pending;
 
     SmithWaterman(const std::string& n, const Scoring& sc, bool cs)  // smith_waterman/algo/mod.rs:21-42
@@ -1020,6 +1026,7 @@ struct SmithWaterman {
             return match_greedy(needle, haystack, hlen, scoring, case_sensitive, include_prefix, s) ? s : 0;
         }
         size_t haystack_chunks = (hlen + LANES - 1) / LANES + 1;
+        chunks_used = haystack_chunks;
         S gap_extend_penalty = S::splat(scoring.gap_extend_penalty);
         S gap_open_penalty = S::splat(sat_sub16(scoring.gap_open_penalty, scoring.gap_extend_penalty));
         S match_score = S::splat(sat_add16(scoring.match_score, scoring.mismatch_penalty));
@@ -1135,6 +1142,7 @@ struct SmithWaterman {
         }
         if (needle_unicode.empty()) return 0;
         size_t haystack_chunks = (hlen + LANES - 1) / LANES + 1;
+        chunks_used = haystack_chunks;
         S gap_extend_penalty = S::splat(scoring.gap_extend_penalty);
         S gap_open_penalty = S::splat(sat_sub16(scoring.gap_open_penalty, scoring.gap_extend_penalty));
         S match_score = S::splat(sat_add16(scoring.match_score, scoring.mismatch_penalty));
@@ -1220,7 +1228,85 @@ struct SmithWaterman {
         }
         return max_scores.horizontal_max();
     }
+    // ---- traceback (smith_waterman/alignment_iter.rs:35-181): walks the stored matrices from the first lane of the last row
+    // that holds `score`; pushes the haystack byte position of every Match step (reverse order).  Returns false when the typo
+    // budget was exceeded (the iterator yields None).  Columns are global lane numbers, column = chunk * LANES + lane, chunk 0 =
+    // the zero column.
+    u16 cell(size_t row, size_t col) { return (u16)sm(row, col / LANES).lane((int)(col % LANES)); }
+    bool cell_is_match(size_t row, size_t col) { return mmx(row, col / LANES).lane((int)(col % LANES)) != 0; }
+    template <typename F>
+    bool walk_alignment(size_t needle_len, size_t haystack_start_pos, const u8* unicode_haystack, size_t unicode_len, u16 score, int max_typos, F on_match) {
+        size_t col = SIZE_MAX;
+        for (size_t c = 1; c < chunks_used && col == SIZE_MAX; c++)
+            for (int i = 0; i < LANES; i++)
+                if ((u16)sm(needle_len, c).lane(i) == score) { col = c * LANES + i; break; }
+        if (col == SIZE_MAX) throw std::runtime_error("could not find max score in score matrix final row");
+        size_t row = needle_len;
+        u32 typos = 0;
+        for (;;) {
+            if (row == 0) return true;
+            if (max_typos >= 0 && typos > (u32)max_typos) return false;
+            if (col < (size_t)LANES || score == 0) {  // must be moving up only (at left edge), or lost alignment
+                if (max_typos >= 0 && typos + (u32)row > (u32)max_typos) return false;
+                return true;
+            }
+            size_t haystack_idx = col - LANES;
+            if (unicode_haystack && haystack_idx < unicode_len && (unicode_haystack[haystack_idx] & 0xC0) == 0x80) {  // continuation byte: walk left
+                col -= 1;
+                score = cell(row, col);
+                continue;
+            }
+            if (cell_is_match(row, col)) {
+                on_match(row - 1, haystack_idx + haystack_start_pos);
+                row -= 1;
+                col -= 1;
+                score = cell(row, col);
+                continue;
+            }
+            u16 diag = cell(row - 1, col - 1), left = cell(row, col - 1), up = cell(row - 1, col);
+            if (diag >= left && diag >= up) { row -= 1; col -= 1; typos += 1; score = diag; }
+            else if (left >= up) { col -= 1; score = left; }
+            else { typos += 1; row -= 1; score = up; }
+        }
+    }
+    // has_alignment_path (smith_waterman/alignment.rs:24-35)
+    bool has_alignment_path(u16 score, int max_typos) {
+        return walk_alignment(needle.size(), 0, nullptr, 0, score, max_typos, [](size_t, size_t) {});
+    }
+    // smith_waterman/algo/mod.rs:49-94
+    u16 score_haystack_indices(const u8* haystack, size_t hlen, size_t haystack_start_pos, int max_typos, std::vector<u32>& indices) {
+        indices.clear();
+        if (hlen > MAX_HAYSTACK_LEN) return greedy_indices(haystack, hlen, haystack_start_pos, indices);
+        u16 score = score_haystack(haystack, hlen, haystack_start_pos == 0);
+        if (score == 0) return 0;
+        walk_alignment(needle.size(), haystack_start_pos, nullptr, 0, score, max_typos, [&](size_t, size_t pos) { indices.push_back((u32)pos); });
+        return score;
+    }
+    // smith_waterman/algo/mod.rs:97-152
+    u16 score_haystack_unicode_indices(const u8* haystack, size_t hlen, size_t haystack_start_pos, int max_typos, std::vector<u32>& indices) {
+        indices.clear();
+        if (hlen > MAX_HAYSTACK_LEN) return greedy_indices(haystack, hlen, haystack_start_pos, indices);
+        u16 score = score_haystack_unicode(haystack, hlen, haystack_start_pos == 0);
+        if (score == 0) return 0;
+        size_t prev = SIZE_MAX;
+        walk_alignment(needle_unicode.size(), haystack_start_pos, haystack, hlen, score, max_typos, [&](size_t needle_idx, size_t pos) {
+            if (prev != pos) {
+                int len = needle_unicode[needle_idx].len;
+                for (int off = len - 1; off >= 0; off--) indices.push_back((u32)(pos + off));
+                prev = pos;
+            }
+        });
+        return score;
+    }
+    u16 greedy_indices(const u8* haystack, size_t hlen, size_t haystack_start_pos, std::vector<u32>& indices) {
+        u16 s;
+        std::vector<u32> fwd;
+        if (!match_greedy(needle, haystack, hlen, scoring, case_sensitive, haystack_start_pos == 0, s, &fwd)) return 0;
+        for (size_t i = fwd.size(); i-- > 0;) indices.push_back((u32)(fwd[i] + haystack_start_pos));
+        return s;
+    }
 };
+
 
 // =======================================================================================
 // ORDERING: src/sort.rs:6-40, src/k_merge.rs:90-170
@@ -1301,6 +1387,8 @@ struct HaystackList {  // packed bytes + exclusive end offsets (the boundary's c
 struct MatcherBase {
     virtual ~MatcherBase() {}
     virtual void match_list_into(const HaystackList& hs, size_t lo, size_t hi, u32 index_offset, std::vector<Match>& out) = 0;
+    // match_list_indices_impl (matcher/algo.rs:196-227; literal/algo.rs:129-155): matches + the matched byte positions, reverse order
+    virtual void match_list_indices(const HaystackList& hs, std::vector<Match>& out, std::vector<std::vector<u32>>& indices) = 0;
     virtual MatcherBase* clone() const = 0;
 };
 
@@ -1354,6 +1442,27 @@ struct MatcherImpl : MatcherBase {
             bool exact = include_exact && needle.size() == tlen && memcmp(needle.data(), trimmed, tlen) == 0;
             if (exact) score = (u16)(score + config.scoring.exact_match_bonus);
             out.push_back(Match{(u32)(index_offset + (i - lo)), score, (u8)(exact ? 1 : 0), 0});
+        }
+    }
+
+    void match_list_indices(const HaystackList& hs, std::vector<Match>& out, std::vector<std::vector<u32>>& indices) override {  // algo.rs:196-227, 264-292
+        const int max_typos_opt = config.max_typos < 0 ? -1 : config.max_typos;  // NO_PREFILTER -> None
+        for (size_t i = 0; i < hs.n; i++) {
+            const u8* h = hs.ptr(i);
+            size_t original_len = hs.len(i);
+            if (original_len < min_haystack_len) continue;
+            Window w = prefilter_haystack(h, original_len);
+            if (!w.matched) continue;
+            size_t start_pos = w.start > 0 ? w.start - 1 : 0;
+            bool include_exact = start_pos == 0 && w.end == original_len;
+            const u8* trimmed = h + start_pos;
+            size_t tlen = w.end - start_pos;
+            std::vector<u32> idx;
+            u16 score = needs_unicode ? sw.score_haystack_unicode_indices(trimmed, tlen, start_pos, max_typos_opt, idx) : sw.score_haystack_indices(trimmed, tlen, start_pos, max_typos_opt, idx);
+            bool exact = include_exact && needle.size() == tlen && memcmp(needle.data(), trimmed, tlen) == 0;
+            if (exact) score = (u16)(score + config.scoring.exact_match_bonus);
+            out.push_back(Match{(u32)i, score, (u8)(exact ? 1 : 0), 0});
+            indices.push_back(idx);
         }
     }
 };
@@ -1445,6 +1554,18 @@ struct LiteralMatcher : MatcherBase {
             if (!find(hs.ptr(i), hs.len(i), pos, score)) continue;
             bool exact = pos == 0 && needle.size() == hs.len(i);
             out.push_back(Match{(u32)(index_offset + (i - lo)), score, (u8)(exact ? 1 : 0), 0});
+        }
+    }
+    void match_list_indices(const HaystackList& hs, std::vector<Match>& out, std::vector<std::vector<u32>>& indices) override {  // algo.rs:129-155
+        for (size_t i = 0; i < hs.n; i++) {
+            size_t pos = 0;
+            u16 score = 0;
+            if (!find(hs.ptr(i), hs.len(i), pos, score)) continue;
+            bool exact = pos == 0 && needle.size() == hs.len(i);
+            out.push_back(Match{(u32)i, score, (u8)(exact ? 1 : 0), 0});
+            std::vector<u32> idx;
+            for (size_t k = needle.size(); k-- > 0;) idx.push_back((u32)(pos + k));  // the whole UTF-8 run, reversed
+            indices.push_back(idx);
         }
     }
 };

@@ -25,6 +25,18 @@ static u16 sw_run(const std::string& n, const Scoring& sc, bool cs, const u8* h,
     return unicode ? sw.score_haystack_unicode(h, hlen, include_prefix) : sw.score_haystack(h, hlen, include_prefix);
 }
 
+template <int L, typename T>
+static int sw_indices_run(const std::string& n, const Scoring& sc, bool cs, const u8* h, size_t hlen, size_t start_pos, bool unicode, int max_typos, std::vector<u32>& idx) {
+    SmithWaterman<L, T> sw(n, sc, cs);
+    return unicode ? sw.score_haystack_unicode_indices(h, hlen, start_pos, max_typos, idx) : sw.score_haystack_indices(h, hlen, start_pos, max_typos, idx);
+}
+template <int L, typename T>
+static int sw_path_run(const std::string& n, const Scoring& sc, bool cs, const u8* h, size_t hlen, int max_typos) {
+    SmithWaterman<L, T> sw(n, sc, cs);
+    u16 score = sw.score_haystack(h, hlen, true);
+    return sw.has_alignment_path(score, max_typos) ? (int)score : -1;
+}
+
 extern "C" {
 
 // which lane-vector implementation this build of the oracle runs on
@@ -92,6 +104,74 @@ int fzo_sw_score(const uint8_t* needle, size_t nlen, const uint8_t* hay, size_t 
         }
 #undef RUN
     } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
+
+// score_haystack[_unicode]_indices (smith_waterman/algo/mod.rs:49-152): returns the score, *out_n indices (reverse order) in out_idx.
+// max_typos < 0 = None.
+int fzo_sw_indices(const uint8_t* needle, size_t nlen, const uint8_t* hay, size_t hlen, const uint16_t scoring[9], int case_sensitive, size_t start_pos, int unicode, int lanes,
+                   int is_u8, int max_typos, uint32_t* out_idx, size_t cap, size_t* out_n) {
+    try {
+        std::string n((const char*)needle, nlen);
+        Scoring sc = scoring_from(scoring);
+        std::vector<u32> idx;
+        int score;
+#define RUN(L) (is_u8 ? sw_indices_run<L, u8>(n, sc, case_sensitive, hay, hlen, start_pos, unicode, max_typos, idx) : sw_indices_run<L, u16>(n, sc, case_sensitive, hay, hlen, start_pos, unicode, max_typos, idx))
+        switch (lanes) {
+            case 8: score = RUN(8); break;
+            case 16: score = RUN(16); break;
+            case 32: score = RUN(32); break;
+            case 64: score = RUN(64); break;
+            default: g_err = "bad lanes"; return -1;
+        }
+#undef RUN
+        if (idx.size() > cap) { g_err = "fzo_sw_indices: output too small"; return -1; }
+        if (!idx.empty()) memcpy(out_idx, idx.data(), idx.size() * 4);
+        *out_n = idx.size();
+        return score;
+    } catch (std::exception& e) { g_err = e.what(); return -1; }
+}
+// score_haystack + has_alignment_path (smith_waterman/alignment.rs:24-35): the score, or -1 when no path fits the typo budget
+int fzo_sw_score_typos(const uint8_t* needle, size_t nlen, const uint8_t* hay, size_t hlen, const uint16_t scoring[9], int case_sensitive, int lanes, int is_u8, int max_typos) {
+    try {
+        std::string n((const char*)needle, nlen);
+        Scoring sc = scoring_from(scoring);
+#define RUN(L) (is_u8 ? sw_path_run<L, u8>(n, sc, case_sensitive, hay, hlen, max_typos) : sw_path_run<L, u16>(n, sc, case_sensitive, hay, hlen, max_typos))
+        switch (lanes) {
+            case 8: return RUN(8);
+            case 16: return RUN(16);
+            case 32: return RUN(32);
+            case 64: return RUN(64);
+            default: g_err = "bad lanes"; return -2;
+        }
+#undef RUN
+    } catch (std::exception& e) { g_err = e.what(); return -2; }
+}
+// Matcher::match_list_indices for one pattern (matcher/mod.rs:234-262, index order): records + per-record index lists, flattened.
+// out_offsets has n_records + 1 entries.  Everything malloc'd; free with fzo_free.
+int fzo_match_list_indices(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, Match** out, size_t* out_len, uint32_t** out_idx, uint64_t** out_offsets) {
+    try {
+        HaystackList hs{bytes, ends, n};
+        Matcher* mm = (Matcher*)m;
+        std::vector<Match> recs;
+        std::vector<std::vector<u32>> idx;
+        if (!mm->empty) mm->impl->match_list_indices(hs, recs, idx);
+        else for (size_t i = 0; i < n; i++) { recs.push_back(Match{(u32)i, 0, 0, 0}); idx.emplace_back(); }
+        size_t total = 0;
+        for (auto& v : idx) total += v.size();
+        *out = (Match*)malloc(std::max<size_t>(recs.size(), 1) * sizeof(Match));
+        *out_idx = (uint32_t*)malloc(std::max<size_t>(total, 1) * 4);
+        *out_offsets = (uint64_t*)malloc((recs.size() + 1) * 8);
+        size_t off = 0;
+        for (size_t i = 0; i < recs.size(); i++) {
+            (*out)[i] = recs[i];
+            (*out_offsets)[i] = off;
+            if (!idx[i].empty()) memcpy(*out_idx + off, idx[i].data(), idx[i].size() * 4);
+            off += idx[i].size();
+        }
+        (*out_offsets)[recs.size()] = off;
+        *out_len = recs.size();
+        return 0;
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
 
 // match_greedy: returns score or -1 for None

@@ -307,4 +307,22 @@ multi_queries = [
 json.dump(dict(scores=lit_scores, matches=lit_matches, greater=lit_greater, lists=lit_lists, prefix_equals_fuzzy=lit_prefix_equals_fuzzy, corpus=lit_corpus,
                parse_atoms=parse_atoms, parse_queries=parse_queries, multi_queries=multi_queries),
           open(os.path.join(HERE, "literal.json"), "w"), ensure_ascii=False, indent=1)
+# ---- traceback / matched indices (src/smith_waterman/mod.rs tests; BackendScalar8 = 8 lanes x u16, default scoring, case-insensitive) ----
+idx_ascii = [("aa", "aaa", [1, 0], "src/smith_waterman/mod.rs:323"), ("ab", "abab", [1, 0], "src/smith_waterman/mod.rs:324"), ("abc", "xabcabc", [3, 2, 1], "src/smith_waterman/mod.rs:325"),
+             ("_", "abc", [], "src/smith_waterman/mod.rs:444"), ("a", "abc", [0], "src/smith_waterman/mod.rs:445"), ("b", "abc", [1], "src/smith_waterman/mod.rs:446"),
+             ("c", "abc", [2], "src/smith_waterman/mod.rs:447"), ("ac", "________________abc", [18, 16], "src/smith_waterman/mod.rs:448"), ("foo", "Uf", [1], "src/smith_waterman/mod.rs:449")]
+idx_ascii += [("abc", "x" * (L - 3) + "abc", [L - 1, L - 2, L - 3], "src/smith_waterman/mod.rs:510-520") for L in (1023, 1024, 1025)]
+idx_unicode = [  # (needle, haystack, haystack_start_pos, expected)
+    ("é", "é", 0, [1, 0], "src/smith_waterman/mod.rs:454"), ("😀", "😀", 0, [3, 2, 1, 0], "src/smith_waterman/mod.rs:455"), ("aé", "aé", 0, [2, 1, 0], "src/smith_waterman/mod.rs:456"),
+    ("é", "é", 3, [4, 3], "src/smith_waterman/mod.rs:460-468"), ("éx", "é😀x", 3, [9, 4, 3], "src/smith_waterman/mod.rs:472-480"),
+    ("ab", "aéb", 0, [3, 0], "src/smith_waterman/mod.rs:485"), ("ab", "aé😀b", 0, [7, 0], "src/smith_waterman/mod.rs:486"), ("éx", "é😀x", 0, [6, 1, 0], "src/smith_waterman/mod.rs:487"),
+    ("éé", "ééé", 0, [3, 2, 1, 0], "src/smith_waterman/mod.rs:492"), ("😀x", "_______😀x", 0, [11, 10, 9, 8, 7], "src/smith_waterman/mod.rs:493-496"),
+    ("😀.a", "..😀a", 0, [6, 1], "src/smith_waterman/mod.rs:503"), ("😀.é", "..😀é", 0, [7, 6, 1], "src/smith_waterman/mod.rs:504"),
+    ("😀 a", "  😀a", 0, [6, 1], "src/smith_waterman/mod.rs:505"), ("😀é", "..😀é", 0, [7, 6, 5, 4, 3, 2], "src/smith_waterman/mod.rs:506"),
+]
+score_typos = [  # get_score_typos(needle, haystack, max_typos): score if an alignment path within the budget exists (src/smith_waterman/mod.rs:421-440)
+    ("foo", "Ufooo", 0, 3 * CHAR), ("foo", "Ufo", 0, None), ("foo", "Ufo", 1, 2 * CHAR - GOP), ("foo", "Ufo", 2, 2 * CHAR - GOP), ("foo", "Uf", 1, None),
+    ("foo", "Uf", 2, CHAR - GOP - GEX), ("foo", "U", 2, None), ("foo", "U", 3, 0), ("foo", "U", 4, 0),
+]
+json.dump(dict(ascii=idx_ascii, unicode=idx_unicode, score_typos=score_typos), open(os.path.join(HERE, "indices.json"), "w"), ensure_ascii=False, indent=1)
 print("golden written")

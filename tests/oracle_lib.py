@@ -49,6 +49,9 @@ def lib(native=False):
         l.fzo_simd_kind.restype = C.c_char_p
         l.fzo_prefilter.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
         l.fzo_sw_score.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.fzo_sw_indices.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]
+        l.fzo_sw_score_typos.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int, C.c_int]
+        l.fzo_match_list_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         l.fzo_greedy.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int]
         l.fzo_score_fits_in_u8.argtypes = [C.c_size_t, C.POINTER(C.c_uint16)]
         l.fzo_max_needle_len.argtypes = [C.POINTER(C.c_uint16)]
@@ -100,6 +103,27 @@ def sw_score(needle, haystack, scoring=None, case_sensitive=False, include_prefi
     if r < 0:
         raise RuntimeError(lib().fzo_last_error().decode())
     return r
+
+
+def sw_indices(needle, haystack, start_pos=0, unicode=False, max_typos=None, scoring=None, case_sensitive=False, lanes=8, is_u8=False, native=False):
+    """score_haystack[_unicode]_indices (smith_waterman/algo/mod.rs:49-152) -> (score, matched byte positions in reverse order)"""
+    n, h = _b(needle), _b(haystack)
+    cap = 4 * len(n) + 16
+    out = (C.c_uint32 * cap)()
+    cnt = C.c_size_t()
+    r = lib(native).fzo_sw_indices(n, len(n), h, len(h), _scoring(scoring), int(case_sensitive), start_pos, int(unicode), lanes, int(is_u8), -1 if max_typos is None else max_typos, out, cap, C.byref(cnt))
+    if r < 0:
+        raise RuntimeError(lib(native).fzo_last_error().decode())
+    return r, list(out[: cnt.value])
+
+
+def sw_score_typos(needle, haystack, max_typos, scoring=None, case_sensitive=False, lanes=8, is_u8=False):
+    """get_score_typos of the reference's tests: the score if an alignment path within the typo budget exists, else None"""
+    n, h = _b(needle), _b(haystack)
+    r = lib().fzo_sw_score_typos(n, len(n), h, len(h), _scoring(scoring), int(case_sensitive), lanes, int(is_u8), max_typos)
+    if r < -1:
+        raise RuntimeError(lib().fzo_last_error().decode())
+    return None if r < 0 else r
 
 
 def greedy(needle, haystack, scoring=None, case_sensitive=False, include_prefix=True):
@@ -179,6 +203,20 @@ class Matcher:
 
     def match_list(self, haystacks):
         return self.match_packed(*pack(haystacks))
+
+    def match_list_indices(self, haystacks):
+        """`Matcher::match_list_indices` for one pattern, index order: (records, list of index lists in reverse byte order)"""
+        data, ends = pack(haystacks)
+        out, n, oi, oo = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_void_p()
+        rc = self.lib.fzo_match_list_indices(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), C.byref(out), C.byref(n), C.byref(oi), C.byref(oo))
+        if rc:
+            raise RuntimeError(self.lib.fzo_last_error().decode())
+        recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 8,))[: n.value * 8].view(MATCH_DTYPE).copy()
+        offs = np.ctypeslib.as_array(C.cast(oo, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+        flat = np.ctypeslib.as_array(C.cast(oi, C.POINTER(C.c_uint32)), shape=(max(int(offs[-1]), 1),)).copy()
+        for p in (out, oi, oo):
+            self.lib.fzo_free(p)
+        return recs, [flat[int(offs[i]) : int(offs[i + 1])].tolist() for i in range(n.value)]
 
     def match_list_parallel(self, haystacks, threads):
         return self.match_packed(*pack(haystacks), threads=threads)

@@ -1,0 +1,63 @@
+"""Traceback / matched indices: the oracle's restatement of src/smith_waterman/alignment_iter.rs and
+score_haystack[_unicode]_indices (src/smith_waterman/algo/mod.rs:49-152) against the reference's known answers.  The walk
+reads the stored score matrix and match masks cell by cell (with diag >= left >= up tie-breaking), so these vectors pin the
+matrices the scorer builds, not only their maxima.  (The product delegates `*_indices` to the reference's CPU code - see
+INTEGRATION.md - so this is oracle-side only.)"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+IX = json.load(open(os.path.join(G, "indices.json")))
+SW = json.load(open(os.path.join(G, "smith_waterman.json")))
+
+
+@pytest.mark.parametrize("needle,haystack,want,ref", IX["ascii"])
+def test_ascii_indices(needle, haystack, want, ref):
+    assert O.sw_indices(needle, haystack)[1] == want, ref
+
+
+@pytest.mark.parametrize("needle,haystack,start,want,ref", IX["unicode"])
+def test_unicode_indices(needle, haystack, start, want, ref):
+    assert O.sw_indices(needle, haystack, start_pos=start, unicode=True)[1] == want, ref
+
+
+@pytest.mark.parametrize("needle,haystack,typos,want", IX["score_typos"])
+def test_alignment_path_within_typo_budget(needle, haystack, typos, want):
+    assert O.sw_score_typos(needle, haystack, typos) == want
+
+
+def test_indices_contract_on_random_inputs():
+    # tests/api_properties.rs:116-174 (assert_indices_contract): same (index, score, exact) as match_list; indices strictly
+    # descending, inside the haystack, at most one per needle byte
+    rng = np.random.default_rng(31)
+    alpha = "abcABC_-/ 01xyz"
+    for it in range(400):
+        needle = "".join(alpha[int(x)] for x in rng.integers(0, len(alpha), int(rng.integers(1, 9))))
+        hs = []
+        for _ in range(20):
+            L = int(rng.choice([0, 1, 7, 8, 15, 16, 31, 32, 48, 70, 140]))
+            h = [alpha[int(x)] for x in rng.integers(0, len(alpha), L)]
+            if L >= len(needle) and rng.random() < 0.6:
+                for q, c in zip(np.sort(rng.choice(L, len(needle), replace=False)), needle):
+                    h[q] = c
+            hs.append("".join(h))
+        typos = [None, 0, 1, 2][int(rng.integers(0, 4))]
+        for lanes in ((16, 16, 8), (64, 64, 32)):
+            m = O.Matcher(needle, lanes=lanes, max_typos=typos, sort="IndexAsc")
+            recs, idx = m.match_list_indices(hs)
+            assert recs.tolist() == m.match_list(hs).tolist()
+            for r, ix in zip(recs, idx):
+                h = hs[int(r["index"])].encode()
+                assert all(a > b for a, b in zip(ix[:-1], ix[1:])) and all(0 <= i < len(h) for i in ix) and len(ix) <= len(needle.encode())
+
+
+def test_literal_indices_are_the_contiguous_run_reversed():
+    recs, idx = O.Matcher("abc", matching="Substring", sort="IndexAsc").match_list_indices(["xxabcxx"])  # src/literal/mod.rs:177-182
+    assert idx == [[4, 3, 2]]
+    recs, idx = O.Matcher("é다", matching="Substring", sort="IndexAsc").match_list_indices(["xxé다yy"])  # src/literal/mod.rs:354-361
+    assert idx == [[6, 5, 4, 3, 2]]
