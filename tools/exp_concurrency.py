@@ -4,12 +4,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, synth, frizbee_amd as F
 dev = torch.device("cuda", 0)
-n, L = 5_000_000, 32
+n, L = 10_000_000, 32
 def mk(seed):
     flat = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
     flat[: n * L].view(n, L).copy_(synth.make_rows(b"deadbe", n, L, seed=seed, device=dev))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * L).to(torch.int32)
-    return F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends))
+    return F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=L)
 cs = [mk(1), mk(2)]
 ms = [F.Matcher("deadbe", F.Config(pf_lanes=64, sw_lanes=64)) for _ in range(2)]
 outs = [torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev) for _ in range(2)]
