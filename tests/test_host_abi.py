@@ -119,3 +119,14 @@ def test_parse_query_matches_the_references_known_answers():
     for query in ("foo !^bar 'lit baz$ ^ex$ !neg a\\ b \\!x ! \\", "다나 !é$ ^\\^x"):
         got, want = F.parse_query(query), O.parse_query(query)
         assert [(p.needle, p.negated, None if p.matching is None else p.matching.name) for p in got] == [(p["needle"], p["negated"], p["matching"]) for p in want]
+
+
+def test_parse_query_differential_against_the_oracle_on_random_queries():
+    # two separately written parsers (host side of the product, oracle) over random strings of the syntax's alphabet
+    rng = np.random.default_rng(77)
+    alpha = ["a", "b", "Z", "é", "다", " ", "  ", "\t", "\\", "\\\\", "!", "^", "$", "'", "\\ ", "\\!", "\\^", "\\$", "\\'", "　", "!^", "$ "]
+    for _ in range(3000):
+        q = "".join(alpha[int(i)] for i in rng.integers(0, len(alpha), int(rng.integers(0, 12))))
+        got = [(p.needle, p.negated, None if p.matching is None else p.matching.name) for p in F.parse_query(q)]
+        want = [(p["needle"], p["negated"], p["matching"]) for p in O.parse_query(q)]
+        assert got == want, repr(q)
