@@ -130,3 +130,38 @@ def test_parse_query_differential_against_the_oracle_on_random_queries():
         got = [(p.needle, p.negated, None if p.matching is None else p.matching.name) for p in F.parse_query(q)]
         want = [(p["needle"], p["negated"], p["matching"]) for p in O.parse_query(q)]
         assert got == want, repr(q)
+
+
+def test_matcher_new_differential_on_random_scorings():
+    # class selection (score_fits_in_u8), Smart case / unicode resolution and the overflow guards, host side vs oracle
+    rng = np.random.default_rng(1234)
+    pool = ["a", "B", "0", "_", "é", "다", "ß", "Z"]
+    agree_panics = ok = 0
+    for _ in range(1500):
+        needle = "".join(pool[int(i)] for i in rng.integers(0, len(pool), int(rng.integers(1, 20))))
+        if len(needle.encode()) > 64:
+            continue
+        big = rng.random() < 0.15
+        sc = [int(rng.integers(0, 60000 if big else 40)) for _ in range(9)]
+        casing = ["Ignore", "Smart", "Respect"][int(rng.integers(0, 3))]
+        uni = ["Ignore", "Smart", "Always"][int(rng.integers(0, 3))]
+        matching = ["Fuzzy", "Substring"][int(rng.integers(0, 2))]
+        try:
+            want = O.Matcher(needle, lanes=(64, 64, 32), scoring=sc, casing=casing, unicode=uni, matching=matching).info()
+            oerr = None
+        except RuntimeError as e:
+            want, oerr = None, str(e)
+        fc = F.Config(casing=F.CaseMatching[casing], unicode=F.UnicodeMatching[uni], scoring=F.Scoring(*sc), matching=F.Matching[matching], pf_lanes=64)
+        try:
+            got = F.Matcher(needle, fc).info()
+            ferr = None
+        except F.PanicError as e:
+            got, ferr = None, str(e)
+        assert (oerr is None) == (ferr is None), (needle, sc, oerr, ferr)
+        if oerr is not None:
+            assert ferr == oerr, (needle, sc)
+            agree_panics += 1
+        elif matching == "Fuzzy":
+            assert (got["pf_lanes"], got["sw_lanes"], got["use_u8"]) == (want["pf_lanes"], want["sw_lanes"], want["use_u8"]), (needle, sc)
+            ok += 1
+    assert agree_panics > 20 and ok > 300
