@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.environ.get("FRIZBEE_HIP_LIB", os.path.join(_HERE, "libfrizbee_hip.so"))
 
 MATCH_DTYPE = np.dtype([("index", "<u4"), ("score", "<u2"), ("exact", "u1"), ("_pad", "u1")])
+MATCH_INDICES_DTYPE = np.dtype([("index", "<u4"), ("score", "<u2"), ("exact", "u1"), ("_pad", "u1"), ("positions_begin", "<u4"), ("positions_len", "<u4")])
 
 
 class FrizbeeError(RuntimeError):
@@ -110,7 +111,7 @@ SYMBOLS = [
     "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
     "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
-    "fzb_parse_query", "fzb_patterns_free",
+    "fzb_parse_query", "fzb_patterns_free", "fzb_match_list_indices", "fzb_match_indices_free",
 ]
 
 
@@ -154,6 +155,8 @@ def lib():
         l.fzb_multi_matcher_len.restype = C.c_size_t
         l.fzb_multi_match_list.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzb_multi_match_list_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        l.fzb_match_list_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        l.fzb_match_indices_free.argtypes = [C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
 
@@ -305,6 +308,21 @@ class MultiMatcher:
             pass
 
 
+class MatchIndices:
+    """`frizbee::MatchIndices` (src/lib.rs:189-199)"""
+
+    __slots__ = ("index", "score", "exact", "indices")
+
+    def __init__(self, index, score, exact, indices):
+        self.index, self.score, self.exact, self.indices = index, score, exact, indices
+
+    def __eq__(self, o):
+        return (self.index, self.score, self.exact, self.indices) == (o.index, o.score, o.exact, o.indices)
+
+    def __repr__(self):
+        return f"MatchIndices(index={self.index}, score={self.score}, exact={self.exact}, indices={self.indices})"
+
+
 class Matcher:
     """`frizbee::Matcher` for one (non-negated, fuzzy) pattern: `Matcher::new(needle, &config)` (src/matcher/mod.rs:90-92)."""
 
@@ -349,6 +367,25 @@ class Matcher:
         out, n = C.c_void_p(), C.c_size_t()
         _check(lib().fzb_match_list_parallel(self.h, cp.h, threads, C.byref(out), C.byref(n)))
         return _take(out, n)
+
+    def match_list_indices(self, haystacks, selection=None):
+        """`Matcher::match_list_indices` (src/matcher/mod.rs:234-275): list of `MatchIndices` (src/lib.rs:189-199), the matched byte
+        positions in reverse order.  `selection` (corpus indices) plays the role of the haystack list - typically the top of a
+        `match_list` result over a resident `Corpus`; `index` then numbers the selection."""
+        cp = self._corpus(haystacks)
+        sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.uint32)
+        out, n, pos = C.c_void_p(), C.c_size_t(), C.c_void_p()
+        _check(lib().fzb_match_list_indices(self.h, cp.h, sel.ctypes.data if sel is not None and len(sel) else None, 0 if sel is None else len(sel), C.byref(out), C.byref(n), C.byref(pos)))
+        try:
+            if sel is not None and len(sel) == 0:
+                return []
+            recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 16,))[: n.value * 16].view(MATCH_INDICES_DTYPE).copy()
+            total = int((recs["positions_begin"].astype(np.int64) + recs["positions_len"]).max()) if len(recs) else 0
+            flat = np.ctypeslib.as_array(C.cast(pos, C.POINTER(C.c_uint32)), shape=(max(total, 1),)).copy()
+        finally:
+            lib().fzb_match_indices_free(out, pos)
+        return [MatchIndices(int(r["index"]), int(r["score"]), bool(r["exact"]), flat[int(r["positions_begin"]) : int(r["positions_begin"]) + int(r["positions_len"])].tolist())
+                for r in recs]
 
     def match_list_into(self, haystacks, first=0, count=None, index_offset=0):
         """`Specialized::match_list(haystacks, haystack_index_offset, &mut matches)` (src/matcher/algo.rs:78-103): unsorted, input order."""

@@ -81,6 +81,9 @@ struct Workspace {
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
     size_t cap_level2;  // capacity of the second-level arrays (0 = not allocated)
     bool tables_stale;  // the matcher's needle / config changed since `table` and `dfa` were uploaded
+    // matched-indices path (fzb_match_list_indices)
+    u32* trace_cells;   // per-wave score / match matrices of the traced scorer
+    size_t trace_cells_words;
 };
 
 struct LaunchCfg {
@@ -129,8 +132,12 @@ void fzb_launch_copy_records(const fzb_match_rec* in, const u32* n_ptr, fzb_matc
 void fzb_launch_literal_filter(const CorpusDev& c, u64 first, u32 count, const u32* items, const u32* n_items_ptr, const NeedleDev& nd, int mode, u64* bitmap, u32* tile_counts,
                                int grid, hipStream_t st);
 void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* n_items_ptr, const NeedleDev& nd, int mode, fzb_match_rec* out,
-                              u32 capacity, u32* dev_count, int grid, hipStream_t st);
+                              u32 capacity, u32* dev_count, u32* tpos, u32* tnpos, u32 tstride, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st);
+size_t fzb_trace_scratch_words(const NeedleDev& nd, int grid);
+void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleDev& nd,
+                              int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u32* cells, u32* pos, u32* npos, u32 stride,
+                              int grid, hipStream_t st);
 #endif

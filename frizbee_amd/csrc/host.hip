@@ -184,6 +184,11 @@ struct fzb_matcher {
     fzb_match_rec* out_dev = nullptr;
     size_t out_cap = 0;
     u32* count_dev = nullptr;
+    // fzb_match_list_indices: the selection (+ its length), the positions (`stride` per record) and their counts
+    u32* trace_sel = nullptr;
+    u32* trace_pos = nullptr;
+    u32* trace_npos = nullptr;
+    size_t trace_cap = 0, trace_pos_words = 0;
 };
 
 extern "C" {
@@ -202,7 +207,8 @@ void fzb_config_default(fzb_config* out) {
 }
 
 static void free_workspace(Workspace& w) {
-    void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa};
+    void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
+                    w.trace_cells};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -386,6 +392,8 @@ void fzb_matcher_free(fzb_matcher* m) {
     free_workspace(m->ws);
     if (m->out_dev) (void)hipFree(m->out_dev);
     if (m->count_dev) (void)hipFree(m->count_dev);
+    for (void* p : {(void*)m->trace_sel, (void*)m->trace_pos, (void*)m->trace_npos})
+        if (p) (void)hipFree(p);
     for (auto& tr : m->evring)
         for (auto& e : tr)
             if (e) (void)hipEventDestroy(e);
@@ -541,10 +549,18 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
 // The pipeline.  items_in == nullptr: the haystacks are the contiguous range [first, first + count).  Otherwise they are the
 // listed ones, items_in[j] = index relative to `first`, *n_items_in of them (a device-side count <= count): the narrowing
 // step of the multi-pattern composition.
+// `trace` != nullptr: the matched-indices form - every record also gets its matched byte positions (the traced generic scorer
+// replaces the fast scorers; literal modes write the needle run).
+struct TraceOut {
+    u32* pos;
+    u32* npos;
+    u32 stride;
+};
 static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, const u32* items_in, const u32* n_items_in,
-                        fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream) {
+                        fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream, const TraceOut* trace = nullptr) {
     if (!m || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
-    if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
+    // an item list may repeat haystacks, so only the contiguous form bounds `count` by the corpus
+    if (first > c->dev.n || (!items_in && count > c->dev.n - first)) return fail(FZB_ERR_INVALID, "range outside the corpus");
     // guard_against_haystack_overflow (src/matcher/mod.rs:438-446)
     if ((u64)count + (u64)index_offset > 0xFFFFFFFFull)
         return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
@@ -593,7 +609,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("literal filter");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, items_in ? n_items_in : nullptr, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
         FZB_STAGE("literal compact");
-        fzb_launch_literal_score(cd, first, index_offset, w.surv_idx, &cnt_c[0], nd, m->literal_mode, (fzb_match_rec*)dev_out, cap32, dev_count, cus * 4, st);
+        fzb_launch_literal_score(cd, first, index_offset, w.surv_idx, &cnt_c[0], nd, m->literal_mode, (fzb_match_rec*)dev_out, cap32, dev_count, trace ? trace->pos : nullptr,
+                                 trace ? trace->npos : nullptr, trace ? trace->stride : 0u, cus * 4, st);
         FZB_STAGE("literal score");
         HIPCHK(hipGetLastError());
         return FZB_OK;
@@ -653,7 +670,21 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     fzb_match_rec* outp = (fzb_match_rec*)dev_out;
     const u32 qcap = cnt;  // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back
     const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
-    if (nd.unicode && lc.bias_ok) {
+    if (trace) {
+        // matched indices: one traced generic scorer for every window width, ASCII and unicode (kernels_generic.hip)
+        const int tgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)cus / 2, (count + 3) / 4));
+        const size_t words = fzb_trace_scratch_words(nd, tgrid);
+        if (w.trace_cells_words < words) {
+            if (w.trace_cells) HIPCHK(hipFree(w.trace_cells));
+            w.trace_cells = nullptr;
+            w.trace_cells_words = 0;
+            HIPCHK(dev_alloc((void**)&w.trace_cells, words * 4));
+            w.trace_cells_words = words;
+        }
+        fzb_launch_generic_trace(cd, first, index_offset, items, win, wmode, n_items_ptr, nd, lc.sw_lanes, nd.unicode, outp, cap32, dev_count, cnt_c, w.trace_cells, trace->pos,
+                                 trace->npos, trace->stride, tgrid, st);
+        FZB_STAGE("generic(trace)");
+    } else if (nd.unicode && lc.bias_ok) {
         fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
@@ -855,6 +886,105 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
     if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
     if (threads == 0) return fail(FZB_ERR_PANIC, "threads must be positive");  // parallel.rs:24
     return fzb_match_list(m, c, out, out_len);
+}
+
+// ---- matched indices: Matcher::match_list_indices (src/matcher/mod.rs:234-275) ------------------------------------------------
+int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
+                           uint32_t** out_positions) {
+    if (!m || !c || !out || !out_len || !out_positions || (!selection && n_selection)) return fail(FZB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    *out_len = 0;
+    *out_positions = nullptr;
+    const size_t count = selection ? n_selection : (size_t)c->dev.n;
+    if ((u64)count > 0xFFFFFFFFull)  // guard_against_haystack_overflow(haystacks.len(), 0), mod.rs:235
+        return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count) + " > 4294967295 (index offset: 0)");
+    for (size_t i = 0; i < n_selection; i++)
+        if (selection[i] >= c->dev.n) return fail(FZB_ERR_INVALID, "selection entry outside the corpus");
+    const int sort = m->config.sort;
+    const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;          // mod.rs:268-270
+    const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;  // mod.rs:271-273
+    std::vector<fzb_match_indices> recs;
+    std::vector<u32> positions;
+    if (m->empty) {  // CompiledPatterns::Empty (mod.rs:237-246): every index, no positions, reversed if the strategy says so
+        recs.resize(count);
+        for (size_t i = 0; i < count; i++) recs[i] = fzb_match_indices{(uint32_t)(reversed ? count - 1 - i : i), 0, 0, 0, 0, 0};
+    } else if (count) {
+        Workspace& w = m->ws;
+        const u32 stride = (u32)std::max(1, m->nd.nbytes);
+        if (m->trace_cap < count || m->trace_pos_words < count * (size_t)stride) {
+            for (void* p : {(void*)m->trace_sel, (void*)m->trace_pos, (void*)m->trace_npos})
+                if (p) HIPCHK(hipFree(p));
+            m->trace_sel = m->trace_pos = m->trace_npos = nullptr;
+            m->trace_cap = m->trace_pos_words = 0;
+            HIPCHK(dev_alloc((void**)&m->trace_sel, (count + 4) * 4));  // [count] = the list length
+            HIPCHK(dev_alloc((void**)&m->trace_npos, count * 4));
+            HIPCHK(dev_alloc((void**)&m->trace_pos, count * (size_t)stride * 4));
+            m->trace_cap = count;
+            m->trace_pos_words = count * (size_t)stride;
+        }
+        if (m->out_cap < count || !m->count_dev) {
+            if (m->out_dev) (void)hipFree(m->out_dev);
+            m->out_dev = nullptr;
+            m->out_cap = 0;
+            HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
+            m->out_cap = count;
+            if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
+        }
+        const u32* items_dev = nullptr;
+        const u32* n_items_dev = nullptr;
+        if (selection) {
+            const u32 n32 = (u32)count;
+            HIPCHK(hipMemcpy(m->trace_sel, selection, count * 4, hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(m->trace_sel + count, &n32, 4, hipMemcpyHostToDevice));
+            items_dev = m->trace_sel;
+            n_items_dev = m->trace_sel + count;
+        }
+        const TraceOut tr{m->trace_pos, m->trace_npos, stride};
+        int rc = run_pipeline(m, c, 0, count, 0, items_dev, n_items_dev, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr, &tr);
+        if (rc) return rc;
+        u32 n = 0;
+        HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));
+        std::vector<fzb_match_rec> dev_recs(n);
+        std::vector<u32> npos(n), pos((size_t)n * stride);
+        if (n) {
+            HIPCHK(hipMemcpy(dev_recs.data(), m->out_dev, (size_t)n * sizeof(fzb_match_rec), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(npos.data(), m->trace_npos, (size_t)n * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(pos.data(), m->trace_pos, (size_t)n * stride * 4, hipMemcpyDeviceToHost));
+        }
+        recs.resize(n);
+        size_t sel_at = 0;  // records come back in list order, so each one is the next selection entry that names its haystack
+        for (u32 j = 0; j < n; j++) {
+            u32 index = dev_recs[j].index;
+            if (selection) {
+                while (sel_at < count && selection[sel_at] != index) sel_at++;
+                if (sel_at == count) return fail(FZB_ERR_HIP, "internal: record outside the selection");
+                index = (u32)sel_at++;
+            }
+            const u32 len = std::min(npos[j], stride);
+            recs[j] = fzb_match_indices{index, dev_recs[j].score, dev_recs[j].exact, 0, (uint32_t)positions.size(), len};
+            positions.insert(positions.end(), pos.begin() + (size_t)j * stride, pos.begin() + (size_t)j * stride + len);
+        }
+        if (reversed) std::reverse(recs.begin(), recs.end());
+        if (by_score) std::stable_sort(recs.begin(), recs.end(), [](const fzb_match_indices& a, const fzb_match_indices& b) { return a.score > b.score; });
+    }
+    fzb_match_indices* r = (fzb_match_indices*)malloc(std::max<size_t>(recs.size(), 1) * sizeof(fzb_match_indices));
+    u32* p = (u32*)malloc(std::max<size_t>(positions.size(), 1) * 4);
+    if (!r || !p) {
+        free(r);
+        free(p);
+        return fail(FZB_ERR_INVALID, "out of memory");
+    }
+    if (!recs.empty()) memcpy(r, recs.data(), recs.size() * sizeof(fzb_match_indices));
+    if (!positions.empty()) memcpy(p, positions.data(), positions.size() * 4);
+    *out = r;
+    *out_len = recs.size();
+    *out_positions = p;
+    return FZB_OK;
+}
+
+void fzb_match_indices_free(fzb_match_indices* matches, uint32_t* positions) {
+    free(matches);
+    free(positions);
 }
 
 // ---- query syntax: Pattern::parse / Pattern::parse_query (src/pattern.rs:87-222) ---------------------------------------------

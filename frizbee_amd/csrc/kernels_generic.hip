@@ -31,8 +31,11 @@ __device__ __forceinline__ u32 shift_pad_reg(u32 v, int k, u32 adjv, int lane) {
 }
 
 // match_greedy (src/smith_waterman/greedy.rs:7-91), run by one lane
-__device__ u32 greedy_score(const NeedleDev& nd, const u8* __restrict__ h, u32 hlen, bool include_prefix) {
+// `fwd` (optional): receives the haystack position matched by every needle byte, in needle order
+__device__ u32 greedy_score(const NeedleDev& nd, const u8* __restrict__ h, u32 hlen, bool include_prefix, u32* __restrict__ fwd = nullptr,
+                        bool* matched = nullptr) {
     const u32 n = (u32)nd.nbytes;
+    if (matched) *matched = false;
     if (n > hlen) return 0;
     u32 score = 0, hi = 0;
     bool dben = false, prev_lower = false, prev_delim = false;
@@ -53,6 +56,7 @@ __device__ u32 greedy_score(const NeedleDev& nd, const u8* __restrict__ h, u32 h
                 continue;
             }
             score = sadd(score, nd.match_score);
+            if (fwd) fwd[ni] = hi;
             if (hi != hstart && ni != 0) {
                 u32 gl = hi - hstart;
                 gl = gl > 0 ? gl - 1 : 0;
@@ -73,14 +77,28 @@ __device__ u32 greedy_score(const NeedleDev& nd, const u8* __restrict__ h, u32 h
         }
         if (!found) return 0;
     }
+    if (matched) *matched = true;
     return score;
 }
 
-template <int SWL, bool UNICODE, typename ET>
+// TRACE = the matched-indices form (src/smith_waterman/algo/mod.rs:49-152, alignment_iter.rs:35-181): direct mode only; every
+// (row, column) cell is also written to the wave's slot of `trace.cells` (score | match bit << 16, the reference's score_matrix
+// and match_masks), and lane 0 then walks the alignment back from the first column of the last row that holds the score,
+// writing the matched byte positions (reverse order, as the reference returns them) to trace.pos[opos * stride ..].
+struct TraceArgs {
+    u32* cells;   // per wave: (rows + 1) x TRACE_W dwords
+    u32* pos;     // per output record: `stride` positions
+    u32* npos;    // per output record: how many
+    u32 stride;
+};
+#define TRACE_W (FZB_MAX_HAYSTACK_LEN + 2 * 64)  // columns: the zero chunk + up to 1024 bytes rounded up to a chunk
+
+template <int SWL, bool UNICODE, bool TRACE, typename ET>
 __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                               const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
                                                               const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
-                                                              fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters) {
+                                                              fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters,
+                                                              const TraceArgs trace) {
     // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row
     __shared__ u16 s_adj_row[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
     __shared__ u16 s_adj_aux[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
@@ -93,6 +111,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
     const u32 Mc = nd.match_plus_mismatch & LM, X = nd.mismatch & LM, gex = nd.gex & LM, gopm = nd.gopm & LM;
     const u32 caseb = nd.matching_case & LM, capb = nd.capitalization & LM, delimb = nd.delimiter & LM, prefixb = nd.prefix & LM;
     const bool active = lane < SWL;
+    u32* const cells = TRACE ? trace.cells + (size_t)(blockIdx.x * GEN_WAVES + wv) * (size_t)(rows + 1) * TRACE_W : nullptr;
 
     for (u32 q = blockIdx.x * GEN_WAVES + wv; q < nlist; q += gridDim.x * GEN_WAVES) {
         // list entries: (output position, window start, window end, local haystack index) queued by the single-chunk kernel
@@ -109,15 +128,44 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
         u32 ws, we;
         if (list) { ws = le[1]; we = le[2]; }
         else if (wmode == 2) { ws = 0; we = L; }
-        else { ws = win[2 * j]; we = win[2 * j + 1]; }
+        else if (TRACE && wmode == 1) {
+            // 0-typo ASCII window in its lane-free form (src/prefilter/algo/ascii.rs:6-72): first occurrence of the first needle
+            // byte, one past the last occurrence of the last one (either case); the haystack passed the exact filter
+            ws = 0xFFFFFFFFu;
+            we = 0;
+            for (u32 b = 0; b < L; b += 64) {
+                const u32 p = b + lane;
+                const u32 hb = p < L ? hay[p] : 0u;
+                const u64 mf = __ballot(p < L && (hb == nd.c[0] || hb == nd.f[0]));
+                const u64 ml = __ballot(p < L && (hb == nd.c[rows - 1] || hb == nd.f[rows - 1]));
+                if (mf && ws == 0xFFFFFFFFu) ws = b + (u32)__builtin_ctzll(mf);
+                if (ml) we = b + 64u - (u32)__builtin_clzll(ml);
+            }
+            if (ws == 0xFFFFFFFFu) ws = 0;
+        } else { ws = win[2 * j]; we = win[2 * j + 1]; }
         const u32 sp = ws ? ws - 1 : 0;
         const bool include_exact = sp == 0 && we == L;
         const bool include_prefix = sp == 0;
         const u32 m = we - sp;
         const u8* th = hay + sp;  // trimmed haystack
         u32 score = 0;
+        u32 npos = 0;  // TRACE: positions written for this record (lane 0)
+        u32* const posv = TRACE ? trace.pos + (size_t)opos * trace.stride : nullptr;
         if (m > FZB_MAX_HAYSTACK_LEN) {
-            if (lane == 0) score = greedy_score(nd, th, m, include_prefix);
+            if (lane == 0) {
+                if (TRACE) {
+                    // match_greedy's positions, shifted by the trim offset and reversed (algo/mod.rs:55-72); None => no positions
+                    u32* fwd = cells;
+                    bool matched = false;
+                    score = greedy_score(nd, th, m, include_prefix, fwd, &matched);
+                    const u32 n = (u32)nd.nbytes;
+                    if (matched)
+                        for (u32 k = 0; k < n; k++) posv[k] = fwd[n - 1 - k] + sp;
+                    npos = matched ? n : 0;
+                } else {
+                    score = greedy_score(nd, th, m, include_prefix);
+                }
+            }
             score = __shfl(score, 0);
         } else if (m > 0 && rows > 0) {
             const u32 nchunks = (m + SWL - 1) / SWL;
@@ -248,6 +296,9 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                         s_adj_aux[wv][r][lane] = (u16)aux;
                     }
                     __builtin_amdgcn_wave_barrier();
+                    if (TRACE) {
+                        if (active) cells[(size_t)r * TRACE_W + base + SWL + lane] = row | (mm ? 0x10000u : 0u);
+                    }
                     carry_last = next_carry;
                     prev_row = row;
                     up_mm = mm ? 1 : 0;
@@ -258,6 +309,57 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
             // horizontal max
             for (int off = 32; off > 0; off >>= 1) maxs = max(maxs, (u32)__shfl_xor(maxs, off));
             score = maxs;
+            if (TRACE && score != 0) {
+                // first column of the last row holding the score (alignment_iter.rs:52-66).  The slot is reused from haystack to
+                // haystack, so every read of it goes around the vector L1 (agent-scope loads) after a fence.
+                __threadfence();
+                __builtin_amdgcn_wave_barrier();
+                u32 col = 0xFFFFFFFFu;
+                for (u32 ch = 0; ch < nchunks && col == 0xFFFFFFFFu; ch++) {
+                    const u32 v = active ? (__hip_atomic_load(&cells[(size_t)rows * TRACE_W + (ch + 1) * SWL + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFu) : 0u;
+                    const u64 hit = __ballot(active && v == score);
+                    if (hit) col = (ch + 1) * SWL + (u32)__builtin_ctzll(hit);
+                }
+                if (lane == 0 && col != 0xFFFFFFFFu) {
+                    auto cell = [&](u32 r, u32 c) -> u32 {
+                        if (r == 0 || c < (u32)SWL) return 0u;  // row 0 and the zero chunk
+                        return __hip_atomic_load(&cells[(size_t)r * TRACE_W + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    };
+                    const int mt = nd.max_typos;
+                    u32 r = rows, typos = 0, sc = score, prev = 0xFFFFFFFFu;
+                    for (;;) {
+                        if (r == 0) break;
+                        if (mt >= 0 && typos > (u32)mt) break;
+                        if (col < (u32)SWL || sc == 0) break;  // at the left edge (only moves up remain) or lost the alignment
+                        const u32 hidx = col - SWL;
+                        if (UNICODE && hidx < m && (th[hidx] & 0xC0) == 0x80) {  // continuation byte: walk left
+                            col--;
+                            sc = cell(r, col) & 0xFFFFu;
+                            continue;
+                        }
+                        if (cell(r, col) >> 16) {
+                            const u32 p = hidx + sp;
+                            if (UNICODE) {
+                                if (prev != p) {
+                                    for (int off = (int)nd.ulen[r - 1] - 1; off >= 0; off--)
+                                        if (npos < trace.stride) posv[npos++] = p + (u32)off;
+                                    prev = p;
+                                }
+                            } else if (npos < trace.stride) {
+                                posv[npos++] = p;
+                            }
+                            r--;
+                            col--;
+                            sc = cell(r, col) & 0xFFFFu;
+                            continue;
+                        }
+                        const u32 dg = cell(r - 1, col - 1) & 0xFFFFu, lf = cell(r, col - 1) & 0xFFFFu, upv = cell(r - 1, col) & 0xFFFFu;
+                        if (dg >= lf && dg >= upv) { r--; col--; typos++; sc = dg; }
+                        else if (lf >= upv) { col--; sc = lf; }
+                        else { typos++; r--; sc = upv; }
+                    }
+                }
+            }
         }
         if (lane == 0) {
             bool exact = include_exact && m == (u32)nd.nbytes;
@@ -270,13 +372,15 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
             rec.exact = exact ? 1 : 0;
             rec.valid = 0;
             out[opos] = rec;
+            if (TRACE) trace.npos[opos] = npos;
         }
     }
 }
 
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters)
+    const TraceArgs none{nullptr, nullptr, nullptr, 0};
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none)
 #define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
 #define FZB_K2C_U(SWL) do { if (unicode) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
     switch (sw_lanes) {
@@ -285,4 +389,23 @@ void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u
         case 16: FZB_K2C_U(16); break;
         default: FZB_K2C_U(8); break;
     }
+#undef FZB_K2C
+}
+
+// dwords of trace scratch the traced launch needs for `grid` blocks
+size_t fzb_trace_scratch_words(const NeedleDev& nd, int grid) { return (size_t)grid * GEN_WAVES * (size_t)(nd.rows + 1) * TRACE_W; }
+
+// the matched-indices form: direct mode over (items, win); record j at out[j], its positions at pos[j * stride ..], npos[j] of them
+void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleDev& nd,
+                              int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u32* cells, u32* pos, u32* npos, u32 stride,
+                              int grid, hipStream_t st) {
+    const TraceArgs tr{cells, pos, npos, stride};
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr)
+    switch (sw_lanes) {
+        case 64: FZB_K2C_U(64); break;
+        case 32: FZB_K2C_U(32); break;
+        case 16: FZB_K2C_U(16); break;
+        default: FZB_K2C_U(8); break;
+    }
+#undef FZB_K2C
 }

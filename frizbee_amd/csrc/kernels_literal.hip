@@ -168,11 +168,12 @@ __global__ __launch_bounds__(256) void k_literal_filter(const u8* __restrict__ b
     }
 }
 
-// pass 2: one thread per survivor (items = local haystack indices), record j at out[j]
+// pass 2: one thread per survivor (items = local haystack indices), record j at out[j].  With tpos != nullptr also the matched
+// byte positions (match_list_indices_impl, algo.rs:129-155: the whole needle run, reversed) at tpos[j * tstride ..], tnpos[j] of them.
 template <typename ET>
 __global__ __launch_bounds__(256) void k_literal_score(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
                                                        const u32* __restrict__ n_items_ptr, const NeedleDev nd, int mode, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                       u32* __restrict__ dev_count) {
+                                                       u32* __restrict__ dev_count, u32* __restrict__ tpos, u32* __restrict__ tnpos, u32 tstride) {
     const u32 M = *n_items_ptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
     for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < M && j < capacity; j += gridDim.x * blockDim.x) {
@@ -188,6 +189,11 @@ __global__ __launch_bounds__(256) void k_literal_score(const u8* __restrict__ by
         rec.exact = (pos == 0 && (u32)nd.nbytes == L) ? 1 : 0;  // algo.rs:113
         rec.valid = 0;
         out[j] = rec;
+        if (tpos) {
+            const u32 n = (u32)nd.nbytes;
+            for (u32 k = 0; k < n && k < tstride; k++) tpos[(size_t)j * tstride + k] = pos + (n - 1 - k);
+            tnpos[j] = n < tstride ? n : tstride;
+        }
     }
 }
 
@@ -197,7 +203,7 @@ void fzb_launch_literal_filter(const CorpusDev& c, u64 first, u32 count, const u
     else hipLaunchKernelGGL((k_literal_filter<u32>), dim3(grid), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, count, items, n_items_ptr, nd, mode, bitmap, tile_counts);
 }
 void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* n_items_ptr, const NeedleDev& nd, int mode, fzb_match_rec* out,
-                              u32 capacity, u32* dev_count, int grid, hipStream_t st) {
-    if (c.ends_u64) hipLaunchKernelGGL((k_literal_score<u64>), dim3(grid), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count);
-    else hipLaunchKernelGGL((k_literal_score<u32>), dim3(grid), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count);
+                              u32 capacity, u32* dev_count, u32* tpos, u32* tnpos, u32 tstride, int grid, hipStream_t st) {
+    if (c.ends_u64) hipLaunchKernelGGL((k_literal_score<u64>), dim3(grid), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count, tpos, tnpos, tstride);
+    else hipLaunchKernelGGL((k_literal_score<u32>), dim3(grid), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count, tpos, tnpos, tstride);
 }

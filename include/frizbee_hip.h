@@ -138,6 +138,30 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
 
 void fzb_matches_free(fzb_match* p);
 
+/* `MatchIndices` (src/lib.rs:189-199): a Match plus the haystack byte positions that matched the needle, in reverse
+ * order.  positions[positions_begin .. positions_begin + positions_len) of the array returned next to the records. */
+typedef struct fzb_match_indices {
+    uint32_t index;
+    uint16_t score;
+    uint8_t exact;
+    uint8_t _pad;
+    uint32_t positions_begin;
+    uint32_t positions_len;
+} fzb_match_indices;
+
+/* `Matcher::match_list_indices(&haystacks)` (src/matcher/mod.rs:234-275 -> match_list_indices_impl src/matcher/algo.rs:196-227,
+ * smith_waterman_indices_one :264-292, score_haystack[_unicode]_indices src/smith_waterman/algo/mod.rs:49-152, the traceback
+ * src/smith_waterman/alignment_iter.rs:35-181; literal modes src/literal/algo.rs:129-155), on the GPU: the scorer keeps its
+ * score / match matrices in HBM and walks the alignment back on the device.  The haystack list is the `selection`
+ * (n_selection corpus indices, host memory, any order, repeats allowed - typically the top of a fzb_match_list result) or,
+ * with selection == NULL, the whole corpus; `index` numbers that list like the reference numbers `haystacks`
+ * (selection[index] is the corpus index).  Order: as the reference, list order, reversed for the *Desc strategies, then a
+ * stable sort by descending score for the Score* strategies.  Single-pattern matchers only.  Free with
+ * fzb_match_indices_free. */
+int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection,
+                           fzb_match_indices** out, size_t* out_len, uint32_t** out_positions);
+void fzb_match_indices_free(fzb_match_indices* matches, uint32_t* positions);
+
 /* `radix_sort_matches(&mut [Match])` (src/sort.rs:6-40): stable, descending score, host side */
 void fzb_radix_sort_matches(fzb_match* matches, size_t n);
 /* `k_merge_matches_by_*` (src/k_merge.rs:56-132): merges per-shard runs (each sorted per `sort`) - the

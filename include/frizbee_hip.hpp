@@ -9,7 +9,7 @@
 //   CaseMatching / UnicodeMatching / SortStrategy / Matching  src/lib.rs:311-427   enum classes of the same names
 //   Match { index, score, exact }          src/lib.rs:141-153             frizbee::Match
 //   Pattern, PatternConfig, parse_query    src/pattern.rs:9-18, 186-262   frizbee::Pattern, frizbee::PatternConfig
-//   Matcher::new / from_patterns / from_query / set_pattern / set_config / match_list / match_list_parallel
+//   Matcher::new / from_patterns / from_query / set_pattern / set_config / match_list / match_list_parallel / match_list_indices
 //                                          src/matcher/mod.rs:90-222, parallel.rs:18-89          frizbee::Matcher
 //   (the borrowed &[S: AsRef<str>])                                        frizbee::Corpus: the list packed once, resident in HBM
 #pragma once
@@ -99,6 +99,14 @@ struct Match {  // src/lib.rs:141-153
     uint16_t score;
     bool exact;
     bool operator==(const Match& o) const { return index == o.index && score == o.score && exact == o.exact; }
+};
+
+struct MatchIndices {  // src/lib.rs:189-199
+    uint16_t score;
+    uint32_t index;
+    bool exact;
+    std::vector<uint32_t> indices;  // matched haystack byte positions, reverse order
+    bool operator==(const MatchIndices& o) const { return index == o.index && score == o.score && exact == o.exact && indices == o.indices; }
 };
 
 struct PatternConfig {  // src/pattern.rs:230-244: every field optional, nullopt inherits the matcher's Config
@@ -207,6 +215,31 @@ class Matcher {  // src/matcher/mod.rs:77-222
     }
     template <typename Strings>
     std::vector<Match> match_list(const Strings& haystacks) { return match_list(Corpus(haystacks)); }
+
+    // `match_list_indices(&haystacks)` (src/matcher/mod.rs:234-275).  `selection`: corpus indices standing in for the haystack
+    // list (the top of a match_list result); empty optional = the whole corpus.  Single-pattern matchers only.
+    std::vector<MatchIndices> match_list_indices(const Corpus& corpus, const std::optional<std::vector<uint32_t>>& selection = std::nullopt) {
+        if (selection && selection->empty()) return {};
+        if (!single_ && multi_ && fzb_multi_matcher_len(multi_.get()) == 0) {  // CompiledPatterns::Empty (mod.rs:237-246): every index, no positions
+            const size_t n = selection ? selection->size() : fzb_corpus_len(corpus.raw());
+            const bool reversed = config_.sort_ == SortStrategy::IndexDesc || config_.sort_ == SortStrategy::ScoreThenIndexDesc;
+            std::vector<MatchIndices> v(n);
+            for (size_t i = 0; i < n; i++) v[i] = MatchIndices{0, (uint32_t)(reversed ? n - 1 - i : i), false, {}};
+            return v;
+        }
+        if (!single_) throw Error(FZB_ERR_INVALID, "match_list_indices: multi-pattern matchers are not supported on the device");
+        fzb_match_indices* out = nullptr;
+        uint32_t* pos = nullptr;
+        size_t n = 0;
+        check(fzb_match_list_indices(single_.get(), corpus.raw(), selection ? selection->data() : nullptr, selection ? selection->size() : 0, &out, &n, &pos));
+        std::vector<MatchIndices> v(n);
+        for (size_t i = 0; i < n; i++)
+            v[i] = MatchIndices{out[i].score, out[i].index, out[i].exact != 0, std::vector<uint32_t>(pos + out[i].positions_begin, pos + out[i].positions_begin + out[i].positions_len)};
+        fzb_match_indices_free(out, pos);
+        return v;
+    }
+    template <typename Strings>
+    std::vector<MatchIndices> match_list_indices(const Strings& haystacks) { return match_list_indices(Corpus(haystacks)); }
 
     // `match_list_parallel(&haystacks, threads)`: same result for every thread count; threads == 0 panics like the reference
     std::vector<Match> match_list_parallel(const Corpus& corpus, size_t threads) {

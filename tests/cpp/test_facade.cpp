@@ -101,6 +101,30 @@ static void gpu_side() {
         auto matches = Matcher("fBr").match_list(std::vector<std::string>{"fooBar", "foo_bar", "barfoo", "prelude", "println!"});
         CHECK(matches.size() == 1 && (matches[0] == Match{0, 53, false}));
     }
+    {  // match_list_indices: the scorer's known answers (src/smith_waterman/mod.rs:323-325, 454-456), src/matcher/mod.rs:605-616, 724-735
+        const Config none = Config().max_typos(std::nullopt);
+        CHECK((Matcher("abc", none).match_list_indices(std::vector<std::string>{"xabcabc"})[0].indices == std::vector<uint32_t>{3, 2, 1}));
+        CHECK((Matcher("ab", none).match_list_indices(std::vector<std::string>{"abab"})[0].indices == std::vector<uint32_t>{1, 0}));
+        CHECK((Matcher("a\xc3\xa9", none).match_list_indices(std::vector<std::string>{"a\xc3\xa9"})[0].indices == std::vector<uint32_t>{2, 1, 0}));
+        auto ix = Matcher("\xc3\xa9", Config().unicode(UnicodeMatching::Ignore)).match_list_indices(std::vector<std::string>{"xx\xc3\xa9"});
+        CHECK(ix.size() == 1);
+        if (ix.size() == 1) {
+            std::sort(ix[0].indices.begin(), ix[0].indices.end());
+            CHECK((ix[0].indices == std::vector<uint32_t>{2, 3}));
+        }
+        auto all = Matcher("").match_list_indices(std::vector<std::string>{"foo", "bar"});
+        CHECK(all.size() == 2 && all[0].index == 0 && all[1].index == 1 && all[0].indices.empty());
+        // positions for the top of a match_list result over a resident corpus
+        const Corpus corpus(haystack);
+        Matcher m("deadbe");
+        auto top = m.match_list(corpus);
+        std::vector<uint32_t> sel;
+        for (const Match& t : top) sel.push_back(t.index);
+        auto pos = m.match_list_indices(corpus, sel);
+        CHECK(pos.size() == top.size());
+        for (size_t i = 0; i < pos.size() && i < top.size(); i++)
+            CHECK(pos[i].index == i && pos[i].score == top[i].score && pos[i].exact == top[i].exact && (pos[i].indices == std::vector<uint32_t>{5, 4, 3, 2, 1, 0}));
+    }
     {  // literal modes (src/literal/mod.rs:55-91)
         const Config ia = Config().sort(SortStrategy::IndexAsc);
         CHECK((indices(Matcher("foo", ia.matching(Matching::Exact)).match_list(std::vector<std::string>{"foo", "foobar", "xfoo", "FOO"})) == std::vector<uint32_t>{0, 3}));

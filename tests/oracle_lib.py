@@ -218,6 +218,17 @@ class Matcher:
             self.lib.fzo_free(p)
         return recs, [flat[int(offs[i]) : int(offs[i + 1])].tolist() for i in range(n.value)]
 
+    def match_list_indices_ordered(self, haystacks):
+        """`Matcher::match_list_indices` with its ordering step (src/matcher/mod.rs:268-273: reverse for the *Desc strategies, then a
+        stable sort by descending score for the Score* ones): list of (index, score, exact, indices)."""
+        recs, idx = self.match_list_indices(haystacks)
+        items = [(int(r["index"]), int(r["score"]), bool(r["exact"]), ix) for r, ix in zip(recs, idx)]
+        if self.cfg.sort in (SORT["IndexDesc"], SORT["ScoreThenIndexDesc"]):
+            items.reverse()
+        if self.cfg.sort in (SORT["ScoreThenIndexAsc"], SORT["ScoreThenIndexDesc"]):
+            items.sort(key=lambda t: -t[1])  # list.sort is stable, like sort_by_key
+        return items
+
     def match_list_parallel(self, haystacks, threads):
         return self.match_packed(*pack(haystacks), threads=threads)
 

@@ -1,8 +1,8 @@
 """Traceback / matched indices: the oracle's restatement of src/smith_waterman/alignment_iter.rs and
 score_haystack[_unicode]_indices (src/smith_waterman/algo/mod.rs:49-152) against the reference's known answers.  The walk
 reads the stored score matrix and match masks cell by cell (with diag >= left >= up tie-breaking), so these vectors pin the
-matrices the scorer builds, not only their maxima.  (The product delegates `*_indices` to the reference's CPU code - see
-INTEGRATION.md - so this is oracle-side only.)"""
+matrices the scorer builds, not only their maxima.  (The HIP path's `fzb_match_list_indices` is checked against this
+restatement in tests/test_gpu_indices.py.)"""
 import json
 import os
 
