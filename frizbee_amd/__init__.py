@@ -111,7 +111,7 @@ SYMBOLS = [
     "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
     "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
-    "fzb_parse_query", "fzb_patterns_free", "fzb_match_list_indices", "fzb_match_indices_free",
+    "fzb_parse_query", "fzb_patterns_free", "fzb_match_list_indices", "fzb_match_indices_free", "fzb_multi_match_list_indices",
 ]
 
 
@@ -157,6 +157,7 @@ def lib():
         l.fzb_multi_match_list_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         l.fzb_match_list_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         l.fzb_match_indices_free.argtypes = [C.c_void_p, C.c_void_p]
+        l.fzb_multi_match_list_indices.argtypes = l.fzb_match_list_indices.argtypes
         _lib = l
     return _lib
 
@@ -295,6 +296,12 @@ class MultiMatcher:
         _check(lib().fzb_multi_match_list(self.h, cp.h, C.byref(out), C.byref(n)))
         return _take(out, n, copy)
 
+    def match_list_indices(self, haystacks, selection=None):
+        """`Matcher::match_list_indices` over the compiled patterns (`match_one_indices_multi`, src/matcher/multi.rs:56-82); see
+        `Matcher.match_list_indices` for `selection`."""
+        cp = haystacks if isinstance(haystacks, Corpus) else Corpus(haystacks)
+        return _match_list_indices(lib().fzb_multi_match_list_indices, self.h, cp, selection)
+
     def match_list_device(self, corpus, dev_out_ptr, capacity, dev_count_ptr, stream=0, first=0, count=None, index_offset=0):
         count = len(corpus) - first if count is None else count
         _check(lib().fzb_multi_match_list_device(self.h, corpus.h, first, count, index_offset, dev_out_ptr, capacity, dev_count_ptr, stream))
@@ -306,6 +313,22 @@ class MultiMatcher:
                 self.h = None
         except Exception:
             pass
+
+
+def _match_list_indices(fn, handle, cp, selection):
+    sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.uint32)
+    if sel is not None and len(sel) == 0:
+        return []
+    out, n, pos = C.c_void_p(), C.c_size_t(), C.c_void_p()
+    _check(fn(handle, cp.h, sel.ctypes.data if sel is not None else None, 0 if sel is None else len(sel), C.byref(out), C.byref(n), C.byref(pos)))
+    try:
+        recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 16,))[: n.value * 16].view(MATCH_INDICES_DTYPE).copy()
+        total = int((recs["positions_begin"].astype(np.int64) + recs["positions_len"]).max()) if len(recs) else 0
+        flat = np.ctypeslib.as_array(C.cast(pos, C.POINTER(C.c_uint32)), shape=(max(total, 1),)).copy()
+    finally:
+        lib().fzb_match_indices_free(out, pos)
+    return [MatchIndices(int(r["index"]), int(r["score"]), bool(r["exact"]), flat[int(r["positions_begin"]) : int(r["positions_begin"]) + int(r["positions_len"])].tolist())
+            for r in recs]
 
 
 class MatchIndices:
@@ -372,20 +395,7 @@ class Matcher:
         """`Matcher::match_list_indices` (src/matcher/mod.rs:234-275): list of `MatchIndices` (src/lib.rs:189-199), the matched byte
         positions in reverse order.  `selection` (corpus indices) plays the role of the haystack list - typically the top of a
         `match_list` result over a resident `Corpus`; `index` then numbers the selection."""
-        cp = self._corpus(haystacks)
-        sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.uint32)
-        out, n, pos = C.c_void_p(), C.c_size_t(), C.c_void_p()
-        _check(lib().fzb_match_list_indices(self.h, cp.h, sel.ctypes.data if sel is not None and len(sel) else None, 0 if sel is None else len(sel), C.byref(out), C.byref(n), C.byref(pos)))
-        try:
-            if sel is not None and len(sel) == 0:
-                return []
-            recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 16,))[: n.value * 16].view(MATCH_INDICES_DTYPE).copy()
-            total = int((recs["positions_begin"].astype(np.int64) + recs["positions_len"]).max()) if len(recs) else 0
-            flat = np.ctypeslib.as_array(C.cast(pos, C.POINTER(C.c_uint32)), shape=(max(total, 1),)).copy()
-        finally:
-            lib().fzb_match_indices_free(out, pos)
-        return [MatchIndices(int(r["index"]), int(r["score"]), bool(r["exact"]), flat[int(r["positions_begin"]) : int(r["positions_begin"]) + int(r["positions_len"])].tolist())
-                for r in recs]
+        return _match_list_indices(lib().fzb_match_list_indices, self.h, self._corpus(haystacks), selection)
 
     def match_list_into(self, haystacks, first=0, count=None, index_offset=0):
         """`Specialized::match_list(haystacks, haystack_index_offset, &mut matches)` (src/matcher/algo.rs:78-103): unsorted, input order."""

@@ -889,84 +889,92 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
 }
 
 // ---- matched indices: Matcher::match_list_indices (src/matcher/mod.rs:234-275) ------------------------------------------------
-int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
-                           uint32_t** out_positions) {
-    if (!m || !c || !out || !out_len || !out_positions || (!selection && n_selection)) return fail(FZB_ERR_INVALID, "null argument");
-    *out = nullptr;
-    *out_len = 0;
-    *out_positions = nullptr;
-    const size_t count = selection ? n_selection : (size_t)c->dev.n;
+namespace {
+// The haystack list of the *_indices entry points: a selection of the corpus, or all of it.
+int check_selection(const fzb_corpus* c, const uint32_t* selection, size_t n_selection, size_t& count) {
+    count = selection ? n_selection : (size_t)c->dev.n;
     if ((u64)count > 0xFFFFFFFFull)  // guard_against_haystack_overflow(haystacks.len(), 0), mod.rs:235
         return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count) + " > 4294967295 (index offset: 0)");
     for (size_t i = 0; i < n_selection; i++)
         if (selection[i] >= c->dev.n) return fail(FZB_ERR_INVALID, "selection entry outside the corpus");
-    const int sort = m->config.sort;
-    const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;          // mod.rs:268-270
-    const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;  // mod.rs:271-273
-    std::vector<fzb_match_indices> recs;
-    std::vector<u32> positions;
-    if (m->empty) {  // CompiledPatterns::Empty (mod.rs:237-246): every index, no positions, reversed if the strategy says so
+    return FZB_OK;
+}
+
+// One pattern over the list, LIST order (match_list_indices_impl, algo.rs:196-227): recs[k].index = position in the list,
+// its positions appended to `positions`.  An empty needle matches everything with no positions.
+int indices_in_list_order(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t count, std::vector<fzb_match_indices>& recs, std::vector<u32>& positions) {
+    recs.clear();
+    if (m->empty) {
         recs.resize(count);
-        for (size_t i = 0; i < count; i++) recs[i] = fzb_match_indices{(uint32_t)(reversed ? count - 1 - i : i), 0, 0, 0, 0, 0};
-    } else if (count) {
-        Workspace& w = m->ws;
-        const u32 stride = (u32)std::max(1, m->nd.nbytes);
-        if (m->trace_cap < count || m->trace_pos_words < count * (size_t)stride) {
-            for (void* p : {(void*)m->trace_sel, (void*)m->trace_pos, (void*)m->trace_npos})
-                if (p) HIPCHK(hipFree(p));
-            m->trace_sel = m->trace_pos = m->trace_npos = nullptr;
-            m->trace_cap = m->trace_pos_words = 0;
-            HIPCHK(dev_alloc((void**)&m->trace_sel, (count + 4) * 4));  // [count] = the list length
-            HIPCHK(dev_alloc((void**)&m->trace_npos, count * 4));
-            HIPCHK(dev_alloc((void**)&m->trace_pos, count * (size_t)stride * 4));
-            m->trace_cap = count;
-            m->trace_pos_words = count * (size_t)stride;
-        }
-        if (m->out_cap < count || !m->count_dev) {
-            if (m->out_dev) (void)hipFree(m->out_dev);
-            m->out_dev = nullptr;
-            m->out_cap = 0;
-            HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
-            m->out_cap = count;
-            if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
-        }
-        const u32* items_dev = nullptr;
-        const u32* n_items_dev = nullptr;
-        if (selection) {
-            const u32 n32 = (u32)count;
-            HIPCHK(hipMemcpy(m->trace_sel, selection, count * 4, hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(m->trace_sel + count, &n32, 4, hipMemcpyHostToDevice));
-            items_dev = m->trace_sel;
-            n_items_dev = m->trace_sel + count;
-        }
-        const TraceOut tr{m->trace_pos, m->trace_npos, stride};
-        int rc = run_pipeline(m, c, 0, count, 0, items_dev, n_items_dev, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr, &tr);
-        if (rc) return rc;
-        u32 n = 0;
-        HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));
-        std::vector<fzb_match_rec> dev_recs(n);
-        std::vector<u32> npos(n), pos((size_t)n * stride);
-        if (n) {
-            HIPCHK(hipMemcpy(dev_recs.data(), m->out_dev, (size_t)n * sizeof(fzb_match_rec), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(npos.data(), m->trace_npos, (size_t)n * 4, hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(pos.data(), m->trace_pos, (size_t)n * stride * 4, hipMemcpyDeviceToHost));
-        }
-        recs.resize(n);
-        size_t sel_at = 0;  // records come back in list order, so each one is the next selection entry that names its haystack
-        for (u32 j = 0; j < n; j++) {
-            u32 index = dev_recs[j].index;
-            if (selection) {
-                while (sel_at < count && selection[sel_at] != index) sel_at++;
-                if (sel_at == count) return fail(FZB_ERR_HIP, "internal: record outside the selection");
-                index = (u32)sel_at++;
-            }
-            const u32 len = std::min(npos[j], stride);
-            recs[j] = fzb_match_indices{index, dev_recs[j].score, dev_recs[j].exact, 0, (uint32_t)positions.size(), len};
-            positions.insert(positions.end(), pos.begin() + (size_t)j * stride, pos.begin() + (size_t)j * stride + len);
-        }
-        if (reversed) std::reverse(recs.begin(), recs.end());
-        if (by_score) std::stable_sort(recs.begin(), recs.end(), [](const fzb_match_indices& a, const fzb_match_indices& b) { return a.score > b.score; });
+        for (size_t i = 0; i < count; i++) recs[i] = fzb_match_indices{(uint32_t)i, 0, 0, 0, (uint32_t)positions.size(), 0};
+        return FZB_OK;
     }
+    if (!count) return FZB_OK;
+    const u32 stride = (u32)std::max(1, m->nd.nbytes);
+    if (m->trace_cap < count || m->trace_pos_words < count * (size_t)stride) {
+        for (void* p : {(void*)m->trace_sel, (void*)m->trace_pos, (void*)m->trace_npos})
+            if (p) HIPCHK(hipFree(p));
+        m->trace_sel = m->trace_pos = m->trace_npos = nullptr;
+        m->trace_cap = m->trace_pos_words = 0;
+        HIPCHK(dev_alloc((void**)&m->trace_sel, (count + 4) * 4));  // [count] = the list length
+        HIPCHK(dev_alloc((void**)&m->trace_npos, count * 4));
+        HIPCHK(dev_alloc((void**)&m->trace_pos, count * (size_t)stride * 4));
+        m->trace_cap = count;
+        m->trace_pos_words = count * (size_t)stride;
+    }
+    if (m->out_cap < count || !m->count_dev) {
+        if (m->out_dev) (void)hipFree(m->out_dev);
+        m->out_dev = nullptr;
+        m->out_cap = 0;
+        HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
+        m->out_cap = count;
+        if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
+    }
+    const u32* items_dev = nullptr;
+    const u32* n_items_dev = nullptr;
+    if (selection) {
+        const u32 n32 = (u32)count;
+        HIPCHK(hipMemcpy(m->trace_sel, selection, count * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(m->trace_sel + count, &n32, 4, hipMemcpyHostToDevice));
+        items_dev = m->trace_sel;
+        n_items_dev = m->trace_sel + count;
+    }
+    const TraceOut tr{m->trace_pos, m->trace_npos, stride};
+    int rc = run_pipeline(m, c, 0, count, 0, items_dev, n_items_dev, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr, &tr);
+    if (rc) return rc;
+    u32 n = 0;
+    HIPCHK(hipMemcpy(&n, m->count_dev, 4, hipMemcpyDeviceToHost));
+    std::vector<fzb_match_rec> dev_recs(n);
+    std::vector<u32> npos(n), pos((size_t)n * stride);
+    if (n) {
+        HIPCHK(hipMemcpy(dev_recs.data(), m->out_dev, (size_t)n * sizeof(fzb_match_rec), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(npos.data(), m->trace_npos, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pos.data(), m->trace_pos, (size_t)n * stride * 4, hipMemcpyDeviceToHost));
+    }
+    recs.resize(n);
+    size_t sel_at = 0;  // records come back in list order, so each one is the next selection entry that names its haystack
+    for (u32 j = 0; j < n; j++) {
+        u32 index = dev_recs[j].index;
+        if (selection) {
+            while (sel_at < count && selection[sel_at] != index) sel_at++;
+            if (sel_at == count) return fail(FZB_ERR_HIP, "internal: record outside the selection");
+            index = (u32)sel_at++;
+        }
+        const u32 len = std::min(npos[j], stride);
+        recs[j] = fzb_match_indices{index, dev_recs[j].score, dev_recs[j].exact, 0, (uint32_t)positions.size(), len};
+        positions.insert(positions.end(), pos.begin() + (size_t)j * stride, pos.begin() + (size_t)j * stride + len);
+    }
+    return FZB_OK;
+}
+
+// the ordering step (mod.rs:268-273) and the hand-over to the caller
+int finish_indices(std::vector<fzb_match_indices>& recs, const std::vector<u32>& positions, int sort, bool sort_by_score, fzb_match_indices** out, size_t* out_len,
+                   uint32_t** out_positions) {
+    const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;
+    const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;
+    if (reversed) std::reverse(recs.begin(), recs.end());
+    if (by_score && sort_by_score)  // `sort_by_key(|m| Reverse(m.score))`: stable
+        std::stable_sort(recs.begin(), recs.end(), [](const fzb_match_indices& a, const fzb_match_indices& b) { return a.score > b.score; });
     fzb_match_indices* r = (fzb_match_indices*)malloc(std::max<size_t>(recs.size(), 1) * sizeof(fzb_match_indices));
     u32* p = (u32*)malloc(std::max<size_t>(positions.size(), 1) * 4);
     if (!r || !p) {
@@ -980,6 +988,24 @@ int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* 
     *out_len = recs.size();
     *out_positions = p;
     return FZB_OK;
+}
+}  // namespace
+
+int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
+                           uint32_t** out_positions) {
+    if (!m || !c || !out || !out_len || !out_positions || (!selection && n_selection)) return fail(FZB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    *out_len = 0;
+    *out_positions = nullptr;
+    size_t count = 0;
+    int rc = check_selection(c, selection, n_selection, count);
+    if (rc) return rc;
+    std::vector<fzb_match_indices> recs;
+    std::vector<u32> positions;
+    rc = indices_in_list_order(m, c, selection, count, recs, positions);
+    if (rc) return rc;
+    // CompiledPatterns::Empty returns before the score sort (mod.rs:237-246) - all scores are 0 anyway
+    return finish_indices(recs, positions, m->config.sort, !m->empty, out, out_len, out_positions);
 }
 
 void fzb_match_indices_free(fzb_match_indices* matches, uint32_t* positions) {
@@ -1247,6 +1273,78 @@ int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match**
         HIPCHK(hipGetLastError());
     }
     return fetch_records(mm->out_dev, mm->count_dev, out, out_len);
+}
+
+// `Matcher::match_list_indices` over CompiledPatterns (mod.rs:234-275): Empty / Single as above; Multi = match_one_indices_multi
+// (multi.rs:56-82) for every haystack of the list.  Like match_list_multi_into, every pattern only sees the haystacks that are
+// still alive, and each pattern's positions come from the traced scorer on the device; the per-haystack union is host work.
+int fzb_multi_match_list_indices(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
+                                 uint32_t** out_positions) {
+    if (!mm || !c || !out || !out_len || !out_positions || (!selection && n_selection)) return fail(FZB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    *out_len = 0;
+    *out_positions = nullptr;
+    size_t count = 0;
+    int rc = check_selection(c, selection, n_selection, count);
+    if (rc) return rc;
+    std::vector<fzb_match_indices> recs;
+    std::vector<u32> positions;
+    if (mm->patterns.empty()) {  // CompiledPatterns::Empty
+        recs.resize(count);
+        for (size_t i = 0; i < count; i++) recs[i] = fzb_match_indices{(uint32_t)i, 0, 0, 0, 0, 0};
+        return finish_indices(recs, positions, mm->config.sort, false, out, out_len, out_positions);
+    }
+    if (mm->patterns.size() == 1 && !mm->patterns[0].negated) {  // CompiledPatterns::Single
+        rc = indices_in_list_order(mm->patterns[0].m, c, selection, count, recs, positions);
+        if (rc) return rc;
+        return finish_indices(recs, positions, mm->config.sort, true, out, out_len, out_positions);
+    }
+    // alive[k] = (position in the caller's list, corpus index); combined score / exact / positions per alive haystack
+    std::vector<u32> alive_pos(count), alive_idx(count);
+    for (size_t i = 0; i < count; i++) {
+        alive_pos[i] = (u32)i;
+        alive_idx[i] = selection ? selection[i] : (u32)i;
+    }
+    std::vector<u32> score(count, 0);
+    std::vector<u8> exact(count, 0);
+    std::vector<std::vector<u32>> found(count);
+    std::vector<fzb_match_indices> hits;
+    std::vector<u32> hit_positions;
+    for (auto& p : mm->patterns) {
+        if (alive_idx.empty()) break;
+        hit_positions.clear();
+        rc = indices_in_list_order(p.m, c, alive_idx.data(), alive_idx.size(), hits, hit_positions);
+        if (rc) return rc;
+        std::vector<u32> next_pos, next_idx;
+        if (p.negated) {  // a negated pattern that matches drops the haystack
+            size_t h = 0;
+            for (size_t k = 0; k < alive_idx.size(); k++) {
+                if (h < hits.size() && hits[h].index == k) { h++; continue; }
+                next_pos.push_back(alive_pos[k]);
+                next_idx.push_back(alive_idx[k]);
+            }
+        } else {  // every other pattern must match; scores add with saturation, exact flags OR, positions accumulate
+            for (const fzb_match_indices& hit : hits) {
+                const u32 at = alive_pos[hit.index];
+                score[at] = std::min<u32>(0xFFFFu, score[at] + hit.score);
+                exact[at] |= hit.exact;
+                found[at].insert(found[at].end(), hit_positions.begin() + hit.positions_begin, hit_positions.begin() + hit.positions_begin + hit.positions_len);
+                next_pos.push_back(at);
+                next_idx.push_back(alive_idx[hit.index]);
+            }
+        }
+        alive_pos.swap(next_pos);
+        alive_idx.swap(next_idx);
+    }
+    recs.reserve(alive_pos.size());
+    for (u32 at : alive_pos) {  // "Indices are reported in reverse order, and patterns may share matched chars" (multi.rs:75-77)
+        std::vector<u32>& f = found[at];
+        std::sort(f.begin(), f.end(), [](u32 a, u32 b) { return a > b; });
+        f.erase(std::unique(f.begin(), f.end()), f.end());
+        recs.push_back(fzb_match_indices{at, (uint16_t)score[at], exact[at], 0, (uint32_t)positions.size(), (uint32_t)f.size()});
+        positions.insert(positions.end(), f.begin(), f.end());
+    }
+    return finish_indices(recs, positions, mm->config.sort, true, out, out_len, out_positions);
 }
 
 void fzb_matches_free(fzb_match* p) {

@@ -156,8 +156,7 @@ typedef struct fzb_match_indices {
  * (n_selection corpus indices, host memory, any order, repeats allowed - typically the top of a fzb_match_list result) or,
  * with selection == NULL, the whole corpus; `index` numbers that list like the reference numbers `haystacks`
  * (selection[index] is the corpus index).  Order: as the reference, list order, reversed for the *Desc strategies, then a
- * stable sort by descending score for the Score* strategies.  Single-pattern matchers only.  Free with
- * fzb_match_indices_free. */
+ * stable sort by descending score for the Score* strategies.  Free with fzb_match_indices_free. */
 int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection,
                            fzb_match_indices** out, size_t* out_len, uint32_t** out_positions);
 void fzb_match_indices_free(fzb_match_indices* matches, uint32_t* positions);
@@ -199,6 +198,11 @@ void fzb_multi_matcher_free(fzb_multi_matcher* mm);
 size_t fzb_multi_matcher_len(const fzb_multi_matcher* mm); /* compiled (non-empty) patterns */
 /* `Matcher::match_list` over CompiledPatterns::{Empty, Single, Multi} (src/matcher/mod.rs:212-222, 373-392): ordered per config.sort */
 int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match** out, size_t* out_len);
+/* `Matcher::match_list_indices` for a `from_patterns` matcher (see fzb_match_list_indices): CompiledPatterns::Multi runs
+ * `match_one_indices_multi` (src/matcher/multi.rs:56-82) - a negated pattern that matches drops the haystack, every other pattern
+ * must match, scores add with saturation, exact flags OR, and the patterns' positions are merged (descending, de-duplicated). */
+int fzb_multi_match_list_indices(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection,
+                                 fzb_match_indices** out, size_t* out_len, uint32_t** out_positions);
 /* `match_list_multi_into(patterns, haystacks, haystack_index_offset, matches)` (src/matcher/multi.rs:84-152): index order, result in HBM */
 int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset,
                                 fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);

@@ -216,22 +216,17 @@ class Matcher {  // src/matcher/mod.rs:77-222
     template <typename Strings>
     std::vector<Match> match_list(const Strings& haystacks) { return match_list(Corpus(haystacks)); }
 
-    // `match_list_indices(&haystacks)` (src/matcher/mod.rs:234-275).  `selection`: corpus indices standing in for the haystack
-    // list (the top of a match_list result); empty optional = the whole corpus.  Single-pattern matchers only.
+    // `match_list_indices(&haystacks)` (src/matcher/mod.rs:234-275; multi-pattern: match_one_indices_multi, multi.rs:56-82).
+    // `selection`: corpus indices standing in for the haystack list (the top of a match_list result); empty optional = the whole corpus.
     std::vector<MatchIndices> match_list_indices(const Corpus& corpus, const std::optional<std::vector<uint32_t>>& selection = std::nullopt) {
         if (selection && selection->empty()) return {};
-        if (!single_ && multi_ && fzb_multi_matcher_len(multi_.get()) == 0) {  // CompiledPatterns::Empty (mod.rs:237-246): every index, no positions
-            const size_t n = selection ? selection->size() : fzb_corpus_len(corpus.raw());
-            const bool reversed = config_.sort_ == SortStrategy::IndexDesc || config_.sort_ == SortStrategy::ScoreThenIndexDesc;
-            std::vector<MatchIndices> v(n);
-            for (size_t i = 0; i < n; i++) v[i] = MatchIndices{0, (uint32_t)(reversed ? n - 1 - i : i), false, {}};
-            return v;
-        }
-        if (!single_) throw Error(FZB_ERR_INVALID, "match_list_indices: multi-pattern matchers are not supported on the device");
         fzb_match_indices* out = nullptr;
         uint32_t* pos = nullptr;
         size_t n = 0;
-        check(fzb_match_list_indices(single_.get(), corpus.raw(), selection ? selection->data() : nullptr, selection ? selection->size() : 0, &out, &n, &pos));
+        const uint32_t* sel = selection ? selection->data() : nullptr;
+        const size_t nsel = selection ? selection->size() : 0;
+        if (single_) check(fzb_match_list_indices(single_.get(), corpus.raw(), sel, nsel, &out, &n, &pos));
+        else check(fzb_multi_match_list_indices(multi_.get(), corpus.raw(), sel, nsel, &out, &n, &pos));
         std::vector<MatchIndices> v(n);
         for (size_t i = 0; i < n; i++)
             v[i] = MatchIndices{out[i].score, out[i].index, out[i].exact != 0, std::vector<uint32_t>(pos + out[i].positions_begin, pos + out[i].positions_begin + out[i].positions_len)};

@@ -1864,6 +1864,43 @@ struct MultiMatcher {
         return matches;
     }
 
+    // Matcher::match_list_indices over CompiledPatterns (mod.rs:234-262), haystack order (the caller applies mod.rs:268-273).
+    // Multi: match_one_indices_multi per haystack (multi.rs:56-82): a negated pattern that matches drops the haystack; every other
+    // pattern must match, scores add with saturation, exact flags OR, the position lists are concatenated, sorted descending and
+    // de-duplicated (patterns may share matched bytes).
+    void match_list_indices(const HaystackList& hs, std::vector<Match>& out, std::vector<std::vector<u32>>& indices) const {
+        std::string err = Matcher::guard_against_haystack_overflow(hs.n, 0);
+        if (!err.empty()) throw std::runtime_error(err);
+        if (is_empty()) { for (size_t i = 0; i < hs.n; i++) { out.push_back(Match{(u32)i, 0, 0, 0}); indices.emplace_back(); } return; }
+        if (is_single()) { patterns[0].m->impl->match_list_indices(hs, out, indices); return; }
+        for (size_t i = 0; i < hs.n; i++) {
+            const u32 one = (u32)hs.at(i);
+            HaystackList sub{hs.bytes, hs.ends, 1, &one};
+            Match combined{(u32)i, 0, 0, 0};
+            std::vector<u32> all;
+            bool keep = true;
+            for (const Compiled& p : patterns) {
+                std::vector<Match> r;
+                if (p.negated) {
+                    p.m->match_list_into(p.m->impl, sub, 0, 1, 0, r);
+                    if (!r.empty()) { keep = false; break; }
+                } else {
+                    std::vector<std::vector<u32>> ix;
+                    p.m->impl->match_list_indices(sub, r, ix);
+                    if (r.empty()) { keep = false; break; }
+                    combined.score = sat_add16(combined.score, r[0].score);
+                    combined.exact = (u8)(combined.exact | r[0].exact);
+                    all.insert(all.end(), ix[0].begin(), ix[0].end());
+                }
+            }
+            if (!keep) continue;
+            std::sort(all.begin(), all.end(), [](u32 a, u32 b) { return a > b; });
+            all.erase(std::unique(all.begin(), all.end()), all.end());
+            out.push_back(combined);
+            indices.push_back(all);
+        }
+    }
+
     // The reference's own oracle for this composition (tests/api_properties.rs:316-361): match every pattern on its own,
     // intersect the non-negated ones (scores add with saturation, exact flags OR), subtract the negated ones.  Index order.
     std::vector<Match> reference_composition(const HaystackList& hs) const {

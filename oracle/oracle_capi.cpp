@@ -148,6 +148,25 @@ int fzo_sw_score_typos(const uint8_t* needle, size_t nlen, const uint8_t* hay, s
 }
 // Matcher::match_list_indices for one pattern (matcher/mod.rs:234-262, index order): records + per-record index lists, flattened.
 // out_offsets has n_records + 1 entries.  Everything malloc'd; free with fzo_free.
+static int pack_indices(const std::vector<Match>& recs, const std::vector<std::vector<u32>>& idx, Match** out, size_t* out_len, uint32_t** out_idx, uint64_t** out_offsets) {
+    size_t total = 0;
+    for (auto& v : idx) total += v.size();
+    *out = (Match*)malloc(std::max<size_t>(recs.size(), 1) * sizeof(Match));
+    *out_idx = (uint32_t*)malloc(std::max<size_t>(total, 1) * 4);
+    *out_offsets = (uint64_t*)malloc((recs.size() + 1) * 8);
+    size_t off = 0;
+    for (size_t i = 0; i < recs.size(); i++) {
+        (*out)[i] = recs[i];
+        (*out_offsets)[i] = off;
+        if (!idx[i].empty()) memcpy(*out_idx + off, idx[i].data(), idx[i].size() * 4);
+        off += idx[i].size();
+    }
+    (*out_offsets)[recs.size()] = off;
+    *out_len = recs.size();
+    return 0;
+}
+
+// Matcher::match_list_indices before its ordering step (haystack order): records, flat positions, offsets[n + 1]
 int fzo_match_list_indices(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, Match** out, size_t* out_len, uint32_t** out_idx, uint64_t** out_offsets) {
     try {
         HaystackList hs{bytes, ends, n};
@@ -156,21 +175,18 @@ int fzo_match_list_indices(void* m, const uint8_t* bytes, const uint64_t* ends, 
         std::vector<std::vector<u32>> idx;
         if (!mm->empty) mm->impl->match_list_indices(hs, recs, idx);
         else for (size_t i = 0; i < n; i++) { recs.push_back(Match{(u32)i, 0, 0, 0}); idx.emplace_back(); }
-        size_t total = 0;
-        for (auto& v : idx) total += v.size();
-        *out = (Match*)malloc(std::max<size_t>(recs.size(), 1) * sizeof(Match));
-        *out_idx = (uint32_t*)malloc(std::max<size_t>(total, 1) * 4);
-        *out_offsets = (uint64_t*)malloc((recs.size() + 1) * 8);
-        size_t off = 0;
-        for (size_t i = 0; i < recs.size(); i++) {
-            (*out)[i] = recs[i];
-            (*out_offsets)[i] = off;
-            if (!idx[i].empty()) memcpy(*out_idx + off, idx[i].data(), idx[i].size() * 4);
-            off += idx[i].size();
-        }
-        (*out_offsets)[recs.size()] = off;
-        *out_len = recs.size();
-        return 0;
+        return pack_indices(recs, idx, out, out_len, out_idx, out_offsets);
+    } catch (std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// the same over CompiledPatterns::Multi (match_one_indices_multi, multi.rs:56-82)
+int fzo_multi_match_list_indices(void* m, const uint8_t* bytes, const uint64_t* ends, size_t n, Match** out, size_t* out_len, uint32_t** out_idx, uint64_t** out_offsets) {
+    try {
+        HaystackList hs{bytes, ends, n};
+        std::vector<Match> recs;
+        std::vector<std::vector<u32>> idx;
+        ((MultiMatcher*)m)->match_list_indices(hs, recs, idx);
+        return pack_indices(recs, idx, out, out_len, out_idx, out_offsets);
     } catch (std::exception& e) { g_err = e.what(); return 1; }
 }
 

@@ -114,6 +114,9 @@ static void gpu_side() {
         }
         auto all = Matcher("").match_list_indices(std::vector<std::string>{"foo", "bar"});
         CHECK(all.size() == 2 && all[0].index == 0 && all[1].index == 1 && all[0].indices.empty());
+        // multi_pattern_overlapping_indices_deduped (src/matcher/multi.rs:277-282)
+        auto mi = multi("foo fo", Config()).match_list_indices(std::vector<std::string>{"foo"});
+        CHECK(mi.size() == 1 && (mi[0].indices == std::vector<uint32_t>{2, 1, 0}));
         // positions for the top of a match_list result over a resident corpus
         const Corpus corpus(haystack);
         Matcher m("deadbe");

@@ -324,5 +324,29 @@ score_typos = [  # get_score_typos(needle, haystack, max_typos): score if an ali
     ("foo", "Ufooo", 0, 3 * CHAR), ("foo", "Ufo", 0, None), ("foo", "Ufo", 1, 2 * CHAR - GOP), ("foo", "Ufo", 2, 2 * CHAR - GOP), ("foo", "Uf", 1, None),
     ("foo", "Uf", 2, CHAR - GOP - GEX), ("foo", "U", 2, None), ("foo", "U", 3, 0), ("foo", "U", 4, 0),
 ]
-json.dump(dict(ascii=idx_ascii, unicode=idx_unicode, score_typos=score_typos), open(os.path.join(HERE, "indices.json"), "w"), ensure_ascii=False, indent=1)
+# Matcher::match_list_indices known answers (API level: prefilter -> trim -> scorer -> traceback, byte offsets of the ORIGINAL haystack).
+# expect = one [index, exact or None (not asserted), positions or None, "sorted" positions or None] per returned record.
+FLAT = [12, 6, 0, 0, 12, 0, 4, 8, 0]  # Scoring { gap_open_penalty: 0, gap_extend_penalty: 0, capitalization_bonus: 0, delimiter_bonus: 0, ..default }
+idx_matcher = [
+    dict(needle="إن", haystacks=["xxإنyy", "إن", "\u06e5\u0606", "nomatch", "x" * 65], config=dict(max_typos=0, sort="IndexAsc"),
+         expect=[[0, False, [5, 4, 3, 2]], [1, True, [3, 2, 1, 0]]], ref="tests/api_properties.rs:452-485"),
+    dict(needle="éx", haystacks=["é😀x"], config=dict(max_typos=None, sort="IndexAsc"), expect=[[0, None, [6, 1, 0]]], ref="tests/api_properties.rs:488-503"),
+    dict(needle="😀x", haystacks=["_______😀x"], config=dict(max_typos=None, sort="IndexAsc"), expect=[[0, None, [11, 10, 9, 8, 7]]], ref="tests/api_properties.rs:505-513"),
+    dict(needle="ab", haystacks=["xa" + "_" * 1200 + "b"], config=dict(sort="IndexAsc", scoring=FLAT), expect=[[0, None, [1202, 1]]], ref="tests/api_properties.rs:516-540"),
+    dict(needle="ab", haystacks=["xa" + "_" * 1200 + "b"], config=dict(sort="IndexAsc", scoring=FLAT, max_typos=None), expect=[[0, None, [1202, 1]]], ref="tests/api_properties.rs:516-540"),
+    dict(needle="éb", haystacks=["xé" + "_" * 1200 + "b"], config=dict(sort="IndexAsc", scoring=FLAT), expect=[[0, None, [1203, 2, 1]]], ref="tests/api_properties.rs:542-556"),
+    dict(needle="éb", haystacks=["xé" + "_" * 1200 + "b"], config=dict(sort="IndexAsc", scoring=FLAT, max_typos=None), expect=[[0, None, [1203, 2, 1]]], ref="tests/api_properties.rs:542-556"),
+    dict(needle="é", haystacks=["xxé"], config=dict(unicode="Ignore", sort="IndexAsc"), expect=[[0, None, None, [2, 3]]], ref="src/matcher/mod.rs:604-616"),
+    dict(needle="foo", haystacks=["foo", "FOO", "fOo", "xxfooxx"], config=dict(casing="Respect", sort="IndexAsc"), expect=[[0, None, None], [3, None, None]], ref="src/matcher/mod.rs:630-643"),
+    dict(needle="", haystacks=["foo", "bar"], config=dict(), expect=[[0, False, []], [1, False, []]], ref="tests/api_properties.rs:429-433; src/matcher/mod.rs:745-748"),
+]
+# CompiledPatterns::Multi (match_one_indices_multi, src/matcher/multi.rs:56-82)
+idx_multi = [
+    dict(query="foo fo", haystacks=["foo"], config=dict(), expect=[[0, None, [2, 1, 0]]], ref="src/matcher/multi.rs:277-282"),
+]
+# multi_pattern_match_list_indices_matches_match_list (src/matcher/multi.rs:253-274): same (index, score, exact) as match_list, positions strictly descending
+idx_multi_same = dict(haystacks=["foobar", "foo", "barfoo", "bar", "qux", "FooBar"], queries=["foo !bar", "foo bar", "!foo", "foo fo"], config=dict(sort="IndexAsc"),
+                      ref="src/matcher/multi.rs:253-274")
+json.dump(dict(ascii=idx_ascii, unicode=idx_unicode, score_typos=score_typos, matcher=idx_matcher, multi=idx_multi, multi_same=idx_multi_same),
+          open(os.path.join(HERE, "indices.json"), "w"), ensure_ascii=False, indent=1)
 print("golden written")

@@ -52,6 +52,7 @@ def lib(native=False):
         l.fzo_sw_indices.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_size_t)]
         l.fzo_sw_score_typos.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int, C.c_int, C.c_int]
         l.fzo_match_list_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        l.fzo_multi_match_list_indices.argtypes = l.fzo_match_list_indices.argtypes
         l.fzo_greedy.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint16), C.c_int, C.c_int]
         l.fzo_score_fits_in_u8.argtypes = [C.c_size_t, C.POINTER(C.c_uint16)]
         l.fzo_max_needle_len.argtypes = [C.POINTER(C.c_uint16)]
@@ -206,28 +207,11 @@ class Matcher:
 
     def match_list_indices(self, haystacks):
         """`Matcher::match_list_indices` for one pattern, index order: (records, list of index lists in reverse byte order)"""
-        data, ends = pack(haystacks)
-        out, n, oi, oo = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_void_p()
-        rc = self.lib.fzo_match_list_indices(self.h, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), C.byref(out), C.byref(n), C.byref(oi), C.byref(oo))
-        if rc:
-            raise RuntimeError(self.lib.fzo_last_error().decode())
-        recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 8,))[: n.value * 8].view(MATCH_DTYPE).copy()
-        offs = np.ctypeslib.as_array(C.cast(oo, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
-        flat = np.ctypeslib.as_array(C.cast(oi, C.POINTER(C.c_uint32)), shape=(max(int(offs[-1]), 1),)).copy()
-        for p in (out, oi, oo):
-            self.lib.fzo_free(p)
-        return recs, [flat[int(offs[i]) : int(offs[i + 1])].tolist() for i in range(n.value)]
+        return _indices_call(self.lib, self.lib.fzo_match_list_indices, self.h, haystacks)
 
     def match_list_indices_ordered(self, haystacks):
-        """`Matcher::match_list_indices` with its ordering step (src/matcher/mod.rs:268-273: reverse for the *Desc strategies, then a
-        stable sort by descending score for the Score* ones): list of (index, score, exact, indices)."""
-        recs, idx = self.match_list_indices(haystacks)
-        items = [(int(r["index"]), int(r["score"]), bool(r["exact"]), ix) for r, ix in zip(recs, idx)]
-        if self.cfg.sort in (SORT["IndexDesc"], SORT["ScoreThenIndexDesc"]):
-            items.reverse()
-        if self.cfg.sort in (SORT["ScoreThenIndexAsc"], SORT["ScoreThenIndexDesc"]):
-            items.sort(key=lambda t: -t[1])  # list.sort is stable, like sort_by_key
-        return items
+        """`Matcher::match_list_indices` with its ordering step: list of (index, score, exact, indices)."""
+        return _order_indices(*self.match_list_indices(haystacks), self.cfg.sort)
 
     def match_list_parallel(self, haystacks, threads):
         return self.match_packed(*pack(haystacks), threads=threads)
@@ -239,6 +223,31 @@ class Matcher:
                 self.h = None
         except Exception:
             pass
+
+
+def _indices_call(l, fn, handle, haystacks):
+    data, ends = pack(haystacks)
+    out, n, oi, oo = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_void_p()
+    rc = fn(handle, data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), C.byref(out), C.byref(n), C.byref(oi), C.byref(oo))
+    if rc:
+        raise RuntimeError(l.fzo_last_error().decode())
+    recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 8,))[: n.value * 8].view(MATCH_DTYPE).copy()
+    offs = np.ctypeslib.as_array(C.cast(oo, C.POINTER(C.c_uint64)), shape=(n.value + 1,)).copy()
+    flat = np.ctypeslib.as_array(C.cast(oi, C.POINTER(C.c_uint32)), shape=(max(int(offs[-1]), 1),)).copy()
+    for p in (out, oi, oo):
+        l.fzo_free(p)
+    return recs, [flat[int(offs[i]) : int(offs[i + 1])].tolist() for i in range(n.value)]
+
+
+def _order_indices(recs, idx, sort):
+    """The ordering step of `Matcher::match_list_indices` (src/matcher/mod.rs:268-273): reverse for the *Desc strategies, then a
+    stable sort by descending score for the Score* ones."""
+    items = [(int(r["index"]), int(r["score"]), bool(r["exact"]), ix) for r, ix in zip(recs, idx)]
+    if sort in (SORT["IndexDesc"], SORT["ScoreThenIndexDesc"]):
+        items.reverse()
+    if sort in (SORT["ScoreThenIndexAsc"], SORT["ScoreThenIndexDesc"]):
+        items.sort(key=lambda t: -t[1])  # list.sort is stable, like sort_by_key
+    return items
 
 
 INHERIT = "inherit"
@@ -288,6 +297,13 @@ class MultiMatcher:
 
     def match_list(self, haystacks):
         return self._run(*pack(haystacks), 0)
+
+    def match_list_indices(self, haystacks):
+        """`Matcher::match_list_indices` over CompiledPatterns (match_one_indices_multi, src/matcher/multi.rs:56-82), haystack order"""
+        return _indices_call(self.lib, self.lib.fzo_multi_match_list_indices, self.h, haystacks)
+
+    def match_list_indices_ordered(self, haystacks):
+        return _order_indices(*self.match_list_indices(haystacks), self.cfg.sort)
 
     def reference_composition(self, haystacks):
         """the reference's own test oracle for the composition (tests/api_properties.rs:316-361), index order"""

@@ -174,3 +174,64 @@ def test_whole_list_agrees_with_match_list_at_bench_shape():
             full += 1
             assert bytes(h[g.indices[::-1]]).lower() == b"deadbe"
     assert full > 0
+
+
+def _check_expect(got, expect, ref):
+    assert len(got) == len(expect), (ref, got)
+    for g, e in zip(got, expect):
+        assert g[0] == e[0], ref
+        if e[1] is not None:
+            assert g[2] == e[1], ref
+        if len(e) > 2 and e[2] is not None:
+            assert g[3] == e[2], (ref, g)
+        if len(e) > 3 and e[3] is not None:
+            assert sorted(g[3]) == e[3], (ref, g)
+
+
+@pytest.mark.parametrize("pf", [64, 32, 16])
+def test_matcher_level_known_answers(pf):
+    # tests/api_properties.rs:429-556, src/matcher/mod.rs:604-643, 745-748: byte offsets of the ORIGINAL haystack after prefilter + trim,
+    # incl. the > 1024-byte greedy fallback
+    for case in IX["matcher"]:
+        cfg = dict(case["config"])
+        if "scoring" in cfg:
+            cfg["scoring"] = tuple(cfg["scoring"])
+        got = check(case["needle"], case["haystacks"], pf, ctx=case["ref"], **cfg) if case["needle"] else tuples(F.Matcher("", F.Config(pf_lanes=pf)).match_list_indices(case["haystacks"]))
+        _check_expect(got, case["expect"], case["ref"])
+
+
+def multi_pair(query_or_patterns, pf=64, **cfg):
+    pats_o = O.parse_query(query_or_patterns)
+    pats_f = F.parse_query(query_or_patterns)
+    om = O.MultiMatcher(pats_o, lanes=LANES[pf], **cfg)
+    fc = F.Config(max_typos=cfg.get("max_typos", 0), sort=F.SortStrategy[cfg.get("sort", "ScoreThenIndexAsc")], pf_lanes=pf)
+    return F.MultiMatcher(pats_f, fc), om
+
+
+@pytest.mark.parametrize("pf", [64, 16])
+def test_multi_pattern_indices(pf):
+    for case in IX["multi"]:  # src/matcher/multi.rs:277-282
+        fm, om = multi_pair(case["query"], pf, **case["config"])
+        got = tuples(fm.match_list_indices(case["haystacks"]))
+        assert got == om.match_list_indices_ordered(case["haystacks"])
+        _check_expect(got, case["expect"], case["ref"])
+    same = IX["multi_same"]  # src/matcher/multi.rs:253-274
+    for query in same["queries"]:
+        fm, om = multi_pair(query, pf, **same["config"])
+        got = tuples(fm.match_list_indices(same["haystacks"]))
+        assert got == om.match_list_indices_ordered(same["haystacks"]), query
+        assert [(g[0], g[1], int(g[2])) for g in got] == [(int(r["index"]), int(r["score"]), int(r["exact"])) for r in fm.match_list(same["haystacks"])], query
+    rng = np.random.default_rng(500 + pf)
+    alpha = "abcAB_ /xé"
+    for it in range(40):
+        words = ["".join(alpha[int(x)] for x in rng.integers(0, 7, int(rng.integers(1, 4)))) for _ in range(int(rng.integers(1, 4)))]
+        query = " ".join(("!" if rng.random() < 0.25 else "") + ["", "^", "'"][int(rng.integers(0, 3))] + w for w in words)
+        hs = ["".join(alpha[int(x)] for x in rng.integers(0, len(alpha), int(rng.integers(0, 60)))) for _ in range(40)]
+        sort = ["IndexAsc", "ScoreThenIndexDesc", "IndexDesc", "ScoreThenIndexAsc"][it % 4]
+        fm, om = multi_pair(query, pf, sort=sort, max_typos=[0, 1, None][it % 3])
+        got = tuples(fm.match_list_indices(hs))
+        assert got == om.match_list_indices_ordered(hs), (query, sort)
+        if it % 5 == 0:  # a selection with repeats
+            sel = rng.integers(0, len(hs), 25).astype(np.uint32)
+            cp = F.Corpus(hs)
+            assert tuples(fm.match_list_indices(cp, sel)) == om.match_list_indices_ordered([hs[int(i)] for i in sel]), (query, sort)
