@@ -100,3 +100,31 @@ if "C5" in which:
     data = np.tile(data, reps); ends = np.arange(1, n5 * reps + 1, dtype=np.uint64) * np.uint64(32)
     cp = F.Corpus(packed=(data, ends))
     run("C5 utf8 len32 typos0 (2M distinct x5)", "إنما", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n5 * reps)
+if "INDICES" in which:
+    # matched byte positions for the top K of a sorted match_list over the resident C2 list
+    # (host call -> selection upload -> item pipeline -> traced scorer + on-device traceback -> copies -> host ordering)
+    flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
+    flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
+    ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+    for typos in (0, 1):
+        m = F.Matcher("deadbe", F.Config(max_typos=typos, pf_lanes=64, sw_lanes=64))
+        top = m.match_list(cp)
+        for k in (100, 1000, 10000, 100000):
+            sel = top["index"][:k].astype(np.uint32)
+            m.match_list_indices(cp, sel)
+            ts = []
+            for _ in range(5):
+                t0 = time.perf_counter(); r = m.match_list_indices(cp, sel); ts.append(time.perf_counter() - t0)
+            # the C call alone (without building Python objects)
+            import ctypes as C
+            out, nn, pos = C.c_void_p(), C.c_size_t(), C.c_void_p()
+            tc = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                F.lib().fzb_match_list_indices(m.h, cp.h, sel.ctypes.data, len(sel), C.byref(out), C.byref(nn), C.byref(pos))
+                tc.append(time.perf_counter() - t0)
+                F.lib().fzb_match_indices_free(out, pos)
+            print(json.dumps(dict(config=f"C2 list, positions for the top {k} of match_list, max_typos={typos}", selection=k, records=len(r),
+                                  c_call_ms=sorted(tc)[2] * 1e3, python_call_ms=sorted(ts)[2] * 1e3, haystacks_per_s=k / sorted(tc)[2])), flush=True)
+    del cp, flat, ends
