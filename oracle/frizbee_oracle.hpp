@@ -8,7 +8,10 @@
 // The reference is a Rust crate and there is no Rust toolchain in the build image, so it
 // cannot be compiled into oracle/_ref.  The restatement is instead pinned by the
 // reference's own known-answer tests (tests/golden/*.json, harvested from
-// src/smith_waterman/mod.rs, src/prefilter/mod.rs, src/matcher/*.rs, tests/api_properties.rs).
+// src/smith_waterman/mod.rs, src/prefilter/mod.rs, src/matcher/*.rs, tests/api_properties.rs)
+// and by its property tests re-run here on its own input generators
+// (tests/test_oracle_reference_properties.py: prefilter == LCS criterion with identical
+// windows at every lane width, cross-width score / position identities, the public-API contract).
 // Parity with the real AVX-512 binary on large random inputs is NOT pinned.
 //
 // Every function cites the reference file:line it restates.  The SIMD-generic Rust code is

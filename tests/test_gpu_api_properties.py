@@ -1,0 +1,61 @@
+"""The reference's generated public-API property test (tests/api_properties.rs:72-166) through the HIP path: for cases drawn with
+the reference's own generator (needle / haystack list / max_typos / casing / matching mode / sort), `match_list`,
+`match_list_parallel` and `match_list_indices` equal the oracle's record for record, and the reference's indices contract holds."""
+import numpy as np
+import pytest
+
+import frizbee_amd as F
+import oracle_lib as O
+from ref_generators import api_cases, assert_indices_contract
+
+pytestmark = pytest.mark.gpu
+LANES = {64: (64, 64, 32), 32: (32, 32, 16), 16: (16, 16, 8)}
+
+
+@pytest.mark.parametrize("pf", [64, 32, 16])
+def test_generated_public_api_properties_through_hip(pf):
+    for it, (needle, haystacks, cfg) in enumerate(api_cases(400, 1000 + pf)):
+        om = O.Matcher(needle, lanes=LANES[pf], **cfg)
+        fc = F.Config(max_typos=cfg["max_typos"], casing=F.CaseMatching[cfg["casing"]], matching=F.Matching[cfg["matching"]], sort=F.SortStrategy[cfg["sort"]], pf_lanes=pf)
+        fm = F.Matcher(needle, fc)
+        corpus = F.Corpus(haystacks)
+        want = om.match_list(haystacks)
+        got = fm.match_list(corpus)
+        assert got.tolist() == want.tolist(), (it, needle, cfg)
+        assert fm.match_list(corpus).tolist() == want.tolist(), (it, needle, cfg)  # reusable == one-shot
+        for threads in (1, 3):
+            assert fm.match_list_parallel(corpus, threads).tolist() == want.tolist(), (it, needle, cfg, threads)
+        ix = [(m.index, m.score, m.exact, m.indices) for m in fm.match_list_indices(corpus)]
+        assert ix == om.match_list_indices_ordered(haystacks), (it, needle, cfg)
+        assert_indices_contract(needle, haystacks, cfg, got, ix)
+
+
+def test_reuse_handles_state_changes():
+    # src/matcher/mod.rs:787-850: one matcher taken through set_pattern / set_config sequences equals a freshly built one every time
+    def fresh(needle, hs, **cfg):
+        return O.Matcher(needle, **cfg).match_list(hs).tolist()
+
+    def conf(**cfg):
+        return F.Config(max_typos=cfg.get("max_typos", 0), casing=F.CaseMatching[cfg.get("casing", "Smart")], sort=F.SortStrategy[cfg.get("sort", "ScoreThenIndexAsc")], pf_lanes=64)
+
+    long_needle = "abcdefghijklmnopqrst"
+    first = ["xxabcdefghijklmnopqrstxx", "abcdefghijklmnopqrst", "no-match"]
+    c1 = dict(max_typos=None, sort="IndexAsc")
+    m = F.Matcher(long_needle, conf(**c1))
+    assert m.info()["use_u8"] is False  # u16_path_selected_for_long_needle, src/matcher/mod.rs:770-785
+    assert m.match_list(first).tolist() == fresh(long_needle, first, **c1)
+    second = ["fooBar", "foo_bar", "fbr", "bar"]
+    c2 = dict(casing="Smart", sort="IndexAsc")
+    m.set_pattern("fB")
+    m.set_config(conf(**c2))
+    assert m.info()["use_u8"] is True  # u8_path_selected_for_short_needle, src/matcher/mod.rs:751-768
+    assert m.match_list(second).tolist() == fresh("fB", second, **c2)
+    uni = ["é다😀", "xxé__다__😀yy", "é다", "plain ascii"]
+    c3 = dict(max_typos=0, sort="IndexAsc")
+    m.set_pattern("é다😀")
+    m.set_config(conf(**c3))
+    assert m.match_list(uni).tolist() == fresh("é다😀", uni, **c3)
+    c4 = dict(casing="Ignore", max_typos=1)
+    m.set_pattern("fB")
+    m.set_config(conf(**c4))
+    assert m.match_list(first).tolist() == fresh("fB", first, **c4)

@@ -1,0 +1,194 @@
+"""The reference's own PROPERTY tests, restated and run against the oracle - the strongest pin there is short of running the
+reference: its test-suite holds these for every backend on generated inputs, so a faithful restatement must hold them too.
+
+* prefilter (src/prefilter/mod.rs:407-550, 895-1125): for every typo budget, the accept decision equals the LCS criterion
+  `lcs(needle, haystack) + max_typos >= len(needle)` (the reference's `reference_matches_by_deleting_needle_{bytes,chars}`), the
+  window is valid, and ALL backends (16 / 32 / 64 lanes) return the identical (matched, start, end) - inputs drawn with the
+  reference's own `ByteCursor` generator from random byte strings, like its proptest run;
+* Smith-Waterman (src/smith_waterman/backend/tests/parity.rs:95-198): on the fixed corpus every width and score class gives
+  the same score AND the same alignment positions as the 8 x u16 scalar backend;
+* k-way merge known answers (src/k_merge.rs:187-266), the score-class selection (src/matcher/mod.rs:751-785)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from ref_generators import ByteCursor, SwCursor, api_cases, assert_indices_contract
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+SW = json.load(open(os.path.join(G, "smith_waterman.json")))
+
+
+def lcs_len(needle, haystack, eq):  # src/prefilter/mod.rs:1024-1046
+    prev = [0] * (len(haystack) + 1)
+    for n in needle:
+        cur = [0] * (len(haystack) + 1)
+        for i, h in enumerate(haystack):
+            cur[i + 1] = prev[i] + 1 if eq(n, h) else max(prev[i + 1], cur[i])
+        prev = cur
+    return prev[len(haystack)]
+
+
+def byte_eq(case_sensitive):  # bytes_match, src/prefilter/mod.rs:1048-1050
+    def eq(n, h):
+        return n == h or (not case_sensitive and n < 128 and h < 128 and chr(n).lower() == chr(h).lower())
+    return eq
+
+
+def check_ascii_case(needle, haystack, max_typos, case_sensitive, want=None):
+    oracle = max_typos >= len(needle) or lcs_len(needle, haystack, byte_eq(case_sensitive)) + max_typos >= len(needle)
+    if want is not None:
+        assert oracle == want, (needle, haystack, max_typos, case_sensitive)
+    results = [O.prefilter(needle, haystack, max_typos, case_sensitive, False, lanes) for lanes in (16, 32, 64)]
+    for r in results:
+        assert r[0] == oracle, (needle, haystack, max_typos, case_sensitive, results)
+    if oracle:
+        assert results[0] == results[1] == results[2], (needle, haystack, max_typos, case_sensitive, results)  # assert_same_case_result
+        assert results[0][1] <= results[0][2] <= len(haystack), results  # assert_valid_window
+
+
+def check_unicode_case(needle, haystack, max_typos):
+    nc, hc = list(needle), list(haystack)
+    oracle = max_typos >= len(nc) or lcs_len(nc, hc, lambda a, b: a == b) + max_typos >= len(nc)
+    hb = haystack.encode()
+    results = [O.prefilter(needle, hb, max_typos, True, True, lanes) for lanes in (16, 32, 64)]
+    for r in results:
+        assert r[0] == oracle, (needle, haystack, max_typos, results)
+    if oracle:
+        assert results[0] == results[1] == results[2], (needle, haystack, max_typos, results)
+        bounds, p = {0}, 0
+        for ch in haystack:
+            p += len(ch.encode())
+            bounds.add(p)
+        assert results[0][1] <= results[0][2] <= len(hb) and results[0][1] in bounds and results[0][2] in bounds, results  # char boundaries
+
+
+def test_prefilter_manual_cases():
+    for needle, haystack, max_typos in [  # backend_parity_suite, src/prefilter/mod.rs:407-430
+        ("foo", "foo", 0), ("foo", "oof", 0), ("foo", "f_o_o", 0), ("foo", "f_______________o_______________o", 0), ("\0", "abc", 0), ("a", "", 0), ("bar", "ba", 1),
+        ("abc", "c", 2), ("bar", "rb", 1), ("a\0b", "ab", 1), ("abcdef", "abdf", 2), ("abcdef", "fcda", 2), ("abc", "", 3), ("abcdefghij", "abxxcxxdxxe", 5),
+        ("abcdefghij", "jihgfedcba", 5), ("abcdefghij", "abc", 8), ("abcdefghijklmnop", "abcxxxdefxxxghixxxjklxxxmnop", 4), ("abcdefghijklmnop", "ponmlkjihgfedcba", 10),
+    ]:
+        check_ascii_case(needle.encode(), haystack.encode(), max_typos, False)
+    for needle, haystack, max_typos, case_sensitive, want in [  # reference_oracle_manual_cases, src/prefilter/mod.rs:433-470
+        ("abc", b"", 2, False, False), ("abc", b"", 3, False, True), ("abc", b"bc", 1, False, True), ("abc", b"ac", 1, False, True), ("abc", b"ab", 1, False, True),
+        ("abc", b"cba", 2, False, True), ("aaa", b"aa", 1, False, True), ("aba", b"aa", 1, False, True), ("Ab", b"ab", 0, False, True), ("Ab", b"ab", 0, True, False),
+        ("A\0b", b"a\0b", 0, False, True), ("A\0b", b"a\0b", 0, True, False), ("éa", "é_a".encode(), 0, False, True), ("ÿA", "ÿa".encode(), 0, False, True),
+        ("ÿA", "ÿa".encode(), 0, True, False),
+    ]:
+        check_ascii_case(needle.encode(), haystack, max_typos, case_sensitive, want)
+    for prefix_len in (0, 1, 7, 8, 15, 16, 31, 32, 63, 64):  # reference_oracle_chunk_boundaries, src/prefilter/mod.rs:473-503
+        for needle, max_typos, want in (("abc", 0, True), ("ac", 0, True), ("abcd", 0, False), ("abcd", 1, True)):
+            check_ascii_case(needle.encode(), b"x" * prefix_len + b"abc", max_typos, False, want)
+
+
+def test_prefilter_equals_the_lcs_criterion_and_all_widths_agree_on_generated_inputs():
+    # randomized_backend_parity_and_oracle, src/prefilter/mod.rs:895-908 + PrefilterCase::from_bytes :697-716 (the reference runs 256 cases)
+    rng = np.random.default_rng(20260925)
+    for _ in range(1200):
+        c = ByteCursor(rng.integers(0, 256, int(rng.integers(0, 2049))).tolist())
+        needle_len = max(1, c.len(96, [1, 7, 8, 15, 16, 31, 32, 63, 64]))
+        haystack_len = c.len(768, [0, 1, 7, 8, 15, 16, 31, 32, 63, 64, 511, 512, 513])
+        max_typos = c.next() % 17
+        case_sensitive = c.bool()
+        needle = "".join(c.char() for _ in range(needle_len)).encode()
+        haystack = bytes(c.byte() for _ in range(haystack_len))
+        check_ascii_case(needle, haystack, max_typos, case_sensitive)
+
+
+def test_unicode_prefilter_equals_the_lcs_criterion_and_all_widths_agree():
+    # randomized_unicode_backend_parity_and_oracle, src/prefilter/mod.rs:506-519 + UnicodePrefilterCase::from_bytes :726-748 (128 cases there)
+    rng = np.random.default_rng(77)
+    for _ in range(800):
+        c = ByteCursor(rng.integers(0, 256, int(rng.integers(0, 1025))).tolist())
+        needle_len = max(1, c.len(48, [1, 2, 3, 7, 8, 15, 16, 31, 32]))
+        haystack_len = c.len(192, [0, 1, 2, 3, 7, 8, 15, 16, 31, 32, 63, 64])
+        max_typos = c.next() % 6
+        needle = "".join(c.unicode_char() for _ in range(needle_len))
+        if needle.isascii():
+            needle += "é"
+        check_unicode_case(needle, "".join(c.unicode_char() for _ in range(haystack_len)), max_typos)
+    for needle in ("aé", "éa", "aébc", "é✓", "✓é", "a✓é", "é😀x", "aXé😀"):  # unicode_mixed_width_matches_oracle, src/prefilter/mod.rs:522-550
+        for haystack in ("", "aé", "xaéy", "aébc", "é✓", "a✓é", "zzaé😀xx", "éeé", "aaébcbc", "no match", "aXé😀qw"):
+            for max_typos in range(4):
+                check_unicode_case(needle, haystack, max_typos)
+
+
+WIDTHS = [(8, False), (16, False), (32, False), (16, True), (32, True), (64, True)]
+
+
+def test_alignment_positions_agree_across_widths_on_the_fixed_corpus():
+    # cross_backend_parity_indices, src/smith_waterman/backend/tests/parity.rs:193-198 (corpus :95-124)
+    for v in SW["sw_cross_width"]:
+        want = O.sw_indices(v["needle"], v["haystack"], lanes=8, is_u8=False)
+        for lanes, u8 in WIDTHS:
+            if u8 and not O.score_fits_in_u8(len(v["needle"].encode())):
+                continue
+            assert O.sw_indices(v["needle"], v["haystack"], lanes=lanes, is_u8=u8) == want, (lanes, u8, v)
+
+
+def test_generated_inputs_give_valid_positions_and_the_same_score_with_and_without_traceback():
+    # randomized_cross_backend_parity, src/smith_waterman/backend/tests/parity.rs:207-334: per backend, score_haystack_indices' score equals
+    # score_haystack's and the positions are valid (strictly descending, at most one per needle byte, inside the haystack)
+    rng = np.random.default_rng(5)
+    for _ in range(400):
+        c = SwCursor(rng.integers(0, 256, int(rng.integers(0, 2049))).tolist())
+        needle_len = max(1, c.len(96, [1, 7, 8, 15, 16, 31, 32, 63, 64]))
+        haystack_len = c.len(768, [0, 1, 7, 8, 15, 16, 31, 32, 63, 64, 1023, 1024, 1025])
+        b = c.next() % 5
+        max_typos = None if b == 0 else (b - 1) % 17
+        case_sensitive = c.bool()
+        needle = bytes(c.byte() for _ in range(needle_len)).decode("utf-8", "replace")  # String::from_utf8_lossy
+        haystack = bytes(c.byte() for _ in range(haystack_len))
+        nb = needle.encode()
+        if len(nb) > O.max_needle_len():
+            continue
+        for lanes, u8 in WIDTHS:
+            if u8 and not O.score_fits_in_u8(len(nb)):
+                continue
+            score = O.sw_score(nb, haystack, case_sensitive=case_sensitive, lanes=lanes, is_u8=u8)
+            got, ix = O.sw_indices(nb, haystack, max_typos=max_typos, case_sensitive=case_sensitive, lanes=lanes, is_u8=u8)
+            assert got == score, (needle, lanes, u8)
+            assert all(a > b for a, b in zip(ix[:-1], ix[1:])) and len(ix) <= len(nb) and all(i < len(haystack) for i in ix), (needle, lanes, u8, ix)
+
+
+def _mk(pairs):
+    a = np.zeros(len(pairs), O.MATCH_DTYPE)
+    for i, (s, ix) in enumerate(pairs):
+        a[i]["score"], a[i]["index"] = s, ix
+    return a
+
+
+def test_k_merge_known_answers():
+    pairs = lambda arr: [(int(x["score"]), int(x["index"])) for x in arr]
+    # merges_two_sorted_match_runs, src/k_merge.rs:187-208
+    got = O.k_merge("ScoreThenIndexAsc", [_mk([(100, 1), (80, 3), (20, 4)]), _mk([(100, 0), (90, 2), (80, 5)])])
+    assert pairs(got) == [(100, 0), (100, 1), (90, 2), (80, 3), (80, 5), (20, 4)]
+    # heap_merge_skips_empty_runs, :210-233
+    got = O.k_merge("ScoreThenIndexAsc", [_mk([(90, 2)]), _mk([]), _mk([(100, 0), (80, 4)]), _mk([]), _mk([(95, 1), (80, 3)])])
+    assert pairs(got) == [(100, 0), (95, 1), (90, 2), (80, 3), (80, 4)]
+    # heap_merge_handles_many_runs, :235-251
+    got = O.k_merge("ScoreThenIndexAsc", [_mk([(100 - r, r)]) for r in reversed(range(17))])
+    assert pairs(got) == [(100 - i, i) for i in range(17)]
+    # merges_by_index_only, :253-266
+    got = O.k_merge("IndexAsc", [_mk([(100, 1), (80, 3), (20, 5)]), _mk([(100, 0), (90, 2), (80, 4)])])
+    assert [int(x["index"]) for x in got] == [0, 1, 2, 3, 4, 5]
+
+
+def test_score_class_selection():
+    # u8_path_selected_for_short_needle / u16_path_selected_for_long_needle, src/matcher/mod.rs:751-785
+    assert O.Matcher("abc").info()["use_u8"] is True
+    assert O.Matcher("abcdefghijklmnopqrst").info()["use_u8"] is False
+
+
+@pytest.mark.parametrize("lanes", [(64, 64, 32), (16, 16, 8)])
+def test_generated_public_api_properties(lanes):
+    # generated_public_api_properties, tests/api_properties.rs:72-114 (1024 generated cases there)
+    for needle, haystacks, cfg in api_cases(300, 11):
+        m = O.Matcher(needle, lanes=lanes, **cfg)
+        one_shot = m.match_list(haystacks)
+        for threads in (1, 2, 3, 8):  # sorted: identical; unsorted: the same multiset (here even the same order)
+            assert m.match_list_parallel(haystacks, threads).tolist() == one_shot.tolist(), (needle, cfg, threads)
+        assert_indices_contract(needle, haystacks, cfg, one_shot, m.match_list_indices_ordered(haystacks))
