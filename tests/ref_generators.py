@@ -142,3 +142,25 @@ def assert_indices_contract(needle, haystacks, cfg, matches, indices):  # tests/
         assert {i[0]: (i[1], i[2]) for i in indices} == match_set, (needle, cfg)
 
 
+
+
+def _multi_case(data):  # MultiPatternCase::from_bytes, tests/api_properties.rs:251-309
+    c = SwCursor(data)
+    patterns = []
+    for _ in range(1 + c.next() % 3):
+        matching = [None, "Fuzzy", "Exact", "Prefix", "Suffix", "Substring"][min(c.next() % 6, 5)]
+        negated = c.bool()
+        needle_len = c.len(8, [0, 1, 2, 3, 7, 8])
+        patterns.append(dict(needle=c.string(needle_len), negated=negated, matching=matching))
+    haystack_count = c.len(24, [0, 1, 2, 7, 8, 15, 16, 24])
+    haystacks = [c.string(c.len(48, [0, 1, 2, 7, 8, 15, 16, 31, 32, 48])) for _ in range(haystack_count)]
+    max_typos = [None, 0, 1, 2][min(c.next() % 4, 3)]
+    casing = ["Ignore", "Smart", "Respect"][c.next() % 3]
+    matching = ["Fuzzy", "Exact", "Prefix", "Suffix", "Substring"][c.next() % 5]
+    return patterns, haystacks, dict(max_typos=max_typos, casing=casing, matching=matching)
+
+
+def multi_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(n):
+        yield _multi_case(rng.integers(0, 256, int(rng.integers(0, 4097))).tolist())

@@ -59,3 +59,22 @@ def test_reuse_handles_state_changes():
     m.set_pattern("fB")
     m.set_config(conf(**c4))
     assert m.match_list(first).tolist() == fresh("fB", first, **c4)
+
+
+@pytest.mark.parametrize("pf", [64, 16])
+def test_generated_multi_pattern_properties_through_hip(pf):
+    # generated_multi_pattern_properties, tests/api_properties.rs:311-416, with the reference's MultiPatternCase generator
+    from ref_generators import multi_cases
+    for it, (patterns, haystacks, cfg) in enumerate(multi_cases(250, 2000 + pf)):
+        opats = [O.P(p["needle"], negated=p["negated"], matching=p["matching"]) for p in patterns]
+        fpats = [F.Pattern(p["needle"], negated=p["negated"], matching=None if p["matching"] is None else F.Matching[p["matching"]]) for p in patterns]
+        corpus = F.Corpus(haystacks)
+        for sort in ("IndexAsc", "ScoreThenIndexAsc"):
+            om = O.MultiMatcher(opats, lanes=LANES[pf], sort=sort, **cfg)
+            fm = F.MultiMatcher(fpats, F.Config(max_typos=cfg["max_typos"], casing=F.CaseMatching[cfg["casing"]], matching=F.Matching[cfg["matching"]], sort=F.SortStrategy[sort], pf_lanes=pf))
+            got = fm.match_list(corpus)
+            assert got.tolist() == om.match_list(haystacks).tolist(), (it, patterns, cfg, sort)
+            if sort == "IndexAsc":
+                assert got.tolist() == om.reference_composition(haystacks).tolist(), (it, patterns, cfg)
+            ix = [(m.index, m.score, m.exact, m.indices) for m in fm.match_list_indices(corpus)]
+            assert ix == om.match_list_indices_ordered(haystacks), (it, patterns, cfg, sort)

@@ -192,3 +192,18 @@ def test_generated_public_api_properties(lanes):
         for threads in (1, 2, 3, 8):  # sorted: identical; unsorted: the same multiset (here even the same order)
             assert m.match_list_parallel(haystacks, threads).tolist() == one_shot.tolist(), (needle, cfg, threads)
         assert_indices_contract(needle, haystacks, cfg, one_shot, m.match_list_indices_ordered(haystacks))
+
+
+@pytest.mark.parametrize("lanes", [(64, 64, 32), (16, 16, 8)])
+def test_generated_multi_pattern_properties(lanes):
+    # generated_multi_pattern_properties / assert_multi_pattern_case, tests/api_properties.rs:311-416 (512 generated cases there):
+    # Matcher::from_patterns == every pattern matched on its own, intersected / subtracted per haystack
+    from ref_generators import multi_cases
+    for patterns, haystacks, cfg in multi_cases(300, 23):
+        pats = [O.P(p["needle"], negated=p["negated"], matching=p["matching"]) for p in patterns]
+        by_index = O.MultiMatcher(pats, lanes=lanes, sort="IndexAsc", **cfg)
+        reference = by_index.reference_composition(haystacks)
+        assert by_index.match_list(haystacks).tolist() == reference.tolist(), (patterns, cfg)
+        sorted_ = O.MultiMatcher(pats, lanes=lanes, sort="ScoreThenIndexAsc", **cfg).match_list(haystacks)
+        assert all(a["score"] > b["score"] or (a["score"] == b["score"] and a["index"] < b["index"]) for a, b in zip(sorted_[:-1], sorted_[1:])), (patterns, cfg)
+        assert sorted(sorted_.tolist()) == sorted(reference.tolist()), (patterns, cfg)
