@@ -754,6 +754,7 @@ int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match*
 // DMA speed (a pageable destination is staged through bounce buffers: ~3x slower for a 4 MB list).  Pinning is expensive, so
 // the buffers are pooled: fzb_matches_free returns a buffer to the pool and a steady stream of queries keeps reusing the same
 // few.  Lists that never were on the device (empty needle) come from malloc; fzb_matches_free tells the two apart.
+}  // extern "C"
 namespace {
 struct PinnedPool {
     std::mutex mu;
@@ -811,6 +812,7 @@ int fetch_records(const void* dev_records, const u32* dev_count, fzb_match** out
     return FZB_OK;
 }
 }  // namespace
+extern "C" {
 
 int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len) {
     if (!m || !c || !out || !out_len) return fail(FZB_ERR_INVALID, "null argument");
@@ -889,6 +891,7 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
 }
 
 // ---- matched indices: Matcher::match_list_indices (src/matcher/mod.rs:234-275) ------------------------------------------------
+}  // extern "C"
 namespace {
 // The haystack list of the *_indices entry points: a selection of the corpus, or all of it.
 int check_selection(const fzb_corpus* c, const uint32_t* selection, size_t n_selection, size_t& count) {
@@ -990,6 +993,7 @@ int finish_indices(std::vector<fzb_match_indices>& recs, const std::vector<u32>&
     return FZB_OK;
 }
 }  // namespace
+extern "C" {
 
 int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
                            uint32_t** out_positions) {
@@ -1014,6 +1018,7 @@ void fzb_match_indices_free(fzb_match_indices* matches, uint32_t* positions) {
 }
 
 // ---- query syntax: Pattern::parse / Pattern::parse_query (src/pattern.rs:87-222) ---------------------------------------------
+}  // extern "C"
 namespace {
 bool is_rust_whitespace(u32 c) {  // char::is_whitespace = Unicode White_Space
     return c == ' ' || (c >= 9 && c <= 13) || c == 0x85 || c == 0xA0 || c == 0x1680 || (c >= 0x2000 && c <= 0x200A) || c == 0x2028 || c == 0x2029 || c == 0x202F ||
@@ -1050,6 +1055,7 @@ ParsedAtom parse_atom(const std::vector<u32>& atom) {
     return a;
 }
 }  // namespace
+extern "C" {
 
 int fzb_parse_query(const uint8_t* query_utf8, size_t query_len, fzb_pattern** out_patterns, size_t* out_n) {
     if (!out_patterns || !out_n || (query_len && !query_utf8)) return fail(FZB_ERR_INVALID, "null argument");
