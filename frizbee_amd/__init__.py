@@ -112,6 +112,7 @@ SYMBOLS = [
     "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
     "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
     "fzb_parse_query", "fzb_patterns_free", "fzb_match_list_indices", "fzb_match_indices_free", "fzb_multi_match_list_indices",
+    "fzb_match_list_indices_into", "fzb_multi_match_list_into", "fzb_multi_match_list_indices_into",
 ]
 
 
@@ -158,6 +159,9 @@ def lib():
         l.fzb_match_list_indices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         l.fzb_match_indices_free.argtypes = [C.c_void_p, C.c_void_p]
         l.fzb_multi_match_list_indices.argtypes = l.fzb_match_list_indices.argtypes
+        l.fzb_match_list_indices_into.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
+        l.fzb_multi_match_list_indices_into.argtypes = l.fzb_match_list_indices_into.argtypes
+        l.fzb_multi_match_list_into.argtypes = l.fzb_match_list_into.argtypes
         _lib = l
     return _lib
 
@@ -264,7 +268,40 @@ def parse_query(query):
     return out
 
 
-class MultiMatcher:
+class _IterApi:
+    """The per-item side of the reference's interface (`match_iter`, `match_one`, `match_iter_indices`, `match_one_indices`,
+    src/matcher/mod.rs:277-371), served by ONE batched device pass in list order - there is no per-item CPU path."""
+
+    def match_iter(self, haystacks):
+        """`Matcher::match_iter` (src/matcher/mod.rs:290-301): the matches in haystack order, whatever `config.sort` says"""
+        return iter(self.match_list_into(haystacks))
+
+    def match_one(self, haystack, index=0):
+        """`Matcher::match_one(haystack, index)` (src/matcher/mod.rs:341-349) -> one record of MATCH_DTYPE or None"""
+        r = self.match_list_into([haystack], index_offset=index)
+        return r[0] if len(r) else None
+
+    def match_iter_indices(self, haystacks):
+        """`Matcher::match_iter_indices` (src/matcher/mod.rs:321-334)"""
+        return iter(self._indices_into(haystacks, 0))
+
+    def match_one_indices(self, haystack, index=0):
+        """`Matcher::match_one_indices` (src/matcher/mod.rs:357-371)"""
+        r = self._indices_into([haystack], index)
+        return r[0] if r else None
+
+
+def fuzzy_match(haystacks, needle, config=None):
+    """`iter::FuzzyMatchExt::fuzzy_match` (src/matcher/iter.rs:35-78) = `Matcher::new(needle, config).match_iter(haystacks)`"""
+    return Matcher(needle, config).match_iter(haystacks)
+
+
+def fuzzy_match_indices(haystacks, needle, config=None):
+    """`iter::FuzzyMatchExt::fuzzy_match_indices` (src/matcher/iter.rs:80-126)"""
+    return Matcher(needle, config).match_iter_indices(haystacks)
+
+
+class MultiMatcher(_IterApi):
     """`Matcher::from_patterns(&patterns, &config)` (src/matcher/mod.rs:95-111; composition src/matcher/multi.rs:84-152)."""
 
     def __init__(self, patterns, config=None):
@@ -302,6 +339,18 @@ class MultiMatcher:
         cp = haystacks if isinstance(haystacks, Corpus) else Corpus(haystacks)
         return _match_list_indices(lib().fzb_multi_match_list_indices, self.h, cp, selection)
 
+    def _indices_into(self, haystacks, index_offset):
+        cp = haystacks if isinstance(haystacks, Corpus) else Corpus(haystacks)
+        return _match_list_indices(lib().fzb_multi_match_list_indices_into, self.h, cp, None, index_offset)
+
+    def match_list_into(self, haystacks, first=0, count=None, index_offset=0):
+        """`Matcher::match_list_into` over the compiled patterns (src/matcher/mod.rs:373-392): unsorted, input order"""
+        cp = haystacks if isinstance(haystacks, Corpus) else Corpus(haystacks)
+        count = len(cp) - first if count is None else count
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_multi_match_list_into(self.h, cp.h, first, count, index_offset, C.byref(out), C.byref(n)))
+        return _take(out, n)
+
     def match_list_device(self, corpus, dev_out_ptr, capacity, dev_count_ptr, stream=0, first=0, count=None, index_offset=0):
         count = len(corpus) - first if count is None else count
         _check(lib().fzb_multi_match_list_device(self.h, corpus.h, first, count, index_offset, dev_out_ptr, capacity, dev_count_ptr, stream))
@@ -315,12 +364,13 @@ class MultiMatcher:
             pass
 
 
-def _match_list_indices(fn, handle, cp, selection):
+def _match_list_indices(fn, handle, cp, selection, index_offset=None):
     sel = None if selection is None else np.ascontiguousarray(selection, dtype=np.uint32)
     if sel is not None and len(sel) == 0:
         return []
     out, n, pos = C.c_void_p(), C.c_size_t(), C.c_void_p()
-    _check(fn(handle, cp.h, sel.ctypes.data if sel is not None else None, 0 if sel is None else len(sel), C.byref(out), C.byref(n), C.byref(pos)))
+    args = (handle, cp.h, sel.ctypes.data if sel is not None else None, 0 if sel is None else len(sel)) + (() if index_offset is None else (index_offset,))
+    _check(fn(*args, C.byref(out), C.byref(n), C.byref(pos)))
     try:
         recs = np.ctypeslib.as_array(C.cast(out, C.POINTER(C.c_uint8)), shape=(max(n.value, 1) * 16,))[: n.value * 16].view(MATCH_INDICES_DTYPE).copy()
         total = int((recs["positions_begin"].astype(np.int64) + recs["positions_len"]).max()) if len(recs) else 0
@@ -340,13 +390,15 @@ class MatchIndices:
         self.index, self.score, self.exact, self.indices = index, score, exact, indices
 
     def __eq__(self, o):
+        if not isinstance(o, MatchIndices):
+            return NotImplemented
         return (self.index, self.score, self.exact, self.indices) == (o.index, o.score, o.exact, o.indices)
 
     def __repr__(self):
         return f"MatchIndices(index={self.index}, score={self.score}, exact={self.exact}, indices={self.indices})"
 
 
-class Matcher:
+class Matcher(_IterApi):
     """`frizbee::Matcher` for one (non-negated, fuzzy) pattern: `Matcher::new(needle, &config)` (src/matcher/mod.rs:90-92)."""
 
     def __init__(self, needle, config=None):
@@ -396,6 +448,9 @@ class Matcher:
         positions in reverse order.  `selection` (corpus indices) plays the role of the haystack list - typically the top of a
         `match_list` result over a resident `Corpus`; `index` then numbers the selection."""
         return _match_list_indices(lib().fzb_match_list_indices, self.h, self._corpus(haystacks), selection)
+
+    def _indices_into(self, haystacks, index_offset):
+        return _match_list_indices(lib().fzb_match_list_indices_into, self.h, self._corpus(haystacks), None, index_offset)
 
     def match_list_into(self, haystacks, first=0, count=None, index_offset=0):
         """`Specialized::match_list(haystacks, haystack_index_offset, &mut matches)` (src/matcher/algo.rs:78-103): unsorted, input order."""

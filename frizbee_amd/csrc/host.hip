@@ -894,10 +894,11 @@ int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads,
 }  // extern "C"
 namespace {
 // The haystack list of the *_indices entry points: a selection of the corpus, or all of it.
-int check_selection(const fzb_corpus* c, const uint32_t* selection, size_t n_selection, size_t& count) {
+int check_selection(const fzb_corpus* c, const uint32_t* selection, size_t n_selection, size_t& count, uint32_t index_offset = 0) {
     count = selection ? n_selection : (size_t)c->dev.n;
-    if ((u64)count > 0xFFFFFFFFull)  // guard_against_haystack_overflow(haystacks.len(), 0), mod.rs:235
-        return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count) + " > 4294967295 (index offset: 0)");
+    if ((u64)count + (u64)index_offset > 0xFFFFFFFFull)  // guard_against_haystack_overflow(haystacks.len(), 0), mod.rs:235
+        return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " +
+                                       std::to_string(index_offset) + ")");
     for (size_t i = 0; i < n_selection; i++)
         if (selection[i] >= c->dev.n) return fail(FZB_ERR_INVALID, "selection entry outside the corpus");
     return FZB_OK;
@@ -972,7 +973,9 @@ int indices_in_list_order(fzb_matcher* m, const fzb_corpus* c, const uint32_t* s
 
 // the ordering step (mod.rs:268-273) and the hand-over to the caller
 int finish_indices(std::vector<fzb_match_indices>& recs, const std::vector<u32>& positions, int sort, bool sort_by_score, fzb_match_indices** out, size_t* out_len,
-                   uint32_t** out_positions) {
+                   uint32_t** out_positions, uint32_t index_offset = 0) {
+    if (index_offset)
+        for (fzb_match_indices& r : recs) r.index += index_offset;
     const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;
     const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;
     if (reversed) std::reverse(recs.begin(), recs.end());
@@ -995,21 +998,31 @@ int finish_indices(std::vector<fzb_match_indices>& recs, const std::vector<u32>&
 }  // namespace
 extern "C" {
 
-int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
-                           uint32_t** out_positions) {
+static int match_list_indices_impl(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, int sort, uint32_t index_offset,
+                                   fzb_match_indices** out, size_t* out_len, uint32_t** out_positions) {
     if (!m || !c || !out || !out_len || !out_positions || (!selection && n_selection)) return fail(FZB_ERR_INVALID, "null argument");
     *out = nullptr;
     *out_len = 0;
     *out_positions = nullptr;
     size_t count = 0;
-    int rc = check_selection(c, selection, n_selection, count);
+    int rc = check_selection(c, selection, n_selection, count, index_offset);
     if (rc) return rc;
     std::vector<fzb_match_indices> recs;
     std::vector<u32> positions;
     rc = indices_in_list_order(m, c, selection, count, recs, positions);
     if (rc) return rc;
     // CompiledPatterns::Empty returns before the score sort (mod.rs:237-246) - all scores are 0 anyway
-    return finish_indices(recs, positions, m->config.sort, !m->empty, out, out_len, out_positions);
+    return finish_indices(recs, positions, sort, !m->empty, out, out_len, out_positions, index_offset);
+}
+
+int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
+                           uint32_t** out_positions) {
+    return match_list_indices_impl(m, c, selection, n_selection, m ? m->config.sort : 0, 0, out, out_len, out_positions);
+}
+
+int fzb_match_list_indices_into(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, uint32_t index_offset, fzb_match_indices** out,
+                                size_t* out_len, uint32_t** out_positions) {
+    return match_list_indices_impl(m, c, selection, n_selection, FZB_SORT_INDEX_ASC, index_offset, out, out_len, out_positions);
 }
 
 void fzb_match_indices_free(fzb_match_indices* matches, uint32_t* positions) {
@@ -1284,26 +1297,26 @@ int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match**
 // `Matcher::match_list_indices` over CompiledPatterns (mod.rs:234-275): Empty / Single as above; Multi = match_one_indices_multi
 // (multi.rs:56-82) for every haystack of the list.  Like match_list_multi_into, every pattern only sees the haystacks that are
 // still alive, and each pattern's positions come from the traced scorer on the device; the per-haystack union is host work.
-int fzb_multi_match_list_indices(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
-                                 uint32_t** out_positions) {
+static int multi_match_list_indices_impl(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, int sort, uint32_t index_offset,
+                                         fzb_match_indices** out, size_t* out_len, uint32_t** out_positions) {
     if (!mm || !c || !out || !out_len || !out_positions || (!selection && n_selection)) return fail(FZB_ERR_INVALID, "null argument");
     *out = nullptr;
     *out_len = 0;
     *out_positions = nullptr;
     size_t count = 0;
-    int rc = check_selection(c, selection, n_selection, count);
+    int rc = check_selection(c, selection, n_selection, count, index_offset);
     if (rc) return rc;
     std::vector<fzb_match_indices> recs;
     std::vector<u32> positions;
     if (mm->patterns.empty()) {  // CompiledPatterns::Empty
         recs.resize(count);
         for (size_t i = 0; i < count; i++) recs[i] = fzb_match_indices{(uint32_t)i, 0, 0, 0, 0, 0};
-        return finish_indices(recs, positions, mm->config.sort, false, out, out_len, out_positions);
+        return finish_indices(recs, positions, sort, false, out, out_len, out_positions, index_offset);
     }
     if (mm->patterns.size() == 1 && !mm->patterns[0].negated) {  // CompiledPatterns::Single
         rc = indices_in_list_order(mm->patterns[0].m, c, selection, count, recs, positions);
         if (rc) return rc;
-        return finish_indices(recs, positions, mm->config.sort, true, out, out_len, out_positions);
+        return finish_indices(recs, positions, sort, true, out, out_len, out_positions, index_offset);
     }
     // alive[k] = (position in the caller's list, corpus index); combined score / exact / positions per alive haystack
     std::vector<u32> alive_pos(count), alive_idx(count);
@@ -1350,7 +1363,36 @@ int fzb_multi_match_list_indices(fzb_multi_matcher* mm, const fzb_corpus* c, con
         recs.push_back(fzb_match_indices{at, (uint16_t)score[at], exact[at], 0, (uint32_t)positions.size(), (uint32_t)f.size()});
         positions.insert(positions.end(), f.begin(), f.end());
     }
-    return finish_indices(recs, positions, mm->config.sort, true, out, out_len, out_positions);
+    return finish_indices(recs, positions, sort, true, out, out_len, out_positions, index_offset);
+}
+
+int fzb_multi_match_list_indices(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, fzb_match_indices** out, size_t* out_len,
+                                 uint32_t** out_positions) {
+    return multi_match_list_indices_impl(mm, c, selection, n_selection, mm ? mm->config.sort : 0, 0, out, out_len, out_positions);
+}
+
+int fzb_multi_match_list_indices_into(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, uint32_t index_offset,
+                                      fzb_match_indices** out, size_t* out_len, uint32_t** out_positions) {
+    return multi_match_list_indices_impl(mm, c, selection, n_selection, FZB_SORT_INDEX_ASC, index_offset, out, out_len, out_positions);
+}
+
+// `Matcher::match_list_into` over CompiledPatterns (src/matcher/mod.rs:373-392): index order, host result
+int fzb_multi_match_list_into(fzb_multi_matcher* mm, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len) {
+    if (!mm || !c || !out || !out_len) return fail(FZB_ERR_INVALID, "null argument");
+    if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
+    *out = nullptr;
+    *out_len = 0;
+    if (mm->out_cap < count || !mm->count_dev) {
+        if (mm->out_dev) (void)hipFree(mm->out_dev);
+        mm->out_dev = nullptr;
+        mm->out_cap = 0;
+        HIPCHK(dev_alloc((void**)&mm->out_dev, (count + 16) * sizeof(fzb_match_rec)));
+        mm->out_cap = count;
+        if (!mm->count_dev) HIPCHK(dev_alloc((void**)&mm->count_dev, 16));
+    }
+    int rc = fzb_multi_match_list_device(mm, c, first, count, index_offset, (fzb_match*)mm->out_dev, mm->out_cap, mm->count_dev, nullptr);
+    if (rc) return rc;
+    return fetch_records(mm->out_dev, mm->count_dev, out, out_len);
 }
 
 void fzb_matches_free(fzb_match* p) {

@@ -159,6 +159,11 @@ typedef struct fzb_match_indices {
  * stable sort by descending score for the Score* strategies.  Free with fzb_match_indices_free. */
 int fzb_match_list_indices(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection,
                            fzb_match_indices** out, size_t* out_len, uint32_t** out_positions);
+/* The unordered form: `Specialized::match_list_indices` (src/matcher/algo.rs:24-33) and what `Matcher::match_iter_indices` /
+ * `match_one_indices` (src/matcher/mod.rs:321-334, 357-371) yield - list order whatever `config.sort` says,
+ * `index = index_offset + position in the list`. */
+int fzb_match_list_indices_into(fzb_matcher* m, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, uint32_t index_offset,
+                                fzb_match_indices** out, size_t* out_len, uint32_t** out_positions);
 void fzb_match_indices_free(fzb_match_indices* matches, uint32_t* positions);
 
 /* `radix_sort_matches(&mut [Match])` (src/sort.rs:6-40): stable, descending score, host side */
@@ -203,6 +208,12 @@ int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match**
  * must match, scores add with saturation, exact flags OR, and the patterns' positions are merged (descending, de-duplicated). */
 int fzb_multi_match_list_indices(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection,
                                  fzb_match_indices** out, size_t* out_len, uint32_t** out_positions);
+/* list-order forms (see fzb_match_list_into / fzb_match_list_indices_into): `Matcher::match_list_into` over CompiledPatterns
+ * (src/matcher/mod.rs:373-392) with the result on the host, and what `match_iter` / `match_one` / `match_iter_indices` yield
+ * (`match_one_multi`, `match_one_indices_multi`, src/matcher/multi.rs:29-82) */
+int fzb_multi_match_list_into(fzb_multi_matcher* mm, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len);
+int fzb_multi_match_list_indices_into(fzb_multi_matcher* mm, const fzb_corpus* c, const uint32_t* selection, size_t n_selection, uint32_t index_offset,
+                                      fzb_match_indices** out, size_t* out_len, uint32_t** out_positions);
 /* `match_list_multi_into(patterns, haystacks, haystack_index_offset, matches)` (src/matcher/multi.rs:84-152): index order, result in HBM */
 int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset,
                                 fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);

@@ -236,6 +236,42 @@ class Matcher {  // src/matcher/mod.rs:77-222
     template <typename Strings>
     std::vector<MatchIndices> match_list_indices(const Strings& haystacks) { return match_list_indices(Corpus(haystacks)); }
 
+    // The per-item side of the interface (src/matcher/mod.rs:277-371), served by one batched device pass in list order:
+    // `match_iter(haystacks)`: the matches in haystack order whatever config.sort says; `match_one(haystack, index)`
+    std::vector<Match> match_iter(const Corpus& corpus, uint32_t index_offset = 0) {
+        fzb_match* out = nullptr;
+        size_t n = 0;
+        const size_t count = fzb_corpus_len(corpus.raw());
+        if (single_) check(fzb_match_list_into(single_.get(), corpus.raw(), 0, count, index_offset, &out, &n));
+        else check(fzb_multi_match_list_into(multi_.get(), corpus.raw(), 0, count, index_offset, &out, &n));
+        return take(out, n);
+    }
+    template <typename Strings>
+    std::vector<Match> match_iter(const Strings& haystacks) { return match_iter(Corpus(haystacks)); }
+    std::optional<Match> match_one(const std::string& haystack, uint32_t index) {
+        auto v = match_iter(Corpus(std::vector<std::string>{haystack}), index);
+        return v.empty() ? std::nullopt : std::optional<Match>(v[0]);
+    }
+    // `match_iter_indices(haystacks)` / `match_one_indices(haystack, index)`
+    std::vector<MatchIndices> match_iter_indices(const Corpus& corpus, uint32_t index_offset = 0) {
+        fzb_match_indices* out = nullptr;
+        uint32_t* pos = nullptr;
+        size_t n = 0;
+        if (single_) check(fzb_match_list_indices_into(single_.get(), corpus.raw(), nullptr, 0, index_offset, &out, &n, &pos));
+        else check(fzb_multi_match_list_indices_into(multi_.get(), corpus.raw(), nullptr, 0, index_offset, &out, &n, &pos));
+        std::vector<MatchIndices> v(n);
+        for (size_t i = 0; i < n; i++)
+            v[i] = MatchIndices{out[i].score, out[i].index, out[i].exact != 0, std::vector<uint32_t>(pos + out[i].positions_begin, pos + out[i].positions_begin + out[i].positions_len)};
+        fzb_match_indices_free(out, pos);
+        return v;
+    }
+    template <typename Strings>
+    std::vector<MatchIndices> match_iter_indices(const Strings& haystacks) { return match_iter_indices(Corpus(haystacks)); }
+    std::optional<MatchIndices> match_one_indices(const std::string& haystack, uint32_t index) {
+        auto v = match_iter_indices(Corpus(std::vector<std::string>{haystack}), index);
+        return v.empty() ? std::nullopt : std::optional<MatchIndices>(v[0]);
+    }
+
     // `match_list_parallel(&haystacks, threads)`: same result for every thread count; threads == 0 panics like the reference
     std::vector<Match> match_list_parallel(const Corpus& corpus, size_t threads) {
         if (threads == 0) throw Panic("threads must be positive");
@@ -308,5 +344,15 @@ class Matcher {  // src/matcher/mod.rs:77-222
     std::unique_ptr<fzb_matcher, DelS> single_;
     std::unique_ptr<fzb_multi_matcher, DelM> multi_;
 };
+
+// `iter::FuzzyMatchExt` (src/matcher/iter.rs:35-126): `haystacks.iter().fuzzy_match(needle, &config)`
+template <typename Strings>
+inline std::vector<Match> fuzzy_match(const Strings& haystacks, const std::string& needle, const Config& config = Config()) {
+    return Matcher(needle.c_str(), config).match_iter(haystacks);
+}
+template <typename Strings>
+inline std::vector<MatchIndices> fuzzy_match_indices(const Strings& haystacks, const std::string& needle, const Config& config = Config()) {
+    return Matcher(needle.c_str(), config).match_iter_indices(haystacks);
+}
 
 }  // namespace frizbee

@@ -128,6 +128,36 @@ static void gpu_side() {
         for (size_t i = 0; i < pos.size() && i < top.size(); i++)
             CHECK(pos[i].index == i && pos[i].score == top[i].score && pos[i].exact == top[i].exact && (pos[i].indices == std::vector<uint32_t>{5, 4, 3, 2, 1, 0}));
     }
+    {  // match_iter / match_one / FuzzyMatchExt (src/matcher/mod.rs:655-734, src/matcher/iter.rs:158-222)
+        const std::vector<std::string> hs = {"deadbeef", "deadbf", "deadbeefg", "deadbe", "no-match", "DeAdBe", "\xc3\xa9\xeb\x8b\xa4\xf0\x9f\x98\x80" "dead__be"};
+        for (const char* needle : {"deadbe", "\xc3\xa9\xeb\x8b\xa4\xf0\x9f\x98\x80"}) {
+            for (int t = -1; t <= 3; t++) {
+                const Config cfg = Config().max_typos(t < 0 ? std::nullopt : std::optional<uint16_t>((uint16_t)t)).sort(SortStrategy::IndexAsc);
+                Matcher m(needle, cfg);
+                auto from_list = m.match_list(hs);
+                CHECK(m.match_iter(hs) == from_list);
+                CHECK(fuzzy_match(hs, needle, cfg) == from_list);
+                CHECK(Matcher(needle, cfg.sort(SortStrategy::ScoreThenIndexAsc)).match_iter(hs) == from_list);  // match_iter never sorts
+                auto ix_list = m.match_list_indices(hs);
+                CHECK(m.match_iter_indices(hs) == ix_list);
+                CHECK(fuzzy_match_indices(hs, needle, cfg) == ix_list);
+                for (size_t i = 0; i < hs.size(); i++) {
+                    auto one = m.match_one(hs[i], (uint32_t)i);
+                    bool found = false;
+                    for (const Match& w : from_list)
+                        if (w.index == i) { found = true; CHECK(one && *one == w); }
+                    if (!found) CHECK(!one);
+                }
+            }
+        }
+        auto all = Matcher("").match_iter(std::vector<std::string>{"foo", "bar"});
+        CHECK(all.size() == 2 && all[0].index == 0 && all[1].index == 1);
+        auto all_ix = fuzzy_match_indices(std::vector<std::string>{"foo", "bar"}, "");
+        CHECK(all_ix.size() == 2 && all_ix[0].index == 0 && all_ix[1].index == 1 && all_ix[1].indices.empty());
+        auto mone = multi("dead !bf", Config()).match_one("deadbeef", 7);
+        CHECK(mone && mone->index == 7);
+        CHECK(!multi("dead !bf", Config()).match_one("deadbf", 7));
+    }
     {  // literal modes (src/literal/mod.rs:55-91)
         const Config ia = Config().sort(SortStrategy::IndexAsc);
         CHECK((indices(Matcher("foo", ia.matching(Matching::Exact)).match_list(std::vector<std::string>{"foo", "foobar", "xfoo", "FOO"})) == std::vector<uint32_t>{0, 3}));

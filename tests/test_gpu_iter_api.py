@@ -1,0 +1,71 @@
+"""The per-item side of the reference's interface on the HIP path (`match_iter`, `match_one`, `match_iter_indices`,
+`match_one_indices`, `iter::FuzzyMatchExt`): the reference's own tests for it (src/matcher/mod.rs:655-734, src/matcher/iter.rs:150-239,
+the `match_one` leg of tests/api_properties.rs:381-400), each served by one batched device pass in list order."""
+import numpy as np
+import pytest
+
+import frizbee_amd as F
+import oracle_lib as O
+from ref_generators import multi_cases
+
+pytestmark = pytest.mark.gpu
+
+HAYSTACKS = ["deadbeef", "deadbf", "deadbeefg", "deadbe", "no-match", "DeAdBe", "é다😀dead__be"]
+
+
+def tup(ms):
+    return [(m.index, m.score, m.exact, m.indices) for m in ms]
+
+
+def test_match_iter_matches_match_list():
+    # src/matcher/mod.rs:655-681, 695-721; src/matcher/iter.rs:158-200
+    for needle in ("deadbe", "é다😀"):
+        for max_typos in (None, 0, 1, 2, 3):
+            cfg = F.Config(max_typos=max_typos, sort=F.SortStrategy.IndexAsc, pf_lanes=64)
+            m = F.Matcher(needle, cfg)
+            from_list = m.match_list(HAYSTACKS)
+            assert list(map(tuple, (r.tolist() for r in m.match_iter(HAYSTACKS)))) == list(map(tuple, from_list.tolist())), (needle, max_typos)
+            assert from_list.tolist() == O.Matcher(needle, max_typos=max_typos, sort="IndexAsc").match_list(HAYSTACKS).tolist()
+            assert tup(m.match_iter_indices(HAYSTACKS)) == tup(m.match_list_indices(HAYSTACKS)), (needle, max_typos)
+            assert [r.tolist() for r in F.fuzzy_match(HAYSTACKS, needle, cfg)] == from_list.tolist()
+            assert tup(F.fuzzy_match_indices(HAYSTACKS, needle, cfg)) == tup(m.match_list_indices(HAYSTACKS))
+            # match_iter ignores the sort strategy: haystack order even for a score-sorted matcher
+            ms = F.Matcher(needle, F.Config(max_typos=max_typos, sort=F.SortStrategy.ScoreThenIndexDesc, pf_lanes=64))
+            assert [r.tolist() for r in ms.match_iter(HAYSTACKS)] == from_list.tolist()
+            assert tup(ms.match_iter_indices(HAYSTACKS)) == tup(m.match_list_indices(HAYSTACKS))
+
+
+def test_empty_needle_yields_all():
+    # src/matcher/mod.rs:683-692, 723-733; src/matcher/iter.rs:202-222
+    for it in (F.Matcher("").match_iter(["foo", "bar"]), F.fuzzy_match(["foo", "bar"], "")):
+        assert [int(r["index"]) for r in it] == [0, 1]
+    for it in (F.Matcher("").match_iter_indices(["foo", "bar"]), F.fuzzy_match_indices(["foo", "bar"], "")):
+        assert tup(it) == [(0, 0, False, []), (1, 0, False, [])]
+
+
+def test_fuzzy_match_chains_with_other_adapters():
+    # src/matcher/iter.rs:224-239
+    it = F.fuzzy_match([h for h in HAYSTACKS if not h.startswith("no")], "deadbe", F.Config(max_typos=0, sort=F.SortStrategy.IndexAsc))
+    assert [int(m["index"]) for m in it]
+
+
+def test_match_one_agrees_with_the_list_forms():
+    # tests/api_properties.rs:381-400 (single- and multi-pattern): match_one(haystack, index) is the list's record for that haystack, or None
+    m = F.Matcher("deadbe", F.Config(max_typos=1, pf_lanes=64))
+    want = {int(r["index"]): r.tolist() for r in m.match_list(HAYSTACKS)}
+    want_ix = {x.index: x for x in m.match_list_indices(HAYSTACKS)}
+    for i, h in enumerate(HAYSTACKS):
+        one, one_ix = m.match_one(h, i), m.match_one_indices(h, i)
+        assert (one.tolist() if one is not None else None) == want.get(i)
+        assert one_ix == want_ix.get(i)
+    for it, (patterns, haystacks, cfg) in enumerate(multi_cases(25, 3)):
+        fpats = [F.Pattern(p["needle"], negated=p["negated"], matching=None if p["matching"] is None else F.Matching[p["matching"]]) for p in patterns]
+        fm = F.MultiMatcher(fpats, F.Config(max_typos=cfg["max_typos"], casing=F.CaseMatching[cfg["casing"]], matching=F.Matching[cfg["matching"]], sort=F.SortStrategy.ScoreThenIndexAsc, pf_lanes=64))
+        om = O.MultiMatcher([O.P(p["needle"], negated=p["negated"], matching=p["matching"]) for p in patterns], sort="IndexAsc", **cfg)
+        ref = om.reference_composition(haystacks)
+        assert [r.tolist() for r in fm.match_iter(haystacks)] == ref.tolist(), (it, patterns, cfg)
+        assert tup(fm.match_iter_indices(haystacks)) == om.match_list_indices_ordered(haystacks), (it, patterns, cfg)
+        by_index = {int(r["index"]): r.tolist() for r in ref}
+        for i, h in enumerate(haystacks[:6]):
+            one = fm.match_one(h, i)
+            assert (one.tolist() if one is not None else None) == by_index.get(i), (it, i)
