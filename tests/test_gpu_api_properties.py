@@ -78,3 +78,15 @@ def test_generated_multi_pattern_properties_through_hip(pf):
                 assert got.tolist() == om.reference_composition(haystacks).tolist(), (it, patterns, cfg)
             ix = [(m.index, m.score, m.exact, m.indices) for m in fm.match_list_indices(corpus)]
             assert ix == om.match_list_indices_ordered(haystacks), (it, patterns, cfg, sort)
+
+
+@pytest.mark.parametrize("pf", [64, 32, 16])
+def test_follows_the_reference_where_its_prefilter_deviates_from_the_lcs_criterion(pf):
+    # tests/test_oracle_reference_properties.py LCS_DEVIATIONS_1_TYPO: the reference's two-path scan rejects these at 32 lanes (LCS accepts)
+    from test_oracle_reference_properties import LCS_DEVIATIONS_1_TYPO
+    hs = [h for _, h in LCS_DEVIATIONS_1_TYPO] + ["filler", ""]
+    for needle, hay in LCS_DEVIATIONS_1_TYPO:
+        want = O.Matcher(needle, lanes=LANES[pf], max_typos=1, sort="IndexAsc", casing="Ignore").match_list(hs)
+        got = F.Matcher(needle, F.Config(max_typos=1, sort=F.SortStrategy.IndexAsc, casing=F.CaseMatching.Ignore, pf_lanes=pf)).match_list(hs)
+        assert got.tolist() == want.tolist(), (needle, pf)
+        assert (hs.index(hay) in want["index"].tolist()) == (pf != 32), (needle, pf)

@@ -207,3 +207,90 @@ def test_generated_multi_pattern_properties(lanes):
         sorted_ = O.MultiMatcher(pats, lanes=lanes, sort="ScoreThenIndexAsc", **cfg).match_list(haystacks)
         assert all(a["score"] > b["score"] or (a["score"] == b["score"] and a["index"] < b["index"]) for a, b in zip(sorted_[:-1], sorted_[1:])), (patterns, cfg)
         assert sorted(sorted_.tolist()) == sorted(reference.tolist()), (patterns, cfg)
+
+
+# ---- a second, independent transcription of match_haystack_1_typo (src/prefilter/algo/ascii_typos.rs:14-118), lane count as a parameter ----
+def _one_typo(needle, hay, lanes, case_sensitive):
+    def pair(c):
+        if case_sensitive:
+            return (c, c)
+        return (c, c - 32) if 97 <= c <= 122 else (c, c + 32) if 65 <= c <= 90 else (c, c)  # case_needle, src/prefilter/mod.rs:49-65
+
+    def occ(chunk, p):
+        m = 0
+        for i, b in enumerate(chunk):
+            if b == p[0] or b == p[1]:
+                m |= 1 << i
+        return m
+
+    def clear_through_lowest(mask, matches):
+        low = matches & -matches
+        return mask & ~((low << 1) - 1)
+
+    nd = [pair(c) for c in needle]
+    n, ln = len(nd), len(hay)
+    if n <= 1:
+        return True
+    if ln == 0:
+        return False
+    first, second = 0, 1
+    for start in range(0, ln, lanes):
+        chunk = list(hay[start : start + lanes])
+        chunk_mask = (1 << len(chunk)) - 1
+        chunk += [0] * (lanes - len(chunk))
+        first_mask, second_mask = occ(chunk, nd[first]), occ(chunk, nd[second])
+        first_cm = second_cm = chunk_mask
+        while True:
+            advanced = False
+            cand = first + 1
+            if cand > second:
+                if cand == n:
+                    return True
+                second, second_cm = cand, first_cm
+                second_mask = occ(chunk, nd[second])
+            elif cand == second and first_cm > second_cm:
+                second_cm = first_cm
+            hits = first_mask & first_cm
+            if hits:
+                first += 1
+                first_cm = clear_through_lowest(first_cm, hits)
+                first_mask = occ(chunk, nd[first])
+                advanced = True
+            hits = second_mask & second_cm
+            if hits:
+                second += 1
+                if second >= n:
+                    return True
+                second_cm = clear_through_lowest(second_cm, hits)
+                second_mask = occ(chunk, nd[second])
+                advanced = True
+            if not advanced:
+                break
+    return False
+
+
+# inputs on which the reference's greedy two-path scan REJECTS at 32 lanes although LCS + 1 >= len(needle) (and 16 / 64 lanes accept):
+# its own `randomized_backend_parity_and_oracle` would fail here.  Found by oracle/selfcheck.cpp (~1e-5 of random cases); the HIP path
+# follows the reference, not the LCS criterion (tests/test_gpu_parity.py runs the same inputs).
+LCS_DEVIATIONS_1_TYPO = [
+    ("aa_CB-bA A", "b/-cbcCCc0_C_ cAAc- Ac/_0a0b_b _CBaB0c a_cAbC0A B-CA0c-//aBcbCa0"),
+    ("AA _C/0C-C", "B0_bB1a0CC1_0_-/00aACbAAba/C_ bCc_c -A00-Bb acCb-0_b/1Abc-0bCaaA 0a"),
+    ("x__x-Cc- 1", "x1/-C/cBcx10bCA_00CxBbac/11xCzz/Az _xBb1CzCxcCCaA_xzCa- zb _z-C-a01x/c xC-"),
+]
+
+
+def test_one_typo_prefilter_against_an_independent_transcription():
+    for needle, hay in LCS_DEVIATIONS_1_TYPO:
+        n, h = needle.encode(), hay.encode()
+        assert lcs_len(n, h, byte_eq(False)) + 1 >= len(n)
+        assert [_one_typo(n, h, lanes, False) for lanes in (16, 32, 64)] == [True, False, True]
+        assert [O.prefilter(n, h, 1, False, False, lanes)[0] for lanes in (16, 32, 64)] == [True, False, True]
+    rng = np.random.default_rng(99)
+    alpha = b"abcABC_-/ 01xyz"
+    for _ in range(4000):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(1, 12))))
+        hay = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.choice([0, 1, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 140]))))
+        cs = bool(rng.integers(0, 2))
+        for lanes in (16, 32, 64):
+            assert O.prefilter(needle, hay, 1, cs, False, lanes)[0] == _one_typo(needle, hay, lanes, cs), (needle, hay, cs, lanes)
