@@ -294,3 +294,51 @@ def test_one_typo_prefilter_against_an_independent_transcription():
         cs = bool(rng.integers(0, 2))
         for lanes in (16, 32, 64):
             assert O.prefilter(needle, hay, 1, cs, False, lanes)[0] == _one_typo(needle, hay, lanes, cs), (needle, hay, cs, lanes)
+
+
+def test_smith_waterman_against_an_independent_second_transcription():
+    # both are transcriptions of src/smith_waterman/algo/ascii.rs; they were written separately, so a slip in one shows up here
+    import sw_second_transcription as T2
+    rng = np.random.default_rng(2024)
+    alpha = b"abcABC_-/ 01xyzXYZ."
+    for it in range(600):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(1, 14))))
+        hay = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.choice([0, 1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 140]))))
+        if rng.random() < 0.6 and len(hay) >= len(needle):  # plant the needle as a subsequence
+            h = bytearray(hay)
+            for q, c in zip(np.sort(rng.choice(len(hay), len(needle), replace=False)), needle):
+                h[q] = c
+            hay = bytes(h)
+        scoring = list(O.DEFAULT_SCORING)
+        if it % 3 == 1:  # random small constants (still inside the overflow guards of both classes)
+            scoring = [int(rng.integers(1, 17)), int(rng.integers(0, 9)), int(rng.integers(0, 9)), int(rng.integers(0, 4)), int(rng.integers(0, 17)),
+                       int(rng.integers(0, 9)), int(rng.integers(0, 9)), int(rng.integers(0, 17)), int(rng.integers(0, 9))]
+        cs, prefix = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        for lanes, u8 in WIDTHS:
+            if u8 and not O.score_fits_in_u8(len(needle), scoring):
+                continue
+            want = T2.score_haystack(needle, hay, scoring, cs, prefix, lanes, 8 if u8 else 16)
+            got = O.sw_score(needle, hay, scoring=scoring, case_sensitive=cs, include_prefix=prefix, lanes=lanes, is_u8=u8)
+            assert got == want, (needle, hay, scoring, cs, prefix, lanes, u8, got, want)
+
+
+def test_the_second_transcription_is_itself_pinned_to_the_reference_known_answers():
+    import sw_second_transcription as T2
+    sc = list(O.DEFAULT_SCORING)
+    for v in SW["sw_ascii"]:  # src/smith_waterman/mod.rs:209-345, the 8 x u16 scalar backend; these cases hold at every width
+        for lanes, u8 in WIDTHS:
+            if u8 and not O.score_fits_in_u8(len(v["needle"].encode())):
+                continue
+            assert T2.score_haystack(v["needle"].encode(), v["haystack"].encode(), sc, False, True, lanes, 8 if u8 else 16) == v["score"], (v, lanes, u8)
+    for v in SW["sw_case"]:
+        assert T2.score_haystack(v["needle"].encode(), v["haystack"].encode(), sc, v["case_sensitive"], True, 8, 16) == v["score"], v
+    for v in SW["sw_greater"]:
+        a, b = (T2.score_haystack(n.encode(), h.encode(), sc, False, True, 8, 16) for n, h in (v["a"], v["b"]))
+        assert a > b, v
+    for v in SW["sw_cross_width"]:  # parity.rs:95-124
+        want = T2.score_haystack(v["needle"].encode(), v["haystack"].encode(), sc, False, True, 8, 16)
+        for lanes, u8 in WIDTHS:
+            if u8 and not O.score_fits_in_u8(len(v["needle"].encode())):
+                continue
+            assert T2.score_haystack(v["needle"].encode(), v["haystack"].encode(), sc, False, True, lanes, 8 if u8 else 16) == want, (v, lanes, u8)
