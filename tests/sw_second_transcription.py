@@ -97,3 +97,48 @@ def score_haystack(needle, haystack, scoring, case_sensitive, include_prefix, la
     if matrices is not None:
         matrices["S"], matrices["MM"], matrices["chunks"] = S, MM, chunks
     return max(max_scores)
+
+
+def alignment_indices(needle_len, matrices, lanes, bits, score, max_typos=None, haystack_start_pos=0, unicode_haystack=None, on_match=None):
+    """AlignmentPathIter (src/smith_waterman/alignment_iter.rs:35-181) over the matrices of the call above, collecting what
+    score_haystack_indices (algo/mod.rs:49-94) collects: the haystack position of every Match step, in walk (= reverse) order."""
+    S, MM, chunks = matrices["S"], matrices["MM"], matrices["chunks"]
+    L = lanes
+    zero = [0] * L
+    cell = lambda d, r, c: d.get((r, c // L), zero)[c % L]
+    search = score & ((1 << bits) - 1)
+    col = None
+    for chunk_idx in range(1, chunks):  # get_col_idx: first lane of the last row holding the score
+        row = S.get((needle_len, chunk_idx), zero)
+        if search in row:
+            col = chunk_idx * L + row.index(search)
+            break
+    assert col is not None, "could not find max score in score matrix final row"
+    out = []
+    r, typos = needle_len, 0
+    while True:
+        if r == 0:
+            break
+        if max_typos is not None and typos > max_typos:
+            break
+        if col < L or score == 0:
+            break
+        hidx = col - L
+        if unicode_haystack is not None and hidx < len(unicode_haystack) and unicode_haystack[hidx] & 0xC0 == 0x80:
+            col -= 1
+            score = cell(S, r, col)
+            continue
+        if cell(MM, r, col) != 0:
+            (on_match or (lambda needle_idx, pos: out.append(pos)))(r - 1, hidx + haystack_start_pos)
+            r -= 1
+            col -= 1
+            score = cell(S, r, col)
+            continue
+        diag, left, up = cell(S, r - 1, col - 1), cell(S, r, col - 1), cell(S, r - 1, col)
+        if diag >= left and diag >= up:
+            r, col, typos, score = r - 1, col - 1, typos + 1, diag
+        elif left >= up:
+            col, score = col - 1, left
+        else:
+            typos, r, score = typos + 1, r - 1, up
+    return out

@@ -342,3 +342,30 @@ def test_the_second_transcription_is_itself_pinned_to_the_reference_known_answer
             if u8 and not O.score_fits_in_u8(len(v["needle"].encode())):
                 continue
             assert T2.score_haystack(v["needle"].encode(), v["haystack"].encode(), sc, False, True, lanes, 8 if u8 else 16) == want, (v, lanes, u8)
+
+
+def test_traceback_against_the_second_transcription():
+    import sw_second_transcription as T2
+    rng = np.random.default_rng(31337)
+    alpha = b"abcABC_-/ 01xyz"
+    sc = list(O.DEFAULT_SCORING)
+    for it in range(500):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(1, 11))))
+        hay = bytearray(alpha[int(x)] for x in rng.integers(0, asz, int(rng.choice([1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 64, 65, 100]))))
+        if rng.random() < 0.7 and len(hay) >= len(needle):
+            for q, c in zip(np.sort(rng.choice(len(hay), len(needle), replace=False)), needle):
+                hay[q] = c
+        hay = bytes(hay)
+        cs = bool(rng.integers(0, 2))
+        max_typos = [None, 0, 1, 3][int(rng.integers(0, 4))]
+        start_pos = int(rng.integers(0, 3))
+        for lanes, u8 in WIDTHS:
+            if u8 and not O.score_fits_in_u8(len(needle), sc):
+                continue
+            bits = 8 if u8 else 16
+            mats = {}
+            score = T2.score_haystack(needle, hay, sc, cs, start_pos == 0, lanes, bits, mats)
+            want = T2.alignment_indices(len(needle), mats, lanes, bits, score, max_typos, start_pos) if score else []
+            got = O.sw_indices(needle, hay, start_pos=start_pos, max_typos=max_typos, case_sensitive=cs, lanes=lanes, is_u8=u8)
+            assert got == (score, want), (needle, hay, cs, max_typos, start_pos, lanes, u8, got, (score, want))
