@@ -142,3 +142,161 @@ def alignment_indices(needle_len, matrices, lanes, bits, score, max_typos=None, 
         else:
             typos, r, score = typos + 1, r - 1, up
     return out
+
+
+def case_needle_unicode(needle, case_sensitive):  # src/prefilter/mod.rs:70-96 -> [(utf8 bytes, flipped utf8 bytes)]
+    out = []
+    for c in needle:
+        b = c.encode()
+        flipped = None
+        if not case_sensitive and c.isupper():
+            low = c.lower()
+            if len(low) == 1 and len(low.encode()) == len(b):
+                flipped = low
+        elif not case_sensitive and c.islower():
+            up = c.upper()
+            if len(up) == 1 and len(up.encode()) == len(b):
+                flipped = up
+        out.append((b, (flipped or c).encode()))
+    return out
+
+
+def score_haystack_unicode(needle, haystack, scoring, case_sensitive, include_prefix, lanes, bits, matrices=None):
+    """src/smith_waterman/algo/unicode.rs:10-273 + unicode_gap.rs:110-236; `needle` is a str, `haystack` bytes."""
+    match_s, mismatch, gap_open, gap_extend, prefix_b, cap_b, case_b, _exact, delim_b = scoring
+    M = (1 << bits) - 1
+    L = lanes
+    splat = lambda v: [v & M] * L
+    add = lambda a, b: [(x + y) & M for x, y in zip(a, b)]
+    subs = lambda a, b: [x - y if x > y else 0 for x, y in zip(a, b)]
+    vmax = lambda a, b: [max(x, y) for x, y in zip(a, b)]
+    vand = lambda a, b: [x & y for x, y in zip(a, b)]
+    shift = lambda v, n, prev: prev[L - n :] + v[: L - n]
+    widen = lambda mask: [M if x else 0 for x in mask]
+    zero = [0] * L
+
+    chars = case_needle_unicode(needle, case_sensitive)
+    if not chars:
+        return 0
+    n = len(haystack)
+    chunks = (n + L - 1) // L + 1
+    gex = splat(gap_extend)
+    gop = splat(max(gap_open - gap_extend, 0))
+    match_score = splat(min(match_s + mismatch, 0xFFFF))
+    mismatch_v = splat(mismatch)
+    case_v, cap_v, delim_v = splat(case_b), splat(cap_b), splat(delim_b)
+    rows = len(chars)
+    max_scores = list(zero)
+    pending = {r: list(zero) for r in range(rows + 1)}
+    prefix_masked = [prefix_b & M] + [0] * (L - 1) if include_prefix else list(zero)
+    prev_delim = [False] * L
+    prev_lower = [False] * L
+    prev_cont_gex = list(zero)
+    prev_scalar_start = list(zero)
+    S, MM = {}, {}
+    get = lambda d, r, c: d.get((r, c), zero)
+    load = lambda start: [haystack[start + i] if start + i < n else 0 for i in range(L)]  # load_partial(ptr, start, len)
+
+    def char_match_mask(byte_chunks, scalar_start, b):  # unicode_char_match_mask, unicode.rs:219-241
+        clen = len(b)
+        mask = [x == b[clen - 1] and s for x, s in zip(byte_chunks[4 - clen], scalar_start)]
+        if clen > 1 and any(mask):
+            for byte_idx in range(clen - 1):
+                mask = [m and x == b[byte_idx] for m, x in zip(mask, byte_chunks[3 - byte_idx])]
+        return mask
+
+    for col in range(1, chunks):
+        start = (col - 1) * L
+        byte_chunks = [load(start + 3), load(start + 2), load(start + 1), load(start)]
+        chunk = byte_chunks[3]
+        valid = [i < min(max(n - start, 0), L) for i in range(L)]
+        cont = [0x7F < b < 0xC0 and v for b, v in zip(chunk, valid)]
+        scalar_start = [(not c) and v for c, v in zip(cont, valid)]
+        scalar_start_w = widen(scalar_start)
+        cont_gex = vand(widen(cont), gex)
+
+        is_upper = [65 <= b <= 90 for b in chunk]
+        is_lower = [97 <= b <= 122 for b in chunk]
+        is_letter = [u or l for u, l in zip(is_upper, is_lower)]
+        lower_shifted = [prev_lower[L - 1]] + is_lower[: L - 1]
+        cap_masked = vand(widen([u and p for u, p in zip(is_upper, lower_shifted)]), cap_v)
+        prev_lower = is_lower
+        is_digit = [48 <= b <= 57 for b in chunk]
+        is_delim = [not (le or d or b > 127) for le, d, b in zip(is_letter, is_digit, chunk)]
+        delim_shifted = [prev_delim[L - 1]] + is_delim[: L - 1]
+        delim_masked = vand(widen([p and not c for p, c in zip(delim_shifted, is_delim)]), delim_v)
+        prev_delim = is_delim
+        bonuses = add(add(add(delim_masked, cap_masked), prefix_masked), match_score)
+        prefix_masked = list(zero)
+
+        up_gap_mask = list(zero)
+        prev_row = list(zero)
+        row = list(zero)
+        for r, (exact_b, flipped_b) in enumerate(chars, start=1):
+            exact = char_match_mask(byte_chunks, scalar_start, exact_b)
+            flipped = char_match_mask(byte_chunks, scalar_start, flipped_b)
+            match_mask = widen([a or b for a, b in zip(exact, flipped)])
+            exact_w = widen(exact)
+            diag = shift(prev_row, 1, get(S, r - 1, col - 1))
+            diag = add(diag, vand(match_mask, bonuses))
+            diag = subs(diag, mismatch_v)
+            diag = add(diag, vand(exact_w, case_v))
+            diag = vand(diag, scalar_start_w)
+            up = vand(subs(subs(prev_row, gex), vand(up_gap_mask, gop)), scalar_start_w)
+
+            # propagate_horizontal_unicode_gaps (unicode_gap.rs:172-236): [gap step, prepare] for 1, 2, ..., L/4 then a final gap step at L/2
+            row = vmax(diag, up)
+            pend = list(match_mask)
+            adj_row, adj_pend = get(S, r, col - 1), pending[r]
+            c_gex, adj_c_gex = list(cont_gex), list(prev_cont_gex)
+            end_mask, adj_end_mask = list(scalar_start_w), list(prev_scalar_start)
+            total = list(gex)
+
+            def gap_step(s):
+                nonlocal row, pend
+                shifted_row = shift(row, s, adj_row)
+                shifted_pend = shift(pend, s, adj_pend)
+                scalar_gex = subs(total, c_gex)
+                crossed = vand(shifted_pend, end_mask)
+                penalty = add(scalar_gex, vand(gop, crossed))
+                row = vmax(row, subs(shifted_row, penalty))
+                pend = vmax(pend, subs(shifted_pend, end_mask))
+
+            s = 1
+            while s < L // 2:
+                gap_step(s)
+                # prepare_next_unicode_gap_step
+                c_gex = add(c_gex, shift(c_gex, s, adj_c_gex))
+                adj_c_gex = add(adj_c_gex, shift(adj_c_gex, s, zero))
+                end_mask = vmax(end_mask, shift(end_mask, s, adj_end_mask))
+                adj_end_mask = vmax(adj_end_mask, shift(adj_end_mask, s, zero))
+                total = add(total, total)
+                s *= 2
+            gap_step(s)
+
+            S[(r, col)] = row
+            MM[(r, col)] = match_mask
+            pending[r] = pend
+            prev_row = row
+            up_gap_mask = match_mask
+        max_scores = vmax(max_scores, row)
+        prev_cont_gex = cont_gex
+        prev_scalar_start = scalar_start_w
+    if matrices is not None:
+        matrices["S"], matrices["MM"], matrices["chunks"] = S, MM, chunks
+    return max(max_scores)
+
+
+def unicode_indices(needle, haystack, matrices, lanes, bits, score, max_typos=None, haystack_start_pos=0, case_sensitive=False):
+    """score_haystack_unicode_indices (algo/mod.rs:97-152): every needle scalar's whole UTF-8 run, high byte first, once per position"""
+    chars = case_needle_unicode(needle, case_sensitive)
+    out, prev = [], [None]
+
+    def on_match(needle_idx, pos):
+        if prev[0] != pos:
+            ln = len(chars[needle_idx][0])
+            out.extend(pos + off for off in range(ln - 1, -1, -1))
+            prev[0] = pos
+
+    alignment_indices(len(chars), matrices, lanes, bits, score, max_typos, haystack_start_pos, haystack, on_match)
+    return out

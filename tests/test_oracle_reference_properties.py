@@ -369,3 +369,43 @@ def test_traceback_against_the_second_transcription():
             want = T2.alignment_indices(len(needle), mats, lanes, bits, score, max_typos, start_pos) if score else []
             got = O.sw_indices(needle, hay, start_pos=start_pos, max_typos=max_typos, case_sensitive=cs, lanes=lanes, is_u8=u8)
             assert got == (score, want), (needle, hay, cs, max_typos, start_pos, lanes, u8, got, (score, want))
+
+
+def test_unicode_scorer_and_traceback_against_the_second_transcription():
+    import sw_second_transcription as T2
+    sc = list(O.DEFAULT_SCORING)
+    for v in SW["sw_unicode"]:  # the second transcription is pinned to src/smith_waterman/mod.rs:229-235 first
+        assert T2.score_haystack_unicode(v["needle"], v["haystack"].encode(), sc, False, True, 8, 16) == v["score"], v
+    IXG = json.load(open(os.path.join(G, "indices.json")))
+    for needle, haystack, start, want, ref in IXG["unicode"]:  # src/smith_waterman/mod.rs:453-506
+        mats = {}
+        score = T2.score_haystack_unicode(needle, haystack.encode(), sc, False, start == 0, 8, 16, mats)
+        assert T2.unicode_indices(needle, haystack.encode(), mats, 8, 16, score, None, start) == want, ref
+    rng = np.random.default_rng(4242)
+    alpha = ["a", "b", "c", "A", "B", "_", " ", "/", "é", "É", "ß", "ж", "Ж", "다", "라", "😀", "1"]
+    for it in range(500):
+        asz = int(rng.integers(3, len(alpha) + 1))
+        needle = "".join(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(1, 8))))
+        hay = [alpha[int(x)] for x in rng.integers(0, asz, int(rng.choice([0, 1, 3, 7, 8, 15, 16, 17, 30, 33, 64, 70])))]
+        if rng.random() < 0.7 and len(hay) >= len(needle):
+            for q, c in zip(np.sort(rng.choice(len(hay), len(needle), replace=False)), needle):
+                hay[q] = c
+        hay = "".join(hay).encode()
+        scoring = sc
+        if it % 3 == 1:
+            scoring = [int(rng.integers(1, 17)), int(rng.integers(0, 9)), int(rng.integers(0, 9)), int(rng.integers(0, 4)), int(rng.integers(0, 17)),
+                       int(rng.integers(0, 9)), int(rng.integers(0, 9)), int(rng.integers(0, 17)), int(rng.integers(0, 9))]
+        cs = bool(rng.integers(0, 2))
+        max_typos = [None, 0, 1, 3][int(rng.integers(0, 4))]
+        start_pos = int(rng.integers(0, 3))
+        nchars = len(needle)
+        for lanes, u8 in WIDTHS:
+            if u8 and not O.score_fits_in_u8(nchars, scoring):
+                continue
+            bits = 8 if u8 else 16
+            mats = {}
+            score = T2.score_haystack_unicode(needle, hay, scoring, cs, start_pos == 0, lanes, bits, mats)
+            assert O.sw_score(needle, hay, scoring=scoring, case_sensitive=cs, include_prefix=start_pos == 0, unicode=True, lanes=lanes, is_u8=u8) == score, (needle, hay, scoring, cs, lanes, u8)
+            want = T2.unicode_indices(needle, hay, mats, lanes, bits, score, max_typos, start_pos, cs) if score else []
+            got = O.sw_indices(needle, hay, start_pos=start_pos, unicode=True, max_typos=max_typos, scoring=scoring, case_sensitive=cs, lanes=lanes, is_u8=u8)
+            assert got == (score, want), (needle, hay, scoring, cs, max_typos, start_pos, lanes, u8, got, (score, want))
