@@ -409,3 +409,26 @@ def test_unicode_scorer_and_traceback_against_the_second_transcription():
             want = T2.unicode_indices(needle, hay, mats, lanes, bits, score, max_typos, start_pos, cs) if score else []
             got = O.sw_indices(needle, hay, start_pos=start_pos, unicode=True, max_typos=max_typos, scoring=scoring, case_sensitive=cs, lanes=lanes, is_u8=u8)
             assert got == (score, want), (needle, hay, scoring, cs, max_typos, start_pos, lanes, u8, got, (score, want))
+
+
+def test_ascii_prefilter_windows_against_the_second_transcription():
+    # decision AND window (start, end) of the whole ASCII prefilter family, every typo budget, all three lane widths
+    import pf_second_transcription as P2
+    for needle, hay in LCS_DEVIATIONS_1_TYPO:  # the second transcription reproduces the reference's 32-lane deviation too
+        assert [P2.prefilter(needle.encode(), hay.encode(), 1, False, lanes)[0] for lanes in (16, 32, 64)] == [True, False, True]
+    rng = np.random.default_rng(1234)
+    alpha = b"abcABC_-/ 01xyz\0"
+    for it in range(3000):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(1, 13))))
+        hay = bytearray(alpha[int(x)] for x in rng.integers(0, asz, int(rng.choice([0, 1, 5, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 140, 200]))))
+        if rng.random() < 0.5 and len(hay) >= len(needle):
+            for q, c in zip(np.sort(rng.choice(len(hay), len(needle), replace=False)), needle):
+                hay[q] = c
+        hay = bytes(hay)
+        cs = bool(rng.integers(0, 2))
+        max_typos = int(rng.integers(0, 6))
+        for lanes in (16, 32, 64):
+            want = P2.prefilter(needle, hay, max_typos, cs, lanes)
+            got = O.prefilter(needle, hay, max_typos, cs, False, lanes)
+            assert got[0] == want[0] and (not want[0] or got == want), (needle, hay, max_typos, cs, lanes, got, want)
