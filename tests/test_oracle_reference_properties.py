@@ -432,3 +432,40 @@ def test_ascii_prefilter_windows_against_the_second_transcription():
             want = P2.prefilter(needle, hay, max_typos, cs, lanes)
             got = O.prefilter(needle, hay, max_typos, cs, False, lanes)
             assert got[0] == want[0] and (not want[0] or got == want), (needle, hay, max_typos, cs, lanes, got, want)
+
+
+def test_unicode_prefilter_windows_against_the_second_transcription():
+    import pf_second_transcription as P2
+    rng = np.random.default_rng(4321)
+    alpha = ["a", "b", "A", "_", " ", "é", "É", "ß", "ж", "Ж", "다", "라", "😀", "✓", "1"]
+    n_acc = 0
+    for it in range(2500):
+        asz = int(rng.integers(3, len(alpha) + 1))
+        needle = "".join(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(1, 9))))
+        hay = [alpha[int(x)] for x in rng.integers(0, asz, int(rng.choice([0, 1, 2, 5, 8, 15, 16, 17, 31, 33, 64, 70, 130])))]
+        if rng.random() < 0.5 and len(hay) >= len(needle):
+            for q, c in zip(np.sort(rng.choice(len(hay), len(needle), replace=False)), needle):
+                hay[q] = c
+        hay = "".join(hay).encode()
+        cs = bool(rng.integers(0, 2))
+        max_typos = int(rng.integers(0, 5))
+        for lanes in (16, 32, 64):
+            want = P2.prefilter_unicode(needle, hay, max_typos, cs, lanes)
+            got = O.prefilter(needle, hay, max_typos, cs, True, lanes)
+            assert got[0] == want[0] and (not want[0] or got == want), (needle, hay, max_typos, cs, lanes, got, want)
+            n_acc += want[0]
+    assert n_acc > 2000
+
+
+def test_the_prefilter_transcription_is_itself_pinned_to_the_reference_known_answers():
+    import pf_second_transcription as P2
+    PFG = json.load(open(os.path.join(G, "prefilter.json")))
+    for lanes in (16, 32, 64):
+        for v in PFG["pf_bool"]:  # src/prefilter/mod.rs:187-270
+            assert P2.prefilter(v["needle"].encode(), v["haystack"].encode(), v["max_typos"], v["case_sensitive"], lanes)[0] == v["matched"], v
+        for v in PFG["pf_unicode_bool"]:
+            assert P2.prefilter_unicode(v["needle"], v["haystack"].encode(), v["max_typos"], v["case_sensitive"], lanes)[0] == v["matched"], v
+        for v in PFG["pf_window"]:  # src/prefilter/mod.rs:273-400
+            f = P2.prefilter_unicode if v["unicode"] else P2.prefilter
+            n = v["needle"] if v["unicode"] else v["needle"].encode()
+            assert list(f(n, v["haystack"].encode(), v["max_typos"], v["case_sensitive"], lanes)) == v["window"], (v, lanes)
