@@ -300,3 +300,48 @@ def unicode_indices(needle, haystack, matrices, lanes, bits, score, max_typos=No
 
     alignment_indices(len(chars), matrices, lanes, bits, score, max_typos, haystack_start_pos, haystack, on_match)
     return out
+
+
+def match_greedy(needle, haystack, scoring, case_sensitive, include_prefix):
+    """src/smith_waterman/greedy.rs:7-91 -> (score, forward positions) or None"""
+    match_s, _mismatch, gap_open, gap_extend, prefix_b, cap_b, case_b, _exact, delim_b = scoring
+    sat_add = lambda a, b: min(a + b, 0xFFFF)
+    sat_sub = lambda a, b: max(a - b, 0)
+    nd = case_needle(needle, case_sensitive)
+    if len(nd) > len(haystack):
+        return None
+    score, indices, hi = 0, [], 0
+    bonus_enabled = prev_lower = prev_delim = False
+    for ni, (c, f) in enumerate(nd):
+        start = hi
+        found = False
+        while hi <= len(haystack) - len(nd) + ni:
+            h = haystack[hi]
+            digit, upper, lower = 48 <= h <= 57, 65 <= h <= 90, 97 <= h <= 122
+            delim = h < 128 and not (lower or upper or digit)
+            if not delim:
+                bonus_enabled = True
+            if c != h and f != h:
+                prev_delim, prev_lower = bonus_enabled and delim, lower
+                hi += 1
+                continue
+            score = sat_add(score, match_s)
+            if hi != start and ni != 0:
+                gap_len = min(max(hi - start - 1, 0), 0xFFFF)
+                score = sat_sub(score, sat_add(gap_open, min(gap_extend * gap_len, 0xFFFF)))
+            if c == h:
+                score = sat_add(score, case_b)
+            if upper and prev_lower:
+                score = sat_add(score, cap_b)
+            if include_prefix and hi == 0:
+                score = sat_add(score, prefix_b)
+            if prev_delim and not delim:
+                score = sat_add(score, delim_b)
+            prev_delim, prev_lower = bonus_enabled and delim, lower
+            indices.append(hi)
+            hi += 1
+            found = True
+            break
+        if not found:
+            return None
+    return score, indices

@@ -469,3 +469,30 @@ def test_the_prefilter_transcription_is_itself_pinned_to_the_reference_known_ans
             f = P2.prefilter_unicode if v["unicode"] else P2.prefilter
             n = v["needle"] if v["unicode"] else v["needle"].encode()
             assert list(f(n, v["haystack"].encode(), v["max_typos"], v["case_sensitive"], lanes)) == v["window"], (v, lanes)
+
+
+def test_greedy_fallback_against_the_second_transcription():
+    import sw_second_transcription as T2
+    sc = list(O.DEFAULT_SCORING)
+    for v in SW["greedy"]:  # src/smith_waterman/greedy.rs:112-190
+        r = T2.match_greedy(v["needle"].encode(), v["haystack"].encode(), sc, False, True)
+        assert (r[0] if r else 0) == v["score"], v
+    rng = np.random.default_rng(808)
+    alpha = b"abcABC_-/ 01xyz"
+    for it in range(300):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(1, 9))))
+        hay = bytearray(alpha[int(x)] for x in rng.integers(0, asz, int(rng.choice([1025, 1030, 1500, 3000]))))
+        if rng.random() < 0.8:
+            for q, c in zip(np.sort(rng.choice(len(hay), len(needle), replace=False)), needle):
+                hay[q] = c
+        hay = bytes(hay)
+        cs, prefix = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        scoring = sc if it % 2 else [int(rng.integers(1, 17)), int(rng.integers(0, 9)), int(rng.integers(0, 9)), int(rng.integers(0, 4)), int(rng.integers(0, 17)),
+                                     int(rng.integers(0, 9)), int(rng.integers(0, 9)), int(rng.integers(0, 17)), int(rng.integers(0, 9))]
+        r = T2.match_greedy(needle, hay, scoring, cs, prefix)
+        # beyond 1024 bytes the scorer IS match_greedy (algo/ascii.rs:11-21, algo/mod.rs:55-72): score, and positions reversed + offset
+        assert O.sw_score(needle, hay, scoring=scoring, case_sensitive=cs, include_prefix=prefix, lanes=16, is_u8=False) == (r[0] if r else 0), (needle, cs, prefix)
+        start_pos = 0 if prefix else 3
+        got = O.sw_indices(needle, hay, start_pos=start_pos, scoring=scoring, case_sensitive=cs, lanes=16, is_u8=False)
+        assert got == ((r[0], [p + start_pos for p in reversed(r[1])]) if r else (0, [])), (needle, cs, prefix)
