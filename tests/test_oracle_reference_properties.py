@@ -496,3 +496,41 @@ def test_greedy_fallback_against_the_second_transcription():
         start_pos = 0 if prefix else 3
         got = O.sw_indices(needle, hay, start_pos=start_pos, scoring=scoring, case_sensitive=cs, lanes=16, is_u8=False)
         assert got == ((r[0], [p + start_pos for p in reversed(r[1])]) if r else (0, [])), (needle, cs, prefix)
+
+
+def test_ascii_typo_windows_have_a_lane_free_form():
+    # What the width-independence the reference asserts amounts to for k >= 1 typos (ASCII): whenever the prefilter accepts,
+    #   start = the earliest first occurrence of needle[0..=k] (either case),
+    #   end   = one past the last occurrence of any of needle[n-1-k..] (find_end_pos_with_typos, ascii_typos.rs:374-398), len if none.
+    # (0 typos: first occurrence of needle[0], last occurrence of needle[n-1]: SURVEY 8 a7.)  DESIGN section 7 builds on this.
+    rng = np.random.default_rng(5)
+    alpha = b"abcdefAB_- 01"
+
+    def variants(c, cs):
+        if cs:
+            return (c,)
+        return (c, c - 32) if 97 <= c <= 122 else (c, c + 32) if 65 <= c <= 90 else (c,)
+
+    checked = 0
+    for _ in range(6000):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        n = int(rng.integers(2, 10))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, n))
+        ln = int(rng.choice([5, 16, 31, 32, 33, 64, 70, 130]))
+        hay = bytearray(alpha[int(x)] for x in rng.integers(0, asz, ln))
+        if rng.random() < 0.6 and ln >= n:
+            for q, c in zip(np.sort(rng.choice(ln, n, replace=False)), needle):
+                hay[q] = c
+        hay = bytes(hay)
+        cs, k = bool(rng.integers(0, 2)), int(rng.integers(1, 4))
+        if k >= n:
+            continue
+        firsts = [min((p for p in (hay.find(bytes([v])) for v in variants(needle[j], cs)) if p >= 0), default=None) for j in range(k + 1)]
+        last_set = {v for j in range(n - 1 - k, n) for v in variants(needle[j], cs)}
+        end = max((i for i, b in enumerate(hay) if b in last_set), default=len(hay) - 1) + 1
+        for lanes in (16, 32, 64):
+            w = O.prefilter(needle, hay, k, cs, False, lanes)
+            if w[0]:
+                assert (w[1], w[2]) == (min(f for f in firsts if f is not None), end), (needle, hay, k, cs, lanes, w)
+                checked += 1
+    assert checked > 5000
