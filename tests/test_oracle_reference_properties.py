@@ -534,3 +534,28 @@ def test_ascii_typo_windows_have_a_lane_free_form():
                 assert (w[1], w[2]) == (min(f for f in firsts if f is not None), end), (needle, hay, k, cs, lanes, w)
                 checked += 1
     assert checked > 5000
+
+
+def test_the_typo_prefilter_only_ever_deviates_on_marginal_inputs():
+    # Where the reference's multi-path scan disagrees with its LCS oracle (see LCS_DEVIATIONS_1_TYPO) the input is always MARGINAL:
+    # LCS + k == n exactly.  One spare (LCS + k >= n + 1) is accepted at every width; LCS + k < n is rejected at every width.
+    # (3 M random cases in a C++ harness: 149 deviations, all with zero slack.)  DESIGN section 7 uses this to confine the
+    # lane-exact decision kernel to the marginal survivors.
+    rng = np.random.default_rng(606)
+    alpha = b"abcABC_-/ 01xyz"
+    n_spare = n_reject = 0
+    for _ in range(12000):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(2, 14))))
+        hay = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(0, 150))))
+        cs, k = bool(rng.integers(0, 3) == 0), int(rng.integers(1, 5))
+        if k >= len(needle):
+            continue
+        slack = lcs_len(needle, hay, byte_eq(cs)) + k - len(needle)
+        if slack == 0:
+            continue
+        for lanes in (16, 32, 64):
+            assert O.prefilter(needle, hay, k, cs, False, lanes)[0] == (slack > 0), (needle, hay, k, cs, lanes, slack)
+        n_spare += slack > 0
+        n_reject += slack < 0
+    assert n_spare > 3000 and n_reject > 500
