@@ -1,7 +1,6 @@
 """The reference's generated public-API property test (tests/api_properties.rs:72-166) through the HIP path: for cases drawn with
 the reference's own generator (needle / haystack list / max_typos / casing / matching mode / sort), `match_list`,
 `match_list_parallel` and `match_list_indices` equal the oracle's record for record, and the reference's indices contract holds."""
-import numpy as np
 import pytest
 
 import frizbee_amd as F

@@ -1,7 +1,6 @@
 """The per-item side of the reference's interface on the HIP path (`match_iter`, `match_one`, `match_iter_indices`,
 `match_one_indices`, `iter::FuzzyMatchExt`): the reference's own tests for it (src/matcher/mod.rs:655-734, src/matcher/iter.rs:150-239,
 the `match_one` leg of tests/api_properties.rs:381-400), each served by one batched device pass in list order."""
-import numpy as np
 import pytest
 
 import frizbee_amd as F
