@@ -559,3 +559,34 @@ def test_the_typo_prefilter_only_ever_deviates_on_marginal_inputs():
         n_spare += slack > 0
         n_reject += slack < 0
     assert n_spare > 3000 and n_reject > 500
+
+
+def test_unicode_typo_windows_have_the_same_lane_free_form():
+    # scalars instead of bytes: start = earliest first occurrence of needle scalars [0..=k] (either case variant), end = the latest end
+    # of a last occurrence of the scalars [n-1-k..] (find_end_pos_with_unicode_typos, unicode_typos.rs:483-509)
+    import pf_second_transcription as P2
+    rng = np.random.default_rng(9)
+    alpha = ["a", "b", "A", "_", " ", "é", "É", "ж", "Ж", "다", "😀", "1"]
+    checked = 0
+    for _ in range(4000):
+        asz = int(rng.integers(3, len(alpha) + 1))
+        n = int(rng.integers(2, 8))
+        needle = "".join(alpha[int(x)] for x in rng.integers(0, asz, n))
+        ln = int(rng.choice([4, 10, 16, 20, 33, 50, 70]))
+        hay = [alpha[int(x)] for x in rng.integers(0, asz, ln)]
+        if rng.random() < 0.6 and ln >= n:
+            for q, c in zip(np.sort(rng.choice(ln, n, replace=False)), needle):
+                hay[q] = c
+        hay = "".join(hay).encode()
+        cs, k = bool(rng.integers(0, 2)), int(rng.integers(1, 4))
+        if k >= n:
+            continue
+        chars = P2.case_needle_unicode(needle, cs)
+        firsts = [p for j in range(k + 1) for p in (hay.find(v) for v in set(chars[j])) if p >= 0]
+        ends = [p + len(v) for j in range(n - 1 - k, n) for v in set(chars[j]) for p in (hay.rfind(v),) if p >= 0]
+        for lanes in (16, 32, 64):
+            w = O.prefilter(needle, hay, k, cs, True, lanes)
+            if w[0]:
+                assert (w[1], w[2]) == (min(firsts), max(ends) if ends else len(hay)), (needle, hay, k, cs, lanes, w)
+                checked += 1
+    assert checked > 5000
