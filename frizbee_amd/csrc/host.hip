@@ -334,6 +334,7 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
     // biased gap propagation needs max cell value + lanes*gex (+ headroom) to stay below 2^16
     lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
+    lc.cf_ok = lc.pad_ok && lc.bias_ok && sc.gap_extend_penalty <= sc.mismatch_penalty;  // dp_cf.h preconditions
     *out = m;
     return FZB_OK;
 }
@@ -695,7 +696,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, cnt_c, cus * 4, st);
         FZB_STAGE("generic(unicode)");
     } else {
-        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.bias_ok, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
+        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
         if (!no_wide) {
             const int mgrid = cus * 4;  // 2 waves per SIMD (the kernel is capped at 256 VGPRs)

@@ -14,10 +14,12 @@
 // Gap propagation runs in a biased domain r'[L] = r[L] + L*gex, where "shift by k and pay k*gex" becomes a
 // plain shift; since every row value is >= 0 the saturating subtract of the reference is preserved exactly
 // (see DESIGN.md).  BIAS=false keeps the literal 3-op form for scorings where the bias could overflow u16.
-#include "dp_body.h"
+#include "dp_cf.h"
 
-template <int SWL, bool BIAS, bool UPPER, typename ET>
-__global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+// MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h), 2: biased domain throughout + closed-form
+// padding (dp_cf.h; LaunchCfg::cf_ok)
+template <int SWL, int MODE, bool UPPER, typename ET>
+__global__ __launch_bounds__(128, 2) void k2b_dp(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                               const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                               const NeedleDev nd, int wmode, int pad_ok, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count,
                                               u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters) {
@@ -105,10 +107,18 @@ __global__ __launch_bounds__(128) void k2b_dp(const u8* __restrict__ bytes, cons
             if (m > 0) {
                 if (inreg) load_window_regs<SWL / 4>(q0_c, q1_c, sp, m, hb);
                 else load_window_mem<SWL / 4>(hay + sp, m, hb);
-                // wave-uniform choice: if every window in this wave fits the low half of the chunk, the upper half is pure padding
-                const bool half = pad_ok && SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
-                if (half) score = dp_single_chunk<SWL, BIAS, UPPER, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, sp == 0, cls, hb);
-                else score = dp_single_chunk<SWL, BIAS, UPPER>(nd, m, sp == 0, cls, hb);
+                if (MODE == 2) {
+                    // wave-uniform choice of the computed lanes: the widest window of the wave decides (dp_cf.h)
+                    constexpr int NW = SWL / 2;
+                    if (__all((int)(m <= (u32)SWL / 2))) score = dp_single_chunk_cf<SWL, UPPER, NW / 2>(nd, sp == 0, cls, hb);
+                    else if (__all((int)(m <= 3 * (u32)SWL / 4))) score = dp_single_chunk_cf<SWL, UPPER, 3 * NW / 4>(nd, sp == 0, cls, hb);
+                    else score = dp_single_chunk_cf<SWL, UPPER, NW>(nd, sp == 0, cls, hb);
+                } else {
+                    // wave-uniform choice: if every window in this wave fits the low half of the chunk, the upper half is pure padding
+                    const bool half = pad_ok && SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
+                    if (half) score = dp_single_chunk<SWL, MODE == 1, UPPER, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, sp == 0, cls, hb);
+                    else score = dp_single_chunk<SWL, MODE == 1, UPPER>(nd, m, sp == 0, cls, hb);
+                }
             }
             const bool exact = exact_match<SWL / 4>(nd, include_exact, m, hb);
             if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
@@ -176,7 +186,7 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
 }
 
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int bias_ok, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st) {
+                   int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st) {
     bool upper = false;  // an uppercase letter among the needle bytes as they are compared
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     // the kernel is persistent: launch exactly the workgroups that are resident at once
@@ -188,7 +198,7 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
     } while (0)
 #define FZB_K2B_ET(SWL, B, U) do { if (c.ends_u64) FZB_K2B(SWL, B, U, u64); else FZB_K2B(SWL, B, U, u32); } while (0)
 #define FZB_K2B_U(SWL, B) do { if (upper) FZB_K2B_ET(SWL, B, true); else FZB_K2B_ET(SWL, B, false); } while (0)
-#define FZB_K2B_B(SWL) do { if (bias_ok) FZB_K2B_U(SWL, true); else FZB_K2B_U(SWL, false); } while (0)
+#define FZB_K2B_B(SWL) do { if (mode == 2) FZB_K2B_U(SWL, 2); else if (mode == 1) FZB_K2B_U(SWL, 1); else FZB_K2B_U(SWL, 0); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2B_B(64); break;
         case 32: FZB_K2B_B(32); break;

@@ -1,0 +1,86 @@
+// TEST INFRASTRUCTURE: compiles the DEVICE arithmetic of the single-chunk Smith-Waterman bodies (frizbee_amd/csrc/dp_body.h,
+// dp_cf.h) for the host through tests/kernel_host/shim, one "thread" at a time, so that tests can fuzz the exact code the GPU runs
+// against the oracle without a GPU.  Built by tests/kernel_host_lib.py with ROCm's clang++ (-x c++); never part of the product.
+#include "dp_cf.h"
+
+static u16 sadd16(u32 a, u32 b) { return (u16)(a + b > 0xFFFF ? 0xFFFF : a + b); }
+static u16 ssub16(u32 a, u32 b) { return (u16)(a > b ? a - b : 0); }
+
+// the NeedleDev fields the ASCII scorers read, filled the way fzb_matcher_create fills them (frizbee_amd/csrc/host.hip)
+static void fill_needle(NeedleDev& nd, const u8* needle, int n, int case_sensitive, const u16* sc) {
+    memset(&nd, 0, sizeof(nd));
+    nd.rows = n;
+    nd.nbytes = n;
+    nd.lane_mask = 0xFFFF;
+    nd.match_plus_mismatch = sadd16(sc[0], sc[1]);
+    nd.mismatch = sc[1];
+    nd.gex = sc[3];
+    nd.gopm = ssub16(sc[2], sc[3]);
+    nd.prefix = sc[4];
+    nd.capitalization = sc[5];
+    nd.matching_case = sc[6];
+    nd.exact_bonus = sc[7];
+    nd.delimiter = sc[8];
+    nd.match_score = sc[0];
+    nd.gap_open = sc[2];
+    for (int i = 0; i < n; i++) {
+        const u8 c = needle[i];
+        nd.raw[i] = c;
+        nd.c[i] = c;
+        nd.f[i] = case_sensitive ? c : (c >= 'a' && c <= 'z') ? (u8)(c - 32) : (c >= 'A' && c <= 'Z') ? (u8)(c + 32) : c;
+    }
+}
+
+template <int SWL>
+static int run(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, int form, int real, const u8* cls) {
+    u32 hb[SWL / 4];
+    u8 buf[SWL + 8] = {0};
+    memcpy(buf, hay, m);
+    load_window_mem<SWL / 4>(buf, m, hb);
+    bool upper = false;
+    for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+    constexpr int NW = SWL / 2;
+#define FORMS(U)                                                                                                           \
+    if (form == 0) return (int)dp_single_chunk<SWL, true, U>(nd, m, include_prefix, cls, hb);                              \
+    if (form == 1) return (int)dp_single_chunk<SWL, false, U>(nd, m, include_prefix, cls, hb);                             \
+    if (form == 2) return (int)dp_single_chunk<SWL, true, U, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, include_prefix, cls, hb); \
+    if (form == 3) {                                                                                                       \
+        if (real == NW) return (int)dp_single_chunk_cf<SWL, U, NW>(nd, include_prefix, cls, hb);                           \
+        if (real == NW / 2) return (int)dp_single_chunk_cf<SWL, U, NW / 2>(nd, include_prefix, cls, hb);                   \
+        if (NW >= 4 && real == 3 * NW / 4) return (int)dp_single_chunk_cf<SWL, U, (NW >= 4 ? 3 * NW / 4 : NW)>(nd, include_prefix, cls, hb); \
+        if (NW >= 4 && real == NW / 4) return (int)dp_single_chunk_cf<SWL, U, (NW >= 4 ? NW / 4 : NW)>(nd, include_prefix, cls, hb); \
+    }
+    if (upper) { FORMS(true) } else { FORMS(false) }
+#undef FORMS
+    return -2;
+}
+
+extern "C" {
+// form: 0 = dp_single_chunk biased, 1 = literal (unbiased) scan, 2 = its padded-half form, 3 = dp_single_chunk_cf with `real` dwords.
+// Returns the score of `hay[0..m)` as ONE chunk of `swl` lanes (no exact bonus), or < 0 on a bad argument.
+int kh_dp_single(const u8* needle, int n, int case_sensitive, const u16* scoring, const u8* hay, int m, int include_prefix, int swl, int form, int real) {
+    if (n < 1 || n > FZB_MAX_ROWS || m < 1 || m > swl) return -1;
+    NeedleDev nd;
+    fill_needle(nd, needle, n, case_sensitive, scoring);
+    static u8 cls[256];
+    build_cls_table(cls);
+    switch (swl) {
+        case 64: return run<64>(nd, hay, (u32)m, include_prefix, form, real, cls);
+        case 32: return run<32>(nd, hay, (u32)m, include_prefix, form, real, cls);
+        case 16: return run<16>(nd, hay, (u32)m, include_prefix, form, real, cls);
+        case 8: return run<8>(nd, hay, (u32)m, include_prefix, form, real, cls);
+    }
+    return -1;
+}
+
+// batch form for fuzzing: `count` windows packed back to back with byte lengths lens[i]; scores out
+int kh_dp_batch(const u8* needle, int n, int case_sensitive, const u16* scoring, const u8* hays, const int* lens, int count, const u8* include_prefix, int swl, int form,
+                int real, int* out) {
+    size_t off = 0;
+    for (int i = 0; i < count; i++) {
+        out[i] = kh_dp_single(needle, n, case_sensitive, scoring, hays + off, lens[i], include_prefix[i], swl, form, real);
+        off += (size_t)lens[i];
+    }
+    return 0;
+}
+}

@@ -1,0 +1,55 @@
+"""TEST INFRASTRUCTURE: builds tests/kernel_host/libkernel_host.so - the DEVICE arithmetic of the Smith-Waterman bodies
+(frizbee_amd/csrc/dp_body.h, dp_cf.h) compiled for the host with ROCm's clang++ through a stand-in <hip/hip_runtime.h> - and loads
+it with ctypes.  It lets the CPU test suite fuzz the code the GPU runs against the oracle.  Never imported by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(ROOT, "tests", "kernel_host")
+CSRC = os.path.join(ROOT, "frizbee_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def available():
+    return os.path.exists(CLANG)
+
+
+def build():
+    so = os.path.join(HERE, "libkernel_host.so")
+    srcs = [os.path.join(HERE, "dp_host.cpp"), os.path.join(HERE, "shim", "hip", "hip_runtime.h")] + [
+        os.path.join(CSRC, f) for f in ("dp_body.h", "dp_cf.h", "kernels_common.h", "fzb_internal.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + os.path.join(HERE, "shim"), "-I" + CSRC,
+                               "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-o", so, os.path.join(HERE, "dp_host.cpp")])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.kh_dp_single.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    return _lib
+
+
+def dp_single(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=64, form=3, real=16):
+    sc = (C.c_uint16 * 9)(*scoring)
+    return lib().kh_dp_single(needle, len(needle), int(case_sensitive), sc, hay, len(hay), int(include_prefix), swl, form, real)
+
+
+def dp_batch(needle, hays, scoring, case_sensitive, include_prefix, swl, form, real):
+    """hays: list of bytes; include_prefix: list of bools -> np.int32 scores"""
+    sc = (C.c_uint16 * 9)(*scoring)
+    blob = np.frombuffer(b"".join(hays), dtype=np.uint8).copy() if hays else np.zeros(1, np.uint8)
+    lens = np.array([len(h) for h in hays], dtype=np.int32)
+    ip = np.array(include_prefix, dtype=np.uint8)
+    out = np.zeros(len(hays), dtype=np.int32)
+    lib().kh_dp_batch(needle, len(needle), int(case_sensitive), sc, blob.ctypes.data, lens.ctypes.data, len(hays), ip.ctypes.data, swl, form, real, out.ctypes.data)
+    return out

@@ -1,0 +1,116 @@
+"""The DEVICE arithmetic of the single-chunk Smith-Waterman scorers (frizbee_amd/csrc/dp_body.h and dp_cf.h), compiled for the
+host (tests/kernel_host: ROCm's clang++ with a stand-in hip_runtime.h) and compared with the oracle's score_haystack
+(src/smith_waterman/algo/ascii.rs:10-158) - so the closed-form padding, the biased domain and the skipped last-row scan of dp_cf.h
+are checked bit for bit without a GPU.  The GPU parity tests run the same headers through hipcc."""
+import ctypes as C
+import itertools
+import random
+
+import pytest
+
+import kernel_host_lib as K
+import oracle_lib as O
+
+pytestmark = pytest.mark.skipif(not K.available(), reason="ROCm clang++ not installed")
+
+DEF = [12, 6, 5, 1, 12, 4, 4, 8, 4]
+
+
+def _fits(n, sc):
+    return bool(O.lib().fzo_score_fits_in_u8(n, (C.c_uint16 * 9)(*sc)))
+
+
+def _check(needle, hays, sc, cs, ips, swl, form, real):
+    got = K.dp_batch(needle, hays, sc, cs, ips, swl, form, real)
+    u8 = _fits(len(needle), sc)
+    scc = (C.c_uint16 * 9)(*sc)
+    f = O.lib().fzo_sw_score
+    for h, ip, g in zip(hays, ips, got):
+        want = f(needle, len(needle), h, len(h), scc, int(cs), int(ip), 0, swl, int(u8))
+        assert g == want, (needle, h, sc, cs, ip, swl, form, real, int(g), want)
+
+
+def _rnd(rng, n, alpha):
+    return bytes(rng.choice(alpha) for _ in range(n))
+
+
+def test_reference_known_answers_through_the_device_arithmetic():
+    # src/smith_waterman/mod.rs:208-298 (scalar LANES = 8; the same at every width per backend/tests/parity.rs:95-124)
+    cases = [(b"b", b"abc", 16), (b"a", b"abc", 28), (b"a", b"babc", 16), (b"abc", b"abc", 60), (b"b", b"a-b", 20), (b"a", b"-a--bc", 20),
+             (b"test", b"Uteost", 59), (b"test", b"Uteoost", 58), (b"test", b"Utooooeoooosoooot", 40), (b"a", b"A", 24), (b"D", b"forDist", 20),
+             (b"D", b"foRDist", 16), (b"D", b"FOR_DIST", 20), (b"foo", b"Ufo", 27), (b"foo", b"Uf", 10), (b"foo", b"U", 0)]
+    for needle, hay, want in cases:
+        for swl in (64, 32):
+            nw = swl // 2
+            for real in (nw // 2, 3 * nw // 4, nw):
+                if len(hay) <= 2 * real:
+                    cs = any(65 <= c <= 90 for c in needle)  # smart case, as the tests' `score` helper resolves it
+                    assert K.dp_single(needle, hay, DEF, case_sensitive=cs, swl=swl, form=3, real=real) == want, (needle, hay, swl, real)
+
+
+@pytest.mark.parametrize("swl", [64, 32, 16, 8])
+def test_random_windows_all_forms_match_the_oracle(swl):
+    rng = random.Random(1000 + swl)
+    nw = swl // 2
+    reals = sorted({max(1, nw // 4), nw // 2, 3 * nw // 4 if nw >= 4 else nw, nw})
+    for it in range(400):
+        alpha = rng.choice([b"ab", b"abcA_", b"abcdefABCDEF_-/ 019", bytes(range(33, 127))])
+        needle = _rnd(rng, rng.randint(1, 12), alpha)
+        cs = rng.random() < 0.3
+        sc = DEF
+        if rng.random() < 0.6:
+            while True:
+                sc = [rng.randint(0, 40), rng.randint(0, 20), rng.randint(0, 20), rng.randint(0, 6), rng.randint(0, 30), rng.randint(0, 12), rng.randint(0, 12),
+                      rng.randint(0, 20), rng.randint(0, 12)]
+                if sc[3] <= sc[1]:
+                    break
+        real = rng.choice(reals)
+        hays = [_rnd(rng, rng.randint(1, 2 * real), alpha) for _ in range(12)]
+        ips = [rng.random() < 0.5 for _ in hays]
+        _check(needle, hays, sc, cs, ips, swl, 3, real)
+        # the first form (dp_body.h) on the same inputs: biased scan, literal scan, padded half
+        _check(needle, hays, sc, cs, ips, swl, 0, 0)
+        _check(needle, hays, sc, cs, ips, swl, 1, 0)
+        if real <= max(1, nw // 2) and swl >= 16:
+            _check(needle, [h[: swl // 2] for h in hays], sc, cs, ips, swl, 2, 0)
+
+
+def test_padding_entries_exhaustively_on_a_small_chunk():
+    # 8-lane chunk, 4 computed lanes: every window over {a, b, q} up to 4 bytes x every needle over {a, b} up to 6 rows x gap scorings
+    hays = [bytes(t) for n in range(1, 5) for t in itertools.product(b"abq", repeat=n)]
+    needles = [bytes(t) for n in range(1, 7) for t in itertools.product(b"ab", repeat=n)]
+    for e, o, x in ((0, 3, 0), (1, 4, 6), (1, 10, 1), (2, 0, 5), (0, 10, 3)):
+        sc = [12, x, o + e, e, 6, 4, 4, 8, 4]
+        for needle in needles:
+            _check(needle, hays, sc, False, [True] * len(hays), 8, 3, 2)
+
+
+@pytest.mark.parametrize("swl,real", [(64, 16), (64, 24), (64, 8), (32, 8), (32, 12), (16, 4), (16, 2), (16, 6)])
+def test_full_windows_with_unmatched_needle_tails(swl, real):
+    """The inputs on which the zero padding right of the computed lanes decides the score: the needle's head is matched near the
+    end of a window that fills the computed lanes, its tail matches nothing, so the best alignment leaves the window through the
+    padding (a variant of dp_cf.h without its padding term fails ~4 % of these)."""
+    rng = random.Random(77 + swl + real)
+    P = 2 * real
+    for it in range(250):
+        alpha = rng.choice([b"ab", b"abc", b"abcdeABC_"])
+        sc = DEF
+        if rng.random() < 0.6:
+            while True:
+                sc = [rng.randint(1, 30), rng.randint(0, 12), rng.randint(0, 30), rng.randint(0, 3), rng.randint(0, 20), rng.randint(0, 8), rng.randint(0, 8), rng.randint(0, 20),
+                      rng.randint(0, 8)]
+                if sc[3] <= sc[1]:
+                    break
+        for _ in range(6):
+            t = rng.randint(1, 5)
+            head = _rnd(rng, t, alpha)
+            needle = head + _rnd(rng, rng.randint(1, 6), b"xyz")
+            m = rng.randint(max(1, P - 2), P)
+            body = bytearray(_rnd(rng, m, alpha + b"q"))
+            pos = rng.choice([m - t, m - t, rng.randint(0, max(0, m - t))])
+            if pos >= 0:
+                body[pos:pos + t] = head
+            for s in (1, 2, 4, 8, 16, 32):
+                if rng.random() < 0.4 and 0 <= P - s < m:
+                    body[P - s] = rng.choice(head)
+            _check(needle, [bytes(body[:m])], sc, False, [rng.random() < 0.5], swl, 3, real)
