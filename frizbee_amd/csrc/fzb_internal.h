@@ -93,7 +93,7 @@ struct LaunchCfg {
     int window_mode;    // 0 = from the lane-exact prefilter kernel, 1 = inline first/last occurrence (ASCII 0 typos), 2 = full haystack
     int bias_ok;        // DP gap propagation may run in the biased domain (no u16 overflow possible)
     int pad_ok;         // needle has no NUL byte: zero-padding lanes can never match (enables the padded-half DP form)
-    int cf_ok;          // single-chunk scorer in its second form (dp_cf.h): pad_ok, bias_ok and gap_extend <= mismatch_penalty
+    int cf_ok;          // single-chunk scorer in its second form (dp_cf.h): pad_ok, bias_ok and 2 * gap_extend <= mismatch_penalty
     int num_cus;
     u32 dead_byte;      // a byte value no needle row can match (used to neutralise bytes past a haystack's end in the DFA filter)
 };

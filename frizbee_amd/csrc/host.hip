@@ -334,7 +334,7 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
     // biased gap propagation needs max cell value + lanes*gex (+ headroom) to stay below 2^16
     lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
-    lc.cf_ok = lc.pad_ok && lc.bias_ok && sc.gap_extend_penalty <= sc.mismatch_penalty;  // dp_cf.h preconditions
+    lc.cf_ok = lc.pad_ok && lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty;  // dp_cf.h preconditions
     *out = m;
     return FZB_OK;
 }

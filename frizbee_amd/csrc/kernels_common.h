@@ -37,3 +37,40 @@ __device__ __forceinline__ u32 wave_alloc(u32* counter, bool want) {
     }
     return base + (u32)__popcll(mask & (((u64)1 << lane_id()) - 1));
 }
+
+// a + b on the scalar unit, opaque to the optimiser: a chain `x = fzb_sadd(x, step)` over an unrolled loop stays one s_add per
+// link (the compiler otherwise rewrites it into a multiply and an add per element)
+__device__ __forceinline__ u32 fzb_sadd(u32 a, u32 b) {
+#ifdef FZB_HOST_SHIM  // tests/kernel_host: the same arithmetic compiled for the host
+    return a + b;
+#else
+    u32 r;
+    asm volatile("s_add_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    return r;
+#endif
+}
+
+// Issue priority of the calling wave (s_setprio takes an immediate, hence the switch); p must be wave-uniform.
+// The SIMD's arbiter serves its waves by priority, then age: at equal priority the oldest wave runs nearly unimpeded and the youngest
+// gets the leftover issue slots, so equal shares of work finish one after the other and the last wave runs alone - at about half the
+// VALU rate, because a single wave cannot hide its own scalar instructions, waits and dependencies.  The persistent scorers therefore
+// lower a wave's priority as it progresses through its share (progress in quarters), which keeps the waves of a SIMD within a quarter of
+// each other until the end (MI355X_MICROARCH.md, "VALU issue is arbitrated ... by priority, then age").
+__device__ __forceinline__ void fzb_set_wave_priority(u32 p) {
+    switch (p) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+    }
+}
+// progress of a wave through its share of a persistent kernel, in quarters: called once per item with the item's number and the
+// wave's item count (both wave-uniform SCALARS - pass them through __builtin_amdgcn_readfirstlane), and once more half way
+// through the item
+struct FzbProgressPrio {
+    u32 k2, n2;  // 2 * item number (+ 1 in the second half), 2 * items of this wave
+    __device__ __forceinline__ void apply() const {
+        const u32 q = 4 * k2;  // level = floor(4 * k2 / n2), without a division
+        fzb_set_wave_priority(q < n2 ? 3u : q < 2 * n2 ? 2u : q < 3 * n2 ? 1u : 0u);
+    }
+};

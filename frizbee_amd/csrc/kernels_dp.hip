@@ -26,7 +26,7 @@ __global__ __launch_bounds__(128, 2) void k2b_dp(const u8* __restrict__ bytes, c
     __shared__ u8 cls[256];
     build_cls_table(cls);
     __syncthreads();
-    const u32 M = *n_items_ptr;
+    const u32 M = __builtin_amdgcn_readfirstlane(*n_items_ptr);  // wave-uniform: keeps the loop control on the scalar unit
     if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
     // Persistent threads with a three-deep software pipeline over the dependent loads of one item
     // (survivor index / window -> end offsets -> haystack vectors): each stage is requested one iteration before it is
@@ -137,6 +137,121 @@ __global__ __launch_bounds__(128, 2) void k2b_dp(const u8* __restrict__ bytes, c
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// k2b_dp_short: the same scorer for a corpus whose longest haystack fits half a chunk (and two 16-byte vectors): every
+// window is scored in dp_cf.h's form with SWL/2 computed lanes, the haystack never leaves the two prefetched vectors, the
+// 0-typo window comes from one merged flag word per needle byte and the per-lane bonuses from two small LDS tables.  No
+// queues (nothing can be wider than a chunk) and a third of the registers of the general kernel: four waves per SIMD.
+// Chosen by fzb_launch_dp when LaunchCfg::cf_ok and CorpusDev::max_len allow; otherwise k2b_dp runs.
+// ---------------------------------------------------------------------------------------------------------------
+#ifdef FZB_DP_TIMING
+// Debug build only (make TIMING=1 -> libfrizbee_hip_timing.so, tools/exp_dp_timing.py): per wave, the constant 100 MHz counter
+// (s_memrealtime) and the shader-clock counter (s_memtime) at entry and exit, to split the kernel's duration into dispatch ramp,
+// resident time, tail and effective clock.
+__device__ unsigned long long fzb_dp_timing[6 * 8192];
+extern "C" int fzb_debug_dp_timing(unsigned long long* host_out) { return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fzb_dp_timing), sizeof(fzb_dp_timing)); }
+#define FZB_TIMING_BEGIN const unsigned long long t_rt0 = wall_clock64(), t_ck0 = clock64();
+#define FZB_TIMING_END                                                                                  \
+    if ((threadIdx.x & 63) == 0) {                                                                      \
+        const u32 w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;                                     \
+        if (w < 8192) { fzb_dp_timing[6 * w] = t_rt0; fzb_dp_timing[6 * w + 1] = wall_clock64(); fzb_dp_timing[6 * w + 2] = t_ck0; fzb_dp_timing[6 * w + 3] = clock64(); \
+                        fzb_dp_timing[6 * w + 4] = __builtin_amdgcn_s_getreg(4 | (31 << 11)); fzb_dp_timing[6 * w + 5] = __builtin_amdgcn_s_getreg(20 | (31 << 11)); } /* HW_ID, XCC_ID */ \
+    }
+#else
+#define FZB_TIMING_BEGIN
+#define FZB_TIMING_END
+#endif
+template <int SWL, bool UPPER, typename ET>
+__global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+                                                    const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
+                                                    const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count) {
+    FZB_TIMING_BEGIN
+    __shared__ CfTables tab;
+    cf_build_tables<UPPER>(nd, tab);
+    __syncthreads();
+    const u32 M = __builtin_amdgcn_readfirstlane(*n_items_ptr);  // wave-uniform: keeps the loop control on the scalar unit
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
+    // persistent threads, three-deep software pipeline over the dependent loads of one item (see k2b_dp)
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    auto load_item = [&](u64 j, u32& li, u32& ws, u32& we) {
+        li = 0; ws = 0; we = 0;
+        if (j < M) {
+            li = items ? items[j] : (u32)j;
+            if (wmode == 0) { const uint2 w = *(const uint2*)(win + 2 * j); ws = w.x; we = w.y; }
+        }
+    };
+    auto load_span = [&](u64 j, u32 li, u64& s, u32& L) {
+        s = 0; L = 0;
+        if (j < M) haystack_span(ends, first + li, s, L);
+    };
+    auto load_vecs = [&](u64 s, u32 L, uint4& q0, uint4& q1) {
+        q0 = make_uint4(0, 0, 0, 0);
+        q1 = make_uint4(0, 0, 0, 0);
+        const uint4* vp = (const uint4*)(bytes + s);
+        if (L > 0) q0 = vp[0];
+        if (SWL > 32 && L > 16) q1 = vp[1];
+    };
+    u32 li_c, ws_c, we_c, L_c, li_n, ws_n, we_n, L_n, li_m, ws_m, we_m;
+    u64 s_c, s_n;
+    uint4 q0_c, q1_c;
+    load_item(j0, li_c, ws_c, we_c);
+    load_item(j0 + stride, li_n, ws_n, we_n);
+    load_item(j0 + 2 * stride, li_m, ws_m, we_m);
+    load_span(j0, li_c, s_c, L_c);
+    load_span(j0 + stride, li_n, s_n, L_n);
+    load_vecs(s_c, L_c, q0_c, q1_c);
+    // issue priority follows the wave's progress through its share (kernels_common.h, FzbProgressPrio): wave-uniform scalars
+    const u32 jw = __builtin_amdgcn_readfirstlane((u32)j0);  // the wave's first item (lane 0's)
+    const u32 n_iter = __builtin_amdgcn_readfirstlane(jw < M ? (u32)(((u64)M - jw + stride - 1) / stride) : 1u);
+    struct MidItem {
+        FzbProgressPrio* p;
+        __device__ __forceinline__ void operator()() const { p->k2 += 1; p->apply(); }
+    };
+    FzbProgressPrio prio{0u, 2 * n_iter};
+    for (u64 j = j0; j < M; j += stride) {
+        prio.apply();
+        uint4 q0_n, q1_n;
+        load_vecs(s_n, L_n, q0_n, q1_n);
+        u64 s_m;
+        u32 L_m;
+        load_span(j + 2 * stride, li_m, s_m, L_m);
+        u32 li_f, ws_f, we_f;
+        load_item(j + 3 * stride, li_f, ws_f, we_f);
+        if (j < capacity) {
+            const u32 L = L_c;
+            u32 ws = ws_c, we = we_c;
+            if (wmode == 2) { ws = 0; we = L; }
+            else if (wmode == 1) cf_window_first_last_regs(nd, q0_c, q1_c, ws, we);
+            // ---- trim_haystack (matcher/algo.rs:332-338) --------------------------------------------------
+            const u32 sp = ws ? ws - 1 : 0;
+            const bool include_exact = sp == 0 && we == L;
+            const u32 m = we - sp;
+            u32 score = 0;
+            u32 hb[SWL / 4];
+#pragma unroll
+            for (int k = 0; k < SWL / 4; k++) hb[k] = 0;
+            if (m > 0) {
+                load_window_regs<SWL / 4>(q0_c, q1_c, sp, m, hb);
+                score = dp_single_chunk_cf_tab<SWL, UPPER, SWL / 4, MidItem>(nd, sp == 0, tab, hb, MidItem{&prio});
+            }
+            const bool exact = exact_match<SWL / 4>(nd, include_exact, m, hb);
+            if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+            fzb_match_rec rec;
+            rec.index = index_offset + li_c;
+            rec.score = (u16)score;
+            rec.exact = exact ? 1 : 0;
+            rec.valid = 0;
+            out[j] = rec;
+        }
+        li_c = li_n; ws_c = ws_n; we_c = we_n; s_c = s_n; L_c = L_n; q0_c = q0_n; q1_c = q1_n;
+        li_n = li_m; ws_n = ws_m; we_n = we_m; s_n = s_m; L_n = L_m;
+        li_m = li_f; ws_m = ws_f; we_m = we_f;
+        prio.k2 = (prio.k2 | 1u) + 1;  // next item
+    }
+    FZB_TIMING_END
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k2d: the queued windows of SWL < m <= 1024 bytes, one thread each, chunk by chunk (dp_multi_chunk).
 // ---------------------------------------------------------------------------------------------------------------
 template <int SWL, bool BIAS, typename ET>
@@ -189,6 +304,19 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
                    int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st) {
     bool upper = false;  // an uppercase letter among the needle bytes as they are compared
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+    if (mode == 2 && (sw_lanes == 64 || sw_lanes == 32) && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2) {
+        // every haystack fits half a chunk (and the two prefetched vectors): the short-haystack kernel
+#define FZB_K2S(SWL, U, ET)                                                                                                             \
+    do {                                                                                                                                \
+        static int per_cu = 0;                                                                                                          \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
+        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count); \
+    } while (0)
+#define FZB_K2S_ET(SWL, U) do { if (c.ends_u64) FZB_K2S(SWL, U, u64); else FZB_K2S(SWL, U, u32); } while (0)
+#define FZB_K2S_U(SWL) do { if (upper) FZB_K2S_ET(SWL, true); else FZB_K2S_ET(SWL, false); } while (0)
+        if (sw_lanes == 64) FZB_K2S_U(64); else FZB_K2S_U(32);
+        return;
+    }
     // the kernel is persistent: launch exactly the workgroups that are resident at once
 #define FZB_K2B(SWL, B, U, ET)                                                                                                          \
     do {                                                                                                                                \

@@ -44,6 +44,12 @@ static int run(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, in
     if (form == 0) return (int)dp_single_chunk<SWL, true, U>(nd, m, include_prefix, cls, hb);                              \
     if (form == 1) return (int)dp_single_chunk<SWL, false, U>(nd, m, include_prefix, cls, hb);                             \
     if (form == 2) return (int)dp_single_chunk<SWL, true, U, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, include_prefix, cls, hb); \
+    if (form == 4) {  /* table set-up (short-haystack kernel): SWL/2 computed lanes */                                    \
+        CfTables tab;                                                                                                      \
+        for (unsigned t = 0; t < 16; t++) { threadIdx.x = t; cf_build_tables<U>(nd, tab); }                                \
+        threadIdx.x = 0;                                                                                                   \
+        if (SWL >= 16) return (int)dp_single_chunk_cf_tab<SWL, U, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, include_prefix, tab, hb); \
+    }                                                                                                                      \
     if (form == 3) {                                                                                                       \
         if (real == NW) return (int)dp_single_chunk_cf<SWL, U, NW>(nd, include_prefix, cls, hb);                           \
         if (real == NW / 2) return (int)dp_single_chunk_cf<SWL, U, NW / 2>(nd, include_prefix, cls, hb);                   \
@@ -56,7 +62,8 @@ static int run(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, in
 }
 
 extern "C" {
-// form: 0 = dp_single_chunk biased, 1 = literal (unbiased) scan, 2 = its padded-half form, 3 = dp_single_chunk_cf with `real` dwords.
+// form: 0 = dp_single_chunk biased, 1 = literal (unbiased) scan, 2 = its padded-half form, 3 = dp_single_chunk_cf with `real` dwords,
+// 4 = dp_single_chunk_cf_tab (LDS-table set-up, swl/4 dwords).
 // Returns the score of `hay[0..m)` as ONE chunk of `swl` lanes (no exact bonus), or < 0 on a bad argument.
 int kh_dp_single(const u8* needle, int n, int case_sensitive, const u16* scoring, const u8* hay, int m, int include_prefix, int swl, int form, int real) {
     if (n < 1 || n > FZB_MAX_ROWS || m < 1 || m > swl) return -1;
@@ -71,6 +78,21 @@ int kh_dp_single(const u8* needle, int n, int case_sensitive, const u16* scoring
         case 8: return run<8>(nd, hay, (u32)m, include_prefix, form, real, cls);
     }
     return -1;
+}
+
+// the 0-typo window of a haystack of at most 32 bytes: the short kernel's merged-flag-word search against dp_body.h's (both forms
+// of src/prefilter/algo/ascii.rs:6-72); out = {ws, we} of each
+int kh_window(const u8* needle, int n, int case_sensitive, const u8* hay, int len, unsigned* out) {
+    if (n < 1 || n > FZB_MAX_ROWS || len < 0 || len > 32) return -1;
+    static const u16 sc[9] = {12, 6, 5, 1, 12, 4, 4, 8, 4};
+    NeedleDev nd;
+    fill_needle(nd, needle, n, case_sensitive, sc);
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    memcpy(w, hay, (size_t)len);
+    const uint4 q0 = make_uint4(w[0], w[1], w[2], w[3]), q1 = make_uint4(w[4], w[5], w[6], w[7]);
+    window_first_last_regs(nd, q0, q1, (u32)len, out[0], out[1]);
+    cf_window_first_last_regs(nd, q0, q1, out[2], out[3]);
+    return 0;
 }
 
 // batch form for fuzzing: `count` windows packed back to back with byte lengths lens[i]; scores out

@@ -17,7 +17,8 @@ struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 struct dim3 { unsigned x = 1, y = 1, z = 1; };
-static const dim3 threadIdx{0, 0, 0}, blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
+static dim3 threadIdx{0, 0, 0};  // the harness steps it where a kernel fills a table cooperatively
+static const dim3 blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
 typedef void* hipStream_t;
 
 // one-thread "wave": the cross-lane helpers degenerate
@@ -55,3 +56,8 @@ static inline uint32_t fzb_host_perm(uint32_t s0, uint32_t s1, uint32_t sel) {
 #define __builtin_amdgcn_alignbit fzb_host_alignbit
 #define __builtin_amdgcn_alignbyte fzb_host_alignbyte
 #define __builtin_amdgcn_perm fzb_host_perm
+static inline void __builtin_amdgcn_s_setprio_host(int) {}
+#define __builtin_amdgcn_s_setprio __builtin_amdgcn_s_setprio_host
+#define FZB_HOST_SHIM 1
+static inline uint32_t fzb_host_rfl(uint32_t v) { return v; }
+#define __builtin_amdgcn_readfirstlane fzb_host_rfl

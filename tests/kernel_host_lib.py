@@ -35,6 +35,7 @@ def lib():
     if _lib is None:
         _lib = C.CDLL(build())
         _lib.kh_dp_single.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.kh_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
 
@@ -42,6 +43,13 @@ def lib():
 def dp_single(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=64, form=3, real=16):
     sc = (C.c_uint16 * 9)(*scoring)
     return lib().kh_dp_single(needle, len(needle), int(case_sensitive), sc, hay, len(hay), int(include_prefix), swl, form, real)
+
+
+def window(needle, hay, case_sensitive=False):
+    """((ws, we) of dp_body.h's search, (ws, we) of dp_cf.h's) for a haystack of at most 32 bytes"""
+    out = (C.c_uint32 * 4)()
+    assert lib().kh_window(needle, len(needle), int(case_sensitive), hay, len(hay), out) == 0
+    return (out[0], out[1]), (out[2], out[3])
 
 
 def dp_batch(needle, hays, scoring, case_sensitive, include_prefix, swl, form, real):

@@ -62,12 +62,14 @@ def test_random_windows_all_forms_match_the_oracle(swl):
             while True:
                 sc = [rng.randint(0, 40), rng.randint(0, 20), rng.randint(0, 20), rng.randint(0, 6), rng.randint(0, 30), rng.randint(0, 12), rng.randint(0, 12),
                       rng.randint(0, 20), rng.randint(0, 12)]
-                if sc[3] <= sc[1]:
+                if 2 * sc[3] <= sc[1]:
                     break
         real = rng.choice(reals)
         hays = [_rnd(rng, rng.randint(1, 2 * real), alpha) for _ in range(12)]
         ips = [rng.random() < 0.5 for _ in hays]
         _check(needle, hays, sc, cs, ips, swl, 3, real)
+        if swl >= 16:  # the short-haystack kernel's set-up (LDS tables) in front of the same rows
+            _check(needle, [h[: swl // 2] for h in hays], sc, cs, ips, swl, 4, 0)
         # the first form (dp_body.h) on the same inputs: biased scan, literal scan, padded half
         _check(needle, hays, sc, cs, ips, swl, 0, 0)
         _check(needle, hays, sc, cs, ips, swl, 1, 0)
@@ -79,7 +81,7 @@ def test_padding_entries_exhaustively_on_a_small_chunk():
     # 8-lane chunk, 4 computed lanes: every window over {a, b, q} up to 4 bytes x every needle over {a, b} up to 6 rows x gap scorings
     hays = [bytes(t) for n in range(1, 5) for t in itertools.product(b"abq", repeat=n)]
     needles = [bytes(t) for n in range(1, 7) for t in itertools.product(b"ab", repeat=n)]
-    for e, o, x in ((0, 3, 0), (1, 4, 6), (1, 10, 1), (2, 0, 5), (0, 10, 3)):
+    for e, o, x in ((0, 3, 0), (1, 4, 6), (1, 10, 2), (2, 0, 5), (0, 10, 3)):
         sc = [12, x, o + e, e, 6, 4, 4, 8, 4]
         for needle in needles:
             _check(needle, hays, sc, False, [True] * len(hays), 8, 3, 2)
@@ -99,7 +101,7 @@ def test_full_windows_with_unmatched_needle_tails(swl, real):
             while True:
                 sc = [rng.randint(1, 30), rng.randint(0, 12), rng.randint(0, 30), rng.randint(0, 3), rng.randint(0, 20), rng.randint(0, 8), rng.randint(0, 8), rng.randint(0, 20),
                       rng.randint(0, 8)]
-                if sc[3] <= sc[1]:
+                if 2 * sc[3] <= sc[1]:
                     break
         for _ in range(6):
             t = rng.randint(1, 5)
@@ -114,3 +116,23 @@ def test_full_windows_with_unmatched_needle_tails(swl, real):
                 if rng.random() < 0.4 and 0 <= P - s < m:
                     body[P - s] = rng.choice(head)
             _check(needle, [bytes(body[:m])], sc, False, [rng.random() < 0.5], swl, 3, real)
+            if real == swl // 4:
+                _check(needle, [bytes(body[:m])], sc, False, [rng.random() < 0.5], swl, 4, 0)
+
+
+def test_short_kernel_window_search_equals_the_first_form():
+    """cf_window_first_last_regs (one merged flag word per needle byte) against window_first_last_regs, on haystacks of 0..32 bytes
+    that contain the needle's first and last byte (what a survivor of the exact filter guarantees), both case modes."""
+    rng = random.Random(4242)
+    for it in range(20000):
+        alpha = rng.choice([b"ab", b"abAB_", b"abcdefABCDEF_-/ 019", bytes(range(33, 127))])
+        needle = _rnd(rng, rng.randint(1, 8), alpha)
+        cs = rng.random() < 0.3
+        L = rng.randint(1, 32)
+        hay = bytearray(_rnd(rng, L, alpha))
+        hay[rng.randrange(L)] = needle[0]
+        hay[rng.randrange(L)] = needle[-1]
+        if needle[0] not in hay:
+            hay[0] = needle[0]
+        a, b = K.window(needle, bytes(hay), cs)
+        assert a == b, (needle, bytes(hay), cs, a, b)
