@@ -109,7 +109,7 @@ SYMBOLS = [
     "fzb_last_error", "fzb_config_default", "fzb_matcher_create", "fzb_matcher_clone", "fzb_matcher_free", "fzb_matcher_info", "fzb_matcher_set_pattern", "fzb_matcher_set_config",
     "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_set_max_len", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
     "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
-    "fzb_set_profiling", "fzb_last_timings", "fzb_last_counters",
+    "fzb_set_profiling", "fzb_last_timings", "fzb_last_stage_timings", "fzb_last_counters",
     "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
     "fzb_parse_query", "fzb_patterns_free", "fzb_match_list_indices", "fzb_match_indices_free", "fzb_multi_match_list_indices",
     "fzb_match_list_indices_into", "fzb_multi_match_list_into", "fzb_multi_match_list_indices_into",
@@ -147,6 +147,7 @@ def lib():
         l.fzb_k_merge_matches.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         l.fzb_set_profiling.argtypes = [C.c_void_p, C.c_int]
         l.fzb_last_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        l.fzb_last_stage_timings.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         l.fzb_last_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
         l.fzb_multi_matcher_create.argtypes = [C.POINTER(_CConfig), C.POINTER(_CPattern), C.c_size_t, C.POINTER(C.c_void_p)]
         l.fzb_multi_matcher_free.argtypes = [C.c_void_p]
@@ -476,6 +477,12 @@ class Matcher(_IterApi):
         out = (C.c_float * 4)()
         _check(lib().fzb_last_timings(self.h, out))
         return dict(filter=out[0], total=out[1], calls=int(out[2]))
+
+    def last_stage_timings_ms(self):
+        """HIP-event averages of the profiled calls, by stage (filter kernel / compaction + lane-exact prefilter / scorers / whole pipeline)"""
+        out = (C.c_float * 6)()
+        _check(lib().fzb_last_stage_timings(self.h, out))
+        return dict(filter=out[0], compaction_and_window=out[1], scorers=out[2], total=out[3], calls=int(out[4]))
 
     def last_counters(self):
         out = (C.c_uint32 * 4)()

@@ -174,8 +174,8 @@ struct fzb_matcher {
     Workspace ws{};
     int device = -1;
     bool profiling = false;
-    static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2],[3]=around the filter kernel
-    hipEvent_t evring[PROF_SLOTS][4] = {};
+    static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2],[3]=around the filter kernel [4]=before the scorers
+    hipEvent_t evring[PROF_SLOTS][5] = {};
     int ev_filter[PROF_SLOTS] = {};
     u64 prof_calls = 0;
 
@@ -622,7 +622,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         pev = m->evring[slot];
         m->ev_filter[slot] = (lc.filter_mode && !items_in) ? 1 : 0;
         m->prof_calls++;
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 5; i++)
             if (!pev[i]) HIPCHK(hipEventCreate(&pev[i]));
         HIPCHK(hipEventRecord(pev[0], st));
     }
@@ -653,7 +653,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 2, st);
+        static const int c1mul = getenv("FZB_COMPACT_GRID_MUL") ? atoi(getenv("FZB_COMPACT_GRID_MUL")) : 4;  // tuning knob (workgroups per CU)
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * c1mul, st);
         FZB_STAGE("compact1");
         items = w.surv_idx;
     }
@@ -668,6 +669,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         n_items_ptr = &cnt_c[1];
         wmode = 0;
     }
+    if (pev) HIPCHK(hipEventRecord(pev[4], st));
     fzb_match_rec* outp = (fzb_match_rec*)dev_out;
     const u32 qcap = cnt;  // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back
     const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
@@ -1439,7 +1441,7 @@ int fzb_set_profiling(fzb_matcher* m, int enabled) {
     return FZB_OK;
 }
 
-// Averages over the calls made since fzb_set_profiling(m, 1) (at most the last 32):
+// Averages over the calls made since fzb_set_profiling(m, 1) (at most the last 32 = PROF_SLOTS):
 // out_ms[0] = filter kernel, [1] = whole pipeline, [2] = calls averaged, [3] = 1 if a filter kernel ran
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
     if (!m || !out_ms) return fail(FZB_ERR_INVALID, "null argument");
@@ -1465,6 +1467,43 @@ int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
     out_ms[1] = (float)(t / n);
     out_ms[2] = (float)n;
     out_ms[3] = (float)has_filter;
+    return FZB_OK;
+}
+
+// Per-stage averages over the same calls: out_ms[0] = streaming filter kernel, [1] = compaction (+ the lane-exact prefilter and its
+// compaction when the configuration has them), [2] = the scorers, [3] = whole pipeline, [4] = calls averaged, [5] = 1 if a filter ran
+int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]) {
+    if (!m || !out_ms) return fail(FZB_ERR_INVALID, "null argument");
+    if (!m->profiling || m->prof_calls == 0) return fail(FZB_ERR_INVALID, "profiling not enabled or no call recorded");
+    const u64 n = std::min<u64>(m->prof_calls, fzb_matcher::PROF_SLOTS);
+    double f = 0, mid = 0, sc = 0, t = 0;
+    int has_filter = 0;
+    for (u64 i = 0; i < n; i++) {
+        const int slot = (int)((m->prof_calls - 1 - i) % fzb_matcher::PROF_SLOTS);
+        hipEvent_t* e = m->evring[slot];
+        HIPCHK(hipEventSynchronize(e[1]));
+        float a = 0;
+        HIPCHK(hipEventElapsedTime(&a, e[0], e[1]));
+        t += a;
+        HIPCHK(hipEventElapsedTime(&a, e[4], e[1]));
+        sc += a;
+        has_filter = m->ev_filter[slot];
+        if (has_filter) {
+            HIPCHK(hipEventElapsedTime(&a, e[2], e[3]));
+            f += a;
+            HIPCHK(hipEventElapsedTime(&a, e[3], e[4]));
+            mid += a;
+        } else {
+            HIPCHK(hipEventElapsedTime(&a, e[0], e[4]));
+            mid += a;
+        }
+    }
+    out_ms[0] = (float)(f / n);
+    out_ms[1] = (float)(mid / n);
+    out_ms[2] = (float)(sc / n);
+    out_ms[3] = (float)(t / n);
+    out_ms[4] = (float)n;
+    out_ms[5] = (float)has_filter;
     return FZB_OK;
 }
 

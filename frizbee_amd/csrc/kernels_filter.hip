@@ -341,8 +341,22 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
     const u32 T = (ntiles + gridDim.x - 1) / gridDim.x;
     const u32 t0 = min(blockIdx.x * T, ntiles), t1 = min(t0 + T, ntiles);
     // survivors before tile t0
+    // (16-byte loads, four in flight per thread: this sum is the kernel's critical path - up to ntiles counts per workgroup)
     u32 part = 0;
-    for (u32 i = tid; i < t0; i += 256) part += counts[i];
+    {
+        const uint4* c4 = (const uint4*)counts;
+        const u32 n4 = t0 / 4;
+        u32 i = tid;
+        for (; i + 768 < n4; i += 1024) {
+            const uint4 a = c4[i], b = c4[i + 256], c = c4[i + 512], d = c4[i + 768];
+            part += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+        }
+        for (; i < n4; i += 256) {
+            const uint4 a = c4[i];
+            part += a.x + a.y + a.z + a.w;
+        }
+        for (u32 k = 4 * n4 + tid; k < t0; k += 256) part += counts[k];
+    }
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
     if (lane == 0) red[wave] = part;
     __syncthreads();
@@ -411,8 +425,22 @@ __global__ __launch_bounds__(256) void k_compact2(const u64* __restrict__ bitmap
     const u32 ntiles = (n_items + FZB_TILE - 1) / FZB_TILE;
     const u32 T = (ntiles + gridDim.x - 1) / gridDim.x;
     const u32 t0 = min(blockIdx.x * T, ntiles), t1 = min(t0 + T, ntiles);
+    // (16-byte loads, four in flight per thread: this sum is the kernel's critical path - up to ntiles counts per workgroup)
     u32 part = 0;
-    for (u32 i = tid; i < t0; i += 256) part += counts[i];
+    {
+        const uint4* c4 = (const uint4*)counts;
+        const u32 n4 = t0 / 4;
+        u32 i = tid;
+        for (; i + 768 < n4; i += 1024) {
+            const uint4 a = c4[i], b = c4[i + 256], c = c4[i + 512], d = c4[i + 768];
+            part += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+        }
+        for (; i < n4; i += 256) {
+            const uint4 a = c4[i];
+            part += a.x + a.y + a.z + a.w;
+        }
+        for (u32 k = 4 * n4 + tid; k < t0; k += 256) part += counts[k];
+    }
     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
     if (lane == 0) red[wave] = part;
     __syncthreads();

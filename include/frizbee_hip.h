@@ -220,10 +220,13 @@ int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size
 
 /* Measurement hooks (bench.py): device time of the fzb_match_list_device calls made on this matcher since
  * fzb_set_profiling(m, 1), measured with HIP events recorded on the launch stream (event records only, no
- * synchronisation until read).  fzb_last_timings averages over those calls (at most the last 64):
+ * synchronisation until read).  fzb_last_timings averages over those calls (at most the last 32):
  * out_ms[0]=filter kernel, [1]=whole pipeline, [2]=calls averaged, [3]=1 if a filter kernel ran. */
 int fzb_set_profiling(fzb_matcher* m, int enabled);
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]);
+/* the same calls by stage: out_ms[0]=streaming filter kernel, [1]=compaction (+ lane-exact prefilter and its compaction), [2]=scorers,
+ * [3]=whole pipeline, [4]=calls averaged, [5]=1 if a filter kernel ran */
+int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]);
 /* counters of the last call: out[0]=survivors of the filter stage, [1]=kept by the lane-exact prefilter,
  * [2]=windows scored by the generic wave-per-haystack kernel, [3]=windows scored by the multi-chunk kernel */
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]);
