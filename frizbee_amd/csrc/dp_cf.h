@@ -325,3 +325,35 @@ __device__ __forceinline__ void cf_window_first_last_regs(const NeedleDev& nd, c
     // last occurrence: reversing the word maps bit 8j + k to 8(3-j) + (7-k), so "first" of the reversed word is 31 - last position
     we = yz ? 32u - cf_first_pos(__builtin_bitreverse32(yz)) : 0u;
 }
+
+// ---- the typo prefilter's window of an ACCEPTED haystack of at most 32 bytes, lane-free form ------------------------------------
+// (src/prefilter/algo/ascii_typos.rs: every path records its first hit in match_start_pos, :64-88; find_end_pos_with_typos, :374-398;
+//  checked against the oracle at all three widths by tests/test_oracle_reference_properties.py::test_ascii_typo_windows_have_a_lane_free_form)
+//   start = the earliest first occurrence of any of needle[0..=k], end = one past the last occurrence of any of needle[n-1-k..]
+//   (either case; len when none occurs).
+// fl[byte]: bit 0 = the byte is one of needle[0..=k] (either case), bit 1 = one of needle[n-1-k..].  Bytes past the haystack's end
+// are zero in the padded-16 layout and the needle has no NUL (cf_ok), so fl[0] = 0 masks them.
+__device__ __forceinline__ void cf_build_typo_table(const NeedleDev& nd, u8* fl) {
+    for (int b = threadIdx.x; b < 256; b += blockDim.x) {
+        const int n = nd.rows, k = nd.max_typos;
+        u32 v = 0;
+        for (int j = 0; j < n; j++) {
+            if (b != nd.c[j] && b != nd.f[j]) continue;
+            if (j <= k) v |= 1;
+            if (j + k + 1 >= n) v |= 2;
+        }
+        fl[b] = (u8)v;
+    }
+}
+__device__ __forceinline__ void cf_window_typos_regs(const u8* fl, const uint4& q0, const uint4& q1, u32 L, u32& ws, u32& we) {
+    const u32 w8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    u32 mf = 0, ml = 0;
+#pragma unroll
+    for (int p = 0; p < 32; p++) {
+        const u32 v = fl[(w8[p >> 2] >> (8 * (p & 3))) & 0xFF];
+        mf |= (v & 1u) << p;
+        ml |= (v >> 1) << p;
+    }
+    ws = mf ? (u32)__builtin_ctz(mf) : 0u;  // (an accepted haystack has one of needle[0..=k]: at most k needle bytes go unmatched)
+    we = ml ? 32u - (u32)__builtin_clz(ml) : L;
+}

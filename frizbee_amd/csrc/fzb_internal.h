@@ -76,6 +76,14 @@ struct Workspace {
     u32* items2;        // local haystack index of kept survivor
     u32* win2;          // its window
     u32* counters;      // [0]=filter survivors [1]=kept by the lane-exact prefilter [2]=output base of the NEXT chunk [3]=multi-chunk queue length [4]=greedy (>1024 B) queue length
+                        // [5]=marginal survivors (LCS == need) [6]=of those, rejected by the lane-exact decision
+    u64* bitmap_m;      // typo fast path: "accepted with nothing to spare" bits, their tile counts, the list of those haystacks,
+    u32* tile_counts_m; //   the reject bits / per-tile counts / prefix the decide pass produces
+    u32* marg_list;
+    u64* reject_bits;
+    u32* tile_rejects;
+    u32* rej_prefix;
+    size_t cap_marg;    // capacity (in haystacks) of the six arrays above (0 = not allocated)
     u64* table;         // 256 x u64 filter table (device)
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
@@ -98,11 +106,22 @@ struct LaunchCfg {
     u32 dead_byte;      // a byte value no needle row can match (used to neutralise bytes past a haystack's end in the DFA filter)
 };
 
+// Rejections of the decide pass (typo configurations on the short-haystack path): one bit per haystack of the range, a count per
+// 1024-haystack tile and its exclusive prefix (filled only when anything was rejected), the total in counters[6]
+struct RejectOut {
+    u64* bits;
+    u32* tile_rejects;
+    u32* rej_prefix;
+    u32* count;
+};
+
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 // kernels_filter.hip
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
-                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st);
+                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m = nullptr, u32* tile_counts_m = nullptr,
+                       u64* reject_bits = nullptr, u32* tile_rejects = nullptr);
+void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* reject_count, u32* rej_prefix, hipStream_t st);
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st);
 void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,
                              u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
@@ -110,10 +129,12 @@ void fzb_launch_compact2(const u64* bitmap, const u32* counts, const u32* n_item
                          int grid, hipStream_t st);
 // kernels_window.hip
 void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
-                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st);
+                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide = nullptr);
 // kernels_dp.hip
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st);
+                   int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st,
+                   const RejectOut* rejects = nullptr);
+bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
 void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_unicode.hip

@@ -208,7 +208,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -512,10 +512,18 @@ int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
 }
 
 // ---- pipeline -------------------------------------------------------------------------------------------
+// ASCII typo configuration whose scorer can be the short-haystack kernel: the filter's LCS criterion decides, only its marginal
+// survivors (LCS == rows - k) are re-decided at the exact lane width, and the scorer computes the lane-free window itself
+// (whether the corpus allows it - max_len - is known per call: run_pipeline)
+static bool typo_fast_path_configured(const fzb_matcher* m) {
+    return !m->literal_mode && !m->empty && m->lc.filter_mode == 2 && !m->nd.unicode && m->lc.cf_ok && (m->lc.sw_lanes == 64 || m->lc.sw_lanes == 32);
+}
+
 static int ensure_workspace(fzb_matcher* m, size_t count) {
     Workspace& w = m->ws;
     const bool need_l2 = !m->lc.filter_exact;
-    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && w.counters) {
+    const bool need_marg = typo_fast_path_configured(m);
+    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && (!need_marg || w.cap_marg >= count) && w.counters) {
         if (w.tables_stale) {  // fzb_matcher_set_pattern / set_config kept the device buffers: only the two small tables change
             HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
             if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
@@ -543,6 +551,15 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
         HIPCHK(dev_alloc((void**)&w.items2, cap * 4));
         HIPCHK(dev_alloc((void**)&w.win2, cap * 8));
         w.cap_level2 = cap;
+    }
+    if (need_marg) {
+        HIPCHK(dev_alloc((void**)&w.bitmap_m, (cap / 64 + 17) * 8));
+        HIPCHK(dev_alloc((void**)&w.tile_counts_m, ntiles * 4));
+        HIPCHK(dev_alloc((void**)&w.marg_list, cap * 4));
+        HIPCHK(dev_alloc((void**)&w.reject_bits, (cap / 64 + 17) * 8));
+        HIPCHK(dev_alloc((void**)&w.tile_rejects, ntiles * 4));
+        HIPCHK(dev_alloc((void**)&w.rej_prefix, ntiles * 4));
+        w.cap_marg = cap;
     }
     return FZB_OK;
 }
@@ -647,6 +664,29 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     } else if (lc.filter_mode == 0) {
         // nothing filtered (max_typos = None or >= rows): the survivors are the identity list
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&cnt_c[0], (int)cnt, 1, st));
+    } else if (typo_fast_path_configured(m) && !trace && fzb_dp_short_applies(cd, lc.sw_lanes, 2)) {
+        // ---- typo configuration, every haystack fits half a chunk: LCS filter with the "nothing to spare" bit -> survivors;
+        // the marginal ones are re-decided at the exact lane width (a reject sets a bit), the scorer computes the windows ----
+        const int need = nd.rows - nd.max_typos;
+        const u32 ntiles = (cnt + FZB_TILE - 1) / FZB_TILE;
+        const RejectOut rej{w.reject_bits, w.tile_rejects, w.rej_prefix, &cnt_c[6]};
+        if (pev) HIPCHK(hipEventRecord(pev[2], st));
+        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, w.bitmap_m,
+                          w.tile_counts_m, w.reject_bits, w.tile_rejects);
+        if (pev) HIPCHK(hipEventRecord(pev[3], st));
+        FZB_STAGE("filter(marginal)");
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
+        fzb_launch_compact1(w.bitmap_m, w.tile_counts_m, cnt, nullptr, nullptr, w.marg_list, &cnt_c[5], cus * 4, st);
+        FZB_STAGE("compact1 x2");
+        fzb_launch_window(cd, first, w.marg_list, &cnt_c[5], nd, lc.pf_lanes, nullptr, nullptr, nullptr, cnt_c, cus * 4, st, &rej);
+        FZB_STAGE("window(decide)");
+        fzb_launch_scan_rejects(w.tile_rejects, ntiles, &cnt_c[6], w.rej_prefix, st);
+        if (pev) HIPCHK(hipEventRecord(pev[4], st));
+        fzb_launch_dp(cd, first, index_offset, w.surv_idx, nullptr, &cnt_c[0], nd, lc.sw_lanes, 2, 3, lc.pad_ok, (fzb_match_rec*)dev_out, cap32, dev_count, w.overflow, cnt, cnt_c, cus, st, &rej);
+        FZB_STAGE("dp(short, typo windows)");
+        if (pev) HIPCHK(hipEventRecord(pev[1], st));
+        HIPCHK(hipGetLastError());
+        return FZB_OK;
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2], st));

@@ -163,13 +163,22 @@ extern "C" int fzb_debug_dp_timing(unsigned long long* host_out) { return (int)h
 template <int SWL, bool UPPER, typename ET>
 __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                     const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
-                                                    const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count) {
+                                                    const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count,
+                                                    RejectOut rej, u32* __restrict__ kept_out) {
     FZB_TIMING_BEGIN
     __shared__ CfTables tab;
+    __shared__ u8 fl[256];
     cf_build_tables<UPPER>(nd, tab);
+    if (wmode == 3) cf_build_typo_table(nd, fl);
     __syncthreads();
     const u32 M = __builtin_amdgcn_readfirstlane(*n_items_ptr);  // wave-uniform: keeps the loop control on the scalar unit
-    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
+    // wmode 3 (typos): survivors that the decide pass rejected (rare) are skipped and the records behind them move up
+    const u32 nrej = wmode == 3 ? __builtin_amdgcn_readfirstlane(*rej.count) : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const u32 kept = M - nrej;
+        if (dev_count) *dev_count = kept < capacity ? kept : capacity;
+        if (kept_out) *kept_out = kept;
+    }
     // persistent threads, three-deep software pipeline over the dependent loads of one item (see k2b_dp)
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 j0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,11 +226,22 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
         load_span(j + 2 * stride, li_m, s_m, L_m);
         u32 li_f, ws_f, we_f;
         load_item(j + 3 * stride, li_f, ws_f, we_f);
-        if (j < capacity) {
+        u64 jo = j;  // output position
+        bool live = true;
+        if (nrej) {  // rare: some marginal survivor was rejected at the exact lane width
+            const u32 li = li_c, tile = li / FZB_TILE;
+            const u64 word = rej.bits[li >> 6];
+            live = !((word >> (li & 63)) & 1);
+            u32 before = rej.rej_prefix[tile] + (u32)__popcll(word & ((1ull << (li & 63)) - 1));
+            for (u32 wq = tile * (FZB_TILE / 64); wq < (li >> 6); wq++) before += (u32)__popcll(rej.bits[wq]);
+            jo = j - before;
+        }
+        if (live && jo < capacity) {
             const u32 L = L_c;
             u32 ws = ws_c, we = we_c;
             if (wmode == 2) { ws = 0; we = L; }
             else if (wmode == 1) cf_window_first_last_regs(nd, q0_c, q1_c, ws, we);
+            else if (wmode == 3) cf_window_typos_regs(fl, q0_c, q1_c, L, ws, we);
             // ---- trim_haystack (matcher/algo.rs:332-338) --------------------------------------------------
             const u32 sp = ws ? ws - 1 : 0;
             const bool include_exact = sp == 0 && we == L;
@@ -241,7 +261,7 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
             rec.score = (u16)score;
             rec.exact = exact ? 1 : 0;
             rec.valid = 0;
-            out[j] = rec;
+            out[jo] = rec;
         }
         li_c = li_n; ws_c = ws_n; we_c = we_n; s_c = s_n; L_c = L_n; q0_c = q0_n; q1_c = q1_n;
         li_n = li_m; ws_n = ws_m; we_n = we_m; s_n = s_m; L_n = L_m;
@@ -300,17 +320,24 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
     }
 }
 
+bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode) {
+    return mode == 2 && (sw_lanes == 64 || sw_lanes == 32) && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2;
+}
+
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
-                   int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st) {
+                   int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int num_cus, hipStream_t st,
+                   const RejectOut* rejects) {
     bool upper = false;  // an uppercase letter among the needle bytes as they are compared
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-    if (mode == 2 && (sw_lanes == 64 || sw_lanes == 32) && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2) {
+    if (fzb_dp_short_applies(c, sw_lanes, mode)) {
+        const RejectOut rj = rejects ? *rejects : RejectOut{};
+        u32* kept_out = rejects ? &counters[1] : nullptr;
         // every haystack fits half a chunk (and the two prefetched vectors): the short-haystack kernel
 #define FZB_K2S(SWL, U, ET)                                                                                                             \
     do {                                                                                                                                \
         static int per_cu = 0;                                                                                                          \
         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
-        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count); \
+        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out); \
     } while (0)
 #define FZB_K2S_ET(SWL, U) do { if (c.ends_u64) FZB_K2S(SWL, U, u64); else FZB_K2S(SWL, U, u32); } while (0)
 #define FZB_K2S_U(SWL) do { if (upper) FZB_K2S_ET(SWL, true); else FZB_K2S_ET(SWL, false); } while (0)

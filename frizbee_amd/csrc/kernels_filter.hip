@@ -43,26 +43,36 @@ __device__ __forceinline__ void filter_word(TW& st, u32 w, u32 nbytes, const TW*
     }
 }
 
-template <typename TW, int MODE, typename ET>
+// MARG (MODE 2 only): a second bit per haystack, "accepted with nothing to spare" (LCS == need exactly), with its own per-tile
+// counts - the only inputs on which the reference's chunked typo prefilter can differ from the LCS criterion
+// (tests/test_oracle_reference_properties.py), so only those are re-decided at the exact lane width (k2a_window, decide form).
+// The kernel also clears the per-haystack reject bits / per-tile reject counts that the decide pass sets.
+struct MargOut {
+    u64* bitmap_m;
+    u32* tile_counts_m;
+    u64* reject_bits;
+    u32* tile_rejects;
+};
+template <typename TW, int MODE, typename ET, bool MARG = false>
 __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                                  const u64* __restrict__ Tg, int rows, int need, u32 min_len,
-                                                 u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+                                                 u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, MargOut mo = MargOut{}) {
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
     // compaction kernel reads it
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     __shared__ TW T[256];
-    __shared__ u32 s_cnt;
+    __shared__ u32 s_cnt, s_cnt_m;
     const int tid = threadIdx.x;
     T[tid] = (TW)Tg[tid];
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tid == 0) s_cnt = 0;
+        if (tid == 0) s_cnt = 0, s_cnt_m = 0;
         __syncthreads();
-        u32 cnt = 0;
+        u32 cnt = 0, cnt_m = 0;
 #pragma unroll 1
         for (int p = 0; p < FZB_TILE / 256; p++) {
             const u32 li = tile * FZB_TILE + p * 256 + tid;
-            bool matched = false;
+            bool matched = false, marginal = false;
             if (li < count) {
                 u64 s;
                 u32 L;
@@ -86,6 +96,7 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
                         const TW z = ~st & low;
                         const int lcs = sizeof(TW) == 8 ? __popcll((u64)z) : __popc((u32)z);
                         matched = lcs >= need;
+                        marginal = lcs == need;
                     }
                 }
             }
@@ -94,10 +105,22 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
                 bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
                 cnt += __popcll(b);
             }
+            if (MARG) {
+                const u64 bm = __ballot(marginal);
+                if (lane_id() == 0) {
+                    mo.bitmap_m[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = bm;
+                    mo.reject_bits[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = 0;
+                    cnt_m += __popcll(bm);
+                }
+            }
         }
         if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        if (MARG && lane_id() == 0 && cnt_m) atomicAdd(&s_cnt_m, cnt_m);
         __syncthreads();
-        if (tid == 0) tile_counts[tile] = s_cnt;
+        if (tid == 0) {
+            tile_counts[tile] = s_cnt;
+            if (MARG) mo.tile_counts_m[tile] = s_cnt_m, mo.tile_rejects[tile] = 0;
+        }
         __syncthreads();
     }
 }
@@ -571,7 +594,7 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // host-side launch wrappers (called from host.hip)
 // ---------------------------------------------------------------------------------------------------
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
-                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st) {
+                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects) {
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
@@ -592,7 +615,15 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         return;
     }
     const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
-#define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters)
+    if (mode == 2 && bitmap_m) {  // LCS filter with the "nothing to spare" bit (typo configurations on the short-haystack path)
+        const MargOut mo{bitmap_m, tile_counts_m, reject_bits, tile_rejects};
+#define FZB_K1M(TW, ET) hipLaunchKernelGGL((k1_filter<TW, 2, ET, true>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, mo)
+        if (c.ends_u64) { if (w64) FZB_K1M(u64, u64); else FZB_K1M(u32, u64); }
+        else            { if (w64) FZB_K1M(u64, u32); else FZB_K1M(u32, u32); }
+#undef FZB_K1M
+        return;
+    }
+#define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, MargOut{})
     if (c.ends_u64) {
         if (mode == 1) { if (w64) FZB_K1(u64, 1, u64); else FZB_K1(u32, 1, u64); }
         else           { if (w64) FZB_K1(u64, 2, u64); else FZB_K1(u32, 2, u64); }
@@ -601,6 +632,37 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         else           { if (w64) FZB_K1(u64, 2, u32); else FZB_K1(u32, 2, u32); }
     }
 #undef FZB_K1
+}
+
+// Exclusive prefix of the per-tile reject counts (decide form of k2a_window) - only when something was rejected at all, which on
+// real lists is about one haystack in 1e5 of the marginal ones: one workgroup, and an immediate return otherwise.
+__global__ __launch_bounds__(1024) void k_scan_rejects(const u32* __restrict__ tile_rejects, u32 ntiles, const u32* __restrict__ reject_count, u32* __restrict__ rej_prefix) {
+    if (*reject_count == 0) return;
+    __shared__ u32 wsum[16];
+    __shared__ u32 carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u32 t0 = 0; t0 < ntiles; t0 += 1024) {
+        const u32 t = t0 + tid;
+        const u32 c = t < ntiles ? tile_rejects[t] : 0u;
+        u32 incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 wb = 0;
+        for (int w = 0; w < wave; w++) wb += wsum[w];
+        if (t < ntiles) rej_prefix[t] = carry + wb + incl - c;
+        __syncthreads();
+        if (tid == 1023) carry += wb + incl;
+        __syncthreads();
+    }
+}
+void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* reject_count, u32* rej_prefix, hipStream_t st) {
+    hipLaunchKernelGGL(k_scan_rejects, dim3(1), dim3(1024), 0, st, tile_rejects, ntiles, reject_count, rej_prefix);
 }
 
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st) {

@@ -447,10 +447,13 @@ __device__ Win prefilter_unicode_0(UnicodeSrc<PFL>& src) {
 // ------------------------------------------------------------------------------------------------
 enum { ALG_ASCII_1 = 0, ALG_ASCII_2 = 1, ALG_ASCII_N = 2, ALG_UNI_0 = 3, ALG_UNI_1 = 4, ALG_UNI_2 = 5, ALG_UNI_N = 6 };
 
-template <int PFL, int ALG>
+// DECIDE form (typo configurations on the short-haystack path): the listed haystacks are the filter's MARGINAL survivors; nothing is
+// written for the accepted ones (their window has a lane-free form that the scorer computes itself), a rejected one sets its bit in
+// `rej.bits`, bumps its tile's count and the total.
+template <int PFL, int ALG, bool DECIDE = false>
 __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
                                                   const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
-                                                  u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, int use_cache) {
+                                                  u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, int use_cache, RejectOut rej = RejectOut{}) {
     extern __shared__ __attribute__((aligned(16))) u64 mask_cache[];  // rows x 256 occurrence masks (ASCII algorithms, use_cache)
     __shared__ u32 s_cnt;
     const u32 M = *n_surv_ptr;
@@ -485,15 +488,26 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
                     else w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos);
                 }
                 keep = w.matched;
-                win[2 * j] = keep ? w.start : 0xFFFFFFFFu;
-                win[2 * j + 1] = w.end;
+                if (DECIDE) {
+                    if (!keep) {
+                        atomicOr((unsigned long long*)&rej.bits[li >> 6], 1ull << (li & 63));
+                        atomicAdd(&rej.tile_rejects[li / FZB_TILE], 1u);
+                        atomicAdd(rej.count, 1u);
+                    }
+                } else {
+                    win[2 * j] = keep ? w.start : 0xFFFFFFFFu;
+                    win[2 * j + 1] = w.end;
+                }
             }
-            const u64 b = __ballot(keep);
-            if (lane_id() == 0) {
-                bitmap2[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
-                cnt += __popcll(b);
+            if (!DECIDE) {
+                const u64 b = __ballot(keep);
+                if (lane_id() == 0) {
+                    bitmap2[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
+                    cnt += __popcll(b);
+                }
             }
         }
+        if (DECIDE) continue;
         if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
         __syncthreads();
         if (tid == 0) tile_counts2[tile] = s_cnt;
@@ -503,13 +517,21 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
 
 template <int PFL>
 static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, u32* win, u64* bitmap2,
-                              u32* tile_counts2, int grid, hipStream_t st) {
+                              u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide) {
     const int k = nd.max_typos;
     const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
     // occurrence-mask cache in LDS for the ASCII algorithms: rows x 2 KB per workgroup, up to 16 rows
     const int use_cache = !nd.unicode && nd.rows <= 16;
     const size_t lds = use_cache ? (size_t)nd.rows * 256 * 8 : 0;
-#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache)
+    if (decide) {  // ASCII typo algorithms only (the unicode path keeps the full form)
+#define FZB_K2A_D(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG, true>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, *decide)
+        if (alg == ALG_ASCII_1) FZB_K2A_D(ALG_ASCII_1);
+        else if (alg == ALG_ASCII_2) FZB_K2A_D(ALG_ASCII_2);
+        else FZB_K2A_D(ALG_ASCII_N);
+#undef FZB_K2A_D
+        return;
+    }
+#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{})
     switch (alg) {
         case ALG_ASCII_1: FZB_K2A(ALG_ASCII_1); break;
         case ALG_ASCII_2: FZB_K2A(ALG_ASCII_2); break;
@@ -523,8 +545,8 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 }
 
 void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
-                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st) {
-    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st);
-    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st);
-    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st);
+                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide) {
+    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
+    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
+    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
 }

@@ -1610,6 +1610,8 @@ struct Matcher {
             else if (pf_lanes == 16 && sw_lanes == 16) FZO_MK(16, 16, u8);
             else if (pf_lanes == 64 && sw_lanes == 32) FZO_MK(64, 32, u8);
             else if (pf_lanes == 64 && sw_lanes == 16) FZO_MK(64, 16, u8);
+            else if (pf_lanes == 16 && sw_lanes == 64) FZO_MK(16, 64, u8);  // no CPU backend pairs these; the GPU tests do, to reach the
+            else if (pf_lanes == 32 && sw_lanes == 64) FZO_MK(32, 64, u8);  // short-haystack scorer with a multi-chunk prefilter
             else throw std::runtime_error("unsupported (pf_lanes, sw_lanes) for u8 class");
         } else {
             if (pf_lanes == 64 && sw_lanes == 32) FZO_MK(64, 32, u16);

@@ -95,6 +95,21 @@ int kh_window(const u8* needle, int n, int case_sensitive, const u8* hay, int le
     return 0;
 }
 
+// the typo prefilter's window of an accepted haystack (<= 32 bytes) in the lane-free form the short kernel computes: out = {ws, we}
+int kh_window_typos(const u8* needle, int n, int case_sensitive, int max_typos, const u8* hay, int len, unsigned* out) {
+    if (n < 1 || n > FZB_MAX_ROWS || len < 0 || len > 32) return -1;
+    static const u16 sc[9] = {12, 6, 5, 1, 12, 4, 4, 8, 4};
+    NeedleDev nd;
+    fill_needle(nd, needle, n, case_sensitive, sc);
+    nd.max_typos = max_typos;
+    static u8 fl[256];
+    cf_build_typo_table(nd, fl);
+    u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    memcpy(w, hay, (size_t)len);
+    cf_window_typos_regs(fl, make_uint4(w[0], w[1], w[2], w[3]), make_uint4(w[4], w[5], w[6], w[7]), (u32)len, out[0], out[1]);
+    return 0;
+}
+
 // batch form for fuzzing: `count` windows packed back to back with byte lengths lens[i]; scores out
 int kh_dp_batch(const u8* needle, int n, int case_sensitive, const u16* scoring, const u8* hays, const int* lens, int count, const u8* include_prefix, int swl, int form,
                 int real, int* out) {

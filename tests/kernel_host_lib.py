@@ -36,6 +36,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.kh_dp_single.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
+        _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
 
@@ -50,6 +51,13 @@ def window(needle, hay, case_sensitive=False):
     out = (C.c_uint32 * 4)()
     assert lib().kh_window(needle, len(needle), int(case_sensitive), hay, len(hay), out) == 0
     return (out[0], out[1]), (out[2], out[3])
+
+
+def window_typos(needle, hay, max_typos, case_sensitive=False):
+    """(ws, we) of the short kernel's lane-free typo window for a haystack of at most 32 bytes"""
+    out = (C.c_uint32 * 2)()
+    assert lib().kh_window_typos(needle, len(needle), int(case_sensitive), max_typos, hay, len(hay), out) == 0
+    return out[0], out[1]
 
 
 def dp_batch(needle, hays, scoring, case_sensitive, include_prefix, swl, form, real):

@@ -89,3 +89,36 @@ def test_follows_the_reference_where_its_prefilter_deviates_from_the_lcs_criteri
         got = F.Matcher(needle, F.Config(max_typos=1, sort=F.SortStrategy.IndexAsc, casing=F.CaseMatching.Ignore, pf_lanes=pf)).match_list(hs)
         assert got.tolist() == want.tolist(), (needle, pf)
         assert (hs.index(hay) in want["index"].tolist()) == (pf != 32), (needle, pf)
+
+
+# Haystacks of at most 32 bytes on which the reference's chunked typo prefilter REJECTS at 16 lanes although the LCS criterion (and the
+# 64-lane backend) accepts - found by random search with the oracle (about 1 in 10^4 of such inputs).  A corpus this short takes the
+# typo fast path (LCS filter with the "nothing to spare" bit -> decide pass over the marginal survivors -> k2b_dp_short with the
+# lane-free window): the rejected survivors must disappear from the list and the records behind them move up.
+SHORT_LCS_DEVIATIONS = [
+    ("_C _B  AcA", "a 110C_Bc10_c1C 0c1_bB1Ab/c/ A", 2),
+    ("-BBaca_Ab", "--_-c/ / 0cCa/_/c-B/bC_baB1-_ -", 2),
+    ("_cAa0AA_0", "0Aca1Acc Aa_Cc B1AAa1a_a0A1_1", 1),
+    ("AAC_1_ b_", "0 _cAB1c0C-BbBC-0-a-1Ac1_ 0c01Ba", 2),
+    ("/Abc B1BbB", "b1 //bB01-b_A- _ C_c 01BB1 b1/", 2),
+    ("c1_CAbbAB", "bAa_b BB-Acc0C--1cbCcbb0aBA-_0_", 2),
+]
+
+
+@pytest.mark.parametrize("pf", [64, 16])
+def test_typo_fast_path_drops_the_survivors_the_exact_prefilter_rejects(pf):
+    import random
+
+    rng = random.Random(5)
+    for needle, hay, k in SHORT_LCS_DEVIATIONS:
+        assert O.prefilter(needle, hay, k, False, False, 16)[0] is False and O.prefilter(needle, hay, k, False, False, 64)[0] is True
+        # the deviating haystack several times between accepted and rejected ones, over more than one 1024-haystack tile
+        filler = ["".join(rng.choice("abcABC_-/ 01") for _ in range(rng.randint(0, 32))) for _ in range(3000)]
+        hs = filler[:700] + [hay] + filler[700:1500] + [hay, hay, needle, needle[:-1]] + filler[1500:] + [hay]
+        want = O.Matcher(needle, lanes=(pf, 64, 32), max_typos=k, sort="IndexAsc", casing="Ignore").match_list(hs)
+        m = F.Matcher(needle, F.Config(max_typos=k, sort=F.SortStrategy.IndexAsc, casing=F.CaseMatching.Ignore, pf_lanes=pf, sw_lanes=64))
+        got = m.match_list(hs)
+        assert got.tolist() == want.tolist(), (needle, pf, len(got), len(want))
+        assert (700 in want["index"].tolist()) == (pf != 16), (needle, pf)
+        c = m.last_counters()
+        assert c["kept_by_exact_prefilter"] == len(want) and c["filter_survivors"] >= len(want)

@@ -136,3 +136,31 @@ def test_short_kernel_window_search_equals_the_first_form():
             hay[0] = needle[0]
         a, b = K.window(needle, bytes(hay), cs)
         assert a == b, (needle, bytes(hay), cs, a, b)
+
+
+def test_short_kernel_typo_window_equals_the_reference_prefilter_window():
+    """cf_window_typos_regs (what k2b_dp_short computes for an accepted haystack under max_typos >= 1) against the oracle's chunked
+    multi-path prefilter (src/prefilter/algo/ascii_typos.rs) at all three lane widths, on every input the prefilter accepts."""
+    rng = random.Random(99)
+    checked = 0
+    for it in range(12000):
+        alpha = rng.choice([b"ab", b"abcA_", b"abcdefAB_- 01"])
+        n = rng.randint(2, 9)
+        needle = _rnd(rng, n, alpha)
+        k = rng.randint(1, 3)
+        if k >= n:
+            continue
+        L = rng.randint(1, 32)
+        hay = bytearray(_rnd(rng, L, alpha))
+        if rng.random() < 0.6 and L >= n:
+            for q, c in zip(sorted(rng.sample(range(L), n)), needle):
+                hay[q] = c
+        hay = bytes(hay)
+        cs = rng.random() < 0.4
+        got = K.window_typos(needle, hay, k, cs)
+        for lanes in (16, 32, 64):
+            ok, ws, we = O.prefilter(needle, hay, k, cs, False, lanes)
+            if ok:
+                assert got == (ws, we), (needle, hay, k, cs, lanes, got, (ws, we))
+                checked += 1
+    assert checked > 8000
