@@ -670,17 +670,28 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         const int need = nd.rows - nd.max_typos;
         const u32 ntiles = (cnt + FZB_TILE - 1) / FZB_TILE;
         const RejectOut rej{w.reject_bits, w.tile_rejects, w.rej_prefix, &cnt_c[6]};
+        // A haystack that fits ONE prefilter chunk is decided exactly by the LCS criterion: the reference's multi-path scan loses a
+        // candidate only when a lower path that found nothing more in the current chunk advances again in a later one, after the
+        // path above it has moved more than one needle byte ahead - inside a single chunk a path that cannot advance is stuck for
+        // good (tests/test_oracle_reference_properties.py::test_single_chunk_typo_prefilter_is_the_lcs_criterion;
+        // 1.3e8 random single-chunk cases without a deviation).  Then nothing is marginal and the decide pass is not launched.
+        const bool single_chunk = cd.max_len <= (u32)lc.pf_lanes;
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, w.bitmap_m,
-                          w.tile_counts_m, w.reject_bits, w.tile_rejects);
+        if (single_chunk)
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
+        else
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, w.bitmap_m,
+                              w.tile_counts_m, w.reject_bits, w.tile_rejects);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
-        FZB_STAGE("filter(marginal)");
+        FZB_STAGE("filter(lcs)");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
-        fzb_launch_compact1(w.bitmap_m, w.tile_counts_m, cnt, nullptr, nullptr, w.marg_list, &cnt_c[5], cus * 4, st);
-        FZB_STAGE("compact1 x2");
-        fzb_launch_window(cd, first, w.marg_list, &cnt_c[5], nd, lc.pf_lanes, nullptr, nullptr, nullptr, cnt_c, cus * 4, st, &rej);
-        FZB_STAGE("window(decide)");
-        fzb_launch_scan_rejects(w.tile_rejects, ntiles, &cnt_c[6], w.rej_prefix, st);
+        if (!single_chunk) {
+            fzb_launch_compact1(w.bitmap_m, w.tile_counts_m, cnt, nullptr, nullptr, w.marg_list, &cnt_c[5], cus * 4, st);
+            FZB_STAGE("compact1 x2");
+            fzb_launch_window(cd, first, w.marg_list, &cnt_c[5], nd, lc.pf_lanes, nullptr, nullptr, nullptr, cnt_c, cus * 4, st, &rej);
+            FZB_STAGE("window(decide)");
+            fzb_launch_scan_rejects(w.tile_rejects, ntiles, &cnt_c[6], w.rej_prefix, st);
+        }
         if (pev) HIPCHK(hipEventRecord(pev[4], st));
         fzb_launch_dp(cd, first, index_offset, w.surv_idx, nullptr, &cnt_c[0], nd, lc.sw_lanes, 2, 3, lc.pad_ok, (fzb_match_rec*)dev_out, cap32, dev_count, w.overflow, cnt, cnt_c, cus, st, &rej);
         FZB_STAGE("dp(short, typo windows)");

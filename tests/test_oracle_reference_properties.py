@@ -561,6 +561,31 @@ def test_the_typo_prefilter_only_ever_deviates_on_marginal_inputs():
     assert n_spare > 3000 and n_reject > 500
 
 
+def test_single_chunk_typo_prefilter_is_the_lcs_criterion():
+    # A haystack that fits one prefilter chunk (len <= lanes) is decided exactly by LCS + k >= n at that width: inside one chunk a
+    # path that finds nothing more is stuck for good, so the path above it never gets more than one needle byte ahead of a path that
+    # still produces candidates, and the catch-up comparison (ascii_typos.rs:45-62) sees every one of them.  The known deviations
+    # (LCS_DEVIATIONS_1_TYPO, tests/test_gpu_api_properties.py SHORT_LCS_DEVIATIONS) all span several chunks.  The product uses this to
+    # skip the decide pass when the corpus' longest haystack fits a chunk (host.hip, typo fast path); oracle/single_chunk_check.cpp ran
+    # 1.26e8 such cases (1.45e7 marginal) without a deviation, this is the same check at CI size, marginal inputs favoured.
+    rng = np.random.default_rng(707)
+    alpha = b"abcABC_-/ 01xyz"
+    marginal = 0
+    for _ in range(30000):
+        asz = int(rng.integers(2, len(alpha) + 1))
+        needle = bytes(alpha[int(x)] for x in rng.integers(0, asz, int(rng.integers(2, 13))))
+        cs, k = bool(rng.integers(0, 3) == 0), int(rng.integers(1, 5))
+        if k >= len(needle):
+            continue
+        for lanes in (16, 32, 64):
+            ln = int(rng.integers(1, lanes + 1)) if rng.integers(0, 3) else lanes - int(rng.integers(0, 3))
+            hay = bytes(alpha[int(x)] for x in rng.integers(0, asz, ln))
+            slack = lcs_len(needle, hay, byte_eq(cs)) + k - len(needle)
+            marginal += slack == 0
+            assert O.prefilter(needle, hay, k, cs, False, lanes)[0] == (slack >= 0), (needle, hay, k, cs, lanes, slack)
+    assert marginal > 5000
+
+
 def test_unicode_typo_windows_have_the_same_lane_free_form():
     # scalars instead of bytes: start = earliest first occurrence of needle scalars [0..=k] (either case variant), end = the latest end
     # of a last occurrence of the scalars [n-1-k..] (find_end_pos_with_unicode_typos, unicode_typos.rs:483-509)
