@@ -260,6 +260,14 @@ def main():
         m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=stream, index_offset=index_offset)
         torch.cuda.synchronize(dev)
         ex = ShardExchange(ShardExchange.plan(int(cnt[0].item()), device=dev), dev)
+        # (still set-up: RCCL builds its channels and rings lazily on the first few collectives of a communicator - several
+        # milliseconds each - so a handful of exchanges is run here, before the W warm-up steps of the contract)
+        for s_ in range(8):
+            ex.wait(s_ & 1)
+            m.match_list_device(corpus, ex.records_ptr(s_ & 1), ex.cap, ex.count_ptr(s_ & 1), stream=stream, index_offset=index_offset)
+            ex.post(s_ & 1)
+        ex.collect(0)
+        ex.collect(1)
     step_no = [0]
 
     def step():

@@ -18,6 +18,25 @@ def shard_range(n_total, rank, world):
     return lo, min(lo + per, n_total)
 
 
+def shard_ranges_by_bytes(ends, world):
+    """Byte-balanced contiguous shards of a ragged list (BASELINE config 4): `ends` = exclusive byte end of every haystack (uint64,
+    non-decreasing).  Shard g is the index range [cut[g], cut[g+1]) where cut[g] is the first haystack that starts at or after
+    g/world of the total bytes - contiguous and in list order like `shard_range`, so `index_offset = cut[g]` keeps indices global
+    (what match_list_parallel's workers do with their chunk starts, src/matcher/parallel.rs:55-63), but every GPU streams about the
+    same number of bytes.  Returns the list of (lo, hi)."""
+    ends = np.asarray(ends, dtype=np.uint64)
+    n = len(ends)
+    total = int(ends[-1]) if n else 0
+    cuts = [0]
+    for g in range(1, world):
+        # first haystack whose start offset (= previous end) is >= the byte target
+        target = (total * g) // world
+        cuts.append(int(np.searchsorted(ends, np.uint64(target), side="left")) if target else 0)
+    cuts.append(n)
+    cuts = [min(max(c, cuts[i - 1] if i else 0), n) for i, c in enumerate(cuts)]
+    return [(cuts[g], cuts[g + 1]) for g in range(world)]
+
+
 def all_gather_matches(records_u8, count, group=None):
     """records_u8: uint8 tensor holding >= count 8-byte records (device or CPU); count: python int or 0-dim/1-elem int tensor.
     Returns a list (one per rank) of numpy MATCH_DTYPE arrays.  Two collectives: counts, then records padded to the max count

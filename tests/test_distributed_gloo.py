@@ -66,6 +66,27 @@ def _worker(rank, world, port, q):
             else:
                 ok = ok and runs2 is None
             ex.collect(1)
+    # ---- BASELINE config 4 in miniature: a RAGGED list (8..128 bytes), byte-balanced shards of unequal counts, needle 'deadbeef' ----
+    from frizbee_amd.distributed import shard_ranges_by_bytes
+
+    n4 = 20_011
+    data4, ends4 = synth.ragged_corpus(b"deadbeef", n4)
+    data4 = np.concatenate([data4, np.zeros(64, np.uint8)])
+    ranges = shard_ranges_by_bytes(ends4, world)
+    lo, hi = ranges[rank]
+    b0 = int(ends4[lo - 1]) if lo else 0
+    ok = ok and ranges[0][0] == 0 and ranges[-1][1] == n4 and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+    ok = ok and ranges[0][1] - ranges[0][0] != ranges[1][1] - ranges[1][0]          # counts differ ...
+    ok = ok and abs(int(ends4[ranges[0][1] - 1]) - int(ends4[-1]) // 2) <= 128       # ... the bytes are balanced to within one haystack
+    for sort in ("ScoreThenIndexAsc", "IndexDesc"):
+        m = O.Matcher("deadbeef", max_typos=0, sort="IndexAsc")
+        local = m.match_packed(data4[b0:], ends4[lo:hi] - np.uint64(b0))
+        local["index"] += lo
+        rec = torch.from_numpy(local.view(np.uint8).copy()) if len(local) else torch.zeros(8, dtype=torch.uint8)
+        runs = all_gather_matches(rec, len(local))
+        merged = merge_shard_runs(runs, SortStrategy[sort])
+        want = O.Matcher("deadbeef", max_typos=0, sort=sort).match_packed(data4, ends4)
+        ok = ok and merged.tolist() == want.tolist() and len(want) > 500
     q.put((rank, ok))
     dist.destroy_process_group()
 
@@ -81,6 +102,20 @@ def test_two_rank_shard_gather_merge_equals_single_list():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, True), (1, True)], res
+
+
+def test_byte_balanced_shards_partition_a_ragged_list():
+    from frizbee_amd.distributed import shard_ranges_by_bytes
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 9, 1000, 100_003):
+        ends = np.cumsum(rng.integers(8, 129, n).astype(np.uint64), dtype=np.uint64)
+        for w in (1, 2, 3, 8):
+            r = shard_ranges_by_bytes(ends, w)
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r[:-1], r[1:])) and all(a <= b for a, b in r)
+            if n >= 1000:
+                sizes = [int(ends[b - 1]) - (int(ends[a - 1]) if a else 0) for a, b in r]
+                assert max(sizes) - min(sizes) <= 2 * 128, (n, w, sizes)
+    assert shard_ranges_by_bytes(np.zeros(0, np.uint64), 4) == [(0, 0)] * 4
 
 
 def test_shard_ranges_partition_the_list():
