@@ -57,6 +57,9 @@ bool decode_utf8(const u8* s, size_t n, std::vector<u32>& out) {
             if ((s[i + k] & 0xC0) != 0x80) return false;
             cp = (cp << 6) | (s[i + k] & 0x3F);
         }
+        // what a Rust &str can never hold: overlong forms, UTF-16 surrogates, scalars above U+10FFFF
+        static const u32 min_cp[5] = {0, 0, 0x80, 0x800, 0x10000};
+        if (cp < min_cp[len] || (cp >= 0xD800 && cp <= 0xDFFF) || cp > 0x10FFFF) return false;
         out.push_back(cp);
         i += len;
     }
@@ -375,7 +378,16 @@ int fzb_matcher_set_pattern(fzb_matcher* m, const uint8_t* needle_utf8, size_t n
 
 int fzb_matcher_set_config(fzb_matcher* m, const fzb_config* config) {
     if (!m || !config) return fail(FZB_ERR_INVALID, "null argument");
-    if (memcmp(&m->config, config, sizeof(fzb_config)) == 0) return FZB_OK;
+    {  // field by field: fzb_config has padding bytes a C caller need not have cleared
+        const fzb_config &a = m->config, &b = *config;
+        const bool same = a.max_typos == b.max_typos && a.casing == b.casing && a.unicode == b.unicode && a.sort == b.sort && a.pf_lanes == b.pf_lanes && a.sw_lanes == b.sw_lanes &&
+                          a.matching == b.matching && a.scoring.match_score == b.scoring.match_score && a.scoring.mismatch_penalty == b.scoring.mismatch_penalty &&
+                          a.scoring.gap_open_penalty == b.scoring.gap_open_penalty && a.scoring.gap_extend_penalty == b.scoring.gap_extend_penalty &&
+                          a.scoring.prefix_bonus == b.scoring.prefix_bonus && a.scoring.capitalization_bonus == b.scoring.capitalization_bonus &&
+                          a.scoring.matching_case_bonus == b.scoring.matching_case_bonus && a.scoring.exact_match_bonus == b.scoring.exact_match_bonus &&
+                          a.scoring.delimiter_bonus == b.scoring.delimiter_bonus;
+        if (same) return FZB_OK;
+    }
     const std::string needle = m->needle;
     return rebuild_matcher(m, config, (const uint8_t*)needle.data(), needle.size());
 }
@@ -564,6 +576,41 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     return FZB_OK;
 }
 
+// ---- buffers beyond the per-range workspace, each grown by ONE helper so that fzb_matcher_reserve can size all of them ahead of
+// the first query (a re-query after every keystroke must not meet a hipFree / hipMalloc) --------------------------------------
+static int ensure_dp_scratch(fzb_matcher* m, int mgrid) {  // parked rows of the multi-chunk scorer
+    Workspace& w = m->ws;
+    const size_t words = (size_t)(m->nd.rows + 1) * (size_t)(m->lc.sw_lanes / 2) * (size_t)mgrid * 128;
+    if (w.dp_scratch_words >= words) return FZB_OK;
+    if (w.dp_scratch) HIPCHK(hipFree(w.dp_scratch));
+    w.dp_scratch = nullptr;
+    w.dp_scratch_words = 0;
+    HIPCHK(dev_alloc((void**)&w.dp_scratch, words * 4));
+    w.dp_scratch_words = words;
+    return FZB_OK;
+}
+static int ensure_sort_buffers(fzb_matcher* m, size_t cap) {  // ping-pong buffer + tile histograms of the device radix sort
+    Workspace& w = m->ws;
+    if (w.sort_cap >= cap && w.sort_tmp) return FZB_OK;
+    if (w.sort_tmp) HIPCHK(hipFree(w.sort_tmp));
+    if (w.sort_hist) HIPCHK(hipFree(w.sort_hist));
+    w.sort_tmp = nullptr; w.sort_hist = nullptr; w.sort_cap = 0;
+    HIPCHK(dev_alloc((void**)&w.sort_tmp, (cap + 16) * sizeof(fzb_match_rec)));
+    HIPCHK(dev_alloc((void**)&w.sort_hist, (size_t)256 * (cap / 2048 + 2) * 4));
+    w.sort_cap = cap;
+    return FZB_OK;
+}
+static int ensure_out_staging(fzb_matcher* m, size_t count) {  // device-side result of the synchronous entry points
+    if (m->out_cap >= count && m->count_dev && m->out_dev) return FZB_OK;
+    if (m->out_dev) (void)hipFree(m->out_dev);
+    m->out_dev = nullptr;
+    m->out_cap = 0;
+    HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
+    m->out_cap = count;
+    if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
+    return FZB_OK;
+}
+
 // The pipeline.  items_in == nullptr: the haystacks are the contiguous range [first, first + count).  Otherwise they are the
 // listed ones, items_in[j] = index relative to `first`, *n_items_in of them (a device-side count <= count): the narrowing
 // step of the multi-pattern composition.
@@ -584,6 +631,12 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
     if (m->empty) return fail(FZB_ERR_INVALID, "empty needle: handled on the host by fzb_match_list / fzb_match_list_into");
     hipStream_t st = (hipStream_t)stream;
+    if (m->device >= 0) {  // the workspace lives on the device that was current at the first call
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        if (dev != m->device)
+            return fail(FZB_ERR_INVALID, "matcher is bound to device " + std::to_string(m->device) + " (its workspace lives there) but device " + std::to_string(dev) + " is current");
+    }
     if (m->device < 0) {
         int dev = 0;
         HIPCHK(hipGetDevice(&dev));
@@ -621,7 +674,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
         u32* cnt_c = w.counters;
         if (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode && !items_in)  // the streaming DFA filter over the needle's KMP automaton
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr, nullptr, nullptr, lc.pad_ok);
         else
             fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
         FZB_STAGE("literal filter");
@@ -701,7 +754,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
+        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
+                          nullptr, nullptr, lc.pad_ok);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
         static const int c1mul = getenv("FZB_COMPACT_GRID_MUL") ? atoi(getenv("FZB_COMPACT_GRID_MUL")) : 4;  // tuning knob (workgroups per CU)
@@ -753,14 +807,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("dp");
         if (!no_wide) {
             const int mgrid = cus * 4;  // 2 waves per SIMD (the kernel is capped at 256 VGPRs)
-            const size_t words = (size_t)(nd.rows + 1) * (size_t)(lc.sw_lanes / 2) * (size_t)mgrid * 128;
-            if (w.dp_scratch_words < words) {  // first use only
-                if (w.dp_scratch) HIPCHK(hipFree(w.dp_scratch));
-                w.dp_scratch = nullptr;
-                w.dp_scratch_words = 0;
-                HIPCHK(dev_alloc((void**)&w.dp_scratch, words * 4));
-                w.dp_scratch_words = words;
-            }
+            if ((rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
             fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, lc.bias_ok, outp, cap32, w.dp_scratch, mgrid, st);
             FZB_STAGE("dp_multi");
             if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
@@ -773,6 +820,31 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
 #undef FZB_STAGE
     if (pev) HIPCHK(hipEventRecord(pev[1], st));
     HIPCHK(hipGetLastError());
+    return FZB_OK;
+}
+
+// Sizes every device buffer a query over `c` can need (range workspace incl. the typo-path arrays, multi-chunk scorer scratch when
+// the corpus has haystacks wider than a chunk, staging + sort buffers of the synchronous / sorted entry points), so that the queries
+// that follow - also after fzb_matcher_set_pattern / fzb_matcher_set_config, which keep the workspace - never allocate.
+// (Matched-indices queries size their trace scratch from the selection, on first use.)
+int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
+    if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
+    if (m->empty || c->dev.n == 0) return FZB_OK;
+    if (m->device < 0) {
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, dev));
+        m->device = dev;
+        m->lc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const size_t n = c->dev.n;
+    int rc = ensure_workspace(m, n);
+    if (rc) return rc;
+    const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
+    if (!m->literal_mode && !m->nd.unicode && !no_wide && (rc = ensure_dp_scratch(m, m->lc.num_cus * 4))) return rc;
+    if ((rc = ensure_out_staging(m, n))) return rc;
+    if ((rc = ensure_sort_buffers(m, n))) return rc;
     return FZB_OK;
 }
 
@@ -791,14 +863,7 @@ int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match*
     if ((!reversed && !by_score) || c->dev.n == 0) return FZB_OK;
     Workspace& w = m->ws;
     const size_t cap = std::min<size_t>(capacity, c->dev.n);
-    if (by_score && w.sort_cap < cap) {
-        if (w.sort_tmp) HIPCHK(hipFree(w.sort_tmp));
-        if (w.sort_hist) HIPCHK(hipFree(w.sort_hist));
-        w.sort_tmp = nullptr; w.sort_hist = nullptr; w.sort_cap = 0;
-        HIPCHK(dev_alloc((void**)&w.sort_tmp, (cap + 16) * sizeof(fzb_match_rec)));
-        HIPCHK(dev_alloc((void**)&w.sort_hist, (size_t)256 * (cap / 2048 + 2) * 4));
-        w.sort_cap = cap;
-    }
+    if (by_score && (rc = ensure_sort_buffers(m, cap))) return rc;
     fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream);
     HIPCHK(hipGetLastError());
     return FZB_OK;
@@ -877,19 +942,13 @@ int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     *out_len = 0;
     if (m->empty) {  // src/matcher/mod.rs:381-384
         fzb_match* r = (fzb_match*)malloc(std::max<size_t>(count, 1) * sizeof(fzb_match));
+        if (!r) return fail(FZB_ERR_INVALID, "out of memory");
         for (size_t i = 0; i < count; i++) r[i] = fzb_match{(uint32_t)(index_offset + i), 0, 0, 0};
         *out = r;
         *out_len = count;
         return FZB_OK;
     }
-    if (m->out_cap < count || !m->count_dev) {
-        if (m->out_dev) (void)hipFree(m->out_dev);
-        m->out_dev = nullptr;
-        m->out_cap = 0;
-        HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
-        m->out_cap = count;
-        if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
-    }
+    if (int rc_ = ensure_out_staging(m, count)) return rc_;
     int rc = fzb_match_list_device(m, c, first, count, index_offset, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
     return fetch_records(m->out_dev, m->count_dev, out, out_len);
@@ -924,14 +983,7 @@ int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t*
     const size_t count = c->dev.n;
     *out = nullptr;
     *out_len = 0;
-    if (m->out_cap < count || !m->count_dev) {
-        if (m->out_dev) (void)hipFree(m->out_dev);
-        m->out_dev = nullptr;
-        m->out_cap = 0;
-        HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
-        m->out_cap = count;
-        if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
-    }
+    if (int rc_ = ensure_out_staging(m, count)) return rc_;
     // scoring AND the reverse / stable radix sort post-step run on the device; the host only receives the final list
     int rc = fzb_match_list_sorted_device(m, c, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
@@ -980,14 +1032,7 @@ int indices_in_list_order(fzb_matcher* m, const fzb_corpus* c, const uint32_t* s
         m->trace_cap = count;
         m->trace_pos_words = count * (size_t)stride;
     }
-    if (m->out_cap < count || !m->count_dev) {
-        if (m->out_dev) (void)hipFree(m->out_dev);
-        m->out_dev = nullptr;
-        m->out_cap = 0;
-        HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
-        m->out_cap = count;
-        if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
-    }
+    if (int rc_ = ensure_out_staging(m, count)) return rc_;
     const u32* items_dev = nullptr;
     const u32* n_items_dev = nullptr;
     if (selection) {
@@ -1145,8 +1190,14 @@ int fzb_parse_query(const uint8_t* query_utf8, size_t query_len, fzb_pattern** o
     }
     if (in_atom) flush();
     fzb_pattern* arr = (fzb_pattern*)calloc(std::max<size_t>(atoms.size(), 1), sizeof(fzb_pattern));
+    if (!arr) return fail(FZB_ERR_INVALID, "out of memory");
     for (size_t i = 0; i < atoms.size(); i++) {
         u8* n = (u8*)malloc(atoms[i].needle.size() + 1);
+        if (!n) {
+            for (size_t k = 0; k < i; k++) free((void*)arr[k].needle_utf8);
+            free(arr);
+            return fail(FZB_ERR_INVALID, "out of memory");
+        }
         memcpy(n, atoms[i].needle.data(), atoms[i].needle.size());
         n[atoms[i].needle.size()] = 0;
         arr[i].needle_utf8 = n;
@@ -1464,6 +1515,11 @@ static bool merge_less(int order, const fzb_match& l, const fzb_match& r) {  // 
 
 int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_lens, size_t nruns, fzb_match* out) {
     if (sort < 0 || sort > 3 || (nruns && (!run_lens))) return fail(FZB_ERR_INVALID, "bad argument");
+    {
+        size_t total = 0;
+        for (size_t k = 0; k < nruns; k++) total += run_lens[k];
+        if (total && (!runs || !out)) return fail(FZB_ERR_INVALID, "null argument");
+    }
     // tournament over run heads (any correct k-way merge of runs sorted under a TOTAL order yields the same sequence)
     std::vector<size_t> start(nruns), pos(nruns, 0);
     size_t off = 0;

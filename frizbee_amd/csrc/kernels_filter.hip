@@ -594,7 +594,7 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // host-side launch wrappers (called from host.hip)
 // ---------------------------------------------------------------------------------------------------
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
-                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects) {
+                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe) {
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
@@ -606,7 +606,10 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);
         } else {
             // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
-            // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times)
+            // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times).
+            // Tried in round 2 and dropped: sorting a tile's haystacks by length class in LDS before the DFA (no SIMT length
+            // divergence, no sanitising of the zero fill) - 460-490 us instead of 298: a wave's 64 lanes then touch 64 scattered
+            // 128-byte lines instead of ~34 adjacent ones, and the kernel is bound by cache transactions, not by instruction issue.
             int rgrid = std::min<int>((grid / 8) * 6, (int)ntiles);
             if (rgrid < 1) rgrid = 1;
             if (c.ends_u64) hipLaunchKernelGGL((k1_dfa_ragged<u64, 1>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);

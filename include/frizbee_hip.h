@@ -120,9 +120,20 @@ int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t*
  * This is the seam `MatcherBackend::Hip` implements and what `match_list_parallel`'s per-shard workers call. */
 int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match** out, size_t* out_len);
 
+/* Allocates, once, every device buffer the queries of this matcher over corpus `c` can need (the matcher keeps them across
+ * fzb_matcher_set_pattern / fzb_matcher_set_config): after it no query allocates - the keystroke-latency use (SURVEY 8f rank 2,
+ * callers `Matcher::set_pattern`, src/matcher/mod.rs:154-176).  Optional: without it the buffers grow on first use. */
+int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c);
+
 /* Device-resident form of the above for callers that keep results in HBM (benchmarks, multi-GPU gather):
  * writes the index-ordered records to dev_out (capacity records) and the record count to dev_count
- * (one uint32 in device memory), asynchronously on `stream`.  No host synchronisation. */
+ * (one uint32 in device memory), asynchronously on `stream`.  No host synchronisation.
+ * CAPACITY: nothing on the host knows the number of matches when the call returns, so a buffer that is too small cannot be refused:
+ * *dev_count = min(matches, capacity) and the records at positions >= capacity are NOT written (for the sorted form the sort then
+ * orders that truncated prefix - its head is not the head of the full list).  capacity >= count (one record per haystack of the
+ * range) can never truncate.  After synchronising the stream, fzb_last_counters() reports the untruncated totals: compare
+ * out[1] (or out[0] for a 0-typo / no-prefilter matcher) with the capacity to detect a truncation; frizbee_amd.distributed.ShardExchange
+ * does exactly that (`cnt >= cap` raises).  FZB_ERR_CAPACITY is returned where the host does know: an empty pattern list. */
 int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset,
                           fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);
 

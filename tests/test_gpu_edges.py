@@ -124,3 +124,20 @@ def test_corpus_beyond_4_gib_uses_64_bit_offsets():
         sl = whole[(whole["index"] >= first) & (whole["index"] < first + cnt)].copy()
         sl["index"] -= first
         assert sl.tolist() == want.tolist(), first
+
+
+@pytest.mark.gpu
+def test_reserve_then_requery_does_not_change_results():
+    """fzb_matcher_reserve sizes the workspace, scorer scratch, staging and sort buffers for a corpus; queries after it (and after
+    set_pattern, which keeps them) give what a fresh matcher gives."""
+    import random
+    rng = random.Random(8)
+    hs = ["".join(rng.choice("abcdeDEAB_-/ 01") for _ in range(rng.randint(0, 90))) for _ in range(5000)] + ["dead_beef" * 20, "deadbe"]
+    corpus = F.Corpus(hs)
+    m = F.Matcher("deadbe", F.Config(max_typos=1, pf_lanes=64, sw_lanes=64))
+    m.reserve(corpus)
+    for needle in ("deadbe", "abc", "dead_beefdead", "e"):
+        m.set_pattern(needle)
+        got = m.match_list(corpus)
+        want = F.Matcher(needle, F.Config(max_typos=1, pf_lanes=64, sw_lanes=64)).match_list(corpus)
+        assert got.tolist() == want.tolist(), needle

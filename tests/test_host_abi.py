@@ -165,3 +165,18 @@ def test_matcher_new_differential_on_random_scorings():
             assert (got["pf_lanes"], got["sw_lanes"], got["use_u8"]) == (want["pf_lanes"], want["sw_lanes"], want["use_u8"]), (needle, sc)
             ok += 1
     assert agree_panics > 20 and ok > 300
+
+
+def test_needles_a_rust_str_cannot_hold_are_refused():
+    # overlong encodings, UTF-16 surrogates, scalars above U+10FFFF, truncated sequences: `&str` is always valid UTF-8
+    for bad in (b"\xc0\xaf", b"\xe0\x80\xaf", b"\xf0\x80\x80\xaf", b"\xed\xa0\x80", b"\xed\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf8\x88\x80\x80\x80", b"a\xc3", b"\x80"):
+        with pytest.raises(Exception, match="not valid UTF-8"):
+            F.Matcher(bad)
+    for good in ("\u00e9", "\ud7ff", "\ue000", "\U0010ffff", "\u07ff\u0800"):
+        F.Matcher(good)
+
+
+def test_k_merge_rejects_null_buffers():
+    import ctypes as C
+    lens = (C.c_size_t * 1)(3)
+    assert F.lib().fzb_k_merge_matches(0, None, lens, 1, None) != 0
