@@ -84,6 +84,9 @@ struct Workspace {
     u32* tile_rejects;
     u32* rej_prefix;
     size_t cap_marg;    // capacity (in haystacks) of the six arrays above (0 = not allocated)
+    u32* cls_win;       // classified scoring (corpora with longer haystacks): window per survivor, three class lists
+    u32* cls_lists;     //   [3][cap]; class counts in counters[8..10]
+    size_t cap_cls;
     u64* table;         // 256 x u64 filter table (device)
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
@@ -135,6 +138,9 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
                    int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st,
                    const RejectOut* rejects = nullptr);
 bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
+void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
+                           int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
+                           int num_cus, hipStream_t st);
 void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_unicode.hip

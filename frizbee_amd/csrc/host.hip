@@ -211,7 +211,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -535,7 +535,8 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     Workspace& w = m->ws;
     const bool need_l2 = !m->lc.filter_exact;
     const bool need_marg = typo_fast_path_configured(m);
-    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && (!need_marg || w.cap_marg >= count) && w.counters) {
+    const bool need_cls = !m->literal_mode && !m->empty && !m->nd.unicode && m->lc.cf_ok;  // classified scoring (fzb_launch_dp_classes)
+    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && (!need_marg || w.cap_marg >= count) && (!need_cls || w.cap_cls >= count) && w.counters) {
         if (w.tables_stale) {  // fzb_matcher_set_pattern / set_config kept the device buffers: only the two small tables change
             HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
             if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
@@ -572,6 +573,11 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
         HIPCHK(dev_alloc((void**)&w.tile_rejects, ntiles * 4));
         HIPCHK(dev_alloc((void**)&w.rej_prefix, ntiles * 4));
         w.cap_marg = cap;
+    }
+    if (need_cls) {
+        HIPCHK(dev_alloc((void**)&w.cls_win, cap * 8));
+        HIPCHK(dev_alloc((void**)&w.cls_lists, cap * 12));
+        w.cap_cls = cap;
     }
     return FZB_OK;
 }
@@ -803,7 +809,12 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, cnt_c, cus * 4, st);
         FZB_STAGE("generic(unicode)");
     } else {
-        fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
+        static const bool no_classes = getenv("FZB_NO_DP_CLASSES") != nullptr;  // comparison knob: the per-wave choice of k2b_dp instead
+        if (lc.cf_ok && !no_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2))
+            fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
+                                  (u32)w.cap_cls, cus, st);
+        else
+            fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
         if (!no_wide) {
             const int mgrid = cus * 4;  // 2 waves per SIMD (the kernel is capped at 256 VGPRs)

@@ -15,6 +15,7 @@
 // plain shift; since every row value is >= 0 the saturating subtract of the reference is preserved exactly
 // (see DESIGN.md).  BIAS=false keeps the literal 3-op form for scorings where the bias could overflow u16.
 #include "dp_cf.h"
+#include <cstdlib>
 
 // MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h), 2: biased domain throughout + closed-form
 // padding (dp_cf.h; LaunchCfg::cf_ok)
@@ -272,6 +273,184 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Corpora with longer haystacks (dp_cf.h form, LaunchCfg::cf_ok): windows are found and CLASSIFIED first, then every class is scored
+// by its own launch, so that a wave never mixes window widths (k2b_dp decides per wave: on a ragged list nearly every wave holds one
+// window of the widest class and runs all 64 lanes at 2 waves per SIMD).
+//   k2w_classify: one thread per survivor - window (0 typos: first / last occurrence; typos / unicode: from the prefilter kernel;
+//                 no prefilter: the whole haystack), trimmed length m, class:
+//                   0: m <= SWL/2   1: m <= 3 SWL/4   2: m <= SWL   (single chunk, SWL/2 | 3SWL/4 | SWL computed lanes)
+//                   multi-chunk (<= 1024 bytes) and greedy (> 1024) go to the `overflow` queue exactly as k2b_dp queues them.
+//                 A workgroup appends its members of a class with ONE global atomic per class (order inside a class is free:
+//                 every entry carries its output position).
+//   k2b_dp_class: persistent thread-per-survivor scorer of one class: window bytes from memory (requested one item ahead), bonuses
+//                 from the LDS tables, dp_cf.h rows with the class's number of computed lanes; registers - and therefore waves per
+//                 SIMD (4 / 3 / 2) - follow the class.
+// ---------------------------------------------------------------------------------------------------------------
+template <typename ET, int PER>
+__global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ items,
+                                                    const u32* __restrict__ win_in, const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, u32 swl,
+                                                    u32* __restrict__ win_out, u32* __restrict__ lists, u32 list_stride, u32* __restrict__ overflow, u32 qcap,
+                                                    u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count) {
+    __shared__ u32 s_cnt[5], s_base[5];
+    const u32 M = __builtin_amdgcn_readfirstlane(*n_items_ptr);
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
+    // a workgroup takes 256 * PER survivors at a time (PER per thread) and appends its members of a class with ONE global atomic per class
+    // and tile: atomics that return a value to the same address serialise in L2 (one per 256 survivors cost ~40 us on the 0.6 M
+    // survivors of the ragged list)
+    for (u32 j0 = blockIdx.x * (256 * PER); j0 < M; j0 += gridDim.x * (256 * PER)) {  // uniform trip count per workgroup
+        if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        u32 cls[PER], rank[PER], li[PER], ws[PER], we[PER];
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const u32 j = j0 + p * 256 + threadIdx.x;
+            cls[p] = 5; rank[p] = 0; li[p] = 0; ws[p] = 0; we[p] = 0;
+            if (j < M && j < capacity) {
+                li[p] = items ? items[j] : j;
+                u64 s;
+                u32 L;
+                haystack_span(ends, first + li[p], s, L);
+                if (wmode == 0) { ws[p] = win_in[2 * j]; we[p] = win_in[2 * j + 1]; }
+                else if (wmode == 2) { ws[p] = 0; we[p] = L; }
+                else window_first_last(nd, bytes + s, L, ws[p], we[p]);
+                const u32 sp = ws[p] ? ws[p] - 1 : 0;
+                const u32 m = we[p] - sp;
+                cls[p] = m <= swl / 2 ? 0u : m <= 3 * swl / 4 ? 1u : m <= swl ? 2u : m <= FZB_MAX_HAYSTACK_LEN ? 3u : 4u;
+                rank[p] = atomicAdd(&s_cnt[cls[p]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 5 && s_cnt[threadIdx.x]) {
+            const u32 c = threadIdx.x;
+            s_base[c] = atomicAdd(c < 3 ? &counters[8 + c] : c == 3 ? &counters[3] : &counters[4], s_cnt[c]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PER; p++) {
+            const u32 j = j0 + p * 256 + threadIdx.x;
+            if (cls[p] < 3) {
+                lists[(size_t)cls[p] * list_stride + s_base[cls[p]] + rank[p]] = j;
+                *(uint2*)(win_out + 2 * (size_t)j) = make_uint2(ws[p], we[p]);
+            } else if (cls[p] < 5) {
+                const u32 slot = s_base[cls[p]] + rank[p];
+                u32* qe = cls[p] == 4 ? overflow + 4 * (size_t)(qcap - 1 - slot) : overflow + 4 * (size_t)slot;
+                qe[0] = j;  // (output position, window start, window end, local haystack index)
+                qe[1] = ws[p];
+                qe[2] = we[p];
+                qe[3] = li[p];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int SWL, bool UPPER, int REAL, typename ET>
+__global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3 : 2)) void k2b_dp_class(
+    const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win,
+    const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out) {
+    constexpr int NB = SWL / 4;           // window dwords of a full chunk
+    constexpr int NBR = (REAL + 1) / 2;   // dwords that can hold window bytes of this class
+    __shared__ CfTables tab;
+    cf_build_tables<UPPER>(nd, tab);
+    __syncthreads();
+    const u32 M = __builtin_amdgcn_readfirstlane(*n_list_ptr);
+    const u32 stride = gridDim.x * blockDim.x;
+    const u32 q0 = blockIdx.x * blockDim.x + threadIdx.x;
+    // two-deep pipeline: (list entry -> haystack index, window, span) one item ahead of (window bytes), which are one item ahead of the DP
+    auto load_meta = [&](u32 q, u32& j, u32& li, u32& sp, u32& m, u32& L, u64& s) {
+        j = 0; li = 0; sp = 0; m = 0; L = 0; s = 0;
+        if (q < M) {
+            j = list[q];
+            li = items ? items[j] : j;
+            const uint2 w = *(const uint2*)(win + 2 * (size_t)j);
+            haystack_span(ends, first + li, s, L);
+            sp = w.x ? w.x - 1 : 0;
+            m = w.y - sp;
+            L = (sp == 0 && w.y == L) ? 1u : 0u;  // include_exact
+        }
+    };
+    auto load_bytes = [&](u64 s, u32 sp, u32 m, u32 (&hb)[NBR]) {
+        const u8* th = bytes + s + sp;
+#pragma unroll
+        for (int k = 0; k < NBR; k++) {
+            const u32 p = 4 * k;
+            u32 v = 0;
+            if (p < m) {
+                v = load_u32_unaligned(th, p);
+                const u32 rem = m - p;
+                if (rem < 4) v &= (1u << (8 * rem)) - 1;
+            }
+            hb[k] = v;
+        }
+    };
+    u32 j_c, li_c, sp_c, m_c, ex_c, j_n, li_n, sp_n, m_n, ex_n;
+    u64 s_c, s_n;
+    u32 hb_c[NBR];
+    load_meta(q0, j_c, li_c, sp_c, m_c, ex_c, s_c);
+    load_meta(q0 + stride, j_n, li_n, sp_n, m_n, ex_n, s_n);
+    load_bytes(s_c, sp_c, m_c, hb_c);
+    const u32 qw = __builtin_amdgcn_readfirstlane(q0);
+    const u32 n_iter = __builtin_amdgcn_readfirstlane(qw < M ? (M - qw + stride - 1) / stride : 1u);
+    struct MidItem {
+        FzbProgressPrio* p;
+        __device__ __forceinline__ void operator()() const { p->k2 += 1; p->apply(); }
+    };
+    FzbProgressPrio prio{0u, 2 * n_iter};
+    for (u32 q = q0; q < M; q += stride) {
+        prio.apply();
+        u32 hb_n[NBR];
+        load_bytes(s_n, sp_n, m_n, hb_n);
+        u32 j_f, li_f, sp_f, m_f, ex_f;
+        u64 s_f;
+        load_meta(q + 2 * stride, j_f, li_f, sp_f, m_f, ex_f, s_f);
+        {
+            u32 hb[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) hb[k] = k < NBR ? hb_c[k < NBR ? k : 0] : 0u;
+            u32 score = 0;
+            if (m_c > 0) score = dp_single_chunk_cf_tab<SWL, UPPER, REAL, MidItem>(nd, sp_c == 0, tab, hb, MidItem{&prio});
+            const bool exact = exact_match<NB>(nd, ex_c != 0, m_c, hb);
+            if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+            fzb_match_rec rec;
+            rec.index = index_offset + li_c;
+            rec.score = (u16)score;
+            rec.exact = exact ? 1 : 0;
+            rec.valid = 0;
+            out[j_c] = rec;
+        }
+        j_c = j_n; li_c = li_n; sp_c = sp_n; m_c = m_n; ex_c = ex_n; s_c = s_n;
+#pragma unroll
+        for (int k = 0; k < NBR; k++) hb_c[k] = hb_n[k];
+        j_n = j_f; li_n = li_f; sp_n = sp_f; m_n = m_f; ex_n = ex_f; s_n = s_f;
+        prio.k2 = (prio.k2 | 1u) + 1;  // next item
+    }
+}
+
+void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
+                           int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
+                           int num_cus, hipStream_t st) {
+    bool upper = false;
+    for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+    if (c.ends_u64) hipLaunchKernelGGL((k2w_classify<u64, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count);
+    else hipLaunchKernelGGL((k2w_classify<u32, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count);
+#define FZB_K2C(SWL, U, REAL, CLS, ET)                                                                                                    \
+    do {                                                                                                                                  \
+        static int per_cu = 0;                                                                                                            \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_class<SWL, U, REAL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
+        hipLaunchKernelGGL((k2b_dp_class<SWL, U, REAL, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win_out, lists + (size_t)CLS * list_stride, &counters[8 + CLS], nd, out); \
+    } while (0)
+#define FZB_K2C_ALL(SWL, U, ET) do { FZB_K2C(SWL, U, SWL / 4, 0, ET); FZB_K2C(SWL, U, 3 * SWL / 8, 1, ET); FZB_K2C(SWL, U, SWL / 2, 2, ET); } while (0)
+#define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C_ALL(SWL, U, u64); else FZB_K2C_ALL(SWL, U, u32); } while (0)
+#define FZB_K2C_U(SWL) do { if (upper) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2C_U(64); break;
+        case 32: FZB_K2C_U(32); break;
+        case 16: FZB_K2C_U(16); break;
+        default: FZB_K2C_U(8); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // k2d: the queued windows of SWL < m <= 1024 bytes, one thread each, chunk by chunk (dp_multi_chunk).
 // ---------------------------------------------------------------------------------------------------------------
 template <int SWL, bool BIAS, typename ET>
@@ -337,6 +516,7 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
     do {                                                                                                                                \
         static int per_cu = 0;                                                                                                          \
         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
+        if (const char* e_ = getenv("FZB_DP_WGS_PER_CU")) { const int v_ = atoi(e_); if (v_ >= 1 && v_ < per_cu) per_cu = v_; } /* tuning knob: leave room for a co-resident kernel */ \
         hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out); \
     } while (0)
 #define FZB_K2S_ET(SWL, U) do { if (c.ends_u64) FZB_K2S(SWL, U, u64); else FZB_K2S(SWL, U, u32); } while (0)
