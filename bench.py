@@ -210,10 +210,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4-shard / C5 block")
     ap.add_argument("--no-check", action="store_true", help="skip the 1M-item oracle comparison")
-    ap.add_argument("--fast", action="store_true", help="= --no-cpu-baseline --no-configs --no-check (profiling runs)")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-streams throughput figure")
+    ap.add_argument("--fast", action="store_true", help="= --no-cpu-baseline --no-configs --no-check --no-two-in-flight (profiling runs)")
     args = ap.parse_args()
     if args.fast:
-        args.no_cpu_baseline = args.no_configs = args.no_check = True
+        args.no_cpu_baseline = args.no_configs = args.no_check = args.no_two_in_flight = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -397,28 +398,29 @@ def main():
                 ts.append(time.perf_counter() - t0)
             res["e2e"] = {"match_list_ms_median": _median(ts) * 1e3, "match_list_ms_min": min(ts) * 1e3, "records": int(len(r)), "haystacks_per_s": n / _median(ts),
                           "what": "fzb_match_list = Matcher::match_list (src/matcher/mod.rs:212-222): pipeline + device reverse/radix sort + D2H of the ordered records, corpus resident"}
-            # two independent queries in flight on two streams (two matchers = two workspaces): the HBM-bound filter of one overlaps the
-            # issue-bound scorer of the other.  Reported beside `value`, never as it: bench steps are sequential single queries.
-            m3 = F.Matcher(NEEDLE.decode(), cfg)
-            out3 = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev)
-            cnt3 = torch.zeros(4, dtype=torch.int32, device=dev)
-            sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-            pairs = max(10, args.steps // 2)
+            if not args.no_two_in_flight:
+                # two independent queries in flight on two streams (two matchers = two workspaces): the HBM-bound filter of one overlaps the
+                # issue-bound scorer of the other.  Reported beside `value`, never as it: bench steps are sequential single queries.
+                m3 = F.Matcher(NEEDLE.decode(), cfg)
+                out3 = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev)
+                cnt3 = torch.zeros(4, dtype=torch.int32, device=dev)
+                sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+                pairs = max(10, args.steps // 2)
 
-            def pair_loop(k):
-                for _ in range(k):
-                    m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=sa.cuda_stream)
-                    m3.match_list_device(corpus, out3.data_ptr(), n, cnt3.data_ptr(), stream=sb.cuda_stream)
+                def pair_loop(k):
+                    for _ in range(k):
+                        m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=sa.cuda_stream)
+                        m3.match_list_device(corpus, out3.data_ptr(), n, cnt3.data_ptr(), stream=sb.cuda_stream)
 
-            pair_loop(3)
-            torch.cuda.synchronize(dev)
-            t0 = time.perf_counter()
-            pair_loop(pairs)
-            torch.cuda.synchronize(dev)
-            tp = (time.perf_counter() - t0) / (2 * pairs)
-            res["two_queries_in_flight"] = {"ms_per_query": tp * 1e3, "haystacks_per_s": n / tp, "queries": 2 * pairs,
-                                            "what": "the same query issued alternately on two HIP streams through two matchers; throughput of independent queries, not the latency of one"}
-            del m3, out3, cnt3
+                pair_loop(3)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                pair_loop(pairs)
+                torch.cuda.synchronize(dev)
+                tp = (time.perf_counter() - t0) / (2 * pairs)
+                res["two_queries_in_flight"] = {"ms_per_query": tp * 1e3, "haystacks_per_s": n / tp, "queries": 2 * pairs,
+                                                "what": "the same query issued alternately on two HIP streams through two matchers; throughput of independent queries, not the latency of one"}
+                del m3, out3, cnt3
             if not args.no_check:
                 res["check"] = oracle_check(F, m2, corpus, rows, min(n, 1_000_000), args.max_typos, dev)
             del m2
