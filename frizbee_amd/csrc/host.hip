@@ -875,7 +875,9 @@ int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match*
     Workspace& w = m->ws;
     const size_t cap = std::min<size_t>(capacity, c->dev.n);
     if (by_score && (rc = ensure_sort_buffers(m, cap))) return rc;
-    fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream);
+    // one radix pass is enough when no score can reach 256 (Scoring::guard's bound on the matrix + the exact-match bonus added after it)
+    const bool one_pass = !m->literal_mode && max_matrix_score(m->config.scoring, (size_t)m->rows) + (size_t)m->config.scoring.exact_match_bonus < 256;
+    fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream, one_pass ? 1 : 2);
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }
