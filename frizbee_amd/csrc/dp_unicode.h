@@ -154,6 +154,15 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
                 upm[d] = mmk;  // ... and from here on this row's (read again only by the next row)
             }
         }
+        // the LAST needle row is not propagated: every value the gap scan produces is an earlier lane's value minus a non-negative
+        // cost (continuation bytes are free transport lanes, never a gain), and only the row's maximum is read (unicode.rs: the
+        // horizontal max of the last row) - so that maximum is the maximum before the scan
+        if (r + 1 == rows) {
+            u32 mxl = row[0];
+#pragma unroll
+            for (int d = 1; d < 2 * RB; d++) mxl = p_max(mxl, row[d]);
+            return max(mxl & 0xFFFF, mxl >> 16);
+        }
         // ---- propagate_horizontal_unicode_gaps in the biased domain ----
 #pragma unroll
         for (int d = 0; d < NW; d++) row[d] = p_add(row[d], Pof(d));
