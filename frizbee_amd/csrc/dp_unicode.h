@@ -27,6 +27,33 @@ __device__ __forceinline__ u32 zflag4(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7
 // Q stays at its final value and a hop from padding to padding crosses no scalar start (no gap-open charge, pending irrelevant).
 // They still receive row values through the gap scan and enter the final max, so they are computed - but only the score row,
 // which is what REAL < NW saves in registers (no Q / bonus / pending / up-mask entries for them) and instructions.
+// 0-typo unicode window of an ACCEPTED haystack (src/prefilter/algo/unicode.rs:118-219, lane-free: see host.hip, unicode DFA):
+// start = the first byte position at which the FIRST needle scalar (either case variant) occurs, end = one past the last byte of
+// the LAST occurrence of the last needle scalar.  One thread scans its haystack through a sliding 8-byte register window.
+__device__ __forceinline__ void unicode_window_first_last(const NeedleDev& nd, const u8* __restrict__ hay, u32 L, u32& ws, u32& we) {
+    const u32 n = (u32)nd.rows;
+    const u32 la = nd.ulen[0], lz = nd.ulen[n - 1];
+    const u32 ma = la >= 4 ? 0xFFFFFFFFu : ((1u << (8 * la)) - 1), mz = lz >= 4 ? 0xFFFFFFFFu : ((1u << (8 * lz)) - 1);
+    const u32 a0 = *(const u32*)nd.uc[0] & ma, a1 = *(const u32*)nd.uf[0] & ma;
+    const u32 z0 = *(const u32*)nd.uc[n - 1] & mz, z1 = *(const u32*)nd.uf[n - 1] & mz;
+    ws = 0xFFFFFFFFu;
+    we = 0;
+    const u32* hp = (const u32*)hay;  // every haystack starts on a 16-byte boundary; >= 80 readable bytes follow the corpus
+    u32 cur = L ? hp[0] : 0u;
+    for (u32 p = 0; p < L; p += 4) {
+        const u32 nxt = p + 4 < L + 4 ? hp[(p >> 2) + 1] : 0u;
+#pragma unroll
+        for (u32 b = 0; b < 4; b++) {
+            const u32 v = __builtin_amdgcn_alignbyte(nxt, cur, b);
+            const u32 q = p + b;
+            if (ws == 0xFFFFFFFFu && q + la <= L && ((v & ma) == a0 || (v & ma) == a1)) ws = q;
+            if (q + lz <= L && ((v & mz) == z0 || (v & mz) == z1)) we = q + lz;
+        }
+        cur = nxt;
+    }
+    if (ws == 0xFFFFFFFFu) ws = 0;  // cannot happen for a survivor of the exact filter
+}
+
 template <int SWL, int REAL = SWL / 2>
 __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls) {
     constexpr int NW = SWL / 2;

@@ -174,6 +174,8 @@ struct fzb_matcher {
     LaunchCfg lc{};
     std::vector<u64> table;  // host copy of the filter table
     std::vector<u8> dfa;     // host copy of the subsequence DFA
+    std::vector<u8> uni_dfa; // unicode path, 0 typos: byte-level DFA of the exact prefilter (empty if it needs more than 255 states)
+    int uni_dfa_states = 0;
     Workspace ws{};
     int device = -1;
     bool profiling = false;
@@ -211,7 +213,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -332,6 +334,61 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
         }
         for (int b = 0; b < 256; b++) m->dfa[(size_t)n * 256 + b] = (u8)n;  // found: absorbing
     }
+    // Unicode path, 0 typos: the prefilter accepts iff the needle's scalars occur, in order, at increasing byte positions, each as its own
+    // bytes or as the bytes of its same-width case flip (src/prefilter/algo/unicode.rs:118-219; the same at 16 / 32 / 64 lanes - checked
+    // against the oracle by tests/test_host_abi.py::test_unicode_dfa_is_the_unicode_prefilter).  That is a byte-level DFA: state = (scalars
+    // matched, bytes of the current scalar matched, which of the two variants are still alive); a mismatch inside a scalar falls back to
+    // "is this byte the scalar's first byte" (UTF-8 lead bytes never occur inside a scalar, so no longer border exists).  With <= 255
+    // states it runs in the streaming DFA filter kernels unchanged and replaces superset filter + lane-exact window pass + second compaction.
+    m->uni_dfa_states = 0;
+    if (m->unicode && !m->literal_mode && config->max_typos == 0 && m->rows >= 1 && lc.filter_mode == 1) {
+        struct St { int i, k, alive; };
+        std::vector<St> states;
+        auto find = [&](int i, int k, int alive) {
+            for (size_t q = 0; q < states.size(); q++)
+                if (states[q].i == i && states[q].k == k && states[q].alive == alive) return (int)q;
+            states.push_back(St{i, k, alive});
+            return (int)states.size() - 1;
+        };
+        std::vector<std::vector<int>> trans;
+        find(0, 0, 3);
+        bool ok = true;
+        for (size_t q = 0; q < states.size() && ok; q++) {
+            const St cur = states[q];
+            std::vector<int> row(256, (int)q);
+            if (cur.i < m->rows) {
+                const u8* va = nd.uc[cur.i];
+                const u8* vb = nd.uf[cur.i];
+                const int len = nd.ulen[cur.i];
+                auto from_start = [&](int b) {  // state (i, 0) reading b
+                    const int alive = (va[0] == b ? 1 : 0) | (vb[0] == b ? 2 : 0);
+                    if (!alive) return find(cur.i, 0, 3);
+                    return len == 1 ? find(cur.i + 1, 0, 3) : find(cur.i, 1, alive);
+                };
+                for (int b = 0; b < 256; b++) {
+                    if (cur.k == 0) { row[b] = from_start(b); continue; }
+                    const int alive = ((cur.alive & 1) && va[cur.k] == b ? 1 : 0) | ((cur.alive & 2) && vb[cur.k] == b ? 2 : 0);
+                    if (alive) row[b] = cur.k + 1 == len ? find(cur.i + 1, 0, 3) : find(cur.i, cur.k + 1, alive);
+                    else row[b] = from_start(b);
+                }
+            }  // i == rows: accepting, absorbing
+            trans.push_back(row);
+            if (states.size() > 255) ok = false;
+        }
+        if (ok) {
+            // renumber so that the accepting state is the LAST one (the kernels test `state == number of states - 1`)
+            const int ns = (int)states.size();
+            int acc = -1;
+            for (int q = 0; q < ns; q++)
+                if (states[q].i == m->rows) acc = q;
+            std::vector<int> renum(ns);
+            for (int q = 0, nx = 0; q < ns; q++) renum[q] = q == acc ? ns - 1 : nx++;
+            m->uni_dfa.assign((size_t)ns * 256, 0);
+            for (int q = 0; q < ns; q++)
+                for (int b = 0; b < 256; b++) m->uni_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[trans[q][b]];
+            m->uni_dfa_states = ns;  // start state 0 = (0, 0): first created, never the accepting one (rows >= 1)
+        }
+    }
     lc.pad_ok = 1;
     for (size_t i = 0; i < needle_len; i++)
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
@@ -360,7 +417,7 @@ static int rebuild_matcher(fzb_matcher* m, const fzb_config* config, const uint8
     fresh->profiling = m->profiling;
     fresh->prof_calls = m->prof_calls;
     for (int i = 0; i < fzb_matcher::PROF_SLOTS; i++) {
-        for (int k = 0; k < 4; k++) std::swap(fresh->evring[i][k], m->evring[i][k]);
+        for (int k = 0; k < 5; k++) std::swap(fresh->evring[i][k], m->evring[i][k]);
         fresh->ev_filter[i] = m->ev_filter[i];
     }
     // ... and then the handle the caller holds takes the rebuilt matcher's place
@@ -540,6 +597,7 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
         if (w.tables_stale) {  // fzb_matcher_set_pattern / set_config kept the device buffers: only the two small tables change
             HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
             if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
+            if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
             w.tables_stale = false;
         }
         return FZB_OK;
@@ -556,6 +614,8 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
     HIPCHK(dev_alloc((void**)&w.dfa, (size_t)(FZB_MAX_ROWS + 2) * 256 + 16));  // room for any needle: set_pattern re-uploads in place
     if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
+    HIPCHK(dev_alloc((void**)&w.uni_dfa, 256 * 256 + 16));  // room for any unicode DFA (<= 255 states + 1): set_pattern re-uploads in place
+    if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
     w.cap_items = cap;
     if (need_l2) {
         HIPCHK(dev_alloc((void**)&w.win, cap * 8));
@@ -708,6 +768,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     const u32* win = nullptr;
     const u32* n_items_ptr = &cnt_c[0];
     int wmode = lc.window_mode;
+    bool uni_exact = false;  // the unicode DFA filter decided exactly: no lane-exact window pass, the scorer computes the window
     if (items_in) {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (lc.filter_mode == 0) {
@@ -757,6 +818,17 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         if (pev) HIPCHK(hipEventRecord(pev[1], st));
         HIPCHK(hipGetLastError());
         return FZB_OK;
+    } else if (m->uni_dfa_states && lc.bias_ok && !trace) {
+        // unicode path, 0 typos: the exact prefilter as a byte-level DFA in the streaming filter; the scorer finds the window itself
+        if (pev) HIPCHK(hipEventRecord(pev[2], st));
+        fzb_launch_filter(cd, first, cnt, w.table, w.uni_dfa, lc.dead_byte, m->uni_dfa_states - 1, 1, 0, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
+                          nullptr, nullptr, nullptr, lc.pad_ok);
+        if (pev) HIPCHK(hipEventRecord(pev[3], st));
+        FZB_STAGE("filter(unicode dfa)");
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
+        FZB_STAGE("compact1");
+        items = w.surv_idx;
+        uni_exact = true;
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
@@ -769,7 +841,10 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("compact1");
         items = w.surv_idx;
     }
-    if (!lc.filter_exact) {
+    if (uni_exact) {
+        wmode = 1;
+        HIPCHK(hipMemcpyAsync(&cnt_c[1], &cnt_c[0], 4, hipMemcpyDeviceToDevice, st));  // kept by the exact prefilter = the filter's survivors
+    } else if (!lc.filter_exact) {
         // the stream stage was a superset: re-decide every survivor with the reference's chunked algorithm at its exact lane width
         fzb_launch_window(cd, first, items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, cus * 4, st);
         FZB_STAGE("window");
@@ -1625,6 +1700,15 @@ int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]) {
     out_ms[4] = (float)n;
     out_ms[5] = (float)has_filter;
     return FZB_OK;
+}
+
+// Test hook (host only, no GPU): runs the unicode 0-typo prefilter DFA the streaming filter would run over one haystack.
+// Returns 1 / 0 = accept / reject, -1 if this matcher has no such DFA (not the unicode path, typos, or more than 255 states).
+int fzb_debug_unicode_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t len) {
+    if (!m || m->uni_dfa_states == 0 || (!bytes && len)) return -1;
+    u32 st = 0;
+    for (size_t i = 0; i < len; i++) st = m->uni_dfa[(size_t)st * 256 + bytes[i]];
+    return st == (u32)m->uni_dfa_states - 1 ? 1 : 0;
 }
 
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {

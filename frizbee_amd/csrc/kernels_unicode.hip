@@ -24,7 +24,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
         li = 0; ws = 0; we = 0;
         if (j < M) {
             li = items ? items[j] : (u32)j;
-            if (wmode != 2) { const uint2 w = *(const uint2*)(win + 2 * j); ws = w.x; we = w.y; }
+            if (wmode == 0) { const uint2 w = *(const uint2*)(win + 2 * j); ws = w.x; we = w.y; }
         }
     };
     auto load_span = [&](u64 j, u32 li, u64& s, u32& L) {
@@ -53,6 +53,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             const u8* hay = bytes + s_c;
             u32 ws = ws_c, we = we_c;
             if (wmode == 2) { ws = 0; we = L; }
+            else if (wmode == 1) unicode_window_first_last(nd, hay, L, ws, we);
             const u32 sp = ws ? ws - 1 : 0;
             const bool include_exact = sp == 0 && we == L;
             const u32 m = we - sp;

@@ -242,6 +242,9 @@ int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]);
  * [2]=windows scored by the generic wave-per-haystack kernel, [3]=windows scored by the multi-chunk kernel */
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]);
 
+/* test hook, host only: the byte-level DFA of the unicode 0-typo prefilter run over one haystack (1 / 0), -1 if the matcher has none */
+int fzb_debug_unicode_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,3 +180,33 @@ def test_k_merge_rejects_null_buffers():
     import ctypes as C
     lens = (C.c_size_t * 1)(3)
     assert F.lib().fzb_k_merge_matches(0, None, lens, 1, None) != 0
+
+
+def test_unicode_dfa_is_the_unicode_prefilter():
+    """The byte-level DFA that replaces superset filter + lane-exact window pass on the unicode path with 0 typos (host.hip) accepts
+    exactly what the reference's unicode prefilter accepts (src/prefilter/algo/unicode.rs:118-219, oracle at 16 / 32 / 64 lanes),
+    both case modes, scalars of 1-4 bytes, also on byte strings that are not valid UTF-8."""
+    import random
+    rng = random.Random(12)
+    alphabets = ["abéÉüÜ_ ", "aéñ中文😀b ", "إنماab ", "ΑαΒβΓγ xyz", "ßẞss", "éÉeE", "𐐀𐐨a𝒳"]
+    checked = accepted = 0
+    for it in range(6000):
+        al = rng.choice(alphabets)
+        needle = "".join(rng.choice(al) for _ in range(rng.randint(1, 6)))
+        casing = rng.choice([F.CaseMatching.Ignore, F.CaseMatching.Respect, F.CaseMatching.Smart])
+        m = F.Matcher(needle, F.Config(max_typos=0, casing=casing, unicode=F.UnicodeMatching.Always, pf_lanes=64))
+        cs = O.respects_case_for(casing.name, needle)
+        for _ in range(6):
+            hay = "".join(rng.choice(al) for _ in range(rng.randint(0, 40))).encode()
+            if rng.random() < 0.2 and hay:  # cut inside a scalar / repeat a lead byte: not valid UTF-8 any more
+                cut = rng.randrange(len(hay))
+                hay = hay[:cut] + hay[cut:cut + 1] + hay[cut:]
+            got = F.lib().fzb_debug_unicode_dfa_accepts(m.h, hay, len(hay))
+            assert got in (0, 1), (needle, got)
+            for lanes in (16, 32, 64):
+                want = O.prefilter(needle, hay, 0, cs, True, lanes)[0]
+                assert bool(got) == want, (needle, hay, casing, lanes, got, want)
+            checked += 1
+            accepted += got
+    assert checked > 30000 and accepted > 5000
+    assert F.lib().fzb_debug_unicode_dfa_accepts(F.Matcher("abc", F.Config(max_typos=0)).h, b"abc", 3) == -1  # ASCII path: no such DFA
