@@ -348,6 +348,77 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K1-DFA for ragged lists, burst form: a thread requests ALL vectors of its haystack (up to 8 = 128 bytes per round) back to
+// back and only then runs the DFA over them from registers.  In the rolling form above a 128-byte line is touched by ~8 loads
+// of a wave that are separated by the DFA work of every resident wave, and the CU's footprint (24 waves x 64 haystacks x up to
+// 128 B) is far beyond the vector L1, so most of those touches re-fetch the line from L2; issued back to back they hit.
+// C4 shard: 297 -> 242 us.  (Two or four haystacks per thread as interleaved DFA chains on top of it: 276 / 300 us - with 8 waves per SIMD
+// the lookup chain is already hidden, the extra registers and the longer rounds only cost.)
+// ---------------------------------------------------------------------------------------------------
+template <typename ET, bool SAN>
+__global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
+                                                           const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                                           u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
+    extern __shared__ __attribute__((aligned(16))) u8 dfa[];
+    __shared__ u32 s_cnt;
+    const int tid = threadIdx.x;
+    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    const u32 deadv = dead * 0x01010101u;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        u32 cnt = 0;
+#pragma unroll 1
+        for (int sub = 0; sub < 4; sub++) {
+            const u32 li = tile * FZB_TILE + sub * 256 + tid;
+            u64 hs = 0;
+            u32 hl = 0;
+            if (li < count) haystack_span(ends, first + li, hs, hl);
+            const uint4* vp = (const uint4*)(bytes + hs);
+            u32 st = 0;
+            for (u32 v0 = 0; 16 * v0 < hl; v0 += 8) {  // rounds of 8 vectors (one round for haystacks up to 128 bytes)
+                uint4 q[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) q[k] = hl > 16 * (v0 + k) ? vp[v0 + k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (hl <= 16 * (v0 + k)) break;
+                    u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+                    if (SAN) {
+                        const u32 rem = hl - 16 * (v0 + k);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
+                            const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
+                            w[j] = (w[j] & mask) | (deadv & ~mask);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        st = dfa_step<0>(st, w[j], dfa);
+                        st = dfa_step<1>(st, w[j], dfa);
+                        st = dfa_step<2>(st, w[j], dfa);
+                        st = dfa_step<3>(st, w[j], dfa);
+                    }
+                }
+            }
+            const bool matched = li < count && hl >= min_len && st == (u32)rows;
+            const u64 b = __ballot(matched);
+            if (lane_id() == 0) {
+                bitmap[(tile * FZB_TILE + sub * 256) / 64 + (tid >> 6)] = b;
+                cnt += __popcll(b);
+            }
+        }
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Level-1 compaction in ONE kernel: every workgroup owns a
 // contiguous run of tiles, obtains the number of survivors before its run by reducing the (small, L2-resident)
 // per-tile count array itself - redundant across workgroups but far cheaper than a dependent scan launch -
@@ -614,6 +685,16 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             // 128-byte lines instead of ~34 adjacent ones, and the kernel is bound by cache transactions, not by instruction issue.
             int rgrid = std::min<int>((grid / 8) * 6, (int)ntiles);
             if (rgrid < 1) rgrid = 1;
+            static const int burst = getenv("FZB_RAGGED_BURST") ? atoi(getenv("FZB_RAGGED_BURST")) : 1;  // 0 = the rolling form, for comparison
+            static const int bwgs = getenv("FZB_RAGGED_WGS") ? atoi(getenv("FZB_RAGGED_WGS")) : 8;
+            if (burst) {
+                rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
+#define FZB_K1B(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_burst<ET, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters)
+                if (c.ends_u64) { if (nul_safe) FZB_K1B(u64, false); else FZB_K1B(u64, true); }
+                else            { if (nul_safe) FZB_K1B(u32, false); else FZB_K1B(u32, true); }
+#undef FZB_K1B
+                return;
+            }
 #define FZB_K1R(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged<ET, 1, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters)
             if (c.ends_u64) { if (nul_safe) FZB_K1R(u64, false); else FZB_K1R(u64, true); }
             else            { if (nul_safe) FZB_K1R(u32, false); else FZB_K1R(u32, true); }
