@@ -141,3 +141,29 @@ def test_reserve_then_requery_does_not_change_results():
         got = m.match_list(corpus)
         want = F.Matcher(needle, F.Config(max_typos=1, pf_lanes=64, sw_lanes=64)).match_list(corpus)
         assert got.tolist() == want.tolist(), needle
+
+
+@pytest.mark.parametrize("pf", [64, 32, 16])
+@pytest.mark.parametrize("typos", [0, 1, None])
+def test_every_window_width_around_the_class_boundaries(pf, typos):
+    """Classified scoring (k2w_classify + k2b_dp_class) and the short scorer: windows of EVERY width from 1 byte to well past a chunk, so
+    that each class boundary (1/2, 3/4, 1 chunk, multi-chunk) is crossed at the three lane widths; the needle's bytes sit at both ends of
+    the window and the filler holds partial matches.  A list with long haystacks (classes) and a short-only list (k2b_dp_short)."""
+    import random
+    rng = random.Random(1000 * pf + (typos or 7))
+    lanes = {64: (64, 64, 32), 32: (32, 32, 16), 16: (16, 16, 8)}[pf]
+    needle = "ab_c"
+    hs = []
+    for width in range(1, 150):
+        for rep in range(3):
+            inner = "".join(rng.choice("xyab_cAB ") for _ in range(max(0, width - 2)))
+            core = ("a" + inner + "c")[:width] if width >= 2 else "a"
+            lead = "".join(rng.choice("xyz") for _ in range(rng.choice([0, 0, 1, 5])))
+            tail = "".join(rng.choice("xyz") for _ in range(rng.choice([0, 0, 3])))
+            hs.append(lead + core + tail)
+    rng.shuffle(hs)
+    for sub in (hs, [h for h in hs if len(h) <= lanes[1] // 2]):
+        want = O.Matcher(needle, lanes=lanes, max_typos=typos, sort="IndexAsc").match_list(sub)
+        got = F.Matcher(needle, F.Config(max_typos=typos, sort=F.SortStrategy.IndexAsc, pf_lanes=pf)).match_list(sub)
+        assert got.tolist() == want.tolist(), (pf, typos, len(sub))
+        assert len(want) >= len(sub) // 8
