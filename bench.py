@@ -12,10 +12,11 @@ when the closing barrier + synchronize returns).
 
 Prints ONE JSON line on rank 0 (see the driver contract): `value` = haystacks scored per second, whole job.  Beside it:
   roofline        the dominant kernel = the streaming filter k1_dfa, HBM-bound: achieved = algorithmic bytes per launch
-                  (sum len + 4 B end offset per haystack + 1 decision bit) / its average duration over the profiled steps, measured
+                  (sum len + 1 decision bit per haystack; the list has uniform length, so no end offsets are read) / its average duration over the profiled steps, measured
                   with HIP events recorded on the launch stream by the library (fzb_last_stage_timings).  `traffic` is NOT measured in
                   this run: it is the PMC figure of the committed profile named in `traffic_source`.
-  roofline_step   the whole step against the same roofline: SURVEY 8(d) bytes (sum len + 4 N + 8 M) / ms_per_step / 8 TB/s.
+  roofline_step   the whole step against the same roofline: bytes the step needs (sum len + 8 M; SURVEY 8(d) adds 4 N of end offsets, which a
+                  uniform-length list does not read - `frac_with_survey_bytes` uses that formula) / ms_per_step / 8 TB/s.
   stages          HIP-event averages per stage; the scorer is VALU-issue-bound, its `issue_frac` = wave-instructions of the committed
                   SQ profile x 4 cycles / (SIMDs x duration x clock) - stored counters, labelled as such.
   e2e             what a caller of `Matcher::match_list` gets: pipeline + device reverse/radix sort + D2H of the records (median).
@@ -147,16 +148,21 @@ def oracle_check(F, m_gpu, corpus, rows, n_check, max_typos, dev):
             "what": "HIP path vs oracle/ (portable C++ restatement of the reference, emulating its AVX-512 backend) on the first items of the bench list, untimed"}
 
 
-def step_roofline(sum_len, n, matches, ms):
-    b = sum_len + 4 * n + 8 * matches
-    return {"bytes": b, "GBps": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+def step_roofline(sum_len, n, matches, ms, ends_read=True):
+    """sum len + 4 N (u32 end offsets) + 8 M.  A corpus of uniform-length haystacks needs no offsets (the kernels compute the
+    spans): the bytes then are sum len + 8 M, and the figure with the survey's formula is given beside it for comparison across rounds."""
+    b = sum_len + (4 * n if ends_read else 0) + 8 * matches
+    r = {"bytes": b, "GBps": b / (ms * 1e-3) / 1e9, "frac": b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "end_offsets_read": bool(ends_read)}
+    if not ends_read:
+        r["frac_with_survey_bytes"] = (sum_len + 4 * n + 8 * matches) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return r
 
 
 def other_configs(F, synth, dev, steps):
     """C3 / C4-shard / C5 of BASELINE.json on this GPU: device pipeline time per step (corpus resident), same definitions as the headline."""
     res = {}
 
-    def run(name, needle, cfg, corpus, n, sum_len):
+    def run(name, needle, cfg, corpus, n, sum_len, ends_read=True):
         m = F.Matcher(needle, cfg)
         out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev)
         cnt = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -174,7 +180,7 @@ def other_configs(F, synth, dev, steps):
         torch.cuda.synchronize(dev)
         st = m.last_stage_timings_ms()
         matches = int(cnt[0].item())
-        res[name] = {"haystacks": n, "ms_per_step": ms, "haystacks_per_s": n / (ms * 1e-3), "matches": matches, "roofline_step": step_roofline(sum_len, n, matches, ms),
+        res[name] = {"haystacks": n, "ms_per_step": ms, "haystacks_per_s": n / (ms * 1e-3), "matches": matches, "roofline_step": step_roofline(sum_len, n, matches, ms, ends_read),
                      "stages_ms": {k: st[k] for k in ("filter", "compaction_and_window", "scorers", "total")}, **{k: v for k, v in m.last_counters().items()}}
         del m, out, cnt
 
@@ -182,8 +188,8 @@ def other_configs(F, synth, dev, steps):
     flat = torch.zeros(n * HAY_LEN + 256, dtype=torch.uint8, device=dev)
     flat[: n * HAY_LEN].view(n, HAY_LEN).copy_(synth.make_rows(NEEDLE, n, HAY_LEN, seed=12345, device=dev))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * HAY_LEN).to(torch.int32)
-    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=HAY_LEN)
-    run("C3 10M x 32 B, 'deadbe', max_typos=2", "deadbe", F.Config(max_typos=2, pf_lanes=64, sw_lanes=64), cp, n, n * HAY_LEN)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=HAY_LEN, uniform_len=HAY_LEN)
+    run("C3 10M x 32 B, 'deadbe', max_typos=2", "deadbe", F.Config(max_typos=2, pf_lanes=64, sw_lanes=64), cp, n, n * HAY_LEN, ends_read=False)
     del cp, flat, ends
     n4 = 12_500_000
     data, e4 = synth.ragged_corpus(b"deadbeef", n4, device=dev)
@@ -195,7 +201,7 @@ def other_configs(F, synth, dev, steps):
     d5 = np.tile(d5, reps)
     e5 = np.arange(1, n5 * reps + 1, dtype=np.uint64) * np.uint64(HAY_LEN)
     cp = F.Corpus(packed=(d5, e5))
-    run("C5 10M x 32 B UTF-8 (2M distinct x 5), 4-scalar Arabic needle, max_typos=0", "إنما", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n5 * reps, n5 * reps * HAY_LEN)
+    run("C5 10M x 32 B UTF-8 (2M distinct x 5), 4-scalar Arabic needle, max_typos=0", "إنما", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n5 * reps, n5 * reps * HAY_LEN, ends_read=False)  # uploaded list of uniform length: detected by fzb_corpus_upload
     del cp
     return res
 
@@ -243,7 +249,9 @@ def main():
     rows = flat[: n * HAY_LEN].view(n, HAY_LEN)
     rows.copy_(synth.make_rows(NEEDLE, n, HAY_LEN, seed=12345 + rank, device=dev))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * HAY_LEN).to(torch.int32)
-    corpus = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), ends_are_u64=False, keep=(flat, ends), max_len=HAY_LEN)
+    # every haystack has exactly HAY_LEN bytes: declared to the library (an uploaded list is detected), whose hot kernels then compute the
+    # spans instead of reading the end offsets
+    corpus = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), ends_are_u64=False, keep=(flat, ends), max_len=HAY_LEN, uniform_len=HAY_LEN)
     cfg = F.Config(max_typos=args.max_typos, pf_lanes=64, sw_lanes=64)  # bit-exact against the AVX-512 (VBMI) reference backend
     m = F.Matcher(NEEDLE.decode(), cfg)
     out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev)
@@ -343,8 +351,8 @@ def main():
     counters = m.last_counters()
     if rank == 0:
         total = n * world
-        # algorithmic bytes of one filter launch (this rank's shard): payload once + u32 end offset + 1 decision bit per haystack
-        filt_bytes = n * HAY_LEN + 4 * n + n / 8
+        # algorithmic bytes of one filter launch (this rank's shard): payload once + 1 decision bit per haystack (no end offsets: uniform length)
+        filt_bytes = n * HAY_LEN + n / 8
         achieved = filt_bytes / (st["filter"] * 1e-3) / 1e9
         tr = stored_json("latest_traffic.json") or {}
         sq = stored_json("latest_sq.json") or {}
@@ -380,7 +388,7 @@ def main():
                          "traffic": tr.get("k1_filter_hbm_bytes_per_launch"),
                          "traffic_source": "STORED, not measured in this run: profiles/latest_traffic.json (" + str(tr.get("source")) + ")",
                          "bytes_per_launch": filt_bytes, "avg_kernel_ms": st["filter"], "launches_averaged": st["calls"]},
-            "roofline_step": step_roofline(n * HAY_LEN, n, n_matches, ms_per_step),
+            "roofline_step": step_roofline(n * HAY_LEN, n, n_matches, ms_per_step, ends_read=False),
             "stages": {"filter_ms": st["filter"], "compaction_ms": st["compaction_and_window"], "scorer_ms": st["scorers"], "device_pipeline_ms": st["total"], "scorer": scorer,
                        "what": "HIP events on the launch stream around each stage, averaged over the profiled steps (the K steps after the timed K)"},
         }

@@ -107,7 +107,7 @@ _lib = None
 
 SYMBOLS = [
     "fzb_last_error", "fzb_config_default", "fzb_matcher_create", "fzb_matcher_clone", "fzb_matcher_free", "fzb_matcher_info", "fzb_matcher_set_pattern", "fzb_matcher_set_config",
-    "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_set_max_len", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
+    "fzb_corpus_upload", "fzb_corpus_from_device", "fzb_corpus_set_max_len", "fzb_corpus_set_uniform_len", "fzb_corpus_free", "fzb_corpus_len", "fzb_match_list", "fzb_match_list_into",
     "fzb_match_list_device", "fzb_match_list_sorted_device", "fzb_match_list_parallel", "fzb_matches_free", "fzb_radix_sort_matches", "fzb_k_merge_matches",
     "fzb_matcher_reserve", "fzb_debug_unicode_dfa_accepts", "fzb_set_profiling", "fzb_last_timings", "fzb_last_stage_timings", "fzb_last_counters",
     "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
@@ -134,6 +134,7 @@ def lib():
         l.fzb_corpus_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         l.fzb_corpus_from_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_uint64, C.POINTER(C.c_void_p)]
         l.fzb_corpus_set_max_len.argtypes = [C.c_void_p, C.c_uint32]
+        l.fzb_corpus_set_uniform_len.argtypes = [C.c_void_p, C.c_uint32]
         l.fzb_corpus_free.argtypes = [C.c_void_p]
         l.fzb_corpus_len.argtypes = [C.c_void_p]
         l.fzb_corpus_len.restype = C.c_size_t
@@ -213,15 +214,18 @@ class Corpus:
         _check(lib().fzb_corpus_upload(data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), C.byref(self.h)))
 
     @classmethod
-    def from_device(cls, dev_bytes_ptr, dev_ends_ptr, n, total_bytes, ends_are_u64=False, keep=None, max_len=0):
+    def from_device(cls, dev_bytes_ptr, dev_ends_ptr, n, total_bytes, ends_are_u64=False, keep=None, max_len=0, uniform_len=0):
         """Borrow device memory already in the padded-16 layout (see include/frizbee_hip.h).  max_len: optional upper bound
-        on the haystack length (0 = unknown)."""
+        on the haystack length (0 = unknown).  uniform_len: optional promise that EVERY haystack has exactly this many bytes
+        (the hot kernels then do not read the end offsets; Corpus(...) / fzb_corpus_upload detect it themselves)."""
         self = cls.__new__(cls)
         self.h = C.c_void_p()
         self._keep = keep
         _check(lib().fzb_corpus_from_device(dev_bytes_ptr, dev_ends_ptr, int(ends_are_u64), n, total_bytes, C.byref(self.h)))
         if max_len:
             _check(lib().fzb_corpus_set_max_len(self.h, max_len))
+        if uniform_len:
+            _check(lib().fzb_corpus_set_uniform_len(self.h, uniform_len))
         return self
 
     def __len__(self):

@@ -50,6 +50,7 @@ struct CorpusDev {
     u64 total_bytes;   // padded size
     int ends_u64;
     u32 max_len;       // longest haystack in bytes, 0 = unknown (lets the pipeline skip the multi-chunk scorer launch)
+    u32 uniform_len;   // every haystack has exactly this many bytes (0 = not known): start(i) = i * roundup16(len), no end offsets read
 };
 
 struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between kernels (0 in final output)

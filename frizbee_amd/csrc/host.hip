@@ -484,7 +484,7 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
     // ranges, then every range copies its haystacks (and zeroes its own gaps: the buffer is not cleared as a whole)
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::thread::hardware_concurrency(), n / 65536 + 1}));
     const size_t per = (n + nthreads - 1) / nthreads;
-    std::vector<u64> range_bytes(nthreads, 0), range_max(nthreads, 0);
+    std::vector<u64> range_bytes(nthreads, 0), range_max(nthreads, 0), range_min(nthreads, ~(u64)0);
     std::vector<int> range_bad(nthreads, 0);
     auto for_ranges = [&](auto fn) {
         std::vector<std::thread> pool;
@@ -494,24 +494,27 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
     };
     for_ranges([&](size_t t) {
         const size_t lo = std::min(t * per, n), hi = std::min(lo + per, n);
-        u64 prev = lo ? end_offsets[lo - 1] : 0, bytes_padded = 0, mx = 0;
+        u64 prev = lo ? end_offsets[lo - 1] : 0, bytes_padded = 0, mx = 0, mn = ~(u64)0;
         for (size_t i = lo; i < hi; i++) {
             if (end_offsets[i] < prev) { range_bad[t] = 1; break; }
             const u64 len = end_offsets[i] - prev;
             mx = std::max(mx, len);
+            mn = std::min(mn, len);
             bytes_padded += (len + 15) & ~(u64)15;
             prev = end_offsets[i];
         }
         range_bytes[t] = bytes_padded;
         range_max[t] = mx;
+        range_min[t] = mn;
     });
-    u64 max_len = 0, total_padded = 0;
+    u64 max_len = 0, min_len = ~(u64)0, total_padded = 0;
     std::vector<u64> range_start(nthreads, 0);
     for (size_t t = 0; t < nthreads; t++) {
         if (range_bad[t]) return fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
         range_start[t] = total_padded;
         total_padded += range_bytes[t];
         max_len = std::max(max_len, range_max[t]);
+        min_len = std::min(min_len, range_min[t]);
     }
     const u64 total = total_padded + 96;
     const bool ends_u64 = total > 0xFFFFFFF0ull;
@@ -539,6 +542,7 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
     c->dev.total_bytes = total;
     c->dev.ends_u64 = ends_u64;
     c->dev.max_len = (u32)std::min<u64>(max_len, 0xFFFFFFFFu);
+    c->dev.uniform_len = (n && min_len == max_len && max_len && max_len < 0xFFFFFFFFu) ? (u32)max_len : 0u;  // kernels then skip the end offsets
     hipError_t e = dev_alloc(&c->own_bytes, total);
     if (e == hipSuccess) e = hipMemcpy(c->own_bytes, packed.get(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = dev_alloc(&c->own_ends, std::max<size_t>(n, 1) * (ends_u64 ? 8 : 4));
@@ -574,6 +578,14 @@ void fzb_corpus_free(fzb_corpus* c) {
     delete c;
 }
 size_t fzb_corpus_len(const fzb_corpus* c) { return c ? (size_t)c->dev.n : 0; }
+int fzb_corpus_set_uniform_len(fzb_corpus* c, uint32_t len) {
+    if (!c) return fail(FZB_ERR_INVALID, "null argument");
+    if (len && (u64)((len + 15u) & ~15u) * (c->dev.n ? c->dev.n - 1 : 0) + len > c->dev.total_bytes) return fail(FZB_ERR_INVALID, "uniform length does not fit the corpus buffer");
+    c->dev.uniform_len = len;
+    if (len) c->dev.max_len = len;
+    return FZB_OK;
+}
+
 int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
     if (!c) return fail(FZB_ERR_INVALID, "null argument");
     c->dev.max_len = max_len;

@@ -17,6 +17,18 @@ __device__ __forceinline__ void haystack_span(const ET* __restrict__ ends, u64 i
     len = (u32)(e - start);
 }
 
+// the same when every haystack of the corpus has `ulen` bytes (CorpusDev::uniform_len): no loads, and the haystack's vectors can be
+// requested without waiting for an end offset
+template <typename ET>
+__device__ __forceinline__ void haystack_span_u(const ET* __restrict__ ends, u32 ulen, u64 i, u64& start, u32& len) {
+    if (ulen) {
+        start = i * (u64)((ulen + 15u) & ~15u);
+        len = ulen;
+    } else {
+        haystack_span(ends, i, start, len);
+    }
+}
+
 // Read the 32-bit word holding bytes [p, p+4) of `base` for an arbitrary byte offset p
 // (two aligned loads + v_alignbyte; the corpus has >= 80 readable bytes past the end).
 __device__ __forceinline__ u32 load_u32_unaligned(const u8* __restrict__ base, u64 p) {

@@ -165,7 +165,7 @@ template <int SWL, bool UPPER, typename ET>
 __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                     const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                     const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count,
-                                                    RejectOut rej, u32* __restrict__ kept_out) {
+                                                    RejectOut rej, u32* __restrict__ kept_out, u32 ulen) {
     FZB_TIMING_BEGIN
     __shared__ CfTables tab;
     __shared__ u8 fl[256];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
     };
     auto load_span = [&](u64 j, u32 li, u64& s, u32& L) {
         s = 0; L = 0;
-        if (j < M) haystack_span(ends, first + li, s, L);
+        if (j < M) haystack_span_u(ends, ulen, first + li, s, L);
     };
     auto load_vecs = [&](u64 s, u32 L, uint4& q0, uint4& q1) {
         q0 = make_uint4(0, 0, 0, 0);
@@ -517,7 +517,7 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
         static int per_cu = 0;                                                                                                          \
         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
         if (const char* e_ = getenv("FZB_DP_WGS_PER_CU")) { const int v_ = atoi(e_); if (v_ >= 1 && v_ < per_cu) per_cu = v_; } /* tuning knob: leave room for a co-resident kernel */ \
-        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out); \
+        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out, c.uniform_len); \
     } while (0)
 #define FZB_K2S_ET(SWL, U) do { if (c.ends_u64) FZB_K2S(SWL, U, u64); else FZB_K2S(SWL, U, u32); } while (0)
 #define FZB_K2S_U(SWL) do { if (upper) FZB_K2S_ET(SWL, true); else FZB_K2S_ET(SWL, false); } while (0)

@@ -56,7 +56,7 @@ struct MargOut {
 template <typename TW, int MODE, typename ET, bool MARG = false>
 __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                                  const u64* __restrict__ Tg, int rows, int need, u32 min_len,
-                                                 u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, MargOut mo = MargOut{}) {
+                                                 u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, MargOut mo = MargOut{}, u32 ulen = 0) {
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
     // compaction kernel reads it
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
             if (li < count) {
                 u64 s;
                 u32 L;
-                haystack_span(ends, first + li, s, L);
+                haystack_span_u(ends, ulen, first + li, s, L);
                 if (L >= min_len) {
                     const uint4* vp = (const uint4*)(bytes + s);
                     TW st = (MODE == 1) ? (TW)1 : (TW)~(TW)0;
@@ -162,7 +162,7 @@ __device__ __forceinline__ u32 dfa_partial(u32 st, const uint4& q, u32 nbytes, c
 template <typename ET>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                               const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
-                                              u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+                                              u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 ulen) {
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
     // compaction kernel reads it
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
             const u32 li = tile * FZB_TILE + p * 256 + tid;
             hs[p] = 0;
             hl[p] = 0;
-            if (li < count) haystack_span(ends, first + li, hs[p], hl[p]);
+            if (li < count) haystack_span_u(ends, ulen, first + li, hs[p], hl[p]);
         }
 #pragma unroll
         for (int p = 0; p < 4; p++) {
@@ -675,8 +675,8 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         const size_t lds = (size_t)(rows + 1) * 256;
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
-            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);
-            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters);
+            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.uniform_len);
+            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.uniform_len);
         } else {
             // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
             // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times).
@@ -705,13 +705,13 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
     const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
     if (mode == 2 && bitmap_m) {  // LCS filter with the "nothing to spare" bit (typo configurations on the short-haystack path)
         const MargOut mo{bitmap_m, tile_counts_m, reject_bits, tile_rejects};
-#define FZB_K1M(TW, ET) hipLaunchKernelGGL((k1_filter<TW, 2, ET, true>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, mo)
+#define FZB_K1M(TW, ET) hipLaunchKernelGGL((k1_filter<TW, 2, ET, true>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, mo, c.uniform_len)
         if (c.ends_u64) { if (w64) FZB_K1M(u64, u64); else FZB_K1M(u32, u64); }
         else            { if (w64) FZB_K1M(u64, u32); else FZB_K1M(u32, u32); }
 #undef FZB_K1M
         return;
     }
-#define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, MargOut{})
+#define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, MargOut{}, c.uniform_len)
     if (c.ends_u64) {
         if (mode == 1) { if (w64) FZB_K1(u64, 1, u64); else FZB_K1(u32, 1, u64); }
         else           { if (w64) FZB_K1(u64, 2, u64); else FZB_K1(u32, 2, u64); }

@@ -8,7 +8,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
                                                       const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                       const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity,
                                                       u32* __restrict__ dev_count, u32* __restrict__ overflow, u32 qcap,
-                                                      u32* __restrict__ counters) {
+                                                      u32* __restrict__ counters, u32 ulen) {
     __shared__ u8 cls[256];
     build_cls_table(cls);
     __syncthreads();
@@ -29,7 +29,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
     };
     auto load_span = [&](u64 j, u32 li, u64& s, u32& L) {
         s = 0; L = 0;
-        if (j < M) haystack_span(ends, first + li, s, L);
+        if (j < M) haystack_span_u(ends, ulen, first + li, s, L);
     };
     u32 li_c, ws_c, we_c, L_c, li_n, ws_n, we_n, L_n, li_m, ws_m, we_m;
     u64 s_c, s_n;
@@ -93,8 +93,8 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
 
 #define FZB_K2U_PARAMS const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win, \
     const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ overflow, \
-    u32 qcap, u32* __restrict__ counters
-#define FZB_K2U_ARGS bytes, ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters
+    u32 qcap, u32* __restrict__ counters, u32 ulen
+#define FZB_K2U_ARGS bytes, ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, ulen
 template <int SWL, typename ET>
 __global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, ET>(FZB_K2U_ARGS); }
 // every haystack of the list fits the low half of a chunk (host-known: corpus max_len <= SWL / 2): the general form is compiled out,
@@ -112,10 +112,10 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
         static int per_cu = 0, per_cu_half = 0;                                                                                        \
         if (half_only) {                                                                                                               \
             if (!per_cu_half && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_half, k2u_dp_unicode_half<SWL, ET>, 128, 0) != hipSuccess || per_cu_half < 1)) per_cu_half = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters); \
+            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
         } else {                                                                                                                       \
             if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
-            hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters); \
+            hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
         }                                                                                                                              \
     } while (0)
 #define FZB_K2U_ET(SWL) do { if (c.ends_u64) FZB_K2U(SWL, u64); else FZB_K2U(SWL, u32); } while (0)

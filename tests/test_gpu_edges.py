@@ -167,3 +167,25 @@ def test_every_window_width_around_the_class_boundaries(pf, typos):
         got = F.Matcher(needle, F.Config(max_typos=typos, sort=F.SortStrategy.IndexAsc, pf_lanes=pf)).match_list(sub)
         assert got.tolist() == want.tolist(), (pf, typos, len(sub))
         assert len(want) >= len(sub) // 8 or sub is not hs  # (the short-only list may hold few matches)
+
+
+@pytest.mark.parametrize("length", [32, 20, 16, 7])
+def test_uniform_length_corpus_needs_no_end_offsets(length):
+    """A list whose haystacks all have the same length is detected by fzb_corpus_upload (or declared for borrowed memory): the hot kernels
+    then compute start(i) = i * roundup16(len) instead of reading the end offsets.  Same records as the oracle, and as the same list made
+    non-uniform by one extra haystack."""
+    import random
+    rng = random.Random(length)
+    hs = ["".join(rng.choice("deadbeDEAB_x01") for _ in range(length)) for _ in range(4000)]
+    for needle, kw in (("deadbe", dict(max_typos=0)), ("deadbe", dict(max_typos=2)), ("dea", dict(max_typos=None)), ("éa", dict(max_typos=0))):
+        want = O.Matcher(needle, lanes=(64, 64, 32), sort="IndexAsc", **kw).match_list(hs)
+        cfg = F.Config(sort=F.SortStrategy.IndexAsc, pf_lanes=64, sw_lanes=64, **kw)
+        got_u = F.Matcher(needle, cfg).match_list(F.Corpus(hs))                 # uniform: detected at upload
+        got_n = F.Matcher(needle, cfg).match_list(F.Corpus(hs + ["x" * (length + 3)]))  # not uniform
+        assert got_u.tolist() == want.tolist(), (needle, kw, length)
+        assert got_n[got_n["index"] < len(hs)].tolist() == want.tolist(), (needle, kw, length)
+    # borrowed device memory with the promise
+    cp = padded16([h.encode() for h in hs], torch.device("cuda", 0), False)
+    F._check(F.lib().fzb_corpus_set_uniform_len(cp.h, length))
+    want = O.Matcher("deadbe", lanes=(64, 64, 32), sort="IndexAsc", max_typos=1).match_list(hs)
+    assert F.Matcher("deadbe", F.Config(sort=F.SortStrategy.IndexAsc, pf_lanes=64, sw_lanes=64, max_typos=1)).match_list(cp).tolist() == want.tolist()

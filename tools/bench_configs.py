@@ -24,7 +24,7 @@ if "C2" in which or "C3" in which:
     flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
     flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
-    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32, uniform_len=32)
     if "C2" in which: run("C2 len32 typos0", "deadbe", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n)
     if "C3" in which: run("C3 len32 typos2", "deadbe", F.Config(max_typos=2, pf_lanes=64, sw_lanes=64), cp, n)
     if "C2none" in which: run("C2 len32 typosNone(all scored)", "deadbe", F.Config(max_typos=None, pf_lanes=64, sw_lanes=64), cp, n, steps=3)
@@ -35,7 +35,7 @@ for mixname, full, partial in (("MIXALL", 1.0, 0.0), ("MIXNONE", 0.0, 0.0)):
         flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
         flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev, full=full, partial=partial))
         ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
-        cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+        cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32, uniform_len=32)
         run(f"C2 list with mix full={full} partial={partial}", "deadbe", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n, steps=5)
         del cp, flat, ends
 if "MULTI" in which:
@@ -43,7 +43,7 @@ if "MULTI" in which:
     flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
     flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
-    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32, uniform_len=32)
     mm = F.MultiMatcher([F.Pattern("dead"), F.Pattern("be"), F.Pattern("x", negated=True)], F.Config(max_typos=0, pf_lanes=64))
     out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev); cnt = torch.zeros(4, dtype=torch.int32, device=dev)
     for _ in range(2): mm.match_list_device(cp, out.data_ptr(), n, cnt.data_ptr())
@@ -57,7 +57,7 @@ if "LITERAL" in which:
     flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
     flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
-    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32, uniform_len=32)
     out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev); cnt = torch.zeros(4, dtype=torch.int32, device=dev)
     for needle, matching in (("de", "Substring"), ("deadbe", "Substring"), ("d", "Prefix"), ("e", "Suffix")):
         m = F.Matcher(needle, F.Config(matching=F.Matching[matching]))
@@ -106,7 +106,7 @@ if "INDICES" in which:
     flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
     flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
-    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=32, uniform_len=32)
     for typos in (0, 1):
         m = F.Matcher("deadbe", F.Config(max_typos=typos, pf_lanes=64, sw_lanes=64))
         top = m.match_list(cp)
