@@ -13,8 +13,9 @@ when the closing barrier + synchronize returns).
 Prints ONE JSON line on rank 0 (see the driver contract): `value` = haystacks scored per second, whole job.  Beside it:
   roofline        the dominant kernel = the streaming filter k1_dfa, HBM-bound: achieved = algorithmic bytes per launch
                   (sum len + 1 decision bit per haystack; the list has uniform length, so no end offsets are read) / its average duration over the profiled steps, measured
-                  with HIP events recorded on the launch stream by the library (fzb_last_stage_timings).  `traffic` is NOT measured in
-                  this run: it is the PMC figure of the committed profile named in `traffic_source`.
+                  with HIP events recorded on the launch stream by the library (fzb_last_stage_timings).  `traffic` = HBM bytes per launch from the
+                  FETCH_SIZE / WRITE_SIZE counters, collected by two rocprofv3 --pmc child runs of this script (`traffic_source` says so, or
+                  names the stored profile if that failed or --no-live-traffic was given).
   roofline_step   the whole step against the same roofline: bytes the step needs (sum len + 8 M; SURVEY 8(d) adds 4 N of end offsets, which a
                   uniform-length list does not read - `frac_with_survey_bytes` uses that formula) / ms_per_step / 8 TB/s.
   stages          HIP-event averages per stage; the scorer is VALU-issue-bound, its `issue_frac` = wave-instructions of the committed
@@ -119,6 +120,59 @@ def cpu_baseline(rows_dev, n_sample, max_typos):
                                 "what": "the reference's published 1.15e8 haystacks/s/thread (BENCHMARKS.md:123, Ryzen 9950X3D, same length and mix) x physical cores"}}
 
 
+def _pmc_child(counters, kernel_substr):
+    """One child run of this script under `rocprofv3 --pmc <counters>` (counters only, no trace domains); returns {counter: (average per
+    dispatch of the kernels whose name contains kernel_substr, dispatches)}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    tmp = tempfile.mkdtemp(prefix="fzb_pmc_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--fast", "--steps", "3", "--warmup", "1"]
+        subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        acc = {}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] in counters and kernel_substr in r["Kernel_Name"]:
+                    t = acc.setdefault(r["Counter_Name"], [0.0, 0])
+                    t[0] += float(r["Counter_Value"])
+                    t[1] += 1
+        return {k: (v[0] / v[1], v[1]) for k, v in acc.items() if v[1]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def live_counters():
+    """Measured NOW, by child runs of this script under rocprofv3 --pmc (separate passes, counters only - as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes):
+      * HBM bytes per k1_dfa launch = (FETCH_SIZE x 2 + WRITE_SIZE) KiB: both counters are KiB per dispatch, and on gfx950 FETCH_SIZE counts
+        64 B per 128-B request for wide coalesced 16 B/lane reads, so it is doubled (the reduction of tools/pmc_traffic.py);
+      * wave-instructions per scorer launch (SQ_INSTS_VALU, SQ_INSTS_SALU; SQ_ACTIVE_INST_ANY = quad-cycles of instruction issue, all kinds).
+    Returns (dict, None) or (None, reason): a profiler problem must not cost the bench line."""
+    import shutil
+
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not on PATH"
+    try:
+        f = _pmc_child(["FETCH_SIZE"], "k1_dfa")
+        w = _pmc_child(["WRITE_SIZE"], "k1_dfa")
+        if "FETCH_SIZE" not in f or "WRITE_SIZE" not in w:
+            return None, "no FETCH_SIZE / WRITE_SIZE rows for k1_dfa in the child runs' output"
+        out = {"traffic": (f["FETCH_SIZE"][0] * 2 + w["WRITE_SIZE"][0]) * 1024,
+               "traffic_source": f"MEASURED in this run: child runs `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) of `bench.py --fast --steps 3 --warmup 1`, "
+                                 f"{f['FETCH_SIZE'][1]} / {w['WRITE_SIZE'][1]} k1_dfa dispatches averaged; FETCH_SIZE doubled (gfx950: 64 B counted per 128-B request)"}
+        q = _pmc_child(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_ANY"], "k2b_dp")
+        if "SQ_INSTS_VALU" in q:
+            out["scorer"] = {k: v[0] for k, v in q.items()}
+            out["scorer"]["dispatches"] = q["SQ_INSTS_VALU"][1]
+        return out, None
+    except Exception as e:
+        return None, f"{type(e).__name__}: {e}"
+
+
 def stored_json(name):
     p = os.path.join(ROOT, "profiles", name)
     try:
@@ -217,10 +271,11 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4-shard / C5 block")
     ap.add_argument("--no-check", action="store_true", help="skip the 1M-item oracle comparison")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-streams throughput figure")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child runs; report the stored traffic figure")
     ap.add_argument("--fast", action="store_true", help="= --no-cpu-baseline --no-configs --no-check --no-two-in-flight (profiling runs)")
     args = ap.parse_args()
     if args.fast:
-        args.no_cpu_baseline = args.no_configs = args.no_check = args.no_two_in_flight = True
+        args.no_cpu_baseline = args.no_configs = args.no_check = args.no_two_in_flight = args.no_live_traffic = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -387,6 +442,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k1_dfa", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr.get("k1_filter_hbm_bytes_per_launch"),
                          "traffic_source": "STORED, not measured in this run: profiles/latest_traffic.json (" + str(tr.get("source")) + ")",
+                         "traffic_stored": tr.get("k1_filter_hbm_bytes_per_launch"),
                          "bytes_per_launch": filt_bytes, "avg_kernel_ms": st["filter"], "launches_averaged": st["calls"]},
             "roofline_step": step_roofline(n * HAY_LEN, n, n_matches, ms_per_step, ends_read=False),
             "stages": {"filter_ms": st["filter"], "compaction_ms": st["compaction_and_window"], "scorer_ms": st["scorers"], "device_pipeline_ms": st["total"], "scorer": scorer,
@@ -434,6 +490,22 @@ def main():
             del m2
             if not args.no_configs:
                 res["configs"] = other_configs(F, synth, dev, 10)
+            if not args.no_live_traffic:
+                torch.cuda.synchronize(dev)
+                lc_, why = live_counters()
+                if lc_ is not None:
+                    res["roofline"]["traffic"] = lc_["traffic"]
+                    res["roofline"]["traffic_source"] = lc_["traffic_source"]
+                    if "scorer" in lc_ and st["scorers"] > 0:
+                        clk = (stored_json("latest_sq.json") or {}).get("shader_clock_GHz", 2.25)
+                        sc_ = res["stages"]["scorer"]
+                        sc_.update({"valu_wave_instructions_per_launch": lc_["scorer"]["SQ_INSTS_VALU"], "salu_wave_instructions_per_launch": lc_["scorer"].get("SQ_INSTS_SALU"),
+                                    "issue_quad_cycles_all_instructions_per_launch": lc_["scorer"].get("SQ_ACTIVE_INST_ANY"),
+                                    "issue_frac": lc_["scorer"]["SQ_INSTS_VALU"] * 4 / (4 * 256 * st["scorers"] * 1e-3 * clk * 1e9),
+                                    "issue_frac_all_instructions": (lc_["scorer"]["SQ_ACTIVE_INST_ANY"] * 4 / (4 * 256 * st["scorers"] * 1e-3 * clk * 1e9)) if "SQ_ACTIVE_INST_ANY" in lc_["scorer"] else None,
+                                    "counters_source": f"MEASURED in this run: child run `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY` of `bench.py --fast --steps 3 --warmup 1`, {lc_['scorer']['dispatches']} scorer dispatches averaged"})
+                else:
+                    res["roofline"]["traffic_source"] += "; live collection failed: " + why
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(rows, min(n, 10_000_000), args.max_typos)
                 res["gpu_over_cpu"] = res["value"] / res["cpu_baseline"]["value"]
