@@ -106,7 +106,8 @@ struct LaunchCfg {
     int window_mode;    // 0 = from the lane-exact prefilter kernel, 1 = inline first/last occurrence (ASCII 0 typos), 2 = full haystack
     int bias_ok;        // DP gap propagation may run in the biased domain (no u16 overflow possible)
     int pad_ok;         // needle has no NUL byte: zero-padding lanes can never match (enables the padded-half DP form)
-    int cf_ok;          // single-chunk scorer in its second form (dp_cf.h): pad_ok, bias_ok and 2 * gap_extend <= mismatch_penalty
+    int cf_ok;
+    int cfm_ok;  // dp_cfm.h preconditions (multi-chunk windows in the biased domain)          // single-chunk scorer in its second form (dp_cf.h): pad_ok, bias_ok and 2 * gap_extend <= mismatch_penalty
     int num_cus;
     u32 dead_byte;      // a byte value no needle row can match (used to neutralise bytes past a haystack's end in the DFA filter)
 };
@@ -143,7 +144,7 @@ bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
                            int num_cus, hipStream_t st);
-void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
+void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int mode,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_unicode.hip
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,

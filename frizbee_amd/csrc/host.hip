@@ -394,6 +394,8 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
     // biased gap propagation needs max cell value + lanes*gex (+ headroom) to stay below 2^16
     lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
+    lc.cfm_ok = 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty &&
+                max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 200 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;  // dp_cfm.h: lanes up to 3/2 chunks + rows of bias
     lc.cf_ok = lc.pad_ok && lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty;  // dp_cf.h preconditions
     *out = m;
     return FZB_OK;
@@ -906,7 +908,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         if (!no_wide) {
             const int mgrid = cus * 4;  // 2 waves per SIMD (the kernel is capped at 256 VGPRs)
             if ((rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
-            fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, lc.bias_ok, outp, cap32, w.dp_scratch, mgrid, st);
+            fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, (lc.cfm_ok && !getenv("FZB_NO_DP_CFM")) ? 2 : lc.bias_ok ? 1 : 0, outp, cap32, w.dp_scratch, mgrid, st);
             FZB_STAGE("dp_multi");
             if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
                 fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, cnt_c,

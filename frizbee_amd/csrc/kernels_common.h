@@ -56,8 +56,8 @@ __device__ __forceinline__ u32 fzb_sadd(u32 a, u32 b) {
 #ifdef FZB_HOST_SHIM  // tests/kernel_host: the same arithmetic compiled for the host
     return a + b;
 #else
-    u32 r;
-    asm volatile("s_add_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc");
+    u32 r;  // operands must be wave-uniform; readfirstlane is free when the compiler already holds them in scalar registers
+    asm volatile("s_add_u32 %0, %1, %2" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane(a)), "s"(__builtin_amdgcn_readfirstlane(b)) : "scc");
     return r;
 #endif
 }

@@ -14,7 +14,7 @@
 // Gap propagation runs in a biased domain r'[L] = r[L] + L*gex, where "shift by k and pay k*gex" becomes a
 // plain shift; since every row value is >= 0 the saturating subtract of the reference is preserved exactly
 // (see DESIGN.md).  BIAS=false keeps the literal 3-op form for scorings where the bias could overflow u16.
-#include "dp_cf.h"
+#include "dp_cfm.h"
 #include <cstdlib>
 
 // MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h), 2: biased domain throughout + closed-form
@@ -486,8 +486,58 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi(const u8* __restrict__ by
     }
 }
 
-void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int bias_ok,
+// the same list through dp_cfm.h's form (LaunchCfg::cfm_ok); bonuses from the LDS tables as in the other dp_cf.h kernels
+template <int SWL, bool UPPER, typename ET>
+__global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+                                                      const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
+                                                      fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
+    __shared__ CfTables tab;
+    cf_build_tables<UPPER>(nd, tab);
+    __syncthreads();
+    const u32 nlist = *n_list_ptr;
+    const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u32 q = gtid; q < nlist; q += nthreads) {
+        const u32 opos = list[4 * q], ws = list[4 * q + 1], we = list[4 * q + 2], li = list[4 * q + 3];
+        if (opos >= capacity) continue;
+        u64 s;
+        u32 L;
+        haystack_span(ends, first + li, s, L);
+        const u8* hay = bytes + s;
+        const u32 sp = ws ? ws - 1 : 0;
+        const bool include_exact = sp == 0 && we == L;
+        const u32 m = we - sp;
+        u32 score = dp_multi_chunk_t<SWL, UPPER>(nd, hay + sp, m, sp == 0, tab, scratch, nthreads, gtid);
+        bool exact = include_exact && m == (u32)nd.nbytes;
+        if (exact)
+            for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+        if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+        fzb_match_rec rec;
+        rec.index = index_offset + li;
+        rec.score = (u16)score;
+        rec.exact = exact ? 1 : 0;
+        rec.valid = 0;
+        out[opos] = rec;
+    }
+}
+
+// mode: 0 = unbiased scan, 1 = dp_body.h's biased scan (bias_ok), 2 = dp_cfm.h (cfm_ok)
+void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int mode,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st) {
+    const int bias_ok = mode >= 1;
+    if (mode == 2) {
+        bool upper = false;
+        for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+#define FZB_K2T(SWL, U, ET) hipLaunchKernelGGL((k2d_dp_multi_t<SWL, U, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch)
+#define FZB_K2T_ET(SWL, U) do { if (c.ends_u64) FZB_K2T(SWL, U, u64); else FZB_K2T(SWL, U, u32); } while (0)
+#define FZB_K2T_U(SWL) do { if (upper) FZB_K2T_ET(SWL, true); else FZB_K2T_ET(SWL, false); } while (0)
+        switch (sw_lanes) {
+            case 64: FZB_K2T_U(64); break;
+            case 32: FZB_K2T_U(32); break;
+            case 16: FZB_K2T_U(16); break;
+            default: FZB_K2T_U(8); break;
+        }
+        return;
+    }
 #define FZB_K2D(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_multi<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch)
 #define FZB_K2D_ET(SWL, B) do { if (c.ends_u64) FZB_K2D(SWL, B, u64); else FZB_K2D(SWL, B, u32); } while (0)
 #define FZB_K2D_B(SWL) do { if (bias_ok) FZB_K2D_ET(SWL, true); else FZB_K2D_ET(SWL, false); } while (0)

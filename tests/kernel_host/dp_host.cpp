@@ -1,7 +1,8 @@
 // TEST INFRASTRUCTURE: compiles the DEVICE arithmetic of the single-chunk Smith-Waterman bodies (frizbee_amd/csrc/dp_body.h,
 // dp_cf.h) for the host through tests/kernel_host/shim, one "thread" at a time, so that tests can fuzz the exact code the GPU runs
 // against the oracle without a GPU.  Built by tests/kernel_host_lib.py with ROCm's clang++ (-x c++); never part of the product.
-#include "dp_cf.h"
+#include <vector>
+#include "dp_cfm.h"
 
 static u16 sadd16(u32 a, u32 b) { return (u16)(a + b > 0xFFFF ? 0xFFFF : a + b); }
 static u16 ssub16(u32 a, u32 b) { return (u16)(a > b ? a - b : 0); }
@@ -61,6 +62,21 @@ static int run(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, in
     return -2;
 }
 
+// multi-chunk windows (swl < m <= 1024): form 5 = dp_multi_chunk (first form, biased scan), 6 = dp_multi_chunk_t (dp_cfm.h)
+template <int SWL>
+static int run_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, int form, const u8* cls) {
+    static u32 scratch[(FZB_MAX_ROWS + 1) * (SWL / 2) + 64];
+    std::vector<u8> buf(m + 96, 0);
+    memcpy(buf.data(), hay, m);
+    bool upper = false;
+    for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+    if (form == 5) return (int)dp_multi_chunk<SWL, true>(nd, buf.data(), m, include_prefix, cls, scratch, 1, 0);
+    CfTables tab;
+    for (unsigned t = 0; t < 16; t++) { threadIdx.x = t; if (upper) cf_build_tables<true>(nd, tab); else cf_build_tables<false>(nd, tab); }
+    threadIdx.x = 0;
+    return upper ? (int)dp_multi_chunk_t<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0) : (int)dp_multi_chunk_t<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0);
+}
+
 extern "C" {
 // form: 0 = dp_single_chunk biased, 1 = literal (unbiased) scan, 2 = its padded-half form, 3 = dp_single_chunk_cf with `real` dwords,
 // 4 = dp_single_chunk_cf_tab (LDS-table set-up, swl/4 dwords).
@@ -76,6 +92,22 @@ int kh_dp_single(const u8* needle, int n, int case_sensitive, const u16* scoring
         case 32: return run<32>(nd, hay, (u32)m, include_prefix, form, real, cls);
         case 16: return run<16>(nd, hay, (u32)m, include_prefix, form, real, cls);
         case 8: return run<8>(nd, hay, (u32)m, include_prefix, form, real, cls);
+    }
+    return -1;
+}
+
+int kh_dp_multi(const u8* needle, int n, int case_sensitive, int is_u8, const u16* scoring, const u8* hay, int m, int include_prefix, int swl, int form) {
+    if (n < 1 || n > FZB_MAX_ROWS || m <= swl || m > 1024) return -1;
+    NeedleDev nd;
+    fill_needle(nd, needle, n, case_sensitive, scoring);
+    nd.lane_mask = is_u8 ? 0xFF : 0xFFFF;
+    static u8 cls[256];
+    build_cls_table(cls);
+    switch (swl) {
+        case 64: return run_multi<64>(nd, hay, (u32)m, include_prefix, form, cls);
+        case 32: return run_multi<32>(nd, hay, (u32)m, include_prefix, form, cls);
+        case 16: return run_multi<16>(nd, hay, (u32)m, include_prefix, form, cls);
+        case 8: return run_multi<8>(nd, hay, (u32)m, include_prefix, form, cls);
     }
     return -1;
 }

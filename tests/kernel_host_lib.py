@@ -20,7 +20,7 @@ def available():
 def build():
     so = os.path.join(HERE, "libkernel_host.so")
     srcs = [os.path.join(HERE, "dp_host.cpp"), os.path.join(HERE, "shim", "hip", "hip_runtime.h")] + [
-        os.path.join(CSRC, f) for f in ("dp_body.h", "dp_cf.h", "kernels_common.h", "fzb_internal.h")]
+        os.path.join(CSRC, f) for f in ("dp_body.h", "dp_cf.h", "dp_cfm.h", "kernels_common.h", "fzb_internal.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + os.path.join(HERE, "shim"), "-I" + CSRC,
                                "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-o", so, os.path.join(HERE, "dp_host.cpp")])
@@ -36,6 +36,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.kh_dp_single.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
+        _lib.kh_dp_multi.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
@@ -51,6 +52,12 @@ def window(needle, hay, case_sensitive=False):
     out = (C.c_uint32 * 4)()
     assert lib().kh_window(needle, len(needle), int(case_sensitive), hay, len(hay), out) == 0
     return (out[0], out[1]), (out[2], out[3])
+
+
+def dp_multi(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=64, form=6, is_u8=True):
+    """score of a window wider than one chunk (swl < len(hay) <= 1024): form 5 = first form (dp_body.h), 6 = dp_cfm.h"""
+    sc = (C.c_uint16 * 9)(*scoring)
+    return lib().kh_dp_multi(needle, len(needle), int(case_sensitive), int(is_u8), sc, hay, len(hay), int(include_prefix), swl, form)
 
 
 def window_typos(needle, hay, max_typos, case_sensitive=False):

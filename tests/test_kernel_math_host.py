@@ -164,3 +164,47 @@ def test_short_kernel_typo_window_equals_the_reference_prefilter_window():
                 assert got == (ws, we), (needle, hay, k, cs, lanes, got, (ws, we))
                 checked += 1
     assert checked > 8000
+
+
+@pytest.mark.parametrize("swl", [64, 32, 16, 8])
+def test_multi_chunk_windows_both_forms_match_the_oracle(swl):
+    """windows wider than one chunk (dp_body.h's dp_multi_chunk and dp_cfm.h's dp_multi_chunk_t): the adjacent chunk's parked rows, the
+    carry of the last lane across the chunk boundary, the last chunk's unpropagated last row - against score_haystack's multi-chunk
+    loop (ascii.rs:91-158) with propagate_horizontal_gaps's adjacent vector (ascii_gap.rs:11-105)"""
+    rng = random.Random(500 + swl)
+    for it in range(500):
+        alpha = rng.choice([b"ab", b"abcA_", b"abcdefABCDEF_-/ 019", bytes(range(33, 127))])
+        n = rng.randint(1, 14)
+        needle = _rnd(rng, n, alpha)
+        cs = rng.random() < 0.3
+        sc = DEF
+        if rng.random() < 0.5:
+            while True:
+                sc = [rng.randint(0, 40), rng.randint(0, 20), rng.randint(0, 20), rng.randint(0, 6), rng.randint(0, 30), rng.randint(0, 12), rng.randint(0, 12),
+                      rng.randint(0, 20), rng.randint(0, 12)]
+                if 2 * sc[3] <= sc[1]:  # LaunchCfg::cfm_ok
+                    break
+        m = rng.randint(swl + 1, min(1024, swl * rng.choice([2, 2, 3, 5, 16])))
+        if it % 50 == 0:
+            m = rng.choice([swl + 1, 2 * swl, 2 * swl + 1, min(1024, 16 * swl)])
+        hay = _rnd(rng, m, alpha)
+        if rng.random() < 0.5:
+            for q, c in zip(sorted(rng.sample(range(m), min(n, m))), needle):
+                hay = hay[:q] + bytes([c]) + hay[q + 1:]
+        ip = rng.random() < 0.5
+        u8 = _fits(n, sc)
+        want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, lanes=swl, is_u8=u8)
+        for form in (5, 6):
+            got = K.dp_multi(needle, hay, sc, cs, ip, swl, form, u8)
+            assert got == want, (needle, hay, sc, cs, ip, swl, form, got, want)
+
+
+def test_multi_chunk_biased_form_at_the_largest_values_it_is_configured_for():
+    # cfm_ok's bound: 63 rows, the maximal default-scoring values, 1024-byte window of matches
+    needle = b"a" * 63
+    hay = b"a" * 1024
+    for swl in (64, 32):
+        u8 = _fits(63, DEF)
+        want = O.sw_score(needle, hay, scoring=DEF, case_sensitive=False, include_prefix=True, lanes=swl, is_u8=u8)
+        assert K.dp_multi(needle, hay, DEF, False, True, swl, 6, u8) == want
+        assert K.dp_multi(needle, hay, DEF, False, True, swl, 5, u8) == want
