@@ -88,6 +88,12 @@ struct Workspace {
     u32* cls_win;       // classified scoring (corpora with longer haystacks): window per survivor, three class lists
     u32* cls_lists;     //   [3][cap]; class counts in counters[8..10]
     size_t cap_cls;
+    u16* fused_tile_counts;      // k12_fused: survivors per 256-haystack tile, per group of 4 tiles (zero between launches), and the
+    u32* fused_group_counts;     //   staging array (256 record slots per tile) that k_fused_gather packs
+    fzb_match_rec* fused_stage;
+    size_t fused_cap;            // haystacks the three are sized for (0 = not allocated)
+    size_t fused_groups;         // entries of ONE of the two group-count arrays (alternate launches use alternate arrays)
+    int fused_flip;
     u64* table;         // 256 x u64 filter table (device)
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     u8* uni_dfa;        // unicode path, 0 typos: states x 256 table of the exact prefilter's byte-level DFA (device)
@@ -140,6 +146,9 @@ void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                    int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st,
                    const RejectOut* rejects = nullptr);
+bool fzb_fused_applies(const CorpusDev& c, const LaunchCfg& lc, const NeedleDev& nd, int wmode);
+void fzb_launch_fused(const CorpusDev& c, u64 first, u32 count, u32 index_offset, const u8* dfa, const NeedleDev& nd, int sw_lanes, int wmode, u32 min_len, u16* tile_counts,
+                      u32* group_counts, u32* group_counts_next, fzb_match_rec* stage, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int num_cus, hipStream_t st);
 bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,

@@ -213,7 +213,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.fused_tile_counts, w.fused_group_counts, w.fused_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -658,6 +658,22 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
 
 // ---- buffers beyond the per-range workspace, each grown by ONE helper so that fzb_matcher_reserve can size all of them ahead of
 // the first query (a re-query after every keystroke must not meet a hipFree / hipMalloc) --------------------------------------
+static int ensure_fused_buffers(fzb_matcher* m) {  // tile counts, group counts and the staging array of k12_fused, sized with the range workspace
+    Workspace& w = m->ws;
+    if (w.fused_cap >= w.cap_items && w.fused_stage) return FZB_OK;
+    for (void* p : {(void*)w.fused_tile_counts, (void*)w.fused_group_counts, (void*)w.fused_stage})
+        if (p) HIPCHK(hipFree(p));
+    w.fused_tile_counts = nullptr; w.fused_group_counts = nullptr; w.fused_stage = nullptr; w.fused_cap = 0;
+    const size_t tiles = w.cap_items / 256 + 8;
+    HIPCHK(dev_alloc((void**)&w.fused_tile_counts, tiles * 2));
+    w.fused_groups = (tiles / 16 + 8 + 3) & ~(size_t)3;  // 16-byte aligned halves
+    HIPCHK(dev_alloc((void**)&w.fused_group_counts, 2 * w.fused_groups * 4));
+    HIPCHK(hipMemset(w.fused_group_counts, 0, 2 * w.fused_groups * 4));  // every launch's gather kernel clears the array of the next one
+    w.fused_flip = 0;
+    HIPCHK(dev_alloc((void**)&w.fused_stage, tiles * 256 * sizeof(fzb_match_rec)));
+    w.fused_cap = w.cap_items;
+    return FZB_OK;
+}
 static int ensure_dp_scratch(fzb_matcher* m, int mgrid) {  // parked rows of the multi-chunk scorer
     Workspace& w = m->ws;
     const size_t words = (size_t)(m->nd.rows + 1) * (size_t)(m->lc.sw_lanes / 2) * (size_t)mgrid * 128;
@@ -843,6 +859,22 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("compact1");
         items = w.surv_idx;
         uni_exact = true;
+    } else if (!trace && fzb_fused_applies(cd, lc, nd, lc.window_mode)) {
+        // ---- ASCII, 0 typos, every haystack fits half a chunk: filter, ordering and scorer in one persistent kernel (kernels_fused.hip) ----
+        if ((rc = ensure_fused_buffers(m))) return rc;  // first use only (or fzb_matcher_reserve)
+        if (pev) HIPCHK(hipEventRecord(pev[2], st));
+        fzb_launch_fused(cd, first, cnt, index_offset, w.dfa, nd, lc.sw_lanes, lc.window_mode, (u32)nd.min_haystack_len, w.fused_tile_counts, w.fused_group_counts + (size_t)w.fused_flip * w.fused_groups,
+                         w.fused_group_counts + (size_t)(w.fused_flip ^ 1) * w.fused_groups, w.fused_stage,
+                         (fzb_match_rec*)dev_out, cap32, dev_count, w.counters, cus, st);
+        w.fused_flip ^= 1;
+        if (pev) {
+            HIPCHK(hipEventRecord(pev[3], st));
+            HIPCHK(hipEventRecord(pev[4], st));
+            HIPCHK(hipEventRecord(pev[1], st));
+        }
+        FZB_STAGE("fused filter+scorer");
+        HIPCHK(hipGetLastError());
+        return FZB_OK;
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2], st));

@@ -9,6 +9,7 @@
 //     path, where this stage only looks at each scalar's LAST byte - this stage is a conservative superset
 //     and the lane-exact prefilter (kernels_window.hip) re-decides every survivor.
 #include "kernels_common.h"
+#include "dfa_lds.h"
 #include <algorithm>
 #include <cstdlib>
 
@@ -134,31 +135,6 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
 // from HBM up front.  The table has (rows + 1) * 256 bytes; 4 byte values share a dword, so the
 // alphanumerics of one state row spread over distinct LDS banks.
 // ---------------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ u32 dfa_step(u32 st, u32 w, const u8* dfa) {
-    // address = (st << 8) | byte K of w  (v_perm_b32: byte0 <- w.byteK, byte1 <- st.byte0, bytes 2,3 <- 0)
-    const u32 addr = __builtin_amdgcn_perm(st, w, 0x0c0c0400u | (u32)K);
-    return dfa[addr];
-}
-__device__ __forceinline__ void dfa_word4(u32 (&st)[4], const u32 (&w)[4], const u8* dfa) {
-#pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<0>(st[p], w[p], dfa);
-#pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<1>(st[p], w[p], dfa);
-#pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<2>(st[p], w[p], dfa);
-#pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<3>(st[p], w[p], dfa);
-}
-__device__ __forceinline__ u32 dfa_partial(u32 st, const uint4& q, u32 nbytes, const u8* dfa) {
-    const u32 w4[4] = {q.x, q.y, q.z, q.w};
-    for (u32 k = 0; k < nbytes; k++) {
-        const u32 b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
-        st = dfa[(st << 8) | b];
-    }
-    return st;
-}
-
 template <typename ET>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                               const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
@@ -166,8 +142,10 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
     // compaction kernel reads it
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
+    // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
+    // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    __shared__ u32 s_cnt;
+    u32& s_cnt = *(u32*)(dfa + (rows + 1) * 256);
     const int tid = threadIdx.x;
     for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
@@ -244,12 +222,16 @@ template <int P>
 __device__ __forceinline__ void dfa_wordP(u32 (&st)[P], const u32 (&w)[P], const u8* dfa) {
 #pragma unroll
     for (int p = 0; p < P; p++) st[p] = dfa_step<0>(st[p], w[p], dfa);
+    if (P > 1) FZB_WAIT_LDS();
 #pragma unroll
     for (int p = 0; p < P; p++) st[p] = dfa_step<1>(st[p], w[p], dfa);
+    if (P > 1) FZB_WAIT_LDS();
 #pragma unroll
     for (int p = 0; p < P; p++) st[p] = dfa_step<2>(st[p], w[p], dfa);
+    if (P > 1) FZB_WAIT_LDS();
 #pragma unroll
     for (int p = 0; p < P; p++) st[p] = dfa_step<3>(st[p], w[p], dfa);
+    if (P > 1) FZB_WAIT_LDS();
 }
 
 // SAN = false (needle without a NUL byte): the zero fill between a haystack's end and its 16-byte boundary - and the zero vectors a lane
@@ -261,8 +243,10 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
     // compaction kernel reads it
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
+    // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
+    // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    __shared__ u32 s_cnt;
+    u32& s_cnt = *(u32*)(dfa + (rows + 1) * 256);
     const int tid = threadIdx.x;
     for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
@@ -352,16 +336,20 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
 // back and only then runs the DFA over them from registers.  In the rolling form above a 128-byte line is touched by ~8 loads
 // of a wave that are separated by the DFA work of every resident wave, and the CU's footprint (24 waves x 64 haystacks x up to
 // 128 B) is far beyond the vector L1, so most of those touches re-fetch the line from L2; issued back to back they hit.
-// C4 shard: 297 -> 242 us.  (Two or four haystacks per thread as interleaved DFA chains on top of it: 276 / 300 us - with 8 waves per SIMD
-// the lookup chain is already hidden, the extra registers and the longer rounds only cost.)
+// C4 shard: 297 -> 242 us.  (Two or four haystacks per thread as interleaved DFA chains on top of it: 276 / 300 us, and again 281 / 405 us after
+// the lookups were cut to v_perm + ds_read with one wait per round - with 8 waves per SIMD the lookup chain is already hidden; neither that
+// nor removing a quarter of the loop's instructions moved the kernel, so it is bound by its cache transactions: every 16-byte piece of a
+// lane is its own request, ~35 lines per wave instruction.)
 // ---------------------------------------------------------------------------------------------------
 template <typename ET, bool SAN>
 __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                                            const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
                                                            u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
+    // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
+    // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    __shared__ u32 s_cnt;
+    u32& s_cnt = *(u32*)(dfa + (rows + 1) * 256);
     const int tid = threadIdx.x;
     for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
@@ -672,7 +660,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     if (mode == 1) {
-        const size_t lds = (size_t)(rows + 1) * 256;
+        const size_t lds = (size_t)(rows + 1) * 256 + 16;  // table + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
             if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.uniform_len);
