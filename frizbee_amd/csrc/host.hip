@@ -338,7 +338,7 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     // bytes or as the bytes of its same-width case flip (src/prefilter/algo/unicode.rs:118-219; the same at 16 / 32 / 64 lanes - checked
     // against the oracle by tests/test_host_abi.py::test_unicode_dfa_is_the_unicode_prefilter).  That is a byte-level DFA: state = (scalars
     // matched, bytes of the current scalar matched, which of the two variants are still alive); a mismatch inside a scalar falls back to
-    // "is this byte the scalar's first byte" (UTF-8 lead bytes never occur inside a scalar, so no longer border exists).  With <= 255
+    // "is this byte the scalar's first byte" (UTF-8 lead bytes never occur inside a scalar, so no longer border exists).  With <= 226
     // states it runs in the streaming DFA filter kernels unchanged and replaces superset filter + lane-exact window pass + second compaction.
     m->uni_dfa_states = 0;
     if (m->unicode && !m->literal_mode && config->max_typos == 0 && m->rows >= 1 && lc.filter_mode == 1) {
@@ -373,7 +373,7 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
                 }
             }  // i == rows: accepting, absorbing
             trans.push_back(row);
-            if (states.size() > 255) ok = false;
+            if (states.size() > 226) ok = false;  // 226 x 288 bytes (dfa_lds.h's row stride) + the tile counter fit the 64 KiB of dynamic LDS
         }
         if (ok) {
             // renumber so that the accepting state is the LAST one (the kernels test `state == number of states - 1`)
@@ -692,7 +692,7 @@ static int ensure_sort_buffers(fzb_matcher* m, size_t cap) {  // ping-pong buffe
     if (w.sort_hist) HIPCHK(hipFree(w.sort_hist));
     w.sort_tmp = nullptr; w.sort_hist = nullptr; w.sort_cap = 0;
     HIPCHK(dev_alloc((void**)&w.sort_tmp, (cap + 16) * sizeof(fzb_match_rec)));
-    HIPCHK(dev_alloc((void**)&w.sort_hist, (size_t)256 * (cap / 2048 + 2) * 4));
+    HIPCHK(dev_alloc((void**)&w.sort_hist, (size_t)2 * 256 * (cap / 2048 + 2) * 4));  // tile histograms + their scan
     w.sort_cap = cap;
     return FZB_OK;
 }
@@ -975,6 +975,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     if (rc) return rc;
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
     if (!m->literal_mode && !m->nd.unicode && !no_wide && (rc = ensure_dp_scratch(m, m->lc.num_cus * 4))) return rc;
+    if (fzb_fused_applies(c->dev, m->lc, m->nd, m->lc.window_mode) && (rc = ensure_fused_buffers(m))) return rc;
     if ((rc = ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;
     return FZB_OK;
@@ -1524,7 +1525,7 @@ int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match**
             if (mm->sort_hist) (void)hipFree(mm->sort_hist);
             mm->sort_tmp = nullptr; mm->sort_hist = nullptr; mm->sort_cap = 0;
             HIPCHK(dev_alloc((void**)&mm->sort_tmp, (count + 16) * sizeof(fzb_match_rec)));
-            HIPCHK(dev_alloc((void**)&mm->sort_hist, (size_t)256 * (count / 2048 + 2) * 4));
+            HIPCHK(dev_alloc((void**)&mm->sort_hist, (size_t)2 * 256 * (count / 2048 + 2) * 4));
             mm->sort_cap = count;
         }
         fzb_launch_sort(mm->out_dev, mm->sort_tmp, mm->count_dev, mm->sort_hist, (u32)(mm->sort_cap / 2048 + 2), reversed, by_score, mm->num_cus * 2, nullptr);

@@ -145,9 +145,9 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
     // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    u32& s_cnt = *(u32*)(dfa + (rows + 1) * 256);
+    u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
     const int tid = threadIdx.x;
-    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
+    dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (tid == 0) s_cnt = 0;
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
     // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    u32& s_cnt = *(u32*)(dfa + (rows + 1) * 256);
+    u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
     const int tid = threadIdx.x;
-    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
+    dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     const u32 deadv = dead * 0x01010101u;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -349,9 +349,9 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
     // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    u32& s_cnt = *(u32*)(dfa + (rows + 1) * 256);
+    u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
     const int tid = threadIdx.x;
-    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(dfa + i) = *(const u32*)(dfa_g + i);
+    dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     const u32 deadv = dead * 0x01010101u;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -660,7 +660,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     if (mode == 1) {
-        const size_t lds = (size_t)(rows + 1) * 256 + 16;  // table + the tile counter
+        const size_t lds = (size_t)(rows + 1) * 288 + 16;  // table (FZB_DFA_STRIDE per state) + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
             if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.uniform_len);

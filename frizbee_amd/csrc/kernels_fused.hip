@@ -44,8 +44,8 @@
 #define FZB_FT 256u             // haystacks per wave tile
 #define FZB_FG_SHIFT 4          // tiles per group count: 16 (4096 haystacks)
 #define FZB_FUSED_QCAP 512u     // per wave: >= 95 left over + 256 new survivors; power of two
-#define FZB_FUSED_DFA_BYTES 16384u  // the DFA table's LDS region: (FZB_MAX_ROWS + 1) * 256
-static_assert((FZB_MAX_ROWS + 1) * 256 <= FZB_FUSED_DFA_BYTES, "DFA region");
+#define FZB_FUSED_DFA_BYTES 18432u  // the DFA table's LDS region: (FZB_MAX_ROWS + 1) * FZB_DFA_STRIDE
+static_assert((FZB_MAX_ROWS + 1) * FZB_DFA_STRIDE <= FZB_FUSED_DFA_BYTES, "DFA region");
 
 struct FusedShared {
     CfTables tab;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256, 4) void k12_fused(const u8* __restrict__ bytes
     const u8* dfa = lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const u32 wave = __builtin_amdgcn_readfirstlane((u32)tid >> 6);
-    for (int i = tid * 4; i < (rows + 1) * 256; i += 256 * 4) *(u32*)(lds + i) = *(const u32*)(dfa_g + i);
+    dfa_load_lds(lds, dfa_g, rows);
     cf_build_tables<UPPER>(nd, sh.tab);
     __syncthreads();  // the only barrier
     const u32 ntiles = (count + FZB_FT - 1) / FZB_FT;

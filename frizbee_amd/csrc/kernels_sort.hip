@@ -33,12 +33,15 @@ __global__ __launch_bounds__(256) void k_sort_hist(const fzb_match_rec* __restri
     }
 }
 
-// exclusive scan, in place, of the digit-major histogram: 256 rows of `ntiles` live entries (row stride ntiles_cap)
-__global__ __launch_bounds__(1024) void k_sort_scan(u32* __restrict__ hist, const u32* __restrict__ n_ptr, u32 ntiles_cap) {
+// exclusive scan of the digit-major histogram (256 rows of `ntiles` live entries, row stride ntiles_cap) into `offs` (same layout)
+__global__ __launch_bounds__(1024) void k_sort_scan(const u32* __restrict__ hist, u32* __restrict__ offs, const u32* __restrict__ n_ptr, u32 ntiles_cap) {
     // Exclusive scan of the digit-major tile histogram, element (digit d, tile t) at hist[d * ntiles_cap + t], in the order
-    // (d, t) lexicographic.  One workgroup of 16 waves, a wave owns 16 digits: (1) per-digit totals (lanes stride over the tiles:
-    // coalesced, no index arithmetic per element - the first version linearised (d, t) and paid a division and a modulo per
-    // element, 59 us for 244 tiles), (2) scan of the 256 totals, (3) per digit, a wave scan over its tiles from the digit's base.
+    // (d, t) lexicographic.  16 workgroups of 16 waves.  Every workgroup computes (1) all 256 per-digit totals itself (a wave owns 16
+    // digits, lanes stride over the tiles: coalesced, no index arithmetic per element - the first version linearised (d, t) and paid a
+    // division and a modulo per element, 59 us for 244 tiles) and (2) their scan; then (3) workgroup b scans the tiles of ITS 16 digits,
+    // one digit per wave, from the digit's base.  With one workgroup doing (3) for all 256 digits - 16 per wave, 96 dependent shuffles
+    // per chunk of 64 tiles - the kernel took 32 us; the redundant (1) costs reads of an L2-resident 250 KB.  Not in place: another
+    // workgroup may still be reducing the rows this one scans.
     __shared__ u32 dtot[256];
     const u32 n = *n_ptr;
     const u32 ntiles = (n + SORT_TILE - 1) / SORT_TILE;
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(1024) void k_sort_scan(u32* __restrict__ hist, cons
         }
     }
     __syncthreads();
-    if (wave == 0) {  // exclusive scan of the 256 digit totals: 4 per lane
+    if (wave == 0) {  // (2) exclusive scan of the 256 digit totals: 4 per lane
         u32 v[4], s4 = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) { v[k] = dtot[lane * 4 + k]; s4 += v[k]; }
@@ -74,27 +77,19 @@ __global__ __launch_bounds__(1024) void k_sort_scan(u32* __restrict__ hist, cons
         for (int k = 0; k < 4; k++) { dtot[lane * 4 + k] = run; run += v[k]; }
     }
     __syncthreads();
-    {  // (3) per digit, a wave scan over its tiles from the digit's base - again the 16 digits of the wave side by side
-        u32 carry[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) carry[k] = dtot[wave * 16 + k];
+    {  // (3) this workgroup's digits, one per wave: a wave scan over the digit's tiles from its base
+        const u32 d = blockIdx.x * 16 + wave;
+        u32 carry = dtot[d];
         for (u32 t0 = 0; t0 < ntiles; t0 += 64) {  // uniform trip count: every lane takes part in the shuffles
             const u32 t = t0 + lane;
-            u32 v[16], incl[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) incl[k] = v[k] = t < ntiles ? hist[(size_t)(wave * 16 + k) * ntiles_cap + t] : 0u;
+            const u32 v = t < ntiles ? hist[(size_t)d * ntiles_cap + t] : 0u;
+            u32 incl = v;
             for (int off = 1; off < 64; off <<= 1) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const u32 x = __shfl_up(incl[k], off);
-                    if (lane >= off) incl[k] += x;
-                }
+                const u32 x = __shfl_up(incl, off);
+                if (lane >= off) incl += x;
             }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                if (t < ntiles) hist[(size_t)(wave * 16 + k) * ntiles_cap + t] = carry[k] + incl[k] - v[k];
-                carry[k] += __shfl(incl[k], 63);
-            }
+            if (t < ntiles) offs[(size_t)d * ntiles_cap + t] = carry + incl - v;
+            carry += __shfl(incl, 63);
         }
     }
 }
@@ -156,7 +151,7 @@ __global__ __launch_bounds__(256) void k_reverse(fzb_match_rec* __restrict__ a, 
     }
 }
 
-// records: `buf` (n = *n_ptr records, capacity cap) sorted in place; tmp >= cap records; hist >= 256 * ntiles_cap words
+// records: `buf` (n = *n_ptr records, capacity cap) sorted in place; tmp >= cap records; hist >= 2 * 256 * ntiles_cap words
 __global__ __launch_bounds__(256) void k_sort_copy_back(const fzb_match_rec* __restrict__ tmp, fzb_match_rec* __restrict__ buf, const u32* __restrict__ n_ptr) {
     const u32 n = *n_ptr;
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) buf[i] = tmp[i];
@@ -167,10 +162,11 @@ __global__ __launch_bounds__(256) void k_sort_copy_back(const fzb_match_rec* __r
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st, int passes) {
     if (reverse_first) hipLaunchKernelGGL(k_reverse, dim3(grid), dim3(256), 0, st, buf, n_ptr);
     if (!by_score) return;
+    u32* offs = hist + (size_t)256 * ntiles_cap;  // the scanned histogram (second half of the buffer)
     if (passes == 1) {
         hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, buf, n_ptr, 0, hist, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, hist, n_ptr, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, buf, tmp, n_ptr, 0, hist, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, buf, tmp, n_ptr, 0, offs, ntiles_cap);
         hipLaunchKernelGGL(k_sort_copy_back, dim3(grid), dim3(256), 0, st, tmp, buf, n_ptr);
         return;
     }
@@ -179,7 +175,7 @@ void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u
         fzb_match_rec* dst = pass == 0 ? tmp : buf;
         const int shift = pass * 8;
         hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, src, n_ptr, shift, hist, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, st, hist, n_ptr, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, src, dst, n_ptr, shift, hist, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, src, dst, n_ptr, shift, offs, ntiles_cap);
     }
 }
