@@ -988,18 +988,25 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
 
 int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream) {
     if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
-    int rc = fzb_match_list_device(m, c, 0, c->dev.n, 0, dev_out, capacity, dev_count, stream);
-    if (rc) return rc;
     const int sort = m->config.sort;
     const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;          // src/matcher/mod.rs:215-217
     const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;  // :218-220
-    if ((!reversed && !by_score) || c->dev.n == 0) return FZB_OK;
     Workspace& w = m->ws;
     const size_t cap = std::min<size_t>(capacity, c->dev.n);
-    if (by_score && (rc = ensure_sort_buffers(m, cap))) return rc;
     // one radix pass is enough when no score can reach 256 (Scoring::guard's bound on the matrix + the exact-match bonus added after it)
     const bool one_pass = !m->literal_mode && max_matrix_score(m->config.scoring, (size_t)m->rows) + (size_t)m->config.scoring.exact_match_bonus < 256;
-    fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream, one_pass ? 1 : 2);
+    // With a single pass the pipeline writes its index-ordered records into the sort's second buffer and the pass scatters them into the
+    // caller's array: no copy back.
+    const bool via_tmp = by_score && one_pass && !m->empty && c->dev.n != 0 && cap != 0;
+    int rc;
+    // (the range workspace first: growing it releases every workspace buffer, the sort's included)
+    if (via_tmp && ((rc = ensure_workspace(m, c->dev.n)) || (rc = ensure_sort_buffers(m, cap)))) return rc;
+    rc = fzb_match_list_device(m, c, 0, c->dev.n, 0, via_tmp ? (fzb_match*)w.sort_tmp : dev_out, via_tmp ? cap : capacity, dev_count, stream);
+    if (rc) return rc;
+    if ((!reversed && !by_score) || c->dev.n == 0) return FZB_OK;
+    if (by_score && !via_tmp && (rc = ensure_sort_buffers(m, cap))) return rc;
+    fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream,
+                    via_tmp ? -1 : one_pass ? 1 : 2);
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }

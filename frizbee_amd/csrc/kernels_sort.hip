@@ -160,9 +160,16 @@ __global__ __launch_bounds__(256) void k_sort_copy_back(const fzb_match_rec* __r
 // passes = 1: every score is known (on the host, from the scoring and the needle length) to be below 256, so the pass over the high
 // byte would move every record to where it already is - the sorted list is copied back instead (a 4 MB copy instead of a 45 us pass)
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st, int passes) {
-    if (reverse_first) hipLaunchKernelGGL(k_reverse, dim3(grid), dim3(256), 0, st, buf, n_ptr);
+    // passes = -1: one pass, and the unsorted records are in `tmp` already (the pipeline wrote them there): tmp -> buf, no copy back
+    if (reverse_first) hipLaunchKernelGGL(k_reverse, dim3(grid), dim3(256), 0, st, passes == -1 ? tmp : buf, n_ptr);
     if (!by_score) return;
     u32* offs = hist + (size_t)256 * ntiles_cap;  // the scanned histogram (second half of the buffer)
+    if (passes == -1) {
+        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, tmp, n_ptr, 0, hist, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, tmp, buf, n_ptr, 0, offs, ntiles_cap);
+        return;
+    }
     if (passes == 1) {
         hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, buf, n_ptr, 0, hist, ntiles_cap);
         hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap);
