@@ -11,6 +11,11 @@
 // moves every state's letters 8 banks on, so four consecutive states do not meet at all.  Costs one v_lshl_add per lookup.
 #define FZB_DFA_STRIDE 288u
 #define FZB_DFA_LDS_BYTES(rows) (((u32)(rows) + 1u) * FZB_DFA_STRIDE)
+// Kernels that use the ABS = true lookups call this first: a table that does not start at LDS address 0 (somebody added a static
+// __shared__ variable to the kernel) must stop the kernel, not read the wrong rows.
+__device__ __forceinline__ void dfa_require_lds_base0(const u8* lds) {
+    if ((u32)(uintptr_t)(const __attribute__((address_space(3))) u8*)lds != 0u) __builtin_trap();
+}
 __device__ __forceinline__ void dfa_load_lds(u8* lds, const u8* __restrict__ dfa_g, int rows) {  // every thread of the workgroup; sync afterwards
     for (u32 i = threadIdx.x * 4; i < ((u32)rows + 1) * 256; i += blockDim.x * 4) *(u32*)(lds + (i >> 8) * FZB_DFA_STRIDE + (i & 255)) = *(const u32*)(dfa_g + i);
 }

@@ -147,6 +147,7 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
     const int tid = threadIdx.x;
+    dfa_require_lds_base0(dfa);
     dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
     const int tid = threadIdx.x;
+    dfa_require_lds_base0(dfa);
     dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     const u32 deadv = dead * 0x01010101u;
@@ -351,6 +353,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
     const int tid = threadIdx.x;
+    dfa_require_lds_base0(dfa);
     dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     const u32 deadv = dead * 0x01010101u;
