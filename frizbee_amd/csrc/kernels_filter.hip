@@ -388,10 +388,11 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        st = dfa_step<0>(st, w[j], dfa);
-                        st = dfa_step<1>(st, w[j], dfa);
-                        st = dfa_step<2>(st, w[j], dfa);
-                        st = dfa_step<3>(st, w[j], dfa);
+                        const u32 wf = FZB_DFA_FOLDW(w[j]);
+                        st = dfa_step<0>(st, wf, dfa);
+                        st = dfa_step<1>(st, wf, dfa);
+                        st = dfa_step<2>(st, wf, dfa);
+                        st = dfa_step<3>(st, wf, dfa);
                     }
                 }
             }
@@ -663,7 +664,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     if (mode == 1) {
-        const size_t lds = (size_t)(rows + 1) * 288 + 16;  // table (FZB_DFA_STRIDE per state) + the tile counter
+        const size_t lds = (size_t)(rows + 1) * FZB_DFA_STRIDE + 16;  // table + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
             if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.uniform_len);
