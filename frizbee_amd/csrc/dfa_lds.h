@@ -9,11 +9,6 @@
 // for every state - and text is mostly lowercase letters, 7 dwords of a row: the lanes of a wave, in 3-4 different states, met in those
 // 7 banks (rocprofv3: SQ_LDS_BANK_CONFLICT = 53% of SQ_LDS_IDX_ACTIVE in k1_dfa, 4.2 LDS cycles per lookup instead of 2).  72 mod 32 = 8
 // moves every state's letters 8 banks on, so four consecutive states do not meet at all.  Costs one v_lshl_add per lookup.
-#ifdef FZB_DFA_FOLD_EXPERIMENT  // experiment only (exact only for needles of lowercase letters and digits)
-#define FZB_DFA_FOLDW(w) ((w) | (((w) & 0x40404040u) >> 1))
-#else
-#define FZB_DFA_FOLDW(w) (w)
-#endif
 #ifndef FZB_DFA_STRIDE
 #define FZB_DFA_STRIDE 288u
 #endif
@@ -41,10 +36,7 @@ __device__ __forceinline__ u32 dfa_step(u32 st, u32 w, const u8* dfa) {
 // (lgkmcnt(3), (2), (1), (0)) - on this chip a wait takes an issue slot like any other instruction (issue model)
 #define FZB_WAIT_LDS() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)  // the barriers keep the next round's v_perm behind the wait
 template <bool ABS = true>
-__device__ __forceinline__ void dfa_word4(u32 (&st)[4], const u32 (&w_in)[4], const u8* dfa) {
-    u32 w[4];
-#pragma unroll
-    for (int p = 0; p < 4; p++) w[p] = FZB_DFA_FOLDW(w_in[p]);
+__device__ __forceinline__ void dfa_word4(u32 (&st)[4], const u32 (&w)[4], const u8* dfa) {
 #pragma unroll
     for (int p = 0; p < 4; p++) st[p] = dfa_step<0, ABS>(st[p], w[p], dfa);
     FZB_WAIT_LDS();

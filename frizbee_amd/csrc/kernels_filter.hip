@@ -388,11 +388,10 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
                     }
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const u32 wf = FZB_DFA_FOLDW(w[j]);
-                        st = dfa_step<0>(st, wf, dfa);
-                        st = dfa_step<1>(st, wf, dfa);
-                        st = dfa_step<2>(st, wf, dfa);
-                        st = dfa_step<3>(st, wf, dfa);
+                        st = dfa_step<0>(st, w[j], dfa);
+                        st = dfa_step<1>(st, w[j], dfa);
+                        st = dfa_step<2>(st, w[j], dfa);
+                        st = dfa_step<3>(st, w[j], dfa);
                     }
                 }
             }
