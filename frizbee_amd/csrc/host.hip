@@ -181,6 +181,8 @@ struct fzb_matcher {
     bool profiling = false;
     static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2],[3]=around the filter kernel [4]=before the scorers
     hipEvent_t evring[PROF_SLOTS][5] = {};
+    hipStream_t aux_stream = nullptr;  // second stream of a query (multi-chunk scorer beside the class launches) and its fork / join events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ev_filter[PROF_SLOTS] = {};
     u64 prof_calls = 0;
 
@@ -414,6 +416,9 @@ static int rebuild_matcher(fzb_matcher* m, const fzb_config* config, const uint8
     std::swap(fresh->out_dev, m->out_dev);
     std::swap(fresh->out_cap, m->out_cap);
     std::swap(fresh->count_dev, m->count_dev);
+    std::swap(fresh->aux_stream, m->aux_stream);
+    std::swap(fresh->ev_fork, m->ev_fork);
+    std::swap(fresh->ev_join, m->ev_join);
     fresh->device = m->device;
     fresh->lc.num_cus = m->lc.num_cus;
     fresh->profiling = m->profiling;
@@ -469,6 +474,9 @@ void fzb_matcher_free(fzb_matcher* m) {
     for (auto& tr : m->evring)
         for (auto& e : tr)
             if (e) (void)hipEventDestroy(e);
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
     delete m;
 }
 
@@ -658,6 +666,13 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
 
 // ---- buffers beyond the per-range workspace, each grown by ONE helper so that fzb_matcher_reserve can size all of them ahead of
 // the first query (a re-query after every keystroke must not meet a hipFree / hipMalloc) --------------------------------------
+static int ensure_aux_stream(fzb_matcher* m) {
+    if (m->aux_stream) return FZB_OK;
+    HIPCHK(hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    return FZB_OK;
+}
 static int ensure_fused_buffers(fzb_matcher* m) {  // tile counts, group counts and the staging array of k12_fused, sized with the range workspace
     Workspace& w = m->ws;
     if (w.fused_cap >= w.cap_items && w.fused_stage) return FZB_OK;
@@ -931,17 +946,36 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("generic(unicode)");
     } else {
         static const bool no_classes = getenv("FZB_NO_DP_CLASSES") != nullptr;  // comparison knob: the per-wave choice of k2b_dp instead
-        if (lc.cf_ok && !no_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2))
+        static const bool no_overlap = getenv("FZB_NO_OVERLAP") != nullptr;     // comparison knob: everything on the caller's stream
+        const bool classes = lc.cf_ok && !no_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2);
+        const int mgrid = cus * 4;  // multi-chunk scorer: 2 waves per SIMD (the kernel is capped at 256 VGPRs)
+        const int mmode = (lc.cfm_ok && !getenv("FZB_NO_DP_CFM")) ? 2 : lc.bias_ok ? 1 : 0;
+        if (!no_wide && (rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
+        // The class launches and the multi-chunk scorer both start from k2w_classify's lists and write disjoint records, and each is a persistent
+        // grid whose last round leaves most of the chip idle (the multi-chunk scorer's third round is 4 % full on the C4 shard): the multi-chunk
+        // scorer runs on a second stream, forked after the classifier and joined before the caller's stream continues.
+        const bool fork = classes && !no_wide && !no_overlap && ensure_aux_stream(m) == FZB_OK;
+        if (classes)
             fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                                  (u32)w.cap_cls, cus, st);
+                                  (u32)w.cap_cls, cus, st, fork ? 1 : 0);
         else
             fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
+        if (fork) {
+            HIPCHK(hipEventRecord(m->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
+            fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, m->aux_stream);
+            HIPCHK(hipEventRecord(m->ev_join, m->aux_stream));
+            fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
+                                  (u32)w.cap_cls, cus, st, 2);
+            HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
+            FZB_STAGE("dp classes + dp_multi (second stream)");
+        }
         if (!no_wide) {
-            const int mgrid = cus * 4;  // 2 waves per SIMD (the kernel is capped at 256 VGPRs)
-            if ((rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
-            fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, (lc.cfm_ok && !getenv("FZB_NO_DP_CFM")) ? 2 : lc.bias_ok ? 1 : 0, outp, cap32, w.dp_scratch, mgrid, st);
-            FZB_STAGE("dp_multi");
+            if (!fork) {
+                fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, st);
+                FZB_STAGE("dp_multi");
+            }
             if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
                 fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, cnt_c,
                                    cus / 4 + 1, st);
@@ -974,7 +1008,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     int rc = ensure_workspace(m, n);
     if (rc) return rc;
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
-    if (!m->literal_mode && !m->nd.unicode && !no_wide && (rc = ensure_dp_scratch(m, m->lc.num_cus * 4))) return rc;
+    if (!m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
     if (fzb_fused_applies(c->dev, m->lc, m->nd, m->lc.window_mode) && (rc = ensure_fused_buffers(m))) return rc;
     if ((rc = ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;

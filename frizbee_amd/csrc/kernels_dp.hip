@@ -428,11 +428,15 @@ __global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3
 
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
-                           int num_cus, hipStream_t st) {
+                           int num_cus, hipStream_t st, int part) {
+    // part: 0 = classify + the three class launches, 1 = classify only, 2 = the class launches only (host.hip runs the multi-chunk scorer on a
+    // second stream between the two)
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-    if (c.ends_u64) hipLaunchKernelGGL((k2w_classify<u64, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count);
+    if (part == 2) {
+    } else if (c.ends_u64) hipLaunchKernelGGL((k2w_classify<u64, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count);
     else hipLaunchKernelGGL((k2w_classify<u32, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count);
+    if (part == 1) return;
 #define FZB_K2C(SWL, U, REAL, CLS, ET)                                                                                                    \
     do {                                                                                                                                  \
         static int per_cu = 0;                                                                                                            \
