@@ -427,20 +427,30 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
     const u32 ntiles = (n_items + FZB_TILE - 1) / FZB_TILE;
     const u32 T = (ntiles + gridDim.x - 1) / gridDim.x;
     const u32 t0 = min(blockIdx.x * T, ntiles), t1 = min(t0 + T, ntiles);
+    // Everything this workgroup reads is requested up front - its first batch of tile counts, the first 256 bitmap words of that batch and
+    // the counts before its run - so that the three dependent round trips of the straightforward order (prefix, batch counts, words)
+    // overlap into one; for the 10 M-haystack list a workgroup has ~10 tiles = 152 words, i.e. nothing is left to load afterwards.
+    const u32 nwords = (n_items + 63) / 64;
+    const u32 nt_first = min(256u, t1 - t0);
+    const u32 c_first = (u32)tid < nt_first ? counts[t0 + tid] : 0u;
+    const u32 w_first = t0 * (FZB_TILE / 64) + tid;
+    const u64 bits_first = (w_first < (t0 + nt_first) * (FZB_TILE / 64) && w_first < nwords) ? bitmap[w_first] : 0ull;
     // survivors before tile t0
-    // (16-byte loads, four in flight per thread: this sum is the kernel's critical path - up to ntiles counts per workgroup)
+    // (this sum is the kernel's critical path - up to ntiles counts per workgroup: 16-byte loads, TWELVE in flight per thread, so that the
+    // 10 M-haystack list's 9766 counts are one round trip for every workgroup instead of three)
     u32 part = 0;
     {
         const uint4* c4 = (const uint4*)counts;
         const u32 n4 = t0 / 4;
-        u32 i = tid;
-        for (; i + 768 < n4; i += 1024) {
-            const uint4 a = c4[i], b = c4[i + 256], c = c4[i + 512], d = c4[i + 768];
-            part += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
-        }
-        for (; i < n4; i += 256) {
-            const uint4 a = c4[i];
-            part += a.x + a.y + a.z + a.w;
+        for (u32 i0 = 0; i0 < n4; i0 += 12 * 256) {
+            uint4 v[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                const u32 i = i0 + k * 256 + tid;
+                v[k] = i < n4 ? c4[i] : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) part += v[k].x + v[k].y + v[k].z + v[k].w;
         }
         for (u32 k = 4 * n4 + tid; k < t0; k += 256) part += counts[k];
     }
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
     __syncthreads();
     for (u32 tb = t0; tb < t1; tb += 256) {  // batches of up to 256 tiles
         const u32 nt = min(256u, t1 - tb);
-        const u32 c = (u32)tid < nt ? counts[tb + tid] : 0u;
+        const u32 c = tb == t0 ? c_first : ((u32)tid < nt ? counts[tb + tid] : 0u);
         // exclusive scan of c over the batch
         u32 incl = c;
         for (int off = 1; off < 64; off <<= 1) {
@@ -468,11 +478,10 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
         // expand the bitmap words of these tiles: the 16 words of a tile sit in 16 consecutive lanes (w0 is a multiple of 16),
         // so a word's offset inside its tile is a 16-lane segmented scan of the popcounts - no re-reading of the earlier words
         const u32 w0 = tb * (FZB_TILE / 64), w1 = (tb + nt) * (FZB_TILE / 64);
-        const u32 nwords = (n_items + 63) / 64;
         for (u32 wb0 = w0; wb0 < w1; wb0 += 256) {  // uniform trip count: the shuffles below need every lane
             const u32 w = wb0 + tid;
             const bool live = w < w1 && w < nwords;
-            u64 bits = live ? bitmap[w] : 0ull;
+            u64 bits = (tb == t0 && wb0 == w0) ? bits_first : (live ? bitmap[w] : 0ull);
             const u32 c = (u32)__popcll(bits);
             u32 incl = c;
 #pragma unroll
