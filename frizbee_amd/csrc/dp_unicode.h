@@ -23,10 +23,8 @@ __device__ __forceinline__ u32 p_neg_mask(u32 neg) {  // per 16-bit lane: 0xFFFF
 __device__ __forceinline__ u32 zflag4(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }
 
 // REAL = packed dwords (2 lanes each) that may hold haystack bytes: the caller guarantees m <= 2 * REAL.  Lanes at or past m are
-// not valid, so they are never scalar starts: diag / up are masked to 0 there, their match / pending masks are 0, the prefix count
-// Q stays at its final value and a hop from padding to padding crosses no scalar start (no gap-open charge, pending irrelevant).
-// They still receive row values through the gap scan and enter the final max, so they are computed - but only the score row,
-// which is what REAL < NW saves in registers (no Q / bonus / pending / up-mask entries for them) and instructions.
+// not valid, so they are never scalar starts: diag / up are masked to 0 there, their match / pending masks are 0.  Dwords that can
+// hold no haystack byte at all are not computed (see NR below).
 // 0-typo unicode window of an ACCEPTED haystack (src/prefilter/algo/unicode.rs:118-219, lane-free: see host.hip, unicode DFA):
 // start = the first byte position at which the FIRST needle scalar (either case variant) occurs, end = one past the last byte of
 // the LAST occurrence of the last needle scalar.  One thread scans its haystack through a sliding 8-byte register window.
@@ -59,6 +57,11 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
     constexpr int NW = SWL / 2;
     constexpr int NB = SWL / 4;
     constexpr int RB = (REAL + 1) / 2;  // byte dwords that may hold haystack bytes
+    // Score dwords that are computed: the 2 * RB that can hold a haystack byte.  The dwords above them are pure padding, and nothing they
+    // hold is ever read: values only travel rightwards (gap steps, diagonal), a padding lane is never a scalar start (its diag / up are
+    // masked to 0), and the score is the maximum of the LAST row before its propagation (below), where padding lanes are 0.  (Round 1 took
+    // the maximum after the propagation and had to carry all SWL / 2 dwords.)
+    constexpr int NR = 2 * RB;
     static_assert(REAL >= 1 && REAL <= NW, "REAL");
     const u32 rows = (u32)nd.rows;
     const u32 ONE = 0x00010001u;
@@ -124,9 +127,9 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
         const u32 lanepos1 = (u32)(2 * d + 1) | ((u32)(2 * d + 2) << 16);
         return p_mul(p_add(Qof(d), p_subs(lanepos1, mv)), gexv);
     };
-    u32 prev[NW], upm[2 * RB];
+    u32 prev[NR], upm[2 * RB];
 #pragma unroll
-    for (int d = 0; d < NW; d++) prev[d] = 0;
+    for (int d = 0; d < NR; d++) prev[d] = 0;
 #pragma unroll
     for (int d = 0; d < 2 * RB; d++) upm[d] = 0;
 #pragma unroll 1
@@ -135,10 +138,15 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
         const u8* uc = nd.uc[r];
         const u8* uf = nd.uf[r];
         const bool two = (uc[0] != uf[0]) || (uc[1] != uf[1]) || (uc[2] != uf[2]) || (uc[3] != uf[3]);
-        // ---- byte-level match flags: scalar start && bytes [L, L+cl) equal the needle scalar (unicode.rs:221-241) ----
-        u32 row[NW], pend[2 * RB];
+        // Keep what is derived from the prefix counts and the byte views (scalar-start masks, biases, shifted views) out of registers
+        // across rows: the compiler otherwise hoists ~100 loop-invariant values out of this loop (k2u_dp_unicode_half<64>: 256 VGPRs + 92
+        // bytes of scratch at 2 waves per SIMD; with these barriers 168 VGPRs at 3 waves, 5 % fewer VALU instructions: C5 179 -> 162 us).
 #pragma unroll
-        for (int d = 2 * RB; d < NW; d++) row[d] = 0;  // padding dwords: diag / up are masked to scalar-start lanes, and there are none
+        for (int d = 0; d < 2 * RB; d++) asm volatile("" : "+v"(Q[d]));
+#pragma unroll
+        for (int k = 0; k <= RB; k++) asm volatile("" : "+v"(hb[k]));
+        // ---- byte-level match flags: scalar start && bytes [L, L+cl) equal the needle scalar (unicode.rs:221-241) ----
+        u32 row[NR], pend[2 * RB];
 #pragma unroll
         for (int k = 0; k < RB; k++) {
             const u32 w0 = hb[k];
@@ -192,11 +200,11 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
         }
         // ---- propagate_horizontal_unicode_gaps in the biased domain ----
 #pragma unroll
-        for (int d = 0; d < NW; d++) row[d] = p_add(row[d], Pof(d));
+        for (int d = 0; d < NR; d++) row[d] = p_add(row[d], Pof(d));
         // every step updates in place from the highest dword down: entry d only reads entries <= d, which are still the
         // values from before the step (keeps the live register set to one copy of row / pending)
 #pragma unroll
-        for (int d = NW - 1; d >= 0; d--) {
+        for (int d = NR - 1; d >= 0; d--) {
             const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : 0u, 16);
             if (d <= 2 * RB) {  // a source lane (2d-1 or 2d) may be a real lane
                 const u32 ps = __builtin_amdgcn_alignbit(d < 2 * RB ? pend[d < 2 * RB ? d : 0] : 0u, (d && d - 1 < 2 * RB) ? pend[d ? d - 1 : 0] : 0u, 16);
@@ -209,9 +217,9 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
             }
         }
 #pragma unroll
-        for (int off = 1; off < NW; off *= 2) {
+        for (int off = 1; off < NR; off *= 2) {
 #pragma unroll
-            for (int d = NW - 1; d >= off; d--) {
+            for (int d = NR - 1; d >= off; d--) {
                 if (d - off < 2 * RB) {
                     const u32 fl = p_neg_mask(p_sub(Q[d - off < 2 * RB ? d - off : 0], Qof(d)));
                     row[d] = p_max(row[d], p_subs(row[d - off], pend[d - off < 2 * RB ? d - off : 0] & fl & gopmv));
@@ -222,10 +230,10 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
             }
         }
 #pragma unroll
-        for (int d = 0; d < NW; d++) prev[d] = p_sub(row[d], Pof(d));
+        for (int d = 0; d < NR; d++) prev[d] = p_sub(row[d], Pof(d));
     }
-    u32 mx = prev[0];
+    u32 mx = prev[0];  // (rows == 0 only: the loop returns from its last row)
 #pragma unroll
-    for (int d = 1; d < NW; d++) mx = p_max(mx, prev[d]);
+    for (int d = 1; d < NR; d++) mx = p_max(mx, prev[d]);
     return max(mx & 0xFFFF, mx >> 16);
 }

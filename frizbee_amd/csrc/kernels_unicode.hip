@@ -98,9 +98,9 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
 template <int SWL, typename ET>
 __global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, ET>(FZB_K2U_ARGS); }
 // every haystack of the list fits the low half of a chunk (host-known: corpus max_len <= SWL / 2): the general form is compiled out,
-// which lets the kernel fit 256 VGPRs (a few spills outside the row loop) and run two waves per SIMD
+// which lets the kernel fit 168 VGPRs (a few spills outside the row loop) and run three waves per SIMD
 template <int SWL, typename ET>
-__global__ __launch_bounds__(128, 2) void k2u_dp_unicode_half(FZB_K2U_PARAMS) { k2u_body<SWL, true, ET>(FZB_K2U_ARGS); }
+__global__ __launch_bounds__(128, 3) void k2u_dp_unicode_half(FZB_K2U_PARAMS) { k2u_body<SWL, true, ET>(FZB_K2U_ARGS); }
 
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
