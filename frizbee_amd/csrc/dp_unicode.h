@@ -142,9 +142,9 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
         // across rows: the compiler otherwise hoists ~100 loop-invariant values out of this loop (k2u_dp_unicode_half<64>: 256 VGPRs + 92
         // bytes of scratch at 2 waves per SIMD; with these barriers 168 VGPRs at 3 waves, 5 % fewer VALU instructions: C5 179 -> 162 us).
 #pragma unroll
-        for (int d = 0; d < 2 * RB; d++) asm volatile("" : "+v"(Q[d]));
+        for (int d = 0; d < 2 * RB; d++) FZB_OPAQUE_V(Q[d]);
 #pragma unroll
-        for (int k = 0; k <= RB; k++) asm volatile("" : "+v"(hb[k]));
+        for (int k = 0; k <= RB; k++) FZB_OPAQUE_V(hb[k]);
         // ---- byte-level match flags: scalar start && bytes [L, L+cl) equal the needle scalar (unicode.rs:221-241) ----
         u32 row[NR], pend[2 * RB];
 #pragma unroll

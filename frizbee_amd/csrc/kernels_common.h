@@ -50,6 +50,14 @@ __device__ __forceinline__ u32 wave_alloc(u32* counter, bool want) {
     return base + (u32)__popcll(mask & (((u64)1 << lane_id()) - 1));
 }
 
+// An optimisation barrier on a vector value: what is derived from x after this point is computed after this point (keeps the compiler
+// from hoisting loop-invariant values out of a loop at the price of registers, see dp_unicode.h).  No instruction is emitted.
+#ifdef FZB_HOST_SHIM
+#define FZB_OPAQUE_V(x) ((void)0)
+#else
+#define FZB_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+
 // a + b on the scalar unit, opaque to the optimiser: a chain `x = fzb_sadd(x, step)` over an unrolled loop stays one s_add per
 // link (the compiler otherwise rewrites it into a multiply and an add per element)
 __device__ __forceinline__ u32 fzb_sadd(u32 a, u32 b) {

@@ -1,8 +1,9 @@
-// TEST INFRASTRUCTURE: compiles the DEVICE arithmetic of the single-chunk Smith-Waterman bodies (frizbee_amd/csrc/dp_body.h,
-// dp_cf.h) for the host through tests/kernel_host/shim, one "thread" at a time, so that tests can fuzz the exact code the GPU runs
+// TEST INFRASTRUCTURE: compiles the DEVICE arithmetic of the Smith-Waterman bodies (frizbee_amd/csrc/dp_body.h, dp_cf.h, dp_cfm.h,
+// dp_unicode.h) for the host through tests/kernel_host/shim, one "thread" at a time, so that tests can fuzz the exact code the GPU runs
 // against the oracle without a GPU.  Built by tests/kernel_host_lib.py with ROCm's clang++ (-x c++); never part of the product.
 #include <vector>
 #include "dp_cfm.h"
+#include "dp_unicode.h"
 
 static u16 sadd16(u32 a, u32 b) { return (u16)(a + b > 0xFFFF ? 0xFFFF : a + b); }
 static u16 ssub16(u32 a, u32 b) { return (u16)(a > b ? a - b : 0); }
@@ -77,6 +78,17 @@ static int run_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_pref
     return upper ? (int)dp_multi_chunk_t<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0) : (int)dp_multi_chunk_t<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0);
 }
 
+// the unicode single-chunk scorer (dp_unicode.h): rows are needle scalars (bytes, flipped bytes, UTF-8 length per row)
+template <int SWL>
+static int run_unicode(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, int real, const u8* cls) {
+    std::vector<u8> buf(m + 96, 0);
+    memcpy(buf.data(), hay, m);
+    constexpr int NW = SWL / 2;
+    if (real == NW) return (int)dp_unicode_single_chunk<SWL>(nd, buf.data(), m, include_prefix, cls);
+    if (SWL >= 16 && real == NW / 2) return (int)dp_unicode_single_chunk<SWL, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, buf.data(), m, include_prefix, cls);
+    return -2;
+}
+
 extern "C" {
 // form: 0 = dp_single_chunk biased, 1 = literal (unbiased) scan, 2 = its padded-half form, 3 = dp_single_chunk_cf with `real` dwords,
 // 4 = dp_single_chunk_cf_tab (LDS-table set-up, swl/4 dwords).
@@ -92,6 +104,29 @@ int kh_dp_single(const u8* needle, int n, int case_sensitive, const u16* scoring
         case 32: return run<32>(nd, hay, (u32)m, include_prefix, form, real, cls);
         case 16: return run<16>(nd, hay, (u32)m, include_prefix, form, real, cls);
         case 8: return run<8>(nd, hay, (u32)m, include_prefix, form, real, cls);
+    }
+    return -1;
+}
+
+int kh_dp_unicode(const u8* uc, const u8* uf, const u8* ulen, int rows, const u16* sc, const u8* hay, int m, int include_prefix, int swl, int real) {
+    if (rows < 1 || rows > FZB_MAX_ROWS || m < 0 || m > swl) return -1;
+    NeedleDev nd;
+    const u8 dummy[1] = {0};
+    fill_needle(nd, dummy, 0, 1, sc);
+    nd.rows = rows;
+    nd.unicode = 1;
+    for (int r = 0; r < rows; r++) {
+        memcpy(nd.uc[r], uc + 4 * r, 4);
+        memcpy(nd.uf[r], uf + 4 * r, 4);
+        nd.ulen[r] = ulen[r];
+    }
+    static u8 cls[256];
+    build_cls_table(cls);
+    switch (swl) {
+        case 64: return run_unicode<64>(nd, hay, (u32)m, include_prefix, real, cls);
+        case 32: return run_unicode<32>(nd, hay, (u32)m, include_prefix, real, cls);
+        case 16: return run_unicode<16>(nd, hay, (u32)m, include_prefix, real, cls);
+        case 8: return run_unicode<8>(nd, hay, (u32)m, include_prefix, real, cls);
     }
     return -1;
 }

@@ -20,7 +20,7 @@ def available():
 def build():
     so = os.path.join(HERE, "libkernel_host.so")
     srcs = [os.path.join(HERE, "dp_host.cpp"), os.path.join(HERE, "shim", "hip", "hip_runtime.h")] + [
-        os.path.join(CSRC, f) for f in ("dp_body.h", "dp_cf.h", "dp_cfm.h", "kernels_common.h", "fzb_internal.h")]
+        os.path.join(CSRC, f) for f in ("dp_body.h", "dp_cf.h", "dp_cfm.h", "dp_unicode.h", "kernels_common.h", "fzb_internal.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + os.path.join(HERE, "shim"), "-I" + CSRC,
                                "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-o", so, os.path.join(HERE, "dp_host.cpp")])
@@ -36,6 +36,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.kh_dp_single.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
+        _lib.kh_dp_unicode.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_dp_multi.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -52,6 +53,16 @@ def window(needle, hay, case_sensitive=False):
     out = (C.c_uint32 * 4)()
     assert lib().kh_window(needle, len(needle), int(case_sensitive), hay, len(hay), out) == 0
     return (out[0], out[1]), (out[2], out[3])
+
+
+def dp_unicode(rows, hay, scoring, include_prefix=True, swl=64, real=None):
+    """score of a single-chunk window by the unicode scorer; rows = [(scalar bytes[4], flipped bytes[4], utf8 length)] as the oracle's
+    case_needle_unicode returns them (what fzb_matcher_create stores in NeedleDev::uc / uf / ulen)"""
+    sc = (C.c_uint16 * 9)(*scoring)
+    uc = b"".join(r[0] for r in rows)
+    uf = b"".join(r[1] for r in rows)
+    ul = bytes(r[2] for r in rows)
+    return lib().kh_dp_unicode(uc, uf, ul, len(rows), sc, hay, len(hay), int(include_prefix), swl, swl // 2 if real is None else real)
 
 
 def dp_multi(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=64, form=6, is_u8=True):

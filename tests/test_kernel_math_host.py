@@ -208,3 +208,56 @@ def test_multi_chunk_biased_form_at_the_largest_values_it_is_configured_for():
         want = O.sw_score(needle, hay, scoring=DEF, case_sensitive=False, include_prefix=True, lanes=swl, is_u8=u8)
         assert K.dp_multi(needle, hay, DEF, False, True, swl, 6, u8) == want
         assert K.dp_multi(needle, hay, DEF, False, True, swl, 5, u8) == want
+
+
+def _rnd_utf8(rng, nbytes, alphabet):
+    """a valid UTF-8 string of at most nbytes bytes from `alphabet` (a list of 1-3-byte characters)"""
+    out = b""
+    while True:
+        c = rng.choice(alphabet).encode()
+        if len(out) + len(c) > nbytes:
+            return out
+        out += c
+
+
+@pytest.mark.parametrize("swl", [64, 32, 16])
+def test_unicode_scorer_matches_the_oracle(swl):
+    """dp_unicode.h's single-chunk scorer (rows = needle scalars, lanes = haystack bytes, continuation bytes as free transport lanes, the
+    last row unpropagated, only the dwords that can hold a haystack byte computed) against score_haystack_unicode
+    (src/smith_waterman/algo/unicode.rs:10-273) with propagate_horizontal_unicode_gaps (unicode_gap.rs:110-236)"""
+    rng = random.Random(900 + swl)
+    alphabets = [list("abcAB_ -"), list("abéÉñÑüÜß/_ "), list("aب人äÄé_. 語"), list("إنماÉé_-ab")]
+    checked = 0
+    for it in range(700):
+        alpha = rng.choice(alphabets)
+        n = rng.randint(1, 6)
+        needle = "".join(rng.choice(alpha) for _ in range(n))
+        cs = rng.random() < 0.3
+        sc = DEF
+        if rng.random() < 0.4:
+            sc = [rng.randint(0, 30), rng.randint(0, 16), rng.randint(0, 16), rng.randint(0, 5), rng.randint(0, 20), rng.randint(0, 10), rng.randint(0, 10),
+                  rng.randint(0, 16), rng.randint(0, 10)]
+        nbytes = rng.randint(1, swl) if it % 3 else rng.randint(1, swl // 2)
+        hay = _rnd_utf8(rng, nbytes, alpha)
+        if rng.random() < 0.6:  # plant the needle's characters in order
+            chars = hay.decode()
+            if len(chars) >= n:
+                pos = sorted(rng.sample(range(len(chars)), n))
+                lst = list(chars)
+                for q, c in zip(pos, needle):
+                    lst[q] = c if rng.random() < 0.7 else c.swapcase() if len(c.swapcase().encode()) == len(c.encode()) else c
+                cand = "".join(lst).encode()
+                if len(cand) <= swl:
+                    hay = cand
+        if not hay:
+            continue
+        ip = rng.random() < 0.5
+        rows = O.case_needle_unicode(needle, cs)
+        u8 = _fits(len(rows), sc)
+        want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, unicode=True, lanes=swl, is_u8=u8)
+        reals = [swl // 2] + ([swl // 4] if len(hay) <= swl // 2 else [])
+        for real in reals:
+            got = K.dp_unicode(rows, hay, sc, ip, swl, real)
+            assert got == want, (needle, hay, sc, cs, ip, swl, real, got, want)
+            checked += 1
+    assert checked > 700
