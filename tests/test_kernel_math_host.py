@@ -1,4 +1,4 @@
-"""The DEVICE arithmetic of the single-chunk Smith-Waterman scorers (frizbee_amd/csrc/dp_body.h and dp_cf.h), compiled for the
+"""The DEVICE arithmetic of the Smith-Waterman scorers (frizbee_amd/csrc/dp_body.h, dp_cf.h, dp_cfm.h, dp_unicode.h), compiled for the
 host (tests/kernel_host: ROCm's clang++ with a stand-in hip_runtime.h) and compared with the oracle's score_haystack
 (src/smith_waterman/algo/ascii.rs:10-158) - so the closed-form padding, the biased domain and the skipped last-row scan of dp_cf.h
 are checked bit for bit without a GPU.  The GPU parity tests run the same headers through hipcc."""
