@@ -131,6 +131,27 @@ int kh_dp_unicode(const u8* uc, const u8* uf, const u8* ulen, int rows, const u1
     return -1;
 }
 
+// the 0-typo unicode window the unicode scorer computes itself (dp_unicode.h, unicode_window_first_last)
+int kh_unicode_window(const u8* uc, const u8* uf, const u8* ulen, int rows, const u8* hay, int len, unsigned* out) {
+    if (rows < 1 || rows > FZB_MAX_ROWS || len < 0) return -1;
+    NeedleDev nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.rows = rows;
+    nd.unicode = 1;
+    for (int r = 0; r < rows; r++) {
+        memcpy(nd.uc[r], uc + 4 * r, 4);
+        memcpy(nd.uf[r], uf + 4 * r, 4);
+        nd.ulen[r] = ulen[r];
+    }
+    std::vector<u32> buf((len + 96 + 3) / 4 + 4, 0);  // 4-byte aligned, zero tail as in the device layout
+    memcpy(buf.data(), hay, len);
+    u32 ws = 0, we = 0;
+    unicode_window_first_last(nd, (const u8*)buf.data(), (u32)len, ws, we);
+    out[0] = ws;
+    out[1] = we;
+    return 0;
+}
+
 int kh_dp_multi(const u8* needle, int n, int case_sensitive, int is_u8, const u16* scoring, const u8* hay, int m, int include_prefix, int swl, int form) {
     if (n < 1 || n > FZB_MAX_ROWS || m <= swl || m > 1024) return -1;
     NeedleDev nd;

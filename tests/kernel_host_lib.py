@@ -37,6 +37,7 @@ def lib():
         _lib.kh_dp_single.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_unicode.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.kh_unicode_window.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_multi.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -63,6 +64,13 @@ def dp_unicode(rows, hay, scoring, include_prefix=True, swl=64, real=None):
     uf = b"".join(r[1] for r in rows)
     ul = bytes(r[2] for r in rows)
     return lib().kh_dp_unicode(uc, uf, ul, len(rows), sc, hay, len(hay), int(include_prefix), swl, swl // 2 if real is None else real)
+
+
+def unicode_window(rows, hay):
+    """(start, end) of the 0-typo unicode window as the unicode scorer finds it for an accepted haystack"""
+    out = (C.c_uint32 * 2)()
+    assert lib().kh_unicode_window(b"".join(r[0] for r in rows), b"".join(r[1] for r in rows), bytes(r[2] for r in rows), len(rows), hay, len(hay), out) == 0
+    return int(out[0]), int(out[1])
 
 
 def dp_multi(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=64, form=6, is_u8=True):

@@ -261,3 +261,32 @@ def test_unicode_scorer_matches_the_oracle(swl):
             assert got == want, (needle, hay, sc, cs, ip, swl, real, got, want)
             checked += 1
     assert checked > 700
+
+
+def test_unicode_window_equals_the_reference_prefilter_window():
+    """unicode_window_first_last (dp_unicode.h) against the window the reference's unicode prefilter returns for an accepted haystack
+    (src/prefilter/algo/unicode.rs:118-219), at the three lane widths (the window does not depend on the width)"""
+    rng = random.Random(77)
+    alphabets = [list("abcAB_ -"), list("abéÉñÑüÜß/_ "), list("aب人äÄé_. 語"), list("إنماÉé_-ab")]
+    accepted = 0
+    for it in range(3000):
+        alpha = rng.choice(alphabets)
+        n = rng.randint(1, 5)
+        needle = "".join(rng.choice(alpha) for _ in range(n))
+        cs = rng.random() < 0.3
+        hay = _rnd_utf8(rng, rng.randint(1, 120), alpha)
+        chars = hay.decode()
+        if len(chars) >= n and rng.random() < 0.7:
+            pos = sorted(rng.sample(range(len(chars)), n))
+            lst = list(chars)
+            for q, c in zip(pos, needle):
+                lst[q] = c
+            hay = "".join(lst).encode()
+        ok, ws, we = O.prefilter(needle, hay, max_typos=0, case_sensitive=cs, unicode=True, lanes=64)
+        for lanes in (32, 16):
+            assert O.prefilter(needle, hay, max_typos=0, case_sensitive=cs, unicode=True, lanes=lanes) == (ok, ws, we)
+        if not ok:
+            continue
+        accepted += 1
+        assert K.unicode_window(O.case_needle_unicode(needle, cs), hay) == (ws, we), (needle, hay, cs)
+    assert accepted > 1000
