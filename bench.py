@@ -277,11 +277,30 @@ def main():
     if args.fast:
         args.no_cpu_baseline = args.no_configs = args.no_check = args.no_two_in_flight = args.no_live_traffic = True
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node - refusing to run fewer ranks than asked for")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # invoked as plain `python bench.py --gpus N`: start the N ranks ourselves, exactly the way the driver would
+        # (one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1), and hand over to them
+        import socket
+
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__), *sys.argv[1:]]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvpe(cmd[0], cmd, os.environ)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -438,6 +457,7 @@ def main():
                        "haystacks_per_gpu": n, "haystack_len": HAY_LEN, "max_typos": args.max_typos,
                        "emulated_reference_backend": "AVX-512 (prefilter 64 lanes, Smith-Waterman 64 x u8)",
                        "sharding": f"contiguous index ranges over {world} GPU(s); per step an asynchronous, double-buffered RCCL gather of the match records to rank 0" if world > 1 else "single GPU",
+                       "ranks_seen": (dist.get_world_size() if use_dist else 1), "backend": ("nccl (RCCL)" if use_dist else "none (single process)"),
                        "matches_per_shard": n_matches, "filter_survivors": counters["filter_survivors"], "exchange": gathered},
             "roofline": {"bound": "hbm", "kernel": "k1_dfa", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr.get("k1_filter_hbm_bytes_per_launch"),

@@ -113,6 +113,8 @@ SYMBOLS = [
     "fzb_multi_matcher_create", "fzb_multi_matcher_free", "fzb_multi_matcher_len", "fzb_multi_match_list", "fzb_multi_match_list_device",
     "fzb_parse_query", "fzb_patterns_free", "fzb_match_list_indices", "fzb_match_indices_free", "fzb_multi_match_list_indices",
     "fzb_match_list_indices_into", "fzb_multi_match_list_into", "fzb_multi_match_list_indices_into",
+    "fzb_device_count", "fzb_shard_ranges", "fzb_corpus_upload_sharded", "fzb_sharded_corpus_free", "fzb_sharded_corpus_len", "fzb_sharded_corpus_shards",
+    "fzb_sharded_corpus_shard", "fzb_match_list_parallel_sharded",
 ]
 
 
@@ -166,6 +168,15 @@ def lib():
         l.fzb_match_list_indices_into.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p)]
         l.fzb_multi_match_list_indices_into.argtypes = l.fzb_match_list_indices_into.argtypes
         l.fzb_multi_match_list_into.argtypes = l.fzb_match_list_into.argtypes
+        l.fzb_device_count.argtypes = [C.POINTER(C.c_int)]
+        l.fzb_shard_ranges.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        l.fzb_corpus_upload_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        l.fzb_sharded_corpus_free.argtypes = [C.c_void_p]
+        l.fzb_sharded_corpus_len.argtypes = [C.c_void_p]
+        l.fzb_sharded_corpus_len.restype = C.c_size_t
+        l.fzb_sharded_corpus_shards.argtypes = [C.c_void_p]
+        l.fzb_sharded_corpus_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+        l.fzb_match_list_parallel_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         _lib = l
     return _lib
 
@@ -235,6 +246,56 @@ class Corpus:
         try:
             if getattr(self, "h", None):
                 lib().fzb_corpus_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+SHARD_BY_COUNT, SHARD_BY_BYTES, SHARD_OVERSUBSCRIBE = 0, 1, 2  # include/frizbee_hip.h FZB_SHARD_*
+
+
+def device_count():
+    n = C.c_int()
+    _check(lib().fzb_device_count(C.byref(n)))
+    return n.value
+
+
+def shard_ranges(ends, nshards, by_bytes=False):
+    """fzb_shard_ranges: the contiguous index ranges [(lo, hi)] the sharded upload cuts a list into (host arithmetic, no device)."""
+    ends = np.ascontiguousarray(ends, dtype=np.uint64)
+    out = np.zeros(nshards + 1, np.uint64)
+    _check(lib().fzb_shard_ranges(ends.ctypes.data if len(ends) else None, len(ends), nshards, int(by_bytes), out.ctypes.data))
+    return [(int(out[g]), int(out[g + 1])) for g in range(nshards)]
+
+
+class ShardedCorpus:
+    """A haystack list cut into contiguous shards, shard g resident on device g (fzb_corpus_upload_sharded): the multi-device form of
+    `match_list_parallel`'s chunks (src/matcher/parallel.rs:55-63).  Everything below it is the C ABI - no torch, no process group."""
+
+    def __init__(self, haystacks=None, ndev=1, *, packed=None, by_bytes=False, oversubscribe=False):
+        data, ends = packed if packed is not None else pack(haystacks)
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        ends = np.ascontiguousarray(ends, dtype=np.uint64)
+        self.h = C.c_void_p()
+        flags = (SHARD_BY_BYTES if by_bytes else 0) | (SHARD_OVERSUBSCRIBE if oversubscribe else 0)
+        _check(lib().fzb_corpus_upload_sharded(data.ctypes.data, ends.ctypes.data if len(ends) else None, len(ends), ndev, flags, C.byref(self.h)))
+
+    def __len__(self):
+        return lib().fzb_sharded_corpus_len(self.h)
+
+    def shards(self):
+        """[(lo, hi, device)] per shard"""
+        out = []
+        for g in range(lib().fzb_sharded_corpus_shards(self.h)):
+            lo, hi, dev = C.c_uint64(), C.c_uint64(), C.c_int()
+            _check(lib().fzb_sharded_corpus_shard(self.h, g, C.byref(lo), C.byref(hi), C.byref(dev)))
+            out.append((lo.value, hi.value, dev.value))
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().fzb_sharded_corpus_free(self.h)
                 self.h = None
         except Exception:
             pass
@@ -449,6 +510,13 @@ class Matcher(_IterApi):
         out, n = C.c_void_p(), C.c_size_t()
         _check(lib().fzb_match_list_parallel(self.h, cp.h, threads, C.byref(out), C.byref(n)))
         return _take(out, n)
+
+    def match_list_parallel_sharded(self, sharded, copy=True):
+        """`Matcher::match_list_parallel` with one DEVICE per worker (fzb_match_list_parallel_sharded): per-shard pipeline + device sort,
+        k-way merge of the runs on the host (src/matcher/parallel.rs:66-87).  Equals `match_list` on the unsharded list."""
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_match_list_parallel_sharded(self.h, sharded.h, C.byref(out), C.byref(n)))
+        return _take(out, n, copy)
 
     def match_list_indices(self, haystacks, selection=None):
         """`Matcher::match_list_indices` (src/matcher/mod.rs:234-275): list of `MatchIndices` (src/lib.rs:189-199), the matched byte

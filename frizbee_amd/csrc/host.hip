@@ -23,22 +23,13 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/frizbee_hip.h"
-#include "fzb_internal.h"
+#include "host_internal.h"
 
 namespace {
 #include "unicode_case_table.inc"
 
 thread_local std::string g_err;
-int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
-#define HIPCHK(expr)                                                                                         \
-    do {                                                                                                     \
-        hipError_t e_ = (expr);                                                                              \
-        if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));   \
-    } while (0)
+inline int fail(int code, const std::string& msg) { return fzb_fail(code, msg); }
 
 // ---- UTF-8 / case helpers ---------------------------------------------------------------------------
 bool decode_utf8(const u8* s, size_t n, std::vector<u32>& out) {
@@ -154,49 +145,15 @@ void detect_host_lanes(bool use_u8, int& pf, int& sw) {
 #endif
 }
 
-hipError_t dev_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16); }
+hipError_t dev_alloc(void** p, size_t bytes) { return fzb_dev_alloc(p, bytes); }
 
 }  // namespace
 
-struct fzb_corpus {
-    CorpusDev dev{};
-    void* own_bytes = nullptr;
-    void* own_ends = nullptr;
-};
-
-struct fzb_matcher {
-    fzb_config config{};
-    std::string needle;
-    bool empty = false, case_sensitive = false, unicode = false, use_u8 = false;
-    int literal_mode = 0;  // 0 = fuzzy; else FZB_MATCH_EXACT / PREFIX / SUFFIX / SUBSTRING (src/literal)
-    int rows = 0;
-    NeedleDev nd{};
-    LaunchCfg lc{};
-    std::vector<u64> table;  // host copy of the filter table
-    std::vector<u8> dfa;     // host copy of the subsequence DFA
-    std::vector<u8> uni_dfa; // unicode path, 0 typos: byte-level DFA of the exact prefilter (empty if it needs more than 255 states)
-    int uni_dfa_states = 0;
-    Workspace ws{};
-    int device = -1;
-    bool profiling = false;
-    static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2],[3]=around the filter kernel [4]=before the scorers
-    hipEvent_t evring[PROF_SLOTS][5] = {};
-    hipStream_t aux_stream = nullptr;  // second stream of a query (multi-chunk scorer beside the class launches) and its fork / join events
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int ev_filter[PROF_SLOTS] = {};
-    u64 prof_calls = 0;
-
-    u32 last_counters[4] = {0, 0, 0, 0};
-    // staging for the synchronous API
-    fzb_match_rec* out_dev = nullptr;
-    size_t out_cap = 0;
-    u32* count_dev = nullptr;
-    // fzb_match_list_indices: the selection (+ its length), the positions (`stride` per record) and their counts
-    u32* trace_sel = nullptr;
-    u32* trace_pos = nullptr;
-    u32* trace_npos = nullptr;
-    size_t trace_cap = 0, trace_pos_words = 0;
-};
+int fzb_fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+void fzb_clear_error() { g_err.clear(); }
 
 extern "C" {
 
@@ -427,9 +384,29 @@ static int rebuild_matcher(fzb_matcher* m, const fzb_config* config, const uint8
         for (int k = 0; k < 5; k++) std::swap(fresh->evring[i][k], m->evring[i][k]);
         fresh->ev_filter[i] = m->ev_filter[i];
     }
+    fresh->shard_stream = m->shard_stream;  // (non-null only on a shard clone)
+    fresh->shard_device = m->shard_device;
+    m->shard_stream = nullptr;
+    m->shard_device = -1;
+    std::swap(fresh->shard_clones, m->shard_clones);
     // ... and then the handle the caller holds takes the rebuilt matcher's place
     std::swap(*fresh, *m);
     fzb_matcher_free(fresh);
+    // the per-shard clones of the multi-device form follow (same needle, same config with the resolved lane pair); their device
+    // workspaces stay where they are
+    if (!m->shard_clones.empty()) {
+        fzb_config ccfg = m->config;
+        ccfg.pf_lanes = (uint16_t)m->lc.pf_lanes;
+        ccfg.sw_lanes = (uint16_t)m->lc.sw_lanes;
+        bool ok = true;
+        for (fzb_matcher* cm : m->shard_clones) ok = ok && rebuild_matcher(cm, &ccfg, needle_utf8, needle_len) == FZB_OK;
+        if (!ok) {  // cannot happen for a needle / config the main matcher accepted; drop the clones rather than keep stale ones
+            std::vector<fzb_matcher*> drop;
+            drop.swap(m->shard_clones);
+            for (fzb_matcher* cm : drop) fzb_matcher_free(cm);
+            fzb_clear_error();
+        }
+    }
     return FZB_OK;
 }
 
@@ -477,6 +454,20 @@ void fzb_matcher_free(fzb_matcher* m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
+    if (!m->shard_clones.empty() || m->shard_device >= 0) {
+        // a clone's device state lives on its shard's device
+        int cur = 0;
+        const bool have_cur = hipGetDevice(&cur) == hipSuccess;
+        if (m->shard_device >= 0) (void)hipSetDevice(m->shard_device);
+        if (m->shard_stream) (void)hipStreamDestroy(m->shard_stream);
+        m->shard_stream = nullptr;
+        for (fzb_matcher* cm : m->shard_clones) {
+            if (cm->shard_device >= 0) (void)hipSetDevice(cm->shard_device);
+            fzb_matcher_free(cm);
+        }
+        m->shard_clones.clear();
+        if (have_cur) (void)hipSetDevice(cur);
+    }
     delete m;
 }
 
@@ -486,87 +477,7 @@ int fzb_matcher_info(const fzb_matcher* m, int32_t out[6]) {
     return FZB_OK;
 }
 
-// ---- corpus -----------------------------------------------------------------------------------------
-int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t n, fzb_corpus** out) {
-    if (!out || (n && (!bytes || !end_offsets))) return fail(FZB_ERR_INVALID, "null argument");
-    if (n > 0xFFFFFFFFull) return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(n) + " > 4294967295 (index offset: 0)");
-    // repack into the padded-16 device layout, on up to 32 host threads: per-range padded sizes, a serial prefix over the
-    // ranges, then every range copies its haystacks (and zeroes its own gaps: the buffer is not cleared as a whole)
-    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)32, (size_t)std::thread::hardware_concurrency(), n / 65536 + 1}));
-    const size_t per = (n + nthreads - 1) / nthreads;
-    std::vector<u64> range_bytes(nthreads, 0), range_max(nthreads, 0), range_min(nthreads, ~(u64)0);
-    std::vector<int> range_bad(nthreads, 0);
-    auto for_ranges = [&](auto fn) {
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(fn, t);
-        fn((size_t)0);
-        for (auto& th : pool) th.join();
-    };
-    for_ranges([&](size_t t) {
-        const size_t lo = std::min(t * per, n), hi = std::min(lo + per, n);
-        u64 prev = lo ? end_offsets[lo - 1] : 0, bytes_padded = 0, mx = 0, mn = ~(u64)0;
-        for (size_t i = lo; i < hi; i++) {
-            if (end_offsets[i] < prev) { range_bad[t] = 1; break; }
-            const u64 len = end_offsets[i] - prev;
-            mx = std::max(mx, len);
-            mn = std::min(mn, len);
-            bytes_padded += (len + 15) & ~(u64)15;
-            prev = end_offsets[i];
-        }
-        range_bytes[t] = bytes_padded;
-        range_max[t] = mx;
-        range_min[t] = mn;
-    });
-    u64 max_len = 0, min_len = ~(u64)0, total_padded = 0;
-    std::vector<u64> range_start(nthreads, 0);
-    for (size_t t = 0; t < nthreads; t++) {
-        if (range_bad[t]) return fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
-        range_start[t] = total_padded;
-        total_padded += range_bytes[t];
-        max_len = std::max(max_len, range_max[t]);
-        min_len = std::min(min_len, range_min[t]);
-    }
-    const u64 total = total_padded + 96;
-    const bool ends_u64 = total > 0xFFFFFFF0ull;
-    std::unique_ptr<u8[]> packed(new (std::nothrow) u8[total]);
-    std::unique_ptr<u8[]> pends(new (std::nothrow) u8[std::max<size_t>(n, 1) * (ends_u64 ? 8 : 4)]);
-    if (!packed || !pends) return fail(FZB_ERR_INVALID, "out of host memory while packing the corpus");
-    memset(packed.get() + total_padded, 0, 96);
-    for_ranges([&](size_t t) {
-        const size_t lo = std::min(t * per, n), hi = std::min(lo + per, n);
-        u64 prev = lo ? end_offsets[lo - 1] : 0, ppos = range_start[t];  // every haystack starts on a 16-byte boundary
-        u8* dst = packed.get();
-        for (size_t i = lo; i < hi; i++) {
-            const u64 len = end_offsets[i] - prev;
-            memcpy(dst + ppos, bytes + prev, len);
-            const u64 end = ppos + len, next = (end + 15) & ~(u64)15;
-            if (next != end) memset(dst + end, 0, next - end);
-            if (ends_u64) ((u64*)pends.get())[i] = end;
-            else ((u32*)pends.get())[i] = (u32)end;
-            ppos = next;
-            prev = end_offsets[i];
-        }
-    });
-    auto c = new fzb_corpus();
-    c->dev.n = n;
-    c->dev.total_bytes = total;
-    c->dev.ends_u64 = ends_u64;
-    c->dev.max_len = (u32)std::min<u64>(max_len, 0xFFFFFFFFu);
-    c->dev.uniform_len = (n && min_len == max_len && max_len && max_len < 0xFFFFFFFFu) ? (u32)max_len : 0u;  // kernels then skip the end offsets
-    hipError_t e = dev_alloc(&c->own_bytes, total);
-    if (e == hipSuccess) e = hipMemcpy(c->own_bytes, packed.get(), total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = dev_alloc(&c->own_ends, std::max<size_t>(n, 1) * (ends_u64 ? 8 : 4));
-    if (e == hipSuccess && n) e = hipMemcpy(c->own_ends, pends.get(), n * (ends_u64 ? 8 : 4), hipMemcpyHostToDevice);
-    if (e != hipSuccess) {
-        fzb_corpus_free(c);
-        return fail(FZB_ERR_HIP, std::string("corpus upload: ") + hipGetErrorString(e));
-    }
-    c->dev.bytes = (const u8*)c->own_bytes;
-    c->dev.ends = c->own_ends;
-    *out = c;
-    return FZB_OK;
-}
-
+// ---- corpus (fzb_corpus_upload: host_upload.hip) -------------------------------------------------------
 int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends_are_u64, size_t n, uint64_t total_bytes, fzb_corpus** out) {
     if (!out || (n && (!dev_bytes || !dev_ends))) return fail(FZB_ERR_INVALID, "null argument");
     if (((uintptr_t)dev_bytes & 15) != 0) return fail(FZB_ERR_INVALID, "dev_bytes must be 16-byte aligned");
@@ -590,9 +501,17 @@ void fzb_corpus_free(fzb_corpus* c) {
 size_t fzb_corpus_len(const fzb_corpus* c) { return c ? (size_t)c->dev.n : 0; }
 int fzb_corpus_set_uniform_len(fzb_corpus* c, uint32_t len) {
     if (!c) return fail(FZB_ERR_INVALID, "null argument");
+    // an uploaded corpus knows its lengths: only the detected value (a no-op) is accepted, anything else would make the kernels that
+    // compute spans and the ones that read the end offsets disagree within one query
+    if (c->own_bytes) {
+        if (len == c->dev.uniform_len) return FZB_OK;
+        return fail(FZB_ERR_INVALID, "the corpus was uploaded by fzb_corpus_upload, which detected its lengths itself (uniform length " + std::to_string(c->dev.uniform_len) +
+                                         ", 0 = not uniform); the promise can only be made for borrowed device memory");
+    }
     if (len && (u64)((len + 15u) & ~15u) * (c->dev.n ? c->dev.n - 1 : 0) + len > c->dev.total_bytes) return fail(FZB_ERR_INVALID, "uniform length does not fit the corpus buffer");
+    if (!len && c->dev.uniform_len && c->dev.max_len == c->dev.uniform_len) c->dev.max_len = 0;  // clearing the promise also clears the bound it implied
     c->dev.uniform_len = len;
-    if (len) c->dev.max_len = len;
+    if (len) c->dev.max_len = len;  // (overwrites an earlier fzb_corpus_set_max_len)
     return FZB_OK;
 }
 
@@ -607,6 +526,10 @@ int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
 // survivors (LCS == rows - k) are re-decided at the exact lane width, and the scorer computes the lane-free window itself
 // (whether the corpus allows it - max_len - is known per call: run_pipeline)
 static bool typo_fast_path_configured(const fzb_matcher* m) {
+    // FZB_TYPO_EXACT_WINDOW=1: every typo query takes the reference's chunked multi-path scan at the exact lane width for every survivor
+    // (superset filter -> k2a_window -> k_compact2), i.e. nothing rests on the two properties of DESIGN.md section 3e
+    static const bool exact_window = getenv("FZB_TYPO_EXACT_WINDOW") != nullptr && atoi(getenv("FZB_TYPO_EXACT_WINDOW")) != 0;
+    if (exact_window) return false;
     return !m->literal_mode && !m->empty && m->lc.filter_mode == 2 && !m->nd.unicode && m->lc.cf_ok && (m->lc.sw_lanes == 64 || m->lc.sw_lanes == 32);
 }
 
@@ -667,10 +590,22 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
 // ---- buffers beyond the per-range workspace, each grown by ONE helper so that fzb_matcher_reserve can size all of them ahead of
 // the first query (a re-query after every keystroke must not meet a hipFree / hipMalloc) --------------------------------------
 static int ensure_aux_stream(fzb_matcher* m) {
-    if (m->aux_stream) return FZB_OK;
-    HIPCHK(hipStreamCreateWithFlags(&m->aux_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming));
+    if (m->aux_stream && m->ev_fork && m->ev_join) return FZB_OK;
+    // all three or none: created into locals and published together, so a failure half way leaves the matcher on its single-stream path
+    hipStream_t s = nullptr;
+    hipEvent_t ef = nullptr, ej = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ef, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ej, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        if (ej) (void)hipEventDestroy(ej);
+        if (ef) (void)hipEventDestroy(ef);
+        if (s) (void)hipStreamDestroy(s);
+        return fail(FZB_ERR_HIP, std::string("second stream of the query: ") + hipGetErrorString(e));
+    }
+    m->aux_stream = s;
+    m->ev_fork = ef;
+    m->ev_join = ej;
     return FZB_OK;
 }
 static int ensure_fused_buffers(fzb_matcher* m) {  // tile counts, group counts and the staging array of k12_fused, sized with the range workspace
@@ -711,7 +646,8 @@ static int ensure_sort_buffers(fzb_matcher* m, size_t cap) {  // ping-pong buffe
     w.sort_cap = cap;
     return FZB_OK;
 }
-static int ensure_out_staging(fzb_matcher* m, size_t count) {  // device-side result of the synchronous entry points
+}  // extern "C"
+int fzb_ensure_out_staging(fzb_matcher* m, size_t count) {  // device-side result of the synchronous entry points
     if (m->out_cap >= count && m->count_dev && m->out_dev) return FZB_OK;
     if (m->out_dev) (void)hipFree(m->out_dev);
     m->out_dev = nullptr;
@@ -721,6 +657,7 @@ static int ensure_out_staging(fzb_matcher* m, size_t count) {  // device-side re
     if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
     return FZB_OK;
 }
+extern "C" {
 
 // The pipeline.  items_in == nullptr: the haystacks are the contiguous range [first, first + count).  Otherwise they are the
 // listed ones, items_in[j] = index relative to `first`, *n_items_in of them (a device-side count <= count): the narrowing
@@ -778,7 +715,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     const bool filter_resets = count != 0 && !items_in && (m->literal_mode ? (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode) : lc.filter_mode != 0);
     if (!filter_resets) HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
     if (count == 0) {
-        HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
+        HIPCHK(hipMemsetAsync(dev_count, 0, 8, st));
         return FZB_OK;
     }
     if (m->literal_mode) {
@@ -954,7 +891,11 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // The class launches and the multi-chunk scorer both start from k2w_classify's lists and write disjoint records, and each is a persistent
         // grid whose last round leaves most of the chip idle (the multi-chunk scorer's third round is 4 % full on the C4 shard): the multi-chunk
         // scorer runs on a second stream, forked after the classifier and joined before the caller's stream continues.
-        const bool fork = classes && !no_wide && !no_overlap && ensure_aux_stream(m) == FZB_OK;
+        bool fork = classes && !no_wide && !no_overlap;
+        if (fork && ensure_aux_stream(m) != FZB_OK) {  // no second stream: everything on the caller's stream (the error text is dropped with the fallback)
+            fork = false;
+            fzb_clear_error();
+        }
         if (classes)
             fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
                                   (u32)w.cap_cls, cus, st, fork ? 1 : 0);
@@ -1010,7 +951,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
     if (!m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
     if (fzb_fused_applies(c->dev, m->lc, m->nd, m->lc.window_mode) && (rc = ensure_fused_buffers(m))) return rc;
-    if ((rc = ensure_out_staging(m, n))) return rc;
+    if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;
     return FZB_OK;
 }
@@ -1022,28 +963,39 @@ int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, siz
 
 int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream) {
     if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
+    return fzb_sorted_range_device(m, c, 0, c->dev.n, 0, dev_out, capacity, dev_count, stream);
+}
+
+}  // extern "C"
+// The ordered form over any sub-range, records numbered from index_offset: what one worker of `match_list_parallel` produces for its
+// share (per-run reverse / radix sort, src/matcher/parallel.rs:66-76) - fzb_match_list_parallel_sharded runs one per device
+int fzb_sorted_range_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity, uint32_t* dev_count,
+                            void* stream) {
+    if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
+    if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
     const int sort = m->config.sort;
     const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;          // src/matcher/mod.rs:215-217
     const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;  // :218-220
     Workspace& w = m->ws;
-    const size_t cap = std::min<size_t>(capacity, c->dev.n);
+    const size_t cap = std::min<size_t>(capacity, count);
     // one radix pass is enough when no score can reach 256 (Scoring::guard's bound on the matrix + the exact-match bonus added after it)
     const bool one_pass = !m->literal_mode && max_matrix_score(m->config.scoring, (size_t)m->rows) + (size_t)m->config.scoring.exact_match_bonus < 256;
     // With a single pass the pipeline writes its index-ordered records into the sort's second buffer and the pass scatters them into the
     // caller's array: no copy back.
-    const bool via_tmp = by_score && one_pass && !m->empty && c->dev.n != 0 && cap != 0;
+    const bool via_tmp = by_score && one_pass && !m->empty && count != 0 && cap != 0;
     int rc;
     // (the range workspace first: growing it releases every workspace buffer, the sort's included)
-    if (via_tmp && ((rc = ensure_workspace(m, c->dev.n)) || (rc = ensure_sort_buffers(m, cap)))) return rc;
-    rc = fzb_match_list_device(m, c, 0, c->dev.n, 0, via_tmp ? (fzb_match*)w.sort_tmp : dev_out, via_tmp ? cap : capacity, dev_count, stream);
+    if (via_tmp && ((rc = ensure_workspace(m, count)) || (rc = ensure_sort_buffers(m, cap)))) return rc;
+    rc = fzb_match_list_device(m, c, first, count, index_offset, via_tmp ? (fzb_match*)w.sort_tmp : dev_out, via_tmp ? cap : capacity, dev_count, stream);
     if (rc) return rc;
-    if ((!reversed && !by_score) || c->dev.n == 0) return FZB_OK;
+    if ((!reversed && !by_score) || count == 0) return FZB_OK;
     if (by_score && !via_tmp && (rc = ensure_sort_buffers(m, cap))) return rc;
     fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream,
                     via_tmp ? -1 : one_pass ? 1 : 2);
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }
+extern "C" {
 
 // Result lists handed to the caller live in page-locked host memory so that the device-to-host copy of the records runs at
 // DMA speed (a pageable destination is staged through bounce buffers: ~3x slower for a 4 MB list).  Pinning is expensive, so
@@ -1055,7 +1007,7 @@ struct PinnedPool {
     std::mutex mu;
     std::unordered_map<void*, size_t> live;             // handed out: pointer -> capacity in bytes
     std::vector<std::pair<void*, size_t>> free_list;    // ready for reuse
-    static constexpr size_t kMaxFree = 8;
+    static constexpr size_t kMaxFree = 32;  // result lists + the staging buffers of an upload (two per worker thread)
     void* get(size_t bytes) {
         std::lock_guard<std::mutex> g(mu);
         size_t best = free_list.size();
@@ -1089,6 +1041,10 @@ PinnedPool& pinned_pool() {
     static PinnedPool* pool = new PinnedPool;  // never destroyed: the HIP runtime may already be gone at exit
     return *pool;
 }
+}  // namespace
+void* fzb_pinned_get(size_t bytes) { return pinned_pool().get(bytes); }
+bool fzb_pinned_put(void* p) { return pinned_pool().put(p); }
+namespace {
 // count (device) -> host, then the records into a pooled pinned buffer
 int fetch_records(const void* dev_records, const u32* dev_count, fzb_match** out, size_t* out_len) {
     u32 n = 0;
@@ -1124,7 +1080,7 @@ int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         *out_len = count;
         return FZB_OK;
     }
-    if (int rc_ = ensure_out_staging(m, count)) return rc_;
+    if (int rc_ = fzb_ensure_out_staging(m, count)) return rc_;
     int rc = fzb_match_list_device(m, c, first, count, index_offset, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
     return fetch_records(m->out_dev, m->count_dev, out, out_len);
@@ -1159,7 +1115,7 @@ int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t*
     const size_t count = c->dev.n;
     *out = nullptr;
     *out_len = 0;
-    if (int rc_ = ensure_out_staging(m, count)) return rc_;
+    if (int rc_ = fzb_ensure_out_staging(m, count)) return rc_;
     // scoring AND the reverse / stable radix sort post-step run on the device; the host only receives the final list
     int rc = fzb_match_list_sorted_device(m, c, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
@@ -1208,7 +1164,7 @@ int indices_in_list_order(fzb_matcher* m, const fzb_corpus* c, const uint32_t* s
         m->trace_cap = count;
         m->trace_pos_words = count * (size_t)stride;
     }
-    if (int rc_ = ensure_out_staging(m, count)) return rc_;
+    if (int rc_ = fzb_ensure_out_staging(m, count)) return rc_;
     const u32* items_dev = nullptr;
     const u32* n_items_dev = nullptr;
     if (selection) {
@@ -1404,7 +1360,7 @@ struct fzb_multi_matcher {
     // and the bitmap / per-tile counts of the negation's compaction
     size_t cap = 0;
     fzb_match_rec* cand[2] = {nullptr, nullptr};
-    u32* counts = nullptr;  // [0],[1] = lengths of cand[0], cand[1]
+    u32* counts = nullptr;  // [0],[4] = lengths of cand[0], cand[1]; [8] = hits of a negated pattern (each slot: count, untruncated total)
     u32* items = nullptr;
     u64* bitmap = nullptr;
     u32* tile_counts = nullptr;
@@ -1482,7 +1438,7 @@ int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size
     const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
     auto& ps = mm->patterns;
     if (count == 0) {
-        HIPCHK(hipMemsetAsync(dev_count, 0, 4, st));
+        HIPCHK(hipMemsetAsync(dev_count, 0, 8, st));
         return FZB_OK;
     }
     // CompiledPatterns::{Empty, Single, Multi} (src/matcher/mod.rs:178-190; a single NEGATED pattern is Multi)
@@ -1511,32 +1467,32 @@ int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size
     int cur = 0;  // cand[cur] / counts[cur] = the candidates
     int rc;
     if (base != ps.size()) {
-        rc = fzb_match_list_device(ps[base].m, c, first, count, index_offset, (fzb_match*)mm->cand[0], mm->cap, &mm->counts[0], stream);
+        rc = fzb_match_list_device(ps[base].m, c, first, count, index_offset, (fzb_match*)mm->cand[0], mm->cap, &mm->counts[4 * 0], stream);
         if (rc) return rc;
     } else {
-        fzb_launch_identity_records(mm->cand[0], (u32)count, index_offset, &mm->counts[0], cus * 2, st);  // all patterns negated: every haystack is a candidate
+        fzb_launch_identity_records(mm->cand[0], (u32)count, index_offset, &mm->counts[4 * 0], cus * 2, st);  // all patterns negated: every haystack is a candidate
     }
     for (size_t pi = 0; pi < ps.size(); pi++) {
         if (pi == base) continue;
         // (the reference skips the remaining patterns once no candidate is left; with the count on the device the kernels just find nothing to do)
-        fzb_launch_records_to_items(mm->cand[cur], &mm->counts[cur], index_offset, mm->items, cus * 2, st);
+        fzb_launch_records_to_items(mm->cand[cur], &mm->counts[4 * cur], index_offset, mm->items, cus * 2, st);
         const int oth = cur ^ 1;
         if (!ps[pi].negated) {
-            rc = run_pipeline(ps[pi].m, c, first, count, index_offset, mm->items, &mm->counts[cur], (fzb_match*)mm->cand[oth], mm->cap, &mm->counts[oth], stream);
+            rc = run_pipeline(ps[pi].m, c, first, count, index_offset, mm->items, &mm->counts[4 * cur], (fzb_match*)mm->cand[oth], mm->cap, &mm->counts[4 * oth], stream);
             if (rc) return rc;
-            fzb_launch_join_add(mm->cand[oth], &mm->counts[oth], mm->cand[cur], &mm->counts[cur], cus * 2, st);
+            fzb_launch_join_add(mm->cand[oth], &mm->counts[4 * oth], mm->cand[cur], &mm->counts[4 * cur], cus * 2, st);
             cur = oth;
         } else {
             // the negated pattern's hits land in the other slot; k_flag_absent reads them, then k_compact_records (next in stream
             // order) overwrites that same slot with the candidates that were not hit
             fzb_match_rec* hits = mm->cand[oth];
-            rc = run_pipeline(ps[pi].m, c, first, count, index_offset, mm->items, &mm->counts[cur], (fzb_match*)hits, mm->cap, &mm->counts[2], stream);
+            rc = run_pipeline(ps[pi].m, c, first, count, index_offset, mm->items, &mm->counts[4 * cur], (fzb_match*)hits, mm->cap, &mm->counts[4 * 2], stream);
             if (rc) return rc;
-            fzb_launch_remove_hits(mm->cand[cur], &mm->counts[cur], hits, &mm->counts[2], mm->bitmap, mm->tile_counts, mm->cand[oth], &mm->counts[oth], cus * 2, st);
+            fzb_launch_remove_hits(mm->cand[cur], &mm->counts[4 * cur], hits, &mm->counts[4 * 2], mm->bitmap, mm->tile_counts, mm->cand[oth], &mm->counts[4 * oth], cus * 2, st);
             cur = oth;
         }
     }
-    fzb_launch_copy_records(mm->cand[cur], &mm->counts[cur], (fzb_match_rec*)dev_out, cap32, dev_count, cus * 2, st);
+    fzb_launch_copy_records(mm->cand[cur], &mm->counts[4 * cur], (fzb_match_rec*)dev_out, cap32, dev_count, cus * 2, st);
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }
@@ -1691,31 +1647,43 @@ static bool merge_less(int order, const fzb_match& l, const fzb_match& r) {  // 
 
 int fzb_k_merge_matches(int32_t sort, const fzb_match* runs, const size_t* run_lens, size_t nruns, fzb_match* out) {
     if (sort < 0 || sort > 3 || (nruns && (!run_lens))) return fail(FZB_ERR_INVALID, "bad argument");
-    {
-        size_t total = 0;
-        for (size_t k = 0; k < nruns; k++) total += run_lens[k];
-        if (total && (!runs || !out)) return fail(FZB_ERR_INVALID, "null argument");
-    }
-    // tournament over run heads (any correct k-way merge of runs sorted under a TOTAL order yields the same sequence)
-    std::vector<size_t> start(nruns), pos(nruns, 0);
+    size_t total = 0;
+    for (size_t k = 0; k < nruns; k++) total += run_lens[k];
+    if (total && (!runs || !out)) return fail(FZB_ERR_INVALID, "null argument");
+    std::vector<const fzb_match*> ptrs(nruns);
     size_t off = 0;
-    for (size_t k = 0; k < nruns; k++) { start[k] = off; off += run_lens[k]; }
+    for (size_t k = 0; k < nruns; k++) { ptrs[k] = runs + off; off += run_lens[k]; }
+    return fzb_k_merge_runs(sort, ptrs.data(), run_lens, nruns, out);
+}
+
+}  // extern "C"
+int fzb_k_merge_runs(int32_t sort, const fzb_match* const* runs, const size_t* run_lens, size_t nruns, fzb_match* out) {
+    if (sort < 0 || sort > 3 || (nruns && (!run_lens || !runs))) return fail(FZB_ERR_INVALID, "bad argument");
+    // tournament over run heads (any correct k-way merge of runs sorted under a TOTAL order yields the same sequence)
+    std::vector<size_t> pos(nruns, 0);
     std::vector<size_t> heap;
-    auto less_run = [&](size_t a, size_t b) { return merge_less(sort, runs[start[a] + pos[a]], runs[start[b] + pos[b]]); };
+    auto less_run = [&](size_t a, size_t b) { return merge_less(sort, runs[a][pos[a]], runs[b][pos[b]]); };
     auto cmp = [&](size_t a, size_t b) { return less_run(b, a); };  // std heap is a max-heap
     for (size_t k = 0; k < nruns; k++)
         if (run_lens[k]) heap.push_back(k);
+    if (!heap.empty() && !out) return fail(FZB_ERR_INVALID, "null argument");
     std::make_heap(heap.begin(), heap.end(), cmp);
     size_t o = 0;
     while (!heap.empty()) {
+        if (heap.size() == 1) {  // one run left: the rest is a copy
+            const size_t k = heap[0];
+            memcpy(out + o, runs[k] + pos[k], (run_lens[k] - pos[k]) * sizeof(fzb_match));
+            break;
+        }
         std::pop_heap(heap.begin(), heap.end(), cmp);
         const size_t k = heap.back();
-        out[o++] = runs[start[k] + pos[k]];
+        out[o++] = runs[k][pos[k]];
         if (++pos[k] < run_lens[k]) std::push_heap(heap.begin(), heap.end(), cmp);
         else heap.pop_back();
     }
     return FZB_OK;
 }
+extern "C" {
 
 int fzb_set_profiling(fzb_matcher* m, int enabled) {
     if (!m) return fail(FZB_ERR_INVALID, "null argument");
@@ -1731,7 +1699,7 @@ int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
     if (!m->profiling || m->prof_calls == 0) return fail(FZB_ERR_INVALID, "profiling not enabled or no call recorded");
     const u64 n = std::min<u64>(m->prof_calls, fzb_matcher::PROF_SLOTS);
     double f = 0, t = 0;
-    int has_filter = 0;
+    u64 n_filter = 0;
     for (u64 i = 0; i < n; i++) {
         const int slot = (int)((m->prof_calls - 1 - i) % fzb_matcher::PROF_SLOTS);
         hipEvent_t* e = m->evring[slot];
@@ -1739,17 +1707,17 @@ int fzb_last_timings(fzb_matcher* m, float out_ms[4]) {
         float b = 0;
         HIPCHK(hipEventElapsedTime(&b, e[0], e[1]));
         t += b;
-        has_filter = m->ev_filter[slot];
-        if (has_filter) {
+        if (m->ev_filter[slot]) {
             float a = 0;
             HIPCHK(hipEventElapsedTime(&a, e[2], e[3]));
             f += a;
+            n_filter++;
         }
     }
-    out_ms[0] = (float)(f / n);
+    out_ms[0] = n_filter ? (float)(f / n_filter) : 0.0f;
     out_ms[1] = (float)(t / n);
     out_ms[2] = (float)n;
-    out_ms[3] = (float)has_filter;
+    out_ms[3] = (float)n_filter;
     return FZB_OK;
 }
 
@@ -1759,8 +1727,10 @@ int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]) {
     if (!m || !out_ms) return fail(FZB_ERR_INVALID, "null argument");
     if (!m->profiling || m->prof_calls == 0) return fail(FZB_ERR_INVALID, "profiling not enabled or no call recorded");
     const u64 n = std::min<u64>(m->prof_calls, fzb_matcher::PROF_SLOTS);
+    // calls with a streaming filter kernel and calls without one (item lists, no prefilter) are averaged separately: the filter
+    // figure is the mean over the calls that had one, "compaction" the mean of what lies between filter and scorers in each kind
     double f = 0, mid = 0, sc = 0, t = 0;
-    int has_filter = 0;
+    u64 n_filter = 0;
     for (u64 i = 0; i < n; i++) {
         const int slot = (int)((m->prof_calls - 1 - i) % fzb_matcher::PROF_SLOTS);
         hipEvent_t* e = m->evring[slot];
@@ -1770,8 +1740,8 @@ int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]) {
         t += a;
         HIPCHK(hipEventElapsedTime(&a, e[4], e[1]));
         sc += a;
-        has_filter = m->ev_filter[slot];
-        if (has_filter) {
+        if (m->ev_filter[slot]) {
+            n_filter++;
             HIPCHK(hipEventElapsedTime(&a, e[2], e[3]));
             f += a;
             HIPCHK(hipEventElapsedTime(&a, e[3], e[4]));
@@ -1781,12 +1751,12 @@ int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]) {
             mid += a;
         }
     }
-    out_ms[0] = (float)(f / n);
+    out_ms[0] = n_filter ? (float)(f / n_filter) : 0.0f;
     out_ms[1] = (float)(mid / n);
     out_ms[2] = (float)(sc / n);
     out_ms[3] = (float)(t / n);
     out_ms[4] = (float)n;
-    out_ms[5] = (float)has_filter;
+    out_ms[5] = (float)n_filter;  // calls (of the averaged ones) that ran a streaming filter kernel; 0 = none
     return FZB_OK;
 }
 

@@ -1,0 +1,81 @@
+// Host-side internals shared by the translation units of the C ABI (host.hip: matcher + pipeline; host_upload.hip: corpus upload;
+// host_shard.hip: the multi-device form).  Not part of the boundary: include/frizbee_hip.h is.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/frizbee_hip.h"
+#include "fzb_internal.h"
+
+// error state of the calling thread (fzb_last_error) + the usual early return
+int fzb_fail(int code, const std::string& msg);
+void fzb_clear_error();
+#define HIPCHK(expr)                                                                                            \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) return fzb_fail(FZB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline hipError_t fzb_dev_alloc(void** p, size_t bytes) { return hipMalloc(p, bytes ? bytes : 16); }
+
+struct fzb_corpus {
+    CorpusDev dev{};
+    void* own_bytes = nullptr;
+    void* own_ends = nullptr;
+};
+
+struct fzb_matcher {
+    fzb_config config{};
+    std::string needle;
+    bool empty = false, case_sensitive = false, unicode = false, use_u8 = false;
+    int literal_mode = 0;  // 0 = fuzzy; else FZB_MATCH_EXACT / PREFIX / SUFFIX / SUBSTRING (src/literal)
+    int rows = 0;
+    NeedleDev nd{};
+    LaunchCfg lc{};
+    std::vector<u64> table;  // host copy of the filter table
+    std::vector<u8> dfa;     // host copy of the subsequence DFA
+    std::vector<u8> uni_dfa; // unicode path, 0 typos: byte-level DFA of the exact prefilter (empty if it needs more than 255 states)
+    int uni_dfa_states = 0;
+    Workspace ws{};
+    int device = -1;
+    bool profiling = false;
+    static constexpr int PROF_SLOTS = 32;  // ring of per-call events: [0]=pipeline start [1]=pipeline end [2],[3]=around the filter kernel [4]=before the scorers
+    hipEvent_t evring[PROF_SLOTS][5] = {};
+    hipStream_t aux_stream = nullptr;  // second stream of a query (multi-chunk scorer beside the class launches) and its fork / join events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int ev_filter[PROF_SLOTS] = {};
+    u64 prof_calls = 0;
+
+    u32 last_counters[4] = {0, 0, 0, 0};
+    // staging for the synchronous API
+    fzb_match_rec* out_dev = nullptr;
+    size_t out_cap = 0;
+    u32* count_dev = nullptr;
+    // fzb_match_list_indices: the selection (+ its length), the positions (`stride` per record) and their counts
+    u32* trace_sel = nullptr;
+    u32* trace_pos = nullptr;
+    u32* trace_npos = nullptr;
+    size_t trace_cap = 0, trace_pos_words = 0;
+    // multi-device form (host_shard.hip): the per-shard clones of this matcher (their device state lives on the shard's device);
+    // on a clone: its stream and the device it is bound to
+    std::vector<fzb_matcher*> shard_clones;
+    hipStream_t shard_stream = nullptr;
+    int shard_device = -1;
+};
+
+
+// pooled page-locked host buffers (result lists, upload staging): get() returns nullptr on failure; put() returns false for a pointer
+// that is not the pool's
+void* fzb_pinned_get(size_t bytes);
+bool fzb_pinned_put(void* p);
+
+// host.hip internals used by the other translation units
+int fzb_ensure_out_staging(fzb_matcher* m, size_t count);
+// `Matcher::match_list` over the sub-range [first, first + count) of a corpus, records numbered from index_offset, ordered per
+// config.sort on the device (fzb_match_list_sorted_device = the whole corpus from 0)
+// k_merge_matches_by_* (src/k_merge.rs:56-132) over runs given by pointer
+int fzb_k_merge_runs(int32_t sort, const fzb_match* const* runs, const size_t* run_lens, size_t nruns, fzb_match* out);
+int fzb_sorted_range_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity, uint32_t* dev_count,
+                            void* stream);

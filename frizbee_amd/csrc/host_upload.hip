@@ -1,0 +1,369 @@
+// fzb_corpus_upload: what `match_list(&haystacks)` borrows (src/matcher/mod.rs:212), brought into HBM at link speed.
+//
+// The caller's two arrays (all haystack bytes back to back + exclusive end offsets) travel AS THEY ARE: several host threads each
+// own a slice of the source, copy it piecewise into their own small page-locked staging buffers and queue asynchronous H2D copies on
+// their own stream (a pageable hipMemcpy is staged by ONE runtime thread through bounce buffers: 3.9 GB/s for the 10 M x 32 B list of
+// round 2; the DMA engines take >= 50 GB/s).  The library's device layout ("padded-16": every haystack on a 16-byte boundary, zero
+// gaps, end offsets inside that layout) is then built ON the device:
+//   k_up_tiles    per 1024 haystacks: sum of the padded lengths, min / max length, "offsets decrease" flag
+//   k_up_scan     exclusive scan of the tile sums (one workgroup)
+//   k_up_build    per tile: the haystacks' padded starts (scan in LDS), the end offsets in the padded layout, and the bytes - one
+//                 thread per 16-byte OUTPUT vector (binary search of its haystack in the tile's starts), so writes are whole aligned
+//                 vectors and reads run along each haystack
+// A list whose lengths are all multiples of 16 (the 32-byte bench lists) already IS the padded layout: the uploaded buffer is kept and
+// only the offsets are rewritten.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+#include "host_internal.h"
+
+namespace {
+
+constexpr int UP_TILE = 1024;
+constexpr int UP_THREADS = 256;
+
+// stats block (device, 64 bytes): [0] total padded bytes (u64) [1] min len [2] max len (u64 each) [3] bad flag
+struct UpStats {
+    u64 total_padded, min_len, max_len, bad;
+};
+
+__global__ __launch_bounds__(UP_THREADS) void k_up_tiles(const u64* __restrict__ ends, u64 n, u64 ends_base, u64* __restrict__ tile_sums, UpStats* __restrict__ stats) {
+    __shared__ u64 s_sum[UP_THREADS / 64];
+    __shared__ u64 s_min[UP_THREADS / 64];
+    __shared__ u64 s_max[UP_THREADS / 64];
+    const u64 tile = blockIdx.x;
+    u64 sum = 0, mn = ~(u64)0, mx = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < UP_TILE / UP_THREADS; k++) {
+        const u64 i = tile * UP_TILE + (u64)k * UP_THREADS + threadIdx.x;
+        if (i < n) {
+            const u64 e = ends[i], p = i ? ends[i - 1] : ends_base;
+            if (e < p) bad = true;
+            const u64 len = e >= p ? e - p : 0;
+            sum += (len + 15) & ~(u64)15;
+            mn = min(mn, len);
+            mx = max(mx, len);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off);
+        mn = min(mn, (u64)__shfl_xor(mn, off));
+        mx = max(mx, (u64)__shfl_xor(mx, off));
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr((unsigned long long*)&stats->bad, 1ull);
+    if ((threadIdx.x & 63) == 0) {
+        s_sum[threadIdx.x >> 6] = sum;
+        s_min[threadIdx.x >> 6] = mn;
+        s_max[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0, a = ~(u64)0, b = 0;
+        for (int w = 0; w < UP_THREADS / 64; w++) {
+            t += s_sum[w];
+            a = min(a, s_min[w]);
+            b = max(b, s_max[w]);
+        }
+        tile_sums[tile] = t;
+        atomicMin((unsigned long long*)&stats->min_len, (unsigned long long)a);
+        atomicMax((unsigned long long*)&stats->max_len, (unsigned long long)b);
+    }
+}
+
+// exclusive scan of the tile sums in place (one workgroup of 1024 threads, chunks of 1024 tiles with a running carry)
+__global__ __launch_bounds__(1024) void k_up_scan(u64* __restrict__ tile_sums, u64 ntiles, UpStats* __restrict__ stats) {
+    __shared__ u64 s_wave[16];
+    __shared__ u64 s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (u64 base = 0; base < ntiles; base += 1024) {
+        const u64 i = base + threadIdx.x;
+        const u64 v = i < ntiles ? tile_sums[i] : 0;
+        u64 incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u64 t = __shfl_up(incl, off);
+            if ((int)(threadIdx.x & 63) >= off) incl += t;
+        }
+        if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        u64 wave_base = 0;
+        for (u32 w = 0; w < (threadIdx.x >> 6); w++) wave_base += s_wave[w];
+        const u64 carry = s_carry;
+        if (i < ntiles) tile_sums[i] = carry + wave_base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_base + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stats->total_padded = s_carry;
+}
+
+// ET = u32 / u64 end offsets of the padded layout.  COPY = false: the raw buffer already is the padded layout (only offsets are written).
+template <typename ET, bool COPY>
+__global__ __launch_bounds__(UP_THREADS) void k_up_build(const u8* __restrict__ raw, const u64* __restrict__ ends, u64 n, u64 ends_base, const u64* __restrict__ tile_base,
+                                                         u8* __restrict__ padded, ET* __restrict__ ends_out) {
+    __shared__ u64 s_pstart[UP_TILE + 1];  // padded start of each haystack of the tile, relative to the tile's base
+    __shared__ u64 s_wave[UP_THREADS / 64];
+    const u64 tile = blockIdx.x;
+    const u64 i0 = tile * UP_TILE;
+    const u64 base = tile_base[tile];
+    // every thread owns 4 CONSECUTIVE haystacks: serial prefix of their padded lengths, then a scan over the threads
+    const u64 first = i0 + (u64)threadIdx.x * 4;
+    const u64 e_prev = first == 0 ? ends_base : (first <= n ? ends[first - 1] : 0);
+    u64 plen[4], e[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 i = first + k;
+        const u64 p = k ? e[k - 1] : e_prev;
+        e[k] = i < n ? ends[i] : p;
+        plen[k] = ((e[k] - p) + 15) & ~(u64)15;
+        mine += plen[k];
+    }
+    u64 incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const u64 t = __shfl_up(incl, off);
+        if ((int)(threadIdx.x & 63) >= off) incl += t;
+    }
+    if ((threadIdx.x & 63) == 63) s_wave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    u64 run = incl - mine;
+    for (u32 w = 0; w < (threadIdx.x >> 6); w++) run += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u64 i = first + k;
+        s_pstart[threadIdx.x * 4 + k] = run;
+        if (i < n) ends_out[i] = (ET)(base + run + (e[k] - (k ? e[k - 1] : e_prev)));
+        run += plen[k];
+    }
+    if (threadIdx.x == UP_THREADS - 1) s_pstart[UP_TILE] = run;
+    __syncthreads();
+    if (!COPY) return;
+    const u64 tile_bytes = s_pstart[UP_TILE];
+    const u32 cnt = (u32)min((u64)UP_TILE, n - i0);
+    for (u64 v = (u64)threadIdx.x * 16u; v < tile_bytes; v += UP_THREADS * 16u) {
+        // the haystack this output vector belongs to: last j with pstart[j] <= v (empty haystacks share a start with their successor:
+        // the search lands on the last of them, the one that owns the bytes)
+        u32 lo = 0, hi = cnt;
+        while (hi - lo > 1) {
+            const u32 mid = (lo + hi) >> 1;
+            if (s_pstart[mid] <= v) lo = mid;
+            else hi = mid;
+        }
+        const u64 i = i0 + lo;
+        const u64 src_lo = i ? ends[i - 1] : ends_base, src_hi = ends[i];
+        const u64 off = v - s_pstart[lo];
+        const u64 len = src_hi - src_lo;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (off < len) {
+            const u64 p = src_lo - ends_base + off;  // byte position in `raw`
+            const u32 rem = (u32)min((u64)16, len - off);
+            const u32* a = (const u32*)(raw + (p & ~(u64)3));
+            const u32 sh = (u32)(p & 3);
+            // 16 bytes from an arbitrary byte position: five aligned dwords, funnel-shifted (the raw buffer has >= 96 readable bytes of slack)
+            const u32 w0 = a[0], w1 = a[1], w2 = a[2], w3 = a[3], w4 = sh ? a[4] : 0u;
+            u32 x[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh), __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const u32 lo_b = 4u * k;
+                if (rem <= lo_b) x[k] = 0;
+                else if (rem - lo_b < 4) x[k] &= (1u << (8 * (rem - lo_b))) - 1;
+            }
+            q = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+        *(uint4*)(padded + base + v) = q;
+    }
+}
+
+// ---- host -> device at link speed ---------------------------------------------------------------------------------------------
+// FZB_UPLOAD_MODE: "staged" (default; per-thread pinned staging + async copies), "register" (hipHostRegister the caller's memory, one
+// async copy), "pageable" (plain hipMemcpy: round 2's path, kept for comparison)
+int upload_mode() {
+    static const int mode = [] {
+        const char* e = getenv("FZB_UPLOAD_MODE");
+        if (!e) return 0;
+        if (!strcmp(e, "register")) return 1;
+        if (!strcmp(e, "pageable")) return 2;
+        return 0;
+    }();
+    return mode;
+}
+
+struct H2DJob {
+    void* dst;
+    const void* src;
+    size_t bytes;
+};
+
+// copies every job; returns hipSuccess or the first error
+hipError_t h2d_all(const std::vector<H2DJob>& jobs, int device) {
+    size_t total = 0;
+    for (const H2DJob& j : jobs) total += j.bytes;
+    if (total == 0) return hipSuccess;
+    const int mode = upload_mode();
+    if (mode == 2 || total < ((size_t)1 << 20)) {
+        for (const H2DJob& j : jobs)
+            if (j.bytes) {
+                hipError_t e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
+                if (e != hipSuccess) return e;
+            }
+        return hipSuccess;
+    }
+    if (mode == 1) {
+        for (const H2DJob& j : jobs) {
+            if (!j.bytes) continue;
+            hipError_t e = hipHostRegister((void*)j.src, j.bytes, hipHostRegisterDefault);
+            if (e != hipSuccess) {  // not registrable (e.g. read-only mapping): the plain copy still works
+                (void)hipGetLastError();
+                e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
+                if (e != hipSuccess) return e;
+                continue;
+            }
+            e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
+            (void)hipHostUnregister((void*)j.src);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+    // staged: the concatenation of all jobs is cut into equal slices, one per worker thread
+    constexpr size_t CHUNK = (size_t)4 << 20;
+    const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+    static const size_t env_threads = getenv("FZB_UPLOAD_THREADS") ? (size_t)atoi(getenv("FZB_UPLOAD_THREADS")) : 0;
+    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({env_threads ? env_threads : (size_t)12, hw, (total + CHUNK - 1) / CHUNK}));
+    const size_t per = ((total + nthreads - 1) / nthreads + 63) & ~(size_t)63;
+    std::vector<hipError_t> errs(nthreads, hipSuccess);
+    auto worker = [&](size_t t) {
+        hipError_t e = hipSetDevice(device);
+        hipStream_t st = nullptr;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        void* stage[2] = {nullptr, nullptr};
+        bool used[2] = {false, false};
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        for (int k = 0; k < 2 && e == hipSuccess; k++) {
+            e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+            if (e == hipSuccess && !(stage[k] = fzb_pinned_get(CHUNK))) e = hipErrorOutOfMemory;
+        }
+        size_t lo = std::min(t * per, total), hi = std::min(lo + per, total);  // this worker's byte range of the concatenation
+        size_t job = 0, job_lo = 0;
+        int slot = 0;
+        while (e == hipSuccess && lo < hi) {
+            while (job < jobs.size() && lo >= job_lo + jobs[job].bytes) job_lo += jobs[job++].bytes;
+            const size_t off = lo - job_lo;
+            const size_t len = std::min({CHUNK, hi - lo, jobs[job].bytes - off});
+            if (used[slot]) e = hipEventSynchronize(ev[slot]);
+            if (e != hipSuccess) break;
+            memcpy(stage[slot], (const u8*)jobs[job].src + off, len);
+            e = hipMemcpyAsync((u8*)jobs[job].dst + off, stage[slot], len, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(ev[slot], st);
+            used[slot] = true;
+            slot ^= 1;
+            lo += len;
+        }
+        if (st) {
+            hipError_t e2 = hipStreamSynchronize(st);
+            if (e == hipSuccess) e = e2;
+            (void)hipStreamDestroy(st);
+        }
+        for (int k = 0; k < 2; k++) {
+            if (ev[k]) (void)hipEventDestroy(ev[k]);
+            if (stage[k]) fzb_pinned_put(stage[k]);
+        }
+        errs[t] = e;
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker, t);
+    worker(0);
+    for (auto& th : pool) th.join();
+    for (hipError_t e : errs)
+        if (e != hipSuccess) return e;
+    return hipSuccess;
+}
+
+}  // namespace
+
+// The upload proper, on the CURRENT device: `bytes` points at the first byte of haystack 0 of this list, `end_offsets[i]` are exclusive
+// ends counted from `ends_base` (0 for a whole list; a shard passes the end of the haystack before its first one).
+int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, size_t n, uint64_t ends_base, fzb_corpus** out) {
+    if (!out || (n && (!bytes || !end_offsets))) return fzb_fail(FZB_ERR_INVALID, "null argument");
+    if (n > 0xFFFFFFFFull)
+        return fzb_fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(n) + " > 4294967295 (index offset: 0)");
+    if (n && end_offsets[n - 1] < ends_base) return fzb_fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
+    int device = 0;
+    HIPCHK(hipGetDevice(&device));
+    const u64 raw_bytes = n ? end_offsets[n - 1] - ends_base : 0;
+    const u64 ntiles = (n + UP_TILE - 1) / UP_TILE;
+    auto c = new fzb_corpus();
+    u8* d_raw = nullptr;
+    u64* d_ends64 = nullptr;
+    u64* d_tiles = nullptr;
+    UpStats* d_stats = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)d_raw, (void*)d_ends64, (void*)d_tiles, (void*)d_stats})
+            if (p) (void)hipFree(p);
+    };
+    auto bail = [&](hipError_t e, const char* what) {
+        cleanup();
+        fzb_corpus_free(c);
+        return fzb_fail(FZB_ERR_HIP, std::string("corpus upload (") + what + "): " + hipGetErrorString(e));
+    };
+    hipError_t e = fzb_dev_alloc((void**)&d_raw, raw_bytes + 96);
+    if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_ends64, std::max<size_t>(n, 1) * 8);
+    if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_tiles, std::max<u64>(ntiles, 1) * 8);
+    if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_stats, sizeof(UpStats));
+    if (e != hipSuccess) return bail(e, "device buffers");
+    const UpStats init{0, ~(u64)0, 0, 0};
+    e = hipMemcpy(d_stats, &init, sizeof(init), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(d_raw + raw_bytes, 0, 96);
+    if (e == hipSuccess) e = h2d_all({H2DJob{d_ends64, end_offsets, n * 8}, H2DJob{d_raw, bytes, (size_t)raw_bytes}}, device);
+    if (e != hipSuccess) return bail(e, "host to device");
+    UpStats st{0, 0, 0, 0};
+    if (n) {
+        hipLaunchKernelGGL(k_up_tiles, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, d_ends64, (u64)n, ends_base, d_tiles, d_stats);
+        hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, nullptr, d_tiles, ntiles, d_stats);
+        e = hipMemcpy(&st, d_stats, sizeof(st), hipMemcpyDeviceToHost);  // the one synchronisation of the upload: sizes the padded buffer
+        if (e != hipSuccess) return bail(e, "layout pass");
+        if (st.bad) {
+            cleanup();
+            fzb_corpus_free(c);
+            return fzb_fail(FZB_ERR_INVALID, "end_offsets must be non-decreasing");
+        }
+    }
+    const u64 total = st.total_padded + 96;
+    const bool ends_u64 = total > 0xFFFFFFF0ull;
+    const bool adopt = st.total_padded == raw_bytes;  // every length a multiple of 16: the upload format is the device layout
+    c->dev.n = n;
+    c->dev.total_bytes = total;
+    c->dev.ends_u64 = ends_u64;
+    c->dev.max_len = (u32)std::min<u64>(st.max_len, 0xFFFFFFFFu);
+    c->dev.uniform_len = (n && st.min_len == st.max_len && st.max_len && st.max_len < 0xFFFFFFFFu) ? (u32)st.max_len : 0u;  // kernels then skip the end offsets
+    e = fzb_dev_alloc(&c->own_ends, std::max<size_t>(n, 1) * (ends_u64 ? 8 : 4));
+    if (e == hipSuccess && !adopt) e = fzb_dev_alloc(&c->own_bytes, total);
+    if (e != hipSuccess) return bail(e, "padded layout");
+    if (adopt) {
+        c->own_bytes = d_raw;
+        d_raw = nullptr;
+    } else {
+        e = hipMemsetAsync((u8*)c->own_bytes + st.total_padded, 0, 96, nullptr);
+        if (e != hipSuccess) return bail(e, "padded layout");
+    }
+    if (n) {
+#define FZB_UP_BUILD(ET, COPY) \
+    hipLaunchKernelGGL((k_up_build<ET, COPY>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u8*)(adopt ? (u8*)c->own_bytes : d_raw), d_ends64, (u64)n, ends_base, d_tiles, (u8*)c->own_bytes, (ET*)c->own_ends)
+        if (ends_u64) { if (adopt) FZB_UP_BUILD(u64, false); else FZB_UP_BUILD(u64, true); }
+        else { if (adopt) FZB_UP_BUILD(u32, false); else FZB_UP_BUILD(u32, true); }
+#undef FZB_UP_BUILD
+    }
+    e = hipDeviceSynchronize();  // the temporaries are released below; the corpus is complete when the call returns
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return bail(e, "layout kernels");
+    cleanup();
+    c->dev.bytes = (const u8*)c->own_bytes;
+    c->dev.ends = c->own_ends;
+    *out = c;
+    return FZB_OK;
+}
+
+extern "C" int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t n, fzb_corpus** out) {
+    return fzb_corpus_upload_impl(bytes, end_offsets, n, 0, out);
+}

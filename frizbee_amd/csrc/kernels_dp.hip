@@ -28,7 +28,7 @@ __global__ __launch_bounds__(128, 2) void k2b_dp(const u8* __restrict__ bytes, c
     build_cls_table(cls);
     __syncthreads();
     const u32 M = __builtin_amdgcn_readfirstlane(*n_items_ptr);  // wave-uniform: keeps the loop control on the scalar unit
-    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = M < capacity ? M : capacity; dev_count[1] = M; }  // [1] = the untruncated total
     // Persistent threads with a three-deep software pipeline over the dependent loads of one item
     // (survivor index / window -> end offsets -> haystack vectors): each stage is requested one iteration before it is
     // needed, so the ~7 us of integer DP of the current item cover the latency and only the prologue waits on memory.
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
     const u32 nrej = wmode == 3 ? __builtin_amdgcn_readfirstlane(*rej.count) : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const u32 kept = M - nrej;
-        if (dev_count) *dev_count = kept < capacity ? kept : capacity;
+        if (dev_count) { dev_count[0] = kept < capacity ? kept : capacity; dev_count[1] = kept; }
         if (kept_out) *kept_out = kept;
     }
     // persistent threads, three-deep software pipeline over the dependent loads of one item (see k2b_dp)
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
                                                     u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count) {
     __shared__ u32 s_cnt[5], s_base[5];
     const u32 M = __builtin_amdgcn_readfirstlane(*n_items_ptr);
-    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = M < capacity ? M : capacity; dev_count[1] = M; }  // [1] = the untruncated total
     // a workgroup takes 256 * PER survivors at a time (PER per thread) and appends its members of a class with ONE global atomic per class
     // and tile: atomics that return a value to the same address serialise in L2 (one per 256 survivors cost ~40 us on the 0.6 M
     // survivors of the ragged list)

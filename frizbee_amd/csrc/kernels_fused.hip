@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_fused_gather(const u16* __restrict__ ti
         for (int k = 2; k < 16; k++) counters[k] = 0;
         counters[0] = base;
         counters[1] = base;
-        if (dev_count) *dev_count = base < capacity ? base : capacity;
+        if (dev_count) { dev_count[0] = base < capacity ? base : capacity; dev_count[1] = base; }
     }
 }
 

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
     const int lane = lane_id();
     const int wv = threadIdx.x >> 6;
     const u32 nlist = *n_list_ptr;
-    if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = nlist < capacity ? nlist : capacity;
+    if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = nlist < capacity ? nlist : capacity; dev_count[1] = nlist; }
     const u32 LM = (u32)nd.lane_mask;
     const u32 rows = (u32)nd.rows;
     const u32 Mc = nd.match_plus_mismatch & LM, X = nd.mismatch & LM, gex = nd.gex & LM, gopm = nd.gopm & LM;

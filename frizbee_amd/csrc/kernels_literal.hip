@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_literal_score(const u8* __restrict__ by
                                                        const u32* __restrict__ n_items_ptr, const NeedleDev nd, int mode, fzb_match_rec* __restrict__ out, u32 capacity,
                                                        u32* __restrict__ dev_count, u32* __restrict__ tpos, u32* __restrict__ tnpos, u32 tstride) {
     const u32 M = *n_items_ptr;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = M < capacity ? M : capacity; dev_count[1] = M; }
     for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < M && j < capacity; j += gridDim.x * blockDim.x) {
         const u32 li = items[j];
         u64 s;

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void k_identity_records(fzb_match_rec* __restr
         r.valid = 0;
         out[j] = r;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { count_out[0] = n; count_out[1] = n; }
 }
 
 // position of the record with `index` in the index-ascending list, or n if absent
@@ -139,9 +139,10 @@ __global__ __launch_bounds__(256) void k_compact_records(const u64* __restrict__
 
 __global__ __launch_bounds__(256) void k_copy_records(const fzb_match_rec* __restrict__ in, const u32* __restrict__ n_ptr, fzb_match_rec* __restrict__ out, u32 capacity,
                                                       u32* __restrict__ count_out) {
-    const u32 n = min(*n_ptr, capacity);
+    const u32 total = *n_ptr;
+    const u32 n = min(total, capacity);
     for (u32 j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) out[j] = in[j];
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { count_out[0] = n; count_out[1] = total; }  // [1] = the untruncated total
 }
 
 void fzb_launch_records_to_items(const fzb_match_rec* cand, const u32* n_ptr, u32 index_offset, u32* items, int grid, hipStream_t st) {

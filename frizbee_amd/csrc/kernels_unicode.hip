@@ -13,7 +13,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
     build_cls_table(cls);
     __syncthreads();
     const u32 M = *n_items_ptr;
-    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) *dev_count = M < capacity ? M : capacity;
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = M < capacity ? M : capacity; dev_count[1] = M; }
     // Persistent threads with the same three-deep software pipeline as k2b_dp over the dependent loads (item / window -> end
     // offsets -> haystack bytes).  This kernel needs nearly the whole register file (one wave per SIMD), so no second wave covers
     // a stall: the stages are requested one iteration ahead, and the haystack's first line is touched one iteration ahead so that

@@ -20,18 +20,20 @@ def shard_range(n_total, rank, world):
 
 def shard_ranges_by_bytes(ends, world):
     """Byte-balanced contiguous shards of a ragged list (BASELINE config 4): `ends` = exclusive byte end of every haystack (uint64,
-    non-decreasing).  Shard g is the index range [cut[g], cut[g+1]) where cut[g] is the first haystack that starts at or after
-    g/world of the total bytes - contiguous and in list order like `shard_range`, so `index_offset = cut[g]` keeps indices global
-    (what match_list_parallel's workers do with their chunk starts, src/matcher/parallel.rs:55-63), but every GPU streams about the
-    same number of bytes.  Returns the list of (lo, hi)."""
+    non-decreasing).  Shard g is the index range [cut[g], cut[g+1]) where cut[g] is the first haystack that STARTS at or after
+    g/world of the total bytes (a haystack that straddles the byte target stays with the shard it starts in) - contiguous and in
+    list order like `shard_range`, so `index_offset = cut[g]` keeps indices global (what match_list_parallel's workers do with their
+    chunk starts, src/matcher/parallel.rs:55-63), but every GPU streams about the same number of bytes.  Returns the list of (lo, hi).
+    The C ABI's fzb_shard_ranges(by_bytes = 1) applies the same rule (tests/test_host_abi.py compares the two)."""
     ends = np.asarray(ends, dtype=np.uint64)
     n = len(ends)
     total = int(ends[-1]) if n else 0
     cuts = [0]
     for g in range(1, world):
-        # first haystack whose start offset (= previous end) is >= the byte target
+        # haystack i starts at ends[i-1]: the first i with ends[i-1] >= target is one past the first END that reaches the target
+        # (ends 10,20,30,40 and world 2: target 20 -> cut 2, shards [0,2) and [2,4), 20 bytes each)
         target = (total * g) // world
-        cuts.append(int(np.searchsorted(ends, np.uint64(target), side="left")) if target else 0)
+        cuts.append(int(np.searchsorted(ends, np.uint64(target), side="left")) + 1 if target else 0)
     cuts.append(n)
     cuts = [min(max(c, cuts[i - 1] if i else 0), n) for i, c in enumerate(cuts)]
     return [(cuts[g], cuts[g + 1]) for g in range(world)]
@@ -63,7 +65,7 @@ class ShardExchange:
     """Steady-state exchange of per-shard match lists with NO host synchronisation in the loop: a gather to the root
     rank (the process whose host consumes the merged result) of fixed-capacity buffers, double-buffered and asynchronous.
 
-    Buffer layout per rank and slot: [u32 count | u32 0 | capacity x 8-byte records].  The scoring pipeline writes the
+    Buffer layout per rank and slot: [u32 records written | u32 matches found | capacity x 8-byte records].  The scoring pipeline writes the
     count and the records straight into it (`count_ptr` / `records_ptr` are what `fzb_match_list_device` takes), `post`
     launches the gather on the backend's own stream (RCCL send/recv over the point-to-point xGMI links: the root
     receives its world-1 peers' buffers on separate links in parallel), and the next step's kernels overlap it.
@@ -112,9 +114,9 @@ class ShardExchange:
         runs = []
         for r, buf in enumerate(self.recv[slot]):
             host = buf.cpu().numpy()
-            cnt = int(host[:4].view(np.uint32)[0])
-            if cnt >= self.cap:
-                raise RuntimeError(f"shard {r} produced at least {cnt} matches, exchange capacity is {self.cap}: plan a larger capacity")
+            cnt, total = (int(x) for x in host[:8].view(np.uint32))  # fzb_match_list_device: records written, matches found (unclamped)
+            if total > self.cap or cnt > self.cap:
+                raise RuntimeError(f"shard {r} produced {max(total, cnt)} matches, exchange capacity is {self.cap}: plan a larger capacity")
             runs.append(host[self.HEADER : self.HEADER + cnt * 8].copy().view(MATCH_DTYPE))
         return runs
 

@@ -107,7 +107,9 @@ int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends
 int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len);
 /* Optional promise for borrowed corpora: EVERY haystack has exactly `len` bytes (so haystack i starts at i * roundup16(len)); the hot
  * kernels then compute the spans instead of reading the end offsets (a tenth of the filter's traffic on 32-byte records and one
- * dependent load less per survivor).  fzb_corpus_upload detects it by itself.  0 clears the promise. */
+ * dependent load less per survivor).  fzb_corpus_upload detects it by itself, and on a corpus it uploaded only the detected value is
+ * accepted (FZB_ERR_INVALID otherwise).  A non-zero `len` also becomes the corpus' max_len (overwriting fzb_corpus_set_max_len);
+ * 0 clears the promise and the bound it implied. */
 int fzb_corpus_set_uniform_len(fzb_corpus* c, uint32_t len);
 void fzb_corpus_free(fzb_corpus* c);
 size_t fzb_corpus_len(const fzb_corpus* c);
@@ -130,14 +132,14 @@ int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
 int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c);
 
 /* Device-resident form of the above for callers that keep results in HBM (benchmarks, multi-GPU gather):
- * writes the index-ordered records to dev_out (capacity records) and the record count to dev_count
- * (one uint32 in device memory), asynchronously on `stream`.  No host synchronisation.
- * CAPACITY: nothing on the host knows the number of matches when the call returns, so a buffer that is too small cannot be refused:
- * *dev_count = min(matches, capacity) and the records at positions >= capacity are NOT written (for the sorted form the sort then
- * orders that truncated prefix - its head is not the head of the full list).  capacity >= count (one record per haystack of the
- * range) can never truncate.  After synchronising the stream, fzb_last_counters() reports the untruncated totals: compare
- * out[1] (or out[0] for a 0-typo / no-prefilter matcher) with the capacity to detect a truncation; frizbee_amd.distributed.ShardExchange
- * does exactly that (`cnt >= cap` raises).  FZB_ERR_CAPACITY is returned where the host does know: an empty pattern list. */
+ * writes the index-ordered records to dev_out (capacity records) and the counts to dev_count - TWO uint32 in device memory:
+ * dev_count[0] = records written = min(matches, capacity), dev_count[1] = matches found (not clamped) - asynchronously on
+ * `stream`.  No host synchronisation.
+ * CAPACITY: nothing on the host knows the number of matches when the call returns, so a buffer that is too small cannot be
+ * refused: the records at positions >= capacity are NOT written (for the sorted form the sort then orders that truncated prefix -
+ * its head is not the head of the full list), and dev_count[1] > capacity is how the reader of the buffer sees it
+ * (frizbee_amd.distributed.ShardExchange raises on it).  capacity >= count (one record per haystack of the range) can never
+ * truncate.  FZB_ERR_CAPACITY is returned where the host does know: an empty pattern list. */
 int fzb_match_list_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset,
                           fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream);
 
@@ -152,6 +154,35 @@ int fzb_match_list_sorted_device(fzb_matcher* m, const fzb_corpus* c, fzb_match*
 int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads, fzb_match** out, size_t* out_len);
 
 void fzb_matches_free(fzb_match* p);
+
+/* ---- the multi-device form: `Matcher::match_list_parallel` with the GPUs of one node as its workers ---------------------------
+ * The reference's match_list_parallel (src/matcher/parallel.rs:18-89) cuts the list into contiguous chunks, hands every worker thread
+ * a chunk with its global index offset (:55-63), sorts each worker's run (:66-76) and k-way merges the runs (:78-87).  Here a worker
+ * is a DEVICE: the list is cut into `ndev` contiguous shards, shard g resident on device g; a query runs one host thread per shard
+ * (hipSetDevice + a per-shard clone of the matcher, i.e. pipeline and device sort on that GPU, one D2H copy of the ordered run) and
+ * merges the runs on the calling thread (fzb_k_merge_matches' order).  The result equals fzb_match_list on the unsharded list for
+ * every sort strategy.  No device-to-device exchange: only the host consumes the result.  (`threads` of fzb_match_list_parallel keeps
+ * the reference's contract on ONE device; the number of devices is a property of the sharded corpus, never inferred from `threads`.) */
+typedef struct fzb_sharded_corpus fzb_sharded_corpus;
+enum {
+    FZB_SHARD_BY_COUNT = 0,       /* shard g = [g * ceil(n / ndev), ...): equal haystack counts                           */
+    FZB_SHARD_BY_BYTES = 1,       /* shard g starts at the first haystack that starts at or after g/ndev of the bytes (ragged lists) */
+    FZB_SHARD_OVERSUBSCRIBE = 2   /* more shards than visible devices is allowed: shard g lives on device g % devices (testing)     */
+};
+int fzb_device_count(int* out);
+/* the shard boundaries (haystack indices) the upload uses: out_bounds has nshards + 1 entries; host arithmetic only */
+int fzb_shard_ranges(const uint64_t* end_offsets, size_t n, int nshards, int by_bytes, uint64_t* out_bounds);
+/* fzb_corpus_upload of every shard onto its device, the shards in parallel.  FZB_ERR_HIP when fewer than ndev devices are visible
+ * (unless FZB_SHARD_OVERSUBSCRIBE). */
+int fzb_corpus_upload_sharded(const uint8_t* bytes, const uint64_t* end_offsets, size_t n, int ndev, int flags, fzb_sharded_corpus** out);
+void fzb_sharded_corpus_free(fzb_sharded_corpus* sc);
+size_t fzb_sharded_corpus_len(const fzb_sharded_corpus* sc);
+int fzb_sharded_corpus_shards(const fzb_sharded_corpus* sc);
+int fzb_sharded_corpus_shard(const fzb_sharded_corpus* sc, int g, uint64_t* lo, uint64_t* hi, int* device);
+/* `Matcher::match_list_parallel(&haystacks, threads)` over the sharded list, one worker per shard.  The matcher keeps one clone of
+ * itself per shard (device workspaces on the shards' devices; they follow fzb_matcher_set_pattern / fzb_matcher_set_config).
+ * Free the result with fzb_matches_free. */
+int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc, fzb_match** out, size_t* out_len);
 
 /* `MatchIndices` (src/lib.rs:189-199): a Match plus the haystack byte positions that matched the needle, in reverse
  * order.  positions[positions_begin .. positions_begin + positions_len) of the array returned next to the records. */
@@ -236,11 +267,11 @@ int fzb_multi_match_list_device(fzb_multi_matcher* mm, const fzb_corpus* c, size
 /* Measurement hooks (bench.py): device time of the fzb_match_list_device calls made on this matcher since
  * fzb_set_profiling(m, 1), measured with HIP events recorded on the launch stream (event records only, no
  * synchronisation until read).  fzb_last_timings averages over those calls (at most the last 32):
- * out_ms[0]=filter kernel, [1]=whole pipeline, [2]=calls averaged, [3]=1 if a filter kernel ran. */
+ * out_ms[0]=filter kernel (mean over the calls that ran one), [1]=whole pipeline, [2]=calls averaged, [3]=how many of them ran a filter kernel. */
 int fzb_set_profiling(fzb_matcher* m, int enabled);
 int fzb_last_timings(fzb_matcher* m, float out_ms[4]);
 /* the same calls by stage: out_ms[0]=streaming filter kernel, [1]=compaction (+ lane-exact prefilter and its compaction), [2]=scorers,
- * [3]=whole pipeline, [4]=calls averaged, [5]=1 if a filter kernel ran */
+ * [3]=whole pipeline, [4]=calls averaged, [5]=how many of them ran a streaming filter kernel (the filter figure is their mean) */
 int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]);
 /* counters of the last call: out[0]=survivors of the filter stage, [1]=kept by the lane-exact prefilter,
  * [2]=windows scored by the generic wave-per-haystack kernel, [3]=windows scored by the multi-chunk kernel */

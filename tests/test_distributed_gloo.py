@@ -57,7 +57,7 @@ def _worker(rank, world, port, q):
                 slot = step % 2
                 ex.wait(slot)
                 buf = ex.send[slot].numpy()  # stands in for the device pipeline writing count + records in place
-                buf[:4] = np.array([len(local)], np.uint32).view(np.uint8)
+                buf[:8] = np.array([len(local), len(local)], np.uint32).view(np.uint8)  # records written, matches found
                 buf[ex.HEADER : ex.HEADER + len(local) * 8] = local.view(np.uint8)
                 ex.post(slot)
             runs2 = ex.collect(0)  # steps 0 and 2 used slot 0

@@ -1,0 +1,159 @@
+"""The multi-device form of the boundary (`fzb_corpus_upload_sharded` + `fzb_match_list_parallel_sharded`: match_list_parallel with
+one DEVICE per worker, src/matcher/parallel.rs:18-89) and the RCCL exchange of frizbee_amd.distributed, both on whatever the box has:
+with one GPU the shards share it (FZB_SHARD_OVERSUBSCRIBE) and the process group has one rank - the code paths are the ones N GPUs run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import frizbee_amd as F
+import oracle_lib as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+SORTS = ("ScoreThenIndexAsc", "ScoreThenIndexDesc", "IndexAsc", "IndexDesc")
+
+
+def test_sharded_match_list_parallel_equals_match_list_for_every_sort_and_shard_count():
+    rows, ends = synth.fixed_corpus(b"deadbe", 120_001, 32)
+    data = rows.numpy().reshape(-1)
+    odata = np.concatenate([data, np.zeros(64, np.uint8)])
+    have = F.device_count()
+    for ndev in (1, 2, 3, 8):
+        sc = F.ShardedCorpus(packed=(data, ends), ndev=ndev, oversubscribe=ndev > have)
+        assert len(sc) == 120_001 and [s[:2] for s in sc.shards()] == F.shard_ranges(ends, ndev)
+        assert all(dev == g % have for g, (_, _, dev) in enumerate(sc.shards()))
+        for sort in SORTS:
+            for typos in (0, 1):
+                m = F.Matcher("deadbe", F.Config(max_typos=typos, sort=F.SortStrategy[sort], pf_lanes=64, sw_lanes=64))
+                want = O.Matcher("deadbe", lanes=(64, 64, 32), max_typos=typos, sort=sort).match_packed(odata, ends)
+                got = m.match_list_parallel_sharded(sc)
+                assert got.tolist() == want.tolist(), (ndev, sort, typos, len(got), len(want))
+                assert m.match_list_parallel_sharded(sc).tolist() == want.tolist()  # again: the clones' workspaces are reused
+        del sc
+
+
+def test_sharded_ragged_list_byte_balanced_and_requery_after_set_pattern():
+    data, ends = synth.ragged_corpus(b"deadbeef", 60_013)
+    odata = np.concatenate([data, np.zeros(64, np.uint8)])
+    have = F.device_count()
+    sc = F.ShardedCorpus(packed=(data, ends), ndev=4, by_bytes=True, oversubscribe=4 > have)
+    shards = sc.shards()
+    assert [s[:2] for s in shards] == F.shard_ranges(ends, 4, by_bytes=True)
+    sizes = [int(ends[hi - 1]) - (int(ends[lo - 1]) if lo else 0) for lo, hi, _ in shards]
+    assert max(sizes) - min(sizes) <= 2 * 128 and len({hi - lo for lo, hi, _ in shards}) > 1  # bytes balanced, counts differ
+    m = F.Matcher("deadbeef", F.Config(pf_lanes=64, sw_lanes=64))
+    for needle in ("deadbeef", "dead", "Beef", "", "déad", "deadbeef"):  # Matcher::set_pattern: the per-shard clones follow
+        m.set_pattern(needle)
+        want = O.Matcher(needle, lanes=(64, 64, 32)).match_packed(odata, ends)
+        assert m.match_list_parallel_sharded(sc).tolist() == want.tolist(), needle
+    m.set_config(F.Config(max_typos=1, sort=F.SortStrategy.IndexDesc, pf_lanes=64, sw_lanes=64))
+    want = O.Matcher("deadbeef", lanes=(64, 64, 32), max_typos=1, sort="IndexDesc").match_packed(odata, ends)
+    assert m.match_list_parallel_sharded(sc).tolist() == want.tolist()
+
+
+def test_sharded_edge_cases():
+    have = F.device_count()
+    for hs in ([], ["deadbe"], ["x", "deadbe", "", "dead_be"]):
+        for ndev in (1, 3):
+            sc = F.ShardedCorpus(hs, ndev=ndev, oversubscribe=ndev > have)
+            for needle in ("deadbe", ""):
+                for sort in SORTS:
+                    got = F.Matcher(needle, F.Config(sort=F.SortStrategy[sort], pf_lanes=64)).match_list_parallel_sharded(sc)
+                    assert got.tolist() == O.Matcher(needle, sort=sort).match_list(hs).tolist(), (hs, ndev, needle, sort)
+    with pytest.raises(F.FrizbeeError) as e:  # more devices than the box has, not allowed to share: refused, never run on fewer
+        F.ShardedCorpus(["a"], ndev=have + 1)
+    assert e.value.code == 4 and "visible" in str(e.value)
+    with pytest.raises(F.FrizbeeError):
+        F.ShardedCorpus(["a"], ndev=0)
+
+
+def test_upload_builds_the_device_layout_for_every_length_mix():
+    # fzb_corpus_upload (raw bytes + offsets travel as they are, the padded-16 layout is built by device kernels): lengths around the
+    # 16-byte vector, empty haystacks (also runs of them, first and last), multi-chunk and > 1024-byte haystacks, NUL bytes
+    rng = np.random.default_rng(11)
+    alpha = b"abcdeDEF_-/ 01\0"
+    pool = [0, 0, 1, 2, 5, 15, 16, 17, 31, 32, 33, 47, 48, 63, 64, 65, 100, 127, 128, 129, 200, 1023, 1024, 1025, 1100, 3000]
+    for n, lens in ((5000, None), (3, [0, 0, 0]), (4, [0, 7, 0, 0]), (2049, None), (1024, [16] * 1024), (1025, [48] * 1025), (2000, [33] * 2000)):
+        ls = rng.choice(pool, n) if lens is None else np.array(lens)
+        hs = [bytes(alpha[int(x)] for x in rng.integers(0, len(alpha), int(k))) for k in ls]
+        cp = F.Corpus(hs)
+        for needle, cfg in (("deadbe", dict(max_typos=0)), ("dea", dict(max_typos=1)), ("ab_c", dict(max_typos=None)), ("é", dict(max_typos=0, unicode="Always"))):
+            want = O.Matcher(needle, **cfg).match_list(hs)
+            fc = F.Config(max_typos=cfg["max_typos"], unicode=F.UnicodeMatching[cfg.get("unicode", "Smart")], pf_lanes=64)
+            assert F.Matcher(needle, fc).match_list(cp).tolist() == want.tolist(), (n, needle)
+    for mode in ("register", "pageable"):  # the two alternative host-to-device paths give the same corpus
+        code = ("import os,sys,numpy as np; sys.path[:0]=[%r,%r]; import frizbee_amd as F, oracle_lib as O\n"
+                "hs=[('x'*k+'deadbe'+'y'*(k%%7)).encode() for k in range(0,400)]*40\n"
+                "assert F.Matcher('deadbe',F.Config(pf_lanes=64)).match_list(hs).tolist()==O.Matcher('deadbe').match_list(hs).tolist()\n") % (ROOT, os.path.join(ROOT, "tests"))
+        subprocess.run([sys.executable, "-c", code], check=True, env={**os.environ, "FZB_UPLOAD_MODE": mode}, timeout=600)
+    with pytest.raises(F.FrizbeeError) as e:
+        F.Corpus(packed=(np.zeros(64, np.uint8), np.array([8, 4, 12], np.uint64)))
+    assert "non-decreasing" in str(e.value)
+
+
+def test_uniform_length_promise_is_refused_on_an_uploaded_corpus():
+    cp = F.Corpus(["abcdefgh"] * 10)
+    assert F.lib().fzb_corpus_set_uniform_len(cp.h, 8) == 0        # the detected value: accepted (no-op)
+    assert F.lib().fzb_corpus_set_uniform_len(cp.h, 16) == 1       # anything else would make span-computing and offset-reading kernels disagree
+    cp2 = F.Corpus(["abc", "abcdefgh"])
+    assert F.lib().fzb_corpus_set_uniform_len(cp2.h, 0) == 0 and F.lib().fzb_corpus_set_uniform_len(cp2.h, 8) == 1
+
+
+def test_rccl_exchange_with_one_rank_matches_the_oracle():
+    """The N > 1 path of bench.py end to end on one GPU: `nccl` process group (world size 1), ShardExchange's asynchronous double-buffered
+    gather, per-shard device sort, host k-merge - the merged list must be the oracle's."""
+    code = r'''
+import os, sys
+sys.path[:0] = [%(root)r, %(tests)r, %(tools)r]
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577"); os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np, torch, torch.distributed as dist
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+import frizbee_amd as F, oracle_lib as O, synth
+from frizbee_amd.distributed import ShardExchange, merge_shard_runs, all_gather_matches
+n = 300_000
+rows, ends = synth.fixed_corpus(b"deadbe", n, 32)
+data = rows.numpy().reshape(-1)
+cp = F.Corpus(packed=(data, ends))
+odata = np.concatenate([data, np.zeros(64, np.uint8)])
+for typos in (0, 2):
+    m = F.Matcher("deadbe", F.Config(max_typos=typos, pf_lanes=64, sw_lanes=64))
+    out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev); cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+    m.match_list_device(cp, out.data_ptr(), n, cnt.data_ptr(), index_offset=7); torch.cuda.synchronize()
+    k = int(cnt[0].item()); assert int(cnt[1].item()) == k
+    ex = ShardExchange(ShardExchange.plan(k, device=dev), dev)
+    for step in range(5):  # the bench loop: pipeline writes count + records into the slot, asynchronous gather, next step overlaps
+        slot = step & 1
+        ex.wait(slot)
+        m.match_list_device(cp, ex.records_ptr(slot), ex.cap, ex.count_ptr(slot), index_offset=7)
+        ex.post(slot)
+    runs = ex.collect(0); ex.collect(1)
+    for sort in ("ScoreThenIndexAsc", "IndexDesc"):
+        want = O.Matcher("deadbe", lanes=(64, 64, 32), max_typos=typos, sort=sort).match_packed(odata, ends); want["index"] += 7
+        assert merge_shard_runs(runs, F.SortStrategy[sort]).tolist() == want.tolist(), (typos, sort)
+    runs2 = all_gather_matches(out, cnt[0])
+    assert len(runs2) == 1 and runs2[0].tolist() == runs[0].tolist()
+    small = ShardExchange(10, dev)   # a capacity below the match count is reported, never truncated silently
+    m.match_list_device(cp, small.records_ptr(0), small.cap, small.count_ptr(0)); small.post(0)
+    try:
+        small.collect(0); raise SystemExit("truncation not reported")
+    except RuntimeError as e:
+        assert str(k) in str(e), e
+dist.barrier(); dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK")
+''' % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "tools": os.path.join(ROOT, "tools")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    have = F.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "visible" in (r.stderr + r.stdout), (r.stdout[-500:], r.stderr[-500:])

@@ -210,3 +210,33 @@ def test_unicode_dfa_is_the_unicode_prefilter():
             accepted += got
     assert checked > 30000 and accepted > 5000
     assert F.lib().fzb_debug_unicode_dfa_accepts(F.Matcher("abc", F.Config(max_typos=0)).h, b"abc", 3) == -1  # ASCII path: no such DFA
+
+
+def test_shard_ranges_of_the_c_abi_are_the_python_ones():
+    # fzb_shard_ranges (host arithmetic of fzb_corpus_upload_sharded) == frizbee_amd.distributed.shard_range / shard_ranges_by_bytes
+    from frizbee_amd.distributed import shard_range, shard_ranges_by_bytes
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 2, 9, 1000, 100_003):
+        ends = np.cumsum(rng.integers(0, 129, n).astype(np.uint64), dtype=np.uint64)
+        for w in (1, 2, 3, 8):
+            assert F.shard_ranges(ends, w) == [shard_range(n, k, w) for k in range(w)]
+            r = F.shard_ranges(ends, w, by_bytes=True)
+            assert r == shard_ranges_by_bytes(ends, w)
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r[:-1], r[1:]))
+    # hand-computed: ends 10,20,30,40 in two shards by bytes -> the byte target 20 is where haystack 2 starts
+    assert F.shard_ranges(np.array([10, 20, 30, 40], np.uint64), 2, by_bytes=True) == [(0, 2), (2, 4)]
+    assert F.shard_ranges(np.array([10, 25, 30, 40], np.uint64), 2, by_bytes=True) == [(0, 2), (2, 4)]  # the straddling haystack stays left
+    with pytest.raises(F.FrizbeeError):
+        F.shard_ranges(np.array([1], np.uint64), 0)
+
+
+def test_multi_device_entry_points_fail_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    with pytest.raises(F.FrizbeeError) as e:
+        F.ShardedCorpus(["a", "b"], ndev=2)
+    assert e.value.code == 4
+    with pytest.raises(F.FrizbeeError) as e:
+        F.Corpus(["a", "b"])
+    assert e.value.code == 4  # no CPU fallback anywhere on the product path

@@ -3,6 +3,7 @@
 sharded over the GPUs of one node.  Not the driver's bench (bench.py is): the runner for this configuration, 1 process per GPU:
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 tools/bench_c4_dist.py
+    python tools/bench_c4_dist.py --gpus 8                    # the same: starts the 8 ranks itself (fails loudly with fewer GPUs)
     python tools/bench_c4_dist.py --total 12500000            # one GPU, one shard's worth
 
 The list is defined globally (lengths: one seeded vector all ranks derive identically), cut into BYTE-balanced contiguous index ranges
@@ -24,8 +25,24 @@ def main():
     ap.add_argument("--total", type=int, default=100_000_000)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--check", type=int, default=200_000)
+    ap.add_argument("--gpus", type=int, default=0, help="ranks to start when not launched under torch.distributed.run (0 = WORLD_SIZE or 1)")
     args = ap.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("needs an MI355X (no CPU fallback exists for the product path)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:  # plain `python tools/bench_c4_dist.py --gpus N`: start the N ranks ourselves
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+        import socket
+        s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__), *sys.argv[1:]]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execvpe(cmd[0], cmd, os.environ)
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    if args.gpus and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -102,7 +119,7 @@ def main():
         key = (0xFFFF - merged["score"].astype(np.int64)) * (1 << 32) + merged["index"].astype(np.int64)
         ordered = bool((np.diff(key) > 0).all()) if len(key) > 1 else True
         sum_len = int(ends_all[-1])
-        res = {"config": "C4: 'deadbeef' vs mixed-length 8..128 haystacks, max_typos=0", "haystacks": n, "n_gpus": world, "bytes": sum_len,
+        res = {"config": "C4: 'deadbeef' vs mixed-length 8..128 haystacks, max_typos=0", "haystacks": n, "n_gpus": world, "ranks_seen": (dist.get_world_size() if use_dist else 1), "bytes": sum_len,
                "shards": [{"range": list(r), "bytes": int(ends_all[r[1] - 1]) - (int(ends_all[r[0] - 1]) if r[0] else 0)} for r in ranges],
                "scoring_ms_per_step": float(t[0]) * 1e3, "haystacks_per_s_scoring": n / float(t[0]),
                "roofline_step_frac": (sum_len + 4 * n + 8 * total_matches) / float(t[0]) / 8e12 / world,
