@@ -1,9 +1,12 @@
 // fzb_corpus_upload: what `match_list(&haystacks)` borrows (src/matcher/mod.rs:212), brought into HBM at link speed.
 //
-// The caller's two arrays (all haystack bytes back to back + exclusive end offsets) travel AS THEY ARE: several host threads each
-// own a slice of the source, copy it piecewise into their own small page-locked staging buffers and queue asynchronous H2D copies on
-// their own stream (a pageable hipMemcpy is staged by ONE runtime thread through bounce buffers: 3.9 GB/s for the 10 M x 32 B list of
-// round 2; the DMA engines take >= 50 GB/s).  The library's device layout ("padded-16": every haystack on a 16-byte boundary, zero
+// The caller's two arrays (all haystack bytes back to back + exclusive end offsets) travel AS THEY ARE, one hipMemcpy each: the runtime
+// pins the pageable source on the fly and the DMA engines run at 52-53 GB/s (measured on the MI355X box, tools/bench_upload.py:
+// 10 M x 32 B = 400 MB of bytes + offsets in 7.6 ms, a 12.5 M-item ragged shard = 950 MB in 18 ms).  Round 2 repacked the list on the
+// host first (82 ms for the same 10 M list - the repack, not the copy, was the cost).  Two alternatives are kept behind
+// FZB_UPLOAD_MODE for comparison: "register" (hipHostRegister + copy: the same 7.6 ms) and "staged" (worker threads copying through
+// their own page-locked staging buffers into asynchronous copies: 20 ms, bound by the host memcpy).  The library's device layout
+// ("padded-16": every haystack on a 16-byte boundary, zero
 // gaps, end offsets inside that layout) is then built ON the device:
 //   k_up_tiles    per 1024 haystacks: sum of the padded lengths, min / max length, "offsets decrease" flag
 //   k_up_scan     exclusive scan of the tile sums (one workgroup)
@@ -177,15 +180,15 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_build(const u8* __restrict__ 
 }
 
 // ---- host -> device at link speed ---------------------------------------------------------------------------------------------
-// FZB_UPLOAD_MODE: "staged" (default; per-thread pinned staging + async copies), "register" (hipHostRegister the caller's memory, one
-// async copy), "pageable" (plain hipMemcpy: round 2's path, kept for comparison)
+// FZB_UPLOAD_MODE: "direct" (default; one hipMemcpy per array straight from the caller's pageable memory; "pageable" is accepted as a
+// synonym), "register" (hipHostRegister the caller's memory, then copy), "staged" (per-thread pinned staging + asynchronous copies)
 int upload_mode() {
     static const int mode = [] {
         const char* e = getenv("FZB_UPLOAD_MODE");
-        if (!e) return 0;
+        if (!e) return 2;
         if (!strcmp(e, "register")) return 1;
-        if (!strcmp(e, "pageable")) return 2;
-        return 0;
+        if (!strcmp(e, "staged")) return 0;
+        return 2;
     }();
     return mode;
 }
