@@ -8,7 +8,7 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
-#define FZB_MAX_ROWS 63        // needle rows handled on the GPU (bytes on the ASCII path, scalars on the unicode path)
+#define FZB_MAX_ROWS 63        // needle rows of the by-value NeedleDev (bytes on the ASCII path, scalars on the unicode path); longer needles: NeedleLongDev
 #define FZB_MAX_NEEDLE_BYTES 64
 #define FZB_MAX_HAYSTACK_LEN 1024  // reference: src/smith_waterman/algo/mod.rs:18 (beyond this the greedy fallback scores)
 #define FZB_TILE 1024          // haystacks per filter tile (one bitmap group + one count)
@@ -38,6 +38,25 @@ struct NeedleDev {
     u8 uc[FZB_MAX_ROWS + 1][4];    // unicode rows: scalar bytes  (case_needle_unicode, src/prefilter/mod.rs:71-96)
     u8 uf[FZB_MAX_ROWS + 1][4];    //               flipped scalar bytes
     u8 ulen[FZB_MAX_ROWS + 1];     //               UTF-8 length
+    static constexpr bool kLong = false;
+};
+
+// A needle beyond NeedleDev's by-value arrays (> 64 bytes or > 63 rows; the reference takes needles up to `Scoring::max_needle_len()`,
+// src/lib.rs:480-503 - 10 922 rows with the default scoring): the same scalars, the arrays in device memory.  Member NAMES are those of
+// NeedleDev: the kernels that serve such needles (lane-exact prefilter kernels_window.hip, wave-per-haystack scorer
+// kernels_generic.hip, literal modes kernels_literal.hip) are templates over the needle type.
+struct NeedleLongDev {
+    int32_t rows, nbytes, max_typos, min_haystack_len, unicode, lane_mask;
+    u16 match_plus_mismatch, mismatch, gex, gopm;
+    u16 prefix, capitalization, matching_case, exact_bonus, delimiter;
+    u16 match_score, gap_open, _pad;
+    const u8* raw;          // [nbytes]
+    const u8* c;            // [nbytes] ASCII rows
+    const u8* f;            // [nbytes]
+    const u8 (*uc)[4];      // [rows] unicode rows
+    const u8 (*uf)[4];      // [rows]
+    const u8* ulen;         // [rows]
+    static constexpr bool kLong = true;
 };
 
 // One haystack list resident in HBM.  Layout ("padded-16"): every haystack starts on a 16-byte boundary of
@@ -177,6 +196,19 @@ void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, c
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st);
 size_t fzb_trace_scratch_words(const NeedleDev& nd, int grid);
+// long needles (NeedleLongDev): kernels_window.hip / kernels_generic.hip / kernels_literal.hip
+size_t fzb_window_long_scratch_bytes(const NeedleLongDev& nd, int grid);
+void fzb_launch_window_long(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleLongDev& nd, int pf_lanes, u32* win, u64* bitmap2,
+                            u32* tile_counts2, void* scratch, int grid, hipStream_t st);
+size_t fzb_generic_long_adj_bytes(const NeedleLongDev& nd, int sw_lanes, int grid);
+size_t fzb_trace_scratch_words_long(const NeedleLongDev& nd, int grid);
+void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd,
+                             int sw_lanes, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u16* adj, const u32* cells, u32* pos, u32* npos, u32 stride, int grid,
+                             hipStream_t st);
+void fzb_launch_literal_filter_long(const CorpusDev& c, u64 first, u32 count, const u32* items, const u32* n_items_ptr, const NeedleLongDev& nd, int mode, u64* bitmap,
+                                    u32* tile_counts, int grid, hipStream_t st);
+void fzb_launch_literal_score_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* n_items_ptr, const NeedleLongDev& nd, int mode, fzb_match_rec* out,
+                                   u32 capacity, u32* dev_count, u32* tpos, u32* tnpos, u32 tstride, int grid, hipStream_t st);
 void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleDev& nd,
                               int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u32* cells, u32* pos, u32* npos, u32 stride,
                               int grid, hipStream_t st);

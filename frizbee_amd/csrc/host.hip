@@ -216,10 +216,9 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     std::string perr = m->literal_mode ? overflow_guard(sc, needle_len, sadd16(std::max(sc.capitalization_bonus, sc.delimiter_bonus), sc.matching_case_bonus), 0)
                                        : overflow_guard(sc, (size_t)m->rows);
     if (!perr.empty()) { delete m; return fail(FZB_ERR_PANIC, perr); }
-    if (needle_len > FZB_MAX_NEEDLE_BYTES || m->rows > FZB_MAX_ROWS) {
-        delete m;
-        return fail(FZB_ERR_UNSUPPORTED, "needles longer than 64 bytes / 63 rows are not handled by the HIP backend");
-    }
+    // beyond NeedleDev's by-value arrays: the needle's arrays go to device memory (NeedleLongDev) and the query runs through the
+    // kernels that take it from there (run_pipeline_long) - any length the reference's guard above accepted
+    m->long_needle = needle_len > FZB_MAX_NEEDLE_BYTES || m->rows > FZB_MAX_ROWS;
     NeedleDev& nd = m->nd;
     memset(&nd, 0, sizeof(nd));
     nd.rows = m->rows;
@@ -239,11 +238,49 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     nd.delimiter = sc.delimiter_bonus;
     nd.match_score = sc.match_score;
     nd.gap_open = sc.gap_open_penalty;
+    auto flip_ascii = [&](u8 c) { return m->case_sensitive ? c : (c >= 'a' && c <= 'z') ? (u8)(c - 32) : (c >= 'A' && c <= 'Z') ? (u8)(c + 32) : c; };
+    if (m->long_needle) {
+        // [raw | c | f | uc | uf | ulen], 16-byte aligned sections (device pointers are set when the blob is uploaded)
+        auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+        const size_t nb = needle_len, nr = cps.size();
+        m->long_off_c = al(nb);
+        m->long_off_f = m->long_off_c + al(nb);
+        m->long_off_uc = m->long_off_f + al(nb);
+        m->long_off_uf = m->long_off_uc + al(4 * nr);
+        m->long_off_ulen = m->long_off_uf + al(4 * nr);
+        m->long_blob_host.assign(m->long_off_ulen + al(nr) + 16, 0);
+        u8* blob = m->long_blob_host.data();
+        for (size_t i = 0; i < nb; i++) {  // case_needle (src/prefilter/mod.rs:49-65)
+            blob[i] = needle_utf8[i];
+            blob[m->long_off_c + i] = needle_utf8[i];
+            blob[m->long_off_f + i] = flip_ascii(needle_utf8[i]);
+        }
+        for (size_t i = 0; i < nr; i++) {  // case_needle_unicode (src/prefilter/mod.rs:71-96)
+            blob[m->long_off_ulen + i] = (u8)encode_utf8(cps[i], blob + m->long_off_uc + 4 * i);
+            encode_utf8(m->case_sensitive ? cps[i] : flip_same_width(cps[i]), blob + m->long_off_uf + 4 * i);
+        }
+        NeedleLongDev& l = m->ndl;
+        memset(&l, 0, sizeof(l));
+        l.rows = nd.rows; l.nbytes = nd.nbytes; l.max_typos = nd.max_typos; l.min_haystack_len = nd.min_haystack_len; l.unicode = nd.unicode; l.lane_mask = nd.lane_mask;
+        l.match_plus_mismatch = nd.match_plus_mismatch; l.mismatch = nd.mismatch; l.gex = nd.gex; l.gopm = nd.gopm;
+        l.prefix = nd.prefix; l.capitalization = nd.capitalization; l.matching_case = nd.matching_case; l.exact_bonus = nd.exact_bonus; l.delimiter = nd.delimiter;
+        l.match_score = nd.match_score; l.gap_open = nd.gap_open;
+        // stage configuration: no streaming filter; either no prefilter at all or the lane-exact prefilter kernel as the first stage
+        const int k = config->max_typos;
+        LaunchCfg& lc = m->lc;
+        lc.filter_mode = 0;
+        lc.filter_exact = 0;  // (sizes the second-level arrays the lane-exact prefilter writes)
+        lc.window_mode = (k < 0 || k >= m->rows) ? 2 : 0;
+        lc.pad_ok = lc.bias_ok = lc.cf_ok = lc.cfm_ok = 0;
+        m->table.assign(256, 0);
+        *out = m;
+        return FZB_OK;
+    }
     for (size_t i = 0; i < needle_len; i++) {  // case_needle (src/prefilter/mod.rs:49-65)
         u8 c = needle_utf8[i];
         nd.raw[i] = c;
         nd.c[i] = c;
-        nd.f[i] = m->case_sensitive ? c : (c >= 'a' && c <= 'z') ? (u8)(c - 32) : (c >= 'A' && c <= 'Z') ? (u8)(c + 32) : c;
+        nd.f[i] = flip_ascii(c);
     }
     if (cps.size() <= FZB_MAX_ROWS) {
         for (size_t i = 0; i < cps.size(); i++) {  // case_needle_unicode (src/prefilter/mod.rs:71-96)
@@ -373,6 +410,8 @@ static int rebuild_matcher(fzb_matcher* m, const fzb_config* config, const uint8
     std::swap(fresh->out_dev, m->out_dev);
     std::swap(fresh->out_cap, m->out_cap);
     std::swap(fresh->count_dev, m->count_dev);
+    std::swap(fresh->long_scratch, m->long_scratch);
+    std::swap(fresh->long_scratch_bytes, m->long_scratch_bytes);
     std::swap(fresh->aux_stream, m->aux_stream);
     std::swap(fresh->ev_fork, m->ev_fork);
     std::swap(fresh->ev_join, m->ev_join);
@@ -454,6 +493,8 @@ void fzb_matcher_free(fzb_matcher* m) {
     if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
     if (m->ev_join) (void)hipEventDestroy(m->ev_join);
     if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
+    if (m->long_blob_dev) (void)hipFree(m->long_blob_dev);
+    if (m->long_scratch) (void)hipFree(m->long_scratch);
     if (!m->shard_clones.empty() || m->shard_device >= 0) {
         // a clone's device state lives on its shard's device
         int cur = 0;
@@ -669,6 +710,93 @@ struct TraceOut {
     u32* npos;
     u32 stride;
 };
+static int ensure_long_needle(fzb_matcher* m, size_t scratch_bytes) {  // the needle's arrays + the scratch its kernels need, on the device
+    if (!m->long_blob_dev) {
+        HIPCHK(dev_alloc(&m->long_blob_dev, m->long_blob_host.size()));
+        HIPCHK(hipMemcpy(m->long_blob_dev, m->long_blob_host.data(), m->long_blob_host.size(), hipMemcpyHostToDevice));
+        const u8* b = (const u8*)m->long_blob_dev;
+        m->ndl.raw = b;
+        m->ndl.c = b + m->long_off_c;
+        m->ndl.f = b + m->long_off_f;
+        m->ndl.uc = (const u8(*)[4])(b + m->long_off_uc);
+        m->ndl.uf = (const u8(*)[4])(b + m->long_off_uf);
+        m->ndl.ulen = b + m->long_off_ulen;
+    }
+    if (m->long_scratch_bytes < scratch_bytes) {
+        if (m->long_scratch) HIPCHK(hipFree(m->long_scratch));
+        m->long_scratch = nullptr;
+        m->long_scratch_bytes = 0;
+        HIPCHK(dev_alloc(&m->long_scratch, scratch_bytes));
+        m->long_scratch_bytes = scratch_bytes;
+    }
+    return FZB_OK;
+}
+
+// The pipeline of a LONG needle (> 64 bytes or > 63 rows; the reference takes them up to Scoring::max_needle_len(), src/lib.rs:480-503).
+// Such a needle only matches haystacks about as long as itself, so nothing here is tuned for throughput; it is the same arithmetic through
+// the kernels that take the needle from device memory:  [length test + the reference's prefilter at the exact lane width ->
+// order-preserving compaction] -> the wave-per-haystack scorer (every window width; match_greedy beyond 1024 bytes; traced form for the
+// matched-indices entry points) - or the two literal kernels.
+static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, const u32* items_in, const u32* n_items_in,
+                             fzb_match* dev_out, u32 cap32, uint32_t* dev_count, hipStream_t st, const TraceOut* trace) {
+    Workspace& w = m->ws;
+    const CorpusDev& cd = c->dev;
+    const int cus = m->lc.num_cus;
+    const u32 cnt = (u32)count;
+    u32* cnt_c = w.counters;
+    const size_t budget = (size_t)256 << 20;  // global scratch per matcher: the grids below shrink to stay inside it
+    if (m->literal_mode) {
+        int rc = ensure_long_needle(m, 0);
+        if (rc) return rc;
+        fzb_launch_literal_filter_long(cd, first, cnt, items_in, n_items_in, m->ndl, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, items_in ? n_items_in : nullptr, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
+        fzb_launch_literal_score_long(cd, first, index_offset, w.surv_idx, &cnt_c[0], m->ndl, m->literal_mode, (fzb_match_rec*)dev_out, cap32, dev_count, trace ? trace->pos : nullptr,
+                                      trace ? trace->npos : nullptr, trace ? trace->stride : 0u, cus * 4, st);
+        HIPCHK(hipGetLastError());
+        return FZB_OK;
+    }
+    const bool prefilter = m->lc.window_mode == 0;
+    // grids: bounded by the scratch budget (a 10 922-row needle has 0.7 MB of previous-chunk vectors per wave, 50 MB of traced cells)
+    int wgrid = std::max(1, cus * 2);
+    if (prefilter && m->ndl.max_typos >= 3) {
+        const size_t per_block = fzb_window_long_scratch_bytes(m->ndl, 1);
+        wgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)wgrid, budget / std::max<size_t>(per_block, 1)));
+    }
+    int ggrid = std::max(1, cus * 2);
+    {
+        const size_t per_block = fzb_generic_long_adj_bytes(m->ndl, m->lc.sw_lanes, 1) + (trace ? fzb_trace_scratch_words_long(m->ndl, 1) * 4 : 0);
+        ggrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)ggrid, budget / std::max<size_t>(per_block, 1)));
+        if (trace) ggrid = std::min(ggrid, (int)std::max<size_t>(1, (count + 3) / 4));
+    }
+    const size_t win_bytes = prefilter ? fzb_window_long_scratch_bytes(m->ndl, wgrid) : 0;
+    const size_t adj_bytes = fzb_generic_long_adj_bytes(m->ndl, m->lc.sw_lanes, ggrid);
+    const size_t cell_bytes = trace ? fzb_trace_scratch_words_long(m->ndl, ggrid) * 4 : 0;
+    // (the prefilter's path state and the scorer's vectors are never live at the same time: they share the front of the scratch)
+    const size_t front = (std::max(win_bytes, adj_bytes) + 255) & ~(size_t)255;
+    int rc = ensure_long_needle(m, front + cell_bytes + 256);
+    if (rc) return rc;
+    const u32* items = items_in;
+    const u32* win = nullptr;
+    const u32* n_items_ptr = &cnt_c[0];
+    int wmode = 2;
+    if (items_in) HIPCHK(hipMemcpyAsync(&cnt_c[0], n_items_in, 4, hipMemcpyDeviceToDevice, st));
+    else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&cnt_c[0], (int)cnt, 1, st));
+    if (prefilter) {
+        fzb_launch_window_long(cd, first, items_in, &cnt_c[0], m->ndl, m->lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, m->long_scratch, wgrid, st);
+        fzb_launch_compact2(w.bitmap2, w.tile_counts2, &cnt_c[0], items_in, w.win, w.items2, w.win2, &cnt_c[1], cus * 2, st);
+        items = w.items2;
+        win = w.win2;
+        n_items_ptr = &cnt_c[1];
+        wmode = 0;
+    } else {
+        HIPCHK(hipMemcpyAsync(&cnt_c[1], &cnt_c[0], 4, hipMemcpyDeviceToDevice, st));
+    }
+    fzb_launch_generic_long(cd, first, index_offset, items, win, wmode, n_items_ptr, m->ndl, m->lc.sw_lanes, (fzb_match_rec*)dev_out, cap32, dev_count, cnt_c, (u16*)m->long_scratch,
+                            trace ? (const u32*)((u8*)m->long_scratch + front) : nullptr, trace ? trace->pos : nullptr, trace ? trace->npos : nullptr, trace ? trace->stride : 0u, ggrid, st);
+    HIPCHK(hipGetLastError());
+    return FZB_OK;
+}
+
 static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, const u32* items_in, const u32* n_items_in,
                         fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream, const TraceOut* trace = nullptr) {
     if (!m || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
@@ -712,12 +840,13 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         }                                                                                                      \
     } while (0)
     // the streaming filter kernels clear the counter block themselves (one launch less on the hot path)
-    const bool filter_resets = count != 0 && !items_in && (m->literal_mode ? (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode) : lc.filter_mode != 0);
+    const bool filter_resets = count != 0 && !items_in && !m->long_needle && (m->literal_mode ? (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode) : lc.filter_mode != 0);
     if (!filter_resets) HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
     if (count == 0) {
         HIPCHK(hipMemsetAsync(dev_count, 0, 8, st));
         return FZB_OK;
     }
+    if (m->long_needle) return run_pipeline_long(m, c, first, count, index_offset, items_in, n_items_in, dev_out, cap32, dev_count, st, trace);
     if (m->literal_mode) {
         // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
         u32* cnt_c = w.counters;
@@ -949,7 +1078,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     int rc = ensure_workspace(m, n);
     if (rc) return rc;
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
-    if (!m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
+    if (!m->long_needle && !m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
     if (fzb_fused_applies(c->dev, m->lc, m->nd, m->lc.window_mode) && (rc = ensure_fused_buffers(m))) return rc;
     if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;

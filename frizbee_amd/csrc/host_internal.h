@@ -58,6 +58,15 @@ struct fzb_matcher {
     u32* trace_pos = nullptr;
     u32* trace_npos = nullptr;
     size_t trace_cap = 0, trace_pos_words = 0;
+    // a needle beyond NeedleDev's arrays (> 64 bytes or > 63 rows): scalars in `ndl`, the arrays in one device blob (uploaded on first
+    // use), and the global scratch of its kernels (N-typo path state, per-row previous-chunk vectors, traced cells)
+    bool long_needle = false;
+    NeedleLongDev ndl{};
+    std::vector<u8> long_blob_host;
+    size_t long_off_c = 0, long_off_f = 0, long_off_uc = 0, long_off_uf = 0, long_off_ulen = 0;
+    void* long_blob_dev = nullptr;
+    void* long_scratch = nullptr;
+    size_t long_scratch_bytes = 0;
     // multi-device form (host_shard.hip): the per-shard clones of this matcher (their device state lives on the shard's device);
     // on a clone: its stream and the device it is bound to
     std::vector<fzb_matcher*> shard_clones;

@@ -15,11 +15,18 @@
 
 __device__ __forceinline__ u32 subs(u32 a, u32 b) { return a > b ? a - b : 0; }
 
-// shift right by k lanes; lanes < k take adj[SWL - k + lane] (adj = previous chunk's vector in LDS, or nullptr => 0)
-template <int SWL>
+// one entry of a previous chunk's vector.  GLOBAL: the vectors of a long needle live in a per-wave global slab that is rewritten
+// chunk after chunk by other lanes of the same wave - read around the vector L1 (agent-scope load), after the writer's fence
+template <bool GLOBAL>
+__device__ __forceinline__ u32 adj_load(const u16* p) {
+    if (GLOBAL) return (u32)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (u32)*p;
+}
+// shift right by k lanes; lanes < k take adj[SWL - k + lane] (adj = previous chunk's vector in LDS / the slab, or nullptr => 0)
+template <int SWL, bool GLOBAL = false>
 __device__ __forceinline__ u32 shift_pad(u32 v, int k, const u16* adj, int lane) {
     u32 t = __shfl_up(v, k);
-    if (lane < k) t = adj ? (u32)adj[SWL - k + lane] : 0u;
+    if (lane < k) t = adj ? adj_load<GLOBAL>(&adj[SWL - k + lane]) : 0u;
     return t;
 }
 // same with the adjacent vector held in registers of the same wave (lane l holds adjv[l])
@@ -32,7 +39,8 @@ __device__ __forceinline__ u32 shift_pad_reg(u32 v, int k, u32 adjv, int lane) {
 
 // match_greedy (src/smith_waterman/greedy.rs:7-91), run by one lane
 // `fwd` (optional): receives the haystack position matched by every needle byte, in needle order
-__device__ u32 greedy_score(const NeedleDev& nd, const u8* __restrict__ h, u32 hlen, bool include_prefix, u32* __restrict__ fwd = nullptr,
+template <typename ND>
+__device__ u32 greedy_score(const ND& nd, const u8* __restrict__ h, u32 hlen, bool include_prefix, u32* __restrict__ fwd = nullptr,
                         bool* matched = nullptr) {
     const u32 n = (u32)nd.nbytes;
     if (matched) *matched = false;
@@ -93,17 +101,21 @@ struct TraceArgs {
 };
 #define TRACE_W (FZB_MAX_HAYSTACK_LEN + 2 * 64)  // columns: the zero chunk + up to 1024 bytes rounded up to a chunk
 
-template <int SWL, bool UNICODE, bool TRACE, typename ET>
+template <int SWL, bool UNICODE, bool TRACE, typename ET, typename ND = NeedleDev>
 __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                               const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
-                                                              const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
+                                                              const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const ND nd,
                                                               fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters,
-                                                              const TraceArgs trace) {
-    // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row
-    __shared__ u16 s_adj_row[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
-    __shared__ u16 s_adj_aux[GEN_WAVES][FZB_MAX_ROWS + 1][SWL];
+                                                              const TraceArgs trace, u16* __restrict__ long_adj) {
+    // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row - in LDS for needles
+    // that fit NeedleDev, in the wave's slab of `long_adj` ((rows + 1) x SWL x 2 entries) for long ones
+    constexpr bool LONG = ND::kLong;
+    __shared__ u16 s_adj_row[LONG ? 1 : GEN_WAVES][LONG ? 1 : FZB_MAX_ROWS + 1][SWL];
+    __shared__ u16 s_adj_aux[LONG ? 1 : GEN_WAVES][LONG ? 1 : FZB_MAX_ROWS + 1][SWL];
     const int lane = lane_id();
     const int wv = threadIdx.x >> 6;
+    u16* const adj_row_base = LONG ? long_adj + (size_t)(blockIdx.x * GEN_WAVES + wv) * 2 * (size_t)(nd.rows + 1) * SWL : &s_adj_row[LONG ? 0 : wv][0][0];
+    u16* const adj_aux_base = LONG ? adj_row_base + (size_t)(nd.rows + 1) * SWL : &s_adj_aux[LONG ? 0 : wv][0][0];
     const u32 nlist = *n_list_ptr;
     if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = nlist < capacity ? nlist : capacity; dev_count[1] = nlist; }
     const u32 LM = (u32)nd.lane_mask;
@@ -256,18 +268,18 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                         if (!sstart) { diag = 0; up = 0; }
                     }
                     row = max(diag, up);
-                    const u16* adj = ch ? s_adj_row[wv][r] : nullptr;
-                    const u16* adja = ch ? s_adj_aux[wv][r] : nullptr;
+                    const u16* adj = ch ? adj_row_base + (size_t)r * SWL : nullptr;
+                    const u16* adja = ch ? adj_aux_base + (size_t)r * SWL : nullptr;
                     // capture S(r, prev chunk)[SWL-1] for the next row's diagonal before overwriting
-                    const u32 next_carry = ch ? (u32)s_adj_row[wv][r][SWL - 1] : 0u;
+                    const u32 next_carry = ch ? adj_load<LONG>(&adj[SWL - 1]) : 0u;
                     u32 aux;  // ASCII: this row's match mask (0 / LM); unicode: pending gap-open mask
                     if (!UNICODE) {
                         // propagate_horizontal_gaps (ascii_gap.rs:11-105)
                         const u32 mmv = mm ? LM : 0;
                         u32 kg = gex;
                         for (int sh = 1; sh < SWL; sh *= 2) {
-                            const u32 srow = shift_pad<SWL>(row, sh, adj, lane);
-                            const u32 smm = shift_pad<SWL>(mmv, sh, adja, lane);
+                            const u32 srow = shift_pad<SWL, LONG>(row, sh, adj, lane);
+                            const u32 smm = shift_pad<SWL, LONG>(mmv, sh, adja, lane);
                             const u32 pen = (kg + (gopm & smm)) & LM;
                             row = max(row, subs(srow, pen));
                             kg = (kg + kg) & LM;
@@ -279,8 +291,8 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                         u32 tot = gex;
                         int k = 0;
                         for (int sh = 1; sh < SWL; sh *= 2, k++) {
-                            const u32 srow = shift_pad<SWL>(row, sh, adj, lane);
-                            const u32 spend = shift_pad<SWL>(pending, sh, adja, lane);
+                            const u32 srow = shift_pad<SWL, LONG>(row, sh, adj, lane);
+                            const u32 spend = shift_pad<SWL, LONG>(pending, sh, adja, lane);
                             const u32 sgex = subs(tot, cont_k[k]);
                             const u32 crossed = spend & sm_k[k];
                             const u32 pen = (sgex + (gopm & crossed)) & LM;
@@ -292,8 +304,8 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (active && ch + 1 < nchunks) {
-                        s_adj_row[wv][r][lane] = (u16)row;
-                        s_adj_aux[wv][r][lane] = (u16)aux;
+                        adj_row_base[(size_t)r * SWL + lane] = (u16)row;
+                        adj_aux_base[(size_t)r * SWL + lane] = (u16)aux;
                     }
                     __builtin_amdgcn_wave_barrier();
                     if (TRACE) {
@@ -305,6 +317,10 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                 }
                 if (active) maxs = max(maxs, row);
                 if (UNICODE) { prev_cont = contgex; prev_sm = smask; }
+                if (LONG) {  // this chunk's vectors are read by other lanes in the next chunk: make the slab writes visible first
+                    __threadfence();
+                    __builtin_amdgcn_wave_barrier();
+                }
             }
             // horizontal max
             for (int off = 32; off > 0; off >>= 1) maxs = max(maxs, (u32)__shfl_xor(maxs, off));
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st) {
     const TraceArgs none{nullptr, nullptr, nullptr, 0};
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none)
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none, (u16*)nullptr)
 #define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
 #define FZB_K2C_U(SWL) do { if (unicode) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
     switch (sw_lanes) {
@@ -400,7 +416,7 @@ void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, c
                               int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u32* cells, u32* pos, u32* npos, u32 stride,
                               int grid, hipStream_t st) {
     const TraceArgs tr{cells, pos, npos, stride};
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr)
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, (u16*)nullptr)
     switch (sw_lanes) {
         case 64: FZB_K2C_U(64); break;
         case 32: FZB_K2C_U(32); break;
@@ -408,4 +424,27 @@ void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, c
         default: FZB_K2C_U(8); break;
     }
 #undef FZB_K2C
+}
+
+// ---- long needles (NeedleLongDev): the same kernel, needle arrays and the per-row previous-chunk vectors in global memory.  Direct mode
+// only (the generic scorer is the ONLY scorer of a long needle: every window, any width, greedy beyond 1024 bytes) ---------------------
+size_t fzb_generic_long_adj_bytes(const NeedleLongDev& nd, int sw_lanes, int grid) { return (size_t)grid * GEN_WAVES * 2 * (size_t)(nd.rows + 1) * (size_t)sw_lanes * sizeof(u16); }
+size_t fzb_trace_scratch_words_long(const NeedleLongDev& nd, int grid) { return (size_t)grid * GEN_WAVES * (size_t)(nd.rows + 1) * TRACE_W; }
+
+void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd,
+                             int sw_lanes, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u16* adj, const u32* cells, u32* pos, u32* npos, u32 stride, int grid,
+                             hipStream_t st) {
+    const TraceArgs tr{(u32*)cells, pos, npos, stride};
+    const bool trace = cells != nullptr;
+#define FZB_K2C_L(SWL, U, T, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj)
+#define FZB_K2C_L_ET(SWL, U, T) do { if (c.ends_u64) FZB_K2C_L(SWL, U, T, u64); else FZB_K2C_L(SWL, U, T, u32); } while (0)
+#define FZB_K2C_L_T(SWL, U) do { if (trace) FZB_K2C_L_ET(SWL, U, true); else FZB_K2C_L_ET(SWL, U, false); } while (0)
+#define FZB_K2C_L_U(SWL) do { if (nd.unicode) FZB_K2C_L_T(SWL, true); else FZB_K2C_L_T(SWL, false); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2C_L_U(64); break;
+        case 32: FZB_K2C_L_U(32); break;
+        case 16: FZB_K2C_L_U(16); break;
+        default: FZB_K2C_L_U(8); break;
+    }
+#undef FZB_K2C_L
 }

@@ -16,7 +16,8 @@
 #define LIT_SUFFIX 3
 #define LIT_SUBSTRING 4
 
-__device__ __forceinline__ bool lit_matches_at(const NeedleDev& nd, const u8* __restrict__ h, u32 pos) {
+template <typename ND>
+__device__ __forceinline__ bool lit_matches_at(const ND& nd, const u8* __restrict__ h, u32 pos) {
     if (nd.unicode) {
         u32 k = pos;
         for (int r = 0; r < nd.rows; r++) {
@@ -41,7 +42,8 @@ __device__ __forceinline__ bool lit_matches_at(const NeedleDev& nd, const u8* __
 
 __device__ __forceinline__ bool lit_is_delim(u8 b) { return b <= 127 && !((b >= 'a' && b <= 'z') || (b >= 'A' && b <= 'Z') || (b >= '0' && b <= '9')); }
 
-__device__ __forceinline__ u32 lit_score_scalar(const NeedleDev& nd, const u8* __restrict__ h, u32 start, bool exact_case) {
+template <typename ND>
+__device__ __forceinline__ u32 lit_score_scalar(const ND& nd, const u8* __restrict__ h, u32 start, bool exact_case) {
     u32 s = nd.match_score;
     if (exact_case) s += nd.matching_case;
     if (start == 0) {
@@ -54,7 +56,8 @@ __device__ __forceinline__ u32 lit_score_scalar(const NeedleDev& nd, const u8* _
     return s;
 }
 
-__device__ __forceinline__ u32 lit_score_at(const NeedleDev& nd, const u8* __restrict__ h, u32 L, u32 pos) {
+template <typename ND>
+__device__ __forceinline__ u32 lit_score_at(const ND& nd, const u8* __restrict__ h, u32 L, u32 pos) {
     u32 score = 0;
     if (nd.unicode) {
         u32 start = pos;
@@ -84,7 +87,8 @@ __device__ __forceinline__ u32 lit_first_byte_hits(u32 w, u32 a, u32 b) {
 
 // Accept decision only.  Substring: first-byte candidates from the aligned 16-byte vectors, verified by byte reads
 // (which hit the lines the vector load just brought in).
-__device__ __forceinline__ bool lit_accepts(const NeedleDev& nd, int mode, const u8* __restrict__ h, u32 L) {
+template <typename ND>
+__device__ __forceinline__ bool lit_accepts(const ND& nd, int mode, const u8* __restrict__ h, u32 L) {
     const u32 nl = (u32)nd.nbytes;
     if (L < nl) return false;
     if (mode == LIT_EXACT) return L == nl && lit_matches_at(nd, h, 0);
@@ -108,7 +112,8 @@ __device__ __forceinline__ bool lit_accepts(const NeedleDev& nd, int mode, const
 }
 
 // position + score of the match the reference reports (`find`, algo.rs:232-253)
-__device__ __forceinline__ bool lit_find(const NeedleDev& nd, int mode, const u8* __restrict__ h, u32 L, u32& pos_out, u32& score_out) {
+template <typename ND>
+__device__ __forceinline__ bool lit_find(const ND& nd, int mode, const u8* __restrict__ h, u32 L, u32& pos_out, u32& score_out) {
     const u32 nl = (u32)nd.nbytes;
     if (L < nl) return false;
     if (mode == LIT_EXACT || mode == LIT_PREFIX || mode == LIT_SUFFIX) {
@@ -133,9 +138,9 @@ __device__ __forceinline__ bool lit_find(const NeedleDev& nd, int mode, const u8
 }
 
 // pass 1: items == nullptr: haystacks [first, first + count_host); else the listed ones (device-side count)
-template <typename ET>
+template <typename ET, typename ND = NeedleDev>
 __global__ __launch_bounds__(256) void k_literal_filter(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count_host, const u32* __restrict__ items,
-                                                        const u32* __restrict__ n_items_ptr, const NeedleDev nd, int mode, u64* __restrict__ bitmap,
+                                                        const u32* __restrict__ n_items_ptr, const ND nd, int mode, u64* __restrict__ bitmap,
                                                         u32* __restrict__ tile_counts) {
     __shared__ u32 s_cnt;
     const u32 count = items ? *n_items_ptr : count_host;
@@ -170,9 +175,9 @@ __global__ __launch_bounds__(256) void k_literal_filter(const u8* __restrict__ b
 
 // pass 2: one thread per survivor (items = local haystack indices), record j at out[j].  With tpos != nullptr also the matched
 // byte positions (match_list_indices_impl, algo.rs:129-155: the whole needle run, reversed) at tpos[j * tstride ..], tnpos[j] of them.
-template <typename ET>
+template <typename ET, typename ND = NeedleDev>
 __global__ __launch_bounds__(256) void k_literal_score(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
-                                                       const u32* __restrict__ n_items_ptr, const NeedleDev nd, int mode, fzb_match_rec* __restrict__ out, u32 capacity,
+                                                       const u32* __restrict__ n_items_ptr, const ND nd, int mode, fzb_match_rec* __restrict__ out, u32 capacity,
                                                        u32* __restrict__ dev_count, u32* __restrict__ tpos, u32* __restrict__ tnpos, u32 tstride) {
     const u32 M = *n_items_ptr;
     if (blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = M < capacity ? M : capacity; dev_count[1] = M; }
@@ -206,4 +211,16 @@ void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, c
                               u32 capacity, u32* dev_count, u32* tpos, u32* tnpos, u32 tstride, int grid, hipStream_t st) {
     if (c.ends_u64) hipLaunchKernelGGL((k_literal_score<u64>), dim3(grid), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count, tpos, tnpos, tstride);
     else hipLaunchKernelGGL((k_literal_score<u32>), dim3(grid), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count, tpos, tnpos, tstride);
+}
+
+// long needles (NeedleLongDev: needle arrays in device memory): the same two kernels
+void fzb_launch_literal_filter_long(const CorpusDev& c, u64 first, u32 count, const u32* items, const u32* n_items_ptr, const NeedleLongDev& nd, int mode, u64* bitmap,
+                                    u32* tile_counts, int grid, hipStream_t st) {
+    if (c.ends_u64) hipLaunchKernelGGL((k_literal_filter<u64, NeedleLongDev>), dim3(grid), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, count, items, n_items_ptr, nd, mode, bitmap, tile_counts);
+    else hipLaunchKernelGGL((k_literal_filter<u32, NeedleLongDev>), dim3(grid), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, count, items, n_items_ptr, nd, mode, bitmap, tile_counts);
+}
+void fzb_launch_literal_score_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* n_items_ptr, const NeedleLongDev& nd, int mode, fzb_match_rec* out,
+                                   u32 capacity, u32* dev_count, u32* tpos, u32* tnpos, u32 tstride, int grid, hipStream_t st) {
+    if (c.ends_u64) hipLaunchKernelGGL((k_literal_score<u64, NeedleLongDev>), dim3(grid), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count, tpos, tnpos, tstride);
+    else hipLaunchKernelGGL((k_literal_score<u32, NeedleLongDev>), dim3(grid), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, index_offset, items, n_items_ptr, nd, mode, out, capacity, dev_count, tpos, tnpos, tstride);
 }

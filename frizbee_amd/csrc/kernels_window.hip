@@ -91,9 +91,9 @@ __device__ __forceinline__ u64 occ_mask(const Chunk<PFL>& c, u32 a, u32 b) {
 // ------------------------------------------------------------------------------------------------
 // Occurrence sources: what `B::occ(chunk, needle[idx])` / `unicode_char_mask(start, .., needle[idx])` return
 // ------------------------------------------------------------------------------------------------
-template <int PFL>
+template <int PFL, typename ND = NeedleDev>
 struct AsciiSrc {
-    const NeedleDev& nd;
+    const ND& nd;
     const u8* hay;
     u32 len;
     Chunk<PFL> chunk;
@@ -104,7 +104,7 @@ struct AsciiSrc {
     // wave-uniform loop (scalar needle loads), and a request is one ds_read_b64.
     u64* cache;
     u32 loaded;  // chunk start the cache / chunk belong to
-    __device__ AsciiSrc(const NeedleDev& n, const u8* h, u32 l, u64* cache_ = nullptr) : nd(n), hay(h), len(l), cache(cache_), loaded(0xFFFFFFFFu) {}
+    __device__ AsciiSrc(const ND& n, const u8* h, u32 l, u64* cache_ = nullptr) : nd(n), hay(h), len(l), cache(cache_), loaded(0xFFFFFFFFu) {}
     __device__ __forceinline__ void load(u32 start) {
         if (start == loaded) return;  // (the end scan of a one-chunk haystack asks for the chunk that is already here)
         loaded = start;
@@ -118,16 +118,16 @@ struct AsciiSrc {
     __device__ __forceinline__ u32 rows() const { return (u32)nd.rows; }
 };
 
-template <int PFL>
+template <int PFL, typename ND = NeedleDev>
 struct UnicodeSrc {
-    const NeedleDev& nd;
+    const ND& nd;
     const u8* hay;
     u32 len;
     u32 start;
     Chunk<PFL> w0;  // window at start+0
     u32 guard;      // the 4 bytes after it: the windows at start+1 .. start+3 are byte shifts of (w0, guard), formed on demand
                     // (keeping four chunks and indexing them with a per-thread scalar length put the whole set into scratch memory)
-    __device__ UnicodeSrc(const NeedleDev& n, const u8* h, u32 l) : nd(n), hay(h), len(l), start(0), guard(0) {}
+    __device__ UnicodeSrc(const ND& n, const u8* h, u32 l) : nd(n), hay(h), len(l), start(0), guard(0) {}
     __device__ __forceinline__ void load(u32 s) {
         start = s;
         load_chunk<PFL>(w0, hay, s, len);
@@ -173,8 +173,8 @@ struct Win {
 
 // ---- end scans --------------------------------------------------------------------------------
 // find_end_pos_with_typos (ascii_typos.rs:375-397)
-template <int PFL>
-__device__ u32 ascii_end_pos(AsciiSrc<PFL>& src, u32 max_typos) {
+template <int PFL, typename ND>
+__device__ u32 ascii_end_pos(AsciiSrc<PFL, ND>& src, u32 max_typos) {
     const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
     u32 start = (len - 1) / PFL * PFL;
     for (;;) {
@@ -189,8 +189,8 @@ __device__ u32 ascii_end_pos(AsciiSrc<PFL>& src, u32 max_typos) {
     return len;
 }
 // find_end_pos_with_unicode_typos (unicode_typos.rs:479-508)
-template <int PFL>
-__device__ u32 unicode_end_pos(UnicodeSrc<PFL>& src, u32 max_typos) {
+template <int PFL, typename ND>
+__device__ u32 unicode_end_pos(UnicodeSrc<PFL, ND>& src, u32 max_typos) {
     const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
     u32 start = len >= (u32)PFL ? len - PFL : 0;
     for (;;) {
@@ -206,10 +206,10 @@ __device__ u32 unicode_end_pos(UnicodeSrc<PFL>& src, u32 max_typos) {
     }
     return len;
 }
-template <int PFL>
-__device__ __forceinline__ u32 end_pos(AsciiSrc<PFL>& s, u32 k) { return ascii_end_pos<PFL>(s, k); }
-template <int PFL>
-__device__ __forceinline__ u32 end_pos(UnicodeSrc<PFL>& s, u32 k) { return unicode_end_pos<PFL>(s, k); }
+template <int PFL, typename ND>
+__device__ __forceinline__ u32 end_pos(AsciiSrc<PFL, ND>& s, u32 k) { return ascii_end_pos<PFL>(s, k); }
+template <int PFL, typename ND>
+__device__ __forceinline__ u32 end_pos(UnicodeSrc<PFL, ND>& s, u32 k) { return unicode_end_pos<PFL>(s, k); }
 
 // ---- 1 typo (ascii_typos.rs:15-110 / unicode_typos.rs:15-141) -----------------------------------
 template <int PFL, typename Src>
@@ -314,41 +314,61 @@ __device__ Win prefilter_2_typos(Src& src) {
 }
 
 // ---- N typos (ascii_typos.rs:254-360 / unicode_typos.rs:333-466) --------------------------------
-template <int PFL, typename Src>
-__device__ Win prefilter_many_typos(Src& src, u32 max_typos) {
+// Per-path state (needle index + the occurrence mask of that needle row in the current chunk), max_typos + 1 paths.  Needles that fit
+// NeedleDev (<= 63 rows) keep it in the thread's own arrays; long needles (NeedleLongDev, up to ~11 k paths) in a global slab laid out
+// [path][thread].
+struct LocalPaths {
+    u8 idx_[FZB_MAX_ROWS + 1];
+    u64 nmask_[FZB_MAX_ROWS + 1];
+    __device__ __forceinline__ u32 idx(u32 p) const { return idx_[p]; }
+    __device__ __forceinline__ void set_idx(u32 p, u32 v) { idx_[p] = (u8)v; }
+    __device__ __forceinline__ u64 nmask(u32 p) const { return nmask_[p]; }
+    __device__ __forceinline__ void set_nmask(u32 p, u64 v) { nmask_[p] = v; }
+};
+struct GlobalPaths {
+    u32* idx_;     // [path][stride]
+    u64* nmask_;   // [path][stride]
+    u32 stride, slot;
+    __device__ __forceinline__ u32 idx(u32 p) const { return idx_[(size_t)p * stride + slot]; }
+    __device__ __forceinline__ void set_idx(u32 p, u32 v) { idx_[(size_t)p * stride + slot] = v; }
+    __device__ __forceinline__ u64 nmask(u32 p) const { return nmask_[(size_t)p * stride + slot]; }
+    __device__ __forceinline__ void set_nmask(u32 p, u64 v) { nmask_[(size_t)p * stride + slot] = v; }
+};
+
+template <int PFL, typename Src, typename Paths>
+__device__ Win prefilter_many_typos(Src& src, u32 max_typos, Paths& paths) {
     const u32 n = src.rows(), len = src.len;
     if (n <= max_typos) return {true, 0, len};
     if (len == 0) return {false, 0, 0};
-    const u32 path_count = max_typos + 1;  // <= rows <= 63
-    u8 idx[FZB_MAX_ROWS + 1];
-    u64 nmask[FZB_MAX_ROWS + 1];
-    for (u32 p = 0; p < path_count; p++) idx[p] = 0;
+    const u32 path_count = max_typos + 1;  // <= rows
+    for (u32 p = 0; p < path_count; p++) paths.set_idx(p, 0);
     u32 msp = 0xFFFFFFFFu;
     for (u32 start = 0; start < len; start += PFL) {
         src.load(start);
         u64 chunk_mask = src.init_mask();
-        for (u32 p = 0; p < path_count; p++) nmask[p] = src.mask(idx[p]);
+        for (u32 p = 0; p < path_count; p++) paths.set_nmask(p, src.mask(paths.idx(p)));
         for (;;) {
             for (u32 p = 1; p < path_count; p++) {
-                const u32 cand = idx[p - 1] + 1;
-                if (cand > idx[p]) {
+                const u32 cand = paths.idx(p - 1) + 1;
+                if (cand > paths.idx(p)) {
                     if (cand == n) return {true, msp, end_pos<PFL>(src, max_typos)};
-                    idx[p] = (u8)cand;
-                    nmask[p] = src.mask(cand);
+                    paths.set_idx(p, cand);
+                    paths.set_nmask(p, src.mask(cand));
                 }
             }
             u64 match_mask = 0;
-            for (u32 p = 0; p < path_count; p++) match_mask |= nmask[p];
+            for (u32 p = 0; p < path_count; p++) match_mask |= paths.nmask(p);
             const u64 matches = match_mask & chunk_mask;
             if (matches == 0) break;
             const u32 hit_pos = m_tz(matches);
             const u64 hit = matches & m_first_n<PFL>(hit_pos + 1);
             msp = min(msp, start + hit_pos);
             for (u32 p = 0; p < path_count; p++) {
-                if ((nmask[p] & hit) == 0) continue;
-                idx[p] += 1;
-                if (idx[p] == n) return {true, msp, end_pos<PFL>(src, max_typos)};
-                nmask[p] = src.mask(idx[p]);
+                if ((paths.nmask(p) & hit) == 0) continue;
+                const u32 ni = paths.idx(p) + 1;
+                paths.set_idx(p, ni);
+                if (ni == n) return {true, msp, end_pos<PFL>(src, max_typos)};
+                paths.set_nmask(p, src.mask(ni));
             }
             chunk_mask = m_clear_through_lowest<PFL>(chunk_mask, hit);
         }
@@ -356,16 +376,51 @@ __device__ Win prefilter_many_typos(Src& src, u32 max_typos) {
     return {false, 0, len};
 }
 
+// ---- ASCII 0 typos (src/prefilter/algo/ascii.rs:6-72), only launched for long needles: short ones are decided by the streaming DFA
+// filter and their window comes from the scorer.  Chunk by chunk like the reference; its result is lane-free (accept <=> ordered
+// subsequence; start = first occurrence of needle[0]; end = one past the last occurrence of needle[n-1]) -------------------------
+template <int PFL, typename ND>
+__device__ Win prefilter_ascii_0(AsciiSrc<PFL, ND>& src) {
+    const u32 n = src.rows(), len = src.len;
+    if (len == 0) return {false, 0, 0};
+    bool can_skip = true;
+    u32 msp = 0, row = 0;
+    for (u32 start = 0; start < len; start += PFL) {
+        src.load(start);
+        u64 chunk_mask = src.valid;
+        for (;;) {
+            const u64 mask = src.mask(row) & chunk_mask;
+            if (mask == 0) break;
+            chunk_mask = m_clear_through_lowest<PFL>(chunk_mask, mask);
+            if (can_skip) { msp = start + m_tz(mask); can_skip = false; }
+            if (row + 1 < n) { row++; continue; }
+            if (start + PFL >= len) return {true, msp, start + PFL - m_lz<PFL>(mask)};
+            // find_last_char_pos on haystack[start..] (ascii.rs:58-72)
+            const u32 sub_len = len - start;
+            u32 s2 = sub_len >= (u32)PFL ? sub_len - PFL : 0;
+            for (;;) {
+                // a window at an arbitrary offset of the sub-slice: load_chunk handles unaligned positions
+                Chunk<PFL> ch;
+                load_chunk<PFL>(ch, src.hay, start + s2, len);
+                const u64 m2 = occ_mask<PFL>(ch, src.nd.c[n - 1], src.nd.f[n - 1]) & m_first_n<PFL>(sub_len - s2);
+                if (m2 != 0) return {true, msp, start + s2 + PFL - m_lz<PFL>(m2)};
+                s2 = s2 >= (u32)PFL ? s2 - PFL : 0;  // (always terminates: the last needle byte occurs in this sub-slice)
+            }
+        }
+    }
+    return {false, msp, len};
+}
+
 // ---- unicode 0 typos (unicode.rs:119-219) + back scan (unicode.rs:222-276) -----------------------
-template <int PFL>
-__device__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL>& src, u32 row, u32 sub_start) {
+template <int PFL, typename ND>
+__device__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL, ND>& src, u32 row, u32 sub_start) {
     // operates on haystack[sub_start..]; positions returned are relative to sub_start
-    const NeedleDev& nd = src.nd;
+    const ND& nd = src.nd;
     const u32 cl = nd.ulen[row];
     const u32 len = src.len - sub_start;
     const u32 back = PFL + cl - 1;
     u32 start = len >= back ? len - back : 0;
-    UnicodeSrc<PFL> sub(nd, src.hay + sub_start, len);
+    UnicodeSrc<PFL, ND> sub(nd, src.hay + sub_start, len);
     for (;;) {
         sub.load(start);
         // load_window(start + cl - 1): valid lanes are those whose last byte lies inside the haystack
@@ -384,9 +439,9 @@ __device__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL>& src, u32 row, u32 sub
     return len;
 }
 
-template <int PFL>
-__device__ Win prefilter_unicode_0(UnicodeSrc<PFL>& src) {
-    const NeedleDev& nd = src.nd;
+template <int PFL, typename ND>
+__device__ Win prefilter_unicode_0(UnicodeSrc<PFL, ND>& src) {
+    const ND& nd = src.nd;
     const u32 len = src.len, n = src.rows();
     if (len == 0) return {false, 0, 0};
     bool can_skip = true;
@@ -445,15 +500,24 @@ __device__ Win prefilter_unicode_0(UnicodeSrc<PFL>& src) {
 // version (7 algorithms inlined, 134 SGPR spills) was miscompiled by hipcc -O3 (ROCm 7.2) into an endless
 // loop for PFL=64 / unicode / 2 typos while -O1 and the same source built for the host ran correctly.
 // ------------------------------------------------------------------------------------------------
-enum { ALG_ASCII_1 = 0, ALG_ASCII_2 = 1, ALG_ASCII_N = 2, ALG_UNI_0 = 3, ALG_UNI_1 = 4, ALG_UNI_2 = 5, ALG_UNI_N = 6 };
+enum { ALG_ASCII_1 = 0, ALG_ASCII_2 = 1, ALG_ASCII_N = 2, ALG_UNI_0 = 3, ALG_UNI_1 = 4, ALG_UNI_2 = 5, ALG_UNI_N = 6, ALG_ASCII_0 = 7 };
+
+// global path slab of the N-typo algorithms for long needles: (max_typos + 1) x threads entries each (nullptr for NeedleDev)
+struct ManyScratch {
+    u32* idx;
+    u64* nmask;
+};
 
 // DECIDE form (typo configurations on the short-haystack path): the listed haystacks are the filter's MARGINAL survivors; nothing is
 // written for the accepted ones (their window has a lane-free form that the scorer computes itself), a rejected one sets its bit in
 // `rej.bits`, bumps its tile's count and the total.
-template <int PFL, int ALG, bool DECIDE = false>
+// min_len: haystacks shorter than this are rejected first (`original_len >= self.min_haystack_len`, src/matcher/algo.rs:88) - the
+// streaming filter does it on the usual path; for a long needle this kernel is the first stage.
+template <int PFL, int ALG, bool DECIDE = false, typename ND = NeedleDev>
 __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
-                                                  const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
-                                                  u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, int use_cache, RejectOut rej = RejectOut{}) {
+                                                  const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const ND nd,
+                                                  u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, int use_cache, RejectOut rej, u32 min_len,
+                                                  ManyScratch many) {
     extern __shared__ __attribute__((aligned(16))) u64 mask_cache[];  // rows x 256 occurrence masks (ASCII algorithms, use_cache)
     __shared__ u32 s_cnt;
     const u32 M = *n_surv_ptr;
@@ -474,18 +538,33 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
                 if (ends_u64) haystack_span((const u64*)ends_v, first + li, s, L);
                 else haystack_span((const u32*)ends_v, first + li, s, L);
                 const u8* hay = bytes + s;
-                Win w;
-                if (ALG >= ALG_UNI_0) {
-                    UnicodeSrc<PFL> src(nd, hay, L);
+                Win w = {false, 0, 0};
+                if (L < min_len) {
+                    // too short for this needle and typo budget
+                } else if (ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0) {
+                    UnicodeSrc<PFL, ND> src(nd, hay, L);
                     if (ALG == ALG_UNI_0) w = prefilter_unicode_0<PFL>(src);
                     else if (ALG == ALG_UNI_1) w = prefilter_1_typo<PFL>(src);
                     else if (ALG == ALG_UNI_2) w = prefilter_2_typos<PFL>(src);
-                    else w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos);
+                    else if (ND::kLong) {
+                        GlobalPaths paths{many.idx, many.nmask, gridDim.x * 256u, blockIdx.x * 256u + (u32)tid};
+                        w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos, paths);
+                    } else {
+                        LocalPaths paths;
+                        w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos, paths);
+                    }
                 } else {
-                    AsciiSrc<PFL> src(nd, hay, L, use_cache ? mask_cache : nullptr);
-                    if (ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
+                    AsciiSrc<PFL, ND> src(nd, hay, L, use_cache ? mask_cache : nullptr);
+                    if (ALG == ALG_ASCII_0) w = prefilter_ascii_0<PFL>(src);
+                    else if (ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
                     else if (ALG == ALG_ASCII_2) w = prefilter_2_typos<PFL>(src);
-                    else w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos);
+                    else if (ND::kLong) {
+                        GlobalPaths paths{many.idx, many.nmask, gridDim.x * 256u, blockIdx.x * 256u + (u32)tid};
+                        w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos, paths);
+                    } else {
+                        LocalPaths paths;
+                        w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos, paths);
+                    }
                 }
                 keep = w.matched;
                 if (DECIDE) {
@@ -523,15 +602,16 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
     // occurrence-mask cache in LDS for the ASCII algorithms: rows x 2 KB per workgroup, up to 16 rows
     const int use_cache = !nd.unicode && nd.rows <= 16;
     const size_t lds = use_cache ? (size_t)nd.rows * 256 * 8 : 0;
+    const ManyScratch none{nullptr, nullptr};
     if (decide) {  // ASCII typo algorithms only (the unicode path keeps the full form)
-#define FZB_K2A_D(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG, true>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, *decide)
+#define FZB_K2A_D(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG, true>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, *decide, 0u, none)
         if (alg == ALG_ASCII_1) FZB_K2A_D(ALG_ASCII_1);
         else if (alg == ALG_ASCII_2) FZB_K2A_D(ALG_ASCII_2);
         else FZB_K2A_D(ALG_ASCII_N);
 #undef FZB_K2A_D
         return;
     }
-#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{})
+#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none)
     switch (alg) {
         case ALG_ASCII_1: FZB_K2A(ALG_ASCII_1); break;
         case ALG_ASCII_2: FZB_K2A(ALG_ASCII_2); break;
@@ -549,4 +629,43 @@ void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const
     if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
     else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
     else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
+}
+
+// ---- long needles: this kernel is the FIRST stage (length test + the reference's prefilter at the exact lane width, every typo
+// budget, ASCII and unicode), over the whole range or an item list; needle arrays and N-typo path state in global memory ----------
+size_t fzb_window_long_scratch_bytes(const NeedleLongDev& nd, int grid) {
+    const int k = nd.max_typos;
+    if (k < 3) return 0;
+    return (size_t)(k + 1) * (size_t)grid * 256 * (sizeof(u32) + sizeof(u64));
+}
+
+template <int PFL>
+static void launch_window_long_pfl(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleLongDev& nd, u32* win, u64* bitmap2, u32* tile_counts2,
+                                   void* scratch, int grid, hipStream_t st) {
+    const int k = nd.max_typos;
+    const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 0 ? ALG_ASCII_0 : k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
+    ManyScratch many{nullptr, nullptr};
+    if (k >= 3) {
+        many.nmask = (u64*)scratch;  // 8-byte entries first (alignment), then the 4-byte ones
+        many.idx = (u32*)((u8*)scratch + (size_t)(k + 1) * (size_t)grid * 256 * sizeof(u64));
+    }
+#define FZB_K2A_L(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG, false, NeedleLongDev>), dim3(grid), dim3(256), 0, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, 0, RejectOut{}, (u32)nd.min_haystack_len, many)
+    switch (alg) {
+        case ALG_ASCII_0: FZB_K2A_L(ALG_ASCII_0); break;
+        case ALG_ASCII_1: FZB_K2A_L(ALG_ASCII_1); break;
+        case ALG_ASCII_2: FZB_K2A_L(ALG_ASCII_2); break;
+        case ALG_ASCII_N: FZB_K2A_L(ALG_ASCII_N); break;
+        case ALG_UNI_0: FZB_K2A_L(ALG_UNI_0); break;
+        case ALG_UNI_1: FZB_K2A_L(ALG_UNI_1); break;
+        case ALG_UNI_2: FZB_K2A_L(ALG_UNI_2); break;
+        default: FZB_K2A_L(ALG_UNI_N); break;
+    }
+#undef FZB_K2A_L
+}
+
+void fzb_launch_window_long(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleLongDev& nd, int pf_lanes, u32* win, u64* bitmap2,
+                            u32* tile_counts2, void* scratch, int grid, hipStream_t st) {
+    if (pf_lanes == 64) launch_window_long_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, scratch, grid, st);
+    else if (pf_lanes == 32) launch_window_long_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, scratch, grid, st);
+    else launch_window_long_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, scratch, grid, st);
 }

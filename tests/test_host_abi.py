@@ -73,8 +73,23 @@ def test_guards_raise_with_reference_panic_text():
         F.Matcher("f", F.Config(scoring=F.Scoring(capitalization_bonus=60000, matching_case_bonus=40000)))
     with pytest.raises(F.FrizbeeError):
         F.Matcher(b"\xff\xfe")  # not UTF-8 (a Rust &str cannot hold this)
-    with pytest.raises(F.FrizbeeError, match="not handled by the HIP backend"):
-        F.Matcher("a" * 65)
+    # long needles are accepted up to the reference's own bound: `guard_against_score_overflow` (src/lib.rs:506-527) lets 3 639 rows
+    # through with the default scoring ((65535 - 12 - 8 - 6 - 2) / 18; the documented `max_needle_len()` = 10 922 of :483-485 divides by
+    # the per-char BONUS only and is never what panics), in the u16 class; one more row panics with the reference's text
+    for n in (65, 200, 1000, 3639):
+        info = F.Matcher("a" * n).info()
+        assert info["rows"] == n and not info["use_u8"] and O.Matcher("a" * n).info()["use_u8"] is False
+    assert O.max_needle_len() == 10922
+    with pytest.raises(F.PanicError, match=r"needle too long and could overflow the u16 score: 3640 > 3639"):
+        F.Matcher("a" * 3640)
+    with pytest.raises(RuntimeError, match=r"needle too long and could overflow the u16 score: 3640 > 3639"):
+        O.Matcher("a" * 3640)
+    zero = F.Scoring(match_score=0, mismatch_penalty=0, gap_open_penalty=0, gap_extend_penalty=0, prefix_bonus=0, capitalization_bonus=0, matching_case_bonus=0, exact_match_bonus=0, delimiter_bonus=0)
+    assert F.Matcher("a" * 20000, F.Config(scoring=zero)).info()["rows"] == 20000  # "a zero per-char score can never overflow regardless of needle length"
+    assert F.Matcher("é" * 64, F.Config(unicode=F.UnicodeMatching.Always)).info()["rows"] == 64  # 128 bytes, 64 scalar rows: long as well
+    # a scoring under which a 100-byte needle still fits the u8 class (src/smith_waterman/mod.rs:92-116)
+    tiny = F.Scoring(match_score=1, mismatch_penalty=1, gap_open_penalty=1, gap_extend_penalty=0, prefix_bonus=0, capitalization_bonus=0, matching_case_bonus=0, exact_match_bonus=0, delimiter_bonus=0)
+    assert F.Matcher("a" * 100, F.Config(scoring=tiny)).info()["use_u8"] is True
     # unicode rows are counted in chars for the guard (src/matcher/algo.rs:383-393)
     F.Matcher("一二三四五六七八", F.Config(scoring=F.Scoring(capitalization_bonus=4000)))
 

@@ -90,6 +90,21 @@ def ragged_corpus(needle: bytes, n: int, lo: int = 8, hi: int = 128, seed=12345,
     return packed, ends
 
 
+def paths_corpus(needle: bytes = b"linux", n: int = 1_406_941, median: float = 67.0, std: float = 17.0, full=0.08, partial=0.20, seed=12345, device="cpu", width=160):
+    """The shape of the reference's real-data benchmark (BENCHMARKS.md:52-65: all file paths of the Chromium repository - 1 406 941 items,
+    median 67 characters, needle "linux", 8 % matching) produced with its synthetic generator's method (benches/match_list/generate.rs:
+    lengths ~ round(|Normal(median, std)|) >= 1, Full / Partial / None classes, alphanumeric filler).  `partial` and `std` are not published
+    for that list ("unknown"): 20 % and 17 are this repo's choice.  Lengths are capped at `width` (5.5 sigma).  Returns the upload format."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 2)
+    lengths = torch.randn(n, generator=g, device=device).mul_(std).add_(median).round_().abs_().clamp_(1, width).to(torch.int64)
+    rows = make_rows(needle, n, width, lengths=lengths, seed=seed, device=device, full=full, partial=partial)
+    mask = torch.arange(width, device=device)[None, :] < lengths[:, None]
+    packed = rows[mask].cpu().numpy()
+    ends = np.cumsum(lengths.cpu().numpy().astype(np.uint64), dtype=np.uint64)
+    return packed, ends
+
+
 def utf8_corpus(n: int, length: int = 32, seed=12345, needle="إنما", full=0.05, partial=0.20):
     """n valid-UTF-8 haystacks of exactly `length` bytes built from 2-byte Arabic scalars + ASCII space/punct (BASELINE config 5).
     Host-side (numpy) generator; returns (packed uint8 numpy, ends uint64 numpy)."""
