@@ -70,6 +70,14 @@ struct CorpusDev {
     int ends_u64;
     u32 max_len;       // longest haystack in bytes, 0 = unknown (lets the pipeline skip the multi-chunk scorer launch)
     u32 uniform_len;   // every haystack has exactly this many bytes (0 = not known): start(i) = i * roundup16(len), no end offsets read
+    // The streaming filter's view of a ragged list (fzb_corpus_upload builds it; nullptr otherwise): the same bytes with the haystacks of
+    // every 1024-haystack tile reordered by DESCENDING number of 16-byte vectors, in the same padded-16 convention (`fends` = exclusive
+    // ends in `fbytes`; a tile occupies the same byte range as in `bytes`), and fperm[g] = the position INSIDE ITS TILE the haystack at
+    // sorted position g came from.  The 64 lanes of a wave then run haystacks of one length class: no lookups for lanes whose haystack
+    // has ended (47 % of the ragged filter's lookups before).  Every other stage reads the canonical layout.
+    const u8* fbytes;
+    const u32* fends;
+    const u16* fperm;
 };
 
 struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between kernels (0 in final output)

@@ -537,6 +537,8 @@ void fzb_corpus_free(fzb_corpus* c) {
     if (!c) return;
     if (c->own_bytes) (void)hipFree(c->own_bytes);
     if (c->own_ends) (void)hipFree(c->own_ends);
+    for (void* q : {c->own_fbytes, c->own_fends, c->own_fperm})
+        if (q) (void)hipFree(q);
     delete c;
 }
 size_t fzb_corpus_len(const fzb_corpus* c) { return c ? (size_t)c->dev.n : 0; }

@@ -24,6 +24,9 @@ struct fzb_corpus {
     CorpusDev dev{};
     void* own_bytes = nullptr;
     void* own_ends = nullptr;
+    void* own_fbytes = nullptr;  // the filter's length-sorted view (CorpusDev::fbytes / fends / fperm)
+    void* own_fends = nullptr;
+    void* own_fperm = nullptr;
 };
 
 struct fzb_matcher {

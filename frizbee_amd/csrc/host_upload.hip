@@ -179,6 +179,94 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_build(const u8* __restrict__ 
     }
 }
 
+// The streaming filter's view of a ragged list (CorpusDev::fbytes): per 1024-haystack tile, the haystacks reordered by descending number
+// of 16-byte vectors.  A tile keeps its byte range (the padded sizes are the same set), so the view needs no global scan: one workgroup
+// per tile reads the canonical layout, ranks its haystacks (counting sort over the vector count, LDS atomics - upload time), scans the
+// padded lengths in the new order and copies the vectors.
+#define FV_CLASSES 66  // vector counts 0..64 and "more" (haystacks beyond 1024 bytes; their order inside the class is arbitrary)
+__global__ __launch_bounds__(UP_THREADS) void k_up_fview(const u8* __restrict__ bytes, const u32* __restrict__ ends, u64 n, u8* __restrict__ fbytes, u32* __restrict__ fends,
+                                                         u16* __restrict__ fperm) {
+    __shared__ u32 s_start[UP_TILE], s_len[UP_TILE], s_fstart[UP_TILE];
+    __shared__ u16 s_inv[UP_TILE];
+    __shared__ u32 s_hist[FV_CLASSES], s_base[FV_CLASSES];
+    __shared__ u32 s_wave[UP_THREADS / 64];
+    const u64 i0 = (u64)blockIdx.x * UP_TILE;
+    const u32 nt = (u32)min((u64)UP_TILE, n - i0);
+    const u32 tile_base = i0 ? (ends[i0 - 1] + 15u) & ~15u : 0u;
+    const int tid = threadIdx.x;
+    if (tid < FV_CLASSES) s_hist[tid] = 0;
+    u32 cls[4], rk[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 j = tid + UP_THREADS * k;
+        if (j < nt) {
+            const u32 st = (i0 + j) ? (ends[i0 + j - 1] + 15u) & ~15u : 0u;
+            s_start[j] = st;
+            s_len[j] = ends[i0 + j] - st;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 j = tid + UP_THREADS * k;
+        cls[k] = rk[k] = 0;
+        if (j < nt) {
+            cls[k] = min((s_len[j] + 15u) >> 4, (u32)FV_CLASSES - 1);
+            rk[k] = atomicAdd(&s_hist[cls[k]], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {  // descending: the longest class first
+        u32 run = 0;
+        for (int c = FV_CLASSES - 1; c >= 0; c--) { s_base[c] = run; run += s_hist[c]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 j = tid + UP_THREADS * k;
+        if (j < nt) s_inv[s_base[cls[k]] + rk[k]] = (u16)j;
+    }
+    __syncthreads();
+    // padded starts in the new order: thread t owns sorted positions 4t .. 4t+3
+    u32 pl[4], mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 g = 4 * tid + k;
+        pl[k] = g < nt ? (s_len[s_inv[g]] + 15u) & ~15u : 0u;
+        mine += pl[k];
+    }
+    u32 incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const u32 t = __shfl_up(incl, off);
+        if ((tid & 63) >= off) incl += t;
+    }
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    u32 run = incl - mine;
+    for (int w = 0; w < (tid >> 6); w++) run += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const u32 g = 4 * tid + k;
+        if (g < nt) {
+            s_fstart[g] = run;
+            const u32 j = s_inv[g];
+            fends[i0 + g] = tile_base + run + s_len[j];
+            fperm[i0 + g] = (u16)j;
+        }
+        run += pl[k];
+    }
+    __syncthreads();
+    // the bytes: sorted position g's vectors (zero fill included: the canonical layout has it), consecutive threads on consecutive vectors
+    // of one haystack where they can (a warp-wide loop over (position, vector) pairs would need a second search; this is upload time)
+    for (u32 g = tid >> 2; g < nt; g += UP_THREADS / 4) {
+        const u32 j = s_inv[g];
+        const uint4* src = (const uint4*)(bytes + s_start[j]);
+        uint4* dst = (uint4*)(fbytes + tile_base + s_fstart[g]);
+        const u32 nv = (s_len[j] + 15u) >> 4;
+        for (u32 v = tid & 3; v < nv; v += 4) dst[v] = src[v];
+    }
+}
+
 // ---- host -> device at link speed ---------------------------------------------------------------------------------------------
 // FZB_UPLOAD_MODE: "direct" (default; one hipMemcpy per array straight from the caller's pageable memory; "pageable" is accepted as a
 // synonym), "register" (hipHostRegister the caller's memory, then copy), "staged" (per-thread pinned staging + asynchronous copies)
@@ -356,6 +444,22 @@ int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, si
         if (ends_u64) { if (adopt) FZB_UP_BUILD(u64, false); else FZB_UP_BUILD(u64, true); }
         else { if (adopt) FZB_UP_BUILD(u32, false); else FZB_UP_BUILD(u32, true); }
 #undef FZB_UP_BUILD
+    }
+    // the streaming filter's length-sorted view: ragged lists with 32-bit offsets whose haystacks exceed the short-list kernels' 32 bytes
+    // OPT-IN (FZB_FILTER_VIEW=1; a second copy of the bytes): measured on the C4 shard it removes the 47 % of dead lookups and the
+    // filter gets no faster (236 -> 257 us with the burst form, 244 us with the pipelined one; profiles/r03_ragged_filter_variants.txt)
+    static const bool want_view = getenv("FZB_FILTER_VIEW") && atoi(getenv("FZB_FILTER_VIEW")) != 0;
+    if (want_view && n && !ends_u64 && !c->dev.uniform_len && c->dev.max_len > 32) {
+        e = fzb_dev_alloc(&c->own_fbytes, total);
+        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_fends, n * 4);
+        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_fperm, n * 2);
+        if (e == hipSuccess) e = hipMemsetAsync((u8*)c->own_fbytes + st.total_padded, 0, 96, nullptr);
+        if (e != hipSuccess) return bail(e, "filter view");
+        hipLaunchKernelGGL(k_up_fview, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u8*)c->own_bytes, (const u32*)c->own_ends, (u64)n, (u8*)c->own_fbytes,
+                           (u32*)c->own_fends, (u16*)c->own_fperm);
+        c->dev.fbytes = (const u8*)c->own_fbytes;
+        c->dev.fends = (const u32*)c->own_fends;
+        c->dev.fperm = (const u16*)c->own_fperm;
     }
     e = hipDeviceSynchronize();  // the temporaries are released below; the corpus is complete when the call returns
     if (e == hipSuccess) e = hipGetLastError();

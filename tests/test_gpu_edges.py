@@ -86,8 +86,8 @@ def test_set_pattern_and_set_config_requery_a_resident_corpus():
         m.set_config(cfg)
         lanes = (16, 16, 8) if cfg.pf_lanes == 16 else (64, 64, 32)
         assert m.match_list(cp).tolist() == O.Matcher("deadbe", lanes=lanes, **ocfg).match_packed(odata, ends).tolist(), ocfg
-    with pytest.raises(F.FrizbeeError):
-        m.set_pattern("a" * 65)  # refused: the matcher keeps working as it was
+    with pytest.raises(F.PanicError):
+        m.set_pattern("a" * 3640)  # refused (the reference's overflow guard, src/lib.rs:506-527): the matcher keeps working as it was
     assert m.match_list(cp).tolist() == O.Matcher("deadbe", lanes=(16, 16, 8)).match_packed(odata, ends).tolist()
 
 

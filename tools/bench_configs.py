@@ -93,6 +93,12 @@ if "C4" in which:
     cp = F.Corpus(packed=(data, ends))
     run("C4 shard ragged 8..128 typos0", "deadbeef", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n4)
     del cp
+if "PATHS" in which:
+    npaths = 1_406_941
+    data, ends = synth.paths_corpus(b"linux", npaths, device=dev)
+    cp = F.Corpus(packed=(data, ends))
+    run("paths-shaped 1.4M ~Normal(67,17) 'linux' typos0", "linux", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, npaths)
+    del cp
 if "C5" in which:
     n5 = 2_000_000
     data, ends = synth.utf8_corpus(n5, 32)
