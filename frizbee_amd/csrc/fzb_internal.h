@@ -124,6 +124,7 @@ struct Workspace {
     u64* table;         // 256 x u64 filter table (device)
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     u8* uni_dfa;        // unicode path, 0 typos: states x 256 table of the exact prefilter's byte-level DFA (device)
+    u8* lcs_dfa;        // typo configurations: states x 256 table of the LCS automaton (device)
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
     size_t cap_level2;  // capacity of the second-level arrays (0 = not allocated)
     bool tables_stale;  // the matcher's needle / config changed since `table` and `dfa` were uploaded
@@ -159,7 +160,7 @@ struct RejectOut {
 // kernels_filter.hip
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m = nullptr, u32* tile_counts_m = nullptr,
-                       u64* reject_bits = nullptr, u32* tile_rejects = nullptr, int nul_safe = 0);
+                       u64* reject_bits = nullptr, u32* tile_rejects = nullptr, int nul_safe = 0, int acc_lo = -1);
 void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* reject_count, u32* rej_prefix, hipStream_t st);
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st);
 void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,

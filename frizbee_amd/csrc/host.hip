@@ -172,7 +172,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.fused_tile_counts, w.fused_group_counts, w.fused_stage};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.fused_tile_counts, w.fused_group_counts, w.fused_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -385,6 +385,63 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
             m->uni_dfa_states = ns;  // start state 0 = (0, 0): first created, never the accepting one (rows >= 1)
         }
     }
+    // Typo configurations: the streaming filter's LCS criterion `LCS(needle, haystack) >= rows - k` (Hyyro's bit-vector recurrence
+    // V' = (V + (V & M)) | (V & ~M), M = the rows byte b can match) as a table-driven automaton over its REACHABLE bit-vectors - 40-odd
+    // states for a 6-row needle - so that the filter is the same v_perm + ds_read_u8 per byte as the 0-typo one (k1_dfa: 55 us on the
+    // 10 M x 32 B list) instead of a table lookup + four vector operations (k1_filter: 71 us).  States are numbered by ascending LCS, so
+    // "accepts" is one compare; the start state (LCS 0, only reachable as itself) is state 0.  More than 226 states (long needles with
+    // many distinct letters): the bit-vector kernel stays.  FZB_NO_LCS_DFA=1 keeps it for comparison.
+    m->lcs_states = 0;
+    static const bool no_lcs_dfa = getenv("FZB_NO_LCS_DFA") != nullptr;
+    if (lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !no_lcs_dfa) {
+        const u64 mask = m->rows >= 64 ? ~(u64)0 : (((u64)1 << m->rows) - 1);
+        std::vector<u64> masks;  // distinct M over the 256 byte values
+        std::vector<int> mask_of(256);
+        for (int b = 0; b < 256; b++) {
+            const u64 mb = m->table[b] & mask;
+            size_t q = 0;
+            while (q < masks.size() && masks[q] != mb) q++;
+            if (q == masks.size()) masks.push_back(mb);
+            mask_of[b] = (int)q;
+        }
+        std::vector<u64> states{mask};  // V0: all ones in the low `rows` bits
+        std::unordered_map<u64, int> id{{mask, 0}};
+        std::vector<std::vector<int>> next;
+        bool ok = true;
+        for (size_t q = 0; q < states.size() && ok; q++) {
+            const u64 v = states[q];
+            std::vector<int> row(masks.size());
+            for (size_t t = 0; t < masks.size(); t++) {
+                const u64 u = v & masks[t];
+                const u64 nv = ((v + u) | (v & ~masks[t])) & mask;
+                auto it = id.find(nv);
+                if (it == id.end()) {
+                    it = id.emplace(nv, (int)states.size()).first;
+                    states.push_back(nv);
+                    if (states.size() > 226) ok = false;
+                }
+                row[t] = it->second;
+            }
+            next.push_back(row);
+        }
+        if (ok) {
+            const int ns = (int)states.size();
+            const int need = m->rows - k;
+            std::vector<int> lcs(ns), order(ns), renum(ns);
+            for (int q = 0; q < ns; q++) lcs[q] = __builtin_popcountll(~states[q] & mask), order[q] = q;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lcs[a] < lcs[b]; });  // V0 (LCS 0, first created) stays first
+            int acc = ns;
+            for (int pos = 0; pos < ns; pos++) {
+                renum[order[pos]] = pos;
+                if (lcs[order[pos]] >= need && acc == ns) acc = pos;
+            }
+            m->lcs_dfa.assign((size_t)ns * 256, 0);
+            for (int q = 0; q < ns; q++)
+                for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[q][mask_of[b]]];
+            m->lcs_states = ns;
+            m->lcs_acc_lo = acc;
+        }
+    }
     lc.pad_ok = 1;
     for (size_t i = 0; i < needle_len; i++)
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
@@ -586,6 +643,7 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
             HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
             if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
             if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
+            if (!m->lcs_dfa.empty()) HIPCHK(hipMemcpy(w.lcs_dfa, m->lcs_dfa.data(), m->lcs_dfa.size(), hipMemcpyHostToDevice));
             w.tables_stale = false;
         }
         return FZB_OK;
@@ -604,6 +662,8 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
     HIPCHK(dev_alloc((void**)&w.uni_dfa, 256 * 256 + 16));  // room for any unicode DFA (<= 255 states + 1): set_pattern re-uploads in place
     if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
+    HIPCHK(dev_alloc((void**)&w.lcs_dfa, 256 * 256 + 16));  // room for any LCS automaton (<= 226 states): set_pattern re-uploads in place
+    if (!m->lcs_dfa.empty()) HIPCHK(hipMemcpy(w.lcs_dfa, m->lcs_dfa.data(), m->lcs_dfa.size(), hipMemcpyHostToDevice));
     w.cap_items = cap;
     if (need_l2) {
         HIPCHK(dev_alloc((void**)&w.win, cap * 8));
@@ -910,7 +970,10 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // 1.3e8 random single-chunk cases without a deviation).  Then nothing is marginal and the decide pass is not launched.
         const bool single_chunk = cd.max_len <= (u32)lc.pf_lanes;
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        if (single_chunk)
+        if (single_chunk && m->lcs_states)  // the LCS criterion as an automaton in the streaming DFA kernel
+            fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
+                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo);
+        else if (single_chunk)
             fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
         else
             fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, w.bitmap_m,
@@ -961,8 +1024,12 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
-                          nullptr, nullptr, lc.pad_ok);
+        if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
+            fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
+                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo);
+        else
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
+                              nullptr, nullptr, lc.pad_ok);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
         static const int c1mul = getenv("FZB_COMPACT_GRID_MUL") ? atoi(getenv("FZB_COMPACT_GRID_MUL")) : 4;  // tuning knob (workgroups per CU)
@@ -1898,6 +1965,16 @@ int fzb_debug_unicode_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, si
     u32 st = 0;
     for (size_t i = 0; i < len; i++) st = m->uni_dfa[(size_t)st * 256 + bytes[i]];
     return st == (u32)m->uni_dfa_states - 1 ? 1 : 0;
+}
+
+// Test hook (host only): the LCS automaton of a typo configuration run over one haystack.  1 / 0 = the streaming filter accepts / rejects
+// (LCS >= rows - max_typos), -1 if the matcher has no such automaton; *out_states (optional) = its number of states.
+int fzb_debug_lcs_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t len, int32_t* out_states) {
+    if (out_states) *out_states = m ? m->lcs_states : 0;
+    if (!m || m->lcs_states == 0 || (!bytes && len)) return -1;
+    u32 st = 0;
+    for (size_t i = 0; i < len; i++) st = m->lcs_dfa[(size_t)st * 256 + bytes[i]];
+    return st >= (u32)m->lcs_acc_lo ? 1 : 0;
 }
 
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {

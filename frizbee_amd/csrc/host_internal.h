@@ -41,6 +41,10 @@ struct fzb_matcher {
     std::vector<u8> dfa;     // host copy of the subsequence DFA
     std::vector<u8> uni_dfa; // unicode path, 0 typos: byte-level DFA of the exact prefilter (empty if it needs more than 255 states)
     int uni_dfa_states = 0;
+    // typo configurations: the bit-vector LCS test of the streaming filter as a DFA over its REACHABLE states (empty when there are more
+    // than 226): state 0 = nothing matched, states >= lcs_acc_lo accept (LCS >= rows - max_typos)
+    std::vector<u8> lcs_dfa;
+    int lcs_states = 0, lcs_acc_lo = 0;
     Workspace ws{};
     int device = -1;
     bool profiling = false;

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
 // ---------------------------------------------------------------------------------------------------
 template <typename ET>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                              const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                              const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                               u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 ulen) {
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
     // compaction kernel reads it
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
         for (int p = 0; p < 4; p++) {
             const u32 L = hl[p];
             const u32 li = tile * FZB_TILE + p * 256 + tid;
-            const bool matched = li < count && L >= min_len && st[p] == (u32)rows;
+            const bool matched = li < count && L >= min_len && st[p] >= acc_lo;
             const u64 b = __ballot(matched);
             if (lane_id() == 0) {
                 bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
@@ -239,7 +239,7 @@ __device__ __forceinline__ void dfa_wordP(u32 (&st)[P], const u32 (&w)[P], const
 // sees after its haystack ended - match no needle row, so the vectors go through the DFA unmasked (a third of the loop's instructions).
 template <typename ET, int P, bool SAN = true>
 __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                     const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                                     const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                                      u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
     // compaction kernel reads it
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const u32 li = base + p * 256 + tid;
-                const bool matched = li < count && hl[p] >= min_len && st[p] == (u32)rows;
+                const bool matched = li < count && hl[p] >= min_len && st[p] >= acc_lo;
                 const u64 b = __ballot(matched);
                 if (lane_id() == 0) {
                     bitmap[(base + p * 256) / 64 + (tid >> 6)] = b;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
 // lookups for lanes whose haystack has ended.
 template <typename ET, bool SAN, bool PERM = false>
 __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                           const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                                           const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                                            u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, const u16* __restrict__ perm = nullptr) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
                     }
                 }
             }
-            const bool matched = li < count && hl >= min_len && st == (u32)rows;
+            const bool matched = li < count && hl >= min_len && st >= acc_lo;
             if (PERM) {
                 if (matched) atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
                 continue;
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
 // ---------------------------------------------------------------------------------------------------
 template <typename ET, bool SAN, bool PERM>
 __global__ __launch_bounds__(256) void k1_dfa_ragged_pipe(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                          const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                                          const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                                           u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, const u16* __restrict__ perm) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_pipe(const u8* __restrict__
                 }
             }
         }
-        const bool matched = li < count && hl_c >= min_len && st == (u32)rows;
+        const bool matched = li < count && hl_c >= min_len && st >= acc_lo;
         if (PERM) {
             if (matched) atomicOr(&s_bits[or_c >> 5], 1u << (or_c & 31));
         } else {
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_pipe(const u8* __restrict__
 #define FZB_COOP_WIN 4096u
 template <typename ET, bool SAN, bool PERM, int NV>
 __global__ __launch_bounds__(256) void k1_dfa_ragged_coop(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                          const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                                          const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                                           u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, const u16* __restrict__ perm) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];  // table at LDS address 0, then the tile counter, the tile's decision bits, the waves' windows
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_coop(const u8* __restrict__
                     st = dfa_step<3>(st, w[j], dfa);
                 }
             }
-            const bool matched = li < count && hl >= min_len && st == (u32)rows;
+            const bool matched = li < count && hl >= min_len && st >= acc_lo;
             if (PERM) {
                 if (matched) atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
                 continue;
@@ -738,7 +738,7 @@ __device__ __forceinline__ void rl_round(u32 (&st)[4], const uint4 (&q)[4], cons
 
 template <typename ET, bool SAN>
 __global__ __launch_bounds__(256) void k1_dfa_ragged_lds(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                         const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u64* __restrict__ bitmap,
+                                                         const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                                          u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 seg_bytes) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     // ONE dynamic LDS object with the DFA table at address 0 (dfa_lds.h); behind it: the tile's end offsets, the sorted order, the
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_lds(const u8* __restrict__ 
                     const u8* h = bytes + tile_base + start0;
                     u32 st = 0;
                     for (u32 k = 0; k < len; k++) st = *(const __attribute__((address_space(3))) u8*)(uintptr_t)(st * FZB_DFA_STRIDE + h[k]);
-                    if (len >= min_len && st == (u32)rows) atomicOr(&s_bits[j0 >> 5], 1u << (j0 & 31));
+                    if (len >= min_len && st >= acc_lo) atomicOr(&s_bits[j0 >> 5], 1u << (j0 & 31));
                 }
                 j0++;
                 continue;
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_lds(const u8* __restrict__ 
             }
 #pragma unroll
             for (int p = 0; p < 4; p++)
-                if (jj[p] != 0xFFFFFFFFu && len[p] >= min_len && st[p] == (u32)rows) atomicOr(&s_bits[jj[p] >> 5], 1u << (jj[p] & 31));
+                if (jj[p] != 0xFFFFFFFFu && len[p] >= min_len && st[p] >= acc_lo) atomicOr(&s_bits[jj[p] >> 5], 1u << (jj[p] & 31));
             __syncthreads();  // the buffer and the order array are free again
             j0 = j1;
         }
@@ -1181,7 +1181,11 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // host-side launch wrappers (called from host.hip)
 // ---------------------------------------------------------------------------------------------------
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
-                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe) {
+                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe,
+                       int acc_lo) {
+    // mode 1: `dfa` has rows + 1 states, start state 0, and accepts in the states >= acc (the subsequence / unicode / KMP automata: the last
+    // state; the LCS automaton of a typo configuration: every state whose LCS reaches the need)
+    const u32 acc = acc_lo < 0 ? (u32)rows : (u32)acc_lo;
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
@@ -1189,8 +1193,8 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         const size_t lds = (size_t)(rows + 1) * FZB_DFA_STRIDE + 16;  // table + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
-            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.uniform_len);
-            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.uniform_len);
+            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len);
+            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len);
         } else {
             // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
             // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times).
@@ -1212,7 +1216,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             const size_t fixed = (((size_t)(rows + 1) * FZB_DFA_STRIDE + 15) & ~(size_t)15) + (FZB_TILE + 4) * 4 + FZB_TILE * 2 + (16 * FZB_RL_NCLS + FZB_RL_NCLS + 2 + 32 + 4) * 4 + 16;
             if (use_lds && fixed + seg <= 64 * 1024) {
                 const int g = std::max(1, std::min<int>((grid / 8) * lwgs, (int)ntiles));
-#define FZB_K1L(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_lds<ET, SAN>), dim3(g), dim3(256), fixed + seg, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, seg)
+#define FZB_K1L(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_lds<ET, SAN>), dim3(g), dim3(256), fixed + seg, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, seg)
                 if (c.ends_u64) { if (nul_safe) FZB_K1L(u64, false); else FZB_K1L(u64, true); }
                 else            { if (nul_safe) FZB_K1L(u32, false); else FZB_K1L(u32, true); }
 #undef FZB_K1L
@@ -1227,7 +1231,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             if (pipe) {
                 const int g = std::max(1, std::min<int>((grid / 8) * pwgs, (int)ntiles));
                 const size_t lds_p = lds + 16 + 32 * 4;
-#define FZB_K1P(ET, SAN, PERM, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_pipe<ET, SAN, PERM>), dim3(g), dim3(256), lds_p, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, P)
+#define FZB_K1P(ET, SAN, PERM, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_pipe<ET, SAN, PERM>), dim3(g), dim3(256), lds_p, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, P)
                 if (view) { if (nul_safe) FZB_K1P(u32, false, true, c.fbytes, c.fends, c.fperm); else FZB_K1P(u32, true, true, c.fbytes, c.fends, c.fperm); }
                 else if (c.ends_u64) { if (nul_safe) FZB_K1P(u64, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u64, true, false, c.bytes, c.ends, (const u16*)nullptr); }
                 else { if (nul_safe) FZB_K1P(u32, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u32, true, false, c.bytes, c.ends, (const u16*)nullptr); }
@@ -1241,7 +1245,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 const size_t lds_c = (((size_t)(rows + 1) * FZB_DFA_STRIDE + 15) & ~(size_t)15) + 16 + 128 + 4 * FZB_COOP_WIN;
                 const int g = std::max(1, std::min<int>((grid / 8) * cwgs, (int)ntiles));
                 const bool nv8 = c.max_len <= 128;
-#define FZB_K1C(ET, SAN, PERM, NV, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_coop<ET, SAN, PERM, NV>), dim3(g), dim3(256), lds_c, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, P)
+#define FZB_K1C(ET, SAN, PERM, NV, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_coop<ET, SAN, PERM, NV>), dim3(g), dim3(256), lds_c, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, P)
 #define FZB_K1C_NV(ET, SAN, PERM, B, E, P) do { if (nv8) FZB_K1C(ET, SAN, PERM, 8, B, E, P); else FZB_K1C(ET, SAN, PERM, 16, B, E, P); } while (0)
                 if (lds_c <= 64 * 1024) {
                     if (view) { if (nul_safe) FZB_K1C_NV(u32, false, true, c.fbytes, c.fends, c.fperm); else FZB_K1C_NV(u32, true, true, c.fbytes, c.fends, c.fperm); }
@@ -1255,19 +1259,19 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             if (view) {
                 rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
                 const size_t lds_p = lds + 16 + 32 * 4;
-                if (nul_safe) hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, false, true>), dim3(rgrid), dim3(256), lds_p, st, c.fbytes, c.fends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.fperm);
-                else hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, true, true>), dim3(rgrid), dim3(256), lds_p, st, c.fbytes, c.fends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters, c.fperm);
+                if (nul_safe) hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, false, true>), dim3(rgrid), dim3(256), lds_p, st, c.fbytes, c.fends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.fperm);
+                else hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, true, true>), dim3(rgrid), dim3(256), lds_p, st, c.fbytes, c.fends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.fperm);
                 return;
             }
             if (burst) {
                 rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
-#define FZB_K1B(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_burst<ET, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters)
+#define FZB_K1B(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_burst<ET, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
                 if (c.ends_u64) { if (nul_safe) FZB_K1B(u64, false); else FZB_K1B(u64, true); }
                 else            { if (nul_safe) FZB_K1B(u32, false); else FZB_K1B(u32, true); }
 #undef FZB_K1B
                 return;
             }
-#define FZB_K1R(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged<ET, 1, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, bitmap, tile_counts, reset_counters)
+#define FZB_K1R(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged<ET, 1, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
             if (c.ends_u64) { if (nul_safe) FZB_K1R(u64, false); else FZB_K1R(u64, true); }
             else            { if (nul_safe) FZB_K1R(u32, false); else FZB_K1R(u32, true); }
 #undef FZB_K1R

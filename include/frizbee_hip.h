@@ -24,7 +24,7 @@ enum {
     FZB_OK = 0,
     FZB_ERR_INVALID = 1,      /* bad argument (NULL, bad enum, invalid UTF-8 needle)                      */
     FZB_ERR_PANIC = 2,        /* the reference would panic (message = its panic text)                     */
-    FZB_ERR_UNSUPPORTED = 3,  /* valid for the reference but not handled by this backend (stated limit)   */
+    FZB_ERR_UNSUPPORTED = 3,  /* reserved: nothing returns it since round 3 (needles of every accepted length are handled) */
     FZB_ERR_HIP = 4,          /* HIP runtime error / no device                                            */
     FZB_ERR_CAPACITY = 5      /* caller-provided device buffer too small                                  */
 };
@@ -279,6 +279,11 @@ int fzb_last_counters(fzb_matcher* m, uint32_t out[4]);
 
 /* test hook, host only: the byte-level DFA of the unicode 0-typo prefilter run over one haystack (1 / 0), -1 if the matcher has none */
 int fzb_debug_unicode_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t len);
+
+/* test hook, host only: the LCS automaton of a typo configuration (the streaming filter's accept test `LCS(needle, haystack) >= rows -
+ * max_typos` as a DFA over the reachable bit-vector states) run over one haystack: 1 / 0, -1 if the matcher has none (0 typos, no
+ * prefilter, more than 226 states); *out_states (optional) = its number of states */
+int fzb_debug_lcs_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t len, int32_t* out_states);
 
 #ifdef __cplusplus
 }

@@ -255,3 +255,39 @@ def test_multi_device_entry_points_fail_loudly_without_a_device():
     with pytest.raises(F.FrizbeeError) as e:
         F.Corpus(["a", "b"])
     assert e.value.code == 4  # no CPU fallback anywhere on the product path
+
+
+def test_lcs_automaton_is_the_lcs_criterion():
+    # typo configurations: the streaming filter's accept test as a DFA over the reachable bit-vector states (fzb_matcher_create) must be
+    # `LCS(needle, haystack) >= rows - max_typos` with case folding (src/prefilter/mod.rs:1013-1084) - checked against a plain DP
+    import ctypes as C
+
+    def lcs(a, b):
+        prev = [0] * (len(b) + 1)
+        for x in a:
+            cur = [0]
+            for j, y in enumerate(b):
+                cur.append(prev[j] + 1 if x == y else max(prev[j + 1], cur[j]))
+            prev = cur
+        return prev[-1]
+
+    rng = np.random.default_rng(12)
+    seen_states = []
+    for needle, k in (("deadbe", 1), ("deadbe", 2), ("aab", 1), ("abcabc", 3), ("x_Y-z", 2), ("abcdefghijkl", 2), ("aaaaaaaa", 3), ("ab", 1)):
+        m = F.Matcher(needle, F.Config(max_typos=k, casing=F.CaseMatching.Ignore))
+        ns = C.c_int32()
+        alpha = (needle + needle.upper() + "q_ 0").encode()
+        for _ in range(400):
+            h = bytes(alpha[int(x)] for x in rng.integers(0, len(alpha), int(rng.integers(0, 40))))
+            got = F.lib().fzb_debug_lcs_dfa_accepts(m.h, h, len(h), C.byref(ns))
+            if ns.value == 0:
+                assert got == -1  # more reachable states than the table holds: the bit-vector kernel keeps this needle
+                break
+            assert got == int(lcs(needle.lower(), h.decode().lower()) + k >= len(needle)), (needle, k, h)
+        seen_states.append(ns.value)
+    assert all(n <= 226 for n in seen_states) and sum(n > 0 for n in seen_states) >= 6, seen_states
+    print("LCS automaton states:", seen_states)
+    # no automaton: 0 typos, no prefilter, and a needle whose reachable states exceed the table
+    assert F.lib().fzb_debug_lcs_dfa_accepts(F.Matcher("deadbe").h, b"x", 1, None) == -1
+    assert F.lib().fzb_debug_lcs_dfa_accepts(F.Matcher("deadbe", F.Config(max_typos=None)).h, b"x", 1, None) == -1
+    assert F.lib().fzb_debug_lcs_dfa_accepts(F.Matcher("abcdefghijklmnopqrstuvwxyz012345", F.Config(max_typos=3)).h, b"x", 1, None) == -1
