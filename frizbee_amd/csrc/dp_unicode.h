@@ -237,3 +237,203 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
     for (int d = 1; d < NR; d++) mx = p_max(mx, prev[d]);
     return max(mx & 0xFFFF, mx >> 16);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same scorer in dp_cf.h's manner (round 3): BIASED THROUGHOUT.  T(i, L) = S(i, L) + P[L] + (i + 1) * e, with P as above (e per
+// non-continuation lane up to and including L) and one gap-extend per row, is what the registers hold from the first row to the last:
+//   * up:    S(i-1, L) (-) e (-) g   becomes   T(i-1, L) (-) g            (the row bias pays the e; g = gop' where the cell above matched)
+//   * diag:  only scalar-start lanes take it, and for those P[L] - P[L-1] = e, so the bias grows by 2e along the diagonal:
+//            ((S(i-1, L-1) + match*bonus) (-) x) + case   becomes   ((T(i-1, L-1) + match*bonus) (-) (x - 2e)) + case
+//   * the reference's floor at 0 is one max with the cell's bias B(i, L) = P[L] + (i + 1) * e (a match cell is above it anyway:
+//     bonus >= match + mismatch >= x); lanes that are not scalar starts hold exactly B (score 0)
+//   * the gap scan is the biased step of the first form with nothing added before and nothing removed after it
+//   * B(i, L) is ONE v_pk_mad_u16 from Qp[L] = #scalar starts + #padding lanes in [0, L] (the only per-lane state besides the
+//     scalar-start flags; its differences are also the "a scalar start was crossed" test - padding lanes count as crossings, which
+//     only changes values IN padding lanes, and those are never read: see NR above)
+// and the needle row's bytes come from three scalar loads of the by-value argument (dwords of uc / uf / ulen) instead of byte loads
+// with a dynamic index, which the compiler turned into eight dependent global loads per row; the byte compares are specialised per
+// scalar length (a wave-uniform switch) and OR-ed before ONE zero-byte test per case variant.
+// Preconditions (host, LaunchCfg::cfu_ok): 2 * gap_extend <= mismatch_penalty and the biased values fit 16 bits (bias_ok).
+// k2u_dp_unicode_half<64>: 2143 -> see DESIGN.md; tests/test_kernel_math_host.py fuzzes this form against the oracle and the first form.
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 p_mad(u32 a, u32 b, u32 c) { return as_u32(as_us2(a) * as_us2(b) + as_us2(c)); }
+
+// true if bytes [0, m) of `th` hold four UTF-8 continuation bytes (0x80..0xBF) in a row - i.e. the window is not UTF-8 as far as the gap
+// scan's shortcut is concerned (dp_unicode_single_chunk_t, UTF8)
+template <int NBYTES>
+__device__ __forceinline__ bool unicode_has_cont_run4(const u8* __restrict__ th, u32 m) {
+    u32 run4 = 0, cont_prev = 0;
+#pragma unroll
+    for (int k = 0; k < NBYTES / 4; k++) {
+        const u32 p = 4 * k;
+        u32 w = 0;
+        if (p < m) w = load_u32_unaligned(th, p);
+        const u32 nv = m > p ? min(m - p, 4u) : 0u;
+        const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
+        const u32 cv = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u) & validf;
+        // byte j of the shifted views = the flag of the byte 3 / 2 / 1 positions before byte j
+        run4 |= cv & __builtin_amdgcn_alignbyte(cv, cont_prev, 1) & __builtin_amdgcn_alignbyte(cv, cont_prev, 2) & __builtin_amdgcn_alignbyte(cv, cont_prev, 3);
+        cont_prev = cv;
+    }
+    return run4 != 0;
+}
+
+// UTF8 = true: the caller has checked (unicode_has_cont_run4, wave-uniform) that no window of the wave holds four continuation bytes in a
+// row.  In UTF-8 a scalar has at most three, so every window of >= 4 lanes holds a scalar start (or padding, which Qp counts the same
+// way): the "crossed a scalar start" test of the 4-, 8-, 16-lane steps is then always true - the pending charge is always taken and the
+// pending mask never moves - and those steps are a subtract and a max.  Any other byte string takes UTF8 = false (every test kept).
+template <int SWL, int REAL = SWL / 2, bool UTF8 = false>
+__device__ __forceinline__ u32 dp_unicode_single_chunk_t(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls) {
+    constexpr int NW = SWL / 2;
+    constexpr int RB = (REAL + 1) / 2;  // byte dwords that may hold haystack bytes
+    constexpr int NR = 2 * RB;          // score dwords computed (two lanes each)
+    static_assert(REAL >= 1 && REAL <= NW, "REAL");
+    const u32 rows = (u32)nd.rows;
+    const u32 ONE = 0x00010001u;
+    const u32 e = nd.gex;
+    const u32 Mv = splat16(nd.match_plus_mismatch), xqv = splat16(nd.mismatch - 2 * e), gexv = splat16(e), gopmv = splat16(nd.gopm);
+    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+    u32 hb[RB + 1];
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        const u32 p = 4 * k;
+        u32 v = 0;
+        if (p < m) {
+            v = load_u32_unaligned(th, p);
+            const u32 rem = m - p;
+            if (rem < 4) v &= (1u << (8 * rem)) - 1;
+        }
+        hb[k] = v;
+    }
+    hb[RB] = 0;
+    // ---- scalar-start flags per byte (0x80), Qp = #scalar starts + #padding lanes up to and including the lane, bonus -------------
+    u32 sflag[RB], Qp[NR], bonus[NR];
+    {
+        const u32 mv = splat16(m);
+        u32 clsw_prev = 0, qrun = 0;
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+            const u32 w = hb[k];
+            const u32 contf = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u);  // continuation byte: (b & 0xC0) == 0x80
+            const u32 p = 4 * k;
+            const u32 nv = m > p ? min(m - p, 4u) : 0u;
+            const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
+            sflag[k] = validf & ~contf;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int d = 2 * k + h;
+                const u32 b0 = h ? (w >> 16) & 0xFF : w & 0xFF;
+                const u32 b1 = h ? w >> 24 : (w >> 8) & 0xFF;
+                const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
+                const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);
+                const u32 cap01 = (clsw >> 1) & sh & ONE;
+                const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;
+                bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+                clsw_prev = clsw;
+                const u32 t = sflag[k] >> 7;
+                const u32 s0 = h ? (t >> 16) & 1 : t & 1;
+                const u32 s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
+                const u32 q0 = qrun + s0, q1 = q0 + s1;
+                const u32 lanepos1 = (u32)(2 * d + 1) | ((u32)(2 * d + 2) << 16);
+                Qp[d] = p_add(q0 | (q1 << 16), p_subs(lanepos1, mv));
+                qrun = q1;
+            }
+        }
+        if (include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
+    }
+    u32 prev[NR], upg[NR];  // upg / pendg: the match masks already AND-ed with gop' (every use of them is)
+#pragma unroll
+    for (int d = 0; d < NR; d++) prev[d] = p_mul(Qp[d], gexv), upg[d] = 0;  // T(-1, L) = B(-1, L) = P[L]
+#pragma unroll 1
+    for (u32 r = 0; r < rows; r++) {
+        // the needle row: three scalar loads of the by-value argument
+        const u32 ucw = ((const u32*)nd.uc)[r], ufw = ((const u32*)nd.uf)[r];
+        const u32 cl = (((const u32*)nd.ulen)[r >> 2] >> (8 * (r & 3))) & 0xFF;
+        const bool two = ucw != ufw;
+        const u32 c0 = (ucw & 0xFF) * 0x01010101u, c1 = ((ucw >> 8) & 0xFF) * 0x01010101u, c2 = ((ucw >> 16) & 0xFF) * 0x01010101u, c3 = (ucw >> 24) * 0x01010101u;
+        const u32 f0 = (ufw & 0xFF) * 0x01010101u, f1 = ((ufw >> 8) & 0xFF) * 0x01010101u, f2 = ((ufw >> 16) & 0xFF) * 0x01010101u, f3 = (ufw >> 24) * 0x01010101u;
+        const u32 rbv = splat16((r + 1) * e);
+        // keep the per-lane state out of loop-invariant hoisting (see the first form)
+#pragma unroll
+        for (int d = 0; d < NR; d++) FZB_OPAQUE_V(Qp[d]);
+#pragma unroll
+        for (int k = 0; k <= RB; k++) FZB_OPAQUE_V(hb[k]);
+        u32 row[NR], pendg[NR];
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+            // ---- byte-level match flags: scalar start && the cl bytes from the lane on equal the needle scalar (unicode.rs:221-241) ----
+            const u32 v0 = hb[k];
+            u32 ze, zf;
+            if (cl == 1) {
+                ze = v0 ^ c0; zf = v0 ^ f0;
+            } else {
+                const u32 v1 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 1);
+                ze = (v0 ^ c0) | (v1 ^ c1); zf = (v0 ^ f0) | (v1 ^ f1);
+                if (cl > 2) {
+                    const u32 v2 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 2);
+                    ze |= v2 ^ c2; zf |= v2 ^ f2;
+                    if (cl > 3) {
+                        const u32 v3 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 3);
+                        ze |= v3 ^ c3; zf |= v3 ^ f3;
+                    }
+                }
+            }
+            u32 fe = zflag4(ze) & sflag[k];
+            u32 fm = fe;
+            if (two) fm |= zflag4(zf) & sflag[k];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int d = 2 * k + h;
+                const u32 sel = h ? 0x03030202u : 0x01010000u;  // byte 2h -> both bytes of lane 0, byte 2h+1 -> both bytes of lane 1: 0x8080 / 0
+                const u32 exm = p_neg_mask(__builtin_amdgcn_perm(0u, fe, sel));
+                const u32 mmk = p_neg_mask(__builtin_amdgcn_perm(0u, fm, sel));
+                const u32 sst = p_neg_mask(__builtin_amdgcn_perm(0u, sflag[k], sel));
+                const u32 z = (r * e) << 16;  // T(r-1, lane -1) = B(r-1, -1) = r * e: the zero column
+                const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : z, 16);
+                const u32 t = p_subs(p_add(sh, mmk & bonus[d]), xqv);
+                const u32 diag = p_add(t, exm & casev);
+                const u32 up = p_subs(prev[d], upg[d]);  // upg[d] still holds the PREVIOUS row's match mask (& gop')
+                const u32 Bd = p_mad(Qp[d], gexv, rbv);
+                const u32 v = p_max(p_max(diag, up), Bd);
+                row[d] = (v & sst) | (Bd & ~sst);
+                pendg[d] = upg[d] = mmk & gopmv;
+            }
+            FZB_SCHED_FENCE();
+        }
+        if (r + 1 == rows) {  // the last row is not propagated: its maximum, unbiased (non-start lanes hold exactly B: 0)
+            u32 mxl = 0;
+#pragma unroll
+            for (int d = 0; d < NR; d++) mxl = p_max(mxl, p_sub(row[d], p_mad(Qp[d], gexv, rbv)));
+            return max(mxl & 0xFFFF, mxl >> 16);
+        }
+        // ---- propagate_horizontal_unicode_gaps, in place from the highest dword down (entry d reads entries <= d only) ---------------
+#pragma unroll
+        for (int d = NR - 1; d >= 0; d--) {  // shift by one lane: "a scalar start lies in (L-1, L]" <=> lane L is a scalar start
+            const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : 0u, 16);
+            const u32 ps = __builtin_amdgcn_alignbit(pendg[d], d ? pendg[d - 1] : 0u, 16);
+            const u32 fl = p_neg_mask(__builtin_amdgcn_perm(0u, sflag[d >> 1], (d & 1) ? 0x03030202u : 0x01010000u));
+            row[d] = p_max(row[d], p_subs(bs, ps & fl));
+            pendg[d] = pendg[d] | (ps & ~fl);
+            if ((d & 1) == 0) FZB_SCHED_FENCE();
+        }
+#pragma unroll
+        for (int off = 1; off < NR; off *= 2) {
+            if (UTF8 && off >= 2) {
+#pragma unroll
+                for (int d = NR - 1; d >= off; d--) row[d] = p_max(row[d], p_subs(row[d - off], pendg[d - off]));
+                FZB_SCHED_FENCE();
+                continue;
+            }
+#pragma unroll
+            for (int d = NR - 1; d >= off; d--) {
+                const u32 fl = p_neg_mask(p_sub(Qp[d - off], Qp[d]));  // Qp differs <=> a scalar start (or padding) lies in (L - 2 off, L]
+                row[d] = p_max(row[d], p_subs(row[d - off], pendg[d - off] & fl));
+                pendg[d] = pendg[d] | (pendg[d - off] & ~fl);
+                if ((d & 3) == 0) FZB_SCHED_FENCE();
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < NR; d++) prev[d] = row[d];
+    }
+    return 0;  // rows == 0
+}

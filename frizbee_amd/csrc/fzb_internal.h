@@ -140,6 +140,7 @@ struct LaunchCfg {
     int window_mode;    // 0 = from the lane-exact prefilter kernel, 1 = inline first/last occurrence (ASCII 0 typos), 2 = full haystack
     int bias_ok;        // DP gap propagation may run in the biased domain (no u16 overflow possible)
     int pad_ok;         // needle has no NUL byte: zero-padding lanes can never match (enables the padded-half DP form)
+    int cfu_ok;  // dp_unicode.h's biased-throughout form: bias_ok and 2 * gap_extend <= mismatch_penalty
     int cf_ok;
     int cfm_ok;  // dp_cfm.h preconditions (multi-chunk windows in the biased domain)          // single-chunk scorer in its second form (dp_cf.h): pad_ok, bias_ok and 2 * gap_extend <= mismatch_penalty
     int num_cus;
@@ -186,7 +187,7 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
 // kernels_unicode.hip
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
-                           int grid, hipStream_t st);
+                           int grid, hipStream_t st, int tform = 0);
 // kernels_sort.hip
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st, int passes = 2);
 // kernels_multi.hip

@@ -450,6 +450,8 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     lc.cfm_ok = 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty &&
                 max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 200 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;  // dp_cfm.h: lanes up to 3/2 chunks + rows of bias
     lc.cf_ok = lc.pad_ok && lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty;  // dp_cf.h preconditions
+    static const bool no_cfu = getenv("FZB_NO_DP_CFU") != nullptr;  // comparison knob: the unicode scorer's first form
+    lc.cfu_ok = lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty && !no_cfu;
     *out = m;
     return FZB_OK;
 }
@@ -1070,7 +1072,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
                                  trace->npos, trace->stride, tgrid, st);
         FZB_STAGE("generic(trace)");
     } else if (nd.unicode && lc.bias_ok) {
-        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
+        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st, lc.cfu_ok);
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
             fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * 2, st);

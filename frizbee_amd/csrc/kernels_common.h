@@ -58,6 +58,14 @@ __device__ __forceinline__ u32 wave_alloc(u32* counter, bool want) {
 #define FZB_OPAQUE_V(x) asm volatile("" : "+v"(x))
 #endif
 
+// A scheduling fence: the compiler does not move instructions across it.  Used between the unrolled iterations of the register-heavy
+// scorers so that the temporaries of sixteen iterations are not all live at once (dp_unicode.h: spills inside the row loop otherwise).
+#ifdef FZB_HOST_SHIM
+#define FZB_SCHED_FENCE() ((void)0)
+#else
+#define FZB_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
 // a + b on the scalar unit, opaque to the optimiser: a chain `x = fzb_sadd(x, step)` over an unrolled loop stays one s_add per
 // link (the compiler otherwise rewrites it into a multiply and an add per element)
 __device__ __forceinline__ u32 fzb_sadd(u32 a, u32 b) {

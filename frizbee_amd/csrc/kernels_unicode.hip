@@ -2,8 +2,9 @@
 // survivors of the lane-exact unicode prefilter.  Windows wider than one chunk (or > 1024 bytes) are queued for the
 // generic wave-per-haystack kernel (kernels_generic.hip), exactly like the ASCII single-chunk kernel does.
 #include "dp_unicode.h"
+#include <cstdlib>
 
-template <int SWL, bool HALFONLY, typename ET>
+template <int SWL, bool HALFONLY, bool TF, typename ET>
 __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                       const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                       const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity,
@@ -70,8 +71,17 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             if (m > 0 && nd.rows > 0) {
                 // wave-uniform choice: if every window of the wave fits the low half of the chunk, the upper half is pure padding
                 const bool half = HALFONLY || (SWL >= 16 && __all((int)(m <= (u32)SWL / 2)));
-                if (half) score = dp_unicode_single_chunk<SWL, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, hay + sp, m, sp == 0, cls);
-                else if (!HALFONLY) score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
+                // TF: the biased-throughout form (dp_unicode_single_chunk_t; LaunchCfg::cfu_ok), else the first form
+                constexpr int HR = SWL >= 16 ? SWL / 4 : SWL / 2;
+                if (TF) {
+                    // wave-uniform: every window of the wave is free of four-continuation-byte runs (always, for UTF-8 text)
+                    const bool utf8 = __all((int)!(half ? unicode_has_cont_run4<(SWL >= 16 ? SWL / 2 : SWL)>(hay + sp, m) : unicode_has_cont_run4<SWL>(hay + sp, m)));
+                    if (half) score = utf8 ? dp_unicode_single_chunk_t<SWL, HR, true>(nd, hay + sp, m, sp == 0, cls) : dp_unicode_single_chunk_t<SWL, HR, false>(nd, hay + sp, m, sp == 0, cls);
+                    else if (!HALFONLY) score = utf8 ? dp_unicode_single_chunk_t<SWL, SWL / 2, true>(nd, hay + sp, m, sp == 0, cls) : dp_unicode_single_chunk_t<SWL, SWL / 2, false>(nd, hay + sp, m, sp == 0, cls);
+                } else {
+                    if (half) score = dp_unicode_single_chunk<SWL, HR>(nd, hay + sp, m, sp == 0, cls);
+                    else if (!HALFONLY) score = dp_unicode_single_chunk<SWL>(nd, hay + sp, m, sp == 0, cls);
+                }
             }
             bool exact = include_exact && m == (u32)nd.nbytes;
             if (exact)
@@ -95,30 +105,42 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
     const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ overflow, \
     u32 qcap, u32* __restrict__ counters, u32 ulen
 #define FZB_K2U_ARGS bytes, ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, ulen
-template <int SWL, typename ET>
-__global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, ET>(FZB_K2U_ARGS); }
+template <int SWL, bool TF, typename ET>
+__global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, TF, ET>(FZB_K2U_ARGS); }
 // every haystack of the list fits the low half of a chunk (host-known: corpus max_len <= SWL / 2): the general form is compiled out,
 // which lets the kernel fit 168 VGPRs (a few spills outside the row loop) and run three waves per SIMD
-template <int SWL, typename ET>
-__global__ __launch_bounds__(128, 3) void k2u_dp_unicode_half(FZB_K2U_PARAMS) { k2u_body<SWL, true, ET>(FZB_K2U_ARGS); }
+template <int SWL, bool TF, typename ET>
+__global__ __launch_bounds__(128, 3) void k2u_dp_unicode_half(FZB_K2U_PARAMS) { k2u_body<SWL, true, TF, ET>(FZB_K2U_ARGS); }
+// the same at two waves per SIMD (256 VGPRs: no spills in the row loop of the biased-throughout form); FZB_K2U_WAVES=2
+template <int SWL, bool TF, typename ET>
+__global__ __launch_bounds__(128, 2) void k2u_dp_unicode_half_w2(FZB_K2U_PARAMS) { k2u_body<SWL, true, TF, ET>(FZB_K2U_ARGS); }
 
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
-                           int grid, hipStream_t st) {
+                           int grid, hipStream_t st, int tform) {
     // `grid` = number of CUs: the kernel is persistent, launch exactly the resident workgroups
     const bool half_only = sw_lanes >= 16 && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2;
-#define FZB_K2U(SWL, ET)                                                                                                               \
+    // the biased-throughout form wants ~250 registers: at two waves per SIMD it runs without spills (C5: 0.152 ms; capped at 168 registers /
+    // three waves it spills inside the row loop: 0.199 ms; the first form at three waves: 0.161 ms).  FZB_K2U_WAVES=3 forces the capped build.
+    static const bool w3 = getenv("FZB_K2U_WAVES") && atoi(getenv("FZB_K2U_WAVES")) == 3;
+    const bool w2 = tform && !w3;
+#define FZB_K2U(SWL, TF, ET)                                                                                                           \
     do {                                                                                                                               \
         static int per_cu = 0, per_cu_half = 0;                                                                                        \
-        if (half_only) {                                                                                                               \
-            if (!per_cu_half && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_half, k2u_dp_unicode_half<SWL, ET>, 128, 0) != hipSuccess || per_cu_half < 1)) per_cu_half = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
+        if (half_only && w2) {                                                                                                         \
+            static int per_cu_w2 = 0;                                                                                                  \
+            if (!per_cu_w2 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w2, k2u_dp_unicode_half_w2<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_w2 < 1)) per_cu_w2 = 4; \
+            hipLaunchKernelGGL((k2u_dp_unicode_half_w2<SWL, TF, ET>), dim3(grid * per_cu_w2), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
+        } else if (half_only) {                                                                                                        \
+            if (!per_cu_half && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_half, k2u_dp_unicode_half<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_half < 1)) per_cu_half = 4; \
+            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, TF, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
         } else {                                                                                                                       \
-            if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
-            hipLaunchKernelGGL((k2u_dp_unicode<SWL, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
+            if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
+            hipLaunchKernelGGL((k2u_dp_unicode<SWL, TF, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
         }                                                                                                                              \
     } while (0)
-#define FZB_K2U_ET(SWL) do { if (c.ends_u64) FZB_K2U(SWL, u64); else FZB_K2U(SWL, u32); } while (0)
+#define FZB_K2U_TF(SWL, ET) do { if (tform) FZB_K2U(SWL, true, ET); else FZB_K2U(SWL, false, ET); } while (0)
+#define FZB_K2U_ET(SWL) do { if (c.ends_u64) FZB_K2U_TF(SWL, u64); else FZB_K2U_TF(SWL, u32); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2U_ET(64); break;
         case 32: FZB_K2U_ET(32); break;

@@ -80,10 +80,22 @@ static int run_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_pref
 
 // the unicode single-chunk scorer (dp_unicode.h): rows are needle scalars (bytes, flipped bytes, UTF-8 length per row)
 template <int SWL>
-static int run_unicode(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, int real, const u8* cls) {
+static int run_unicode(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, int real, const u8* cls, int form) {
     std::vector<u8> buf(m + 96, 0);
     memcpy(buf.data(), hay, m);
     constexpr int NW = SWL / 2;
+    if (form == 1 || form == 2) {  // the biased-throughout form (dp_unicode_single_chunk_t): 1 = as the kernel chooses, 2 = general steps forced
+        constexpr int HR = SWL >= 16 ? SWL / 4 : SWL / 2;
+        if (real == NW) {
+            const bool utf8 = form == 1 && !unicode_has_cont_run4<SWL>(buf.data(), m);
+            return utf8 ? (int)dp_unicode_single_chunk_t<SWL, NW, true>(nd, buf.data(), m, include_prefix, cls) : (int)dp_unicode_single_chunk_t<SWL, NW, false>(nd, buf.data(), m, include_prefix, cls);
+        }
+        if (SWL >= 16 && real == NW / 2) {
+            const bool utf8 = form == 1 && !unicode_has_cont_run4<(SWL >= 16 ? SWL / 2 : SWL)>(buf.data(), m);
+            return utf8 ? (int)dp_unicode_single_chunk_t<SWL, HR, true>(nd, buf.data(), m, include_prefix, cls) : (int)dp_unicode_single_chunk_t<SWL, HR, false>(nd, buf.data(), m, include_prefix, cls);
+        }
+        return -2;
+    }
     if (real == NW) return (int)dp_unicode_single_chunk<SWL>(nd, buf.data(), m, include_prefix, cls);
     if (SWL >= 16 && real == NW / 2) return (int)dp_unicode_single_chunk<SWL, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, buf.data(), m, include_prefix, cls);
     return -2;
@@ -108,7 +120,7 @@ int kh_dp_single(const u8* needle, int n, int case_sensitive, const u16* scoring
     return -1;
 }
 
-int kh_dp_unicode(const u8* uc, const u8* uf, const u8* ulen, int rows, const u16* sc, const u8* hay, int m, int include_prefix, int swl, int real) {
+int kh_dp_unicode(const u8* uc, const u8* uf, const u8* ulen, int rows, const u16* sc, const u8* hay, int m, int include_prefix, int swl, int real, int form) {
     if (rows < 1 || rows > FZB_MAX_ROWS || m < 0 || m > swl) return -1;
     NeedleDev nd;
     const u8 dummy[1] = {0};
@@ -123,10 +135,10 @@ int kh_dp_unicode(const u8* uc, const u8* uf, const u8* ulen, int rows, const u1
     static u8 cls[256];
     build_cls_table(cls);
     switch (swl) {
-        case 64: return run_unicode<64>(nd, hay, (u32)m, include_prefix, real, cls);
-        case 32: return run_unicode<32>(nd, hay, (u32)m, include_prefix, real, cls);
-        case 16: return run_unicode<16>(nd, hay, (u32)m, include_prefix, real, cls);
-        case 8: return run_unicode<8>(nd, hay, (u32)m, include_prefix, real, cls);
+        case 64: return run_unicode<64>(nd, hay, (u32)m, include_prefix, real, cls, form);
+        case 32: return run_unicode<32>(nd, hay, (u32)m, include_prefix, real, cls, form);
+        case 16: return run_unicode<16>(nd, hay, (u32)m, include_prefix, real, cls, form);
+        case 8: return run_unicode<8>(nd, hay, (u32)m, include_prefix, real, cls, form);
     }
     return -1;
 }

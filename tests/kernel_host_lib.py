@@ -36,7 +36,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.kh_dp_single.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
-        _lib.kh_dp_unicode.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.kh_dp_unicode.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_unicode_window.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_multi.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
@@ -56,14 +56,14 @@ def window(needle, hay, case_sensitive=False):
     return (out[0], out[1]), (out[2], out[3])
 
 
-def dp_unicode(rows, hay, scoring, include_prefix=True, swl=64, real=None):
+def dp_unicode(rows, hay, scoring, include_prefix=True, swl=64, real=None, form=0):
     """score of a single-chunk window by the unicode scorer; rows = [(scalar bytes[4], flipped bytes[4], utf8 length)] as the oracle's
     case_needle_unicode returns them (what fzb_matcher_create stores in NeedleDev::uc / uf / ulen)"""
     sc = (C.c_uint16 * 9)(*scoring)
     uc = b"".join(r[0] for r in rows)
     uf = b"".join(r[1] for r in rows)
     ul = bytes(r[2] for r in rows)
-    return lib().kh_dp_unicode(uc, uf, ul, len(rows), sc, hay, len(hay), int(include_prefix), swl, swl // 2 if real is None else real)
+    return lib().kh_dp_unicode(uc, uf, ul, len(rows), sc, hay, len(hay), int(include_prefix), swl, swl // 2 if real is None else real, form)
 
 
 def unicode_window(rows, hay):

@@ -226,9 +226,9 @@ def test_unicode_scorer_matches_the_oracle(swl):
     last row unpropagated, only the dwords that can hold a haystack byte computed) against score_haystack_unicode
     (src/smith_waterman/algo/unicode.rs:10-273) with propagate_horizontal_unicode_gaps (unicode_gap.rs:110-236)"""
     rng = random.Random(900 + swl)
-    alphabets = [list("abcAB_ -"), list("abéÉñÑüÜß/_ "), list("aب人äÄé_. 語"), list("إنماÉé_-ab")]
-    checked = 0
-    for it in range(700):
+    alphabets = [list("abcAB_ -"), list("abéÉñÑüÜß/_ "), list("aب人äÄé_. 語"), list("إنماÉé_-ab"), list("a😀é人_b")]
+    checked = checked_t = 0
+    for it in range(1200):
         alpha = rng.choice(alphabets)
         n = rng.randint(1, 6)
         needle = "".join(rng.choice(alpha) for _ in range(n))
@@ -251,6 +251,13 @@ def test_unicode_scorer_matches_the_oracle(swl):
                     hay = cand
         if not hay:
             continue
+        if it % 5 == 4:  # not UTF-8: runs of continuation bytes (the scorers work on bytes; the gap scan's UTF-8 shortcut must not be taken)
+            hb_ = bytearray(hay)
+            for _ in range(rng.randint(1, 3)):
+                q = rng.randrange(len(hb_))
+                for t in range(q, min(len(hb_), q + rng.randint(4, 9))):
+                    hb_[t] = rng.choice((0x80, 0x9F, 0xBF, 0xA9))
+            hay = bytes(hb_)
         ip = rng.random() < 0.5
         rows = O.case_needle_unicode(needle, cs)
         u8 = _fits(len(rows), sc)
@@ -260,7 +267,12 @@ def test_unicode_scorer_matches_the_oracle(swl):
             got = K.dp_unicode(rows, hay, sc, ip, swl, real)
             assert got == want, (needle, hay, sc, cs, ip, swl, real, got, want)
             checked += 1
-    assert checked > 700
+            if 2 * sc[3] <= sc[1]:  # the biased-throughout form's precondition (LaunchCfg::cfu_ok); small scorings fit 16 bits anyway
+                for form in (1, 2):  # 1 = with the UTF-8 shortcut where the window allows it (as the kernel chooses), 2 = general steps
+                    got_t = K.dp_unicode(rows, hay, sc, ip, swl, real, form=form)
+                    assert got_t == want, ("T form", form, needle, hay, sc, cs, ip, swl, real, got_t, want)
+                checked_t += 1
+    assert checked > 700 and checked_t > 400, (checked, checked_t)
 
 
 def test_unicode_window_equals_the_reference_prefilter_window():
