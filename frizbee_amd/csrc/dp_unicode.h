@@ -358,6 +358,8 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk_t(const NeedleDev& nd, co
         for (int d = 0; d < NR; d++) FZB_OPAQUE_V(Qp[d]);
 #pragma unroll
         for (int k = 0; k <= RB; k++) FZB_OPAQUE_V(hb[k]);
+#pragma unroll
+        for (int k = 0; k < RB; k++) FZB_OPAQUE_V(sflag[k]);  // (its lane masks are row-invariant: sixteen more registers if hoisted)
         u32 row[NR], pendg[NR];
 #pragma unroll
         for (int k = 0; k < RB; k++) {
