@@ -316,6 +316,11 @@ def main():
                os.path.abspath(__file__), *sys.argv[1:]]
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.execvpe(cmd[0], cmd, os.environ)
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio on fd 1 (seen after the JSON line when stdout is a
+    # file: it is flushed at exit), so the line gets its own duplicate of the original stdout and fd 1 itself is pointed at stderr.
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -574,10 +579,11 @@ def main():
                 bound = max(res["cpu_baseline"]["value"], res["cpu_baseline"]["linear_bound"]["haystacks_per_s"], res["cpu_baseline"]["published_bound"]["haystacks_per_s"])
                 res["gpu_over_cpu_bound"] = {"ratio": res["value"] / bound,
                                              "against": "the largest of: measured port, single-thread x physical cores, published per-thread x physical cores"}
-        print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), file=json_out, flush=True)
 
 
 if __name__ == "__main__":

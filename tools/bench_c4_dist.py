@@ -38,6 +38,7 @@ def main():
                os.path.abspath(__file__), *sys.argv[1:]]
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.execvpe(cmd[0], cmd, os.environ)
+    json_out = os.fdopen(os.dup(1), "w"); sys.stdout.flush(); os.dup2(2, 1)  # RCCL's banner (C stdio on fd 1) goes to stderr, the JSON line to the real stdout
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
     if args.gpus and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
@@ -126,9 +127,10 @@ def main():
                "e2e_ordered_list_on_rank0_ms": float(t[1]) * 1e3, "matches": total_matches, "merged_len": int(len(merged)),
                "checks": {"every_shard_head_equals_oracle_and_indices_in_range": all(int(v[0]) == 1 for v in allv), "merged_len_equals_sum_of_shard_counts": int(len(merged)) == total_matches,
                           "merged_order_is_score_desc_then_index_asc": ordered, "oracle_items_per_shard": c}}
-        print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier(); dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(res), file=json_out, flush=True)
 
 
 if __name__ == "__main__":
