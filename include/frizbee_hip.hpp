@@ -172,6 +172,34 @@ class Corpus {
     std::unique_ptr<fzb_corpus, Del> h_;
 };
 
+// The list cut into one contiguous shard per GPU (fzb_corpus_upload_sharded): the devices of a node in the role of
+// `match_list_parallel`'s worker threads (src/matcher/parallel.rs:18-89).  `gpus == 0`: every visible device.
+class ShardedCorpus {
+  public:
+    template <typename Strings>
+    explicit ShardedCorpus(const Strings& haystacks, int gpus = 0, bool by_bytes = false, bool oversubscribe = false) {
+        std::string bytes;
+        std::vector<uint64_t> ends;
+        for (const auto& h : haystacks) {
+            const std::string_view v(h);
+            bytes.append(v.data(), v.size());
+            ends.push_back(bytes.size());
+        }
+        if (gpus == 0) check(fzb_device_count(&gpus));
+        fzb_sharded_corpus* c = nullptr;
+        check(fzb_corpus_upload_sharded((const uint8_t*)bytes.data(), ends.data(), ends.size(), gpus,
+                                        (by_bytes ? FZB_SHARD_BY_BYTES : 0) | (oversubscribe ? FZB_SHARD_OVERSUBSCRIBE : 0), &c));
+        h_.reset(c);
+    }
+    size_t len() const { return fzb_sharded_corpus_len(h_.get()); }
+    int shards() const { return fzb_sharded_corpus_shards(h_.get()); }
+    const fzb_sharded_corpus* raw() const { return h_.get(); }
+
+  private:
+    struct Del { void operator()(fzb_sharded_corpus* c) const { fzb_sharded_corpus_free(c); } };
+    std::unique_ptr<fzb_sharded_corpus, Del> h_;
+};
+
 class Matcher {  // src/matcher/mod.rs:77-222
   public:
     // `Matcher::new(pattern, &config)`
@@ -281,6 +309,17 @@ class Matcher {  // src/matcher/mod.rs:77-222
     std::vector<Match> match_list_parallel(const Strings& haystacks, size_t threads) {
         if (threads == 0) throw Panic("threads must be positive");
         return match_list(Corpus(haystacks));
+    }
+
+    // `match_list_parallel` with one DEVICE per worker (fzb_match_list_parallel_sharded): per shard pipeline + device sort on its GPU,
+    // k-way merge of the runs on this thread; the same list `match_list` returns.  Single-pattern matchers (the multi-pattern
+    // composition has no sharded entry point yet).
+    std::vector<Match> match_list_parallel(const ShardedCorpus& corpus) {
+        if (!single_) throw Error(FZB_ERR_INVALID, "match_list_parallel over a sharded corpus needs a single-pattern matcher");
+        fzb_match* out = nullptr;
+        size_t n = 0;
+        check(fzb_match_list_parallel_sharded(single_.get(), corpus.raw(), &out, &n));
+        return take(out, n);
     }
 
   private:

@@ -198,6 +198,13 @@ static void gpu_side() {
         auto d = m.match_list(corpus);
         CHECK(d.size() == b.size() && std::is_sorted(d.begin(), d.end(), [](const Match& x, const Match& y) { return x.index > y.index; }));
         for (size_t t : {1, 2, 8}) CHECK(m.match_list_parallel(corpus, t) == d);
+        // match_list_parallel with one DEVICE per worker (parallel.rs:18-89): shards share the device when the box has fewer GPUs
+        for (int shards : {1, 3}) {
+            const ShardedCorpus sc(hs, shards, false, true);
+            CHECK(sc.len() == hs.size() && sc.shards() == shards && m.match_list_parallel(sc) == d);
+            Matcher byscore("deadbe");
+            CHECK(byscore.match_list_parallel(sc) == b);
+        }
     }
 }
 
