@@ -70,14 +70,20 @@ struct CorpusDev {
     int ends_u64;
     u32 max_len;       // longest haystack in bytes, 0 = unknown (lets the pipeline skip the multi-chunk scorer launch)
     u32 uniform_len;   // every haystack has exactly this many bytes (0 = not known): start(i) = i * roundup16(len), no end offsets read
-    // The streaming filter's view of a ragged list (fzb_corpus_upload builds it; nullptr otherwise): the same bytes with the haystacks of
-    // every 1024-haystack tile reordered by DESCENDING number of 16-byte vectors, in the same padded-16 convention (`fends` = exclusive
-    // ends in `fbytes`; a tile occupies the same byte range as in `bytes`), and fperm[g] = the position INSIDE ITS TILE the haystack at
-    // sorted position g came from.  The 64 lanes of a wave then run haystacks of one length class: no lookups for lanes whose haystack
-    // has ended (47 % of the ragged filter's lookups before).  Every other stage reads the canonical layout.
-    const u8* fbytes;
-    const u32* fends;
-    const u16* fperm;
+    // The streaming filter's VIEW of a ragged list (fzb_corpus_upload builds it for lists whose haystacks are 33..256 bytes; nullptr
+    // otherwise; every other stage reads the canonical layout).  What bounds the thread-per-haystack filter on such a list is the access
+    // pattern itself - 64 lanes x 16 bytes from 64 different lines per load instruction: 215 us for the 0.9 GB of the C4 shard with the
+    // automaton switched off (FZB_CDFA_NODFA=1) - so the view stores the bytes the way the lanes read them:
+    //   * every 1024-haystack tile sorted by DESCENDING number of 16-byte vectors (vperm[p] = position inside its tile the haystack at
+    //     sorted position p came from, vlen[p] = its length);
+    //   * every GROUP of 64 consecutive sorted haystacks (one wave's worth) interleaved by vector: vector v of the group's member j lives
+    //     at vbytes + 16 * vgofs[group] + 1024 * v + 16 * j, for v < vgnv[group] = the group's longest member (zero vectors behind a
+    //     shorter one) - so a wave's load of "vector v of my haystack" is ONE fully coalesced 1 KiB access, like a copy kernel's.
+    const u8* vbytes;
+    const u32* vgofs;  // per group: offset of its block in 16-byte units
+    const u8* vgnv;    // per group: vectors per member (<= 16)
+    const u16* vlen;   // per sorted haystack
+    const u16* vperm;  // per sorted haystack
 };
 
 struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between kernels (0 in final output)
@@ -125,6 +131,7 @@ struct Workspace {
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     u8* uni_dfa;        // unicode path, 0 typos: states x 256 table of the exact prefilter's byte-level DFA (device)
     u8* lcs_dfa;        // typo configurations: states x 256 table of the LCS automaton (device)
+    u8* cdfa;           // class-composite form of the matcher's streaming automaton: [256 byte -> class][states x K^G next state] (device)
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
     size_t cap_level2;  // capacity of the second-level arrays (0 = not allocated)
     bool tables_stale;  // the matcher's needle / config changed since `table` and `dfa` were uploaded
@@ -161,7 +168,8 @@ struct RejectOut {
 // kernels_filter.hip
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m = nullptr, u32* tile_counts_m = nullptr,
-                       u64* reject_bits = nullptr, u32* tile_rejects = nullptr, int nul_safe = 0, int acc_lo = -1);
+                       u64* reject_bits = nullptr, u32* tile_rejects = nullptr, int nul_safe = 0, int acc_lo = -1, const u8* cdfa = nullptr, u32 cdfa_bytes = 0,
+                       int cdfa_K = 0, int cdfa_G = 0);
 void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* reject_count, u32* rej_prefix, hipStream_t st);
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st);
 void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,

@@ -172,7 +172,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.fused_tile_counts, w.fused_group_counts, w.fused_stage};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa, w.fused_tile_counts, w.fused_group_counts, w.fused_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -442,6 +442,55 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
             m->lcs_acc_lo = acc;
         }
     }
+    // The class-composite form of the automaton the streaming filter runs (ragged lists: kernels_filter.hip, k1_cdfa_ragged): bytes with
+    // identical columns are one class (K of them), G transitions are composed into one table indexed by
+    // state * K^G + c0 + K c1 + ... (c0 = the class of the FIRST byte), G = 4 if states * K^4 <= 16 KB, else 2, else none.
+    m->cdfa.clear();
+    m->cdfa_src = m->cdfa_K = m->cdfa_G = 0;
+    {
+        const std::vector<u8>* fa = nullptr;
+        int fstates = 0, src = 0;
+        if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
+        else if (m->literal_mode) {}
+        else if (m->uni_dfa_states) { fa = &m->uni_dfa; fstates = m->uni_dfa_states; src = 2; }
+        else if (lc.filter_mode == 2 && m->lcs_states) { fa = &m->lcs_dfa; fstates = m->lcs_states; src = 3; }
+        else if (lc.filter_mode == 1) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
+        if (fa && fstates >= 1 && fstates <= 255) {
+            std::vector<int> cls(256, -1);
+            std::vector<int> rep;  // a representative byte per class
+            for (int b = 0; b < 256; b++) {
+                for (size_t q = 0; q < rep.size() && cls[b] < 0; q++) {
+                    bool same = true;
+                    for (int stt = 0; stt < fstates && same; stt++) same = (*fa)[(size_t)stt * 256 + b] == (*fa)[(size_t)stt * 256 + rep[q]];
+                    if (same) cls[b] = (int)q;
+                }
+                if (cls[b] < 0) { cls[b] = (int)rep.size(); rep.push_back(b); }
+            }
+            const size_t K = rep.size();
+            int G = 0;
+            if ((size_t)fstates * K * K * K * K <= 16384) G = 4;
+            else if ((size_t)fstates * K * K <= 16384) G = 2;
+            if (G) {
+                size_t KG = 1;
+                for (int i = 0; i < G; i++) KG *= K;
+                m->cdfa.assign(((256 + (size_t)fstates * KG) + 15) & ~(size_t)15, 0);
+                for (int b = 0; b < 256; b++) m->cdfa[b] = (u8)cls[b];
+                for (int stt = 0; stt < fstates; stt++)
+                    for (size_t off = 0; off < KG; off++) {
+                        int cur = stt;
+                        size_t rest = off;
+                        for (int i = 0; i < G; i++) {  // c0 (the least significant digit) is consumed first
+                            cur = (*fa)[(size_t)cur * 256 + rep[rest % K]];
+                            rest /= K;
+                        }
+                        m->cdfa[256 + (size_t)stt * KG + off] = (u8)cur;
+                    }
+                m->cdfa_src = src;
+                m->cdfa_K = (int)K;
+                m->cdfa_G = G;
+            }
+        }
+    }
     lc.pad_ok = 1;
     for (size_t i = 0; i < needle_len; i++)
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
@@ -596,7 +645,7 @@ void fzb_corpus_free(fzb_corpus* c) {
     if (!c) return;
     if (c->own_bytes) (void)hipFree(c->own_bytes);
     if (c->own_ends) (void)hipFree(c->own_ends);
-    for (void* q : {c->own_fbytes, c->own_fends, c->own_fperm})
+    for (void* q : c->own_view)
         if (q) (void)hipFree(q);
     delete c;
 }
@@ -646,6 +695,7 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
             if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
             if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
             if (!m->lcs_dfa.empty()) HIPCHK(hipMemcpy(w.lcs_dfa, m->lcs_dfa.data(), m->lcs_dfa.size(), hipMemcpyHostToDevice));
+            if (!m->cdfa.empty()) HIPCHK(hipMemcpy(w.cdfa, m->cdfa.data(), m->cdfa.size(), hipMemcpyHostToDevice));
             w.tables_stale = false;
         }
         return FZB_OK;
@@ -666,6 +716,8 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
     HIPCHK(dev_alloc((void**)&w.lcs_dfa, 256 * 256 + 16));  // room for any LCS automaton (<= 226 states): set_pattern re-uploads in place
     if (!m->lcs_dfa.empty()) HIPCHK(hipMemcpy(w.lcs_dfa, m->lcs_dfa.data(), m->lcs_dfa.size(), hipMemcpyHostToDevice));
+    HIPCHK(dev_alloc((void**)&w.cdfa, 256 + 16384 + 64));  // room for any class-composite automaton: set_pattern re-uploads in place
+    if (!m->cdfa.empty()) HIPCHK(hipMemcpy(w.cdfa, m->cdfa.data(), m->cdfa.size(), hipMemcpyHostToDevice));
     w.cap_items = cap;
     if (need_l2) {
         HIPCHK(dev_alloc((void**)&w.win, cap * 8));
@@ -915,7 +967,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
         u32* cnt_c = w.counters;
         if (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode && !items_in)  // the streaming DFA filter over the needle's KMP automaton
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr, nullptr, nullptr, lc.pad_ok);
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr, nullptr, nullptr, lc.pad_ok,
+                              -1, m->cdfa_src == 1 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         else
             fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
         FZB_STAGE("literal filter");
@@ -974,7 +1027,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         if (single_chunk && m->lcs_states)  // the LCS criterion as an automaton in the streaming DFA kernel
             fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
-                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo);
+                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         else if (single_chunk)
             fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
         else
@@ -1000,7 +1053,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // unicode path, 0 typos: the exact prefilter as a byte-level DFA in the streaming filter; the scorer finds the window itself
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         fzb_launch_filter(cd, first, cnt, w.table, w.uni_dfa, lc.dead_byte, m->uni_dfa_states - 1, 1, 0, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
-                          nullptr, nullptr, nullptr, lc.pad_ok);
+                          nullptr, nullptr, nullptr, lc.pad_ok, -1, m->cdfa_src == 2 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter(unicode dfa)");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
@@ -1028,10 +1081,10 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
             fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
-                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo);
+                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         else
             fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
-                              nullptr, nullptr, lc.pad_ok);
+                              nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
         static const int c1mul = getenv("FZB_COMPACT_GRID_MUL") ? atoi(getenv("FZB_COMPACT_GRID_MUL")) : 4;  // tuning knob (workgroups per CU)
@@ -1977,6 +2030,25 @@ int fzb_debug_lcs_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t
     u32 st = 0;
     for (size_t i = 0; i < len; i++) st = m->lcs_dfa[(size_t)st * 256 + bytes[i]];
     return st >= (u32)m->lcs_acc_lo ? 1 : 0;
+}
+
+// Test hook (host only): the class-composite form of the matcher's streaming automaton run over one haystack, G bytes per step (the
+// tail padded with a byte of the "matches nothing" class, as the kernel sees zero fill): 1 / 0 = accepts / rejects, -1 if the matcher has none.
+// out_kg (optional): [0] = K, [1] = G.
+int fzb_debug_cdfa_state(const fzb_matcher* m, const uint8_t* bytes, size_t len, int32_t* out_kg) {
+    if (out_kg) { out_kg[0] = m ? m->cdfa_K : 0; out_kg[1] = m ? m->cdfa_G : 0; }
+    if (!m || m->cdfa.empty() || (!bytes && len)) return -1;
+    const size_t K = (size_t)m->cdfa_K;
+    size_t KG = 1;
+    for (int i = 0; i < m->cdfa_G; i++) KG *= K;
+    u32 st = 0;
+    for (size_t i = 0; i < len; i += (size_t)m->cdfa_G) {
+        size_t off = 0, mul = 1;
+        for (int j = 0; j < m->cdfa_G; j++, mul *= K) off += mul * m->cdfa[i + j < len ? bytes[i + j] : (u8)m->lc.dead_byte];
+        st = m->cdfa[256 + (size_t)st * KG + off];
+    }
+    const u32 acc = m->cdfa_src == 1 ? (u32)m->rows : m->cdfa_src == 2 ? (u32)m->uni_dfa_states - 1 : (u32)m->lcs_acc_lo;
+    return st >= acc ? 1 : 0;
 }
 
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {

@@ -24,9 +24,7 @@ struct fzb_corpus {
     CorpusDev dev{};
     void* own_bytes = nullptr;
     void* own_ends = nullptr;
-    void* own_fbytes = nullptr;  // the filter's length-sorted view (CorpusDev::fbytes / fends / fperm)
-    void* own_fends = nullptr;
-    void* own_fperm = nullptr;
+    void* own_view[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the filter's view: vbytes, vgofs, vgnv, vlen, vperm (CorpusDev)
 };
 
 struct fzb_matcher {
@@ -45,6 +43,11 @@ struct fzb_matcher {
     // than 226): state 0 = nothing matched, states >= lcs_acc_lo accept (LCS >= rows - max_typos)
     std::vector<u8> lcs_dfa;
     int lcs_states = 0, lcs_acc_lo = 0;
+    // The matcher's streaming automaton (cdfa_src: 1 = `dfa` (subsequence / KMP), 2 = `uni_dfa`, 3 = `lcs_dfa`) with G transitions composed
+    // over its K byte classes: [256 bytes: byte -> class][states x K^G: next state], for the ragged filter (kernels_filter.hip,
+    // k1_cdfa_ragged).  Empty when states x K^G does not fit 16 KB even for G = 2.
+    std::vector<u8> cdfa;
+    int cdfa_src = 0, cdfa_K = 0, cdfa_G = 0;
     Workspace ws{};
     int device = -1;
     bool profiling = false;

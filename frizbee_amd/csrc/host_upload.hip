@@ -179,39 +179,34 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_build(const u8* __restrict__ 
     }
 }
 
-// The streaming filter's view of a ragged list (CorpusDev::fbytes): per 1024-haystack tile, the haystacks reordered by descending number
-// of 16-byte vectors.  A tile keeps its byte range (the padded sizes are the same set), so the view needs no global scan: one workgroup
-// per tile reads the canonical layout, ranks its haystacks (counting sort over the vector count, LDS atomics - upload time), scans the
-// padded lengths in the new order and copies the vectors.
-#define FV_CLASSES 66  // vector counts 0..64 and "more" (haystacks beyond 1024 bytes; their order inside the class is arbitrary)
-__global__ __launch_bounds__(UP_THREADS) void k_up_fview(const u8* __restrict__ bytes, const u32* __restrict__ ends, u64 n, u8* __restrict__ fbytes, u32* __restrict__ fends,
-                                                         u16* __restrict__ fperm) {
-    __shared__ u32 s_start[UP_TILE], s_len[UP_TILE], s_fstart[UP_TILE];
+// The streaming filter's VIEW of a ragged list (CorpusDev::vbytes; layout described there): two passes over the canonical layout, one
+// workgroup per 1024-haystack tile.
+//   k_up_view_sort   ranks the tile's haystacks by descending vector count (counting sort, LDS atomics - upload time), writes vperm / vlen,
+//                    the vectors-per-member of each of its 16 groups, and the tile's size in the view (in 16-byte units)
+//   (k_up_scan: exclusive scan of the tile sizes - the same kernel the canonical layout uses)
+//   k_up_view_fill   writes the groups' block offsets and copies every vector to its interleaved position (the buffer was cleared: the
+//                    zero vectors behind a group's shorter members are already there)
+#define FV_CLASSES 18  // vector counts 0..16 (haystacks up to 256 bytes) and a guard class
+__global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const u32* __restrict__ ends, u64 n, u16* __restrict__ vperm, u16* __restrict__ vlen, u8* __restrict__ vgnv,
+                                                             u64* __restrict__ tile_units) {
+    __shared__ u32 s_len[UP_TILE];
     __shared__ u16 s_inv[UP_TILE];
     __shared__ u32 s_hist[FV_CLASSES], s_base[FV_CLASSES];
-    __shared__ u32 s_wave[UP_THREADS / 64];
     const u64 i0 = (u64)blockIdx.x * UP_TILE;
     const u32 nt = (u32)min((u64)UP_TILE, n - i0);
-    const u32 tile_base = i0 ? (ends[i0 - 1] + 15u) & ~15u : 0u;
     const int tid = threadIdx.x;
     if (tid < FV_CLASSES) s_hist[tid] = 0;
-    u32 cls[4], rk[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const u32 j = tid + UP_THREADS * k;
-        if (j < nt) {
-            const u32 st = (i0 + j) ? (ends[i0 + j - 1] + 15u) & ~15u : 0u;
-            s_start[j] = st;
-            s_len[j] = ends[i0 + j] - st;
-        }
-    }
     __syncthreads();
+    u32 cls[4], rk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const u32 j = tid + UP_THREADS * k;
         cls[k] = rk[k] = 0;
         if (j < nt) {
-            cls[k] = min((s_len[j] + 15u) >> 4, (u32)FV_CLASSES - 1);
+            const u32 st = (i0 + j) ? (ends[i0 + j - 1] + 15u) & ~15u : 0u;
+            const u32 len = ends[i0 + j] - st;
+            s_len[j] = len;
+            cls[k] = min((len + 15u) >> 4, (u32)FV_CLASSES - 1);
             rk[k] = atomicAdd(&s_hist[cls[k]], 1u);
         }
     }
@@ -227,43 +222,52 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_fview(const u8* __restrict__ 
         if (j < nt) s_inv[s_base[cls[k]] + rk[k]] = (u16)j;
     }
     __syncthreads();
-    // padded starts in the new order: thread t owns sorted positions 4t .. 4t+3
-    u32 pl[4], mine = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const u32 g = 4 * tid + k;
-        pl[k] = g < nt ? (s_len[s_inv[g]] + 15u) & ~15u : 0u;
-        mine += pl[k];
-    }
-    u32 incl = mine;
-    for (int off = 1; off < 64; off <<= 1) {
-        const u32 t = __shfl_up(incl, off);
-        if ((tid & 63) >= off) incl += t;
-    }
-    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
-    __syncthreads();
-    u32 run = incl - mine;
-    for (int w = 0; w < (tid >> 6); w++) run += s_wave[w];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const u32 g = 4 * tid + k;
-        if (g < nt) {
-            s_fstart[g] = run;
-            const u32 j = s_inv[g];
-            fends[i0 + g] = tile_base + run + s_len[j];
-            fperm[i0 + g] = (u16)j;
+        const u32 p = tid + UP_THREADS * k;  // sorted position
+        if (p < nt) {
+            const u32 j = s_inv[p];
+            vperm[i0 + p] = (u16)j;
+            vlen[i0 + p] = (u16)s_len[j];
         }
-        run += pl[k];
+    }
+    if (tid < UP_TILE / 64) {  // the tile's 16 groups: vectors per member = the group's first (longest) member's count
+        const u32 p0 = tid * 64;
+        const u32 nv = p0 < nt ? (s_len[s_inv[p0]] + 15u) >> 4 : 0u;
+        vgnv[i0 / 64 + tid] = (u8)nv;
+        s_base[tid] = nv * 64;  // 16-byte units of the group's block (FV_CLASSES >= 16 entries)
     }
     __syncthreads();
-    // the bytes: sorted position g's vectors (zero fill included: the canonical layout has it), consecutive threads on consecutive vectors
-    // of one haystack where they can (a warp-wide loop over (position, vector) pairs would need a second search; this is upload time)
-    for (u32 g = tid >> 2; g < nt; g += UP_THREADS / 4) {
-        const u32 j = s_inv[g];
-        const uint4* src = (const uint4*)(bytes + s_start[j]);
-        uint4* dst = (uint4*)(fbytes + tile_base + s_fstart[g]);
-        const u32 nv = (s_len[j] + 15u) >> 4;
-        for (u32 v = tid & 3; v < nv; v += 4) dst[v] = src[v];
+    if (tid == 0) {
+        u64 t = 0;
+        for (int g = 0; g < UP_TILE / 64; g++) t += s_base[g];
+        tile_units[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restrict__ bytes, const u32* __restrict__ ends, u64 n, const u16* __restrict__ vperm,
+                                                             const u8* __restrict__ vgnv, const u64* __restrict__ tile_base_units, u8* __restrict__ vbytes, u32* __restrict__ vgofs) {
+    __shared__ u32 s_gofs[UP_TILE / 64];
+    const u64 i0 = (u64)blockIdx.x * UP_TILE;
+    const u32 nt = (u32)min((u64)UP_TILE, n - i0);
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        u64 run = tile_base_units[blockIdx.x];
+        for (int g = 0; g < UP_TILE / 64; g++) {
+            s_gofs[g] = (u32)run;
+            vgofs[i0 / 64 + g] = (u32)run;
+            run += (u64)vgnv[i0 / 64 + g] * 64;
+        }
+    }
+    __syncthreads();
+    // four threads per sorted haystack, each copying every fourth vector
+    for (u32 p = tid >> 2; p < nt; p += UP_THREADS / 4) {
+        const u64 j = i0 + vperm[i0 + p];
+        const u32 st = j ? (ends[j - 1] + 15u) & ~15u : 0u;
+        const u32 nv = (ends[j] - st + 15u) >> 4;
+        const uint4* src = (const uint4*)(bytes + st);
+        uint4* dst = (uint4*)(vbytes + (size_t)s_gofs[p >> 6] * 16 + (size_t)(p & 63) * 16);
+        for (u32 v = tid & 3; v < nv; v += 4) dst[(size_t)v * 64] = src[v];
     }
 }
 
@@ -445,21 +449,42 @@ int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, si
         else { if (adopt) FZB_UP_BUILD(u32, false); else FZB_UP_BUILD(u32, true); }
 #undef FZB_UP_BUILD
     }
-    // the streaming filter's length-sorted view: ragged lists with 32-bit offsets whose haystacks exceed the short-list kernels' 32 bytes
-    // OPT-IN (FZB_FILTER_VIEW=1; a second copy of the bytes): measured on the C4 shard it removes the 47 % of dead lookups and the
-    // filter gets no faster (236 -> 257 us with the burst form, 244 us with the pipelined one; profiles/r03_ragged_filter_variants.txt)
-    static const bool want_view = getenv("FZB_FILTER_VIEW") && atoi(getenv("FZB_FILTER_VIEW")) != 0;
-    if (want_view && n && !ends_u64 && !c->dev.uniform_len && c->dev.max_len > 32) {
-        e = fzb_dev_alloc(&c->own_fbytes, total);
-        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_fends, n * 4);
-        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_fperm, n * 2);
-        if (e == hipSuccess) e = hipMemsetAsync((u8*)c->own_fbytes + st.total_padded, 0, 96, nullptr);
-        if (e != hipSuccess) return bail(e, "filter view");
-        hipLaunchKernelGGL(k_up_fview, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u8*)c->own_bytes, (const u32*)c->own_ends, (u64)n, (u8*)c->own_fbytes,
-                           (u32*)c->own_fends, (u16*)c->own_fperm);
-        c->dev.fbytes = (const u8*)c->own_fbytes;
-        c->dev.fends = (const u32*)c->own_fends;
-        c->dev.fperm = (const u16*)c->own_fperm;
+    // the streaming filter's view (CorpusDev::vbytes): ragged lists with 32-bit offsets whose haystacks are 33..256 bytes.  A second copy of
+    // the bytes (+ ~5 % for the zero vectors behind shorter group members, + 4.2 bytes per haystack); FZB_FILTER_VIEW=0 turns it off.
+    static const bool want_view = !(getenv("FZB_FILTER_VIEW") && atoi(getenv("FZB_FILTER_VIEW")) == 0);
+    if (want_view && n && !ends_u64 && !c->dev.uniform_len && c->dev.max_len > 32 && c->dev.max_len <= 256) {
+        const size_t ngroups = (size_t)ntiles * (UP_TILE / 64);
+        u64* d_vt = nullptr;
+        e = fzb_dev_alloc(&c->own_view[3], n * 2);
+        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[4], n * 2);
+        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[2], ngroups);
+        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[1], ngroups * 4);
+        if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_vt, (size_t)ntiles * 8);
+        if (e != hipSuccess) { if (d_vt) (void)hipFree(d_vt); return bail(e, "filter view"); }
+        hipLaunchKernelGGL(k_up_view_sort, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u32*)c->own_ends, (u64)n, (u16*)c->own_view[4], (u16*)c->own_view[3],
+                           (u8*)c->own_view[2], d_vt);
+        hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, nullptr, d_vt, ntiles, d_stats);  // (reuses the stats block: total_padded = the view's size in units)
+        UpStats vst{0, 0, 0, 0};
+        e = hipMemcpy(&vst, d_stats, sizeof(vst), hipMemcpyDeviceToHost);
+        const u64 view_bytes = vst.total_padded * 16;
+        if (e == hipSuccess && view_bytes / 16 > 0xFFFFFFF0ull) {  // group offsets are 32-bit units: no view beyond 64 GB
+            (void)hipFree(d_vt);
+            for (int q = 1; q < 5; q++) { (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
+        } else {
+            if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[0], view_bytes + 1024);
+            if (e == hipSuccess) e = hipMemsetAsync(c->own_view[0], 0, view_bytes + 1024, nullptr);
+            if (e != hipSuccess) { (void)hipFree(d_vt); return bail(e, "filter view"); }
+            hipLaunchKernelGGL(k_up_view_fill, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u8*)c->own_bytes, (const u32*)c->own_ends, (u64)n, (const u16*)c->own_view[4],
+                               (const u8*)c->own_view[2], (const u64*)d_vt, (u8*)c->own_view[0], (u32*)c->own_view[1]);
+            e = hipDeviceSynchronize();
+            (void)hipFree(d_vt);
+            if (e != hipSuccess) return bail(e, "filter view");
+            c->dev.vbytes = (const u8*)c->own_view[0];
+            c->dev.vgofs = (const u32*)c->own_view[1];
+            c->dev.vgnv = (const u8*)c->own_view[2];
+            c->dev.vlen = (const u16*)c->own_view[3];
+            c->dev.vperm = (const u16*)c->own_view[4];
+        }
     }
     e = hipDeviceSynchronize();  // the temporaries are released below; the corpus is complete when the call returns
     if (e == hipSuccess) e = hipGetLastError();

@@ -433,6 +433,197 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// K1-DFA for ragged lists over the CLASS-COMPOSITE automaton (round 3).  The four structural variants below left the burst form's time
+// where it was, which pointed at the one thing they share: every wave is a serial chain of one dependent LDS lookup PER BYTE (~100 cycles
+// each under load), and with all eight wave slots of a SIMD taken the throughput is waves / chain latency.  Here the chain has one link
+// per G bytes: the automaton only distinguishes K byte CLASSES (bytes with identical columns: the needle's letters in either case, and
+// "anything else" - 6 for `deadbeef`), so the host composes G transitions into one table, next = comp[state][c0 + K c1 + K^2 c2 + K^3 c3]
+// (states x K^G bytes; G = 4 when that fits 16 KB, else 2).  Per dword: four class lookups cls[byte] that do NOT depend on the state (issued
+// back to back for the whole 16-byte vector, off the chain), three multiply-adds for the offset, and ONE dependent lookup.
+// LDS: [0, 256) byte -> class, [256, 256 + states * K^G) the composite table; lookups address LDS directly (the object starts at 0).
+// ---------------------------------------------------------------------------------------------------
+template <typename ET, bool SAN, int G>
+__global__ __launch_bounds__(256) void k1_cdfa_ragged(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
+                                                      const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG, u32 min_len, u32 dead, u32 acc_lo,
+                                                      u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    const u32 tab_bytes = (cdfa_bytes + 15u) & ~15u;
+    u32& s_cnt = *(u32*)(lds + tab_bytes);
+    const int tid = threadIdx.x;
+    dfa_require_lds_base0(lds);
+    for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;  // (the blob is padded to 16 bytes)
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    const u32 deadv = dead * 0x01010101u;
+    auto cls_of = [](u32 b) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)b; };
+    auto comp_at = [](u32 a) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)(256u + a); };
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        u32 cnt = 0;
+#pragma unroll 1
+        for (int sub = 0; sub < 4; sub++) {
+            const u32 li = tile * FZB_TILE + sub * 256 + tid;
+            u64 hs = 0;
+            u32 hl = 0;
+            if (li < count) haystack_span(ends, first + li, hs, hl);
+            const uint4* vp = (const uint4*)(bytes + hs);
+            u32 st = 0;
+            for (u32 v0 = 0; 16 * v0 < hl; v0 += 8) {  // rounds of 8 vectors (one round for haystacks up to 128 bytes)
+                uint4 q[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) q[k] = hl > 16 * (v0 + k) ? vp[v0 + k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (hl <= 16 * (v0 + k)) break;
+                    u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+                    if (SAN) {
+                        const u32 rem = hl - 16 * (v0 + k);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
+                            const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
+                            w[j] = (w[j] & mask) | (deadv & ~mask);
+                        }
+                    }
+                    if (K == 0xFFFFu) {  // measurement knob (FZB_CDFA_NODFA=1, results meaningless): the loads alone
+                        st ^= w[0] ^ w[1] ^ w[2] ^ w[3];
+                        continue;
+                    }
+                    // the vector's sixteen class lookups: independent of the state
+                    u32 c[4][4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        c[j][0] = cls_of(w[j] & 0xFF);
+                        c[j][1] = cls_of((w[j] >> 8) & 0xFF);
+                        c[j][2] = cls_of((w[j] >> 16) & 0xFF);
+                        c[j][3] = cls_of(w[j] >> 24);
+                    }
+                    if (G == 4) {
+                        u32 off[4];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) off[j] = c[j][0] + K * (c[j][1] + K * (c[j][2] + K * c[j][3]));
+#pragma unroll
+                        for (int j = 0; j < 4; j++) st = comp_at(st * KG + off[j]);  // the chain: one dependent lookup per dword
+                    } else {
+                        u32 off[8];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) off[2 * j] = c[j][0] + K * c[j][1], off[2 * j + 1] = c[j][2] + K * c[j][3];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);  // one dependent lookup per byte pair
+                    }
+                }
+            }
+            const bool matched = li < count && hl >= min_len && st >= acc_lo;
+            const u64 b = __ballot(matched);
+            if (lane_id() == 0) {
+                bitmap[(tile * FZB_TILE + sub * 256) / 64 + (tid >> 6)] = b;
+                cnt += __popcll(b);
+            }
+        }
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The class-composite automaton over the corpus' filter VIEW (CorpusDev::vbytes: tiles sorted by vector count, groups of 64 interleaved by
+// vector).  One wave per group: "vector v of my haystack" is ONE coalesced 1 KiB load for the whole wave, every lane of the wave has the
+// same number of vectors, and all of a group's loads are issued back to back.  The decision bit goes to the haystack's ORIGINAL position
+// in its tile (vperm) through an LDS atomic-or, so the bitmap, the per-tile counts and every later stage see nothing of the view.
+// NV = vectors held in registers per haystack (8: lists up to 128 bytes, 16: up to 256).
+// ---------------------------------------------------------------------------------------------------
+template <bool SAN, int G, int NV>
+__global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
+                                                    const u16* __restrict__ vperm, u64 first, u32 count, const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG,
+                                                    u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    const u32 tab_bytes = (cdfa_bytes + 15u) & ~15u;
+    u32& s_cnt = *(u32*)(lds + tab_bytes);
+    u32* const s_bits = (u32*)(lds + tab_bytes + 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    dfa_require_lds_base0(lds);
+    for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
+    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    const u32 deadv = dead * 0x01010101u;
+    auto cls_of = [](u32 b) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)b; };
+    auto comp_at = [](u32 a) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)(256u + a); };
+    const u64 g_first = first / 64;  // `first` is a multiple of the tile size
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        if (tid < 32) s_bits[tid] = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int gi = 0; gi < 4; gi++) {
+            const u32 p = tile * FZB_TILE + (u32)(gi * 4 + wave) * 64 + lane;  // sorted position (relative to `first`)
+            const u32 gl = tile * (FZB_TILE / 64) + (u32)(gi * 4 + wave);       // its group
+            if (gl * 64 >= count) continue;
+            const u32 nv = __builtin_amdgcn_readfirstlane((u32)vgnv[g_first + gl]);
+            const u8* base = vbytes + (size_t)__builtin_amdgcn_readfirstlane(vgofs[g_first + gl]) * 16 + (u32)lane * 16;
+            u32 hl = 0, orig = 0;
+            if (p < count) { hl = vlen[first + p]; orig = vperm[first + p]; }
+            uint4 q[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) q[k] = (u32)k < nv ? *(const uint4*)(base + (size_t)k * 1024) : make_uint4(0, 0, 0, 0);
+            u32 st = 0;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if ((u32)k >= nv) continue;  // wave-uniform
+                u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+                if (K == 0xFFFFu) {  // measurement knob (FZB_CDFA_NODFA=1, results meaningless): the loads alone
+                    st ^= w[0] ^ w[1] ^ w[2] ^ w[3];
+                    continue;
+                }
+                if (SAN) {
+                    const u32 rem = hl > 16u * k ? hl - 16u * k : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
+                        const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
+                        w[j] = (w[j] & mask) | (deadv & ~mask);
+                    }
+                }
+                u32 c[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    c[j][0] = cls_of(w[j] & 0xFF);
+                    c[j][1] = cls_of((w[j] >> 8) & 0xFF);
+                    c[j][2] = cls_of((w[j] >> 16) & 0xFF);
+                    c[j][3] = cls_of(w[j] >> 24);
+                }
+                if (G == 4) {
+                    u32 off[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) off[j] = c[j][0] + K * (c[j][1] + K * (c[j][2] + K * c[j][3]));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) st = comp_at(st * KG + off[j]);
+                } else {
+                    u32 off[8];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) off[2 * j] = c[j][0] + K * c[j][1], off[2 * j + 1] = c[j][2] + K * c[j][3];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);
+                }
+            }
+            if (p < count && hl >= min_len && st >= acc_lo) atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
+        }
+        __syncthreads();
+        if (tid < FZB_TILE / 64) {
+            const u64 word = (u64)s_bits[2 * tid] | ((u64)s_bits[2 * tid + 1] << 32);
+            bitmap[(size_t)tile * (FZB_TILE / 64) + tid] = word;
+            const u32 cnt = (u32)__popcll(word);
+            if (cnt) atomicAdd(&s_cnt, cnt);
+        }
+        __syncthreads();
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K1-DFA for ragged lists, software-pipelined burst form (round 3).  Measured: neither removing the dead lookups (length-sorted view),
 // nor making every load fully coalesced (cooperative form below), nor staging in LDS moves the burst form's ~235 us - every wave runs
 // span loads -> vector loads -> a serial chain of DFA lookups one after the other, all eight wave slots of a SIMD are taken, and the
@@ -1182,7 +1373,7 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // ---------------------------------------------------------------------------------------------------
 void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe,
-                       int acc_lo) {
+                       int acc_lo, const u8* cdfa, u32 cdfa_bytes, int cdfa_K, int cdfa_G) {
     // mode 1: `dfa` has rows + 1 states, start state 0, and accepts in the states >= acc (the subsequence / unicode / KMP automata: the last
     // state; the LCS automaton of a typo configuration: every state whose LCS reaches the need)
     const u32 acc = acc_lo < 0 ? (u32)rows : (u32)acc_lo;
@@ -1203,6 +1394,42 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             // 128-byte lines instead of ~34 adjacent ones, and the kernel is bound by cache transactions, not by instruction issue.
             int rgrid = std::min<int>((grid / 8) * 6, (int)ntiles);
             if (rgrid < 1) rgrid = 1;
+            // the class-composite automaton of `dfa` (host-built: fzb_matcher_create): one dependent lookup per 4 (or 2) bytes
+            static const bool no_cdfa = getenv("FZB_NO_CDFA") != nullptr;
+            static const int cwg = getenv("FZB_CDFA_WGS") ? atoi(getenv("FZB_CDFA_WGS")) : 5;  // resident workgroups per CU (C4 shard: 8 -> 247 us, 5 -> 232, 4 -> 229)
+            static const bool no_view = getenv("FZB_FILTER_VIEW") && atoi(getenv("FZB_FILTER_VIEW")) == 0;
+            static const int vwg = getenv("FZB_VIEW_WGS") ? atoi(getenv("FZB_VIEW_WGS")) : 6;  // (C4 shard: 8 -> 190 us, 6 -> 187, 4 -> 194)
+            if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2) && c.vbytes && !no_view && first % FZB_TILE == 0 && (first + count == c.n || count % FZB_TILE == 0) &&
+                c.max_len <= 256) {
+                const size_t lds_v = ((cdfa_bytes + 15) & ~(size_t)15) + 16 + 128;
+                const int g = std::max(1, std::min<int>((grid / 8) * vwg, (int)ntiles));
+                u32 kg = 1;
+                for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
+                if (getenv("FZB_CDFA_NODFA")) cdfa_K = 0xFFFF;
+#define FZB_K1V(SAN, G, NV) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
+#define FZB_K1V_NV(SAN, G) do { if (c.max_len <= 128) FZB_K1V(SAN, G, 8); else FZB_K1V(SAN, G, 16); } while (0)
+#define FZB_K1V_G(SAN) do { if (cdfa_G == 4) FZB_K1V_NV(SAN, 4); else FZB_K1V_NV(SAN, 2); } while (0)
+                if (nul_safe) FZB_K1V_G(false); else FZB_K1V_G(true);
+#undef FZB_K1V_G
+#undef FZB_K1V_NV
+#undef FZB_K1V
+                return;
+            }
+            if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2)) {
+                const size_t lds_c = ((cdfa_bytes + 15) & ~(size_t)15) + 16;
+                const int g = std::max(1, std::min<int>((grid / 8) * cwg, (int)ntiles));
+                u32 kg = 1;
+                for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
+                static const bool nodfa = getenv("FZB_CDFA_NODFA") != nullptr;
+                if (nodfa) cdfa_K = 0xFFFF;
+#define FZB_K1CD(ET, SAN, G) hipLaunchKernelGGL((k1_cdfa_ragged<ET, SAN, G>), dim3(g), dim3(256), lds_c, st, c.bytes, (const ET*)c.ends, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
+#define FZB_K1CD_G(ET, SAN) do { if (cdfa_G == 4) FZB_K1CD(ET, SAN, 4); else FZB_K1CD(ET, SAN, 2); } while (0)
+                if (c.ends_u64) { if (nul_safe) FZB_K1CD_G(u64, false); else FZB_K1CD_G(u64, true); }
+                else            { if (nul_safe) FZB_K1CD_G(u32, false); else FZB_K1CD_G(u32, true); }
+#undef FZB_K1CD_G
+#undef FZB_K1CD
+                return;
+            }
             static const int burst = getenv("FZB_RAGGED_BURST") ? atoi(getenv("FZB_RAGGED_BURST")) : 1;  // 0 = the rolling form, for comparison
             static const int bwgs = getenv("FZB_RAGGED_WGS") ? atoi(getenv("FZB_RAGGED_WGS")) : 8;
             // LDS-staged, length-sorted form (k1_dfa_ragged_lds), OPT-IN (FZB_RAGGED_LDS=1): measured 0.53-0.99 ms against the burst form's
@@ -1223,8 +1450,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 return;
             }
             // the corpus' length-sorted filter view (built by fzb_corpus_upload for ragged lists): whole tiles only
-            static const bool no_view = !(getenv("FZB_FILTER_VIEW") && atoi(getenv("FZB_FILTER_VIEW")) != 0);  // opt-in (the upload builds the view under the same knob)
-            const bool view = burst && c.fbytes && !no_view && !c.ends_u64 && first % FZB_TILE == 0 && (first + count == c.n || count % FZB_TILE == 0);
+            const bool view = false;  // (round 3's first, non-interleaved sorted view is gone: its measurements are in profiles/r03_ragged_filter_variants.txt)
             // software-pipelined burst form (three haystacks in flight per thread)
             static const int pipe = getenv("FZB_RAGGED_PIPE") ? atoi(getenv("FZB_RAGGED_PIPE")) : 0;  // opt-in: measured 244-253 us vs the burst form's 234 us (profiles/r03_ragged_filter_variants.txt)
             static const int pwgs = getenv("FZB_RAGGED_PIPE_WGS") ? atoi(getenv("FZB_RAGGED_PIPE_WGS")) : 5;
@@ -1232,7 +1458,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 const int g = std::max(1, std::min<int>((grid / 8) * pwgs, (int)ntiles));
                 const size_t lds_p = lds + 16 + 32 * 4;
 #define FZB_K1P(ET, SAN, PERM, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_pipe<ET, SAN, PERM>), dim3(g), dim3(256), lds_p, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, P)
-                if (view) { if (nul_safe) FZB_K1P(u32, false, true, c.fbytes, c.fends, c.fperm); else FZB_K1P(u32, true, true, c.fbytes, c.fends, c.fperm); }
+                if (view) { if (nul_safe) FZB_K1P(u32, false, true, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u32, true, true, c.bytes, c.ends, (const u16*)nullptr); }
                 else if (c.ends_u64) { if (nul_safe) FZB_K1P(u64, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u64, true, false, c.bytes, c.ends, (const u16*)nullptr); }
                 else { if (nul_safe) FZB_K1P(u32, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u32, true, false, c.bytes, c.ends, (const u16*)nullptr); }
 #undef FZB_K1P
@@ -1248,7 +1474,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #define FZB_K1C(ET, SAN, PERM, NV, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_coop<ET, SAN, PERM, NV>), dim3(g), dim3(256), lds_c, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, P)
 #define FZB_K1C_NV(ET, SAN, PERM, B, E, P) do { if (nv8) FZB_K1C(ET, SAN, PERM, 8, B, E, P); else FZB_K1C(ET, SAN, PERM, 16, B, E, P); } while (0)
                 if (lds_c <= 64 * 1024) {
-                    if (view) { if (nul_safe) FZB_K1C_NV(u32, false, true, c.fbytes, c.fends, c.fperm); else FZB_K1C_NV(u32, true, true, c.fbytes, c.fends, c.fperm); }
+                    if (view) { if (nul_safe) FZB_K1C_NV(u32, false, true, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1C_NV(u32, true, true, c.bytes, c.ends, (const u16*)nullptr); }
                     else if (c.ends_u64) { if (nul_safe) FZB_K1C_NV(u64, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1C_NV(u64, true, false, c.bytes, c.ends, (const u16*)nullptr); }
                     else { if (nul_safe) FZB_K1C_NV(u32, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1C_NV(u32, true, false, c.bytes, c.ends, (const u16*)nullptr); }
                     return;
@@ -1259,8 +1485,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             if (view) {
                 rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
                 const size_t lds_p = lds + 16 + 32 * 4;
-                if (nul_safe) hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, false, true>), dim3(rgrid), dim3(256), lds_p, st, c.fbytes, c.fends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.fperm);
-                else hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, true, true>), dim3(rgrid), dim3(256), lds_p, st, c.fbytes, c.fends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.fperm);
+                if (nul_safe) hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, false, true>), dim3(rgrid), dim3(256), lds_p, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, (const u16*)nullptr);
                 return;
             }
             if (burst) {

@@ -285,6 +285,10 @@ int fzb_debug_unicode_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, si
  * prefilter, more than 226 states); *out_states (optional) = its number of states */
 int fzb_debug_lcs_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t len, int32_t* out_states);
 
+/* test hook, host only: the class-composite form of the matcher's streaming automaton (G byte transitions composed over the K byte
+ * classes; the ragged filter's table) run over one haystack: 1 / 0 = accepts / rejects, -1 if the matcher has none; out_kg[0] = K, [1] = G */
+int fzb_debug_cdfa_state(const fzb_matcher* m, const uint8_t* bytes, size_t len, int32_t* out_kg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,3 +291,40 @@ def test_lcs_automaton_is_the_lcs_criterion():
     assert F.lib().fzb_debug_lcs_dfa_accepts(F.Matcher("deadbe").h, b"x", 1, None) == -1
     assert F.lib().fzb_debug_lcs_dfa_accepts(F.Matcher("deadbe", F.Config(max_typos=None)).h, b"x", 1, None) == -1
     assert F.lib().fzb_debug_lcs_dfa_accepts(F.Matcher("abcdefghijklmnopqrstuvwxyz012345", F.Config(max_typos=3)).h, b"x", 1, None) == -1
+
+
+def test_class_composite_automaton_equals_the_byte_automaton():
+    # the ragged filter's table (G byte transitions composed over the K byte classes, fzb_matcher_create) must decide exactly like the
+    # byte-level automaton it was built from: ordered subsequence (0 typos), the LCS criterion (typos), the unicode prefilter, KMP (substring)
+    import ctypes as C
+
+    def subseq(n, h):
+        it = iter(h)
+        return all(c in it for c in n)
+
+    rng = np.random.default_rng(21)
+    kg = (C.c_int32 * 2)()
+    seen = []
+    for needle, cfg in (("deadbeef", dict()), ("linux", dict()), ("a", dict()), ("x_Y-z", dict()), ("deadbe", dict(max_typos=2)), ("abcabc", dict(max_typos=1)),
+                        ("إنما", dict()), ("éa", dict()), ("dea", dict(matching=F.Matching.Substring)), ("abcdefghijklmnop", dict())):
+        m = F.Matcher(needle, F.Config(**cfg))
+        info = m.info()
+        alpha = (needle + needle.upper() + needle.lower() + "q_ 0é").encode()
+        for _ in range(600):
+            h = bytes(alpha[int(x)] for x in rng.integers(0, len(alpha), int(rng.integers(0, 45))))
+            got = F.lib().fzb_debug_cdfa_state(m.h, h, len(h), kg)
+            if got < 0:
+                break
+            if cfg.get("max_typos"):
+                want = F.lib().fzb_debug_lcs_dfa_accepts(m.h, h, len(h), None)
+            elif info["unicode"]:
+                want = F.lib().fzb_debug_unicode_dfa_accepts(m.h, h, len(h))
+            elif cfg.get("matching"):
+                want = int(needle.lower().encode() in h.lower()) if not info["case_sensitive"] else int(needle.encode() in h)
+            else:
+                hh, nn = (h, needle.encode()) if info["case_sensitive"] else (h.lower(), needle.lower().encode())
+                want = int(subseq(nn, hh))
+            assert got == want, (needle, cfg, h, got, want)
+        seen.append((needle, kg[0], kg[1]))
+    print("class-composite automata (needle, K, G):", seen)
+    assert sum(1 for _, k, g in seen if g == 4) >= 3 and sum(1 for _, k, g in seen if g == 2) >= 1
