@@ -119,7 +119,7 @@ struct Workspace {
     u32* rej_prefix;
     size_t cap_marg;    // capacity (in haystacks) of the six arrays above (0 = not allocated)
     u32* cls_win;       // classified scoring (corpora with longer haystacks): window per survivor, three class lists
-    u32* cls_lists;     //   [3][cap]; class counts in counters[8..10]
+    u32* cls_lists;     //   [7][cap]; class counts in counters[8..10], multi-chunk tail classes in counters[12..15]
     size_t cap_cls;
     u16* fused_tile_counts;      // k12_fused: survivors per 256-haystack tile, per group of 4 tiles (zero between launches), and the
     u32* fused_group_counts;     //   staging array (256 record slots per tile) that k_fused_gather packs
@@ -189,7 +189,9 @@ void fzb_launch_fused(const CorpusDev& c, u64 first, u32 count, u32 index_offset
 bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
-                           int num_cus, hipStream_t st, int part = 0);
+                           int num_cus, hipStream_t st, int part = 0, int split_multi = 0);
+void fzb_launch_dp_multi_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* lists, u32 list_stride, const u32* counts,
+                                 const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int mode,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_unicode.hip

@@ -738,7 +738,7 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     }
     if (need_cls) {
         HIPCHK(dev_alloc((void**)&w.cls_win, cap * 8));
-        HIPCHK(dev_alloc((void**)&w.cls_lists, cap * 12));
+        HIPCHK(dev_alloc((void**)&w.cls_lists, cap * 28));  // 3 single-chunk classes + 4 multi-chunk tail classes
         w.cap_cls = cap;
     }
     return FZB_OK;
@@ -1144,6 +1144,10 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // The class launches and the multi-chunk scorer both start from k2w_classify's lists and write disjoint records, and each is a persistent
         // grid whose last round leaves most of the chip idle (the multi-chunk scorer's third round is 4 % full on the C4 shard): the multi-chunk
         // scorer runs on a second stream, forked after the classifier and joined before the caller's stream continues.
+        // multi-chunk windows by the width of their last chunk's tail (k2w_classify's lists 3-6 -> k2d_dp_multi_tc): needs the classifier, dp_cfm.h's
+        // form and a needle without NUL (cf_ok includes pad_ok)
+        static const bool no_tail_classes = getenv("FZB_NO_TAIL_CLASSES") != nullptr;  // comparison knob: every last chunk computed in full
+        const int split = classes && !no_wide && mmode == 2 && !no_tail_classes;
         bool fork = classes && !no_wide && !no_overlap;
         if (fork && ensure_aux_stream(m) != FZB_OK) {  // no second stream: everything on the caller's stream (the error text is dropped with the fallback)
             fork = false;
@@ -1151,14 +1155,15 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         }
         if (classes)
             fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                                  (u32)w.cap_cls, cus, st, fork ? 1 : 0);
+                                  (u32)w.cap_cls, cus, st, fork ? 1 : 0, split);
         else
             fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
         if (fork) {
             HIPCHK(hipEventRecord(m->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
-            fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, m->aux_stream);
+            if (split) fzb_launch_dp_multi_classes(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, &cnt_c[12], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, m->aux_stream);
+            else fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, m->aux_stream);
             HIPCHK(hipEventRecord(m->ev_join, m->aux_stream));
             fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
                                   (u32)w.cap_cls, cus, st, 2);
@@ -1167,7 +1172,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         }
         if (!no_wide) {
             if (!fork) {
-                fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, st);
+                if (split) fzb_launch_dp_multi_classes(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, &cnt_c[12], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, st);
+                else fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, st);
                 FZB_STAGE("dp_multi");
             }
             if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
@@ -2054,12 +2060,12 @@ int fzb_debug_cdfa_state(const fzb_matcher* m, const uint8_t* bytes, size_t len,
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {
     if (!m || !out) return fail(FZB_ERR_INVALID, "null argument");
     if (m->ws.counters) {
-        u32 all[8];
+        u32 all[16];
         HIPCHK(hipMemcpy(all, m->ws.counters, sizeof(all), hipMemcpyDeviceToHost));
         m->last_counters[0] = all[0];
         m->last_counters[1] = all[1];
         m->last_counters[2] = all[4];
-        m->last_counters[3] = all[3];
+        m->last_counters[3] = all[3] + all[12] + all[13] + all[14] + all[15];  // multi-chunk windows: the queue, or the four tail-class lists
     }
     memcpy(out, m->last_counters, 16);
     return FZB_OK;

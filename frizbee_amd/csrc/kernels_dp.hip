@@ -290,21 +290,23 @@ template <typename ET, int PER>
 __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ items,
                                                     const u32* __restrict__ win_in, const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, u32 swl,
                                                     u32* __restrict__ win_out, u32* __restrict__ lists, u32 list_stride, u32* __restrict__ overflow, u32 qcap,
-                                                    u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count) {
-    __shared__ u32 s_cnt[5], s_base[5];
+                                                    u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count, u32 split_multi) {
+    // classes: 0-2 single chunk, 3 multi-chunk (queue), 4 greedy (queue, from the back), 5-8 multi-chunk by the width of the LAST chunk's
+    // tail (split_multi: lists 3-6, counts in counters[12..15]; k2d_dp_multi_tc computes only that many lanes of the last chunk)
+    __shared__ u32 s_cnt[9], s_base[9];
     const u32 M = __builtin_amdgcn_readfirstlane(*n_items_ptr);
     if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = M < capacity ? M : capacity; dev_count[1] = M; }  // [1] = the untruncated total
     // a workgroup takes 256 * PER survivors at a time (PER per thread) and appends its members of a class with ONE global atomic per class
     // and tile: atomics that return a value to the same address serialise in L2 (one per 256 survivors cost ~40 us on the 0.6 M
     // survivors of the ragged list)
     for (u32 j0 = blockIdx.x * (256 * PER); j0 < M; j0 += gridDim.x * (256 * PER)) {  // uniform trip count per workgroup
-        if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+        if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
         __syncthreads();
         u32 cls[PER], rank[PER], li[PER], ws[PER], we[PER];
 #pragma unroll
         for (int p = 0; p < PER; p++) {
             const u32 j = j0 + p * 256 + threadIdx.x;
-            cls[p] = 5; rank[p] = 0; li[p] = 0; ws[p] = 0; we[p] = 0;
+            cls[p] = 9; rank[p] = 0; li[p] = 0; ws[p] = 0; we[p] = 0;
             if (j < M && j < capacity) {
                 li[p] = items ? items[j] : j;
                 u64 s;
@@ -316,20 +318,22 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
                 const u32 sp = ws[p] ? ws[p] - 1 : 0;
                 const u32 m = we[p] - sp;
                 cls[p] = m <= swl / 2 ? 0u : m <= 3 * swl / 4 ? 1u : m <= swl ? 2u : m <= FZB_MAX_HAYSTACK_LEN ? 3u : 4u;
+                if (split_multi && cls[p] == 3) cls[p] = 5 + ((m - 1) % swl) / (swl / 4);  // tail of 1 ..= swl bytes -> 0 ..= 3
                 rank[p] = atomicAdd(&s_cnt[cls[p]], 1u);
             }
         }
         __syncthreads();
-        if (threadIdx.x < 5 && s_cnt[threadIdx.x]) {
+        if (threadIdx.x < 9 && s_cnt[threadIdx.x]) {
             const u32 c = threadIdx.x;
-            s_base[c] = atomicAdd(c < 3 ? &counters[8 + c] : c == 3 ? &counters[3] : &counters[4], s_cnt[c]);
+            s_base[c] = atomicAdd(c < 3 ? &counters[8 + c] : c == 3 ? &counters[3] : c == 4 ? &counters[4] : &counters[12 + (c - 5)], s_cnt[c]);
         }
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < PER; p++) {
             const u32 j = j0 + p * 256 + threadIdx.x;
-            if (cls[p] < 3) {
-                lists[(size_t)cls[p] * list_stride + s_base[cls[p]] + rank[p]] = j;
+            if (cls[p] < 3 || (cls[p] >= 5 && cls[p] < 9)) {
+                const u32 l = cls[p] < 3 ? cls[p] : cls[p] - 2;
+                lists[(size_t)l * list_stride + s_base[cls[p]] + rank[p]] = j;
                 *(uint2*)(win_out + 2 * (size_t)j) = make_uint2(ws[p], we[p]);
             } else if (cls[p] < 5) {
                 const u32 slot = s_base[cls[p]] + rank[p];
@@ -428,14 +432,14 @@ __global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3
 
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
-                           int num_cus, hipStream_t st, int part) {
+                           int num_cus, hipStream_t st, int part, int split_multi) {
     // part: 0 = classify + the three class launches, 1 = classify only, 2 = the class launches only (host.hip runs the multi-chunk scorer on a
     // second stream between the two)
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     if (part == 2) {
-    } else if (c.ends_u64) hipLaunchKernelGGL((k2w_classify<u64, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count);
-    else hipLaunchKernelGGL((k2w_classify<u32, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count);
+    } else if (c.ends_u64) hipLaunchKernelGGL((k2w_classify<u64, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi);
+    else hipLaunchKernelGGL((k2w_classify<u32, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi);
     if (part == 1) return;
 #define FZB_K2C(SWL, U, REAL, CLS, ET)                                                                                                    \
     do {                                                                                                                                  \
@@ -521,6 +525,64 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ 
         rec.exact = exact ? 1 : 0;
         rec.valid = 0;
         out[opos] = rec;
+    }
+}
+
+// the multi-chunk windows as k2w_classify's four lists by the width of the last chunk's tail (lists 3-6 of `lists`, counts in counters[12..15]):
+// one persistent walk over the concatenation, widest class first (a slot's later items are its cheaper ones); a wave computes the last chunk
+// with the class of its first lane - the widest among its 64 (only the three waves that straddle a list boundary compute more than needed)
+template <int SWL, bool UPPER, typename ET>
+__global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
+                                                       const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts,
+                                                       const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
+    __shared__ CfTables tab;
+    cf_build_tables<UPPER>(nd, tab);
+    __syncthreads();
+    // positions [0, e3) class 3 (the whole last chunk), [e3, e2) class 2, [e2, e1) class 1, [e1, e0) class 0
+    const u32 e3 = __builtin_amdgcn_readfirstlane(counts[3]), e2 = e3 + __builtin_amdgcn_readfirstlane(counts[2]), e1 = e2 + __builtin_amdgcn_readfirstlane(counts[1]),
+              e0 = e1 + __builtin_amdgcn_readfirstlane(counts[0]);
+    const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u32 q = gtid; q < e0; q += nthreads) {
+        const u32 cls = q < e3 ? 3u : q < e2 ? 2u : q < e1 ? 1u : 0u;
+        const u32 base = cls == 3 ? 0u : cls == 2 ? e3 : cls == 1 ? e2 : e1;
+        const u32 j = lists[(size_t)(3 + cls) * list_stride + (q - base)];
+        if (j >= capacity) continue;
+        const u32 li = items ? items[j] : j;
+        const uint2 w = *(const uint2*)(win + 2 * (size_t)j);
+        u64 s;
+        u32 L;
+        haystack_span(ends, first + li, s, L);
+        const u8* hay = bytes + s;
+        const u32 sp = w.x ? w.x - 1 : 0;
+        const bool include_exact = sp == 0 && w.y == L;
+        const u32 m = w.y - sp;
+        const u32 wcls = __builtin_amdgcn_readfirstlane(cls);  // lanes are in position order: the first active lane holds the widest class
+        u32 score = dp_multi_chunk_tc<SWL, UPPER>(nd, hay + sp, m, sp == 0, tab, scratch, nthreads, gtid, wcls);
+        bool exact = include_exact && m == (u32)nd.nbytes;
+        if (exact)
+            for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+        if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+        fzb_match_rec rec;
+        rec.index = index_offset + li;
+        rec.score = (u16)score;
+        rec.exact = exact ? 1 : 0;
+        rec.valid = 0;
+        out[j] = rec;
+    }
+}
+
+void fzb_launch_dp_multi_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* lists, u32 list_stride, const u32* counts,
+                                 const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st) {
+    bool upper = false;
+    for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+#define FZB_K2TC(SWL, U, ET) hipLaunchKernelGGL((k2d_dp_multi_tc<SWL, U, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, lists, list_stride, counts, nd, out, capacity, scratch)
+#define FZB_K2TC_ET(SWL, U) do { if (c.ends_u64) FZB_K2TC(SWL, U, u64); else FZB_K2TC(SWL, U, u32); } while (0)
+#define FZB_K2TC_U(SWL) do { if (upper) FZB_K2TC_ET(SWL, true); else FZB_K2TC_ET(SWL, false); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2TC_U(64); break;
+        case 32: FZB_K2TC_U(32); break;
+        case 16: FZB_K2TC_U(16); break;
+        default: FZB_K2TC_U(8); break;
     }
 }
 

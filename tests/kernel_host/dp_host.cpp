@@ -63,7 +63,8 @@ static int run(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, in
     return -2;
 }
 
-// multi-chunk windows (swl < m <= 1024): form 5 = dp_multi_chunk (first form, biased scan), 6 = dp_multi_chunk_t (dp_cfm.h)
+// multi-chunk windows (swl < m <= 1024): form 5 = dp_multi_chunk (first form, biased scan), 6 = dp_multi_chunk_t (dp_cfm.h), 7 / 8 = the same
+// with the last chunk's padding lanes in closed form (needle without NUL)
 template <int SWL>
 static int run_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, int form, const u8* cls) {
     static u32 scratch[(FZB_MAX_ROWS + 1) * (SWL / 2) + 64];
@@ -75,6 +76,12 @@ static int run_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_pref
     CfTables tab;
     for (unsigned t = 0; t < 16; t++) { threadIdx.x = t; if (upper) cf_build_tables<true>(nd, tab); else cf_build_tables<false>(nd, tab); }
     threadIdx.x = 0;
+    if (form == 7 || form == 8) {  // the last chunk's NUL lanes in closed form: dp_multi_chunk_tc with the narrowest class that holds the tail (7) / one class wider (8)
+        const u32 tail = m - ((m + SWL - 1) / SWL - 1) * SWL;  // bytes in the last chunk, 1 ..= SWL
+        int cls = (int)((tail - 1) / (SWL / 4)) + (form == 8 ? 1 : 0);
+        if (cls > 3) cls = 3;
+        return upper ? (int)dp_multi_chunk_tc<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, (u32)cls) : (int)dp_multi_chunk_tc<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, (u32)cls);
+    }
     return upper ? (int)dp_multi_chunk_t<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0) : (int)dp_multi_chunk_t<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0);
 }
 

@@ -194,9 +194,92 @@ def test_multi_chunk_windows_both_forms_match_the_oracle(swl):
         ip = rng.random() < 0.5
         u8 = _fits(n, sc)
         want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, lanes=swl, is_u8=u8)
-        for form in (5, 6):
+        for form in (5, 6, 7, 8):
             got = K.dp_multi(needle, hay, sc, cs, ip, swl, form, u8)
             assert got == want, (needle, hay, sc, cs, ip, swl, form, got, want)
+
+
+@pytest.mark.parametrize("swl", [64, 32, 16, 8])
+def test_multi_chunk_last_chunk_padding_in_closed_form(swl):
+    """dp_cfm.h with the last chunk's NUL lanes not computed (forms 7 / 8: the narrowest class of computed lanes that holds the window's tail,
+    and one class wider): windows whose best path ENDS in the padding - the needle's head matched at the very end of the window (real lanes of
+    the last chunk, or the adjacent half-chunk when the tail is short) and its remaining rows unmatched, so that the maximum of the last row
+    sits in a padding lane reached by a gap step or the diagonal and decays down the padding column."""
+    rng = random.Random(7700 + swl)
+    checked = in_padding = 0
+    for it in range(1500):
+        alpha = rng.choice([b"ab", b"abcA_", b"abcdefABCDEF_-/ 019"])
+        n = rng.randint(2, 10)
+        needle = _rnd(rng, n, alpha)
+        cs = rng.random() < 0.3
+        sc = DEF
+        if rng.random() < 0.6:
+            while True:
+                sc = [rng.randint(0, 40), rng.randint(0, 20), rng.randint(0, 20), rng.randint(0, 6), rng.randint(0, 30), rng.randint(0, 12), rng.randint(0, 12),
+                      rng.randint(0, 20), rng.randint(0, 12)]
+                if 2 * sc[3] <= sc[1]:
+                    break
+        nch = rng.choice([2, 2, 2, 3, 5])
+        tail = rng.randint(1, swl)
+        m = (nch - 1) * swl + tail
+        filler = bytes([rng.choice(b"xyz.")])
+        hay = bytearray(filler * m)
+        # the needle's first k bytes planted just before the end of the window, the rest never occurs (filler is outside every alphabet)
+        k = rng.randint(1, n)
+        gap = rng.choice([0, 0, 1, 2, 3, 5])
+        pos = m - k - gap - rng.choice([0, 0, 0, 1, 2, swl // 4, swl // 2])
+        if pos < 0:
+            continue
+        for j in range(k):
+            q = pos + j + (gap if j == k - 1 else 0)
+            if q < m:
+                hay[q] = needle[j]
+        if rng.random() < 0.3:  # and some noise elsewhere
+            for _ in range(rng.randint(1, 6)):
+                hay[rng.randrange(m)] = rng.choice(needle)
+        hay = bytes(hay)
+        ip = rng.random() < 0.5
+        u8 = _fits(n, sc)
+        want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, lanes=swl, is_u8=u8)
+        for form in (6, 7, 8):
+            got = K.dp_multi(needle, hay, sc, cs, ip, swl, form, u8)
+            assert got == want, (needle, hay, sc, cs, ip, swl, form, got, want)
+        checked += 1
+        in_padding += want > 0
+    assert checked > 1200 and in_padding > 300
+
+
+def test_multi_chunk_closed_form_padding_where_gap_steps_into_the_padding_decide():
+    """The gap-step entries into the last chunk's padding (dp_cf.h, 3b; dp_cfm.h adds the adjacent half-chunk's lanes as sources) are the
+    maximum only when every lane a cheaper route could walk down is charged again and again: a free gap extension, an expensive gap opening,
+    a long needle over a one- or two-letter alphabet and a tail of exactly a class's computed lanes.  A build without the real-lane entries
+    differs on about 1 in 15 000 of these (none of the other tests' inputs), so this sweep is large and runs form 7 / 8 against form 6 (which
+    the tests above hold to the oracle), with the oracle itself on a sample."""
+    rng = random.Random(2)
+    checked = 0
+    for it in range(60000):
+        swl = rng.choice([8, 16, 16, 32, 64])
+        n = rng.randint(3, 14)
+        alpha = rng.choice([b"a", b"ab", b"ab", b"abc", b"aA"])
+        needle = bytes(rng.choice(alpha) for _ in range(n))
+        e = rng.choice([0, 0, 0, 1, 1, 2])
+        sc = [rng.randint(4, 40), rng.randint(2 * e, 20), rng.randint(max(2, e), 24), e, rng.randint(0, 30), rng.randint(0, 12), rng.randint(0, 12), rng.randint(0, 20),
+              rng.randint(0, 12)]
+        q = swl // 4
+        m = (rng.choice([2, 2, 3]) - 1) * swl + rng.choice([q, q, 2 * q, 3 * q])
+        hay = bytearray(b"x" * m)
+        for j in range(m - rng.randint(1, min(m, swl)), m):
+            hay[j] = rng.choice(alpha)
+        hay = bytes(hay)
+        cs = rng.random() < 0.3
+        want = K.dp_multi(needle, hay, sc, cs, True, swl, 6, False)
+        if it % 40 == 0:
+            assert want == O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=True, lanes=swl, is_u8=False)
+        for form in (7, 8):
+            got = K.dp_multi(needle, hay, sc, cs, True, swl, form, False)
+            assert got == want, (needle, hay, sc, cs, swl, form, got, want)
+        checked += 1
+    assert checked == 60000
 
 
 def test_multi_chunk_biased_form_at_the_largest_values_it_is_configured_for():
