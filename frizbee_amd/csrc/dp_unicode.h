@@ -278,69 +278,100 @@ __device__ __forceinline__ bool unicode_has_cont_run4(const u8* __restrict__ th,
     return run4 != 0;
 }
 
-// UTF8 = true: the caller has checked (unicode_has_cont_run4, wave-uniform) that no window of the wave holds four continuation bytes in a
-// row.  In UTF-8 a scalar has at most three, so every window of >= 4 lanes holds a scalar start (or padding, which Qp counts the same
-// way): the "crossed a scalar start" test of the 4-, 8-, 16-lane steps is then always true - the pending charge is always taken and the
-// pending mask never moves - and those steps are a subtract and a max.  Any other byte string takes UTF8 = false (every test kept).
-template <int SWL, int REAL = SWL / 2, bool UTF8 = false>
-__device__ __forceinline__ u32 dp_unicode_single_chunk_t(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls) {
+// The needle row's byte-level match flags of dp_unicode_single_chunk_t, specialised per scalar length CL and per "the row has a second case
+// variant" (both wave-uniform: ONE switch per row instead of branches inside the unrolled loop over the byte dwords): fe01 / fm01 = 0x01 in
+// every byte that is a scalar start and whose CL bytes equal the needle scalar (exact case / either case).  unicode.rs:221-241.
+template <int RB, int CL, bool TWO>
+__device__ __forceinline__ void unicode_row_flags(const u32 (&hb)[RB + 1], const u32 (&sflag)[RB], u32 ucw, u32 ufw, u32 (&fe01)[RB], u32 (&fm01)[RB]) {
+    const u32 c0 = (ucw & 0xFF) * 0x01010101u, c1 = ((ucw >> 8) & 0xFF) * 0x01010101u, c2 = ((ucw >> 16) & 0xFF) * 0x01010101u, c3 = (ucw >> 24) * 0x01010101u;
+    const u32 f0 = (ufw & 0xFF) * 0x01010101u, f1 = ((ufw >> 8) & 0xFF) * 0x01010101u, f2 = ((ufw >> 16) & 0xFF) * 0x01010101u, f3 = (ufw >> 24) * 0x01010101u;
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        const u32 v0 = hb[k];
+        u32 ze = v0 ^ c0, zf = v0 ^ f0;
+        if (CL > 1) {
+            const u32 v1 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 1);
+            ze |= v1 ^ c1;
+            if (TWO) zf |= v1 ^ f1;
+        }
+        if (CL > 2) {
+            const u32 v2 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 2);
+            ze |= v2 ^ c2;
+            if (TWO) zf |= v2 ^ f2;
+        }
+        if (CL > 3) {
+            const u32 v3 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 3);
+            ze |= v3 ^ c3;
+            if (TWO) zf |= v3 ^ f3;
+        }
+        const u32 fe = zflag4(ze) & sflag[k];
+        fe01[k] = fe >> 7;
+        fm01[k] = TWO ? (fe | (zflag4(zf) & sflag[k])) >> 7 : fe01[k];
+    }
+}
+
+// set-up of the biased-throughout form from the window's bytes hb[0 .. RB) (zero padded, hb[RB] = 0): scalar-start flags per byte (0x80),
+// Qp = #scalar starts + #padding lanes up to and including the lane, the bonus vector.  Returns whether the window holds four UTF-8
+// continuation bytes in a row (unicode_has_cont_run4's answer, from the continuation flags this needs anyway).
+template <int SWL, int REAL>
+__device__ __forceinline__ bool unicode_setup_t(const NeedleDev& nd, const u32 (&hb)[(REAL + 1) / 2 + 1], u32 m, bool include_prefix, const u8* cls,
+                                                u32 (&sflag)[(REAL + 1) / 2], u32 (&Qp)[2 * ((REAL + 1) / 2)], u32 (&bonus)[2 * ((REAL + 1) / 2)]) {
+    constexpr int RB = (REAL + 1) / 2;
+    const u32 ONE = 0x00010001u;
+    const u32 Mv = splat16(nd.match_plus_mismatch), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+    const u32 mv = splat16(m);
+    u32 clsw_prev = 0, qrun = 0, run4 = 0, cont_prev = 0;
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        const u32 w = hb[k];
+        const u32 contf = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u);  // continuation byte: (b & 0xC0) == 0x80
+        const u32 p = 4 * k;
+        const u32 nv = m > p ? min(m - p, 4u) : 0u;
+        const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
+        sflag[k] = validf & ~contf;
+        const u32 cv = contf & validf;
+        // byte j of the shifted views = the flag of the byte 3 / 2 / 1 positions before byte j
+        run4 |= cv & __builtin_amdgcn_alignbyte(cv, cont_prev, 1) & __builtin_amdgcn_alignbyte(cv, cont_prev, 2) & __builtin_amdgcn_alignbyte(cv, cont_prev, 3);
+        cont_prev = cv;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int d = 2 * k + h;
+            const u32 b0 = h ? (w >> 16) & 0xFF : w & 0xFF;
+            const u32 b1 = h ? w >> 24 : (w >> 8) & 0xFF;
+            const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
+            const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);
+            const u32 cap01 = (clsw >> 1) & sh & ONE;
+            const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;
+            bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+            clsw_prev = clsw;
+            const u32 t = sflag[k] >> 7;
+            const u32 s0 = h ? (t >> 16) & 1 : t & 1;
+            const u32 s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
+            const u32 q0 = qrun + s0, q1 = q0 + s1;
+            const u32 lanepos1 = (u32)(2 * d + 1) | ((u32)(2 * d + 2) << 16);
+            Qp[d] = p_add(q0 | (q1 << 16), p_subs(lanepos1, mv));
+            qrun = q1;
+        }
+    }
+    if (include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
+    return run4 != 0;
+}
+
+// UTF8 = true: the caller has checked (wave-uniform) that no window of the wave holds four continuation bytes in a row.  In UTF-8 a scalar
+// has at most three, so every window of >= 4 lanes holds a scalar start (or padding, which Qp counts the same way): the "crossed a scalar
+// start" test of the 4-, 8-, 16-lane steps is then always true - the pending charge is always taken and the pending mask never moves - and
+// those steps are a subtract and a max.  Any other byte string takes UTF8 = false (every test kept).
+template <int SWL, int REAL, bool UTF8>
+__device__ __forceinline__ u32 unicode_rows_t(const NeedleDev& nd, u32 (&hb)[(REAL + 1) / 2 + 1], u32 (&sflag)[(REAL + 1) / 2], u32 (&Qp)[2 * ((REAL + 1) / 2)],
+                                              const u32 (&bonus)[2 * ((REAL + 1) / 2)]) {
     constexpr int NW = SWL / 2;
     constexpr int RB = (REAL + 1) / 2;  // byte dwords that may hold haystack bytes
     constexpr int NR = 2 * RB;          // score dwords computed (two lanes each)
     static_assert(REAL >= 1 && REAL <= NW, "REAL");
     const u32 rows = (u32)nd.rows;
-    const u32 ONE = 0x00010001u;
     const u32 e = nd.gex;
-    const u32 Mv = splat16(nd.match_plus_mismatch), xqv = splat16(nd.mismatch - 2 * e), gexv = splat16(e), gopmv = splat16(nd.gopm);
-    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
-    u32 hb[RB + 1];
-#pragma unroll
-    for (int k = 0; k < RB; k++) {
-        const u32 p = 4 * k;
-        u32 v = 0;
-        if (p < m) {
-            v = load_u32_unaligned(th, p);
-            const u32 rem = m - p;
-            if (rem < 4) v &= (1u << (8 * rem)) - 1;
-        }
-        hb[k] = v;
-    }
-    hb[RB] = 0;
-    // ---- scalar-start flags per byte (0x80), Qp = #scalar starts + #padding lanes up to and including the lane, bonus -------------
-    u32 sflag[RB], Qp[NR], bonus[NR];
-    {
-        const u32 mv = splat16(m);
-        u32 clsw_prev = 0, qrun = 0;
-#pragma unroll
-        for (int k = 0; k < RB; k++) {
-            const u32 w = hb[k];
-            const u32 contf = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u);  // continuation byte: (b & 0xC0) == 0x80
-            const u32 p = 4 * k;
-            const u32 nv = m > p ? min(m - p, 4u) : 0u;
-            const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
-            sflag[k] = validf & ~contf;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int d = 2 * k + h;
-                const u32 b0 = h ? (w >> 16) & 0xFF : w & 0xFF;
-                const u32 b1 = h ? w >> 24 : (w >> 8) & 0xFF;
-                const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
-                const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);
-                const u32 cap01 = (clsw >> 1) & sh & ONE;
-                const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;
-                bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
-                clsw_prev = clsw;
-                const u32 t = sflag[k] >> 7;
-                const u32 s0 = h ? (t >> 16) & 1 : t & 1;
-                const u32 s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
-                const u32 q0 = qrun + s0, q1 = q0 + s1;
-                const u32 lanepos1 = (u32)(2 * d + 1) | ((u32)(2 * d + 2) << 16);
-                Qp[d] = p_add(q0 | (q1 << 16), p_subs(lanepos1, mv));
-                qrun = q1;
-            }
-        }
-        if (include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
-    }
+    const u32 xqv = splat16(nd.mismatch - 2 * e), gexv = splat16(e), gopmv = splat16(nd.gopm);
+    const u32 casev = splat16(nd.matching_case);
     u32 prev[NR], upg[NR];  // upg / pendg: the match masks already AND-ed with gop' (every use of them is)
 #pragma unroll
     for (int d = 0; d < NR; d++) prev[d] = p_mul(Qp[d], gexv), upg[d] = 0;  // T(-1, L) = B(-1, L) = P[L]
@@ -350,8 +381,6 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk_t(const NeedleDev& nd, co
         const u32 ucw = ((const u32*)nd.uc)[r], ufw = ((const u32*)nd.uf)[r];
         const u32 cl = (((const u32*)nd.ulen)[r >> 2] >> (8 * (r & 3))) & 0xFF;
         const bool two = ucw != ufw;
-        const u32 c0 = (ucw & 0xFF) * 0x01010101u, c1 = ((ucw >> 8) & 0xFF) * 0x01010101u, c2 = ((ucw >> 16) & 0xFF) * 0x01010101u, c3 = (ucw >> 24) * 0x01010101u;
-        const u32 f0 = (ufw & 0xFF) * 0x01010101u, f1 = ((ufw >> 8) & 0xFF) * 0x01010101u, f2 = ((ufw >> 16) & 0xFF) * 0x01010101u, f3 = (ufw >> 24) * 0x01010101u;
         const u32 rbv = splat16((r + 1) * e);
         // keep the per-lane state out of loop-invariant hoisting (see the first form)
 #pragma unroll
@@ -360,47 +389,39 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk_t(const NeedleDev& nd, co
         for (int k = 0; k <= RB; k++) FZB_OPAQUE_V(hb[k]);
 #pragma unroll
         for (int k = 0; k < RB; k++) FZB_OPAQUE_V(sflag[k]);  // (its lane masks are row-invariant: sixteen more registers if hoisted)
+        // ---- byte-level match flags: scalar start && the cl bytes from the lane on equal the needle scalar (unicode.rs:221-241) ----
+        u32 fe01[RB], fm01[RB];
+        switch (two ? cl + 4 : cl) {
+            case 1: unicode_row_flags<RB, 1, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            case 2: unicode_row_flags<RB, 2, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            case 3: unicode_row_flags<RB, 3, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            case 5: unicode_row_flags<RB, 1, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            case 6: unicode_row_flags<RB, 2, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            case 7: unicode_row_flags<RB, 3, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            case 8: unicode_row_flags<RB, 4, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            default: unicode_row_flags<RB, 4, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+        }
         u32 row[NR], pendg[NR];
 #pragma unroll
         for (int k = 0; k < RB; k++) {
-            // ---- byte-level match flags: scalar start && the cl bytes from the lane on equal the needle scalar (unicode.rs:221-241) ----
-            const u32 v0 = hb[k];
-            u32 ze, zf;
-            if (cl == 1) {
-                ze = v0 ^ c0; zf = v0 ^ f0;
-            } else {
-                const u32 v1 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 1);
-                ze = (v0 ^ c0) | (v1 ^ c1); zf = (v0 ^ f0) | (v1 ^ f1);
-                if (cl > 2) {
-                    const u32 v2 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 2);
-                    ze |= v2 ^ c2; zf |= v2 ^ f2;
-                    if (cl > 3) {
-                        const u32 v3 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 3);
-                        ze |= v3 ^ c3; zf |= v3 ^ f3;
-                    }
-                }
-            }
-            u32 fe = zflag4(ze) & sflag[k];
-            u32 fm = fe;
-            if (two) fm |= zflag4(zf) & sflag[k];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int d = 2 * k + h;
-                const u32 sel = h ? 0x03030202u : 0x01010000u;  // byte 2h -> both bytes of lane 0, byte 2h+1 -> both bytes of lane 1: 0x8080 / 0
-                const u32 exm = p_neg_mask(__builtin_amdgcn_perm(0u, fe, sel));
-                const u32 mmk = p_neg_mask(__builtin_amdgcn_perm(0u, fm, sel));
-                const u32 sst = p_neg_mask(__builtin_amdgcn_perm(0u, sflag[k], sel));
+                const u32 sel01 = h ? 0x0c030c02u : 0x0c010c00u;  // flag byte 2h -> lane 0, byte 2h+1 -> lane 1, as 0 / 1 per 16-bit lane
+                const u32 ex01 = __builtin_amdgcn_perm(0u, fe01[k], sel01);
+                const u32 mm01 = __builtin_amdgcn_perm(0u, fm01[k], sel01);
+                const u32 sst = p_neg_mask(__builtin_amdgcn_perm(0u, sflag[k], h ? 0x03030202u : 0x01010000u));  // 0xFFFF where the lane is a scalar start
                 const u32 z = (r * e) << 16;  // T(r-1, lane -1) = B(r-1, -1) = r * e: the zero column
                 const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : z, 16);
-                const u32 t = p_subs(p_add(sh, mmk & bonus[d]), xqv);
-                const u32 diag = p_add(t, exm & casev);
-                const u32 up = p_subs(prev[d], upg[d]);  // upg[d] still holds the PREVIOUS row's match mask (& gop')
+                const u32 t = p_subs(p_mad(mm01, bonus[d], sh), xqv);
+                const u32 diag = p_mad(ex01, casev, t);
+                const u32 up = p_subs(prev[d], upg[d]);  // upg[d] still holds the PREVIOUS row's match mask (x gop')
                 const u32 Bd = p_mad(Qp[d], gexv, rbv);
                 const u32 v = p_max(p_max(diag, up), Bd);
                 row[d] = (v & sst) | (Bd & ~sst);
-                pendg[d] = upg[d] = mmk & gopmv;
+                pendg[d] = upg[d] = p_mul(mm01, gopmv);
             }
-            FZB_SCHED_FENCE();
+            if (k & 1) FZB_SCHED_FENCE();  // four lane pairs between fences: enough independent chains to fill the packed-op forwarding slots
         }
         if (r + 1 == rows) {  // the last row is not propagated: its maximum, unbiased (non-start lanes hold exactly B: 0)
             u32 mxl = 0;
@@ -439,3 +460,104 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk_t(const NeedleDev& nd, co
     }
     return 0;  // rows == 0
 }
+
+// window bytes th[0 .. m) from memory -> hb (zero padded, + the guard dword the shifted views read)
+template <int RB>
+__device__ __forceinline__ void unicode_load_bytes(const u8* __restrict__ th, u32 m, u32 (&hb)[RB + 1]) {
+#pragma unroll
+    for (int k = 0; k < RB; k++) {
+        const u32 p = 4 * k;
+        u32 v = 0;
+        if (p < m) {
+            v = load_u32_unaligned(th, p);
+            const u32 rem = m - p;
+            if (rem < 4) v &= (1u << (8 * rem)) - 1;
+        }
+        hb[k] = v;
+    }
+    hb[RB] = 0;
+}
+
+// the whole scorer with the UTF-8 decision made by the caller (host harness; general kernel)
+template <int SWL, int REAL = SWL / 2, bool UTF8 = false>
+__device__ __forceinline__ u32 dp_unicode_single_chunk_t(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls) {
+    constexpr int RB = (REAL + 1) / 2, NR = 2 * RB;
+    u32 hb[RB + 1], sflag[RB], Qp[NR], bonus[NR];
+    unicode_load_bytes<RB>(th, m, hb);
+    unicode_setup_t<SWL, REAL>(nd, hb, m, include_prefix, cls, sflag, Qp, bonus);
+    return unicode_rows_t<SWL, REAL, UTF8>(nd, hb, sflag, Qp, bonus);
+}
+
+// ... and with the window's bytes already in registers and the UTF-8 decision taken here: `all_of(flag)` is the wave's vote (the kernel
+// passes __all; the host harness the identity)
+template <int SWL, int REAL, typename Vote>
+__device__ __forceinline__ u32 dp_unicode_single_chunk_tr(const NeedleDev& nd, u32 (&hb)[(REAL + 1) / 2 + 1], u32 m, bool include_prefix, const u8* cls, const Vote& all_of) {
+    constexpr int RB = (REAL + 1) / 2, NR = 2 * RB;
+    u32 sflag[RB], Qp[NR], bonus[NR];
+    const bool run4 = unicode_setup_t<SWL, REAL>(nd, hb, m, include_prefix, cls, sflag, Qp, bonus);
+    return all_of(!run4) ? unicode_rows_t<SWL, REAL, true>(nd, hb, sflag, Qp, bonus) : unicode_rows_t<SWL, REAL, false>(nd, hb, sflag, Qp, bonus);
+}
+
+// ---- 0-typo unicode window of a haystack of at most 32 bytes held in two vectors (the kernel for short corpora) --------------------------
+// The same window as unicode_window_first_last (src/prefilter/algo/unicode.rs:118-219), found with SWAR compares: 0x80 in every byte at
+// which the CL bytes of the scalar `cw` start, all eight dwords merged into one word with bit 8j + k = byte j of dword k (position 4k + j).
+template <int CL>
+__device__ __forceinline__ u32 unicode_scalar_positions(const u32 (&w)[9], u32 cw) {
+    const u32 c0 = (cw & 0xFF) * 0x01010101u, c1 = ((cw >> 8) & 0xFF) * 0x01010101u, c2 = ((cw >> 16) & 0xFF) * 0x01010101u, c3 = (cw >> 24) * 0x01010101u;
+    u32 y = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        u32 z = w[k] ^ c0;
+        if (CL > 1) z |= __builtin_amdgcn_alignbyte(w[k + 1], w[k], 1) ^ c1;
+        if (CL > 2) z |= __builtin_amdgcn_alignbyte(w[k + 1], w[k], 2) ^ c2;
+        if (CL > 3) z |= __builtin_amdgcn_alignbyte(w[k + 1], w[k], 3) ^ c3;
+        y |= zflag4(z) >> (7 - k);
+    }
+    return y;
+}
+__device__ __forceinline__ u32 unicode_scalar_positions_cl(const u32 (&w)[9], u32 cw, u32 cl) {
+    switch (cl) {  // wave-uniform
+        case 1: return unicode_scalar_positions<1>(w, cw);
+        case 2: return unicode_scalar_positions<2>(w, cw);
+        case 3: return unicode_scalar_positions<3>(w, cw);
+        default: return unicode_scalar_positions<4>(w, cw);
+    }
+}
+// positions q = 4k + j with q + len <= L, in the merged layout (bit 8j + k)
+__device__ __forceinline__ u32 unicode_valid_positions(u32 L, u32 len) {
+    u32 v = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; j++) {
+        if (L >= len + j) {
+            const u32 kmax = (L - len - j) >> 2;  // positions j, j + 4, ..., j + 4 * kmax are valid
+            v |= (kmax >= 7 ? 0xFFu : ((2u << kmax) - 1)) << (8 * j);
+        }
+    }
+    return v;
+}
+__device__ __forceinline__ u32 unicode_first_pos(u32 y) {  // smallest position in the merged layout (y != 0)
+    u32 best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u32 f = (y >> (8 * j)) & 0xFF;
+        const u32 k = f ? (u32)__builtin_ctz(f) : 0x3FFFFFFFu;
+        best = min(best, 4 * k + j);
+    }
+    return best;
+}
+__device__ __forceinline__ void unicode_window_regs(const NeedleDev& nd, const uint4& q0, const uint4& q1, u32 L, u32& ws, u32& we) {
+    const u32 n = (u32)nd.rows;
+    const u32 la = nd.ulen[0], lz = nd.ulen[n - 1];
+    const u32 a0 = ((const u32*)nd.uc)[0], a1 = ((const u32*)nd.uf)[0], z0 = ((const u32*)nd.uc)[n - 1], z1 = ((const u32*)nd.uf)[n - 1];
+    const u32 w[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, 0u};
+    u32 ya = unicode_scalar_positions_cl(w, a0, la);
+    if (a1 != a0) ya |= unicode_scalar_positions_cl(w, a1, la);
+    u32 yz = unicode_scalar_positions_cl(w, z0, lz);
+    if (z1 != z0) yz |= unicode_scalar_positions_cl(w, z1, lz);
+    ya &= unicode_valid_positions(L, la);
+    yz &= unicode_valid_positions(L, lz);
+    ws = ya ? unicode_first_pos(ya) : 0u;  // (no occurrence cannot happen for a survivor of the exact filter)
+    // last occurrence: reversing the word maps bit 8j + k to 8(3-j) + (7-k), so "first" of the reversed word is 31 - last position
+    we = yz ? 31u - unicode_first_pos(__builtin_bitreverse32(yz)) + lz : 0u;
+}
+

@@ -437,9 +437,12 @@ void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, cons
     // second stream between the two)
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-    if (part == 2) {
-    } else if (c.ends_u64) hipLaunchKernelGGL((k2w_classify<u64, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u64*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi);
-    else hipLaunchKernelGGL((k2w_classify<u32, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const u32*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi);
+    if (part != 2) {
+        static const int per = [] { const char* e = getenv("FZB_CLASSIFY_PER"); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();  // tuning knob: survivors per thread
+#define FZB_K2W(ET, PER) hipLaunchKernelGGL((k2w_classify<ET, PER>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi)
+#define FZB_K2W_ET(PER) do { if (c.ends_u64) FZB_K2W(u64, PER); else FZB_K2W(u32, PER); } while (0)
+        if (per == 1) FZB_K2W_ET(1); else if (per == 4) FZB_K2W_ET(4); else FZB_K2W_ET(2);
+    }
     if (part == 1) return;
 #define FZB_K2C(SWL, U, REAL, CLS, ET)                                                                                                    \
     do {                                                                                                                                  \

@@ -39,10 +39,19 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
     load_item(j0 + 2 * stride, li_m, ws_m, we_m);
     load_span(j0, li_c, s_c, L_c);
     load_span(j0 + stride, li_n, s_n, L_n);
+    // REGS: every haystack of the list fits two 16-byte vectors (HALFONLY at 64 lanes and below) and the biased-throughout form runs: the
+    // vectors are requested one iteration ahead, the 0-typo window is found in them (unicode_window_regs) and the window's bytes are shifted
+    // out of them (load_window_regs) - no byte-wise scan with a dependent load per dword, no second read of the window
+    constexpr bool REGS = HALFONLY && TF && SWL <= 64;
     u32 warm = 0;
+    uint4 q0_c = make_uint4(0, 0, 0, 0), q1_c = q0_c;
+    if (REGS && j0 < M && L_c > 0) { q0_c = *(const uint4*)(bytes + s_c); q1_c = *(const uint4*)(bytes + s_c + 16); }
     for (u64 j = j0; j < M; j += stride) {
         u32 warm_n = 0;
-        if (L_n > 0) warm_n = *(const u32*)(bytes + s_n + (ws_n & ~3u));  // the next item's window start: brings its line(s) into L2
+        uint4 q0_n = make_uint4(0, 0, 0, 0), q1_n = q0_n;
+        if (REGS) {
+            if (L_n > 0) { q0_n = *(const uint4*)(bytes + s_n); q1_n = *(const uint4*)(bytes + s_n + 16); }
+        } else if (L_n > 0) warm_n = *(const u32*)(bytes + s_n + (ws_n & ~3u));  // the next item's window start: brings its line(s) into L2
         u64 s_m;
         u32 L_m;
         load_span(j + 2 * stride, li_m, s_m, L_m);
@@ -54,7 +63,10 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             const u8* hay = bytes + s_c;
             u32 ws = ws_c, we = we_c;
             if (wmode == 2) { ws = 0; we = L; }
-            else if (wmode == 1) unicode_window_first_last(nd, hay, L, ws, we);
+            else if (wmode == 1) {
+                if (REGS) unicode_window_regs(nd, q0_c, q1_c, L, ws, we);
+                else unicode_window_first_last(nd, hay, L, ws, we);
+            }
             const u32 sp = ws ? ws - 1 : 0;
             const bool include_exact = sp == 0 && we == L;
             const u32 m = we - sp;
@@ -73,7 +85,16 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
                 const bool half = HALFONLY || (SWL >= 16 && __all((int)(m <= (u32)SWL / 2)));
                 // TF: the biased-throughout form (dp_unicode_single_chunk_t; LaunchCfg::cfu_ok), else the first form
                 constexpr int HR = SWL >= 16 ? SWL / 4 : SWL / 2;
-                if (TF) {
+                if (REGS) {
+                    u32 hb[HR / 2 + 1];
+                    u32 hw[HR / 2];
+                    load_window_regs<HR / 2>(q0_c, q1_c, sp, m, hw);
+#pragma unroll
+                    for (int k = 0; k < HR / 2; k++) hb[k] = hw[k];
+                    hb[HR / 2] = 0;
+                    // the UTF-8 shortcut of the gap scan is taken when no window of the wave holds four continuation bytes in a row
+                    score = dp_unicode_single_chunk_tr<SWL, HR>(nd, hb, m, sp == 0, cls, [](bool b) { return __all((int)b) != 0; });
+                } else if (TF) {
                     // wave-uniform: every window of the wave is free of four-continuation-byte runs (always, for UTF-8 text)
                     const bool utf8 = __all((int)!(half ? unicode_has_cont_run4<(SWL >= 16 ? SWL / 2 : SWL)>(hay + sp, m) : unicode_has_cont_run4<SWL>(hay + sp, m)));
                     if (half) score = utf8 ? dp_unicode_single_chunk_t<SWL, HR, true>(nd, hay + sp, m, sp == 0, cls) : dp_unicode_single_chunk_t<SWL, HR, false>(nd, hay + sp, m, sp == 0, cls);
@@ -95,6 +116,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             out[j] = rec;
         } while (0);
         li_c = li_n; ws_c = ws_n; we_c = we_n; s_c = s_n; L_c = L_n;
+        q0_c = q0_n; q1_c = q1_n;
         li_n = li_m; ws_n = ws_m; we_n = we_m; s_n = s_m; L_n = L_m;
         li_m = li_f; ws_m = ws_f; we_m = we_f;
         warm = warm_n;

@@ -150,6 +150,62 @@ int kh_dp_unicode(const u8* uc, const u8* uf, const u8* ulen, int rows, const u1
     return -1;
 }
 
+// a haystack of at most 32 bytes through the short-corpus kernel's register path (dp_unicode.h): window from the two vectors
+// (unicode_window_regs), window bytes shifted out of them (load_window_regs), set-up with the UTF-8 decision, rows.  out = {ws, we of the
+// register search, ws, we of unicode_window_first_last, score of the register path, score of the memory path over the same window}
+int kh_unicode_regs(const u8* uc, const u8* uf, const u8* ulen, int rows, const u16* sc, const u8* hay, int len, int swl, unsigned* out) {
+    if (rows < 1 || rows > FZB_MAX_ROWS || len < 1 || len > 32 || len > swl / 2) return -1;
+    NeedleDev nd;
+    const u8 dummy[1] = {0};
+    fill_needle(nd, dummy, 0, 1, sc);
+    nd.rows = rows;
+    nd.unicode = 1;
+    for (int r = 0; r < rows; r++) {
+        memcpy(nd.uc[r], uc + 4 * r, 4);
+        memcpy(nd.uf[r], uf + 4 * r, 4);
+        nd.ulen[r] = ulen[r];
+    }
+    static u8 cls[256];
+    build_cls_table(cls);
+    std::vector<u32> buf(64, 0);
+    memcpy(buf.data(), hay, len);
+    for (int i = len; i < 32; i++) ((u8*)buf.data())[i] = (u8)(0x41 + i);  // what follows a haystack inside its two vectors is not always zero
+    if (len % 16) for (int i = len; i < (len + 15) / 16 * 16; i++) ((u8*)buf.data())[i] = 0;  // ... but its own 16-byte padding is
+    uint4 q0, q1;
+    memcpy(&q0, buf.data(), 16);
+    memcpy(&q1, (const u8*)buf.data() + 16, 16);
+    u32 ws = 0, we = 0, ws2 = 0, we2 = 0;
+    unicode_window_regs(nd, q0, q1, (u32)len, ws, we);
+    std::vector<u32> clean(64, 0);
+    memcpy(clean.data(), hay, len);
+    unicode_window_first_last(nd, (const u8*)clean.data(), (u32)len, ws2, we2);
+    out[0] = ws; out[1] = we; out[2] = ws2; out[3] = we2;
+    const u32 sp = ws ? ws - 1 : 0, m = we - sp;
+    auto ident = [](bool b) { return b; };
+    u32 s_regs = 0, s_mem = 0;
+#define RUN_REGS(SWL)                                                                                                  \
+    do {                                                                                                               \
+        constexpr int HR = SWL >= 16 ? SWL / 4 : SWL / 2, RB = (HR + 1) / 2;                                           \
+        u32 hw[RB], hb[RB + 1];                                                                                        \
+        load_window_regs<RB>(q0, q1, sp, m, hw);                                                                       \
+        for (int k = 0; k < RB; k++) hb[k] = hw[k];                                                                    \
+        hb[RB] = 0;                                                                                                    \
+        s_regs = dp_unicode_single_chunk_tr<SWL, HR>(nd, hb, m, sp == 0, cls, ident);                                  \
+        const bool utf8 = !unicode_has_cont_run4<SWL>((const u8*)clean.data() + sp, m);                                \
+        s_mem = utf8 ? dp_unicode_single_chunk_t<SWL, HR, true>(nd, (const u8*)clean.data() + sp, m, sp == 0, cls)    \
+                     : dp_unicode_single_chunk_t<SWL, HR, false>(nd, (const u8*)clean.data() + sp, m, sp == 0, cls);  \
+    } while (0)
+    if (m >= 1 && we >= ws && m <= (u32)swl / 2) {
+        if (swl == 64) RUN_REGS(64);
+        else if (swl == 32) RUN_REGS(32);
+        else if (swl == 16) RUN_REGS(16);
+        else return -1;
+    }
+#undef RUN_REGS
+    out[4] = s_regs; out[5] = s_mem;
+    return 0;
+}
+
 // the 0-typo unicode window the unicode scorer computes itself (dp_unicode.h, unicode_window_first_last)
 int kh_unicode_window(const u8* uc, const u8* uf, const u8* ulen, int rows, const u8* hay, int len, unsigned* out) {
     if (rows < 1 || rows > FZB_MAX_ROWS || len < 0) return -1;

@@ -38,6 +38,7 @@ def lib():
         _lib.kh_window.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_unicode.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_unicode_window.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
+        _lib.kh_unicode_regs.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_multi.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -71,6 +72,16 @@ def unicode_window(rows, hay):
     out = (C.c_uint32 * 2)()
     assert lib().kh_unicode_window(b"".join(r[0] for r in rows), b"".join(r[1] for r in rows), bytes(r[2] for r in rows), len(rows), hay, len(hay), out) == 0
     return int(out[0]), int(out[1])
+
+
+def unicode_regs(rows, hay, scoring, swl=64):
+    """a haystack of at most 32 bytes through the short-corpus kernel's register path: ((ws, we) of unicode_window_regs, (ws, we) of
+    unicode_window_first_last, score of the register path, score of the memory path over the same window)"""
+    out = (C.c_uint32 * 6)()
+    sc = (C.c_uint16 * 9)(*scoring)
+    rc = lib().kh_unicode_regs(b"".join(r[0] for r in rows), b"".join(r[1] for r in rows), bytes(r[2] for r in rows), len(rows), sc, hay, len(hay), swl, out)
+    assert rc == 0, rc
+    return (int(out[0]), int(out[1])), (int(out[2]), int(out[3])), int(out[4]), int(out[5])
 
 
 def dp_multi(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=64, form=6, is_u8=True):

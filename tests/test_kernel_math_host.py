@@ -358,6 +358,52 @@ def test_unicode_scorer_matches_the_oracle(swl):
     assert checked > 700 and checked_t > 400, (checked, checked_t)
 
 
+@pytest.mark.parametrize("swl", [64, 32, 16])
+def test_unicode_register_path_of_the_short_corpus_kernel(swl):
+    """k2u_dp_unicode_half's register path (haystacks of at most swl/2 <= 32 bytes, two 16-byte vectors): the SWAR window search
+    (unicode_window_regs) against the reference prefilter's window and against the byte-wise search, the window's bytes shifted out of the
+    vectors (whatever follows the haystack in them - the next haystack - must not leak in), the set-up that also decides the UTF-8 shortcut,
+    and the rows - against score_haystack_unicode over the trimmed window"""
+    rng = random.Random(4400 + swl)
+    alphabets = [list("abcAB_ -"), list("abéÉñÑüÜß/_ "), list("aب人äÄé_. 語"), list("إنماÉé_-ab"), list("a😀é人_b")]
+    accepted = 0
+    for it in range(4000):
+        alpha = rng.choice(alphabets)
+        n = rng.randint(1, 5)
+        needle = "".join(rng.choice(alpha) for _ in range(n))
+        cs = rng.random() < 0.3
+        hay = _rnd_utf8(rng, rng.randint(1, swl // 2), alpha)
+        chars = hay.decode()
+        if len(chars) >= n and rng.random() < 0.8:
+            pos = sorted(rng.sample(range(len(chars)), n))
+            lst = list(chars)
+            for q, c in zip(pos, needle):
+                lst[q] = c if rng.random() < 0.7 else c.swapcase() if len(c.swapcase().encode()) == len(c.encode()) else c
+            cand = "".join(lst).encode()
+            if 1 <= len(cand) <= swl // 2:
+                hay = cand
+        if not hay:
+            continue
+        ok, ws, we = O.prefilter(needle, hay, max_typos=0, case_sensitive=cs, unicode=True, lanes=swl)
+        if not ok:
+            continue
+        sc = DEF
+        if rng.random() < 0.4:
+            while True:
+                sc = [rng.randint(0, 30), rng.randint(0, 16), rng.randint(0, 16), rng.randint(0, 5), rng.randint(0, 20), rng.randint(0, 10), rng.randint(0, 10),
+                      rng.randint(0, 16), rng.randint(0, 10)]
+                if 2 * sc[3] <= sc[1]:  # LaunchCfg::cfu_ok
+                    break
+        rows = O.case_needle_unicode(needle, cs)
+        w_regs, w_mem, s_regs, s_mem = K.unicode_regs(rows, hay, sc, swl)
+        assert w_regs == (ws, we) and w_mem == (ws, we), (needle, hay, cs, w_regs, w_mem, (ws, we))
+        sp = ws - 1 if ws else 0
+        want = O.sw_score(needle, hay[sp:we], scoring=sc, case_sensitive=cs, include_prefix=(sp == 0), unicode=True, lanes=swl, is_u8=_fits(len(rows), sc))
+        assert s_regs == want and s_mem == want, (needle, hay, sc, cs, swl, s_regs, s_mem, want)
+        accepted += 1
+    assert accepted > 1200, accepted
+
+
 def test_unicode_window_equals_the_reference_prefilter_window():
     """unicode_window_first_last (dp_unicode.h) against the window the reference's unicode prefilter returns for an accepted haystack
     (src/prefilter/algo/unicode.rs:118-219), at the three lane widths (the window does not depend on the width)"""
