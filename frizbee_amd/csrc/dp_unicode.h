@@ -27,27 +27,41 @@ __device__ __forceinline__ u32 zflag4(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7
 // hold no haystack byte at all are not computed (see NR below).
 // 0-typo unicode window of an ACCEPTED haystack (src/prefilter/algo/unicode.rs:118-219, lane-free: see host.hip, unicode DFA):
 // start = the first byte position at which the FIRST needle scalar (either case variant) occurs, end = one past the last byte of
-// the LAST occurrence of the last needle scalar.  One thread scans its haystack through a sliding 8-byte register window.
+// the LAST occurrence of the last needle scalar.  Haystacks of any length: blocks of 32 bytes (two vectors, four blocks requested together)
+// through the SWAR position search of unicode_window_regs below - per needle scalar one word of match positions per block, validity
+// (position + scalar length <= L) as a mask.  (Round 2 walked the haystack a byte at a time with a dependent dword load per four bytes.)
+template <int CL>
+__device__ __forceinline__ u32 unicode_scalar_positions(const u32 (&w)[9], u32 cw);
+__device__ __forceinline__ u32 unicode_scalar_positions_cl(const u32 (&w)[9], u32 cw, u32 cl);
+__device__ __forceinline__ u32 unicode_valid_positions(u32 L, u32 len);
+__device__ __forceinline__ u32 unicode_first_pos(u32 y);
 __device__ __forceinline__ void unicode_window_first_last(const NeedleDev& nd, const u8* __restrict__ hay, u32 L, u32& ws, u32& we) {
     const u32 n = (u32)nd.rows;
     const u32 la = nd.ulen[0], lz = nd.ulen[n - 1];
-    const u32 ma = la >= 4 ? 0xFFFFFFFFu : ((1u << (8 * la)) - 1), mz = lz >= 4 ? 0xFFFFFFFFu : ((1u << (8 * lz)) - 1);
-    const u32 a0 = *(const u32*)nd.uc[0] & ma, a1 = *(const u32*)nd.uf[0] & ma;
-    const u32 z0 = *(const u32*)nd.uc[n - 1] & mz, z1 = *(const u32*)nd.uf[n - 1] & mz;
+    const u32 a0 = ((const u32*)nd.uc)[0], a1 = ((const u32*)nd.uf)[0], z0 = ((const u32*)nd.uc)[n - 1], z1 = ((const u32*)nd.uf)[n - 1];
     ws = 0xFFFFFFFFu;
     we = 0;
-    const u32* hp = (const u32*)hay;  // every haystack starts on a 16-byte boundary; >= 80 readable bytes follow the corpus
-    u32 cur = L ? hp[0] : 0u;
-    for (u32 p = 0; p < L; p += 4) {
-        const u32 nxt = p + 4 < L + 4 ? hp[(p >> 2) + 1] : 0u;
+    const uint4* vp = (const uint4*)hay;  // every haystack starts on a 16-byte boundary; >= 80 readable bytes follow the corpus
+    const u32 nblk = (L + 31) >> 5;
+    for (u32 b0 = 0; b0 < nblk; b0 += 4) {
+        uint4 qs[9];  // four blocks + the vector behind them (its first dword completes the last block's shifted views)
 #pragma unroll
-        for (u32 b = 0; b < 4; b++) {
-            const u32 v = __builtin_amdgcn_alignbyte(nxt, cur, b);
-            const u32 q = p + b;
-            if (ws == 0xFFFFFFFFu && q + la <= L && ((v & ma) == a0 || (v & ma) == a1)) ws = q;
-            if (q + lz <= L && ((v & mz) == z0 || (v & mz) == z1)) we = q + lz;
+        for (int k = 0; k < 9; k++) qs[k] = 32 * b0 + 16 * k < L + 4 ? vp[2 * b0 + k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const u32 b = b0 + t;
+            if (b >= nblk) break;
+            const u32 w[9] = {qs[2 * t].x, qs[2 * t].y, qs[2 * t].z, qs[2 * t].w, qs[2 * t + 1].x, qs[2 * t + 1].y, qs[2 * t + 1].z, qs[2 * t + 1].w, qs[2 * t + 2].x};
+            const u32 Lb = L - 32 * b;  // bytes of the haystack from this block on (>= 1)
+            u32 ya = unicode_scalar_positions_cl(w, a0, la);
+            if (a1 != a0) ya |= unicode_scalar_positions_cl(w, a1, la);
+            u32 yz = unicode_scalar_positions_cl(w, z0, lz);
+            if (z1 != z0) yz |= unicode_scalar_positions_cl(w, z1, lz);
+            ya &= unicode_valid_positions(Lb, la);
+            yz &= unicode_valid_positions(Lb, lz);
+            if (ws == 0xFFFFFFFFu && ya) ws = 32 * b + unicode_first_pos(ya);
+            if (yz) we = 32 * b + 31u - unicode_first_pos(__builtin_bitreverse32(yz)) + lz;
         }
-        cur = nxt;
     }
     if (ws == 0xFFFFFFFFu) ws = 0;  // cannot happen for a survivor of the exact filter
 }

@@ -460,6 +460,15 @@ int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, si
         if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[2], ngroups);
         if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[1], ngroups * 4);
         if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_vt, (size_t)ntiles * 8);
+        // the view is an accelerator, not part of the corpus: when the device has no room for it the corpus goes without (the filter then
+        // streams the canonical layout); any other error fails the upload
+        auto drop_view = [&]() {
+            if (d_vt) (void)hipFree(d_vt);
+            d_vt = nullptr;
+            for (int q = 0; q < 5; q++) { if (c->own_view[q]) (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
+            (void)hipGetLastError();
+        };
+        if (e == hipErrorOutOfMemory) { drop_view(); goto view_done; }
         if (e != hipSuccess) { if (d_vt) (void)hipFree(d_vt); return bail(e, "filter view"); }
         hipLaunchKernelGGL(k_up_view_sort, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u32*)c->own_ends, (u64)n, (u16*)c->own_view[4], (u16*)c->own_view[3],
                            (u8*)c->own_view[2], d_vt);
@@ -471,7 +480,10 @@ int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, si
             (void)hipFree(d_vt);
             for (int q = 1; q < 5; q++) { (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
         } else {
-            if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[0], view_bytes + 1024);
+            if (e == hipSuccess) {
+                e = fzb_dev_alloc(&c->own_view[0], view_bytes + 1024);
+                if (e == hipErrorOutOfMemory) { drop_view(); goto view_done; }
+            }
             if (e == hipSuccess) e = hipMemsetAsync(c->own_view[0], 0, view_bytes + 1024, nullptr);
             if (e != hipSuccess) { (void)hipFree(d_vt); return bail(e, "filter view"); }
             hipLaunchKernelGGL(k_up_view_fill, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u8*)c->own_bytes, (const u32*)c->own_ends, (u64)n, (const u16*)c->own_view[4],
@@ -486,6 +498,7 @@ int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, si
             c->dev.vperm = (const u16*)c->own_view[4];
         }
     }
+view_done:
     e = hipDeviceSynchronize();  // the temporaries are released below; the corpus is complete when the call returns
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return bail(e, "layout kernels");

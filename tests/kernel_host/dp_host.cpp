@@ -218,8 +218,9 @@ int kh_unicode_window(const u8* uc, const u8* uf, const u8* ulen, int rows, cons
         memcpy(nd.uf[r], uf + 4 * r, 4);
         nd.ulen[r] = ulen[r];
     }
-    std::vector<u32> buf((len + 96 + 3) / 4 + 4, 0);  // 4-byte aligned, zero tail as in the device layout
+    std::vector<u32> buf((len + 160 + 3) / 4 + 4, 0);  // 16-byte aligned start, the haystack's own padding zero as in the device layout ...
     memcpy(buf.data(), hay, len);
+    for (int i = (len + 15) / 16 * 16; i < len + 96; i++) ((u8*)buf.data())[i] = hay[i % (len ? len : 1)];  // ... and behind it the next haystack (here: the same bytes again)
     u32 ws = 0, we = 0;
     unicode_window_first_last(nd, (const u8*)buf.data(), (u32)len, ws, we);
     out[0] = ws;
