@@ -29,43 +29,79 @@ __device__ __forceinline__ void build_cls_table(u8* cls) {
     }
 }
 
-// 0-typo ASCII window: first occurrence of needle[0] (either case), 1 + last occurrence of needle[rows-1]
-// (what src/prefilter/algo/ascii.rs:6-72 returns; lane-width independent)
-__device__ __forceinline__ void window_first_last(const NeedleDev& nd, const u8* __restrict__ hay, u32 L, u32& ws, u32& we) {
-    const u32 rows = (u32)nd.rows;
-    const u32 a0 = nd.c[0] * 0x01010101u, a1 = nd.f[0] * 0x01010101u;
-    const u32 z0 = nd.c[rows - 1] * 0x01010101u, z1 = nd.f[rows - 1] * 0x01010101u;
-    ws = 0xFFFFFFFFu;
-    we = 0;
-    const uint4* vp = (const uint4*)hay;
-    const u32 nvec = (L + 15) >> 4;
-    // eight vectors are requested together and then examined: the scan needs every vector (last occurrence), and one load per
-    // loop trip would expose a full memory round trip per 16 bytes to a kernel that has only two waves per SIMD to cover it
-    for (u32 vb = 0; vb < nvec; vb += 8) {
-        uint4 qs[8];
+// ---- 32 byte positions as one word: bit 8j + k = byte j of dword k (position 4k + j) --------------------------------------------------
+// (the layout in which eight dwords' SWAR flags merge with one shift-or each; dp_cf.h's cf_window_first_last_regs introduced it)
+// positions q with q + len <= L
+__device__ __forceinline__ u32 pos32_valid(u32 L, u32 len) {
+    u32 v = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) qs[k] = vb + k < nvec ? vp[vb + k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const u32 v = vb + k;
-            if (v >= nvec) break;
-            const uint4 q = qs[k];
-            const u32 w4[4] = {q.x, q.y, q.z, q.w};
-            u32 mf = 0, ml = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                mf |= (zero_bytes4_dp(w4[j] ^ a0) | zero_bytes4_dp(w4[j] ^ a1)) << (4 * j);
-                ml |= (zero_bytes4_dp(w4[j] ^ z0) | zero_bytes4_dp(w4[j] ^ z1)) << (4 * j);
-            }
-            const u32 rem = L - 16 * v;
-            const u32 vm = rem >= 16 ? 0xFFFFu : ((1u << rem) - 1);
-            mf &= vm;
-            ml &= vm;
-            if (ws == 0xFFFFFFFFu && mf) ws = 16 * v + __builtin_ctz(mf);
-            if (ml) we = 16 * v + 32 - __builtin_clz(ml);
+    for (u32 j = 0; j < 4; j++) {
+        if (L >= len + j) {
+            const u32 kmax = (L - len - j) >> 2;  // positions j, j + 4, ..., j + 4 * kmax are valid
+            v |= (kmax >= 7 ? 0xFFu : ((2u << kmax) - 1)) << (8 * j);
         }
     }
-    if (ws == 0xFFFFFFFFu) ws = 0;  // cannot happen for a survivor of the exact filter
+    return v;
+}
+// ... for len == 1 (positions q < L) without the per-byte-lane loop: dwords below L/4 are valid in every byte lane, dword L/4 in L%4 of them
+__device__ __forceinline__ u32 pos32_valid1(u32 L) {
+    const u32 kf = min(L >> 2, 8u), rem = L & 3;
+    u32 v = ((1u << kf) - 1) * 0x01010101u;
+    if (kf < 8) v |= (0x01010101u & ((1u << (8 * rem)) - 1)) << kf;
+    return v;
+}
+// smallest position set in y (y != 0); the largest is 31 - pos32_first(bitreverse(y)): reversing maps bit 8j + k to 8(3-j) + (7-k)
+__device__ __forceinline__ u32 pos32_first(u32 y) {
+    u32 best = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const u32 f = (y >> (8 * j)) & 0xFF;
+        const u32 k = f ? (u32)__builtin_ctz(f) : 0x3FFFFFFFu;
+        best = min(best, 4 * k + j);
+    }
+    return best;
+}
+// 0x80 in every byte of x that is zero (exact)
+__device__ __forceinline__ u32 zero_flags4(u32 x) { return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u; }
+
+// 0-typo ASCII window of an ACCEPTED haystack of any length (src/prefilter/algo/ascii.rs:6-72): first occurrence of needle[0], one past
+// the last occurrence of needle[rows-1], either case.  Blocks of 32 bytes, four requested together (the scan needs every vector: last
+// occurrence); per block one word of positions per needle byte - a case-folded letter is ONE compare, (h | 0x20) == (c | 0x20) <=> h is c or
+// its other case - and what follows the haystack in its last block (its own zero padding, then the next haystack) is masked by position.
+// (Rounds 1-2 tested both cases of both bytes per dword and kept 16-bit masks per vector: 40 instructions per dword, now 12.)
+__device__ __forceinline__ void window_first_last(const NeedleDev& nd, const u8* __restrict__ hay, u32 L, u32& ws, u32& we) {
+    const u32 rows = (u32)nd.rows;
+    const u32 a = nd.c[0], af = nd.f[0], z = nd.c[rows - 1], zf = nd.f[rows - 1];
+    const u32 aor = a != af ? 0x20202020u : 0u, zor = z != zf ? 0x20202020u : 0u;
+    const u32 apat = (a != af ? (a | 0x20) : a) * 0x01010101u, zpat = (z != zf ? (z | 0x20) : z) * 0x01010101u;
+    // the block of the first / last occurrence and its position word are kept; the positions are extracted once, after the scan
+    u32 ya_keep = 0, yz_keep = 0, ba = 0, bz = 0;
+    const uint4* vp = (const uint4*)hay;
+    const u32 nblk = (L + 31) >> 5;
+    for (u32 b0 = 0; b0 < nblk; b0 += 4) {
+        uint4 qs[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) qs[k] = 32 * b0 + 16 * k < L ? vp[2 * b0 + k] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const u32 b = b0 + t;
+            if (b >= nblk) break;
+            const u32 w8[8] = {qs[2 * t].x, qs[2 * t].y, qs[2 * t].z, qs[2 * t].w, qs[2 * t + 1].x, qs[2 * t + 1].y, qs[2 * t + 1].z, qs[2 * t + 1].w};
+            u32 ya = 0, yz = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                ya |= zero_flags4((w8[k] | aor) ^ apat) >> (7 - k);
+                yz |= zero_flags4((w8[k] | zor) ^ zpat) >> (7 - k);
+            }
+            const u32 valid = pos32_valid1(L - 32 * b);
+            ya &= valid;
+            yz &= valid;
+            if (ya_keep == 0 && ya) { ya_keep = ya; ba = b; }
+            if (yz) { yz_keep = yz; bz = b; }
+        }
+    }
+    ws = ya_keep ? 32 * ba + pos32_first(ya_keep) : 0u;  // (no occurrence cannot happen for a survivor of the exact filter)
+    we = yz_keep ? 32 * bz + 32u - pos32_first(__builtin_bitreverse32(yz_keep)) : 0u;
 }
 
 // The same for a haystack of at most 32 bytes whose two 16-byte vectors are already in registers (the DP kernel's

@@ -39,8 +39,7 @@ __device__ __forceinline__ void unicode_window_first_last(const NeedleDev& nd, c
     const u32 n = (u32)nd.rows;
     const u32 la = nd.ulen[0], lz = nd.ulen[n - 1];
     const u32 a0 = ((const u32*)nd.uc)[0], a1 = ((const u32*)nd.uf)[0], z0 = ((const u32*)nd.uc)[n - 1], z1 = ((const u32*)nd.uf)[n - 1];
-    ws = 0xFFFFFFFFu;
-    we = 0;
+    u32 ya_keep = 0, yz_keep = 0, ba = 0, bz = 0;  // block and position word of the first / last occurrence; extracted after the scan
     const uint4* vp = (const uint4*)hay;  // every haystack starts on a 16-byte boundary; >= 80 readable bytes follow the corpus
     const u32 nblk = (L + 31) >> 5;
     for (u32 b0 = 0; b0 < nblk; b0 += 4) {
@@ -59,11 +58,12 @@ __device__ __forceinline__ void unicode_window_first_last(const NeedleDev& nd, c
             if (z1 != z0) yz |= unicode_scalar_positions_cl(w, z1, lz);
             ya &= unicode_valid_positions(Lb, la);
             yz &= unicode_valid_positions(Lb, lz);
-            if (ws == 0xFFFFFFFFu && ya) ws = 32 * b + unicode_first_pos(ya);
-            if (yz) we = 32 * b + 31u - unicode_first_pos(__builtin_bitreverse32(yz)) + lz;
+            if (ya_keep == 0 && ya) { ya_keep = ya; ba = b; }
+            if (yz) { yz_keep = yz; bz = b; }
         }
     }
-    if (ws == 0xFFFFFFFFu) ws = 0;  // cannot happen for a survivor of the exact filter
+    ws = ya_keep ? 32 * ba + unicode_first_pos(ya_keep) : 0u;  // (no occurrence cannot happen for a survivor of the exact filter)
+    we = yz_keep ? 32 * bz + 31u - unicode_first_pos(__builtin_bitreverse32(yz_keep)) + lz : 0u;
 }
 
 template <int SWL, int REAL = SWL / 2>
@@ -537,28 +537,8 @@ __device__ __forceinline__ u32 unicode_scalar_positions_cl(const u32 (&w)[9], u3
         default: return unicode_scalar_positions<4>(w, cw);
     }
 }
-// positions q = 4k + j with q + len <= L, in the merged layout (bit 8j + k)
-__device__ __forceinline__ u32 unicode_valid_positions(u32 L, u32 len) {
-    u32 v = 0;
-#pragma unroll
-    for (u32 j = 0; j < 4; j++) {
-        if (L >= len + j) {
-            const u32 kmax = (L - len - j) >> 2;  // positions j, j + 4, ..., j + 4 * kmax are valid
-            v |= (kmax >= 7 ? 0xFFu : ((2u << kmax) - 1)) << (8 * j);
-        }
-    }
-    return v;
-}
-__device__ __forceinline__ u32 unicode_first_pos(u32 y) {  // smallest position in the merged layout (y != 0)
-    u32 best = 0xFFFFFFFFu;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const u32 f = (y >> (8 * j)) & 0xFF;
-        const u32 k = f ? (u32)__builtin_ctz(f) : 0x3FFFFFFFu;
-        best = min(best, 4 * k + j);
-    }
-    return best;
-}
+__device__ __forceinline__ u32 unicode_valid_positions(u32 L, u32 len) { return pos32_valid(L, len); }
+__device__ __forceinline__ u32 unicode_first_pos(u32 y) { return pos32_first(y); }
 __device__ __forceinline__ void unicode_window_regs(const NeedleDev& nd, const uint4& q0, const uint4& q1, u32 L, u32& ws, u32& we) {
     const u32 n = (u32)nd.rows;
     const u32 la = nd.ulen[0], lz = nd.ulen[n - 1];

@@ -247,10 +247,20 @@ int kh_dp_multi(const u8* needle, int n, int case_sensitive, int is_u8, const u1
 // the 0-typo window of a haystack of at most 32 bytes: the short kernel's merged-flag-word search against dp_body.h's (both forms
 // of src/prefilter/algo/ascii.rs:6-72); out = {ws, we} of each
 int kh_window(const u8* needle, int n, int case_sensitive, const u8* hay, int len, unsigned* out) {
-    if (n < 1 || n > FZB_MAX_ROWS || len < 0 || len > 32) return -1;
+    if (n < 1 || n > FZB_MAX_ROWS || len < 0 || len > 4096) return -1;
     static const u16 sc[9] = {12, 6, 5, 1, 12, 4, 4, 8, 4};
     NeedleDev nd;
     fill_needle(nd, needle, n, case_sensitive, sc);
+    if (len > 32) {  // any length: the general search (window_first_last) only; out[2..3] repeat it.  Device layout: the haystack's own
+        // padding to 16 is zero, behind it lies the next haystack (here: the same bytes again)
+        std::vector<u32> buf((len + 160 + 3) / 4 + 4, 0);
+        memcpy(buf.data(), hay, len);
+        for (int i = (len + 15) / 16 * 16; i < len + 96; i++) ((u8*)buf.data())[i] = hay[i % len];
+        window_first_last(nd, (const u8*)buf.data(), (u32)len, out[0], out[1]);
+        out[2] = out[0];
+        out[3] = out[1];
+        return 0;
+    }
     u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     memcpy(w, hay, (size_t)len);
     const uint4 q0 = make_uint4(w[0], w[1], w[2], w[3]), q1 = make_uint4(w[4], w[5], w[6], w[7]);

@@ -358,6 +358,32 @@ def test_unicode_scorer_matches_the_oracle(swl):
     assert checked > 700 and checked_t > 400, (checked, checked_t)
 
 
+def test_ascii_window_of_any_length_equals_the_reference_prefilter_window():
+    """window_first_last (dp_body.h: 32-byte blocks, one compare per case-folded needle byte, positions masked behind the haystack's end)
+    against the window the reference's ASCII prefilter returns for an accepted haystack (src/prefilter/algo/ascii.rs:6-72), haystacks of
+    33 - 700 bytes with the next haystack's bytes behind them"""
+    rng = random.Random(515)
+    accepted = 0
+    for it in range(4000):
+        alpha = rng.choice([b"ab", b"abcA_", b"abcdefABCDEF_-/ 019", bytes(range(33, 127))])
+        n = rng.randint(1, 8)
+        needle = _rnd(rng, n, alpha)
+        cs = rng.random() < 0.3
+        L = rng.choice([rng.randint(33, 70), rng.randint(33, 160), rng.randint(120, 700)])
+        hay = bytearray(_rnd(rng, L, alpha + b"xyzw" * 3))
+        if rng.random() < 0.7:
+            for q, c in zip(sorted(rng.sample(range(L), n)), needle):
+                hay[q] = c
+        hay = bytes(hay)
+        ok, ws, we = O.prefilter(needle, hay, 0, cs, False, 64)
+        if not ok:
+            continue
+        accepted += 1
+        got, _ = K.window(needle, hay, cs)
+        assert got == (ws, we), (needle, hay, cs, got, (ws, we))
+    assert accepted > 1500, accepted
+
+
 @pytest.mark.parametrize("swl", [64, 32, 16])
 def test_unicode_register_path_of_the_short_corpus_kernel(swl):
     """k2u_dp_unicode_half's register path (haystacks of at most swl/2 <= 32 bytes, two 16-byte vectors): the SWAR window search
