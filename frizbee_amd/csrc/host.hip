@@ -1148,12 +1148,22 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // form and a needle without NUL (cf_ok includes pad_ok)
         static const bool no_tail_classes = getenv("FZB_NO_TAIL_CLASSES") != nullptr;  // comparison knob: every last chunk computed in full
         const int split = classes && !no_wide && mmode == 2 && !no_tail_classes;
-        bool fork = classes && !no_wide && !no_overlap;
+        // the three class launches and the multi-chunk scorer as ONE launch (k2_classes_all: the grid cut into four slices) instead of four
+        // launches on two streams: on a list of a million items each of the four is a single round of single items whose latencies and launch
+        // boundaries add up along the stream (paths-shaped list 128 -> 102 us, a 2 M-item ragged list 143 -> 116 us), on the 12.5 M-item shard
+        // the two are equal (0.447 ms).  FZB_SMALL_LIST=n keeps the four launches for lists of n haystacks and more (0: always).
+        static const u32 small_list = getenv("FZB_SMALL_LIST") ? (u32)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
+        const bool all_in_one = split && cnt < small_list;
+        bool fork = classes && !no_wide && !no_overlap && !all_in_one;
         if (fork && ensure_aux_stream(m) != FZB_OK) {  // no second stream: everything on the caller's stream (the error text is dropped with the fallback)
             fork = false;
             fzb_clear_error();
         }
-        if (classes)
+        if (classes && all_in_one) {
+            fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
+                                  (u32)w.cap_cls, cus, st, 1, split);
+            fzb_launch_classes_all(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, cnt_c, nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, cus, st);
+        } else if (classes)
             fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
                                   (u32)w.cap_cls, cus, st, fork ? 1 : 0, split);
         else
@@ -1171,7 +1181,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             FZB_STAGE("dp classes + dp_multi (second stream)");
         }
         if (!no_wide) {
-            if (!fork) {
+            if (!fork && !all_in_one) {
                 if (split) fzb_launch_dp_multi_classes(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, &cnt_c[12], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, st);
                 else fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, st);
                 FZB_STAGE("dp_multi");

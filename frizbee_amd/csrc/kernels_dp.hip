@@ -348,18 +348,17 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
     }
 }
 
+// (vblock of vgrid: the workgroup's index among those that walk this list - blockIdx / gridDim in the class's own launch, a slice of the grid
+// in k2_classes_all)
 template <int SWL, bool UPPER, int REAL, typename ET>
-__global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3 : 2)) void k2b_dp_class(
-    const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win,
-    const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out) {
+__device__ __forceinline__ void dp_class_body(const CfTables& tab, u32 vblock, u32 vgrid, const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+                                              const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ list, const u32* __restrict__ n_list_ptr,
+                                              const NeedleDev& nd, fzb_match_rec* __restrict__ out) {
     constexpr int NB = SWL / 4;           // window dwords of a full chunk
     constexpr int NBR = (REAL + 1) / 2;   // dwords that can hold window bytes of this class
-    __shared__ CfTables tab;
-    cf_build_tables<UPPER>(nd, tab);
-    __syncthreads();
     const u32 M = __builtin_amdgcn_readfirstlane(*n_list_ptr);
-    const u32 stride = gridDim.x * blockDim.x;
-    const u32 q0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 stride = vgrid * blockDim.x;
+    const u32 q0 = vblock * blockDim.x + threadIdx.x;
     // two-deep pipeline: (list entry -> haystack index, window, span) one item ahead of (window bytes), which are one item ahead of the DP
     auto load_meta = [&](u32 q, u32& j, u32& li, u32& sp, u32& m, u32& L, u64& s) {
         j = 0; li = 0; sp = 0; m = 0; L = 0; s = 0;
@@ -428,6 +427,16 @@ __global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3
         j_n = j_f; li_n = li_f; sp_n = sp_f; m_n = m_f; ex_n = ex_f; s_n = s_f;
         prio.k2 = (prio.k2 | 1u) + 1;  // next item
     }
+}
+
+template <int SWL, bool UPPER, int REAL, typename ET>
+__global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3 : 2)) void k2b_dp_class(
+    const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win,
+    const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out) {
+    __shared__ CfTables tab;
+    cf_build_tables<UPPER>(nd, tab);
+    __syncthreads();
+    dp_class_body<SWL, UPPER, REAL, ET>(tab, blockIdx.x, gridDim.x, bytes, ends, first, index_offset, items, win, list, n_list_ptr, nd, out);
 }
 
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
@@ -535,16 +544,13 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ 
 // one persistent walk over the concatenation, widest class first (a slot's later items are its cheaper ones); a wave computes the last chunk
 // with the class of its first lane - the widest among its 64 (only the three waves that straddle a list boundary compute more than needed)
 template <int SWL, bool UPPER, typename ET>
-__global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
-                                                       const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts,
-                                                       const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
-    __shared__ CfTables tab;
-    cf_build_tables<UPPER>(nd, tab);
-    __syncthreads();
+__device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock, u32 vgrid, const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+                                                 const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride,
+                                                 const u32* __restrict__ counts, const NeedleDev& nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
     // positions [0, e3) class 3 (the whole last chunk), [e3, e2) class 2, [e2, e1) class 1, [e1, e0) class 0
     const u32 e3 = __builtin_amdgcn_readfirstlane(counts[3]), e2 = e3 + __builtin_amdgcn_readfirstlane(counts[2]), e1 = e2 + __builtin_amdgcn_readfirstlane(counts[1]),
               e0 = e1 + __builtin_amdgcn_readfirstlane(counts[0]);
-    const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 nthreads = vgrid * blockDim.x, gtid = vblock * blockDim.x + threadIdx.x;
     for (u32 q = gtid; q < e0; q += nthreads) {
         const u32 cls = q < e3 ? 3u : q < e2 ? 2u : q < e1 ? 1u : 0u;
         const u32 base = cls == 3 ? 0u : cls == 2 ? e3 : cls == 1 ? e2 : e1;
@@ -571,6 +577,53 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(const u8* __restrict__
         rec.exact = exact ? 1 : 0;
         rec.valid = 0;
         out[j] = rec;
+    }
+}
+
+template <int SWL, bool UPPER, typename ET>
+__global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
+                                                       const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts,
+                                                       const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
+    __shared__ CfTables tab;
+    cf_build_tables<UPPER>(nd, tab);
+    __syncthreads();
+    dp_multi_tc_body<SWL, UPPER, ET>(tab, blockIdx.x, gridDim.x, bytes, ends, first, index_offset, items, win, lists, list_stride, counts, nd, out, capacity, scratch);
+}
+
+// Small lists: the three single-chunk classes and the multi-chunk tail classes in ONE launch - the grid is cut into four slices, a workgroup
+// runs the body of its slice (widest work first).  On a list of a million items every one of the four launches is a single round of single
+// items, so their latencies (and launch boundaries) add up along the stream; here they run side by side.  Registers follow the widest body
+// (two waves per SIMD), which a small list does not notice.
+template <int SWL, bool UPPER, typename ET>
+__global__ __launch_bounds__(128, 2) void k2_classes_all(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
+                                                      const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counters,
+                                                      const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch, u32 gm, u32 gc) {
+    __shared__ CfTables tab;
+    cf_build_tables<UPPER>(nd, tab);
+    __syncthreads();
+    u32 b = blockIdx.x;
+    if (b < gm) { dp_multi_tc_body<SWL, UPPER, ET>(tab, b, gm, bytes, ends, first, index_offset, items, win, lists, list_stride, &counters[12], nd, out, capacity, scratch); return; }
+    b -= gm;
+    if (b < gc) { dp_class_body<SWL, UPPER, SWL / 2, ET>(tab, b, gc, bytes, ends, first, index_offset, items, win, lists + 2 * (size_t)list_stride, &counters[10], nd, out); return; }
+    b -= gc;
+    if (b < gc) { dp_class_body<SWL, UPPER, 3 * SWL / 8, ET>(tab, b, gc, bytes, ends, first, index_offset, items, win, lists + (size_t)list_stride, &counters[9], nd, out); return; }
+    b -= gc;
+    dp_class_body<SWL, UPPER, SWL / 4, ET>(tab, b, gc, bytes, ends, first, index_offset, items, win, lists, &counters[8], nd, out);
+}
+
+// gm workgroups for the multi-chunk lists (the scratch slab is sized for them: ensure_dp_scratch), gc for each single-chunk class
+void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* lists, u32 list_stride, const u32* counters,
+                            const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int gm, int gc, hipStream_t st) {
+    bool upper = false;
+    for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
+#define FZB_K2A(SWL, U, ET) hipLaunchKernelGGL((k2_classes_all<SWL, U, ET>), dim3(gm + 3 * gc), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc)
+#define FZB_K2A_ET(SWL, U) do { if (c.ends_u64) FZB_K2A(SWL, U, u64); else FZB_K2A(SWL, U, u32); } while (0)
+#define FZB_K2A_U(SWL) do { if (upper) FZB_K2A_ET(SWL, true); else FZB_K2A_ET(SWL, false); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2A_U(64); break;
+        case 32: FZB_K2A_U(32); break;
+        case 16: FZB_K2A_U(16); break;
+        default: FZB_K2A_U(8); break;
     }
 }
 

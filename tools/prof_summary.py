@@ -3,7 +3,7 @@
 (the bench harness's torch data-generation kernels are dropped).  Usage: prof_summary.py kernel_stats.csv out.csv"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-mine = [r for r in rows if any(k in r["Name"] for k in ("k1_", "k12_", "k_fused", "k2a_", "k2b_", "k2w_", "k2c_", "k2d_", "k2u_", "k_compact", "k_sort", "k_reverse", "k_literal", "k_join", "k_flag", "k_records", "k_identity", "k_copy_records"))]
+mine = [r for r in rows if any(k in r["Name"] for k in ("k1_", "k12_", "k_fused", "k2a_", "k2b_", "k2w_", "k2c_", "k2d_", "k2u_", "k2_classes", "k_compact", "k_sort", "k_reverse", "k_literal", "k_join", "k_flag", "k_records", "k_identity", "k_copy_records"))]
 tot = sum(float(r["TotalDurationNs"]) for r in mine) or 1.0
 with open(sys.argv[2], "w", newline="") as f:
     w = csv.writer(f)
