@@ -134,3 +134,20 @@ if "INDICES" in which:
             print(json.dumps(dict(config=f"C2 list, positions for the top {k} of match_list, max_typos={typos}", selection=k, records=len(r),
                                   c_call_ms=sorted(tc)[2] * 1e3, python_call_ms=sorted(ts)[2] * 1e3, haystacks_per_s=k / sorted(tc)[2])), flush=True)
     del cp, flat, ends
+if "PATHSVAR" in which:
+    # the other columns of the reference's Chromium table (BENCHMARKS.md:59-65): All Scores (max_typos None), 1 / 2 / 3 typos
+    npaths = 1_406_941
+    data, ends = synth.paths_corpus(b"linux", npaths, device=dev)
+    cp = F.Corpus(packed=(data, ends))
+    for label, mt in (("All Scores (max_typos None)", None), ("1 typo", 1), ("2 typos", 2), ("3 typos", 3)):
+        run(f"paths-shaped 1.4M 'linux' {label}", "linux", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, npaths, steps=5)
+    del cp
+if "ARABIC" in which:
+    # the shape of the reference's UTF-8 benchmark (BENCHMARKS.md "Arabic": 285 587 sentences, needle of two Arabic letters)
+    t0 = time.perf_counter(); data, ends = synth.arabic_corpus(); tgen = time.perf_counter() - t0
+    cp = F.Corpus(packed=(data, ends))
+    lens = np.diff(np.concatenate([[0], ends.astype(np.int64)]))
+    print(json.dumps(dict(config="arabic-shaped list", items=int(len(ends)), total_bytes=int(ends[-1]), median_len=float(np.median(lens)), mean_len=float(lens.mean()), std_len=float(lens.std()), gen_s=tgen)), flush=True)
+    for label, mt in (("typos0", 0), ("All Scores (max_typos None)", None), ("1 typo", 1)):
+        run(f"arabic-shaped 285k {label}", "إن", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, int(len(ends)), steps=5)
+    del cp

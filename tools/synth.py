@@ -154,3 +154,43 @@ def utf8_corpus(n: int, length: int = 32, seed=12345, needle="إنما", full=0.
         assert len(b) == length, (len(b), length)
         out += b
     return np.frombuffer(bytes(out), dtype=np.uint8).copy(), (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(length))
+
+
+def arabic_corpus(n: int = 285_587, needle="إن", median=37.0, mean=43.18, full=0.07934, partial=0.59514, seed=12345, max_bytes=600):
+    """The shape of the reference's UTF-8 benchmark (BENCHMARKS.md: "Arabic" - 285 587 sentences, needle "إن", 7.9 % matching, 59.5 % partial,
+    median 37 bytes / 21 chars, mean 43.18 bytes, 2 bytes per character) produced synthetically: byte lengths ~ LogNormal with that median and
+    mean (sigma^2 = 2 ln(mean / median); its standard deviation comes out at 26 bytes where the real set has 33), Arabic letters and spaces,
+    Full / Partial / None classes as in the reference's generator.  Host-side (numpy); returns (packed uint8 numpy, ends uint64 numpy)."""
+    rng = np.random.default_rng(seed + 7)
+    sigma = float(np.sqrt(2.0 * np.log(mean / median)))
+    lens = np.clip(np.round(rng.lognormal(np.log(median), sigma, n)), 2, max_bytes).astype(np.int64)
+    needle_chars = list(needle)
+    arabic = [chr(c) for c in range(0x0621, 0x064B) if chr(c) not in needle_chars]
+    u = rng.random(n)
+    out = bytearray()
+    ends = np.empty(n, dtype=np.uint64)
+    for i in range(n):
+        is_partial = u[i] < partial
+        is_full = (not is_partial) and u[i] < partial + full
+        emb = list(needle_chars) if is_full else ([needle_chars[int(rng.integers(len(needle_chars)))]] if is_partial and rng.random() < 0.5 else [])
+        budget = int(lens[i]) - 2 * len(emb)
+        fill = []
+        while budget > 0:
+            if budget >= 2 and rng.random() < 0.85:
+                fill.append(arabic[int(rng.integers(len(arabic)))]); budget -= 2
+            else:
+                fill.append(" "); budget -= 1
+        total = len(emb) + len(fill)
+        take = np.zeros(total, dtype=bool)
+        if emb:
+            take[np.sort(rng.choice(total, size=len(emb), replace=False))] = True
+        ei = fi = 0
+        units = []
+        for t in take:
+            if t:
+                units.append(emb[ei]); ei += 1
+            else:
+                units.append(fill[fi]); fi += 1
+        out += "".join(units).encode()
+        ends[i] = len(out)
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy(), ends
