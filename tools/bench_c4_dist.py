@@ -91,7 +91,7 @@ def main():
     # end to end: device sort per rank, gather of the sorted runs, k-way merge on the root
     res = {}
     if use_dist:
-        ex = ShardExchange(ShardExchange.plan(k_local, device=dev), dev)
+        ex = ShardExchange(ShardExchange.plan(k_local, margin=1.05, device=dev), dev)
         fence(); t0 = time.perf_counter()
         for _ in range(max(3, args.steps // 2)):
             m.match_list_sorted_device(corpus, ex.records_ptr(0), ex.cap, ex.count_ptr(0))

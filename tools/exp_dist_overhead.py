@@ -1,0 +1,75 @@
+"""Where the per-step cost of bench.py's N > 1 path comes from, measured with ONE rank on one GPU (RCCL process group of size 1):
+the same loop as bench.py's step() - wait, pipeline, post - with the CPU-side enqueue time separated from the total, and the pipeline /
+the exchange alone.  Usage: python tools/exp_dist_overhead.py [steps]"""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
+import torch, torch.distributed as dist
+import synth, frizbee_amd as F
+from frizbee_amd.distributed import ShardExchange
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+n = 10_000_000
+flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
+flat[: n * 32].view(n, 32).copy_(synth.make_rows(b"deadbe", n, 32, seed=12345, device=dev))
+ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
+corpus = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), ends_are_u64=False, keep=(flat, ends), max_len=32, uniform_len=32)
+m = F.Matcher("deadbe", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64))
+out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev)
+cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+side = torch.cuda.Stream(dev)
+torch.cuda.synchronize(dev)
+torch.cuda.set_stream(side)
+stream = side.cuda_stream
+m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=stream)
+torch.cuda.synchronize(dev)
+ex = ShardExchange(ShardExchange.plan(int(cnt[0].item()), device=dev), dev)
+for s_ in range(8):
+    ex.wait(s_ & 1)
+    m.match_list_device(corpus, ex.records_ptr(s_ & 1), ex.cap, ex.count_ptr(s_ & 1), stream=stream)
+    ex.post(s_ & 1)
+ex.collect(0); ex.collect(1)
+
+
+def timed(fn, k=K):
+    for i in range(5): fn(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(k): fn(i)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    return t_enq / k * 1e6, (time.perf_counter() - t0) / k * 1e6
+
+
+def step_full(i):
+    s = i & 1
+    ex.wait(s)
+    m.match_list_device(corpus, ex.records_ptr(s), ex.cap, ex.count_ptr(s), stream=stream)
+    ex.post(s)
+
+
+def step_pipeline(i):
+    s = i & 1
+    m.match_list_device(corpus, ex.records_ptr(s), ex.cap, ex.count_ptr(s), stream=stream)
+
+
+def step_exchange(i):
+    s = i & 1
+    ex.wait(s)
+    ex.post(s)
+
+
+res = {}
+for name, fn in (("pipeline_only", step_pipeline), ("exchange_only", step_exchange), ("pipeline_and_exchange", step_full)):
+    enq, tot = timed(fn)
+    res[name] = {"cpu_enqueue_us_per_step": round(enq, 1), "total_us_per_step": round(tot, 1)}
+    ex.collect(0); ex.collect(1)
+print(json.dumps(res))
+dist.barrier()
+dist.destroy_process_group()
