@@ -65,8 +65,29 @@ def step_exchange(i):
     ex.post(s)
 
 
+evs = [torch.cuda.Event(enable_timing=False) for _ in range(2)]
+xs = torch.cuda.Stream(dev)
+
+
+def step_pipeline_event(i):  # the pipeline + ONE event record on the scoring stream per step (what torch's process group does at a collective)
+    s = i & 1
+    m.match_list_device(corpus, ex.records_ptr(s), ex.cap, ex.count_ptr(s), stream=stream)
+    evs[s].record(side)
+
+
+def step_full_side_stream(i):  # the exchange issued from a second stream that waits for the scoring stream through our own event
+    s = i & 1
+    ex.wait(s)
+    m.match_list_device(corpus, ex.records_ptr(s), ex.cap, ex.count_ptr(s), stream=stream)
+    evs[s].record(side)
+    with torch.cuda.stream(xs):
+        xs.wait_event(evs[s])
+        ex.post(s)
+
+
 res = {}
-for name, fn in (("pipeline_only", step_pipeline), ("exchange_only", step_exchange), ("pipeline_and_exchange", step_full)):
+for name, fn in (("pipeline_only", step_pipeline), ("pipeline_plus_event_record", step_pipeline_event), ("exchange_only", step_exchange), ("pipeline_and_exchange", step_full),
+                 ("pipeline_and_exchange_from_side_stream", step_full_side_stream)):
     enq, tot = timed(fn)
     res[name] = {"cpu_enqueue_us_per_step": round(enq, 1), "total_us_per_step": round(tot, 1)}
     ex.collect(0); ex.collect(1)
