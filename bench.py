@@ -367,7 +367,7 @@ def main():
         # set-up (untimed): one synchronous pass sizes the exchange buffers every rank agrees on
         m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=stream, index_offset=index_offset)
         torch.cuda.synchronize(dev)
-        ex = ShardExchange(ShardExchange.plan(int(cnt[0].item()), margin=1.05, device=dev)  # (the bench repeats ONE query: the count does not move), dev)
+        ex = ShardExchange(ShardExchange.plan(int(cnt[0].item()), margin=1.05, device=dev), dev)  # (the bench repeats ONE query: the count does not move)
         # (still set-up: RCCL builds its channels and rings lazily on the first few collectives of a communicator - several
         # milliseconds each - so a handful of exchanges is run here, before the W warm-up steps of the contract)
         for s_ in range(8):

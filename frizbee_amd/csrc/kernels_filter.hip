@@ -343,21 +343,15 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ byte
 // nor removing a quarter of the loop's instructions moved the kernel, so it is bound by its cache transactions: every 16-byte piece of a
 // lane is its own request, ~35 lines per wave instruction.)
 // ---------------------------------------------------------------------------------------------------
-// PERM (round 3): `bytes` / `ends` are the corpus' length-sorted filter view (CorpusDev::fbytes / fends; `first` a multiple of the tile
-// size): the haystack at sorted position g of a tile came from position perm[g] of that tile, where its decision bit belongs - collected
-// in LDS (atomic-or) and written per tile.  A wave's 64 lanes then hold haystacks of one vector-count class: the loop below runs no
-// lookups for lanes whose haystack has ended.
-template <typename ET, bool SAN, bool PERM = false>
+template <typename ET, bool SAN>
 __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                                            const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
-                                                           u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, const u16* __restrict__ perm = nullptr) {
+                                                           u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
-    // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter (and, PERM, the tile's 32
-    // words of decision bits) live behind the table
+    // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
-    u32* const s_bits = &s_cnt + 4;
     const int tid = threadIdx.x;
     dfa_require_lds_base0(dfa);
     dfa_load_lds(dfa, dfa_g, rows);
@@ -365,7 +359,6 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
     const u32 deadv = dead * 0x01010101u;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (tid == 0) s_cnt = 0;
-        if (PERM && tid < 32) s_bits[tid] = 0;
         __syncthreads();
         u32 cnt = 0;
 #pragma unroll 1
@@ -373,11 +366,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
             const u32 li = tile * FZB_TILE + sub * 256 + tid;
             u64 hs = 0;
             u32 hl = 0;
-            u32 orig = 0;
-            if (li < count) {
-                haystack_span(ends, first + li, hs, hl);
-                if (PERM) orig = perm[first + li];
-            }
+            if (li < count) haystack_span(ends, first + li, hs, hl);
             const uint4* vp = (const uint4*)(bytes + hs);
             u32 st = 0;
             for (u32 v0 = 0; 16 * v0 < hl; v0 += 8) {  // rounds of 8 vectors (one round for haystacks up to 128 bytes)
@@ -407,25 +396,13 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
                 }
             }
             const bool matched = li < count && hl >= min_len && st >= acc_lo;
-            if (PERM) {
-                if (matched) atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
-                continue;
-            }
             const u64 b = __ballot(matched);
             if (lane_id() == 0) {
                 bitmap[(tile * FZB_TILE + sub * 256) / 64 + (tid >> 6)] = b;
                 cnt += __popcll(b);
             }
         }
-        if (PERM) {
-            __syncthreads();
-            if (tid < FZB_TILE / 64) {
-                const u64 word = (u64)s_bits[2 * tid] | ((u64)s_bits[2 * tid + 1] << 32);
-                bitmap[(size_t)tile * (FZB_TILE / 64) + tid] = word;
-                cnt = (u32)__popcll(word);
-            }
-            if (tid < FZB_TILE / 64 && cnt) atomicAdd(&s_cnt, cnt);
-        } else if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
         __syncthreads();
         if (tid == 0) tile_counts[tile] = s_cnt;
         __syncthreads();
@@ -433,7 +410,7 @@ __global__ __launch_bounds__(256) void k1_dfa_ragged_burst(const u8* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K1-DFA for ragged lists over the CLASS-COMPOSITE automaton (round 3).  The four structural variants below left the burst form's time
+// K1-DFA for ragged lists over the CLASS-COMPOSITE automaton (round 3).  Four structural variants (profiles/r03_ragged_filter_variants.txt) left the burst form's time
 // where it was, which pointed at the one thing they share: every wave is a serial chain of one dependent LDS lookup PER BYTE (~100 cycles
 // each under load), and with all eight wave slots of a SIMD taken the throughput is waves / chain latency.  Here the chain has one link
 // per G bytes: the automaton only distinguishes K byte CLASSES (bytes with identical columns: the needle's letters in either case, and
@@ -623,496 +600,9 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// K1-DFA for ragged lists, software-pipelined burst form (round 3).  Measured: neither removing the dead lookups (length-sorted view),
-// nor making every load fully coalesced (cooperative form below), nor staging in LDS moves the burst form's ~235 us - every wave runs
-// span loads -> vector loads -> a serial chain of DFA lookups one after the other, all eight wave slots of a SIMD are taken, and the
-// throughput is (waves in flight) x (work per wave) / (that serial latency).  Here a thread has THREE haystacks in flight: the DFA runs
-// over the vectors of haystack i (registers) while the vectors of haystack i+1 and the end offsets of haystack i+2 are on their way.
-// The price is registers (two sets of eight vectors): fewer waves per SIMD, each of them never waiting for memory.
-// ---------------------------------------------------------------------------------------------------
-template <typename ET, bool SAN, bool PERM>
-__global__ __launch_bounds__(256) void k1_dfa_ragged_pipe(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                          const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
-                                                          u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, const u16* __restrict__ perm) {
-    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
-    extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
-    u32* const s_bits = &s_cnt + 4;
-    const int tid = threadIdx.x;
-    dfa_require_lds_base0(dfa);
-    dfa_load_lds(dfa, dfa_g, rows);
-    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    const u32 deadv = dead * 0x01010101u;
-    // item = (tile, sub-pass): this workgroup's items in order; li = the thread's haystack of the item (>= count: none)
-    auto item_li = [&](u32 it) -> u32 {
-        const u32 tile = blockIdx.x + (it >> 2) * gridDim.x;
-        return tile < ntiles ? tile * FZB_TILE + (it & 3) * 256 + tid : 0xFFFFFFFFu;
-    };
-    auto load_span = [&](u32 li, u64& hs, u32& hl, u32& orig) {
-        hs = 0; hl = 0; orig = 0;
-        if (li < count) {
-            haystack_span(ends, first + li, hs, hl);
-            if (PERM) orig = perm[first + li];
-        }
-    };
-    auto load_vecs = [&](u64 hs, u32 hl, uint4 (&q)[8]) {
-        const uint4* vp = (const uint4*)(bytes + hs);
-#pragma unroll
-        for (int k = 0; k < 8; k++) q[k] = hl > 16u * k ? vp[k] : make_uint4(0, 0, 0, 0);
-    };
-    u64 hs_c, hs_n, hs_f;
-    u32 hl_c, hl_n, hl_f, or_c, or_n, or_f;
-    uint4 qc[8], qn[8];
-    load_span(item_li(0), hs_c, hl_c, or_c);
-    load_span(item_li(1), hs_n, hl_n, or_n);
-    load_vecs(hs_c, hl_c, qc);
-    u32 cnt = 0;
-    for (u32 it = 0;; it++) {
-        const u32 tile = blockIdx.x + (it >> 2) * gridDim.x;
-        if (tile >= ntiles) break;
-        const int sub = (int)(it & 3);
-        if (sub == 0) {
-            if (tid == 0) s_cnt = 0;
-            if (PERM && tid < 32) s_bits[tid] = 0;
-            cnt = 0;
-            __syncthreads();
-        }
-        load_vecs(hs_n, hl_n, qn);                       // item it + 1: its vectors
-        load_span(item_li(it + 2), hs_f, hl_f, or_f);     // item it + 2: its span
-        const u32 li = tile * FZB_TILE + sub * 256 + tid;
-        u32 st = 0;
-        {
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if (hl_c <= 16u * k) continue;
-                u32 w[4] = {qc[k].x, qc[k].y, qc[k].z, qc[k].w};
-                if (SAN) {
-                    const u32 rem = hl_c - 16u * k;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
-                        const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
-                        w[j] = (w[j] & mask) | (deadv & ~mask);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    st = dfa_step<0>(st, w[j], dfa);
-                    st = dfa_step<1>(st, w[j], dfa);
-                    st = dfa_step<2>(st, w[j], dfa);
-                    st = dfa_step<3>(st, w[j], dfa);
-                }
-            }
-            // haystacks beyond 128 bytes: the rest in rounds of eight vectors, loaded here (not a case of the streaming lists)
-            const uint4* vp = (const uint4*)(bytes + hs_c);
-            for (u32 v0 = 8; 16 * v0 < hl_c; v0 += 8) {
-                uint4 q[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) q[k] = hl_c > 16 * (v0 + k) ? vp[v0 + k] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    if (hl_c <= 16 * (v0 + k)) continue;
-                    u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-                    if (SAN) {
-                        const u32 rem = hl_c - 16 * (v0 + k);
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
-                            const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
-                            w[j] = (w[j] & mask) | (deadv & ~mask);
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        st = dfa_step<0>(st, w[j], dfa);
-                        st = dfa_step<1>(st, w[j], dfa);
-                        st = dfa_step<2>(st, w[j], dfa);
-                        st = dfa_step<3>(st, w[j], dfa);
-                    }
-                }
-            }
-        }
-        const bool matched = li < count && hl_c >= min_len && st >= acc_lo;
-        if (PERM) {
-            if (matched) atomicOr(&s_bits[or_c >> 5], 1u << (or_c & 31));
-        } else {
-            const u64 b = __ballot(matched);
-            if (lane_id() == 0) {
-                bitmap[(tile * FZB_TILE + sub * 256) / 64 + (tid >> 6)] = b;
-                cnt += __popcll(b);
-            }
-        }
-        if (sub == 3) {
-            if (PERM) {
-                __syncthreads();
-                cnt = 0;
-                if (tid < FZB_TILE / 64) {
-                    const u64 word = (u64)s_bits[2 * tid] | ((u64)s_bits[2 * tid + 1] << 32);
-                    bitmap[(size_t)tile * (FZB_TILE / 64) + tid] = word;
-                    cnt = (u32)__popcll(word);
-                }
-                if (tid < FZB_TILE / 64 && cnt) atomicAdd(&s_cnt, cnt);
-            } else if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
-            __syncthreads();
-            if (tid == 0) tile_counts[tile] = s_cnt;
-            __syncthreads();
-        }
-        hs_c = hs_n; hl_c = hl_n; or_c = or_n;
-#pragma unroll
-        for (int k = 0; k < 8; k++) qc[k] = qn[k];
-        hs_n = hs_f; hl_n = hl_f; or_n = or_f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K1-DFA for ragged lists, cooperative loads (round 3).  The burst form's per-lane 16-byte loads make EVERY piece its own request: a
-// wave's 64 haystacks are a contiguous ~5 KB, but one load instruction touches 64 different 128-byte lines and uses 16 bytes of each, and
-// with 32 waves per CU (~150 KB of live lines against a 32 KB L1) the lane's next piece misses L1 again - 50 M L1 accesses and as many
-// L2 requests for 0.85 GB (profiles/r02_pmc_ragged_filter.txt), ~70 % of what the L2 channels take per cycle.  Removing the 47 % of dead
-// lookups alone (the length-sorted view, PERM) made the kernel SLOWER (236 -> 257 us): it is bound by requests, not by instructions.
-// Here the WAVE loads its 64 haystacks' byte range with fully coalesced instructions (lane l takes bytes 16 l of each KiB: 8 lines per
-// instruction, every line once), passes it through a 4 KiB LDS window of its own (ds_write_b128), and every lane picks its haystack's
-// vectors out of the window (ds_read_b128 at its own offset) into the same registers the burst form fills.  No workgroup barrier: LDS
-// operations of one wave execute in order.  NV = vectors per haystack held in registers (8: <= 128 bytes, 16: <= 256 bytes).
-// ---------------------------------------------------------------------------------------------------
-#define FZB_COOP_WIN 4096u
-template <typename ET, bool SAN, bool PERM, int NV>
-__global__ __launch_bounds__(256) void k1_dfa_ragged_coop(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                          const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
-                                                          u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, const u16* __restrict__ perm) {
-    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
-    extern __shared__ __attribute__((aligned(16))) u8 dfa[];  // table at LDS address 0, then the tile counter, the tile's decision bits, the waves' windows
-    const u32 tab_bytes = (FZB_DFA_LDS_BYTES(rows) + 15u) & ~15u;
-    u32& s_cnt = *(u32*)(dfa + tab_bytes);
-    u32* const s_bits = (u32*)(dfa + tab_bytes + 16);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    u8* const wbuf = dfa + tab_bytes + 16 + 128 + (u32)wave * FZB_COOP_WIN;
-    dfa_require_lds_base0(dfa);
-    dfa_load_lds(dfa, dfa_g, rows);
-    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    const u32 deadv = dead * 0x01010101u;
-    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tid == 0) s_cnt = 0;
-        if (PERM && tid < 32) s_bits[tid] = 0;
-        __syncthreads();
-        u32 cnt = 0;
-#pragma unroll 1
-        for (int sub = 0; sub < 4; sub++) {
-            const u32 li = tile * FZB_TILE + sub * 256 + tid;
-            u64 hs = 0;
-            u32 hl = 0, orig = 0;
-            if (li < count) {
-                haystack_span(ends, first + li, hs, hl);
-                if (PERM) orig = perm[first + li];
-            }
-            // the wave's byte range: from its first haystack's start to the (16-byte rounded) end of its last one
-            const u32 wfirst = tile * FZB_TILE + sub * 256 + (u32)wave * 64;
-            u32 nvalid = wfirst < count ? min(64u, count - wfirst) : 0u;
-            nvalid = __builtin_amdgcn_readfirstlane(nvalid);
-            uint4 q[NV];
-#pragma unroll
-            for (int k = 0; k < NV; k++) q[k] = make_uint4(0, 0, 0, 0);
-            const u32 nv = min((hl + 15u) >> 4, (u32)NV);
-            if (nvalid) {
-                const u32 lo_lo = __builtin_amdgcn_readlane((u32)hs, 0), lo_hi = __builtin_amdgcn_readlane((u32)(hs >> 32), 0);
-                const u64 rstart = ((u64)lo_hi << 32) | lo_lo;
-                const u64 my_end = (hs + hl + 15) & ~(u64)15;
-                const u32 e_lo = __builtin_amdgcn_readlane((u32)my_end, nvalid - 1), e_hi = __builtin_amdgcn_readlane((u32)(my_end >> 32), nvalid - 1);
-                const u32 rlen = (u32)((((u64)e_hi << 32) | e_lo) - rstart);  // a wave's range: 64 haystacks of <= 16 NV bytes
-                const u32 my_off = (u32)(hs - rstart);
-                const u8* rbase = bytes + rstart;
-                for (u32 w0 = 0; w0 < rlen; w0 += FZB_COOP_WIN) {
-                    uint4 g[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const u32 a = w0 + 1024u * k + 16u * lane;
-                        g[k] = a < rlen ? *(const uint4*)(rbase + a) : make_uint4(0, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_wave_barrier();  // (the previous window's reads are issued before these writes: LDS runs a wave's operations in order)
-#pragma unroll
-                    for (int k = 0; k < 4; k++) *(uint4*)(wbuf + 1024u * k + 16u * lane) = g[k];
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int k = 0; k < NV; k++) {
-                        const u32 rel = my_off + 16u * k - w0;  // < window size only if the vector lies in this window (unsigned wrap otherwise)
-                        if ((u32)k < nv && rel < FZB_COOP_WIN) q[k] = *(const uint4*)(wbuf + rel);
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            u32 st = 0;
-#pragma unroll
-            for (int k = 0; k < NV; k++) {  // (no early exit: with a break the loop is not unrolled and q[] goes to scratch memory)
-                if (hl <= 16u * k) continue;
-                u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-                if (SAN) {
-                    const u32 rem = hl - 16u * k;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
-                        const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
-                        w[j] = (w[j] & mask) | (deadv & ~mask);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    st = dfa_step<0>(st, w[j], dfa);
-                    st = dfa_step<1>(st, w[j], dfa);
-                    st = dfa_step<2>(st, w[j], dfa);
-                    st = dfa_step<3>(st, w[j], dfa);
-                }
-            }
-            const bool matched = li < count && hl >= min_len && st >= acc_lo;
-            if (PERM) {
-                if (matched) atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
-                continue;
-            }
-            const u64 b = __ballot(matched);
-            if (lane == 0) {
-                bitmap[(tile * FZB_TILE + sub * 256) / 64 + (tid >> 6)] = b;
-                cnt += __popcll(b);
-            }
-        }
-        if (PERM) {
-            __syncthreads();
-            if (tid < FZB_TILE / 64) {
-                const u64 word = (u64)s_bits[2 * tid] | ((u64)s_bits[2 * tid + 1] << 32);
-                bitmap[(size_t)tile * (FZB_TILE / 64) + tid] = word;
-                cnt = (u32)__popcll(word);
-            }
-            if (tid < FZB_TILE / 64 && cnt) atomicAdd(&s_cnt, cnt);
-        } else if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
-        __syncthreads();
-        if (tid == 0) tile_counts[tile] = s_cnt;
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K1-DFA for ragged lists, LDS-staged and length-sorted (round 3).  What bounded the burst form above (profiles/r02_pmc_ragged_filter.txt):
-// every lane's 16-byte vector is its own L1 access (50 M accesses for 0.85 GB: neighbouring lanes read different haystacks), and a wave
-// runs to its longest haystack - 47 % of its DFA lookups are issued for lanes whose haystack has ended, in a kernel whose instruction
-// issue is 75 % busy.  Here a workgroup
-//   1. loads a SEGMENT of the list - a run of consecutive haystacks, up to seg_bytes of the padded-16 stream - into LDS with fully
-//      coalesced 16-byte loads (1 KiB per wave instruction, each line fetched once),
-//   2. orders the segment's haystacks by their number of 16-byte vectors (descending; wave ballots per class, no atomics),
-//   3. hands blocks of 64 consecutive SORTED haystacks to (chain, wave) pairs - block b to chain b / 4 of wave b % 4 - so that the 64
-//      lanes of a chain have the same vector count (+- 1 at a class boundary) and a thread's chains get shorter with the chain number:
-//      at vector v the live chains of a wave are a PREFIX, run interleaved by dfa_wordP<A> (A = 4, 3, 2, 1),
-//   4. reads the bytes from LDS (ds_read_b128; scattered addresses cost nothing there), runs the same v_perm + ds_read_u8 DFA, and
-//      sets the decision bit at the haystack's ORIGINAL position with an LDS atomic-or, so the bitmap, the per-tile counts and every
-//      later stage are unchanged.
-// A haystack longer than the segment buffer is run straight from global memory by one thread (not a case the streaming lists have).
-// ---------------------------------------------------------------------------------------------------
-#define FZB_RL_NCLS 10  // vector-count classes 0..8 and ">= 9" (haystacks beyond 128 bytes: lengths inside the class differ)
-template <int A>
-__device__ __forceinline__ void rl_round(u32 (&st)[4], const uint4 (&q)[4], const u8* dfa) {
-    u32 sa[A], w[A];
-#pragma unroll
-    for (int p = 0; p < A; p++) sa[p] = st[p];
-#pragma unroll
-    for (int p = 0; p < A; p++) w[p] = q[p].x;
-    dfa_wordP<A>(sa, w, dfa);
-#pragma unroll
-    for (int p = 0; p < A; p++) w[p] = q[p].y;
-    dfa_wordP<A>(sa, w, dfa);
-#pragma unroll
-    for (int p = 0; p < A; p++) w[p] = q[p].z;
-    dfa_wordP<A>(sa, w, dfa);
-#pragma unroll
-    for (int p = 0; p < A; p++) w[p] = q[p].w;
-    dfa_wordP<A>(sa, w, dfa);
-#pragma unroll
-    for (int p = 0; p < A; p++) st[p] = sa[p];
-}
-
-template <typename ET, bool SAN>
-__global__ __launch_bounds__(256) void k1_dfa_ragged_lds(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                         const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
-                                                         u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 seg_bytes) {
-    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
-    // ONE dynamic LDS object with the DFA table at address 0 (dfa_lds.h); behind it: the tile's end offsets, the sorted order, the
-    // per-(pass, wave) class counts, the tile's decision bits, and the segment buffer
-    extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    const u8* dfa = lds;
-    const u32 tab_bytes = (FZB_DFA_LDS_BYTES(rows) + 15u) & ~15u;
-    u32* const s_end = (u32*)(lds + tab_bytes);          // [1024 + 4]: exclusive end of haystack j, relative to the tile's first byte
-    u16* const s_order = (u16*)(s_end + FZB_TILE + 4);   // [1024]: sorted position -> index inside the segment
-    u32* const s_cnt = (u32*)(s_order + FZB_TILE);       // [16][NCLS]: haystacks of class c in (pass i, wave w); then its exclusive prefix
-    u32* const s_tot = s_cnt + 16 * FZB_RL_NCLS;         // [NCLS + 2]
-    u32* const s_bits = s_tot + FZB_RL_NCLS + 2;         // [32]: decision bits of the tile
-    u32* const s_sum = s_bits + 32;                      // [4]
-    u8* const buf = (u8*)(s_sum + 4);                    // [seg_bytes], 16-byte aligned
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    dfa_require_lds_base0(lds);
-    dfa_load_lds(lds, dfa_g, rows);
-    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    const u32 fillv = SAN ? dead * 0x01010101u : 0u;  // what a chain reads once its haystack has ended: bytes no needle row matches
-    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const u32 i0 = tile * FZB_TILE;
-        const u32 nt = min((u32)FZB_TILE, count - i0);
-        const u64 g0 = first + i0;
-        const u64 tile_base = g0 ? (((u64)ends[g0 - 1] + 15) & ~(u64)15) : 0;
-#pragma unroll
-        for (int k = 0; k < FZB_TILE / 256; k++) {
-            const u32 j = tid + 256 * k;
-            if (j < nt) s_end[j] = (u32)((u64)ends[g0 + j] - tile_base);
-        }
-        if (tid < 32) s_bits[tid] = 0;
-        if (tid == 0) s_sum[0] = 0;
-        __syncthreads();
-        auto start_of = [&](u32 j) -> u32 { return j ? (s_end[j - 1] + 15u) & ~15u : 0u; };
-        u32 j0 = 0;
-        while (j0 < nt) {
-            const u32 start0 = start_of(j0);
-            // the segment: haystacks [j0, j1) with start_of(j1) - start0 <= seg_bytes (largest such j1; wave-uniform, everybody computes it)
-            u32 lo = j0, hi = nt;
-            while (lo < hi) {
-                const u32 mid = (lo + hi + 1) >> 1;
-                if (((s_end[mid - 1] + 15u) & ~15u) - start0 <= seg_bytes) lo = mid;
-                else hi = mid - 1;
-            }
-            const u32 j1 = lo;
-            if (j1 == j0) {
-                // one haystack larger than the buffer: straight from global memory, one thread
-                if (tid == 0) {
-                    const u32 len = s_end[j0] - start0;
-                    const u8* h = bytes + tile_base + start0;
-                    u32 st = 0;
-                    for (u32 k = 0; k < len; k++) st = *(const __attribute__((address_space(3))) u8*)(uintptr_t)(st * FZB_DFA_STRIDE + h[k]);
-                    if (len >= min_len && st >= acc_lo) atomicOr(&s_bits[j0 >> 5], 1u << (j0 & 31));
-                }
-                j0++;
-                continue;
-            }
-            const u32 nseg = j1 - j0;
-            const u32 nvec_seg = (((s_end[j1 - 1] + 15u) & ~15u) - start0) >> 4;
-            // ---- 1. the segment's bytes: coalesced 16-byte loads, eight in flight per thread -----------------------------------
-            {
-                const uint4* src = (const uint4*)(bytes + tile_base + start0);
-                uint4* dst = (uint4*)buf;
-                for (u32 b0 = 0; b0 < nvec_seg; b0 += 256 * 8) {
-                    uint4 q[8];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const u32 idx = b0 + u * 256 + tid;
-                        q[u] = idx < nvec_seg ? src[idx] : make_uint4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) {
-                        const u32 idx = b0 + u * 256 + tid;
-                        if (idx < nvec_seg) dst[idx] = q[u];
-                    }
-                }
-            }
-            // ---- 2. class (vector count) and rank inside (pass, wave, class) of every haystack of the segment --------------------
-            u32 cls[4], rank[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 sidx = tid + 256 * i;
-                const bool valid = sidx < nseg;
-                u32 c = 0;
-                if (valid) {
-                    const u32 j = j0 + sidx;
-                    const u32 nv = (s_end[j] - start_of(j) + 15u) >> 4;
-                    c = min(nv, (u32)FZB_RL_NCLS - 1);
-                }
-                cls[i] = c;
-                u32 rk = 0;
-#pragma unroll 1
-                for (int k = 0; k < FZB_RL_NCLS; k++) {  // (not unrolled: forty live ballot masks would not fit the scalar registers)
-                    const u64 mk = __ballot(valid && c == (u32)k);
-                    const u32 below = __builtin_amdgcn_mbcnt_hi((u32)(mk >> 32), __builtin_amdgcn_mbcnt_lo((u32)mk, 0u));  // set bits below my lane
-                    rk = c == (u32)k ? below : rk;
-                    if (lane == 0) s_cnt[(i * 4 + wave) * FZB_RL_NCLS + k] = (u32)__popcll(mk);
-                }
-                rank[i] = rk;
-            }
-            __syncthreads();  // counts complete; the segment's bytes are in LDS
-            if (tid < FZB_RL_NCLS) {  // exclusive prefix of class `tid` over the 16 (pass, wave) slots
-                u32 sum = 0;
-                for (int q = 0; q < 16; q++) {
-                    const u32 v = s_cnt[q * FZB_RL_NCLS + tid];
-                    s_cnt[q * FZB_RL_NCLS + tid] = sum;
-                    sum += v;
-                }
-                s_tot[tid] = sum;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const u32 sidx = tid + 256 * i;
-                if (sidx < nseg) {
-                    u32 base = 0;  // descending vector count: classes above mine come first
-                    for (int k = FZB_RL_NCLS - 1; k > (int)cls[i]; k--) base += s_tot[k];
-                    s_order[base + s_cnt[(i * 4 + wave) * FZB_RL_NCLS + cls[i]] + rank[i]] = (u16)sidx;
-                }
-            }
-            __syncthreads();
-            // ---- 3. + 4. the DFA over blocks of 64 sorted haystacks: block p * 4 + wave is chain p of this wave ---------------------
-            u32 off[4], len[4], nv[4], jj[4], st[4];
-            u32 nvw[4];
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const u32 slot = (u32)(p * 4 + wave) * 64 + lane;
-                const bool act = slot < nseg;
-                jj[p] = act ? j0 + s_order[slot] : 0xFFFFFFFFu;
-                const u32 sj = act ? start_of(jj[p]) : start0;
-                off[p] = sj - start0;
-                len[p] = act ? s_end[jj[p]] - sj : 0u;
-                nv[p] = (len[p] + 15u) >> 4;
-                st[p] = 0;
-                u32 m = nv[p];  // the chain's vector count for the wave: max over its lanes (equal but for class boundaries / the open class)
-                for (int o = 32; o > 0; o >>= 1) m = max(m, (u32)__shfl_xor(m, o));
-                nvw[p] = __builtin_amdgcn_readfirstlane(m);
-            }
-            // (inside the open class ">= 9 vectors" the blocks are not ordered among themselves: the bound is the maximum, and the live
-            // set is taken up to the highest live chain - a finished chain inside it reads fill bytes)
-            const u32 vmax = max(max(nvw[0], nvw[1]), max(nvw[2], nvw[3]));
-            for (u32 v = 0; v < vmax; v++) {
-                uint4 q[4];
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    q[p] = make_uint4(fillv, fillv, fillv, fillv);
-                    if (v < nv[p]) {
-                        q[p] = *(const uint4*)(buf + off[p] + 16 * v);
-                        if (SAN && v + 1 == nv[p]) {  // the zero fill behind the haystack's end could match a needle with a NUL byte
-                            const u32 rem = len[p] - 16 * v;
-                            u32 w4[4] = {q[p].x, q[p].y, q[p].z, q[p].w};
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const u32 nvb = rem > 4u * k ? rem - 4u * k : 0u;
-                                const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
-                                w4[k] = (w4[k] & mask) | (fillv & ~mask);
-                            }
-                            q[p] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                        }
-                    }
-                }
-                // live chains are a prefix (sorted descending: nvw[0] >= nvw[1] >= nvw[2] >= nvw[3] up to the open class)
-                if (v < nvw[3]) rl_round<4>(st, q, dfa);
-                else if (v < nvw[2]) rl_round<3>(st, q, dfa);
-                else if (v < nvw[1]) rl_round<2>(st, q, dfa);
-                else rl_round<1>(st, q, dfa);
-            }
-#pragma unroll
-            for (int p = 0; p < 4; p++)
-                if (jj[p] != 0xFFFFFFFFu && len[p] >= min_len && st[p] >= acc_lo) atomicOr(&s_bits[jj[p] >> 5], 1u << (jj[p] & 31));
-            __syncthreads();  // the buffer and the order array are free again
-            j0 = j1;
-        }
-        __syncthreads();
-        if (tid < FZB_TILE / 64) {
-            const u64 word = (u64)s_bits[2 * tid] | ((u64)s_bits[2 * tid + 1] << 32);
-            bitmap[(size_t)tile * (FZB_TILE / 64) + tid] = word;
-            atomicAdd(&s_sum[0], (u32)__popcll(word));
-        }
-        __syncthreads();
-        if (tid == 0) tile_counts[tile] = s_sum[0];
-        __syncthreads();
-    }
-}
+// (Round 3 measured three more forms of the ragged filter on the canonical layout - software-pipelined burst, cooperative coalesced loads through
+// a per-wave LDS window, LDS-staged + length-sorted - at 244-253 / 234-292 / 530-990 us against the burst form's 234; none is kept: the code
+// is in the history, the numbers in profiles/r03_ragged_filter_variants.txt, the reading in DESIGN.md "The ragged filter".)
 
 // ---------------------------------------------------------------------------------------------------
 // Level-1 compaction in ONE kernel: every workgroup owns a
@@ -1432,62 +922,6 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             }
             static const int burst = getenv("FZB_RAGGED_BURST") ? atoi(getenv("FZB_RAGGED_BURST")) : 1;  // 0 = the rolling form, for comparison
             static const int bwgs = getenv("FZB_RAGGED_WGS") ? atoi(getenv("FZB_RAGGED_WGS")) : 8;
-            // LDS-staged, length-sorted form (k1_dfa_ragged_lds), OPT-IN (FZB_RAGGED_LDS=1): measured 0.53-0.99 ms against the burst form's
-            // 0.234 ms on the C4 shard (profiles/r03_ragged_filter_variants.txt) - with the bytes resident in LDS only ~2 100 haystacks fit a
-            // CU, 3 waves per SIMD with 1-2 live DFA chains each, and the dependent lookup chain is latency-bound.
-            // FZB_RAGGED_SEG = segment buffer in bytes, FZB_RAGGED_LDS_WGS = resident workgroups per CU it is launched with
-            static const int use_lds = getenv("FZB_RAGGED_LDS") ? atoi(getenv("FZB_RAGGED_LDS")) : 0;
-            static const int seg_env = getenv("FZB_RAGGED_SEG") ? atoi(getenv("FZB_RAGGED_SEG")) : 32768;
-            static const int lwgs = getenv("FZB_RAGGED_LDS_WGS") ? atoi(getenv("FZB_RAGGED_LDS_WGS")) : 3;
-            const u32 seg = ((u32)std::max(seg_env, 1024) + 15u) & ~15u;
-            const size_t fixed = (((size_t)(rows + 1) * FZB_DFA_STRIDE + 15) & ~(size_t)15) + (FZB_TILE + 4) * 4 + FZB_TILE * 2 + (16 * FZB_RL_NCLS + FZB_RL_NCLS + 2 + 32 + 4) * 4 + 16;
-            if (use_lds && fixed + seg <= 64 * 1024) {
-                const int g = std::max(1, std::min<int>((grid / 8) * lwgs, (int)ntiles));
-#define FZB_K1L(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_lds<ET, SAN>), dim3(g), dim3(256), fixed + seg, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, seg)
-                if (c.ends_u64) { if (nul_safe) FZB_K1L(u64, false); else FZB_K1L(u64, true); }
-                else            { if (nul_safe) FZB_K1L(u32, false); else FZB_K1L(u32, true); }
-#undef FZB_K1L
-                return;
-            }
-            // the corpus' length-sorted filter view (built by fzb_corpus_upload for ragged lists): whole tiles only
-            const bool view = false;  // (round 3's first, non-interleaved sorted view is gone: its measurements are in profiles/r03_ragged_filter_variants.txt)
-            // software-pipelined burst form (three haystacks in flight per thread)
-            static const int pipe = getenv("FZB_RAGGED_PIPE") ? atoi(getenv("FZB_RAGGED_PIPE")) : 0;  // opt-in: measured 244-253 us vs the burst form's 234 us (profiles/r03_ragged_filter_variants.txt)
-            static const int pwgs = getenv("FZB_RAGGED_PIPE_WGS") ? atoi(getenv("FZB_RAGGED_PIPE_WGS")) : 5;
-            if (pipe) {
-                const int g = std::max(1, std::min<int>((grid / 8) * pwgs, (int)ntiles));
-                const size_t lds_p = lds + 16 + 32 * 4;
-#define FZB_K1P(ET, SAN, PERM, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_pipe<ET, SAN, PERM>), dim3(g), dim3(256), lds_p, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, P)
-                if (view) { if (nul_safe) FZB_K1P(u32, false, true, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u32, true, true, c.bytes, c.ends, (const u16*)nullptr); }
-                else if (c.ends_u64) { if (nul_safe) FZB_K1P(u64, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u64, true, false, c.bytes, c.ends, (const u16*)nullptr); }
-                else { if (nul_safe) FZB_K1P(u32, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1P(u32, true, false, c.bytes, c.ends, (const u16*)nullptr); }
-#undef FZB_K1P
-                return;
-            }
-            // cooperative (coalesced, LDS-transposed) loads: every haystack's vectors must fit the registers of the NV = 8 / 16 forms
-            static const int coop = getenv("FZB_RAGGED_COOP") ? atoi(getenv("FZB_RAGGED_COOP")) : 0;  // opt-in: measured 234-292 us vs 234 us
-            static const int cwgs = getenv("FZB_RAGGED_COOP_WGS") ? atoi(getenv("FZB_RAGGED_COOP_WGS")) : 8;
-            if (coop && c.max_len != 0 && c.max_len <= 256) {
-                const size_t lds_c = (((size_t)(rows + 1) * FZB_DFA_STRIDE + 15) & ~(size_t)15) + 16 + 128 + 4 * FZB_COOP_WIN;
-                const int g = std::max(1, std::min<int>((grid / 8) * cwgs, (int)ntiles));
-                const bool nv8 = c.max_len <= 128;
-#define FZB_K1C(ET, SAN, PERM, NV, B, E, P) hipLaunchKernelGGL((k1_dfa_ragged_coop<ET, SAN, PERM, NV>), dim3(g), dim3(256), lds_c, st, B, (const ET*)E, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, P)
-#define FZB_K1C_NV(ET, SAN, PERM, B, E, P) do { if (nv8) FZB_K1C(ET, SAN, PERM, 8, B, E, P); else FZB_K1C(ET, SAN, PERM, 16, B, E, P); } while (0)
-                if (lds_c <= 64 * 1024) {
-                    if (view) { if (nul_safe) FZB_K1C_NV(u32, false, true, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1C_NV(u32, true, true, c.bytes, c.ends, (const u16*)nullptr); }
-                    else if (c.ends_u64) { if (nul_safe) FZB_K1C_NV(u64, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1C_NV(u64, true, false, c.bytes, c.ends, (const u16*)nullptr); }
-                    else { if (nul_safe) FZB_K1C_NV(u32, false, false, c.bytes, c.ends, (const u16*)nullptr); else FZB_K1C_NV(u32, true, false, c.bytes, c.ends, (const u16*)nullptr); }
-                    return;
-                }
-#undef FZB_K1C_NV
-#undef FZB_K1C
-            }
-            if (view) {
-                rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
-                const size_t lds_p = lds + 16 + 32 * 4;
-                if (nul_safe) hipLaunchKernelGGL((k1_dfa_ragged_burst<u32, false, true>), dim3(rgrid), dim3(256), lds_p, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, (const u16*)nullptr);
-                return;
-            }
             if (burst) {
                 rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
 #define FZB_K1B(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_burst<ET, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
