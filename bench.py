@@ -215,6 +215,26 @@ def step_roofline(sum_len, n, matches, ms, ends_read=True):
     return r
 
 
+def sharded_block(F, needle, cfg, host_bytes, host_ends, unsharded_ms, unsharded_result):
+    out = {"what": "fzb_match_list_parallel_sharded over the C2 list cut into k shards that share this ONE device (FZB_SHARD_OVERSUBSCRIBE): per-shard worker thread, "
+                   "matcher clone and stream; runs copied device to device into one list, ordered once, one D2H.  Ordered records on the host, per call",
+           "unsharded_match_list_ms": unsharded_ms}
+    want = unsharded_result.tobytes()
+    for k in (1, 2, 8):
+        sc = F.ShardedCorpus(packed=(host_bytes, host_ends), ndev=k, oversubscribe=True)
+        m = F.Matcher(needle, cfg)
+        got = m.match_list_parallel_sharded(sc, copy=False)
+        same = got.tobytes() == want
+        ts = []
+        for _ in range(15):
+            t0 = time.perf_counter()
+            got = m.match_list_parallel_sharded(sc, copy=False)
+            ts.append(time.perf_counter() - t0)
+        out[f"shards_{k}"] = {"ms_median": _median(ts) * 1e3, "ms_min": min(ts) * 1e3, "vs_unsharded": _median(ts) * 1e3 / unsharded_ms, "equals_match_list": bool(same)}
+        del m, sc, got
+    return out
+
+
 def other_configs(F, synth, dev, steps):
     """C3 / C4-shard / C5 of BASELINE.json on this GPU: device pipeline time per step (corpus resident), same definitions as the headline."""
     res = {}
@@ -289,13 +309,14 @@ def main():
     ap.add_argument("--max-typos", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the C3 / C4-shard / C5 block")
+    ap.add_argument("--no-sharded", action="store_true", help="skip the sharded-on-one-device block (fzb_match_list_parallel_sharded vs fzb_match_list)")
     ap.add_argument("--no-check", action="store_true", help="skip the 1M-item oracle comparison")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-streams throughput figure")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child runs; report the stored traffic figure")
     ap.add_argument("--fast", action="store_true", help="= --no-cpu-baseline --no-configs --no-check --no-two-in-flight (profiling runs)")
     args = ap.parse_args()
     if args.fast:
-        args.no_cpu_baseline = args.no_configs = args.no_check = args.no_two_in_flight = args.no_live_traffic = True
+        args.no_cpu_baseline = args.no_configs = args.no_check = args.no_two_in_flight = args.no_live_traffic = args.no_sharded = True
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
@@ -427,26 +448,26 @@ def main():
         ex.collect(last ^ 1)
         n_matches = int(ex.send[last][:4].cpu().numpy().view(np.uint32)[0])
         if rank == 0:
-            merged = merge_shard_runs(runs, F.SortStrategy.ScoreThenIndexAsc)
+            merged = merge_shard_runs(runs, F.SortStrategy.ScoreThenIndexAsc)  # host form of the combine (the device form is timed below)
             gathered = {"matches_all_shards": int(sum(len(r) for r in runs)), "merged_len": int(len(merged)), "exchange_capacity_records": ex.cap}
-        # ---- the alternative, end-to-end mode (reported beside `value`, never instead of it): every step ends with the ORDERED
-        # list on rank 0's host - per-rank device sort, synchronous gather of the sorted runs, k-way merge on the root
-        # (parallel.rs:66-87: per-run sort, then k-merge) ------------------------------------------------------------------
+        # ---- the end-to-end mode (reported beside `value`, never instead of it): every step ends with the ORDERED list on rank 0's
+        # host - what match_list_parallel returns (parallel.rs:66-87).  Each rank runs the pipeline unsorted with global indices, a
+        # synchronous gather puts the runs into the root's HBM, and the root orders the whole list ONCE on the device (rank order is
+        # ascending index order: concatenation + reverse / stable radix sort, fzb_merge_shard_runs) and makes one copy to the host.
+        # Round 3 sorted per rank and k-merged on the root's host: 4.1 ms per step with one rank.
         k_e2e = max(3, min(10, args.steps))
+        merged2 = None
         fence()
         t0 = time.perf_counter()
         for _ in range(k_e2e):
-            m.match_list_sorted_device(corpus, ex.records_ptr(0), ex.cap, ex.count_ptr(0), stream=stream)
+            m.match_list_device(corpus, ex.records_ptr(0), ex.cap, ex.count_ptr(0), stream=stream, index_offset=index_offset)
             ex.post(0)
-            sorted_runs = ex.collect(0)
-            if rank == 0:
-                for r_, run_ in enumerate(sorted_runs):
-                    run_["index"] += np.uint32(r_ * n)  # the sorted form numbers a shard from 0: shift to global indices
-                merged2 = F.k_merge_matches(F.SortStrategy.ScoreThenIndexAsc, sorted_runs)
+            merged2 = ex.collect_merged(0, m, stream=stream)
         fence()
         e2e_multi = {"ms_per_step": (time.perf_counter() - t0) / k_e2e * 1e3, "steps": k_e2e,
-                     "what": "per-rank device radix sort + synchronous RCCL gather of the sorted runs + k-way merge on rank 0's host, every step",
-                     "merged_len": int(len(merged2)) if rank == 0 else None}
+                     "what": "per-rank pipeline (index order, global indices) + synchronous RCCL gather into rank 0's HBM + ONE device-side concatenation / stable radix sort + one D2H, every step",
+                     "merged_len": int(len(merged2)) if rank == 0 else None,
+                     "equals_host_merge": bool(merged2.tobytes() == merged.tobytes()) if rank == 0 else None}
     counters = m.last_counters()
     if rank == 0:
         total = n * world
@@ -528,6 +549,14 @@ def main():
                                "haystacks_per_s": n / cold_sorted[len(cold_sorted) // 2][0],
                                "what": "fzb_corpus_upload (pageable host memory -> HBM, padded-16 layout built on the device) + fzb_matcher_create + first fzb_match_list (workspace allocation, pipeline, device sort, D2H); "
                                        "ms_first also pays the first-touch of the process"}
+            if not args.no_sharded:
+                # The multi-device form behind the C ABI (fzb_match_list_parallel_sharded), as far as ONE GPU can show it: the same list
+                # cut into 8 shards that share this device (persistent worker thread + matcher clone + stream per shard, runs gathered
+                # device to device, ordered once on the root), against fzb_match_list on the unsharded list.  Same records, same order.
+                try:
+                    res["sharded"] = sharded_block(F, NEEDLE.decode(), cfg, host_bytes, host_ends, res["e2e"]["match_list_ms_median"], r)
+                except Exception as ex_:  # reported, never fatal for the headline
+                    res["sharded"] = {"error": repr(ex_)}
             del host_bytes, host_ends
             if not args.no_two_in_flight:
                 # two independent queries in flight on two streams (two matchers = two workspaces): the HBM-bound filter of one overlaps the

@@ -115,6 +115,7 @@ SYMBOLS = [
     "fzb_match_list_indices_into", "fzb_multi_match_list_into", "fzb_multi_match_list_indices_into",
     "fzb_device_count", "fzb_shard_ranges", "fzb_corpus_upload_sharded", "fzb_sharded_corpus_free", "fzb_sharded_corpus_len", "fzb_sharded_corpus_shards",
     "fzb_sharded_corpus_shard", "fzb_match_list_parallel_sharded", "fzb_debug_lcs_dfa_accepts", "fzb_debug_cdfa_state",
+    "fzb_merge_shard_runs", "fzb_corpus_build_view", "fzb_debug_reload_knobs",
 ]
 
 
@@ -177,6 +178,8 @@ def lib():
         l.fzb_sharded_corpus_shards.argtypes = [C.c_void_p]
         l.fzb_sharded_corpus_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         l.fzb_match_list_parallel_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_merge_shard_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_corpus_build_view.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         l.fzb_debug_lcs_dfa_accepts.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
         l.fzb_debug_cdfa_state.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
         _lib = l
@@ -240,6 +243,13 @@ class Corpus:
         if uniform_len:
             _check(lib().fzb_corpus_set_uniform_len(self.h, uniform_len))
         return self
+
+    def build_view(self):
+        """fzb_corpus_build_view: the streaming filter's interleaved view for a borrowed ragged corpus (an uploaded one has it already).
+        Returns True when the corpus has a view afterwards."""
+        built = C.c_int()
+        _check(lib().fzb_corpus_build_view(self.h, C.byref(built)))
+        return bool(built.value)
 
     def __len__(self):
         return lib().fzb_corpus_len(self.h)
@@ -514,11 +524,23 @@ class Matcher(_IterApi):
         return _take(out, n)
 
     def match_list_parallel_sharded(self, sharded, copy=True):
-        """`Matcher::match_list_parallel` with one DEVICE per worker (fzb_match_list_parallel_sharded): per-shard pipeline + device sort,
-        k-way merge of the runs on the host (src/matcher/parallel.rs:66-87).  Equals `match_list` on the unsharded list."""
+        """`Matcher::match_list_parallel` with one DEVICE per worker (fzb_match_list_parallel_sharded): per-shard pipeline, the runs
+        gathered device to device on the root and ordered there once (src/matcher/parallel.rs:66-87's result).  Equals `match_list`
+        on the unsharded list."""
         out, n = C.c_void_p(), C.c_size_t()
         _check(lib().fzb_match_list_parallel_sharded(self.h, sharded.h, C.byref(out), C.byref(n)))
         return _take(out, n, copy)
+
+    def merge_shard_runs(self, run_ptrs, count_ptrs, run_caps, stream=0, copy=True):
+        """fzb_merge_shard_runs: index-ordered per-shard runs resident on the current device (ascending shard order; counts in device
+        memory) -> `match_list`'s ordered result on the host.  Concatenation + reverse / stable radix sort on the device."""
+        n = len(run_ptrs)
+        runs = (C.c_void_p * max(n, 1))(*[int(p) for p in run_ptrs])
+        cnts = (C.c_void_p * max(n, 1))(*[int(p) for p in count_ptrs])
+        caps = (C.c_size_t * max(n, 1))(*[int(c) for c in run_caps])
+        out, ln = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_merge_shard_runs(self.h, runs, cnts, caps, n, stream, C.byref(out), C.byref(ln)))
+        return _take(out, ln, copy)
 
     def match_list_indices(self, haystacks, selection=None):
         """`Matcher::match_list_indices` (src/matcher/mod.rs:234-275): list of `MatchIndices` (src/lib.rs:189-199), the matched byte

@@ -84,6 +84,7 @@ struct CorpusDev {
     const u8* vgnv;    // per group: vectors per member (<= 16)
     const u16* vlen;   // per sorted haystack
     const u16* vperm;  // per sorted haystack
+    u32 view_nv;       // the view's widest member in 16-byte vectors (<= 16): read from the lengths when the view is built, not a caller's hint
 };
 
 struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between kernels (0 in final output)
@@ -121,12 +122,6 @@ struct Workspace {
     u32* cls_win;       // classified scoring (corpora with longer haystacks): window per survivor, three class lists
     u32* cls_lists;     //   [7][cap]; class counts in counters[8..10], multi-chunk tail classes in counters[12..15]
     size_t cap_cls;
-    u16* fused_tile_counts;      // k12_fused: survivors per 256-haystack tile, per group of 4 tiles (zero between launches), and the
-    u32* fused_group_counts;     //   staging array (256 record slots per tile) that k_fused_gather packs
-    fzb_match_rec* fused_stage;
-    size_t fused_cap;            // haystacks the three are sized for (0 = not allocated)
-    size_t fused_groups;         // entries of ONE of the two group-count arrays (alternate launches use alternate arrays)
-    int fused_flip;
     u64* table;         // 256 x u64 filter table (device)
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     u8* uni_dfa;        // unicode path, 0 typos: states x 256 table of the exact prefilter's byte-level DFA (device)
@@ -152,6 +147,15 @@ struct LaunchCfg {
     int cfm_ok;  // dp_cfm.h preconditions (multi-chunk windows in the biased domain)          // single-chunk scorer in its second form (dp_cf.h): pad_ok, bias_ok and 2 * gap_extend <= mismatch_penalty
     int num_cus;
     u32 dead_byte;      // a byte value no needle row can match (used to neutralise bytes past a haystack's end in the DFA filter)
+};
+
+// Index-ordered record runs of contiguous shards, all readable from the current device (k_concat_runs); cap[g] bounds count[g]
+#define FZB_MAX_RUNS 64
+struct RunSet {
+    const fzb_match_rec* run[FZB_MAX_RUNS];
+    const u32* count[FZB_MAX_RUNS];
+    u32 cap[FZB_MAX_RUNS];
+    int n;
 };
 
 // Rejections of the decide pass (typo configurations on the short-haystack path): one bit per haystack of the range, a count per
@@ -183,9 +187,6 @@ void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                    int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st,
                    const RejectOut* rejects = nullptr);
-bool fzb_fused_applies(const CorpusDev& c, const LaunchCfg& lc, const NeedleDev& nd, int wmode);
-void fzb_launch_fused(const CorpusDev& c, u64 first, u32 count, u32 index_offset, const u8* dfa, const NeedleDev& nd, int sw_lanes, int wmode, u32 min_len, u16* tile_counts,
-                      u32* group_counts, u32* group_counts_next, fzb_match_rec* stage, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int num_cus, hipStream_t st);
 bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
@@ -202,6 +203,7 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
                            int grid, hipStream_t st, int tform = 0);
 // kernels_sort.hip
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st, int passes = 2);
+void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, hipStream_t st);
 // kernels_multi.hip
 void fzb_launch_records_to_items(const fzb_match_rec* cand, const u32* n_ptr, u32 index_offset, u32* items, int grid, hipStream_t st);
 void fzb_launch_identity_records(fzb_match_rec* out, u32 n, u32 index_offset, u32* count_out, int grid, hipStream_t st);

@@ -159,6 +159,50 @@ extern "C" {
 
 const char* fzb_last_error(void) { return g_err.c_str(); }
 
+}  // extern "C"
+// ---- environment switches: parsed once (knobs.h) --------------------------------------------------------------------------------
+namespace {
+FzbKnobs parse_knobs() {
+    FzbKnobs k;
+    auto on = [](const char* name) { const char* e = getenv(name); return e != nullptr && atoi(e) != 0; };
+    auto set = [](const char* name) { return getenv(name) != nullptr; };
+    auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    k.no_lcs_dfa = set("FZB_NO_LCS_DFA");
+    k.no_dp_cfu = set("FZB_NO_DP_CFU");
+    k.typo_exact_window = on("FZB_TYPO_EXACT_WINDOW");
+    k.no_dp_classes = set("FZB_NO_DP_CLASSES");
+    k.no_overlap = set("FZB_NO_OVERLAP");
+    k.no_dp_cfm = set("FZB_NO_DP_CFM");
+    k.no_tail_classes = set("FZB_NO_TAIL_CLASSES");
+    k.no_cdfa = set("FZB_NO_CDFA");
+    k.no_filter_view = getenv("FZB_FILTER_VIEW") != nullptr && atoi(getenv("FZB_FILTER_VIEW")) == 0;
+    k.cdfa_nodfa = set("FZB_CDFA_NODFA");
+    k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
+    k.debug_sync = set("FZB_DEBUG_SYNC");
+    k.no_handoff = set("FZB_NO_HANDOFF");
+    k.k2u_waves = num("FZB_K2U_WAVES", 0);
+    k.small_list = getenv("FZB_SMALL_LIST") ? (uint32_t)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
+    k.compact_grid_mul = std::max(1, num("FZB_COMPACT_GRID_MUL", 4));
+    { const int v = num("FZB_CLASSIFY_PER", 2); k.classify_per = (v == 1 || v == 4) ? v : 2; }
+    k.dp_wgs_per_cu = std::max(0, num("FZB_DP_WGS_PER_CU", 0));
+    k.cdfa_wgs = std::max(1, num("FZB_CDFA_WGS", 5));
+    k.view_wgs = std::max(1, num("FZB_VIEW_WGS", 6));
+    k.ragged_wgs = std::max(1, num("FZB_RAGGED_WGS", 8));
+    if (const char* e = getenv("FZB_UPLOAD_MODE")) k.upload_mode = !strcmp(e, "register") ? 1 : !strcmp(e, "staged") ? 0 : 2;
+    k.upload_threads = std::max(0, num("FZB_UPLOAD_THREADS", 0));
+    return k;
+}
+FzbKnobs& knobs_storage() {
+    static FzbKnobs k = parse_knobs();
+    return k;
+}
+}  // namespace
+const FzbKnobs& fzb_knobs() { return knobs_storage(); }
+extern "C" {
+// test hook: re-read the environment (tests/test_gpu_knobs.py switches paths inside one process; matchers created BEFORE the call keep
+// what was decided at their creation - the LCS automaton, the unicode scorer's form)
+void fzb_debug_reload_knobs(void) { knobs_storage() = parse_knobs(); }
+
 void fzb_config_default(fzb_config* out) {
     if (!out) return;
     memset(out, 0, sizeof(*out));
@@ -172,7 +216,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa, w.fused_tile_counts, w.fused_group_counts, w.fused_stage};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -392,8 +436,7 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     // "accepts" is one compare; the start state (LCS 0, only reachable as itself) is state 0.  More than 226 states (long needles with
     // many distinct letters): the bit-vector kernel stays.  FZB_NO_LCS_DFA=1 keeps it for comparison.
     m->lcs_states = 0;
-    static const bool no_lcs_dfa = getenv("FZB_NO_LCS_DFA") != nullptr;
-    if (lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !no_lcs_dfa) {
+    if (lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !fzb_knobs().no_lcs_dfa) {
         const u64 mask = m->rows >= 64 ? ~(u64)0 : (((u64)1 << m->rows) - 1);
         std::vector<u64> masks;  // distinct M over the 256 byte values
         std::vector<int> mask_of(256);
@@ -499,8 +542,7 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     lc.cfm_ok = 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty &&
                 max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 200 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;  // dp_cfm.h: lanes up to 3/2 chunks + rows of bias
     lc.cf_ok = lc.pad_ok && lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty;  // dp_cf.h preconditions
-    static const bool no_cfu = getenv("FZB_NO_DP_CFU") != nullptr;  // comparison knob: the unicode scorer's first form
-    lc.cfu_ok = lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty && !no_cfu;
+    lc.cfu_ok = lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty && !fzb_knobs().no_dp_cfu;  // (knob: the unicode scorer's first form)
     *out = m;
     return FZB_OK;
 }
@@ -531,10 +573,11 @@ static int rebuild_matcher(fzb_matcher* m, const fzb_config* config, const uint8
         for (int k = 0; k < 5; k++) std::swap(fresh->evring[i][k], m->evring[i][k]);
         fresh->ev_filter[i] = m->ev_filter[i];
     }
-    fresh->shard_stream = m->shard_stream;  // (non-null only on a shard clone)
-    fresh->shard_device = m->shard_device;
-    m->shard_stream = nullptr;
-    m->shard_device = -1;
+    std::swap(fresh->shard_stream, m->shard_stream);  // the multi-device form's state: a clone's stream / event / count, the parent's workers
+    std::swap(fresh->shard_event, m->shard_event);
+    std::swap(fresh->shard_count_host, m->shard_count_host);
+    std::swap(fresh->shard_device, m->shard_device);
+    std::swap(fresh->shard_workers, m->shard_workers);
     std::swap(fresh->shard_clones, m->shard_clones);
     // ... and then the handle the caller holds takes the rebuilt matcher's place
     std::swap(*fresh, *m);
@@ -603,13 +646,15 @@ void fzb_matcher_free(fzb_matcher* m) {
     if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
     if (m->long_blob_dev) (void)hipFree(m->long_blob_dev);
     if (m->long_scratch) (void)hipFree(m->long_scratch);
-    if (!m->shard_clones.empty() || m->shard_device >= 0) {
+    if (m->shard_workers) fzb_shard_workers_free(m->shard_workers);  // joins the worker threads before their clones go
+    m->shard_workers = nullptr;
+    if (m->shard_stream) (void)hipStreamDestroy(m->shard_stream);
+    if (m->shard_event) (void)hipEventDestroy(m->shard_event);
+    if (m->shard_count_host) (void)hipHostFree(m->shard_count_host);
+    if (!m->shard_clones.empty()) {
         // a clone's device state lives on its shard's device
         int cur = 0;
         const bool have_cur = hipGetDevice(&cur) == hipSuccess;
-        if (m->shard_device >= 0) (void)hipSetDevice(m->shard_device);
-        if (m->shard_stream) (void)hipStreamDestroy(m->shard_stream);
-        m->shard_stream = nullptr;
         for (fzb_matcher* cm : m->shard_clones) {
             if (cm->shard_device >= 0) (void)hipSetDevice(cm->shard_device);
             fzb_matcher_free(cm);
@@ -668,9 +713,36 @@ int fzb_corpus_set_uniform_len(fzb_corpus* c, uint32_t len) {
 
 int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
     if (!c) return fail(FZB_ERR_INVALID, "null argument");
+    // an uploaded corpus knows its longest haystack: a hint can only repeat or loosen it (ignored), and one BELOW it is refused - kernels are
+    // selected by this bound and would skip bytes
+    if (c->own_bytes) {
+        if (max_len == 0 || max_len >= c->dev.max_len) return FZB_OK;
+        return fail(FZB_ERR_INVALID, "the corpus was uploaded by fzb_corpus_upload, which measured its longest haystack (" + std::to_string(c->dev.max_len) + " bytes); " +
+                                         std::to_string(max_len) + " is not an upper bound");
+    }
+    if (c->dev.uniform_len && max_len != c->dev.uniform_len) return fail(FZB_ERR_INVALID, "the corpus promises a uniform length of " + std::to_string(c->dev.uniform_len) + " bytes");
     c->dev.max_len = max_len;
     return FZB_OK;
 }
+
+}  // extern "C"
+// A matcher's device state (workspace, staging, sort buffers) lives on the device that was current at its first query; later queries
+// must find the same device current.
+int fzb_bind_device(fzb_matcher* m) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (m->device >= 0) {
+        if (dev != m->device)
+            return fail(FZB_ERR_INVALID, "matcher is bound to device " + std::to_string(m->device) + " (its workspace lives there) but device " + std::to_string(dev) + " is current");
+        return FZB_OK;
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    m->device = dev;
+    m->lc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return FZB_OK;
+}
+extern "C" {
 
 // ---- pipeline -------------------------------------------------------------------------------------------
 // ASCII typo configuration whose scorer can be the short-haystack kernel: the filter's LCS criterion decides, only its marginal
@@ -679,8 +751,7 @@ int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
 static bool typo_fast_path_configured(const fzb_matcher* m) {
     // FZB_TYPO_EXACT_WINDOW=1: every typo query takes the reference's chunked multi-path scan at the exact lane width for every survivor
     // (superset filter -> k2a_window -> k_compact2), i.e. nothing rests on the two properties of DESIGN.md section 3e
-    static const bool exact_window = getenv("FZB_TYPO_EXACT_WINDOW") != nullptr && atoi(getenv("FZB_TYPO_EXACT_WINDOW")) != 0;
-    if (exact_window) return false;
+    if (fzb_knobs().typo_exact_window) return false;
     return !m->literal_mode && !m->empty && m->lc.filter_mode == 2 && !m->nd.unicode && m->lc.cf_ok && (m->lc.sw_lanes == 64 || m->lc.sw_lanes == 32);
 }
 
@@ -763,22 +834,6 @@ static int ensure_aux_stream(fzb_matcher* m) {
     m->aux_stream = s;
     m->ev_fork = ef;
     m->ev_join = ej;
-    return FZB_OK;
-}
-static int ensure_fused_buffers(fzb_matcher* m) {  // tile counts, group counts and the staging array of k12_fused, sized with the range workspace
-    Workspace& w = m->ws;
-    if (w.fused_cap >= w.cap_items && w.fused_stage) return FZB_OK;
-    for (void* p : {(void*)w.fused_tile_counts, (void*)w.fused_group_counts, (void*)w.fused_stage})
-        if (p) HIPCHK(hipFree(p));
-    w.fused_tile_counts = nullptr; w.fused_group_counts = nullptr; w.fused_stage = nullptr; w.fused_cap = 0;
-    const size_t tiles = w.cap_items / 256 + 8;
-    HIPCHK(dev_alloc((void**)&w.fused_tile_counts, tiles * 2));
-    w.fused_groups = (tiles / 16 + 8 + 3) & ~(size_t)3;  // 16-byte aligned halves
-    HIPCHK(dev_alloc((void**)&w.fused_group_counts, 2 * w.fused_groups * 4));
-    HIPCHK(hipMemset(w.fused_group_counts, 0, 2 * w.fused_groups * 4));  // every launch's gather kernel clears the array of the next one
-    w.fused_flip = 0;
-    HIPCHK(dev_alloc((void**)&w.fused_stage, tiles * 256 * sizeof(fzb_match_rec)));
-    w.fused_cap = w.cap_items;
     return FZB_OK;
 }
 static int ensure_dp_scratch(fzb_matcher* m, int mgrid) {  // parked rows of the multi-chunk scorer
@@ -923,21 +978,9 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         return fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string((u64)count + index_offset) + " > 4294967295 (index offset: " + std::to_string(index_offset) + ")");
     if (m->empty) return fail(FZB_ERR_INVALID, "empty needle: handled on the host by fzb_match_list / fzb_match_list_into");
     hipStream_t st = (hipStream_t)stream;
-    if (m->device >= 0) {  // the workspace lives on the device that was current at the first call
-        int dev = 0;
-        HIPCHK(hipGetDevice(&dev));
-        if (dev != m->device)
-            return fail(FZB_ERR_INVALID, "matcher is bound to device " + std::to_string(m->device) + " (its workspace lives there) but device " + std::to_string(dev) + " is current");
-    }
-    if (m->device < 0) {
-        int dev = 0;
-        HIPCHK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, dev));
-        m->device = dev;
-        m->lc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    int rc = ensure_workspace(m, count);
+    int rc = fzb_bind_device(m);
+    if (rc) return rc;
+    rc = ensure_workspace(m, count);
     if (rc) return rc;
     Workspace& w = m->ws;
     const LaunchCfg& lc = m->lc;
@@ -946,7 +989,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     const int cus = lc.num_cus;
     const u32 cnt = (u32)count;
     const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
-    static const bool dbg = getenv("FZB_DEBUG_SYNC") != nullptr;  // debugging aid: synchronise and report after every stage
+    const FzbKnobs& kn = fzb_knobs();
+    const bool dbg = kn.debug_sync;  // debugging aid: synchronise and report after every stage
 #define FZB_STAGE(name)                                                                                        \
     do {                                                                                                       \
         if (dbg) {                                                                                             \
@@ -1060,22 +1104,6 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("compact1");
         items = w.surv_idx;
         uni_exact = true;
-    } else if (!trace && fzb_fused_applies(cd, lc, nd, lc.window_mode)) {
-        // ---- ASCII, 0 typos, every haystack fits half a chunk: filter, ordering and scorer in one persistent kernel (kernels_fused.hip) ----
-        if ((rc = ensure_fused_buffers(m))) return rc;  // first use only (or fzb_matcher_reserve)
-        if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        fzb_launch_fused(cd, first, cnt, index_offset, w.dfa, nd, lc.sw_lanes, lc.window_mode, (u32)nd.min_haystack_len, w.fused_tile_counts, w.fused_group_counts + (size_t)w.fused_flip * w.fused_groups,
-                         w.fused_group_counts + (size_t)(w.fused_flip ^ 1) * w.fused_groups, w.fused_stage,
-                         (fzb_match_rec*)dev_out, cap32, dev_count, w.counters, cus, st);
-        w.fused_flip ^= 1;
-        if (pev) {
-            HIPCHK(hipEventRecord(pev[3], st));
-            HIPCHK(hipEventRecord(pev[4], st));
-            HIPCHK(hipEventRecord(pev[1], st));
-        }
-        FZB_STAGE("fused filter+scorer");
-        HIPCHK(hipGetLastError());
-        return FZB_OK;
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
@@ -1087,8 +1115,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
                               nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
-        static const int c1mul = getenv("FZB_COMPACT_GRID_MUL") ? atoi(getenv("FZB_COMPACT_GRID_MUL")) : 4;  // tuning knob (workgroups per CU)
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * c1mul, st);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * kn.compact_grid_mul, st);
         FZB_STAGE("compact1");
         items = w.surv_idx;
     }
@@ -1135,24 +1162,24 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, cnt_c, cus * 4, st);
         FZB_STAGE("generic(unicode)");
     } else {
-        static const bool no_classes = getenv("FZB_NO_DP_CLASSES") != nullptr;  // comparison knob: the per-wave choice of k2b_dp instead
-        static const bool no_overlap = getenv("FZB_NO_OVERLAP") != nullptr;     // comparison knob: everything on the caller's stream
+        const bool no_classes = kn.no_dp_classes;  // comparison knob: the per-wave choice of k2b_dp instead
+        const bool no_overlap = kn.no_overlap;     // comparison knob: everything on the caller's stream
         const bool classes = lc.cf_ok && !no_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2);
         const int mgrid = cus * 4;  // multi-chunk scorer: 2 waves per SIMD (the kernel is capped at 256 VGPRs)
-        const int mmode = (lc.cfm_ok && !getenv("FZB_NO_DP_CFM")) ? 2 : lc.bias_ok ? 1 : 0;
+        const int mmode = (lc.cfm_ok && !kn.no_dp_cfm) ? 2 : lc.bias_ok ? 1 : 0;
         if (!no_wide && (rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
         // The class launches and the multi-chunk scorer both start from k2w_classify's lists and write disjoint records, and each is a persistent
         // grid whose last round leaves most of the chip idle (the multi-chunk scorer's third round is 4 % full on the C4 shard): the multi-chunk
         // scorer runs on a second stream, forked after the classifier and joined before the caller's stream continues.
         // multi-chunk windows by the width of their last chunk's tail (k2w_classify's lists 3-6 -> k2d_dp_multi_tc): needs the classifier, dp_cfm.h's
         // form and a needle without NUL (cf_ok includes pad_ok)
-        static const bool no_tail_classes = getenv("FZB_NO_TAIL_CLASSES") != nullptr;  // comparison knob: every last chunk computed in full
+        const bool no_tail_classes = kn.no_tail_classes;  // comparison knob: every last chunk computed in full
         const int split = classes && !no_wide && mmode == 2 && !no_tail_classes;
         // the three class launches and the multi-chunk scorer as ONE launch (k2_classes_all: the grid cut into four slices) instead of four
         // launches on two streams: on a list of a million items each of the four is a single round of single items whose latencies and launch
         // boundaries add up along the stream (paths-shaped list 128 -> 102 us, a 2 M-item ragged list 143 -> 116 us), on the 12.5 M-item shard
         // the two are equal (0.447 ms).  FZB_SMALL_LIST=n keeps the four launches for lists of n haystacks and more (0: always).
-        static const u32 small_list = getenv("FZB_SMALL_LIST") ? (u32)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
+        const u32 small_list = kn.small_list;
         const bool all_in_one = split && cnt < small_list;
         bool fork = classes && !no_wide && !no_overlap && !all_in_one;
         if (fork && ensure_aux_stream(m) != FZB_OK) {  // no second stream: everything on the caller's stream (the error text is dropped with the fallback)
@@ -1206,20 +1233,13 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
 int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
     if (m->empty || c->dev.n == 0) return FZB_OK;
-    if (m->device < 0) {
-        int dev = 0;
-        HIPCHK(hipGetDevice(&dev));
-        hipDeviceProp_t prop;
-        HIPCHK(hipGetDeviceProperties(&prop, dev));
-        m->device = dev;
-        m->lc.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    int rc = fzb_bind_device(m);
+    if (rc) return rc;
     const size_t n = c->dev.n;
-    int rc = ensure_workspace(m, n);
+    rc = ensure_workspace(m, n);
     if (rc) return rc;
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
     if (!m->long_needle && !m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
-    if (fzb_fused_applies(c->dev, m->lc, m->nd, m->lc.window_mode) && (rc = ensure_fused_buffers(m))) return rc;
     if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;
     return FZB_OK;
@@ -1242,25 +1262,43 @@ int fzb_sorted_range_device(fzb_matcher* m, const fzb_corpus* c, size_t first, s
                             void* stream) {
     if (!m || !c) return fail(FZB_ERR_INVALID, "null argument");
     if (first > c->dev.n || count > c->dev.n - first) return fail(FZB_ERR_INVALID, "range outside the corpus");
-    const int sort = m->config.sort;
-    const bool reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;          // src/matcher/mod.rs:215-217
-    const bool by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;  // :218-220
-    Workspace& w = m->ws;
     const size_t cap = std::min<size_t>(capacity, count);
-    // one radix pass is enough when no score can reach 256 (Scoring::guard's bound on the matrix + the exact-match bonus added after it)
-    const bool one_pass = !m->literal_mode && max_matrix_score(m->config.scoring, (size_t)m->rows) + (size_t)m->config.scoring.exact_match_bonus < 256;
-    // With a single pass the pipeline writes its index-ordered records into the sort's second buffer and the pass scatters them into the
-    // caller's array: no copy back.
-    const bool via_tmp = by_score && one_pass && !m->empty && count != 0 && cap != 0;
+    OrderPlan plan;
     int rc;
     // (the range workspace first: growing it releases every workspace buffer, the sort's included)
-    if (via_tmp && ((rc = ensure_workspace(m, count)) || (rc = ensure_sort_buffers(m, cap)))) return rc;
-    rc = fzb_match_list_device(m, c, first, count, index_offset, via_tmp ? (fzb_match*)w.sort_tmp : dev_out, via_tmp ? cap : capacity, dev_count, stream);
+    if (!m->empty && count != 0 && ((rc = fzb_bind_device(m)) || (rc = ensure_workspace(m, count)))) return rc;
+    if ((rc = fzb_order_begin(m, m->empty || count == 0 ? 0 : cap, (fzb_match_rec*)dev_out, &plan))) return rc;
+    rc = fzb_match_list_device(m, c, first, count, index_offset, (fzb_match*)plan.in, plan.via_tmp ? cap : capacity, dev_count, stream);
     if (rc) return rc;
-    if ((!reversed && !by_score) || count == 0) return FZB_OK;
-    if (by_score && !via_tmp && (rc = ensure_sort_buffers(m, cap))) return rc;
-    fzb_launch_sort((fzb_match_rec*)dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), reversed, by_score, m->lc.num_cus * 2, (hipStream_t)stream,
-                    via_tmp ? -1 : one_pass ? 1 : 2);
+    if (count == 0) return FZB_OK;
+    return fzb_order_finish(m, plan, (fzb_match_rec*)dev_out, dev_count, (hipStream_t)stream);
+}
+
+// The ordering post-step of `match_list` (src/matcher/mod.rs:215-221: reverse for the *Desc strategies, radix_sort_matches for the Score*
+// strategies) over index-ordered records that are, or are about to be, in device memory.  fzb_order_begin sizes the sort's buffers for
+// `cap` records and says where the producer should write them (`plan.in`): with a single radix pass that is the sort's SECOND buffer and
+// the pass scatters into the caller's array - no copy back.  fzb_order_finish launches reverse / sort on `stream`; the record count is
+// read from device memory.  Producers: the pipeline (above), the concatenation of per-shard runs (host_shard.hip).
+int fzb_order_begin(fzb_matcher* m, size_t cap, fzb_match_rec* dev_out, OrderPlan* p) {
+    const int sort = m->config.sort;
+    p->reversed = sort == FZB_SORT_INDEX_DESC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;          // src/matcher/mod.rs:215-217
+    p->by_score = sort == FZB_SORT_SCORE_THEN_INDEX_ASC || sort == FZB_SORT_SCORE_THEN_INDEX_DESC;  // :218-220
+    // one radix pass is enough when no score can reach 256 (Scoring::guard's bound on the matrix + the exact-match bonus added after it)
+    p->one_pass = !m->literal_mode && max_matrix_score(m->config.scoring, (size_t)m->rows) + (size_t)m->config.scoring.exact_match_bonus < 256;
+    p->via_tmp = p->by_score && p->one_pass && cap != 0;
+    p->in = dev_out;
+    if (p->by_score) {
+        int rc = ensure_sort_buffers(m, cap);
+        if (rc) return rc;
+        if (p->via_tmp) p->in = m->ws.sort_tmp;
+    }
+    return FZB_OK;
+}
+int fzb_order_finish(fzb_matcher* m, const OrderPlan& p, fzb_match_rec* dev_out, const u32* dev_count, hipStream_t stream) {
+    if (!p.reversed && !p.by_score) return FZB_OK;
+    Workspace& w = m->ws;
+    if (p.by_score && !w.sort_tmp) return fail(FZB_ERR_INVALID, "fzb_order_finish without fzb_order_begin");
+    fzb_launch_sort(dev_out, w.sort_tmp, dev_count, w.sort_hist, (u32)(w.sort_cap / 2048 + 2), p.reversed, p.by_score, m->lc.num_cus * 2, stream, p.via_tmp ? -1 : p.one_pass ? 1 : 2);
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }

@@ -8,6 +8,7 @@
 
 #include "../../include/frizbee_hip.h"
 #include "fzb_internal.h"
+#include "knobs.h"
 
 // error state of the calling thread (fzb_last_error) + the usual early return
 int fzb_fail(int code, const std::string& msg);
@@ -80,7 +81,10 @@ struct fzb_matcher {
     // multi-device form (host_shard.hip): the per-shard clones of this matcher (their device state lives on the shard's device);
     // on a clone: its stream and the device it is bound to
     std::vector<fzb_matcher*> shard_clones;
-    hipStream_t shard_stream = nullptr;
+    void* shard_workers = nullptr;     // on the parent: the persistent worker threads, one per shard (host_shard.hip)
+    hipStream_t shard_stream = nullptr;  // on a clone: the shard's stream; on the parent: the root's stream (ordering + copy to the host)
+    hipEvent_t shard_event = nullptr;    // on a clone: "the run has arrived on the root"
+    u32* shard_count_host = nullptr;     // on a clone: page-locked landing place of its record count
     int shard_device = -1;
 };
 
@@ -91,10 +95,20 @@ void* fzb_pinned_get(size_t bytes);
 bool fzb_pinned_put(void* p);
 
 // host.hip internals used by the other translation units
+int fzb_bind_device(fzb_matcher* m);
 int fzb_ensure_out_staging(fzb_matcher* m, size_t count);
+// the ordering post-step of `match_list` on the device (host.hip, next to fzb_sorted_range_device)
+struct OrderPlan {
+    bool reversed, by_score, one_pass, via_tmp;
+    fzb_match_rec* in;  // where the index-ordered records have to be written before fzb_order_finish
+};
+int fzb_order_begin(fzb_matcher* m, size_t cap, fzb_match_rec* dev_out, OrderPlan* p);
+int fzb_order_finish(fzb_matcher* m, const OrderPlan& p, fzb_match_rec* dev_out, const u32* dev_count, hipStream_t stream);
 // `Matcher::match_list` over the sub-range [first, first + count) of a corpus, records numbered from index_offset, ordered per
 // config.sort on the device (fzb_match_list_sorted_device = the whole corpus from 0)
 // k_merge_matches_by_* (src/k_merge.rs:56-132) over runs given by pointer
 int fzb_k_merge_runs(int32_t sort, const fzb_match* const* runs, const size_t* run_lens, size_t nruns, fzb_match* out);
+void fzb_shard_workers_free(void* workers);  // host_shard.hip
+int fzb_build_filter_view(fzb_corpus* c);     // host_upload.hip
 int fzb_sorted_range_device(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, fzb_match* dev_out, size_t capacity, uint32_t* dev_count,
                             void* stream);

@@ -1,13 +1,20 @@
 // The multi-device form of the boundary: `Matcher::match_list_parallel` (src/matcher/parallel.rs:18-89) with the GPUs of one node in
 // the role of its worker threads.  The reference cuts the list into contiguous chunks, gives every worker a global index offset
 // (parallel.rs:55-63), sorts each worker's run (:66-76) and k-way merges the runs (:78-87).  Here a shard is one contiguous index range
-// resident on one device; per query one host thread per shard (hipSetDevice, its own stream and its own clone of the matcher, whose
-// workspace lives on that device) runs pipeline + device reverse / radix sort and copies its ordered run to the host; the calling
-// thread merges the runs with fzb_k_merge_matches' tournament.  No device-to-device traffic: only the host consumes the result
-// (north_star: "(score,index) top-k feeding radix_sort_matches on the host").  A Rust host binds exactly this - no Python, no torch.
+// resident on one device.  Per query a persistent host thread per shard (hipSetDevice, its own stream and its own clone of the matcher,
+// whose workspace lives on that device) runs the pipeline UNSORTED - the shard's records in index order - reads back the record count
+// (8 bytes) and copies the run, device to device, to its place in one list on the ROOT device (the caller's current device): shard order
+// is ascending index order, so the concatenation is exactly the list `match_list` orders, and the root runs the reverse / stable radix
+// sort ONCE (kernels_sort.hip) and makes ONE copy to the host.  Same result as the reference's per-run sort + k-way merge, without a
+// host heap (round 3 merged on the host: 17 ns per record on one thread, 67 ms for 8 x 500 k records).
+// A Rust host binds exactly this - no Python, no torch.
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "host_internal.h"
@@ -42,6 +49,80 @@ int for_shards(size_t nshards, F fn) {
         if (res[g].rc) return fzb_fail(res[g].rc, "shard " + std::to_string(g) + ": " + res[g].err);
     return FZB_OK;
 }
+
+// The workers of the multi-device query: one persistent host thread per shard, owned by the matcher (the reference spawns its
+// workers per call, src/matcher/parallel.rs:43-64 - for a 0.1 ms query that is most of the time).  A worker that has just finished
+// a job polls for the next one for a short while before it sleeps, so a steady stream of queries never pays a wake-up.
+class ShardWorkers {
+public:
+    explicit ShardWorkers(size_t n) : res_(n) {
+        for (size_t g = 1; g < n; g++) th_.emplace_back([this, g] { loop(g); });
+    }
+    ~ShardWorkers() {
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            stop_ = true;
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        for (auto& t : th_) t.join();
+    }
+    size_t size() const { return res_.size(); }
+    // fn(g) for g < n, shard 0 on the calling thread; the first failure (lowest shard) becomes the calling thread's error
+    int run(size_t n, const std::function<int(size_t)>& fn) {
+        if (!n) return FZB_OK;
+        fn_ = &fn;
+        n_ = n;
+        pending_.store((int)th_.size(), std::memory_order_relaxed);  // every worker wakes; those beyond n have nothing to do
+        {
+            std::lock_guard<std::mutex> l(mu_);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        body(0);
+        for (unsigned spin = 0; pending_.load(std::memory_order_acquire) > 0; spin++)
+            if (spin > 4096) std::this_thread::yield();
+        for (size_t g = 0; g < n; g++)
+            if (res_[g].rc) return fzb_fail(res_[g].rc, "shard " + std::to_string(g) + ": " + res_[g].err);
+        return FZB_OK;
+    }
+
+private:
+    void body(size_t g) {
+        res_[g].rc = (*fn_)(g);
+        if (res_[g].rc) res_[g].err = fzb_last_error();  // the worker's thread-local message
+        else res_[g].err.clear();
+    }
+    void loop(size_t g) {
+        uint64_t seen = 0;
+        for (;;) {
+            uint64_t now;
+            for (unsigned spin = 0; (now = gen_.load(std::memory_order_acquire)) == seen && spin < 20000; spin++) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            if (now == seen) {
+                std::unique_lock<std::mutex> l(mu_);
+                cv_.wait(l, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                now = gen_.load(std::memory_order_acquire);
+            }
+            seen = now;
+            if (stop_) return;
+            if (g < n_) body(g);
+            pending_.fetch_sub(1, std::memory_order_release);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::vector<ThreadResult> res_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<int> pending_{0};
+    const std::function<int(size_t)>* fn_ = nullptr;
+    size_t n_ = 0;
+    bool stop_ = false;
+};
 }  // namespace
 
 extern "C" {
@@ -105,12 +186,15 @@ int fzb_corpus_upload_sharded(const uint8_t* bytes, const uint64_t* end_offsets,
     sc->device.resize((size_t)ndev);
     sc->shard.assign((size_t)ndev, nullptr);
     for (int g = 0; g < ndev; g++) sc->device[(size_t)g] = g % have;
+    int cur = 0;
+    const bool have_cur = hipGetDevice(&cur) == hipSuccess;  // shard 0 is uploaded on the calling thread: its current device is restored below
     rc = for_shards((size_t)ndev, [&](size_t g) -> int {
         HIPCHK(hipSetDevice(sc->device[g]));
         const u64 lo = sc->bounds[g], hi = sc->bounds[g + 1];
         const u64 base = lo ? end_offsets[lo - 1] : 0;
         return fzb_corpus_upload_impl(bytes ? bytes + base : nullptr, end_offsets ? end_offsets + lo : nullptr, (size_t)(hi - lo), base, &sc->shard[g]);
     });
+    if (have_cur) (void)hipSetDevice(cur);
     if (rc) {
         const std::string msg = fzb_last_error();
         fzb_sharded_corpus_free(sc);
@@ -158,70 +242,177 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         *out_len = sc->n;
         return FZB_OK;
     }
-    // one clone of the matcher per shard (host work only; its device state is created by the shard's thread on the shard's device and
-    // kept across queries and across fzb_matcher_set_pattern / set_config)
+    // The ROOT: the device that is current on the calling thread.  It receives every shard's run and orders the whole list once.
+    int rc = fzb_bind_device(m);
+    if (rc) return rc;
+    const int root = m->device;
+    if (!m->shard_stream) HIPCHK(hipStreamCreateWithFlags(&m->shard_stream, hipStreamNonBlocking));
+    if (sc->n == 0) return FZB_OK;
+    if ((rc = fzb_ensure_out_staging(m, sc->n))) return rc;
+    OrderPlan plan;
+    if ((rc = fzb_order_begin(m, sc->n, m->out_dev, &plan))) return rc;
+    fzb_match_rec* const gather = plan.in;  // the concatenation of the runs (the sort's second buffer when one radix pass orders it)
+    // one clone of the matcher per shard (host work only; its device state is created by the shard's worker on the shard's device and
+    // kept across queries and across fzb_matcher_set_pattern / set_config).  A clone follows its shard to another device: its device
+    // state is released where it lives and built again on first use.
     while (m->shard_clones.size() < ns) {
         fzb_matcher* cm = nullptr;
-        int rc = fzb_matcher_clone(m, &cm);
-        if (rc) return rc;
+        if ((rc = fzb_matcher_clone(m, &cm))) return rc;
         m->shard_clones.push_back(cm);
     }
-    std::vector<fzb_match*> runs(ns, nullptr);
-    std::vector<size_t> lens(ns, 0);
-    int cur = 0;
-    HIPCHK(hipGetDevice(&cur));
-    int rc = for_shards(ns, [&](size_t g) -> int {
+    for (size_t g = 0; g < ns; g++) {
+        fzb_matcher*& cm = m->shard_clones[g];
+        if (cm->shard_device >= 0 && cm->shard_device != sc->device[g]) {
+            (void)hipSetDevice(cm->shard_device);
+            fzb_matcher_free(cm);
+            cm = nullptr;
+            (void)hipSetDevice(root);
+            if ((rc = fzb_matcher_clone(m, &cm))) {
+                m->shard_clones.resize(g);  // the clones behind this one were not touched; they are rebuilt on the next call
+                return rc;
+            }
+        }
+    }
+    ShardWorkers* pool = (ShardWorkers*)m->shard_workers;
+    if (!pool || pool->size() < ns) {
+        delete pool;
+        m->shard_workers = pool = new ShardWorkers(ns);
+    }
+    // counts[g]: shard g's number of records, published by its worker as soon as it is known (-1 before); worker g starts its copy
+    // when the counts of the shards below it are in - the prefix is where its run starts in the gathered list
+    std::vector<std::atomic<int64_t>> counts(ns);
+    for (auto& c : counts) c.store(-1, std::memory_order_relaxed);
+    std::vector<u8> copied(ns, 0);
+    rc = pool->run(ns, [&](size_t g) -> int {
+        struct Publish {  // whatever happens, the workers above must not wait for this one
+            std::atomic<int64_t>& slot;
+            ~Publish() { if (slot.load(std::memory_order_relaxed) < 0) slot.store(0, std::memory_order_release); }
+        } publish{counts[g]};
         const fzb_corpus* c = sc->shard[g];
         const size_t count = (size_t)c->dev.n;
         if (!count) return FZB_OK;
         HIPCHK(hipSetDevice(sc->device[g]));
         fzb_matcher* cm = m->shard_clones[g];
-        if (cm->shard_device != sc->device[g]) {
-            if (cm->shard_device >= 0) return fzb_fail(FZB_ERR_INVALID, "matcher was used with another sharded corpus whose shard " + std::to_string(g) + " lives on a different device");
+        if (cm->shard_device < 0) {
             HIPCHK(hipStreamCreateWithFlags(&cm->shard_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&cm->shard_event, hipEventDisableTiming));
+            HIPCHK(hipHostMalloc((void**)&cm->shard_count_host, 16, hipHostMallocDefault));
             cm->shard_device = sc->device[g];
         }
         int rc_ = fzb_ensure_out_staging(cm, count);
         if (rc_) return rc_;
-        rc_ = fzb_sorted_range_device(cm, c, 0, count, (uint32_t)sc->bounds[g], (fzb_match*)cm->out_dev, cm->out_cap, cm->count_dev, cm->shard_stream);
+        // the shard's records in INDEX order, numbered from the shard's first index (what a worker of match_list_parallel pushes,
+        // parallel.rs:55-63) - unsorted: the root orders the whole list
+        rc_ = fzb_match_list_device(cm, c, 0, count, (uint32_t)sc->bounds[g], (fzb_match*)cm->out_dev, cm->out_cap, cm->count_dev, cm->shard_stream);
         if (rc_) return rc_;
-        u32 cnt[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(cnt, cm->count_dev, 8, hipMemcpyDeviceToHost, cm->shard_stream));
+        HIPCHK(hipMemcpyAsync(cm->shard_count_host, cm->count_dev, 8, hipMemcpyDeviceToHost, cm->shard_stream));
         HIPCHK(hipStreamSynchronize(cm->shard_stream));
-        fzb_match* r = (fzb_match*)fzb_pinned_get(std::max<size_t>(cnt[0], 1) * sizeof(fzb_match));
-        if (!r) return fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for a shard's run");
-        if (cnt[0]) {
-            hipError_t e = hipMemcpyAsync(r, cm->out_dev, (size_t)cnt[0] * sizeof(fzb_match), hipMemcpyDeviceToHost, cm->shard_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(cm->shard_stream);
-            if (e != hipSuccess) {
-                fzb_pinned_put(r);
-                return fzb_fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));
-            }
+        const u32 cnt = cm->shard_count_host[0];
+        counts[g].store((int64_t)cnt, std::memory_order_release);
+        if (!cnt) return FZB_OK;
+        size_t at = 0;
+        for (size_t k = 0; k < g; k++) {
+            int64_t v;
+            for (unsigned spin = 0; (v = counts[k].load(std::memory_order_acquire)) < 0; spin++)
+                if (spin > 4096) std::this_thread::yield();
+            at += (size_t)v;
         }
-        runs[g] = r;
-        lens[g] = cnt[0];
+        // the run goes to its place in the root's list: device to device over xGMI (or inside the one device the shards share)
+        if (sc->device[g] == root) HIPCHK(hipMemcpyAsync(gather + at, cm->out_dev, (size_t)cnt * sizeof(fzb_match_rec), hipMemcpyDeviceToDevice, cm->shard_stream));
+        else HIPCHK(hipMemcpyPeerAsync(gather + at, root, cm->out_dev, sc->device[g], (size_t)cnt * sizeof(fzb_match_rec), cm->shard_stream));
+        HIPCHK(hipEventRecord(cm->shard_event, cm->shard_stream));
+        copied[g] = 1;
         return FZB_OK;
     });
-    (void)hipSetDevice(cur);
-    size_t total = 0;
-    for (size_t g = 0; g < ns; g++) total += lens[g];
-    fzb_match* merged = nullptr;
-    if (!rc) {
-        merged = (fzb_match*)malloc(std::max<size_t>(total, 1) * sizeof(fzb_match));
-        if (!merged) rc = fzb_fail(FZB_ERR_INVALID, "out of memory");
-    }
-    // k_merge_matches_by_* over the per-shard runs (parallel.rs:78-87).  Every run is ordered per `sort` and the shards are contiguous,
-    // ascending index ranges, so the merge is a concatenation for the index orders; the score orders take the tournament.
-    if (!rc) rc = fzb_k_merge_runs(sort, runs.data(), lens.data(), ns, merged);
-    for (size_t g = 0; g < ns; g++)
-        if (runs[g]) fzb_pinned_put(runs[g]);
-    if (rc) {
-        free(merged);
+    (void)hipSetDevice(root);
+    if (rc) {  // let the copies that were started finish before anything else touches the buffers
+        for (size_t g = 0; g < ns; g++)
+            if (copied[g]) (void)hipEventSynchronize(m->shard_clones[g]->shard_event);
         return rc;
     }
-    *out = merged;
+    size_t total = 0;
+    u32 agg[4] = {0, 0, 0, 0};
+    for (size_t g = 0; g < ns; g++) {
+        total += (size_t)std::max<int64_t>(counts[g].load(std::memory_order_acquire), 0);
+        if (copied[g]) HIPCHK(hipStreamWaitEvent(m->shard_stream, m->shard_clones[g]->shard_event, 0));
+        for (int k = 0; k < 4; k++) agg[k] += m->shard_clones[g]->last_counters[k];
+    }
+    memcpy(m->last_counters, agg, sizeof(agg));  // fzb_last_counters on the parent = the sum over the shards
+    if (!total) return FZB_OK;
+    // the whole list's count -> device memory (the sort reads it there), reverse / stable radix sort ONCE, one copy to the host
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->count_dev, (int)(u32)total, 1, m->shard_stream));
+    if ((rc = fzb_order_finish(m, plan, m->out_dev, m->count_dev, m->shard_stream))) return rc;
+    fzb_match* r = (fzb_match*)fzb_pinned_get(total * sizeof(fzb_match));
+    if (!r) return fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
+    const fzb_match_rec* final_dev = (plan.reversed || plan.by_score) ? m->out_dev : gather;
+    hipError_t e = hipMemcpyAsync(r, final_dev, total * sizeof(fzb_match), hipMemcpyDeviceToHost, m->shard_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->shard_stream);
+    if (e != hipSuccess) {
+        fzb_pinned_put(r);
+        return fzb_fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));
+    }
+    *out = r;
     *out_len = total;
     return FZB_OK;
 }
 
+// The same combine for runs that are already on ONE device (frizbee_amd.distributed: the root rank after the RCCL gather of the
+// per-rank buffers): concatenation in run order -> reverse / stable radix sort -> one copy to the host.  dev_counts[g] points at run
+// g's record count in device memory, so nothing is read back before the final list.
+int fzb_merge_shard_runs(fzb_matcher* m, const void* const* dev_runs, const uint32_t* const* dev_counts, const size_t* run_caps, size_t nruns, void* stream, fzb_match** out,
+                         size_t* out_len) {
+    if (!m || !out || !out_len || (nruns && (!dev_runs || !dev_counts || !run_caps))) return fzb_fail(FZB_ERR_INVALID, "null argument");
+    *out = nullptr;
+    *out_len = 0;
+    if (!nruns) return FZB_OK;
+    int rc = fzb_bind_device(m);
+    if (rc) return rc;
+    size_t cap = 0;
+    for (size_t g = 0; g < nruns; g++) {
+        if (run_caps[g] > 0xFFFFFFFFull) return fzb_fail(FZB_ERR_INVALID, "run capacity beyond the u32 index space");
+        cap += run_caps[g];
+    }
+    if (cap > 0xFFFFFFFFull) return fzb_fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(cap) + " > 4294967295 (index offset: 0)");
+    if (!cap) return FZB_OK;
+    if ((rc = fzb_ensure_out_staging(m, cap))) return rc;
+    OrderPlan plan;
+    if ((rc = fzb_order_begin(m, cap, m->out_dev, &plan))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    u32* words = m->count_dev;  // [0..1] and [2..3]: running (written, found) totals, alternating between batches of FZB_MAX_RUNS runs
+    const u32* base = nullptr;
+    u32* tot = words;
+    for (size_t g0 = 0; g0 < nruns; g0 += FZB_MAX_RUNS) {
+        RunSet rs{};
+        rs.n = (int)std::min<size_t>(FZB_MAX_RUNS, nruns - g0);
+        for (int k = 0; k < rs.n; k++) {
+            rs.run[k] = (const fzb_match_rec*)dev_runs[g0 + (size_t)k];
+            rs.count[k] = dev_counts[g0 + (size_t)k];
+            rs.cap[k] = (u32)run_caps[g0 + (size_t)k];
+        }
+        fzb_launch_concat_runs(rs, base, tot, plan.in, (u32)cap, m->lc.num_cus * 2, st);
+        base = tot;
+        tot = tot == words ? words + 2 : words;
+    }
+    HIPCHK(hipGetLastError());
+    if ((rc = fzb_order_finish(m, plan, m->out_dev, base, st))) return rc;
+    u32 n = 0;
+    HIPCHK(hipMemcpyAsync(&n, base, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!n) return FZB_OK;
+    fzb_match* r = (fzb_match*)fzb_pinned_get((size_t)n * sizeof(fzb_match));
+    if (!r) return fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
+    const fzb_match_rec* final_dev = (plan.reversed || plan.by_score) ? m->out_dev : plan.in;
+    hipError_t e = hipMemcpyAsync(r, final_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        fzb_pinned_put(r);
+        return fzb_fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));
+    }
+    *out = r;
+    *out_len = n;
+    return FZB_OK;
+}
+
 }  // extern "C"
+
+void fzb_shard_workers_free(void* p) { delete (ShardWorkers*)p; }

@@ -187,8 +187,9 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_build(const u8* __restrict__ 
 //   k_up_view_fill   writes the groups' block offsets and copies every vector to its interleaved position (the buffer was cleared: the
 //                    zero vectors behind a group's shorter members are already there)
 #define FV_CLASSES 18  // vector counts 0..16 (haystacks up to 256 bytes) and a guard class
-__global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const u32* __restrict__ ends, u64 n, u16* __restrict__ vperm, u16* __restrict__ vlen, u8* __restrict__ vgnv,
-                                                             u64* __restrict__ tile_units) {
+template <typename ET>
+__global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restrict__ ends, u64 n, u16* __restrict__ vperm, u16* __restrict__ vlen, u8* __restrict__ vgnv,
+                                                             u64* __restrict__ tile_units, UpStats* __restrict__ stats) {
     __shared__ u32 s_len[UP_TILE];
     __shared__ u16 s_inv[UP_TILE];
     __shared__ u32 s_hist[FV_CLASSES], s_base[FV_CLASSES];
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const u32* __restri
         const u32 j = tid + UP_THREADS * k;
         cls[k] = rk[k] = 0;
         if (j < nt) {
-            const u32 st = (i0 + j) ? (ends[i0 + j - 1] + 15u) & ~15u : 0u;
-            const u32 len = ends[i0 + j] - st;
+            const ET st = (i0 + j) ? (ends[i0 + j - 1] + (ET)15) & ~(ET)15 : (ET)0;
+            const u32 len = (u32)min((u64)(ends[i0 + j] - st), (u64)0xFFFFu);  // (beyond 256 bytes there is no view: the guard class reports it)
             s_len[j] = len;
             cls[k] = min((len + 15u) >> 4, (u32)FV_CLASSES - 1);
             rk[k] = atomicAdd(&s_hist[cls[k]], 1u);
@@ -212,8 +213,14 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const u32* __restri
     }
     __syncthreads();
     if (tid == 0) {  // descending: the longest class first
-        u32 run = 0;
-        for (int c = FV_CLASSES - 1; c >= 0; c--) { s_base[c] = run; run += s_hist[c]; }
+        u32 run = 0, top = 0, low = FV_CLASSES;
+        for (int c = FV_CLASSES - 1; c >= 0; c--) {
+            s_base[c] = run;
+            run += s_hist[c];
+            if (s_hist[c]) { top = max(top, (u32)c); low = min(low, (u32)c); }
+        }
+        atomicMax((unsigned long long*)&stats->max_len, (unsigned long long)top);  // in VECTORS here: the view's widest / narrowest member
+        atomicMin((unsigned long long*)&stats->min_len, (unsigned long long)low);
     }
     __syncthreads();
 #pragma unroll
@@ -245,7 +252,8 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const u32* __restri
     }
 }
 
-__global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restrict__ bytes, const u32* __restrict__ ends, u64 n, const u16* __restrict__ vperm,
+template <typename ET>
+__global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 n, const u16* __restrict__ vperm,
                                                              const u8* __restrict__ vgnv, const u64* __restrict__ tile_base_units, u8* __restrict__ vbytes, u32* __restrict__ vgofs) {
     __shared__ u32 s_gofs[UP_TILE / 64];
     const u64 i0 = (u64)blockIdx.x * UP_TILE;
@@ -263,8 +271,8 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restric
     // four threads per sorted haystack, each copying every fourth vector
     for (u32 p = tid >> 2; p < nt; p += UP_THREADS / 4) {
         const u64 j = i0 + vperm[i0 + p];
-        const u32 st = j ? (ends[j - 1] + 15u) & ~15u : 0u;
-        const u32 nv = (ends[j] - st + 15u) >> 4;
+        const ET st = j ? (ends[j - 1] + (ET)15) & ~(ET)15 : (ET)0;
+        const u32 nv = (u32)((ends[j] - st + (ET)15) >> 4);
         const uint4* src = (const uint4*)(bytes + st);
         uint4* dst = (uint4*)(vbytes + (size_t)s_gofs[p >> 6] * 16 + (size_t)(p & 63) * 16);
         for (u32 v = tid & 3; v < nv; v += 4) dst[(size_t)v * 64] = src[v];
@@ -274,16 +282,7 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restric
 // ---- host -> device at link speed ---------------------------------------------------------------------------------------------
 // FZB_UPLOAD_MODE: "direct" (default; one hipMemcpy per array straight from the caller's pageable memory; "pageable" is accepted as a
 // synonym), "register" (hipHostRegister the caller's memory, then copy), "staged" (per-thread pinned staging + asynchronous copies)
-int upload_mode() {
-    static const int mode = [] {
-        const char* e = getenv("FZB_UPLOAD_MODE");
-        if (!e) return 2;
-        if (!strcmp(e, "register")) return 1;
-        if (!strcmp(e, "staged")) return 0;
-        return 2;
-    }();
-    return mode;
-}
+int upload_mode() { return fzb_knobs().upload_mode; }
 
 struct H2DJob {
     void* dst;
@@ -324,7 +323,7 @@ hipError_t h2d_all(const std::vector<H2DJob>& jobs, int device) {
     // staged: the concatenation of all jobs is cut into equal slices, one per worker thread
     constexpr size_t CHUNK = (size_t)4 << 20;
     const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
-    static const size_t env_threads = getenv("FZB_UPLOAD_THREADS") ? (size_t)atoi(getenv("FZB_UPLOAD_THREADS")) : 0;
+    const size_t env_threads = (size_t)fzb_knobs().upload_threads;
     const size_t nthreads = std::max<size_t>(1, std::min<size_t>({env_threads ? env_threads : (size_t)12, hw, (total + CHUNK - 1) / CHUNK}));
     const size_t per = ((total + nthreads - 1) / nthreads + 63) & ~(size_t)63;
     std::vector<hipError_t> errs(nthreads, hipSuccess);
@@ -376,6 +375,84 @@ hipError_t h2d_all(const std::vector<H2DJob>& jobs, int device) {
 }
 
 }  // namespace
+
+// The streaming filter's view of a corpus whose canonical layout is resident (uploaded or borrowed), on the CURRENT device.  Sets
+// c->dev.v* and view_nv on success; leaves the corpus without a view (and returns FZB_OK) when the list does not call for one - a
+// haystack beyond 256 bytes, nothing beyond 32, a uniform-length list - or when the device has no room: the view is an accelerator,
+// not part of the corpus (the filter then streams the canonical layout).  Any other error is reported.
+int fzb_build_filter_view(fzb_corpus* c) {
+    const bool want_view = !fzb_knobs().no_filter_view;
+    const u64 n = c->dev.n;
+    if (!want_view || !n || c->dev.uniform_len || c->dev.vbytes) return FZB_OK;
+    const u64 ntiles = (n + UP_TILE - 1) / UP_TILE;
+    const size_t ngroups = (size_t)ntiles * (UP_TILE / 64);
+    u64* d_vt = nullptr;
+    UpStats* d_stats = nullptr;
+    auto drop_view = [&]() {
+        if (d_vt) (void)hipFree(d_vt);
+        if (d_stats) (void)hipFree(d_stats);
+        d_vt = nullptr;
+        d_stats = nullptr;
+        for (int q = 0; q < 5; q++) { if (c->own_view[q]) (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
+        (void)hipGetLastError();
+    };
+    auto bail = [&](hipError_t e) {
+        drop_view();
+        return fzb_fail(FZB_ERR_HIP, std::string("filter view: ") + hipGetErrorString(e));
+    };
+    hipError_t e = fzb_dev_alloc(&c->own_view[3], n * 2);
+    if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[4], n * 2);
+    if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[2], ngroups);
+    if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[1], ngroups * 4);
+    if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_vt, (size_t)ntiles * 8);
+    if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_stats, sizeof(UpStats));
+    if (e == hipErrorOutOfMemory) { drop_view(); return FZB_OK; }
+    if (e != hipSuccess) return bail(e);
+    const UpStats init{0, ~(u64)0, 0, 0};
+    e = hipMemcpy(d_stats, &init, sizeof(init), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return bail(e);
+    if (c->dev.ends_u64)
+        hipLaunchKernelGGL((k_up_view_sort<u64>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u64*)c->dev.ends, n, (u16*)c->own_view[4], (u16*)c->own_view[3], (u8*)c->own_view[2], d_vt, d_stats);
+    else
+        hipLaunchKernelGGL((k_up_view_sort<u32>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u32*)c->dev.ends, n, (u16*)c->own_view[4], (u16*)c->own_view[3], (u8*)c->own_view[2], d_vt, d_stats);
+    hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, nullptr, d_vt, ntiles, d_stats);  // total_padded = the view's size in 16-byte units
+    UpStats vst{0, 0, 0, 0};
+    e = hipMemcpy(&vst, d_stats, sizeof(vst), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return bail(e);
+    // (min_len / max_len are in VECTORS here) no view: a member beyond 256 bytes (the guard class), nothing beyond 32 bytes (the short
+    // kernels serve that list), or group offsets beyond 32 bits of 16-byte units (64 GB)
+    if (vst.max_len > 16 || vst.max_len <= 2 || vst.total_padded > 0xFFFFFFF0ull) { drop_view(); return FZB_OK; }
+    const u64 view_bytes = vst.total_padded * 16;
+    e = fzb_dev_alloc(&c->own_view[0], view_bytes + 1024);
+    if (e == hipErrorOutOfMemory) { drop_view(); return FZB_OK; }
+    if (e == hipSuccess) e = hipMemsetAsync(c->own_view[0], 0, view_bytes + 1024, nullptr);
+    if (e != hipSuccess) return bail(e);
+    if (c->dev.ends_u64)
+        hipLaunchKernelGGL((k_up_view_fill<u64>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, c->dev.bytes, (const u64*)c->dev.ends, n, (const u16*)c->own_view[4], (const u8*)c->own_view[2], (const u64*)d_vt, (u8*)c->own_view[0], (u32*)c->own_view[1]);
+    else
+        hipLaunchKernelGGL((k_up_view_fill<u32>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, c->dev.bytes, (const u32*)c->dev.ends, n, (const u16*)c->own_view[4], (const u8*)c->own_view[2], (const u64*)d_vt, (u8*)c->own_view[0], (u32*)c->own_view[1]);
+    e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return bail(e);
+    (void)hipFree(d_vt);
+    (void)hipFree(d_stats);
+    c->dev.vbytes = (const u8*)c->own_view[0];
+    c->dev.vgofs = (const u32*)c->own_view[1];
+    c->dev.vgnv = (const u8*)c->own_view[2];
+    c->dev.vlen = (const u16*)c->own_view[3];
+    c->dev.vperm = (const u16*)c->own_view[4];
+    c->dev.view_nv = (u32)vst.max_len;
+    return FZB_OK;
+}
+
+// For a BORROWED corpus (fzb_corpus_from_device; fzb_corpus_upload builds the view itself): the lengths are read from the end offsets,
+// so no hint is needed and a wrong fzb_corpus_set_max_len cannot mislead it.  *out_built (optional) = 1 when the corpus has a view now.
+extern "C" int fzb_corpus_build_view(fzb_corpus* c, int* out_built) {
+    if (!c) return fzb_fail(FZB_ERR_INVALID, "null argument");
+    const int rc = fzb_build_filter_view(c);
+    if (out_built) *out_built = c->dev.vbytes != nullptr;
+    return rc;
+}
 
 // The upload proper, on the CURRENT device: `bytes` points at the first byte of haystack 0 of this list, `end_offsets[i]` are exclusive
 // ends counted from `ends_base` (0 for a whole list; a shard passes the end of the haystack before its first one).
@@ -449,62 +526,23 @@ int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, si
         else { if (adopt) FZB_UP_BUILD(u32, false); else FZB_UP_BUILD(u32, true); }
 #undef FZB_UP_BUILD
     }
-    // the streaming filter's view (CorpusDev::vbytes): ragged lists with 32-bit offsets whose haystacks are 33..256 bytes.  A second copy of
-    // the bytes (+ ~5 % for the zero vectors behind shorter group members, + 4.2 bytes per haystack); FZB_FILTER_VIEW=0 turns it off.
-    static const bool want_view = !(getenv("FZB_FILTER_VIEW") && atoi(getenv("FZB_FILTER_VIEW")) == 0);
-    if (want_view && n && !ends_u64 && !c->dev.uniform_len && c->dev.max_len > 32 && c->dev.max_len <= 256) {
-        const size_t ngroups = (size_t)ntiles * (UP_TILE / 64);
-        u64* d_vt = nullptr;
-        e = fzb_dev_alloc(&c->own_view[3], n * 2);
-        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[4], n * 2);
-        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[2], ngroups);
-        if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[1], ngroups * 4);
-        if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_vt, (size_t)ntiles * 8);
-        // the view is an accelerator, not part of the corpus: when the device has no room for it the corpus goes without (the filter then
-        // streams the canonical layout); any other error fails the upload
-        auto drop_view = [&]() {
-            if (d_vt) (void)hipFree(d_vt);
-            d_vt = nullptr;
-            for (int q = 0; q < 5; q++) { if (c->own_view[q]) (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
-            (void)hipGetLastError();
-        };
-        if (e == hipErrorOutOfMemory) { drop_view(); goto view_done; }
-        if (e != hipSuccess) { if (d_vt) (void)hipFree(d_vt); return bail(e, "filter view"); }
-        hipLaunchKernelGGL(k_up_view_sort, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u32*)c->own_ends, (u64)n, (u16*)c->own_view[4], (u16*)c->own_view[3],
-                           (u8*)c->own_view[2], d_vt);
-        hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, nullptr, d_vt, ntiles, d_stats);  // (reuses the stats block: total_padded = the view's size in units)
-        UpStats vst{0, 0, 0, 0};
-        e = hipMemcpy(&vst, d_stats, sizeof(vst), hipMemcpyDeviceToHost);
-        const u64 view_bytes = vst.total_padded * 16;
-        if (e == hipSuccess && view_bytes / 16 > 0xFFFFFFF0ull) {  // group offsets are 32-bit units: no view beyond 64 GB
-            (void)hipFree(d_vt);
-            for (int q = 1; q < 5; q++) { (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
-        } else {
-            if (e == hipSuccess) {
-                e = fzb_dev_alloc(&c->own_view[0], view_bytes + 1024);
-                if (e == hipErrorOutOfMemory) { drop_view(); goto view_done; }
-            }
-            if (e == hipSuccess) e = hipMemsetAsync(c->own_view[0], 0, view_bytes + 1024, nullptr);
-            if (e != hipSuccess) { (void)hipFree(d_vt); return bail(e, "filter view"); }
-            hipLaunchKernelGGL(k_up_view_fill, dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u8*)c->own_bytes, (const u32*)c->own_ends, (u64)n, (const u16*)c->own_view[4],
-                               (const u8*)c->own_view[2], (const u64*)d_vt, (u8*)c->own_view[0], (u32*)c->own_view[1]);
-            e = hipDeviceSynchronize();
-            (void)hipFree(d_vt);
-            if (e != hipSuccess) return bail(e, "filter view");
-            c->dev.vbytes = (const u8*)c->own_view[0];
-            c->dev.vgofs = (const u32*)c->own_view[1];
-            c->dev.vgnv = (const u8*)c->own_view[2];
-            c->dev.vlen = (const u16*)c->own_view[3];
-            c->dev.vperm = (const u16*)c->own_view[4];
+    c->dev.bytes = (const u8*)c->own_bytes;
+    c->dev.ends = c->own_ends;
+    // the streaming filter's view (CorpusDev::vbytes): ragged lists whose haystacks are 33..256 bytes.  A second copy of the bytes (+ ~5 %
+    // for the zero vectors behind shorter group members, + 4.2 bytes per haystack); FZB_FILTER_VIEW=0 turns it off.
+    if (n && !c->dev.uniform_len && c->dev.max_len > 32 && c->dev.max_len <= 256) {
+        int rc = fzb_build_filter_view(c);
+        if (rc) {
+            const std::string msg = fzb_last_error();
+            cleanup();
+            fzb_corpus_free(c);
+            return fzb_fail(rc, msg);
         }
     }
-view_done:
     e = hipDeviceSynchronize();  // the temporaries are released below; the corpus is complete when the call returns
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) return bail(e, "layout kernels");
     cleanup();
-    c->dev.bytes = (const u8*)c->own_bytes;
-    c->dev.ends = c->own_ends;
     *out = c;
     return FZB_OK;
 }

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fzb_internal.h"
+#include "knobs.h"
 
 #define FZB_WAVE 64
 

@@ -447,7 +447,7 @@ void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, cons
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     if (part != 2) {
-        static const int per = [] { const char* e = getenv("FZB_CLASSIFY_PER"); const int v = e ? atoi(e) : 2; return v == 1 || v == 4 ? v : 2; }();  // tuning knob: survivors per thread
+        const int per = fzb_knobs().classify_per;  // tuning knob: survivors per thread
 #define FZB_K2W(ET, PER) hipLaunchKernelGGL((k2w_classify<ET, PER>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi)
 #define FZB_K2W_ET(PER) do { if (c.ends_u64) FZB_K2W(u64, PER); else FZB_K2W(u32, PER); } while (0)
         if (per == 1) FZB_K2W_ET(1); else if (per == 4) FZB_K2W_ET(4); else FZB_K2W_ET(2);
@@ -688,8 +688,9 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
     do {                                                                                                                                \
         static int per_cu = 0;                                                                                                          \
         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
-        if (const char* e_ = getenv("FZB_DP_WGS_PER_CU")) { const int v_ = atoi(e_); if (v_ >= 1 && v_ < per_cu) per_cu = v_; } /* tuning knob: leave room for a co-resident kernel */ \
-        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out, c.uniform_len); \
+        int use_cu = per_cu;                                                                                                            \
+        if (const int v_ = fzb_knobs().dp_wgs_per_cu) { if (v_ >= 1 && v_ < per_cu) use_cu = v_; } /* tuning knob: leave room for a co-resident kernel */ \
+        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * use_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out, c.uniform_len); \
     } while (0)
 #define FZB_K2S_ET(SWL, U) do { if (c.ends_u64) FZB_K2S(SWL, U, u64); else FZB_K2S(SWL, U, u32); } while (0)
 #define FZB_K2S_U(SWL) do { if (upper) FZB_K2S_ET(SWL, true); else FZB_K2S_ET(SWL, false); } while (0)

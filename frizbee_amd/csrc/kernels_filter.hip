@@ -885,19 +885,20 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             int rgrid = std::min<int>((grid / 8) * 6, (int)ntiles);
             if (rgrid < 1) rgrid = 1;
             // the class-composite automaton of `dfa` (host-built: fzb_matcher_create): one dependent lookup per 4 (or 2) bytes
-            static const bool no_cdfa = getenv("FZB_NO_CDFA") != nullptr;
-            static const int cwg = getenv("FZB_CDFA_WGS") ? atoi(getenv("FZB_CDFA_WGS")) : 5;  // resident workgroups per CU (C4 shard: 8 -> 247 us, 5 -> 232, 4 -> 229)
-            static const bool no_view = getenv("FZB_FILTER_VIEW") && atoi(getenv("FZB_FILTER_VIEW")) == 0;
-            static const int vwg = getenv("FZB_VIEW_WGS") ? atoi(getenv("FZB_VIEW_WGS")) : 6;  // (C4 shard: 8 -> 190 us, 6 -> 187, 4 -> 194)
+            const FzbKnobs& kn = fzb_knobs();
+            const bool no_cdfa = kn.no_cdfa;
+            const int cwg = kn.cdfa_wgs;  // resident workgroups per CU (C4 shard: 8 -> 247 us, 5 -> 232, 4 -> 229)
+            const bool no_view = kn.no_filter_view;
+            const int vwg = kn.view_wgs;  // (C4 shard: 8 -> 190 us, 6 -> 187, 4 -> 194)
             if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2) && c.vbytes && !no_view && first % FZB_TILE == 0 && (first + count == c.n || count % FZB_TILE == 0) &&
-                c.max_len <= 256) {
+                c.view_nv != 0 && c.view_nv <= 16) {
                 const size_t lds_v = ((cdfa_bytes + 15) & ~(size_t)15) + 16 + 128;
                 const int g = std::max(1, std::min<int>((grid / 8) * vwg, (int)ntiles));
                 u32 kg = 1;
                 for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
-                if (getenv("FZB_CDFA_NODFA")) cdfa_K = 0xFFFF;
+                if (kn.cdfa_nodfa) cdfa_K = 0xFFFF;
 #define FZB_K1V(SAN, G, NV) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
-#define FZB_K1V_NV(SAN, G) do { if (c.max_len <= 128) FZB_K1V(SAN, G, 8); else FZB_K1V(SAN, G, 16); } while (0)
+#define FZB_K1V_NV(SAN, G) do { if (c.view_nv <= 8) FZB_K1V(SAN, G, 8); else FZB_K1V(SAN, G, 16); } while (0)
 #define FZB_K1V_G(SAN) do { if (cdfa_G == 4) FZB_K1V_NV(SAN, 4); else FZB_K1V_NV(SAN, 2); } while (0)
                 if (nul_safe) FZB_K1V_G(false); else FZB_K1V_G(true);
 #undef FZB_K1V_G
@@ -910,8 +911,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 const int g = std::max(1, std::min<int>((grid / 8) * cwg, (int)ntiles));
                 u32 kg = 1;
                 for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
-                static const bool nodfa = getenv("FZB_CDFA_NODFA") != nullptr;
-                if (nodfa) cdfa_K = 0xFFFF;
+                if (kn.cdfa_nodfa) cdfa_K = 0xFFFF;
 #define FZB_K1CD(ET, SAN, G) hipLaunchKernelGGL((k1_cdfa_ragged<ET, SAN, G>), dim3(g), dim3(256), lds_c, st, c.bytes, (const ET*)c.ends, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
 #define FZB_K1CD_G(ET, SAN) do { if (cdfa_G == 4) FZB_K1CD(ET, SAN, 4); else FZB_K1CD(ET, SAN, 2); } while (0)
                 if (c.ends_u64) { if (nul_safe) FZB_K1CD_G(u64, false); else FZB_K1CD_G(u64, true); }
@@ -920,8 +920,8 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #undef FZB_K1CD
                 return;
             }
-            static const int burst = getenv("FZB_RAGGED_BURST") ? atoi(getenv("FZB_RAGGED_BURST")) : 1;  // 0 = the rolling form, for comparison
-            static const int bwgs = getenv("FZB_RAGGED_WGS") ? atoi(getenv("FZB_RAGGED_WGS")) : 8;
+            const bool burst = kn.ragged_burst;  // false = the rolling form, for comparison
+            const int bwgs = kn.ragged_wgs;
             if (burst) {
                 rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
 #define FZB_K1B(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_burst<ET, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)

@@ -151,6 +151,47 @@ __global__ __launch_bounds__(256) void k_reverse(fzb_match_rec* __restrict__ a, 
     }
 }
 
+// Per-shard runs -> one list (fzb_merge_shard_runs: what frizbee_amd.distributed runs on the root after the RCCL gather; more than
+// FZB_MAX_RUNS runs go through it in batches, `base_in` carrying the running total).  Shard g's run is index-ordered and the shards are
+// contiguous ascending index ranges, so the concatenation in shard order IS the index-ordered record list of the whole query: the
+// reverse / stable radix sort that follows reproduces `match_list`'s order exactly (src/matcher/mod.rs:215-221) - the result of
+// `match_list_parallel`'s per-run sort + k-way merge (src/matcher/parallel.rs:66-87) without a host heap.
+// Every workgroup scans the (<= 64) run lengths itself; a record finds its run by binary search in LDS.
+__global__ __launch_bounds__(256) void k_concat_runs(RunSet rs, const u32* __restrict__ base_in, u32* __restrict__ total_out, fzb_match_rec* __restrict__ out, u32 capacity) {
+    __shared__ u32 pre[FZB_MAX_RUNS + 1];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const u32 c = tid < rs.n ? min(*rs.count[tid], rs.cap[tid]) : 0u;
+        u32 incl = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const u32 t = __shfl_up(incl, off);
+            if (tid >= off) incl += t;
+        }
+        pre[tid + 1] = incl;
+        if (tid == 0) pre[0] = 0;
+    }
+    __syncthreads();
+    const u32 base = base_in ? *base_in : 0u;
+    const u32 total = pre[rs.n];
+    for (u32 i = blockIdx.x * 256u + tid; i < total; i += gridDim.x * 256u) {
+        int lo = 0, hi = rs.n - 1;  // last run whose prefix is <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (pre[mid] <= i) lo = mid;
+            else hi = mid - 1;
+        }
+        if (base + i < capacity) out[base + i] = rs.run[lo][i - pre[lo]];
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        total_out[0] = min(base + total, capacity);
+        total_out[1] = base + total;
+    }
+}
+
+void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_concat_runs, dim3(grid), dim3(256), 0, st, rs, base_in, total_out, out, capacity);
+}
+
 // records: `buf` (n = *n_ptr records, capacity cap) sorted in place; tmp >= cap records; hist >= 2 * 256 * ntiles_cap words
 __global__ __launch_bounds__(256) void k_sort_copy_back(const fzb_match_rec* __restrict__ tmp, fzb_match_rec* __restrict__ buf, const u32* __restrict__ n_ptr) {
     const u32 n = *n_ptr;

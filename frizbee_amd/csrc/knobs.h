@@ -1,0 +1,36 @@
+// Every environment switch of the library, in ONE place.  They exist for comparison and debugging only - the defaults are what is measured
+// and shipped - and are parsed once, on first use (fzb_knobs()); no launch path calls getenv.  tests/test_gpu_knobs.py runs every
+// alternative path against the oracle on the GPU through fzb_debug_reload_knobs() (test hook: re-parses the environment).
+#pragma once
+#include <stdint.h>
+
+struct FzbKnobs {
+    // --- which form of a stage runs (the alternative is always the older / literal form of the same arithmetic) ---
+    bool no_lcs_dfa = false;         // FZB_NO_LCS_DFA=1       typo filter: the bit-vector kernel k1_filter instead of the LCS automaton in k1_dfa
+    bool no_dp_cfu = false;          // FZB_NO_DP_CFU=1        unicode scorer in its first form
+    bool typo_exact_window = false;  // FZB_TYPO_EXACT_WINDOW=1 no typo fast path: every survivor re-decided at the exact lane width
+    bool no_dp_classes = false;      // FZB_NO_DP_CLASSES=1    per-wave choice of computed lanes (k2b_dp) instead of classified scoring
+    bool no_overlap = false;         // FZB_NO_OVERLAP=1       multi-chunk scorer on the caller's stream (only matters with FZB_SMALL_LIST)
+    bool no_dp_cfm = false;          // FZB_NO_DP_CFM=1        multi-chunk scorer in its first form (dp_body.h)
+    bool no_tail_classes = false;    // FZB_NO_TAIL_CLASSES=1  every last chunk of a multi-chunk window computed in full
+    bool no_cdfa = false;            // FZB_NO_CDFA=1          ragged filter: the byte automaton instead of the class-composite one
+    bool no_filter_view = false;     // FZB_FILTER_VIEW=0      no interleaved filter view (not built at upload, not used by the filter)
+    bool cdfa_nodfa = false;         // FZB_CDFA_NODFA=1       MEASUREMENT ONLY: the ragged filter's loads without the automaton (results meaningless)
+    bool ragged_burst = true;        // FZB_RAGGED_BURST=0     rolling form of the canonical-layout ragged filter
+    bool debug_sync = false;         // FZB_DEBUG_SYNC=1       synchronise and report after every stage of the pipeline
+    bool no_handoff = false;         // FZB_NO_HANDOFF=1       ragged lists: classifier and scorers gather the survivors' bytes from the corpus (no staging)
+    int k2u_waves = 0;               // FZB_K2U_WAVES=3        unicode scorer's biased form capped at three waves per SIMD (spills)
+    uint32_t small_list = 0xFFFFFFFFu;  // FZB_SMALL_LIST=n   lists of n haystacks and more: four scorer launches on two streams instead of k2_classes_all
+    // --- tuning (grid shapes) ---
+    int compact_grid_mul = 4;        // FZB_COMPACT_GRID_MUL   workgroups per CU of k_compact1
+    int classify_per = 2;            // FZB_CLASSIFY_PER=1|4   survivors per thread of k2w_classify
+    int dp_wgs_per_cu = 0;           // FZB_DP_WGS_PER_CU      fewer resident workgroups of the short scorer (0 = occupancy)
+    int cdfa_wgs = 5;                // FZB_CDFA_WGS           workgroups per CU, class-composite filter on the canonical layout
+    int view_wgs = 6;                // FZB_VIEW_WGS           workgroups per CU, filter over the view
+    int ragged_wgs = 8;              // FZB_RAGGED_WGS         workgroups per CU, burst filter
+    // --- upload ---
+    int upload_mode = 2;             // FZB_UPLOAD_MODE=register|staged (default direct = 2; register = 1; staged = 0)
+    int upload_threads = 0;          // FZB_UPLOAD_THREADS     worker threads of the staged mode
+};
+
+const FzbKnobs& fzb_knobs();

@@ -1,9 +1,11 @@
 """Multi-GPU composition of the hot path: the haystack list is sharded by contiguous index range, one process
 per GPU scores its shard with a global `index_offset` (exactly what `match_list_parallel`'s workers do with
 2048-item chunks, reference src/matcher/parallel.rs:55-63), then the per-shard, index-ordered match lists are
-exchanged with ONE all-gather (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests) and combined on
-the host the way the reference combines its per-thread runs: reverse / radix sort per run, then k-way merge
-(parallel.rs:66-87).  Scoring itself needs no collective."""
+exchanged with ONE gather / all-gather (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests) and combined into the list
+the reference's per-run sort + k-way merge returns (parallel.rs:66-87).  With the runs in the root's HBM that is ONE device pass
+(`ShardExchange.collect_merged` -> fzb_merge_shard_runs: shard order is ascending index order, so the concatenation is the list
+`match_list` orders - reverse / stable radix sort once, one copy to the host); `merge_shard_runs` is the host form of the same combine
+(CPU tensors, the gloo tests).  Scoring itself needs no collective."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -82,6 +84,8 @@ class ShardExchange:
         self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.rank == root else None for _ in range(slots)]
         self.work = [None] * slots
+        # only RCCL's completion query is trusted to stand in for wait(): on other backends wait() is what surfaces a failed collective
+        self._skip_completed_wait = dist.get_backend(group) == "nccl"
 
     @staticmethod
     def plan(local_count, group=None, margin=1.25, device=None):
@@ -103,12 +107,13 @@ class ShardExchange:
         w = self.work[slot]
         if w is not None:
             done = False
-            try:
-                done = bool(w.is_completed())
-            except Exception:  # a backend without completion queries: order the streams
-                done = False
+            if self._skip_completed_wait:
+                try:
+                    done = bool(w.is_completed())
+                except Exception:  # no completion query: order the streams
+                    done = False
             if not done:
-                w.wait()
+                w.wait()  # (raises what the collective raised)
             self.work[slot] = None
 
     def post(self, slot):
@@ -121,13 +126,36 @@ class ShardExchange:
         if self.rank != self.root:
             return None
         runs = []
-        for r, buf in enumerate(self.recv[slot]):
-            host = buf.cpu().numpy()
-            cnt, total = (int(x) for x in host[:8].view(np.uint32))  # fzb_match_list_device: records written, matches found (unclamped)
+        for r, (cnt, total) in enumerate(self._headers(slot)):
+            buf = self.recv[slot][r]
+            runs.append(buf[self.HEADER : self.HEADER + cnt * 8].cpu().numpy().copy().view(MATCH_DTYPE))  # the records that exist, not the capacity
+        return runs
+
+    def _headers(self, slot):
+        """[(records written, matches found)] per rank - fzb_match_list_device's two counters; raises when a shard outgrew the capacity"""
+        hdr = torch.stack([b[: self.HEADER] for b in self.recv[slot]]).cpu().numpy().view(np.uint32).reshape(self.world, 2)
+        out = []
+        for r in range(self.world):
+            cnt, total = int(hdr[r, 0]), int(hdr[r, 1])
             if total > self.cap or cnt > self.cap:
                 raise RuntimeError(f"shard {r} produced {max(total, cnt)} matches, exchange capacity is {self.cap}: plan a larger capacity")
-            runs.append(host[self.HEADER : self.HEADER + cnt * 8].copy().view(MATCH_DTYPE))
-        return runs
+            out.append((cnt, total))
+        return out
+
+    def collect_merged(self, slot, matcher, stream=0):
+        """Root only, synchronising: the exchange posted on `slot` as ONE list in `matcher.config.sort` order - what
+        `match_list_parallel` returns (parallel.rs:66-87).  The gathered runs never leave the root's HBM unordered: concatenation in rank
+        order (= ascending index order) + reverse / stable radix sort on the device (fzb_merge_shard_runs), one copy to the host.
+        Device tensors only (the RCCL path); CPU tensors take `merge_shard_runs(collect(slot), sort)`."""
+        self.wait(slot)
+        if self.rank != self.root:
+            return None
+        bufs = self.recv[slot]
+        if not bufs[0].is_cuda:
+            return merge_shard_runs(self.collect(slot), matcher.config.sort)
+        merged = matcher.merge_shard_runs([b.data_ptr() + self.HEADER for b in bufs], [b.data_ptr() for b in bufs], [self.cap] * self.world, stream=stream)
+        self._headers(slot)  # truncation is reported, never returned as a shorter list
+        return merged
 
 
 def merge_shard_runs(runs, sort):

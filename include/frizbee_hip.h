@@ -102,9 +102,15 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
  * bytes after the last haystack.  dev_ends has n entries (uint32 if ends_are_u64 == 0).  Borrowed, not copied.
  * (A list of 32-byte haystacks stored back to back already has this layout.) */
 int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends_are_u64, size_t n, uint64_t total_bytes, fzb_corpus** out);
-/* Optional hint for borrowed corpora: the longest haystack in bytes (fzb_corpus_upload computes it).  Must be an upper
- * bound; 0 = unknown. */
+/* Optional hint for borrowed corpora: the longest haystack in bytes.  Must be an upper bound; 0 = unknown.  fzb_corpus_upload measures
+ * it: on a corpus it uploaded a looser value (or 0) is ignored and a value below the measured one is refused (FZB_ERR_INVALID). */
 int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len);
+/* Optional accelerator for borrowed RAGGED corpora (fzb_corpus_upload builds it itself): the streaming filter's view of the list - a
+ * second copy of the bytes, every 1024-haystack tile sorted by length and stored interleaved in groups of 64, so that a wavefront's
+ * loads are contiguous.  The lengths are read from the end offsets (no hint is trusted).  A list that does not
+ * call for a view (nothing beyond 32 bytes, something beyond 256, uniform length) or a device without room leaves the corpus as it
+ * is: *out_built (optional) = 1 when the corpus has a view when the call returns.  The corpus' bytes must not change afterwards. */
+int fzb_corpus_build_view(fzb_corpus* c, int* out_built);
 /* Optional promise for borrowed corpora: EVERY haystack has exactly `len` bytes (so haystack i starts at i * roundup16(len)); the hot
  * kernels then compute the spans instead of reading the end offsets (a tenth of the filter's traffic on 32-byte records and one
  * dependent load less per survivor).  fzb_corpus_upload detects it by itself, and on a corpus it uploaded only the detected value is
@@ -158,11 +164,13 @@ void fzb_matches_free(fzb_match* p);
 /* ---- the multi-device form: `Matcher::match_list_parallel` with the GPUs of one node as its workers ---------------------------
  * The reference's match_list_parallel (src/matcher/parallel.rs:18-89) cuts the list into contiguous chunks, hands every worker thread
  * a chunk with its global index offset (:55-63), sorts each worker's run (:66-76) and k-way merges the runs (:78-87).  Here a worker
- * is a DEVICE: the list is cut into `ndev` contiguous shards, shard g resident on device g; a query runs one host thread per shard
- * (hipSetDevice + a per-shard clone of the matcher, i.e. pipeline and device sort on that GPU, one D2H copy of the ordered run) and
- * merges the runs on the calling thread (fzb_k_merge_matches' order).  The result equals fzb_match_list on the unsharded list for
- * every sort strategy.  No device-to-device exchange: only the host consumes the result.  (`threads` of fzb_match_list_parallel keeps
- * the reference's contract on ONE device; the number of devices is a property of the sharded corpus, never inferred from `threads`.) */
+ * is a DEVICE: the list is cut into `ndev` contiguous shards, shard g resident on device g; a query runs one persistent host thread
+ * per shard (hipSetDevice + a per-shard clone of the matcher: the pipeline on that GPU, records in index order) and each run is
+ * copied device to device to its place in ONE list on the root device (the caller's current device).  Shard order is ascending index
+ * order, so that list is the one `match_list` orders: the root runs the reverse / stable radix sort of src/sort.rs:6-40 once and makes
+ * one copy to the host.  The result equals fzb_match_list on the unsharded list for every sort strategy - what the reference's per-run
+ * sort + k-way merge produces, without a host-side merge.  (`threads` of fzb_match_list_parallel keeps the reference's contract on ONE
+ * device; the number of devices is a property of the sharded corpus, never inferred from `threads`.) */
 typedef struct fzb_sharded_corpus fzb_sharded_corpus;
 enum {
     FZB_SHARD_BY_COUNT = 0,       /* shard g = [g * ceil(n / ndev), ...): equal haystack counts                           */
@@ -180,9 +188,18 @@ size_t fzb_sharded_corpus_len(const fzb_sharded_corpus* sc);
 int fzb_sharded_corpus_shards(const fzb_sharded_corpus* sc);
 int fzb_sharded_corpus_shard(const fzb_sharded_corpus* sc, int g, uint64_t* lo, uint64_t* hi, int* device);
 /* `Matcher::match_list_parallel(&haystacks, threads)` over the sharded list, one worker per shard.  The matcher keeps one clone of
- * itself per shard (device workspaces on the shards' devices; they follow fzb_matcher_set_pattern / fzb_matcher_set_config).
+ * itself per shard (device workspaces on the shards' devices; they follow fzb_matcher_set_pattern / fzb_matcher_set_config, and a
+ * clone whose shard lives on another device in a later corpus is rebuilt there) and its worker threads.  The caller's current device
+ * is the root (the matcher binds to it like on any first query).  fzb_last_counters on `m` afterwards = the sum over the shards.
  * Free the result with fzb_matches_free. */
 int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc, fzb_match** out, size_t* out_len);
+/* The combine step alone, for callers that moved the per-shard runs themselves (one process per GPU: the root rank after an RCCL
+ * gather - frizbee_amd.distributed): run g = dev_runs[g], index-ordered records of shard g as fzb_match_list_device wrote them,
+ * *dev_counts[g] of them (a uint32 in DEVICE memory, at most run_caps[g]); runs in ascending shard order, all readable from the current
+ * device.  Concatenation + `match_list`'s ordering (src/matcher/mod.rs:215-221) on the device, on `stream`, then one copy to the
+ * host = the list `match_list_parallel` returns (src/matcher/parallel.rs:66-87).  Free the result with fzb_matches_free. */
+int fzb_merge_shard_runs(fzb_matcher* m, const void* const* dev_runs, const uint32_t* const* dev_counts, const size_t* run_caps, size_t nruns, void* stream,
+                         fzb_match** out, size_t* out_len);
 
 /* `MatchIndices` (src/lib.rs:189-199): a Match plus the haystack byte positions that matched the needle, in reverse
  * order.  positions[positions_begin .. positions_begin + positions_len) of the array returned next to the records. */
@@ -288,6 +305,10 @@ int fzb_debug_lcs_dfa_accepts(const fzb_matcher* m, const uint8_t* bytes, size_t
 /* test hook, host only: the class-composite form of the matcher's streaming automaton (G byte transitions composed over the K byte
  * classes; the ragged filter's table) run over one haystack: 1 / 0 = accepts / rejects, -1 if the matcher has none; out_kg[0] = K, [1] = G */
 int fzb_debug_cdfa_state(const fzb_matcher* m, const uint8_t* bytes, size_t len, int32_t* out_kg);
+
+/* test hook: the library's environment switches (frizbee_amd/csrc/knobs.h - comparison and debugging only, parsed once on first use) are
+ * read again.  Matchers created before the call keep what was decided when they were created. */
+void fzb_debug_reload_knobs(void);
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,14 @@ def _worker(rank, world, port, q):
                 ok = ok and merge_shard_runs(runs2, SortStrategy[sort]).tolist() == want.tolist()
             else:
                 ok = ok and runs2 is None
-            ex.collect(1)
+            # the one-call form bench.py's ordered mode uses (on the GPU: concatenation + radix sort in the root's HBM, fzb_merge_shard_runs;
+            # CPU tensors: the host combine) - slot 1 was used by step 1
+            class _Sorted:  # what collect_merged reads from a Matcher
+                class config:
+                    pass
+            _Sorted.config.sort = SortStrategy[sort]
+            merged3 = ex.collect_merged(1, _Sorted)
+            ok = ok and ((merged3.tolist() == want.tolist()) if rank == 0 else merged3 is None)
     # ---- BASELINE config 4 in miniature: a RAGGED list (8..128 bytes), byte-balanced shards of unequal counts, needle 'deadbeef' ----
     from frizbee_amd.distributed import shard_ranges_by_bytes
 

@@ -57,3 +57,50 @@ def test_c4_one_shard_ragged():
     data, ends = synth.ragged_corpus(b"deadbeef", 12_500_000, device="cuda")
     fm = _check("deadbeef", data, ends, max_typos=0)
     assert fm.last_counters()["multi_chunk_scored"] > 0
+
+
+def test_c4_whole_hundred_million_ragged_on_one_gpu():
+    """BASELINE config 4 UNSHARDED: 100 M haystacks of 8..128 bytes (6.8 GB of bytes, 7.6 GB padded: 64-bit end offsets and a filter view
+    above the 4 GiB line) resident on ONE MI355X.  Two distinct 12.5 M-item shards (seeds 12345 / 777), alternated four times.  Checked
+    against the oracle on windows of the list - the first items, a window that straddles the 4 GiB line of the padded layout, the last
+    items - and through a size-independent property: copy k of a shard must produce copy 0's records with the indices shifted."""
+    threads = os.cpu_count() or 1
+    n1 = 12_500_000
+    parts = [synth.ragged_corpus(b"deadbeef", n1, seed=sd, device="cuda") for sd in (12345, 777)]
+    order = [0, 1] * 4
+    data = np.concatenate([parts[k][0] for k in order])
+    ends = np.empty(n1 * len(order), np.uint64)
+    base = 0
+    for j, k in enumerate(order):
+        ends[j * n1 : (j + 1) * n1] = parts[k][1] + np.uint64(base)
+        base += int(parts[k][1][-1])
+    n = len(ends)
+    corpus = F.Corpus(packed=(data, ends))
+    fm = F.Matcher("deadbeef", F.Config(max_typos=0, sort=F.SortStrategy.IndexAsc, pf_lanes=64, sw_lanes=64))
+    whole = fm.match_list(corpus)
+    assert fm.last_counters()["multi_chunk_scored"] > 0 and len(whole) > 1_000_000
+    om = O.Matcher("deadbeef", lanes=(64, 64, 32), max_typos=0, sort="IndexAsc")
+    # (the padded layout grows ~ 76 bytes per haystack: the 4 GiB line is near item 56.5 M; the window is found from the lengths)
+    padded = np.cumsum((np.diff(ends, prepend=np.uint64(0)) + np.uint64(15)) & ~np.uint64(15), dtype=np.uint64)
+    line = int(np.searchsorted(padded, np.uint64(1 << 32)))
+    assert 0 < line < n - 300_000
+    for first in (0, line - 150_000, n - 300_000):
+        cnt = 300_000
+        lo = int(ends[first - 1]) if first else 0
+        sub = np.concatenate([data[lo : int(ends[first + cnt - 1])], np.zeros(64, np.uint8)])
+        want = om.match_packed(sub, ends[first : first + cnt] - np.uint64(lo), threads=threads)
+        got = fm.match_list_into(corpus, first=first, count=cnt, index_offset=0)
+        assert got.tolist() == want.tolist(), first
+        sl = whole[(whole["index"] >= first) & (whole["index"] < first + cnt)].copy()
+        sl["index"] -= np.uint32(first)
+        assert sl.tolist() == want.tolist(), first
+    for j in range(2, len(order)):  # periodicity: shard copy j == shard copy j - 2, shifted by 2 * n1
+        a = whole[(whole["index"] >= (j - 2) * n1) & (whole["index"] < (j - 1) * n1)]
+        b = whole[(whole["index"] >= j * n1) & (whole["index"] < (j + 1) * n1)]
+        assert len(a) == len(b) and np.array_equal(a["index"] + np.uint32(2 * n1), b["index"]) and np.array_equal(a["score"], b["score"]) and np.array_equal(a["exact"], b["exact"]), j
+    # and the ordered form of the whole list: scores descending, ties by ascending index, same multiset of records
+    fm.set_config(F.Config(max_typos=0, pf_lanes=64, sw_lanes=64))
+    srt = fm.match_list(corpus)
+    s, i = srt["score"].astype(np.int64), srt["index"].astype(np.int64)
+    assert len(srt) == len(whole) and np.all((s[:-1] > s[1:]) | ((s[:-1] == s[1:]) & (i[:-1] < i[1:])))
+    assert int(srt["index"].astype(np.uint64).sum()) == int(whole["index"].astype(np.uint64).sum()) and int(s.sum()) == int(whole["score"].astype(np.int64).sum())

@@ -97,3 +97,45 @@ def test_tiny_ragged_lists():
         hs = _list(rng, n, 90, "deadbeef", "deabfxyz_", plant=0.5)
         got, want, _ = both("deadbeef", hs, pf=64)
         assert_same(got, want, f"n={n}")
+
+
+def _padded16(hs):
+    """list[bytes] -> (uint8 array in the library's device layout, u32 exclusive ends inside it)"""
+    buf = bytearray()
+    ends = []
+    for h in hs:
+        buf += b"\0" * (-len(buf) % 16)
+        buf += h
+        ends.append(len(buf))
+    buf += b"\0" * (-len(buf) % 16) + b"\0" * 96
+    return np.frombuffer(bytes(buf), np.uint8).copy(), np.array(ends, np.uint32)
+
+
+@pytest.mark.parametrize("max_len", [100, 200])
+def test_borrowed_corpus_gets_the_view_and_ignores_a_wrong_length_hint(max_len):
+    # fzb_corpus_build_view on borrowed device memory (what bench.py / a torch caller holds): the same kernel as on an uploaded list.  The
+    # view's vector count comes from the lengths the builder READ - a corpus whose max_len was cleared (fzb_corpus_set_max_len(c, 0) =
+    # "unknown") still scans every vector of its 129..256-byte haystacks (round 3 picked 8 vectors for max_len == 0 and dropped matches).
+    import torch
+    rng = random.Random(71 + max_len)
+    hs = [h.encode() for h in _list(rng, 30000, max_len, "deadbeef", "deabfxyz_-/ 01")]
+    hs[123] = b"x" * (max_len - 8) + b"deadbeef"  # a match that ends in the longest haystack's last vector
+    data, ends = _padded16(hs)
+    dev = torch.device("cuda", 0)
+    d_bytes, d_ends = torch.from_numpy(data).to(dev), torch.from_numpy(ends.astype(np.int64)).to(dev).to(torch.int32)
+    want = O.Matcher("deadbeef", lanes=(64, 64, 32)).match_list(hs)
+    assert 123 in want["index"].tolist()
+    for hint in (0, max_len, 4096):
+        cp = F.Corpus.from_device(d_bytes.data_ptr(), d_ends.data_ptr(), len(hs), d_bytes.numel(), keep=(d_bytes, d_ends), max_len=hint)
+        m = F.Matcher("deadbeef", F.Config(pf_lanes=64, sw_lanes=64))
+        before = m.match_list(cp)
+        assert cp.build_view() is True
+        if hint:
+            assert F.lib().fzb_corpus_set_max_len(cp.h, 0) == 0  # "unknown" again: must not change what the view kernel scans
+        after = m.match_list(cp)
+        assert before.tolist() == want.tolist() and after.tolist() == want.tolist(), hint
+    up = F.Corpus(hs)  # an uploaded corpus measured its lengths: a smaller bound is refused, a looser one ignored
+    assert F.lib().fzb_corpus_set_max_len(up.h, 32) == 1 and F.lib().fzb_corpus_set_max_len(up.h, 0) == 0 and F.lib().fzb_corpus_set_max_len(up.h, 9999) == 0
+    assert F.Matcher("deadbeef", F.Config(pf_lanes=64, sw_lanes=64)).match_list(up).tolist() == want.tolist()
+    short = F.Corpus.from_device(d_bytes.data_ptr(), d_ends.data_ptr(), 5, d_bytes.numel(), keep=(d_bytes, d_ends))
+    assert isinstance(short.build_view(), bool)
