@@ -220,18 +220,28 @@ def sharded_block(F, needle, cfg, host_bytes, host_ends, unsharded_ms, unsharded
                    "matcher clone and stream; runs copied device to device into one list, ordered once, one D2H.  Ordered records on the host, per call",
            "unsharded_match_list_ms": unsharded_ms}
     want = unsharded_result.tobytes()
-    for k in (1, 2, 8):
-        sc = F.ShardedCorpus(packed=(host_bytes, host_ends), ndev=k, oversubscribe=True)
-        m = F.Matcher(needle, cfg)
-        got = m.match_list_parallel_sharded(sc, copy=False)
-        same = got.tobytes() == want
-        ts = []
-        for _ in range(15):
-            t0 = time.perf_counter()
-            got = m.match_list_parallel_sharded(sc, copy=False)
-            ts.append(time.perf_counter() - t0)
-        out[f"shards_{k}"] = {"ms_median": _median(ts) * 1e3, "ms_min": min(ts) * 1e3, "vs_unsharded": _median(ts) * 1e3 / unsharded_ms, "equals_match_list": bool(same)}
-        del m, sc, got
+    for mode in ("pull", "copy"):
+        # pull: the shards share the root device, ONE kernel concatenates the runs (no host round trip before the final list).
+        # copy: what shards on other devices take - count to the host, hipMemcpyPeerAsync to the run's place (forced on this one GPU)
+        if mode == "copy":
+            os.environ["FZB_SHARD_GATHER"] = "copy"
+        F.lib().fzb_debug_reload_knobs()
+        try:
+            for k in (1, 2, 8):
+                sc = F.ShardedCorpus(packed=(host_bytes, host_ends), ndev=k, oversubscribe=True)
+                m = F.Matcher(needle, cfg)
+                got = m.match_list_parallel_sharded(sc, copy=False)
+                same = got.tobytes() == want
+                ts = []
+                for _ in range(15):
+                    t0 = time.perf_counter()
+                    got = m.match_list_parallel_sharded(sc, copy=False)
+                    ts.append(time.perf_counter() - t0)
+                out[f"shards_{k}_{mode}"] = {"ms_median": _median(ts) * 1e3, "ms_min": min(ts) * 1e3, "vs_unsharded": _median(ts) * 1e3 / unsharded_ms, "equals_match_list": bool(same)}
+                del m, sc, got
+        finally:
+            os.environ.pop("FZB_SHARD_GATHER", None)
+            F.lib().fzb_debug_reload_knobs()
     return out
 
 
@@ -239,7 +249,7 @@ def other_configs(F, synth, dev, steps):
     """C3 / C4-shard / C5 of BASELINE.json on this GPU: device pipeline time per step (corpus resident), same definitions as the headline."""
     res = {}
 
-    def run(name, needle, cfg, corpus, n, sum_len, ends_read=True):
+    def run(name, needle, cfg, corpus, n, sum_len, ends_read=True, steps=steps):
         m = F.Matcher(needle, cfg)
         out = torch.zeros(n * 8 + 64, dtype=torch.uint8, device=dev)
         cnt = torch.zeros(4, dtype=torch.int32, device=dev)
@@ -272,7 +282,21 @@ def other_configs(F, synth, dev, steps):
     data, e4 = synth.ragged_corpus(b"deadbeef", n4, device=dev)
     cp = F.Corpus(packed=(data, e4))
     run("C4 one GPU's shard: 12.5M ragged 8..128 B, 'deadbeef', max_typos=0", "deadbeef", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n4, int(e4[-1]))
-    del cp, data, e4
+    del cp
+    # ... and BASELINE config 4 WHOLE on this one GPU: 100 M haystacks (the shard's list eight times; 6.8 GB of bytes, 7.6 GB in the padded
+    # layout: 64-bit end offsets, the filter view above the 4 GiB line), resident in a fraction of the 288 GB.  Parity at this size:
+    # tests/test_gpu_full_size.py::test_c4_whole_hundred_million_ragged_on_one_gpu
+    rep = 8
+    data8 = np.tile(data, rep)
+    e8 = (e4[None, :] + (np.arange(rep, dtype=np.uint64) * e4[-1])[:, None]).reshape(-1)
+    t0 = time.perf_counter()
+    cp = F.Corpus(packed=(data8, e8))
+    up_ms = (time.perf_counter() - t0) * 1e3
+    name8 = "C4 whole: 100M ragged 8..128 B on ONE GPU (the 12.5M-item shard x 8), 'deadbeef', max_typos=0"
+    run(name8, "deadbeef", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n4 * rep, int(e8[-1]), steps=5)
+    res[name8]["upload_ms"] = up_ms
+    res[name8]["vs_shard_step"] = res[name8]["ms_per_step"] / res["C4 one GPU's shard: 12.5M ragged 8..128 B, 'deadbeef', max_typos=0"]["ms_per_step"]
+    del cp, data, e4, data8, e8
     # the shape users see: the reference's real-data benchmark (BENCHMARKS.md:52-65, Chromium file paths: 1 406 941 items, median 67
     # characters, needle "linux", 8 % matching) from its synthetic generator's method - a ragged list, none of the len-32 fast paths
     npaths = 1_406_941

@@ -180,7 +180,10 @@ FzbKnobs parse_knobs() {
     k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
     k.debug_sync = set("FZB_DEBUG_SYNC");
     k.no_handoff = set("FZB_NO_HANDOFF");
+    k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
+    k.stage_dbg = num("FZB_STAGE_DBG", 0);
+    k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");
     k.small_list = getenv("FZB_SMALL_LIST") ? (uint32_t)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
     k.compact_grid_mul = std::max(1, num("FZB_COMPACT_GRID_MUL", 4));
     { const int v = num("FZB_CLASSIFY_PER", 2); k.classify_per = (v == 1 || v == 4) ? v : 2; }
@@ -216,7 +219,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa, w.stage, w.stage_hdr, w.tile_prefix};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -808,7 +811,7 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
         w.cap_marg = cap;
     }
     if (need_cls) {
-        HIPCHK(dev_alloc((void**)&w.cls_win, cap * 8));
+        HIPCHK(dev_alloc((void**)&w.cls_win, cap * 16));  // 16-byte records (window, flag, source address)
         HIPCHK(dev_alloc((void**)&w.cls_lists, cap * 28));  // 3 single-chunk classes + 4 multi-chunk tail classes
         w.cap_cls = cap;
     }
@@ -845,6 +848,20 @@ static int ensure_dp_scratch(fzb_matcher* m, int mgrid) {  // parked rows of the
     w.dp_scratch_words = 0;
     HIPCHK(dev_alloc((void**)&w.dp_scratch, words * 4));
     w.dp_scratch_words = words;
+    return FZB_OK;
+}
+static int ensure_stage(fzb_matcher* m, size_t count) {  // the filter -> scorer handoff of a ragged list (Workspace::stage)
+    Workspace& w = m->ws;
+    if (w.cap_stage >= count && w.stage) return FZB_OK;
+    for (void* p : {(void*)w.stage, (void*)w.stage_hdr, (void*)w.tile_prefix})
+        if (p) HIPCHK(hipFree(p));
+    w.stage = nullptr; w.stage_hdr = nullptr; w.tile_prefix = nullptr; w.cap_stage = 0;
+    const size_t cap = std::max(count, w.cap_items);
+    const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 1;
+    HIPCHK(dev_alloc((void**)&w.stage, ntiles * FZB_STAGE_UNITS * 16 + 256));
+    HIPCHK(dev_alloc((void**)&w.stage_hdr, ntiles * FZB_TILE * 4));
+    HIPCHK(dev_alloc((void**)&w.tile_prefix, ntiles * 4));
+    w.cap_stage = cap;
     return FZB_OK;
 }
 static int ensure_sort_buffers(fzb_matcher* m, size_t cap) {  // ping-pong buffer + tile histograms of the device radix sort
@@ -1041,6 +1058,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     const u32* n_items_ptr = &cnt_c[0];
     int wmode = lc.window_mode;
     bool uni_exact = false;  // the unicode DFA filter decided exactly: no lane-exact window pass, the scorer computes the window
+    bool staged = false;     // the filter staged its survivors' vectors (Workspace::stage): the classifier reads them there
     if (items_in) {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         if (lc.filter_mode == 0) {
@@ -1106,16 +1124,22 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         uni_exact = true;
     } else {
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
+        // filter -> scorer handoff (ragged list with a view, the exact ASCII filter, classified scoring next): the view kernel stores the accepted
+        // haystacks' vectors, which it holds in registers, into the stage; the classifier and the scorers read them there
+        const bool want_stage = !kn.no_handoff && !trace && lc.filter_mode == 1 && lc.filter_exact && lc.window_mode == 1 && !nd.unicode && cd.vbytes && lc.cf_ok &&
+                                !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2);
+        if (want_stage && (rc = ensure_stage(m, count))) return rc;  // first use only (or fzb_matcher_reserve)
+        const StageOut so{want_stage ? w.stage : nullptr, want_stage ? w.stage_hdr : nullptr};
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
             fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
                               nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         else
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
-                              nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
+            staged = fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
+                                       nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, want_stage ? &so : nullptr);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * kn.compact_grid_mul, st);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * kn.compact_grid_mul, st, staged ? w.tile_prefix : nullptr);
         FZB_STAGE("compact1");
         items = w.surv_idx;
     }
@@ -1186,13 +1210,15 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             fork = false;
             fzb_clear_error();
         }
+        const StagedIn sin{w.stage, w.stage_hdr, w.tile_prefix};
+        const StagedIn* sinp = (staged && classes && items == w.surv_idx) ? &sin : nullptr;
         if (classes && all_in_one) {
             fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                                  (u32)w.cap_cls, cus, st, 1, split);
+                                  (u32)w.cap_cls, cus, st, 1, split, sinp);
             fzb_launch_classes_all(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, cnt_c, nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, cus, st);
         } else if (classes)
             fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                                  (u32)w.cap_cls, cus, st, fork ? 1 : 0, split);
+                                  (u32)w.cap_cls, cus, st, fork ? 1 : 0, split, sinp);
         else
             fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
         FZB_STAGE("dp");
@@ -1240,6 +1266,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     if (rc) return rc;
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
     if (!m->long_needle && !m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
+    if (c->dev.vbytes && !m->literal_mode && !m->long_needle && !m->nd.unicode && m->lc.filter_mode == 1 && m->lc.cf_ok && (rc = ensure_stage(m, n))) return rc;
     if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;
     return FZB_OK;

@@ -125,6 +125,56 @@ private:
 };
 }  // namespace
 
+// Runs that the current device can read (its own memory; peers' memory once peer access is on) -> the ordered list on the host: one
+// concatenation kernel that reads the run lengths on the device, `match_list`'s ordering, the count and then the records to the host.
+static int merge_runs_on_device(fzb_matcher* m, const void* const* dev_runs, const uint32_t* const* dev_counts, const size_t* run_caps, size_t nruns, hipStream_t st, fzb_match** out,
+                                size_t* out_len) {
+    int rc;
+    size_t cap = 0;
+    for (size_t g = 0; g < nruns; g++) {
+        if (run_caps[g] > 0xFFFFFFFFull) return fzb_fail(FZB_ERR_INVALID, "run capacity beyond the u32 index space");
+        cap += run_caps[g];
+    }
+    if (cap > 0xFFFFFFFFull) return fzb_fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(cap) + " > 4294967295 (index offset: 0)");
+    if (!cap) return FZB_OK;
+    if ((rc = fzb_ensure_out_staging(m, cap))) return rc;
+    OrderPlan plan;
+    if ((rc = fzb_order_begin(m, cap, m->out_dev, &plan))) return rc;
+    u32* words = m->count_dev;  // [0..1] and [2..3]: running (written, found) totals, alternating between batches of FZB_MAX_RUNS runs
+    const u32* base = nullptr;
+    u32* tot = words;
+    for (size_t g0 = 0; g0 < nruns; g0 += FZB_MAX_RUNS) {
+        RunSet rs{};
+        rs.n = (int)std::min<size_t>(FZB_MAX_RUNS, nruns - g0);
+        for (int k = 0; k < rs.n; k++) {
+            rs.run[k] = (const fzb_match_rec*)dev_runs[g0 + (size_t)k];
+            rs.count[k] = dev_counts[g0 + (size_t)k];
+            rs.cap[k] = (u32)run_caps[g0 + (size_t)k];
+        }
+        fzb_launch_concat_runs(rs, base, tot, plan.in, (u32)cap, m->lc.num_cus * 2, st);
+        base = tot;
+        tot = tot == words ? words + 2 : words;
+    }
+    HIPCHK(hipGetLastError());
+    if ((rc = fzb_order_finish(m, plan, m->out_dev, base, st))) return rc;
+    u32 n = 0;
+    HIPCHK(hipMemcpyAsync(&n, base, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (!n) return FZB_OK;
+    fzb_match* r = (fzb_match*)fzb_pinned_get((size_t)n * sizeof(fzb_match));
+    if (!r) return fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
+    const fzb_match_rec* final_dev = (plan.reversed || plan.by_score) ? m->out_dev : plan.in;
+    hipError_t e = hipMemcpyAsync(r, final_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        fzb_pinned_put(r);
+        return fzb_fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));
+    }
+    *out = r;
+    *out_len = n;
+    return FZB_OK;
+}
+
 extern "C" {
 
 int fzb_device_count(int* out) {
@@ -278,6 +328,13 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         delete pool;
         m->shard_workers = pool = new ShardWorkers(ns);
     }
+    // How the runs reach the root.  PULL (every shard lives on the root device - one GPU holding several shards): the workers only enqueue
+    // their pipelines; the root's stream waits for them and ONE kernel concatenates the runs, reading their lengths on the device - no
+    // host round trip before the final list.  COPY (shards on other devices): each worker reads its count back (8 bytes) and copies its
+    // run to its place with hipMemcpyPeerAsync as soon as the counts below it are known.  FZB_SHARD_GATHER=copy forces the second form
+    // (how it is tested on one GPU).
+    bool pull = !fzb_knobs().shard_gather_copy;
+    for (size_t g = 0; g < ns; g++) pull = pull && sc->device[g] == root;
     // counts[g]: shard g's number of records, published by its worker as soon as it is known (-1 before); worker g starts its copy
     // when the counts of the shards below it are in - the prefix is where its run starts in the gathered list
     std::vector<std::atomic<int64_t>> counts(ns);
@@ -290,7 +347,6 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         } publish{counts[g]};
         const fzb_corpus* c = sc->shard[g];
         const size_t count = (size_t)c->dev.n;
-        if (!count) return FZB_OK;
         HIPCHK(hipSetDevice(sc->device[g]));
         fzb_matcher* cm = m->shard_clones[g];
         if (cm->shard_device < 0) {
@@ -305,6 +361,12 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         // parallel.rs:55-63) - unsorted: the root orders the whole list
         rc_ = fzb_match_list_device(cm, c, 0, count, (uint32_t)sc->bounds[g], (fzb_match*)cm->out_dev, cm->out_cap, cm->count_dev, cm->shard_stream);
         if (rc_) return rc_;
+        if (pull) {
+            HIPCHK(hipEventRecord(cm->shard_event, cm->shard_stream));
+            copied[g] = 1;
+            return FZB_OK;
+        }
+        if (!count) return FZB_OK;
         HIPCHK(hipMemcpyAsync(cm->shard_count_host, cm->count_dev, 8, hipMemcpyDeviceToHost, cm->shard_stream));
         HIPCHK(hipStreamSynchronize(cm->shard_stream));
         const u32 cnt = cm->shard_count_host[0];
@@ -338,6 +400,17 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         for (int k = 0; k < 4; k++) agg[k] += m->shard_clones[g]->last_counters[k];
     }
     memcpy(m->last_counters, agg, sizeof(agg));  // fzb_last_counters on the parent = the sum over the shards
+    if (pull) {
+        std::vector<const void*> runs(ns);
+        std::vector<const uint32_t*> cnts(ns);
+        std::vector<size_t> caps(ns);
+        for (size_t g = 0; g < ns; g++) {
+            runs[g] = m->shard_clones[g]->out_dev;
+            cnts[g] = m->shard_clones[g]->count_dev;
+            caps[g] = (size_t)sc->shard[g]->dev.n;
+        }
+        return merge_runs_on_device(m, runs.data(), cnts.data(), caps.data(), ns, m->shard_stream, out, out_len);
+    }
     if (!total) return FZB_OK;
     // the whole list's count -> device memory (the sort reads it there), reverse / stable radix sort ONCE, one copy to the host
     HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->count_dev, (int)(u32)total, 1, m->shard_stream));
@@ -367,50 +440,7 @@ int fzb_merge_shard_runs(fzb_matcher* m, const void* const* dev_runs, const uint
     if (!nruns) return FZB_OK;
     int rc = fzb_bind_device(m);
     if (rc) return rc;
-    size_t cap = 0;
-    for (size_t g = 0; g < nruns; g++) {
-        if (run_caps[g] > 0xFFFFFFFFull) return fzb_fail(FZB_ERR_INVALID, "run capacity beyond the u32 index space");
-        cap += run_caps[g];
-    }
-    if (cap > 0xFFFFFFFFull) return fzb_fail(FZB_ERR_PANIC, "too many items in haystack, will overflow the u32 index: " + std::to_string(cap) + " > 4294967295 (index offset: 0)");
-    if (!cap) return FZB_OK;
-    if ((rc = fzb_ensure_out_staging(m, cap))) return rc;
-    OrderPlan plan;
-    if ((rc = fzb_order_begin(m, cap, m->out_dev, &plan))) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    u32* words = m->count_dev;  // [0..1] and [2..3]: running (written, found) totals, alternating between batches of FZB_MAX_RUNS runs
-    const u32* base = nullptr;
-    u32* tot = words;
-    for (size_t g0 = 0; g0 < nruns; g0 += FZB_MAX_RUNS) {
-        RunSet rs{};
-        rs.n = (int)std::min<size_t>(FZB_MAX_RUNS, nruns - g0);
-        for (int k = 0; k < rs.n; k++) {
-            rs.run[k] = (const fzb_match_rec*)dev_runs[g0 + (size_t)k];
-            rs.count[k] = dev_counts[g0 + (size_t)k];
-            rs.cap[k] = (u32)run_caps[g0 + (size_t)k];
-        }
-        fzb_launch_concat_runs(rs, base, tot, plan.in, (u32)cap, m->lc.num_cus * 2, st);
-        base = tot;
-        tot = tot == words ? words + 2 : words;
-    }
-    HIPCHK(hipGetLastError());
-    if ((rc = fzb_order_finish(m, plan, m->out_dev, base, st))) return rc;
-    u32 n = 0;
-    HIPCHK(hipMemcpyAsync(&n, base, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (!n) return FZB_OK;
-    fzb_match* r = (fzb_match*)fzb_pinned_get((size_t)n * sizeof(fzb_match));
-    if (!r) return fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
-    const fzb_match_rec* final_dev = (plan.reversed || plan.by_score) ? m->out_dev : plan.in;
-    hipError_t e = hipMemcpyAsync(r, final_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        fzb_pinned_put(r);
-        return fzb_fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));
-    }
-    *out = r;
-    *out_len = n;
-    return FZB_OK;
+    return merge_runs_on_device(m, dev_runs, dev_counts, run_caps, nruns, (hipStream_t)stream, out, out_len);
 }
 
 }  // extern "C"

@@ -38,6 +38,29 @@ __device__ __forceinline__ u32 load_u32_unaligned(const u8* __restrict__ base, u
     return __builtin_amdgcn_alignbyte(hi, lo, (u32)(p & 3));
 }
 
+// A 16-byte load of data that is read ONCE by a streaming kernel: the non-temporal hint keeps the stream from displacing what later
+// stages re-read from the caches (measured on the view filter: 190 -> 183 us on the C4 shard).
+template <bool NT>
+__device__ __forceinline__ uint4 load16_stream(const uint4* p) {
+#ifndef FZB_HOST_SHIM
+    if (NT) {
+        typedef u32 v4u __attribute__((ext_vector_type(4)));
+        const v4u t = __builtin_nontemporal_load((const v4u*)p);
+        return make_uint4(t.x, t.y, t.z, t.w);
+    }
+#endif
+    return *p;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() = fence + s_barrier, and the fence waits for every outstanding memory
+// operation of the wave (s_waitcnt vmcnt(0)), global STORES included; a kernel that stores to global memory for LATER kernels only and
+// synchronises its waves over LDS state need not expose that round trip.
+#ifdef FZB_HOST_SHIM
+__device__ __forceinline__ void barrier_lds_only() {}
+#else
+__device__ __forceinline__ void barrier_lds_only() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
+
 // Queue slots for the lanes of a wave that want one: ONE atomic per wave instead of one per lane.  Every currently active
 // lane must call it (with its own flag); the returned slot is meaningful where `want` is true.
 __device__ __forceinline__ u32 wave_alloc(u32* counter, bool want) {

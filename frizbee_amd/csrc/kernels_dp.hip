@@ -286,11 +286,16 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
 //                 from the LDS tables, dp_cf.h rows with the class's number of computed lanes; registers - and therefore waves per
 //                 SIMD (4 / 3 / 2) - follow the class.
 // ---------------------------------------------------------------------------------------------------------------
+//                 It also decides WHERE the scorers read a survivor's bytes: the filter's stage (Workspace::stage; header entry by the
+//                 survivor's rank inside its tile) when the filter staged it, the corpus otherwise - and writes, per survivor, one 16-byte
+//                 record (window start, window end | bit 31 = "the window is the whole haystack", the 64-bit address of the haystack's
+//                 first byte).  The scorers read that record and nothing else: no end offsets, no second gather of cold corpus lines.
 template <typename ET, int PER>
 __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ items,
                                                     const u32* __restrict__ win_in, const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, u32 swl,
-                                                    u32* __restrict__ win_out, u32* __restrict__ lists, u32 list_stride, u32* __restrict__ overflow, u32 qcap,
-                                                    u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count, u32 split_multi) {
+                                                    uint4* __restrict__ meta, u32* __restrict__ lists, u32 list_stride, u32* __restrict__ overflow, u32 qcap,
+                                                    u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count, u32 split_multi,
+                                                    const u8* __restrict__ stage, const u32* __restrict__ stage_hdr, const u32* __restrict__ tile_prefix) {
     // classes: 0-2 single chunk, 3 multi-chunk (queue), 4 greedy (queue, from the back), 5-8 multi-chunk by the width of the LAST chunk's
     // tail (split_multi: lists 3-6, counts in counters[12..15]; k2d_dp_multi_tc computes only that many lanes of the last chunk)
     __shared__ u32 s_cnt[9], s_base[9];
@@ -303,20 +308,35 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
         if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
         __syncthreads();
         u32 cls[PER], rank[PER], li[PER], ws[PER], we[PER];
+        const u8* src[PER];
 #pragma unroll
         for (int p = 0; p < PER; p++) {
             const u32 j = j0 + p * 256 + threadIdx.x;
-            cls[p] = 9; rank[p] = 0; li[p] = 0; ws[p] = 0; we[p] = 0;
+            cls[p] = 9; rank[p] = 0; li[p] = 0; ws[p] = 0; we[p] = 0; src[p] = bytes;
             if (j < M && j < capacity) {
                 li[p] = items ? items[j] : j;
-                u64 s;
-                u32 L;
-                haystack_span(ends, first + li[p], s, L);
+                u32 L = 0;
+                bool staged = false;
+                if (stage) {  // (kernel argument: uniform) the survivor's header entry: rank inside its tile = rank - survivors before the tile
+                    const u32 tile = li[p] / FZB_TILE;
+                    const u32 ent = stage_hdr[(size_t)tile * FZB_TILE + (j - tile_prefix[tile])];
+                    if ((ent & 0xFFFFu) != 0xFFFFu) {
+                        src[p] = stage + ((size_t)tile * FZB_STAGE_UNITS + (ent & 0xFFFFu)) * 16;
+                        L = ent >> 16;
+                        staged = true;
+                    }
+                }
+                if (!staged) {
+                    u64 s;
+                    haystack_span(ends, first + li[p], s, L);
+                    src[p] = bytes + s;
+                }
                 if (wmode == 0) { ws[p] = win_in[2 * j]; we[p] = win_in[2 * j + 1]; }
                 else if (wmode == 2) { ws[p] = 0; we[p] = L; }
-                else window_first_last(nd, bytes + s, L, ws[p], we[p]);
+                else window_first_last(nd, src[p], L, ws[p], we[p]);
                 const u32 sp = ws[p] ? ws[p] - 1 : 0;
                 const u32 m = we[p] - sp;
+                if (sp == 0 && we[p] == L) we[p] |= 0x80000000u;  // include_exact (src/matcher/algo.rs:238-249): the window is the whole haystack
                 cls[p] = m <= swl / 2 ? 0u : m <= 3 * swl / 4 ? 1u : m <= swl ? 2u : m <= FZB_MAX_HAYSTACK_LEN ? 3u : 4u;
                 if (split_multi && cls[p] == 3) cls[p] = 5 + ((m - 1) % swl) / (swl / 4);  // tail of 1 ..= swl bytes -> 0 ..= 3
                 rank[p] = atomicAdd(&s_cnt[cls[p]], 1u);
@@ -334,13 +354,13 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
             if (cls[p] < 3 || (cls[p] >= 5 && cls[p] < 9)) {
                 const u32 l = cls[p] < 3 ? cls[p] : cls[p] - 2;
                 lists[(size_t)l * list_stride + s_base[cls[p]] + rank[p]] = j;
-                *(uint2*)(win_out + 2 * (size_t)j) = make_uint2(ws[p], we[p]);
+                meta[j] = make_uint4(ws[p], we[p], (u32)(uintptr_t)src[p], (u32)((uintptr_t)src[p] >> 32));
             } else if (cls[p] < 5) {
                 const u32 slot = s_base[cls[p]] + rank[p];
                 u32* qe = cls[p] == 4 ? overflow + 4 * (size_t)(qcap - 1 - slot) : overflow + 4 * (size_t)slot;
                 qe[0] = j;  // (output position, window start, window end, local haystack index)
                 qe[1] = ws[p];
-                qe[2] = we[p];
+                qe[2] = we[p] & 0x7FFFFFFFu;
                 qe[3] = li[p];
             }
         }
@@ -350,30 +370,30 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
 
 // (vblock of vgrid: the workgroup's index among those that walk this list - blockIdx / gridDim in the class's own launch, a slice of the grid
 // in k2_classes_all)
-template <int SWL, bool UPPER, int REAL, typename ET>
-__device__ __forceinline__ void dp_class_body(const CfTables& tab, u32 vblock, u32 vgrid, const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
-                                              const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ list, const u32* __restrict__ n_list_ptr,
+template <int SWL, bool UPPER, int REAL>
+__device__ __forceinline__ void dp_class_body(const CfTables& tab, u32 vblock, u32 vgrid, u32 index_offset,
+                                              const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ list, const u32* __restrict__ n_list_ptr,
                                               const NeedleDev& nd, fzb_match_rec* __restrict__ out) {
     constexpr int NB = SWL / 4;           // window dwords of a full chunk
     constexpr int NBR = (REAL + 1) / 2;   // dwords that can hold window bytes of this class
     const u32 M = __builtin_amdgcn_readfirstlane(*n_list_ptr);
     const u32 stride = vgrid * blockDim.x;
     const u32 q0 = vblock * blockDim.x + threadIdx.x;
-    // two-deep pipeline: (list entry -> haystack index, window, span) one item ahead of (window bytes), which are one item ahead of the DP
+    // two-deep pipeline: (list entry -> haystack index, the classifier's record) one item ahead of (window bytes), which are one item ahead of the DP
     auto load_meta = [&](u32 q, u32& j, u32& li, u32& sp, u32& m, u32& L, u64& s) {
-        j = 0; li = 0; sp = 0; m = 0; L = 0; s = 0;
+        j = 0; li = 0; sp = 0; m = 0; L = 0; s = (u64)(uintptr_t)meta;  // (an address that can be read: the slot's bytes are requested unconditionally only when m > 0)
         if (q < M) {
             j = list[q];
             li = items ? items[j] : j;
-            const uint2 w = *(const uint2*)(win + 2 * (size_t)j);
-            haystack_span(ends, first + li, s, L);
+            const uint4 w = meta[j];
             sp = w.x ? w.x - 1 : 0;
-            m = w.y - sp;
-            L = (sp == 0 && w.y == L) ? 1u : 0u;  // include_exact
+            m = (w.y & 0x7FFFFFFFu) - sp;
+            L = w.y >> 31;  // include_exact
+            s = (u64)w.z | ((u64)w.w << 32);
         }
     };
     auto load_bytes = [&](u64 s, u32 sp, u32 m, u32 (&hb)[NBR]) {
-        const u8* th = bytes + s + sp;
+        const u8* th = (const u8*)(uintptr_t)s + sp;
 #pragma unroll
         for (int k = 0; k < NBR; k++) {
             const u32 p = 4 * k;
@@ -429,39 +449,38 @@ __device__ __forceinline__ void dp_class_body(const CfTables& tab, u32 vblock, u
     }
 }
 
-template <int SWL, bool UPPER, int REAL, typename ET>
+template <int SWL, bool UPPER, int REAL>
 __global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3 : 2)) void k2b_dp_class(
-    const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win,
-    const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out) {
+    u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
+    fzb_match_rec* __restrict__ out) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
-    dp_class_body<SWL, UPPER, REAL, ET>(tab, blockIdx.x, gridDim.x, bytes, ends, first, index_offset, items, win, list, n_list_ptr, nd, out);
+    dp_class_body<SWL, UPPER, REAL>(tab, blockIdx.x, gridDim.x, index_offset, items, meta, list, n_list_ptr, nd, out);
 }
 
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
-                           int num_cus, hipStream_t st, int part, int split_multi) {
+                           int num_cus, hipStream_t st, int part, int split_multi, const StagedIn* staged) {
     // part: 0 = classify + the three class launches, 1 = classify only, 2 = the class launches only (host.hip runs the multi-chunk scorer on a
     // second stream between the two)
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     if (part != 2) {
         const int per = fzb_knobs().classify_per;  // tuning knob: survivors per thread
-#define FZB_K2W(ET, PER) hipLaunchKernelGGL((k2w_classify<ET, PER>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi)
+#define FZB_K2W(ET, PER) hipLaunchKernelGGL((k2w_classify<ET, PER>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, (uint4*)win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi, staged ? staged->stage : nullptr, staged ? staged->hdr : nullptr, staged ? staged->tile_prefix : nullptr)
 #define FZB_K2W_ET(PER) do { if (c.ends_u64) FZB_K2W(u64, PER); else FZB_K2W(u32, PER); } while (0)
         if (per == 1) FZB_K2W_ET(1); else if (per == 4) FZB_K2W_ET(4); else FZB_K2W_ET(2);
     }
     if (part == 1) return;
-#define FZB_K2C(SWL, U, REAL, CLS, ET)                                                                                                    \
+#define FZB_K2C(SWL, U, REAL, CLS)                                                                                                        \
     do {                                                                                                                                  \
         static int per_cu = 0;                                                                                                            \
-        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_class<SWL, U, REAL, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
-        hipLaunchKernelGGL((k2b_dp_class<SWL, U, REAL, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win_out, lists + (size_t)CLS * list_stride, &counters[8 + CLS], nd, out); \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_class<SWL, U, REAL>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
+        hipLaunchKernelGGL((k2b_dp_class<SWL, U, REAL>), dim3(num_cus * per_cu), dim3(128), 0, st, index_offset, items, (const uint4*)win_out, lists + (size_t)CLS * list_stride, &counters[8 + CLS], nd, out); \
     } while (0)
-#define FZB_K2C_ALL(SWL, U, ET) do { FZB_K2C(SWL, U, SWL / 4, 0, ET); FZB_K2C(SWL, U, 3 * SWL / 8, 1, ET); FZB_K2C(SWL, U, SWL / 2, 2, ET); } while (0)
-#define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C_ALL(SWL, U, u64); else FZB_K2C_ALL(SWL, U, u32); } while (0)
-#define FZB_K2C_U(SWL) do { if (upper) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
+#define FZB_K2C_ALL(SWL, U) do { FZB_K2C(SWL, U, SWL / 4, 0); FZB_K2C(SWL, U, 3 * SWL / 8, 1); FZB_K2C(SWL, U, SWL / 2, 2); } while (0)
+#define FZB_K2C_U(SWL) do { if (upper) FZB_K2C_ALL(SWL, true); else FZB_K2C_ALL(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2C_U(64); break;
         case 32: FZB_K2C_U(32); break;
@@ -543,9 +562,9 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ 
 // the multi-chunk windows as k2w_classify's four lists by the width of the last chunk's tail (lists 3-6 of `lists`, counts in counters[12..15]):
 // one persistent walk over the concatenation, widest class first (a slot's later items are its cheaper ones); a wave computes the last chunk
 // with the class of its first lane - the widest among its 64 (only the three waves that straddle a list boundary compute more than needed)
-template <int SWL, bool UPPER, typename ET>
-__device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock, u32 vgrid, const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
-                                                 const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride,
+template <int SWL, bool UPPER>
+__device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock, u32 vgrid, u32 index_offset,
+                                                 const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists, u32 list_stride,
                                                  const u32* __restrict__ counts, const NeedleDev& nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
     // positions [0, e3) class 3 (the whole last chunk), [e3, e2) class 2, [e2, e1) class 1, [e1, e0) class 0
     const u32 e3 = __builtin_amdgcn_readfirstlane(counts[3]), e2 = e3 + __builtin_amdgcn_readfirstlane(counts[2]), e1 = e2 + __builtin_amdgcn_readfirstlane(counts[1]),
@@ -557,14 +576,11 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
         const u32 j = lists[(size_t)(3 + cls) * list_stride + (q - base)];
         if (j >= capacity) continue;
         const u32 li = items ? items[j] : j;
-        const uint2 w = *(const uint2*)(win + 2 * (size_t)j);
-        u64 s;
-        u32 L;
-        haystack_span(ends, first + li, s, L);
-        const u8* hay = bytes + s;
+        const uint4 w = meta[j];  // the classifier's record: window, "whole haystack" flag, where the bytes are (stage or corpus)
+        const u8* hay = (const u8*)(uintptr_t)((u64)w.z | ((u64)w.w << 32));
         const u32 sp = w.x ? w.x - 1 : 0;
-        const bool include_exact = sp == 0 && w.y == L;
-        const u32 m = w.y - sp;
+        const bool include_exact = (w.y >> 31) != 0;
+        const u32 m = (w.y & 0x7FFFFFFFu) - sp;
         const u32 wcls = __builtin_amdgcn_readfirstlane(cls);  // lanes are in position order: the first active lane holds the widest class
         u32 score = dp_multi_chunk_tc<SWL, UPPER>(nd, hay + sp, m, sp == 0, tab, scratch, nthreads, gtid, wcls);
         bool exact = include_exact && m == (u32)nd.nbytes;
@@ -580,35 +596,35 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
     }
 }
 
-template <int SWL, bool UPPER, typename ET>
-__global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
-                                                       const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts,
-                                                       const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
+template <int SWL, bool UPPER>
+__global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
+                                                       u32 list_stride, const u32* __restrict__ counts, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
+                                                       u32* __restrict__ scratch) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
-    dp_multi_tc_body<SWL, UPPER, ET>(tab, blockIdx.x, gridDim.x, bytes, ends, first, index_offset, items, win, lists, list_stride, counts, nd, out, capacity, scratch);
+    dp_multi_tc_body<SWL, UPPER>(tab, blockIdx.x, gridDim.x, index_offset, items, meta, lists, list_stride, counts, nd, out, capacity, scratch);
 }
 
 // Small lists: the three single-chunk classes and the multi-chunk tail classes in ONE launch - the grid is cut into four slices, a workgroup
 // runs the body of its slice (widest work first).  On a list of a million items every one of the four launches is a single round of single
 // items, so their latencies (and launch boundaries) add up along the stream; here they run side by side.  Registers follow the widest body
 // (two waves per SIMD), which a small list does not notice.
-template <int SWL, bool UPPER, typename ET>
-__global__ __launch_bounds__(128, 2) void k2_classes_all(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
-                                                      const u32* __restrict__ win, const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counters,
-                                                      const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch, u32 gm, u32 gc) {
+template <int SWL, bool UPPER>
+__global__ __launch_bounds__(128, 2) void k2_classes_all(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
+                                                      u32 list_stride, const u32* __restrict__ counters, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
+                                                      u32* __restrict__ scratch, u32 gm, u32 gc) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
     u32 b = blockIdx.x;
-    if (b < gm) { dp_multi_tc_body<SWL, UPPER, ET>(tab, b, gm, bytes, ends, first, index_offset, items, win, lists, list_stride, &counters[12], nd, out, capacity, scratch); return; }
+    if (b < gm) { dp_multi_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch); return; }
     b -= gm;
-    if (b < gc) { dp_class_body<SWL, UPPER, SWL / 2, ET>(tab, b, gc, bytes, ends, first, index_offset, items, win, lists + 2 * (size_t)list_stride, &counters[10], nd, out); return; }
+    if (b < gc) { dp_class_body<SWL, UPPER, SWL / 2>(tab, b, gc, index_offset, items, meta, lists + 2 * (size_t)list_stride, &counters[10], nd, out); return; }
     b -= gc;
-    if (b < gc) { dp_class_body<SWL, UPPER, 3 * SWL / 8, ET>(tab, b, gc, bytes, ends, first, index_offset, items, win, lists + (size_t)list_stride, &counters[9], nd, out); return; }
+    if (b < gc) { dp_class_body<SWL, UPPER, 3 * SWL / 8>(tab, b, gc, index_offset, items, meta, lists + (size_t)list_stride, &counters[9], nd, out); return; }
     b -= gc;
-    dp_class_body<SWL, UPPER, SWL / 4, ET>(tab, b, gc, bytes, ends, first, index_offset, items, win, lists, &counters[8], nd, out);
+    dp_class_body<SWL, UPPER, SWL / 4>(tab, b, gc, index_offset, items, meta, lists, &counters[8], nd, out);
 }
 
 // gm workgroups for the multi-chunk lists (the scratch slab is sized for them: ensure_dp_scratch), gc for each single-chunk class
@@ -616,9 +632,8 @@ void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, con
                             const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int gm, int gc, hipStream_t st) {
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-#define FZB_K2A(SWL, U, ET) hipLaunchKernelGGL((k2_classes_all<SWL, U, ET>), dim3(gm + 3 * gc), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc)
-#define FZB_K2A_ET(SWL, U) do { if (c.ends_u64) FZB_K2A(SWL, U, u64); else FZB_K2A(SWL, U, u32); } while (0)
-#define FZB_K2A_U(SWL) do { if (upper) FZB_K2A_ET(SWL, true); else FZB_K2A_ET(SWL, false); } while (0)
+#define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), 0, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc)
+#define FZB_K2A_U(SWL) do { if (upper) FZB_K2A(SWL, true); else FZB_K2A(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2A_U(64); break;
         case 32: FZB_K2A_U(32); break;
@@ -631,9 +646,8 @@ void fzb_launch_dp_multi_classes(const CorpusDev& c, u64 first, u32 index_offset
                                  const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st) {
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-#define FZB_K2TC(SWL, U, ET) hipLaunchKernelGGL((k2d_dp_multi_tc<SWL, U, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, lists, list_stride, counts, nd, out, capacity, scratch)
-#define FZB_K2TC_ET(SWL, U) do { if (c.ends_u64) FZB_K2TC(SWL, U, u64); else FZB_K2TC(SWL, U, u32); } while (0)
-#define FZB_K2TC_U(SWL) do { if (upper) FZB_K2TC_ET(SWL, true); else FZB_K2TC_ET(SWL, false); } while (0)
+#define FZB_K2TC(SWL, U) hipLaunchKernelGGL((k2d_dp_multi_tc<SWL, U>), dim3(grid), dim3(128), 0, st, index_offset, items, (const uint4*)win, lists, list_stride, counts, nd, out, capacity, scratch)
+#define FZB_K2TC_U(SWL) do { if (upper) FZB_K2TC(SWL, true); else FZB_K2TC(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2TC_U(64); break;
         case 32: FZB_K2TC_U(32); break;

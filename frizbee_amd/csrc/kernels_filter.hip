@@ -168,6 +168,8 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
             v0[p] = make_uint4(0, 0, 0, 0);
             v1[p] = make_uint4(0, 0, 0, 0);
             const uint4* vp = (const uint4*)(bytes + hs[p]);
+            // (plain loads: with the non-temporal hint the second vector's request finds the line gone from the vector cache - a wave's two
+            // load instructions share every line of a 32-byte-record list - and the kernel takes 62 us instead of 57)
             if (hl[p] > 0) v0[p] = vp[0];
             if (hl[p] > 16) v1[p] = vp[1];
         }
@@ -512,15 +514,28 @@ __global__ __launch_bounds__(256) void k1_cdfa_ragged(const u8* __restrict__ byt
 // in its tile (vperm) through an LDS atomic-or, so the bitmap, the per-tile counts and every later stage see nothing of the view.
 // NV = vectors held in registers per haystack (8: lists up to 128 bytes, 16: up to 256).
 // ---------------------------------------------------------------------------------------------------
-template <bool SAN, int G, int NV>
+// STAGE: the handoff to the scorers (Workspace::stage).  A lane whose haystack is accepted still holds its vectors: it takes `its vector
+// count` units of the tile's stage block with one LDS atomic and stores them there, 16 bytes per instruction, and notes (unit offset | length
+// << 16) under its ORIGINAL tile position in LDS; when the tile is complete the workgroup ranks the set bits and writes the notes as the
+// tile's header, one entry per survivor in index order - the order of the survivor list, so k2w_classify finds survivor j's entry at
+// rank(j) - survivors-before-its-tile.  What the classifier and the scorers then read is ~ 4 KB of contiguous lines per tile instead of
+// 49 haystacks spread over 80 KB of the corpus (140 MB of cold lines for 43 MB of survivor bytes on the C4 shard).
+template <bool SAN, int G, int NV, bool STAGE>
 __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
                                                     const u16* __restrict__ vperm, u64 first, u32 count, const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG,
-                                                    u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
+                                                    u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters,
+                                                    u8* __restrict__ stage, u32* __restrict__ stage_hdr, u32 stage_dbg) {
+    // (stage_dbg: MEASUREMENT ONLY, FZB_STAGE_DBG - bit 0: no vector writes into LDS, 1: no copy-out, 2: no header; results meaningless)
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 tab_bytes = (cdfa_bytes + 15u) & ~15u;
     u32& s_cnt = *(u32*)(lds + tab_bytes);
+    u32& s_used = *(u32*)(lds + tab_bytes + 4);
+    u32& s_top = *(u32*)(lds + tab_bytes + 8);  // STAGE: end of the last allocation that lives in LDS
     u32* const s_bits = (u32*)(lds + tab_bytes + 16);
+    u32* const s_wpre = (u32*)(lds + tab_bytes + 16 + 128);       // STAGE: set bits before each of the 32 words
+    u32* const s_ent = (u32*)(lds + tab_bytes + 16 + 128 + 128);  // STAGE: header entry by original tile position
+    uint4* const s_stage = (uint4*)(lds + tab_bytes + 16 + 128 + 128 + 4 * FZB_TILE);  // STAGE: the first units of the tile's block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     dfa_require_lds_base0(lds);
     for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
@@ -530,9 +545,9 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
     auto comp_at = [](u32 a) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)(256u + a); };
     const u64 g_first = first / 64;  // `first` is a multiple of the tile size
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tid == 0) s_cnt = 0;
+        if (tid == 0) { s_cnt = 0; s_used = 0; s_top = 0; }
         if (tid < 32) s_bits[tid] = 0;
-        __syncthreads();
+        if (STAGE) barrier_lds_only(); else __syncthreads();
 #pragma unroll 1
         for (int gi = 0; gi < 4; gi++) {
             const u32 p = tile * FZB_TILE + (u32)(gi * 4 + wave) * 64 + lane;  // sorted position (relative to `first`)
@@ -543,8 +558,15 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
             u32 hl = 0, orig = 0;
             if (p < count) { hl = vlen[first + p]; orig = vperm[first + p]; }
             uint4 q[NV];
+            // (non-temporal: a wave's load covers whole lines that nothing reads again - the stream no longer displaces what the later stages
+            // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison)
+            if (stage_dbg & 8) {
 #pragma unroll
-            for (int k = 0; k < NV; k++) q[k] = (u32)k < nv ? *(const uint4*)(base + (size_t)k * 1024) : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < NV; k++) q[k] = (u32)k < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : make_uint4(0, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; k++) q[k] = (u32)k < nv ? *(const uint4*)(base + (size_t)k * 1024) : make_uint4(0, 0, 0, 0);
+            }
             u32 st = 0;
 #pragma unroll
             for (int k = 0; k < NV; k++) {
@@ -585,7 +607,72 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
                     for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);
                 }
             }
-            if (p < count && hl >= min_len && st >= acc_lo) atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
+            if (p < count && hl >= min_len && st >= acc_lo) {
+                atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
+                if (STAGE) {
+                    // the vectors go to the tile's block through LDS (the first FZB_STAGE_LDS_UNITS units: written out below by the whole
+                    // workgroup, 256 contiguous vectors per instruction); direct 16-byte stores from the few accepting lanes of a wave cost
+                    // the memory pipeline an instruction per vector and wave (filter 190 -> 227 us on the C4 shard) and stay the overflow path
+                    const u32 nvh = (hl + 15u) >> 4;
+                    const u32 off = atomicAdd(&s_used, nvh);
+                    u32 ent = 0xFFFFu | (hl << 16);
+                    if (off + nvh <= FZB_STAGE_LDS_UNITS) {
+                        ent = off | (hl << 16);
+                        atomicMax(&s_top, off + nvh);
+                        if (!(stage_dbg & 1)) {
+#pragma unroll
+                            for (int k = 0; k < NV; k++)
+                                if ((u32)k < nvh) s_stage[off + k] = q[k];
+                        }
+                    } else if (off + nvh <= FZB_STAGE_UNITS) {
+                        ent = off | (hl << 16);
+                        uint4* dst = (uint4*)(stage + ((size_t)tile * FZB_STAGE_UNITS + off) * 16);
+#pragma unroll
+                        for (int k = 0; k < NV; k++)
+                            if ((u32)k < nvh) dst[k] = q[k];
+                    }
+                    s_ent[orig] = ent;
+                }
+            }
+        }
+        if (STAGE) {
+            // Barriers of the staging form order LDS traffic only (barrier_lds_only): __syncthreads() also waits for every outstanding GLOBAL
+            // store, and the tile's copy-out would then expose a store round trip per tile (measured: filter 191 -> 230 us on the C4
+            // shard, 25 us of it the copy-out); what this kernel writes to global memory is read by later kernels only.
+            barrier_lds_only();
+            if (tid < 32) {  // set bits before each word (one wave: 32 lanes take part); the last lane holds the tile's count
+                const u32 c = (u32)__popc(s_bits[tid]);
+                u32 incl = c;
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) {
+                    const u32 v = __shfl_up(incl, off);
+                    if (tid >= off) incl += v;
+                }
+                s_wpre[tid] = incl - c;
+                if (tid == 31) tile_counts[tile] = incl;
+            }
+            if (tid >= 64 && tid < 64 + FZB_TILE / 64) {
+                const int t = tid - 64;
+                bitmap[(size_t)tile * (FZB_TILE / 64) + t] = (u64)s_bits[2 * t] | ((u64)s_bits[2 * t + 1] << 32);
+            }
+            if (!(stage_dbg & 2)) {  // the LDS part of the tile's block -> its place in the stage: contiguous 16-byte stores
+                // (an allocation that straddles the LDS limit went to global memory whole: only the units below the last LDS allocation's
+                // end are copied)
+                const u32 live = s_top;
+                uint4* dst = (uint4*)(stage + (size_t)tile * FZB_STAGE_UNITS * 16);
+                for (u32 u = tid; u < live; u += 256) dst[u] = s_stage[u];
+            }
+            barrier_lds_only();
+            if (!(stage_dbg & 4)) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const u32 o = (u32)tid + 256u * k;
+                    const u32 word = s_bits[o >> 5];
+                    if ((word >> (o & 31)) & 1u) stage_hdr[(size_t)tile * FZB_TILE + s_wpre[o >> 5] + (u32)__popc(word & ((1u << (o & 31)) - 1u))] = s_ent[o];
+                }
+            }
+            barrier_lds_only();
+            continue;
         }
         __syncthreads();
         if (tid < FZB_TILE / 64) {
@@ -612,7 +699,7 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
 // The last workgroup also publishes the total.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap, const u32* __restrict__ counts, u32 n_items_host, const u32* __restrict__ n_items_ptr,
-                                                  const u32* __restrict__ src, u32* __restrict__ out_idx, u32* __restrict__ total_out) {
+                                                  const u32* __restrict__ src, u32* __restrict__ out_idx, u32* __restrict__ total_out, u32* __restrict__ tile_prefix_out) {
     // n_items_ptr (device) overrides the host count; src, if given, maps a bit position to the value that is listed
     // (the item-list form of the filter: positions in a candidate list -> haystack indices)
     __shared__ u32 red[4];
@@ -668,6 +755,7 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
         u32 wb = 0;
         for (int w = 0; w < wave; w++) wb += red[w];
         pre[tid] = base + wb + incl - c;
+        if (tile_prefix_out && (u32)tid < nt) tile_prefix_out[tb + tid] = base + wb + incl - c;  // survivors before this tile (the handoff's header is per tile)
         const u32 batch_total = red[0] + red[1] + red[2] + red[3];
         __syncthreads();
         // expand the bitmap words of these tiles: the 16 words of a tile sit in 16 consecutive lanes (w0 is a multiple of 16),
@@ -861,9 +949,9 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // ---------------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from host.hip)
 // ---------------------------------------------------------------------------------------------------
-void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
+bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe,
-                       int acc_lo, const u8* cdfa, u32 cdfa_bytes, int cdfa_K, int cdfa_G) {
+                       int acc_lo, const u8* cdfa, u32 cdfa_bytes, int cdfa_K, int cdfa_G, const StageOut* so) {
     // mode 1: `dfa` has rows + 1 states, start state 0, and accepts in the states >= acc (the subsequence / unicode / KMP automata: the last
     // state; the LCS automaton of a typo configuration: every state whose LCS reaches the need)
     const u32 acc = acc_lo < 0 ? (u32)rows : (u32)acc_lo;
@@ -892,19 +980,22 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             const int vwg = kn.view_wgs;  // (C4 shard: 8 -> 190 us, 6 -> 187, 4 -> 194)
             if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2) && c.vbytes && !no_view && first % FZB_TILE == 0 && (first + count == c.n || count % FZB_TILE == 0) &&
                 c.view_nv != 0 && c.view_nv <= 16) {
-                const size_t lds_v = ((cdfa_bytes + 15) & ~(size_t)15) + 16 + 128;
+                const bool stg = so && so->stage && so->hdr;
+                const size_t lds_v = ((cdfa_bytes + 15) & ~(size_t)15) + 16 + 128 + (stg ? 128 + 4 * FZB_TILE + 16 * FZB_STAGE_LDS_UNITS : 0);
                 const int g = std::max(1, std::min<int>((grid / 8) * vwg, (int)ntiles));
                 u32 kg = 1;
                 for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
                 if (kn.cdfa_nodfa) cdfa_K = 0xFFFF;
-#define FZB_K1V(SAN, G, NV) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
-#define FZB_K1V_NV(SAN, G) do { if (c.view_nv <= 8) FZB_K1V(SAN, G, 8); else FZB_K1V(SAN, G, 16); } while (0)
+#define FZB_K1V(SAN, G, NV, STG) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, STG>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, stg ? so->stage : nullptr, stg ? so->hdr : nullptr, (u32)kn.stage_dbg | (kn.view_plain_loads ? 0u : 8u))
+#define FZB_K1V_S(SAN, G, NV) do { if (stg) FZB_K1V(SAN, G, NV, true); else FZB_K1V(SAN, G, NV, false); } while (0)
+#define FZB_K1V_NV(SAN, G) do { if (c.view_nv <= 8) FZB_K1V_S(SAN, G, 8); else FZB_K1V_S(SAN, G, 16); } while (0)
 #define FZB_K1V_G(SAN) do { if (cdfa_G == 4) FZB_K1V_NV(SAN, 4); else FZB_K1V_NV(SAN, 2); } while (0)
                 if (nul_safe) FZB_K1V_G(false); else FZB_K1V_G(true);
 #undef FZB_K1V_G
 #undef FZB_K1V_NV
+#undef FZB_K1V_S
 #undef FZB_K1V
-                return;
+                return stg && !kn.cdfa_nodfa;
             }
             if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2)) {
                 const size_t lds_c = ((cdfa_bytes + 15) & ~(size_t)15) + 16;
@@ -918,7 +1009,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 else            { if (nul_safe) FZB_K1CD_G(u32, false); else FZB_K1CD_G(u32, true); }
 #undef FZB_K1CD_G
 #undef FZB_K1CD
-                return;
+                return false;
             }
             const bool burst = kn.ragged_burst;  // false = the rolling form, for comparison
             const int bwgs = kn.ragged_wgs;
@@ -928,14 +1019,14 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 if (c.ends_u64) { if (nul_safe) FZB_K1B(u64, false); else FZB_K1B(u64, true); }
                 else            { if (nul_safe) FZB_K1B(u32, false); else FZB_K1B(u32, true); }
 #undef FZB_K1B
-                return;
+                return false;
             }
 #define FZB_K1R(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged<ET, 1, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
             if (c.ends_u64) { if (nul_safe) FZB_K1R(u64, false); else FZB_K1R(u64, true); }
             else            { if (nul_safe) FZB_K1R(u32, false); else FZB_K1R(u32, true); }
 #undef FZB_K1R
         }
-        return;
+        return false;
     }
     const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
     if (mode == 2 && bitmap_m) {  // LCS filter with the "nothing to spare" bit (typo configurations on the short-haystack path)
@@ -944,7 +1035,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         if (c.ends_u64) { if (w64) FZB_K1M(u64, u64); else FZB_K1M(u32, u64); }
         else            { if (w64) FZB_K1M(u64, u32); else FZB_K1M(u32, u32); }
 #undef FZB_K1M
-        return;
+        return false;
     }
 #define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, MargOut{}, c.uniform_len)
     if (c.ends_u64) {
@@ -955,6 +1046,7 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         else           { if (w64) FZB_K1(u64, 2, u32); else FZB_K1(u32, 2, u32); }
     }
 #undef FZB_K1
+    return false;
 }
 
 // Exclusive prefix of the per-tile reject counts (decide form of k2a_window) - only when something was rejected at all, which on
@@ -988,8 +1080,9 @@ void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* rej
     hipLaunchKernelGGL(k_scan_rejects, dim3(1), dim3(1024), 0, st, tile_rejects, ntiles, reject_count, rej_prefix);
 }
 
-void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, n_items_ptr, src, out_idx, total_out);
+void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st,
+                         u32* tile_prefix_out) {
+    hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, n_items_ptr, src, out_idx, total_out, tile_prefix_out);
 }
 
 void fzb_launch_compact2(const u64* bitmap, const u32* counts, const u32* n_items_ptr, const u32* in_idx, const u32* in_win, u32* out_idx, u32* out_win, u32* total_out,

@@ -19,6 +19,9 @@ struct FzbKnobs {
     bool ragged_burst = true;        // FZB_RAGGED_BURST=0     rolling form of the canonical-layout ragged filter
     bool debug_sync = false;         // FZB_DEBUG_SYNC=1       synchronise and report after every stage of the pipeline
     bool no_handoff = false;         // FZB_NO_HANDOFF=1       ragged lists: classifier and scorers gather the survivors' bytes from the corpus (no staging)
+    bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device
+    bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint
+    int stage_dbg = 0;               // FZB_STAGE_DBG=bits     MEASUREMENT ONLY: parts of the view kernel's staging switched off (results meaningless)
     int k2u_waves = 0;               // FZB_K2U_WAVES=3        unicode scorer's biased form capped at three waves per SIMD (spills)
     uint32_t small_list = 0xFFFFFFFFu;  // FZB_SMALL_LIST=n   lists of n haystacks and more: four scorer launches on two streams instead of k2_classes_all
     // --- tuning (grid shapes) ---

@@ -20,7 +20,20 @@ pytestmark = pytest.mark.gpu
 SORTS = ("ScoreThenIndexAsc", "ScoreThenIndexDesc", "IndexAsc", "IndexDesc")
 
 
-def test_sharded_match_list_parallel_equals_match_list_for_every_sort_and_shard_count():
+@pytest.fixture(params=["pull", "copy"])
+def gather_mode(request):
+    """How the runs reach the root: one concatenation kernel that pulls them (every shard on the root device - the only arrangement
+    one GPU offers) or the form shards on OTHER devices take - count to the host, hipMemcpyPeerAsync to the run's place - forced here
+    with FZB_SHARD_GATHER=copy so that one GPU exercises it too."""
+    if request.param == "copy":
+        os.environ["FZB_SHARD_GATHER"] = "copy"
+    F.lib().fzb_debug_reload_knobs()
+    yield request.param
+    os.environ.pop("FZB_SHARD_GATHER", None)
+    F.lib().fzb_debug_reload_knobs()
+
+
+def test_sharded_match_list_parallel_equals_match_list_for_every_sort_and_shard_count(gather_mode):
     rows, ends = synth.fixed_corpus(b"deadbe", 120_001, 32)
     data = rows.numpy().reshape(-1)
     odata = np.concatenate([data, np.zeros(64, np.uint8)])
@@ -39,7 +52,7 @@ def test_sharded_match_list_parallel_equals_match_list_for_every_sort_and_shard_
         del sc
 
 
-def test_sharded_ragged_list_byte_balanced_and_requery_after_set_pattern():
+def test_sharded_ragged_list_byte_balanced_and_requery_after_set_pattern(gather_mode):
     data, ends = synth.ragged_corpus(b"deadbeef", 60_013)
     odata = np.concatenate([data, np.zeros(64, np.uint8)])
     have = F.device_count()
@@ -58,7 +71,7 @@ def test_sharded_ragged_list_byte_balanced_and_requery_after_set_pattern():
     assert m.match_list_parallel_sharded(sc).tolist() == want.tolist()
 
 
-def test_sharded_edge_cases():
+def test_sharded_edge_cases(gather_mode):
     have = F.device_count()
     for hs in ([], ["deadbe"], ["x", "deadbe", "", "dead_be"]):
         for ndev in (1, 3):
