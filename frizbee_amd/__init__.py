@@ -531,13 +531,19 @@ class Matcher(_IterApi):
         _check(lib().fzb_match_list_parallel_sharded(self.h, sharded.h, C.byref(out), C.byref(n)))
         return _take(out, n, copy)
 
-    def merge_shard_runs(self, run_ptrs, count_ptrs, run_caps, stream=0, copy=True):
-        """fzb_merge_shard_runs: index-ordered per-shard runs resident on the current device (ascending shard order; counts in device
-        memory) -> `match_list`'s ordered result on the host.  Concatenation + reverse / stable radix sort on the device."""
+    @staticmethod
+    def merge_args(run_ptrs, count_ptrs, run_caps):
+        """Marshal the arguments of `merge_shard_runs` once (callers that merge the same buffers every step)."""
         n = len(run_ptrs)
-        runs = (C.c_void_p * max(n, 1))(*[int(p) for p in run_ptrs])
-        cnts = (C.c_void_p * max(n, 1))(*[int(p) for p in count_ptrs])
-        caps = (C.c_size_t * max(n, 1))(*[int(c) for c in run_caps])
+        return ((C.c_void_p * max(n, 1))(*[int(p) for p in run_ptrs]), (C.c_void_p * max(n, 1))(*[int(p) for p in count_ptrs]),
+                (C.c_size_t * max(n, 1))(*[int(c) for c in run_caps]), n)
+
+    def merge_shard_runs(self, runs, cnts, caps, n=None, stream=0, copy=True):
+        """fzb_merge_shard_runs: index-ordered per-shard runs resident on the current device (ascending shard order; each count pointer
+        = the (records written, matches found) pair fzb_match_list_device wrote, in device memory) -> `match_list`'s ordered result on the
+        host.  Concatenation + reverse / stable radix sort on the device.  Arguments: lists of addresses, or `merge_args(...)` unpacked."""
+        if n is None:
+            runs, cnts, caps, n = self.merge_args(runs, cnts, caps)
         out, ln = C.c_void_p(), C.c_size_t()
         _check(lib().fzb_merge_shard_runs(self.h, runs, cnts, caps, n, stream, C.byref(out), C.byref(ln)))
         return _take(out, ln, copy)

@@ -164,7 +164,8 @@ struct StageOut {
     u32* hdr;
 };
 
-// Index-ordered record runs of contiguous shards, all readable from the current device (k_concat_runs); cap[g] bounds count[g]
+// Index-ordered record runs of contiguous shards, all readable from the current device (k_concat_runs); count[g] points at the pair
+// fzb_match_list_device writes (records written, matches found), cap[g] is the run's buffer size in records
 #define FZB_MAX_RUNS 64
 struct RunSet {
     const fzb_match_rec* run[FZB_MAX_RUNS];
@@ -227,7 +228,7 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
                            int grid, hipStream_t st, int tform = 0);
 // kernels_sort.hip
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st, int passes = 2);
-void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, hipStream_t st);
+void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, u32* cut_flag, hipStream_t st);
 // kernels_multi.hip
 void fzb_launch_records_to_items(const fzb_match_rec* cand, const u32* n_ptr, u32 index_offset, u32* items, int grid, hipStream_t st);
 void fzb_launch_identity_records(fzb_match_rec* out, u32 n, u32 index_offset, u32* count_out, int grid, hipStream_t st);

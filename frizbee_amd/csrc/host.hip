@@ -563,6 +563,7 @@ static int rebuild_matcher(fzb_matcher* m, const fzb_config* config, const uint8
     std::swap(fresh->out_dev, m->out_dev);
     std::swap(fresh->out_cap, m->out_cap);
     std::swap(fresh->count_dev, m->count_dev);
+    std::swap(fresh->fetch, m->fetch);
     std::swap(fresh->long_scratch, m->long_scratch);
     std::swap(fresh->long_scratch_bytes, m->long_scratch_bytes);
     std::swap(fresh->aux_stream, m->aux_stream);
@@ -649,6 +650,7 @@ void fzb_matcher_free(fzb_matcher* m) {
     if (m->aux_stream) (void)hipStreamDestroy(m->aux_stream);
     if (m->long_blob_dev) (void)hipFree(m->long_blob_dev);
     if (m->long_scratch) (void)hipFree(m->long_scratch);
+    if (m->fetch.count_host) (void)hipHostFree(m->fetch.count_host);
     if (m->shard_workers) fzb_shard_workers_free(m->shard_workers);  // joins the worker threads before their clones go
     m->shard_workers = nullptr;
     if (m->shard_stream) (void)hipStreamDestroy(m->shard_stream);
@@ -883,7 +885,7 @@ int fzb_ensure_out_staging(fzb_matcher* m, size_t count) {  // device-side resul
     m->out_cap = 0;
     HIPCHK(dev_alloc((void**)&m->out_dev, (count + 16) * sizeof(fzb_match_rec)));
     m->out_cap = count;
-    if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 16));
+    if (!m->count_dev) HIPCHK(dev_alloc((void**)&m->count_dev, 64));
     return FZB_OK;
 }
 extern "C" {
@@ -1376,25 +1378,49 @@ PinnedPool& pinned_pool() {
     return *pool;
 }
 }  // namespace
-void* fzb_pinned_get(size_t bytes) { return pinned_pool().get(bytes); }
-bool fzb_pinned_put(void* p) { return pinned_pool().put(p); }
-namespace {
-// count (device) -> host, then the records into a pooled pinned buffer
-int fetch_records(const void* dev_records, const u32* dev_count, fzb_match** out, size_t* out_len) {
-    u32 n = 0;
-    HIPCHK(hipMemcpy(&n, dev_count, 4, hipMemcpyDeviceToHost));  // synchronises the default stream
-    fzb_match* r = (fzb_match*)pinned_pool().get(std::max<size_t>(n, 1) * sizeof(fzb_match));
+// (dev_words: eight u32 in device memory, all copied to h.count_host; the record count is word `n_word`)
+int fzb_fetch_records(FetchHint& h, const void* dev_records, const u32* dev_words, int n_word, size_t capacity, hipStream_t st, fzb_match** out, size_t* out_len) {
+    if (!h.count_host) HIPCHK(hipHostMalloc((void**)&h.count_host, 32, hipHostMallocDefault));
+    // the guess: the previous result's size and a little more (every speculated record that does not exist is copied for nothing - a
+    // quarter more cost 19 us on a 4 MB result, more than the synchronisation it saves); the buffer has room for half as many again, so a
+    // result that outgrew the guess usually only needs its remainder copied
+    const size_t guess = h.last ? std::min(capacity, h.last + h.last / 64 + 64) : 0;
+    size_t room = std::min(capacity, guess + guess / 2);
+    fzb_match* r = (fzb_match*)pinned_pool().get(std::max<size_t>(room, 1) * sizeof(fzb_match));
     if (!r) return fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
-    if (n) {
-        hipError_t e = hipMemcpy(r, dev_records, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
+    hipError_t e = hipMemcpyAsync(h.count_host, dev_words, 32, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess && guess) e = hipMemcpyAsync(r, dev_records, guess * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    const size_t n = e == hipSuccess ? (size_t)h.count_host[n_word] : 0;
+    if (e == hipSuccess && n > guess) {  // the result outgrew the guess (or there was none): the rest in a second copy
+        size_t have = guess;
+        if (n > room) {
             pinned_pool().put(r);
-            return fail(FZB_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+            r = (fzb_match*)pinned_pool().get(n * sizeof(fzb_match));
+            if (!r) return fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
+            have = 0;
         }
+        e = hipMemcpyAsync(r + have, (const fzb_match*)dev_records + have, (n - have) * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
     }
+    if (e != hipSuccess) {
+        pinned_pool().put(r);
+        return fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));
+    }
+    h.last = n;
     *out = r;
     *out_len = n;
     return FZB_OK;
+}
+void* fzb_pinned_get(size_t bytes) { return pinned_pool().get(bytes); }
+bool fzb_pinned_put(void* p) { return pinned_pool().put(p); }
+namespace {
+// The result of a query -> the host: the record count and the records, into a pooled pinned buffer.  The count is not known when the
+// copies are enqueued, so the records are copied SPECULATIVELY - as many as the matcher's previous query returned plus a quarter - right
+// behind the count, and one synchronisation serves both (a re-query of a resident list - the next keystroke - returns about as many
+// matches as the last one, usually fewer); only a result that outgrew the guess costs the second copy that every query used to pay.
+int fetch_records(FetchHint& h, const void* dev_records, const u32* dev_count, size_t capacity, fzb_match** out, size_t* out_len) {
+    return fzb_fetch_records(h, dev_records, dev_count, 0, capacity, nullptr, out, out_len);
 }
 }  // namespace
 extern "C" {
@@ -1417,7 +1443,7 @@ int fzb_match_list_into(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     if (int rc_ = fzb_ensure_out_staging(m, count)) return rc_;
     int rc = fzb_match_list_device(m, c, first, count, index_offset, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
-    return fetch_records(m->out_dev, m->count_dev, out, out_len);
+    return fetch_records(m->fetch, m->out_dev, m->count_dev, m->out_cap, out, out_len);
 }
 
 void fzb_radix_sort_matches(fzb_match* matches, size_t n) {  // src/sort.rs:6-40
@@ -1453,7 +1479,7 @@ int fzb_match_list(fzb_matcher* m, const fzb_corpus* c, fzb_match** out, size_t*
     // scoring AND the reverse / stable radix sort post-step run on the device; the host only receives the final list
     int rc = fzb_match_list_sorted_device(m, c, (fzb_match*)m->out_dev, m->out_cap, m->count_dev, nullptr);
     if (rc) return rc;
-    return fetch_records(m->out_dev, m->count_dev, out, out_len);
+    return fetch_records(m->fetch, m->out_dev, m->count_dev, m->out_cap, out, out_len);
 }
 
 int fzb_match_list_parallel(fzb_matcher* m, const fzb_corpus* c, size_t threads, fzb_match** out, size_t* out_len) {
@@ -1705,6 +1731,7 @@ struct fzb_multi_matcher {
     fzb_match_rec* sort_tmp = nullptr;
     u32* sort_hist = nullptr;
     size_t sort_cap = 0;
+    FetchHint fetch;
 };
 
 static void multi_free_buffers(fzb_multi_matcher* mm) {
@@ -1749,6 +1776,7 @@ void fzb_multi_matcher_free(fzb_multi_matcher* mm) {
     void* ptrs[] = {mm->out_dev, mm->count_dev, mm->sort_tmp, mm->sort_hist};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (mm->fetch.count_host) (void)hipHostFree(mm->fetch.count_host);
     delete mm;
 }
 
@@ -1842,7 +1870,7 @@ int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match**
         mm->out_cap = 0;
         HIPCHK(dev_alloc((void**)&mm->out_dev, (count + 16) * sizeof(fzb_match_rec)));
         mm->out_cap = count;
-        if (!mm->count_dev) HIPCHK(dev_alloc((void**)&mm->count_dev, 16));
+        if (!mm->count_dev) HIPCHK(dev_alloc((void**)&mm->count_dev, 64));
     }
     int rc = fzb_multi_match_list_device(mm, c, 0, count, 0, (fzb_match*)mm->out_dev, mm->out_cap, mm->count_dev, nullptr);
     if (rc) return rc;
@@ -1862,7 +1890,7 @@ int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match**
         fzb_launch_sort(mm->out_dev, mm->sort_tmp, mm->count_dev, mm->sort_hist, (u32)(mm->sort_cap / 2048 + 2), reversed, by_score, mm->num_cus * 2, nullptr);
         HIPCHK(hipGetLastError());
     }
-    return fetch_records(mm->out_dev, mm->count_dev, out, out_len);
+    return fetch_records(mm->fetch, mm->out_dev, mm->count_dev, mm->out_cap, out, out_len);
 }
 
 // `Matcher::match_list_indices` over CompiledPatterns (mod.rs:234-275): Empty / Single as above; Multi = match_one_indices_multi
@@ -1959,11 +1987,11 @@ int fzb_multi_match_list_into(fzb_multi_matcher* mm, const fzb_corpus* c, size_t
         mm->out_cap = 0;
         HIPCHK(dev_alloc((void**)&mm->out_dev, (count + 16) * sizeof(fzb_match_rec)));
         mm->out_cap = count;
-        if (!mm->count_dev) HIPCHK(dev_alloc((void**)&mm->count_dev, 16));
+        if (!mm->count_dev) HIPCHK(dev_alloc((void**)&mm->count_dev, 64));
     }
     int rc = fzb_multi_match_list_device(mm, c, first, count, index_offset, (fzb_match*)mm->out_dev, mm->out_cap, mm->count_dev, nullptr);
     if (rc) return rc;
-    return fetch_records(mm->out_dev, mm->count_dev, out, out_len);
+    return fetch_records(mm->fetch, mm->out_dev, mm->count_dev, mm->out_cap, out, out_len);
 }
 
 void fzb_matches_free(fzb_match* p) {

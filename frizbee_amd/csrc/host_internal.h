@@ -28,6 +28,12 @@ struct fzb_corpus {
     void* own_view[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the filter's view: vbytes, vgofs, vgnv, vlen, vperm (CorpusDev)
 };
 
+// what the synchronous entry points remember between two results (fetch_records, host.hip)
+struct FetchHint {
+    size_t last = 0;            // records of the previous result: the next one's records are copied speculatively, behind the count
+    u32* count_host = nullptr;  // page-locked landing place of the two counters
+};
+
 struct fzb_matcher {
     fzb_config config{};
     std::string needle;
@@ -64,6 +70,7 @@ struct fzb_matcher {
     fzb_match_rec* out_dev = nullptr;
     size_t out_cap = 0;
     u32* count_dev = nullptr;
+    FetchHint fetch;
     // fzb_match_list_indices: the selection (+ its length), the positions (`stride` per record) and their counts
     u32* trace_sel = nullptr;
     u32* trace_pos = nullptr;
@@ -96,6 +103,9 @@ bool fzb_pinned_put(void* p);
 
 // host.hip internals used by the other translation units
 int fzb_bind_device(fzb_matcher* m);
+// count + records of a result in device memory -> a pooled pinned host buffer, with ONE synchronisation when the previous result's size
+// was a good guess (host.hip); dev_words = 8 u32, the record count is word n_word, the others stay readable in h.count_host
+int fzb_fetch_records(FetchHint& h, const void* dev_records, const u32* dev_words, int n_word, size_t capacity, hipStream_t st, fzb_match** out, size_t* out_len);
 int fzb_ensure_out_staging(fzb_matcher* m, size_t count);
 // the ordering post-step of `match_list` on the device (host.hip, next to fzb_sorted_range_device)
 struct OrderPlan {

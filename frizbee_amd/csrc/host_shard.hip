@@ -140,7 +140,10 @@ static int merge_runs_on_device(fzb_matcher* m, const void* const* dev_runs, con
     if ((rc = fzb_ensure_out_staging(m, cap))) return rc;
     OrderPlan plan;
     if ((rc = fzb_order_begin(m, cap, m->out_dev, &plan))) return rc;
-    u32* words = m->count_dev;  // [0..1] and [2..3]: running (written, found) totals, alternating between batches of FZB_MAX_RUNS runs
+    // count_dev: two blocks of four words, alternating between batches of FZB_MAX_RUNS runs - [0] records written so far, [1] matches
+    // found, [2] "a run was truncated by its producer" (sticky: every batch writes into the same word)
+    u32* words = m->count_dev;
+    HIPCHK(hipMemsetAsync(words, 0, 32, st));
     const u32* base = nullptr;
     u32* tot = words;
     for (size_t g0 = 0; g0 < nruns; g0 += FZB_MAX_RUNS) {
@@ -151,24 +154,20 @@ static int merge_runs_on_device(fzb_matcher* m, const void* const* dev_runs, con
             rs.count[k] = dev_counts[g0 + (size_t)k];
             rs.cap[k] = (u32)run_caps[g0 + (size_t)k];
         }
-        fzb_launch_concat_runs(rs, base, tot, plan.in, (u32)cap, m->lc.num_cus * 2, st);
+        fzb_launch_concat_runs(rs, base, tot, plan.in, (u32)cap, m->lc.num_cus * 2, words + 2, st);
         base = tot;
-        tot = tot == words ? words + 2 : words;
+        tot = tot == words ? words + 4 : words;
     }
     HIPCHK(hipGetLastError());
     if ((rc = fzb_order_finish(m, plan, m->out_dev, base, st))) return rc;
-    u32 n = 0;
-    HIPCHK(hipMemcpyAsync(&n, base, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (!n) return FZB_OK;
-    fzb_match* r = (fzb_match*)fzb_pinned_get((size_t)n * sizeof(fzb_match));
-    if (!r) return fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
+    // one synchronisation for the counters and (speculatively, sized by the previous result) the records
     const fzb_match_rec* final_dev = (plan.reversed || plan.by_score) ? m->out_dev : plan.in;
-    hipError_t e = hipMemcpyAsync(r, final_dev, (size_t)n * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e != hipSuccess) {
-        fzb_pinned_put(r);
-        return fzb_fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));
+    fzb_match* r = nullptr;
+    size_t n = 0;
+    if ((rc = fzb_fetch_records(m->fetch, final_dev, words, (int)(base - words), cap, st, &r, &n))) return rc;
+    if (m->fetch.count_host[2]) {
+        fzb_matches_free(r);
+        return fzb_fail(FZB_ERR_CAPACITY, "a shard's run was truncated by its producer (more matches than its buffer holds): nothing merged");
     }
     *out = r;
     *out_len = n;

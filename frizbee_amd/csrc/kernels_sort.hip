@@ -157,11 +157,15 @@ __global__ __launch_bounds__(256) void k_reverse(fzb_match_rec* __restrict__ a, 
 // reverse / stable radix sort that follows reproduces `match_list`'s order exactly (src/matcher/mod.rs:215-221) - the result of
 // `match_list_parallel`'s per-run sort + k-way merge (src/matcher/parallel.rs:66-87) without a host heap.
 // Every workgroup scans the (<= 64) run lengths itself; a record finds its run by binary search in LDS.
-__global__ __launch_bounds__(256) void k_concat_runs(RunSet rs, const u32* __restrict__ base_in, u32* __restrict__ total_out, fzb_match_rec* __restrict__ out, u32 capacity) {
+__global__ __launch_bounds__(256) void k_concat_runs(RunSet rs, const u32* __restrict__ base_in, u32* __restrict__ total_out, fzb_match_rec* __restrict__ out, u32 capacity,
+                                                     u32* __restrict__ cut_flag) {
     __shared__ u32 pre[FZB_MAX_RUNS + 1];
     const int tid = threadIdx.x;
     if (tid < 64) {
-        const u32 c = tid < rs.n ? min(*rs.count[tid], rs.cap[tid]) : 0u;
+        const u32 c = tid < rs.n ? min(rs.count[tid][0], rs.cap[tid]) : 0u;
+        // a run whose producer found more matches than its buffer holds (fzb_match_list_device: count[1] > capacity) is reported, not merged
+        const bool cut = tid < rs.n && rs.count[tid][1] > rs.cap[tid];
+        if (__ballot(cut) && tid == 0 && blockIdx.x == 0) *cut_flag = 1u;
         u32 incl = c;
         for (int off = 1; off < 64; off <<= 1) {
             const u32 t = __shfl_up(incl, off);
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(256) void k_concat_runs(RunSet rs, const u32* __res
     }
 }
 
-void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, hipStream_t st) {
-    hipLaunchKernelGGL(k_concat_runs, dim3(grid), dim3(256), 0, st, rs, base_in, total_out, out, capacity);
+void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, u32* cut_flag, hipStream_t st) {
+    hipLaunchKernelGGL(k_concat_runs, dim3(grid), dim3(256), 0, st, rs, base_in, total_out, out, capacity, cut_flag);
 }
 
 // records: `buf` (n = *n_ptr records, capacity cap) sorted in place; tmp >= cap records; hist >= 2 * 256 * ntiles_cap words

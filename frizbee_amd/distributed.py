@@ -84,6 +84,7 @@ class ShardExchange:
         self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.rank == root else None for _ in range(slots)]
         self.work = [None] * slots
+        self._merge_args = [None] * slots
         # only RCCL's completion query is trusted to stand in for wait(): on other backends wait() is what surfaces a failed collective
         self._skip_completed_wait = dist.get_backend(group) == "nccl"
 
@@ -142,20 +143,23 @@ class ShardExchange:
             out.append((cnt, total))
         return out
 
-    def collect_merged(self, slot, matcher, stream=0):
+    def collect_merged(self, slot, matcher, stream=0, copy=False):
         """Root only, synchronising: the exchange posted on `slot` as ONE list in `matcher.config.sort` order - what
         `match_list_parallel` returns (parallel.rs:66-87).  The gathered runs never leave the root's HBM unordered: concatenation in rank
         order (= ascending index order) + reverse / stable radix sort on the device (fzb_merge_shard_runs), one copy to the host.
-        Device tensors only (the RCCL path); CPU tensors take `merge_shard_runs(collect(slot), sort)`."""
+        CPU tensors (the gloo tests) take the host form, `merge_shard_runs(collect(slot), sort)`."""
         self.wait(slot)
         if self.rank != self.root:
             return None
         bufs = self.recv[slot]
         if not bufs[0].is_cuda:
             return merge_shard_runs(self.collect(slot), matcher.config.sort)
-        merged = matcher.merge_shard_runs([b.data_ptr() + self.HEADER for b in bufs], [b.data_ptr() for b in bufs], [self.cap] * self.world, stream=stream)
-        self._headers(slot)  # truncation is reported, never returned as a shorter list
-        return merged
+        if self._merge_args[slot] is None:  # the buffers never move: their addresses are marshalled once
+            self._merge_args[slot] = matcher.merge_args([b.data_ptr() + self.HEADER for b in bufs], [b.data_ptr() for b in bufs], [self.cap] * self.world)
+        # a shard that outgrew the exchange capacity makes the call fail (FZB_ERR_CAPACITY): reported, never returned as a shorter list
+        # (copy=False: the array wraps the library's pinned buffer, which returns to the pool when the array is collected - a fresh numpy
+        # copy of a 4 MB result costs more than the device-side merge)
+        return matcher.merge_shard_runs(*self._merge_args[slot], stream=stream, copy=copy)
 
 
 def merge_shard_runs(runs, sort):

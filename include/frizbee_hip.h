@@ -195,8 +195,9 @@ int fzb_sharded_corpus_shard(const fzb_sharded_corpus* sc, int g, uint64_t* lo, 
 int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc, fzb_match** out, size_t* out_len);
 /* The combine step alone, for callers that moved the per-shard runs themselves (one process per GPU: the root rank after an RCCL
  * gather - frizbee_amd.distributed): run g = dev_runs[g], index-ordered records of shard g as fzb_match_list_device wrote them,
- * *dev_counts[g] of them (a uint32 in DEVICE memory, at most run_caps[g]); runs in ascending shard order, all readable from the current
- * device.  Concatenation + `match_list`'s ordering (src/matcher/mod.rs:215-221) on the device, on `stream`, then one copy to the
+ * dev_counts[g] -> the two uint32 that call wrote in DEVICE memory (records written, matches found), run_caps[g] = the run's buffer size
+ * in records (a run with matches found > run_caps[g] was truncated by its producer: FZB_ERR_CAPACITY, nothing merged); runs in ascending
+ * shard order, all readable from the current device.  Concatenation + `match_list`'s ordering (src/matcher/mod.rs:215-221) on the device, on `stream`, then one copy to the
  * host = the list `match_list_parallel` returns (src/matcher/parallel.rs:66-87).  Free the result with fzb_matches_free. */
 int fzb_merge_shard_runs(fzb_matcher* m, const void* const* dev_runs, const uint32_t* const* dev_counts, const size_t* run_caps, size_t nruns, void* stream,
                          fzb_match** out, size_t* out_len);

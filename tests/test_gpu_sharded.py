@@ -148,9 +148,21 @@ for typos in (0, 2):
         m.match_list_device(cp, ex.records_ptr(slot), ex.cap, ex.count_ptr(slot), index_offset=7)
         ex.post(slot)
     runs = ex.collect(0); ex.collect(1)
-    for sort in ("ScoreThenIndexAsc", "IndexDesc"):
+    for sort in ("ScoreThenIndexAsc", "ScoreThenIndexDesc", "IndexAsc", "IndexDesc"):
         want = O.Matcher("deadbe", lanes=(64, 64, 32), max_typos=typos, sort=sort).match_packed(odata, ends); want["index"] += 7
         assert merge_shard_runs(runs, F.SortStrategy[sort]).tolist() == want.tolist(), (typos, sort)
+        # the device form of the combine (what bench.py's ordered mode runs on the root): gathered runs -> concatenation + radix sort in HBM
+        ms = F.Matcher("deadbe", F.Config(max_typos=typos, sort=F.SortStrategy[sort], pf_lanes=64, sw_lanes=64))
+        ms.match_list_device(cp, ex.records_ptr(0), ex.cap, ex.count_ptr(0), index_offset=7); ex.post(0)
+        assert ex.collect_merged(0, ms).tolist() == want.tolist(), (typos, sort, "device merge")
+        # ... and the same run three times as three "shards" (indices repeat: only the concatenation order and the stable sort are under test)
+        torch.cuda.synchronize()
+        b = ex.recv[0][0]
+        tri = ms.merge_shard_runs([b.data_ptr() + 8] * 3, [b.data_ptr()] * 3, [ex.cap] * 3)
+        exp = np.concatenate([runs[0]] * 3)                      # match_list's post-step over the concatenation (src/matcher/mod.rs:215-221)
+        if sort.endswith("Desc"): exp = exp[::-1]
+        if sort.startswith("Score"): exp = exp[np.argsort(-exp["score"].astype(np.int64), kind="stable")]
+        assert tri.tolist() == exp.tolist(), (typos, sort, "three runs")
     runs2 = all_gather_matches(out, cnt[0])
     assert len(runs2) == 1 and runs2[0].tolist() == runs[0].tolist()
     small = ShardExchange(10, dev)   # a capacity below the match count is reported, never truncated silently
@@ -159,6 +171,11 @@ for typos in (0, 2):
         small.collect(0); raise SystemExit("truncation not reported")
     except RuntimeError as e:
         assert str(k) in str(e), e
+    m.match_list_device(cp, small.records_ptr(0), small.cap, small.count_ptr(0)); small.post(0)
+    try:
+        small.collect_merged(0, m); raise SystemExit("truncation not reported by the device merge")
+    except F.FrizbeeError as e:
+        assert e.code == 5 and "truncated" in str(e), e
 dist.barrier(); dist.destroy_process_group()
 print("RCCL-ONE-RANK-OK")
 ''' % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "tools": os.path.join(ROOT, "tools")}

@@ -92,5 +92,40 @@ for name, fn in (("pipeline_only", step_pipeline), ("pipeline_plus_event_record"
     res[name] = {"cpu_enqueue_us_per_step": round(enq, 1), "total_us_per_step": round(tot, 1)}
     ex.collect(0); ex.collect(1)
 print(json.dumps(res))
+
+# ---- the ORDERED step (bench.py's e2e_sorted_merge): where its time goes, phase by phase (host clock, a synchronisation after each phase) ----
+def phases(k=20):
+    acc = {"pipeline": 0.0, "post_gather": 0.0, "wait_gather": 0.0, "merge_sort_d2h": 0.0}
+    for i in range(k + 3):
+        torch.cuda.synchronize(dev); t0 = time.perf_counter()
+        m.match_list_device(corpus, ex.records_ptr(0), ex.cap, ex.count_ptr(0), stream=stream)
+        torch.cuda.synchronize(dev); t1 = time.perf_counter()
+        ex.post(0)
+        t2 = time.perf_counter()
+        ex.wait(0); torch.cuda.synchronize(dev); t3 = time.perf_counter()
+        r = ex.collect_merged(0, m, stream=stream)
+        t4 = time.perf_counter()
+        if i >= 3:
+            for key, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                acc[key] += v / k * 1e6
+    return {k_: round(v, 1) for k_, v in acc.items()}, len(r)
+
+ph, nrec = phases()
+def ordered(i):
+    m.match_list_device(corpus, ex.records_ptr(0), ex.cap, ex.count_ptr(0), stream=stream)
+    ex.post(0)
+    ex.collect_merged(0, m, stream=stream)
+for i in range(3): ordered(i)
+torch.cuda.synchronize(dev); t0 = time.perf_counter()
+for i in range(20): ordered(i)
+t_ord = (time.perf_counter() - t0) / 20 * 1e6
+def single(i):
+    return m.match_list(corpus, copy=False)
+torch.cuda.set_stream(torch.cuda.default_stream(dev))
+for i in range(3): single(i)
+t0 = time.perf_counter()
+for i in range(20): single(i)
+t_single = (time.perf_counter() - t0) / 20 * 1e6
+print(json.dumps({"ordered_step_us": round(t_ord, 1), "phases_us_with_a_sync_after_each": ph, "records": nrec, "single_gpu_match_list_us": round(t_single, 1)}))
 dist.barrier()
 dist.destroy_process_group()
