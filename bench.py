@@ -220,11 +220,14 @@ def sharded_block(F, needle, cfg, host_bytes, host_ends, unsharded_ms, unsharded
                    "matcher clone and stream; runs copied device to device into one list, ordered once, one D2H.  Ordered records on the host, per call",
            "unsharded_match_list_ms": unsharded_ms}
     want = unsharded_result.tobytes()
-    for mode in ("pull", "copy"):
-        # pull: the shards share the root device, ONE kernel concatenates the runs (no host round trip before the final list).
+    for mode in ("pull", "pull_workers", "copy"):
+        # pull: the shards share the root device - enqueued by the calling thread, ONE kernel concatenates the runs (no host round trip
+        #       before the final list); pull_workers: the same through the per-shard worker threads (what shards on other devices use).
         # copy: what shards on other devices take - count to the host, hipMemcpyPeerAsync to the run's place (forced on this one GPU)
         if mode == "copy":
             os.environ["FZB_SHARD_GATHER"] = "copy"
+        if mode == "pull_workers":
+            os.environ["FZB_SHARD_INLINE"] = "0"
         F.lib().fzb_debug_reload_knobs()
         try:
             for k in (1, 2, 8):
@@ -241,6 +244,7 @@ def sharded_block(F, needle, cfg, host_bytes, host_ends, unsharded_ms, unsharded
                 del m, sc, got
         finally:
             os.environ.pop("FZB_SHARD_GATHER", None)
+            os.environ.pop("FZB_SHARD_INLINE", None)
             F.lib().fzb_debug_reload_knobs()
     return out
 

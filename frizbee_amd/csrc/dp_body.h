@@ -10,6 +10,20 @@ __device__ __forceinline__ u32 p_add(u32 a, u32 b) { return as_u32(as_us2(a) + a
 __device__ __forceinline__ u32 p_sub(u32 a, u32 b) { return as_u32(as_us2(a) - as_us2(b)); }
 __device__ __forceinline__ u32 p_subs(u32 a, u32 b) { return as_u32(__builtin_elementwise_sub_sat(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ u32 p_max(u32 a, u32 b) { return as_u32(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
+// max(a, b, s) per 16-bit lane in ONE instruction, for values below 0x7C00 (a, b vectors; s wave-uniform): gfx950's v_pk_maximum3_f16.
+// Non-negative finite binary16 patterns order like the integers that spell them and the kernels run with f16 denormals preserved
+// (amdhsa_float_denorm_mode_16_64 = 3), so the instruction returns one of its inputs bit for bit - tools/ubench/max3_f16.hip checks it
+// against two v_pk_max_u16 on 2.9e8 packed triples (0 differences) and times it at 0.62 of the pair's cost.  Callers guarantee the bound
+// (LaunchCfg::cf_ok / cfm_ok: biased scores stay below 0x7C00).
+__device__ __forceinline__ u32 p_max3_s(u32 a, u32 b, u32 s) {
+#ifdef FZB_HOST_SHIM
+    return p_max(p_max(a, b), s);
+#else
+    u32 r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s));
+    return r;
+#endif
+}
 __device__ __forceinline__ u32 p_min(u32 a, u32 b) { return as_u32(__builtin_elementwise_min(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ u32 p_mul(u32 a, u32 b) { return as_u32(as_us2(a) * as_us2(b)); }
 __device__ __forceinline__ u32 splat16(u32 v) { return (v & 0xFFFF) * 0x00010001u; }

@@ -8,7 +8,7 @@
 //   * the needle has no NUL byte              -> a zero-padding lane never matches a needle row,
 //   * 2 * gap_extend <= mismatch_penalty       -> inside the padding a step down ("up" move) is never worse than a diagonal, and the
 //                                                 diagonal's constant x - 2e below is not negative,
-//   * the biased values fit 16 bits (bias_ok).
+//   * the biased values stay below 0x7C00 (cf_ok: the cell's three-way maximum is v_pk_maximum3_f16, exact on such values - p_max3_s).
 //
 // Notation: e = gap_extend, x = mismatch_penalty, o = gap_open - gap_extend, S(i, L) = the reference's row value after
 // propagate_horizontal_gaps (row -1 = the zero row), P = 2 * REAL = number of lanes that are computed ("real" lanes: the window's
@@ -186,7 +186,7 @@ __device__ __forceinline__ u32 cf_rows(const NeedleDev& nd, const u32 (&hw)[REAL
             cf_match<UPPER>(k, hw[d], bonus[d], casev, mm, mb);
             const u32 D = p_subs(p_add(sh, mb), xqv);
             const u32 U = p_subs(T[d], g[d]);
-            b[d] = p_max(p_max(D, U), bias);
+            b[d] = p_max3_s(D, U, bias);  // (all three below 0x7C00: cf_ok)
             gn[d] = p_mul(mm, gopmv);
         }
         cf_scan<SWL, REAL>(b, gn, e, (rows - 2 - r) * o, acc0, acc1);

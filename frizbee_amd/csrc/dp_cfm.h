@@ -10,7 +10,7 @@
 //     after every row's scan as in the first form;
 //   * row 0 needs no special case (T(-1, L) = (L + SWL) * e is the zero row);
 //   * the LAST row of the LAST chunk is not propagated (only its maximum is read; dp_cf.h, 2.).
-// Preconditions (host, LaunchCfg::cfm_ok): 2 * gap_extend <= mismatch_penalty, biased values (up to 192 lanes + 63 rows of e) fit 16 bits.
+// Preconditions (host, LaunchCfg::cfm_ok): 2 * gap_extend <= mismatch_penalty, biased values (up to 192 lanes + 63 rows of e) stay below 0x7C00 (p_max3_s).
 // tests/test_kernel_math_host.py fuzzes it against the oracle and against the first form.
 #pragma once
 #include "dp_cf.h"
@@ -91,7 +91,7 @@ __device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restr
                 cf_match<UPPER>(k, hw[d], bonus[d], casev, mm, mb);
                 const u32 D = p_subs(p_add(sh, mb), xqv);
                 const u32 U = p_subs(T[d], g[d]);
-                b[d] = p_max(p_max(D, U), bias);
+                b[d] = p_max3_s(D, U, bias);  // (all three below 0x7C00: cfm_ok)
                 gn[d] = p_mul(mm, gopmv);
                 if constexpr (!PAD)  // the top half's match flags for the next chunk (they are its gap-open charges): dword HT+t -> bits 2t', 16+2t' of word t/8
                     if (d >= HT) chg[(d - HT) / 8] |= mm << (2 * ((d - HT) % 8));

@@ -183,6 +183,8 @@ FzbKnobs parse_knobs() {
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
+    k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
+    k.shard_inline = num("FZB_SHARD_INLINE", -1);
     k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");
     k.small_list = getenv("FZB_SMALL_LIST") ? (uint32_t)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
     k.compact_grid_mul = std::max(1, num("FZB_COMPACT_GRID_MUL", 4));
@@ -542,9 +544,12 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
     // biased gap propagation needs max cell value + lanes*gex (+ headroom) to stay below 2^16
     lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
+    // dp_cf.h / dp_cfm.h: every biased value stays below 0x7C00, so that the cell's three-way maximum can be v_pk_maximum3_f16 (exact on
+    // non-negative finite binary16 patterns: dp_body.h, p_max3_s); scorings beyond that - needle rows worth thousands of points - take the first forms
     lc.cfm_ok = 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty &&
-                max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 200 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;  // dp_cfm.h: lanes up to 3/2 chunks + rows of bias
-    lc.cf_ok = lc.pad_ok && lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty;  // dp_cf.h preconditions
+                max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 200 * (size_t)sc.gap_extend_penalty + 64 < 0x7C00;  // lanes up to 3/2 chunks + rows of bias
+    lc.cf_ok = lc.pad_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty &&
+               max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 < 0x7C00;
     lc.cfu_ok = lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty && !fzb_knobs().no_dp_cfu;  // (knob: the unicode scorer's first form)
     *out = m;
     return FZB_OK;
@@ -1128,8 +1133,12 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
         // filter -> scorer handoff (ragged list with a view, the exact ASCII filter, classified scoring next): the view kernel stores the accepted
         // haystacks' vectors, which it holds in registers, into the stage; the classifier and the scorers read them there
+        // Only for lists that give every workgroup of the filter several tiles: on a small list (one round of tiles: the 1.4 M-item paths list)
+        // the tile's closing work - copy-out, header, three barriers - sits on the one chain of latencies the kernel consists of (filter 32 ->
+        // 44 us there, the scorers gain 8); FZB_HANDOFF_MIN_TILES overrides the threshold (0: always)
+        const u32 ntiles_f = (cnt + FZB_TILE - 1) / FZB_TILE;
         const bool want_stage = !kn.no_handoff && !trace && lc.filter_mode == 1 && lc.filter_exact && lc.window_mode == 1 && !nd.unicode && cd.vbytes && lc.cf_ok &&
-                                !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2);
+                                !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2) && ntiles_f >= (u32)kn.handoff_min_tiles;
         if (want_stage && (rc = ensure_stage(m, count))) return rc;  // first use only (or fzb_matcher_reserve)
         const StageOut so{want_stage ? w.stage : nullptr, want_stage ? w.stage_hdr : nullptr};
         if (pev) HIPCHK(hipEventRecord(pev[2], st));

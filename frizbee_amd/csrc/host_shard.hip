@@ -322,11 +322,6 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
             }
         }
     }
-    ShardWorkers* pool = (ShardWorkers*)m->shard_workers;
-    if (!pool || pool->size() < ns) {
-        delete pool;
-        m->shard_workers = pool = new ShardWorkers(ns);
-    }
     // How the runs reach the root.  PULL (every shard lives on the root device - one GPU holding several shards): the workers only enqueue
     // their pipelines; the root's stream waits for them and ONE kernel concatenates the runs, reading their lengths on the device - no
     // host round trip before the final list.  COPY (shards on other devices): each worker reads its count back (8 bytes) and copies its
@@ -339,7 +334,7 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
     std::vector<std::atomic<int64_t>> counts(ns);
     for (auto& c : counts) c.store(-1, std::memory_order_relaxed);
     std::vector<u8> copied(ns, 0);
-    rc = pool->run(ns, [&](size_t g) -> int {
+    auto shard_job = [&](size_t g) -> int {
         struct Publish {  // whatever happens, the workers above must not wait for this one
             std::atomic<int64_t>& slot;
             ~Publish() { if (slot.load(std::memory_order_relaxed) < 0) slot.store(0, std::memory_order_release); }
@@ -384,7 +379,25 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         HIPCHK(hipEventRecord(cm->shard_event, cm->shard_stream));
         copied[g] = 1;
         return FZB_OK;
-    });
+    };
+    // Shards that share the root device are enqueued by the CALLING thread, one after the other: launches from several host threads onto
+    // one device serialise inside the runtime anyway (measured with 8 shards on one GPU: 0.35 ms through the workers, see bench.py
+    // `sharded`), and nothing waits between them in the pull form.  Shards on other devices go through their workers.
+    const int inline_mode = fzb_knobs().shard_inline;  // -1 = decide here, 0 = always the workers, 1 = always the calling thread (pull form only)
+    if (pull && (inline_mode == 1 || inline_mode < 0)) {
+        rc = FZB_OK;
+        for (size_t g = 0; g < ns && !rc; g++) {
+            rc = shard_job(g);
+            if (rc) rc = fzb_fail(rc, "shard " + std::to_string(g) + ": " + fzb_last_error());
+        }
+    } else {
+        ShardWorkers* pool = (ShardWorkers*)m->shard_workers;
+        if (!pool || pool->size() < ns) {
+            delete pool;
+            m->shard_workers = pool = new ShardWorkers(ns);
+        }
+        rc = pool->run(ns, shard_job);
+    }
     (void)hipSetDevice(root);
     if (rc) {  // let the copies that were started finish before anything else touches the buffers
         for (size_t g = 0; g < ns; g++)

@@ -54,6 +54,8 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),                      # four scorer launches on two streams
     ({"FZB_SMALL_LIST": "0", "FZB_NO_OVERLAP": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_NO_HANDOFF": "1"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),
+    ({"FZB_HANDOFF_MIN_TILES": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "DeadBeef", dict())]),  # the handoff on a small list (default: big lists only)
+    ({"FZB_HANDOFF_MIN_TILES": "0", "FZB_VIEW_PLAIN_LOADS": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_NO_CDFA": "1"}, [("ragged", "deadbeef", dict())]),                         # the burst filter over the byte automaton
     ({"FZB_NO_CDFA": "1", "FZB_RAGGED_BURST": "0"}, [("ragged", "deadbeef", dict())]),  # ... and its rolling form
     ({"FZB_DEBUG_SYNC": "1"}, [("short", "deadbe", dict())]),

@@ -20,16 +20,20 @@ pytestmark = pytest.mark.gpu
 SORTS = ("ScoreThenIndexAsc", "ScoreThenIndexDesc", "IndexAsc", "IndexDesc")
 
 
-@pytest.fixture(params=["pull", "copy"])
+@pytest.fixture(params=["pull", "pull_workers", "copy"])
 def gather_mode(request):
     """How the runs reach the root: one concatenation kernel that pulls them (every shard on the root device - the only arrangement
-    one GPU offers) or the form shards on OTHER devices take - count to the host, hipMemcpyPeerAsync to the run's place - forced here
-    with FZB_SHARD_GATHER=copy so that one GPU exercises it too."""
+    one GPU offers; the shards enqueued by the calling thread, or - pull_workers - by the per-shard worker threads that shards on other
+    devices use) or the form shards on OTHER devices take - count to the host, hipMemcpyPeerAsync to the run's place - forced here with
+    FZB_SHARD_GATHER=copy so that one GPU exercises it too."""
     if request.param == "copy":
         os.environ["FZB_SHARD_GATHER"] = "copy"
+    if request.param == "pull_workers":
+        os.environ["FZB_SHARD_INLINE"] = "0"
     F.lib().fzb_debug_reload_knobs()
     yield request.param
     os.environ.pop("FZB_SHARD_GATHER", None)
+    os.environ.pop("FZB_SHARD_INLINE", None)
     F.lib().fzb_debug_reload_knobs()
 
 
