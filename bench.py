@@ -318,6 +318,21 @@ def other_configs(F, synth, dev, steps):
     res[name]["match_list_ms_median"] = _median(tq) * 1e3  # what a caller sees: pipeline + device sort + D2H of the ordered records
     res[name]["reference_published_ms"] = {"sequential": 22.36, "parallel_x8": 3.48, "where": "BENCHMARKS.md:62-65, Ryzen 9950X3D, the real Chromium list"}
     del cp, dp, ep, mq, rq
+    # a LONG needle (beyond the 64 bytes / 63 rows the by-value kernels take): the lane-exact prefilter as first stage,
+    # the wave-per-haystack scorer as the only scorer, per-wave slabs in global memory.  Correct for every accepted length
+    # (tests/test_gpu_long_needles.py); this row puts a number on "nothing here is tuned"
+    nl = 1_000_000
+    long_needle = bytes((b"abcdefghijklmnopqrstuvwxyz0123456789_-" * 3)[:80])
+    gl = torch.Generator(device=dev)
+    gl.manual_seed(99)
+    lens_l = torch.randint(100, 201, (nl,), generator=gl, device=dev)
+    rows_l = synth.make_rows(long_needle, nl, 200, lengths=lens_l, seed=4242, device=dev, chunk=1 << 18)
+    mask_l = torch.arange(200, device=dev)[None, :] < lens_l[:, None]
+    dl, el = rows_l[mask_l].cpu().numpy(), np.cumsum(lens_l.cpu().numpy().astype(np.uint64), dtype=np.uint64)
+    del rows_l, mask_l
+    cp = F.Corpus(packed=(dl, el))
+    run("long needle: 80 bytes vs 1M haystacks of 100..200 B (5% contain it), max_typos=0", long_needle.decode(), F.Config(max_typos=0, pf_lanes=64, sw_lanes=32), cp, nl, int(el[-1]), steps=3)
+    del cp, dl, el
     n5, reps = 2_000_000, 5
     d5, _ = synth.utf8_corpus(n5, HAY_LEN)
     d5 = np.tile(d5, reps)

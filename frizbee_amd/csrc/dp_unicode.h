@@ -253,6 +253,245 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
+// Windows WIDER than one chunk (SWL < m <= 1024 bytes), still one thread per haystack (round 4; until then every such window took a whole
+// wavefront in kernels_generic.hip - 45 k of them under "All Scores" on the Arabic-shaped list: 209 of the step's 305 us).
+// The reference walks the window chunk by chunk (score_haystack_unicode, unicode.rs:10-217): per needle row it keeps the previous chunk's
+// propagated row (score_matrix) and pending mask (unicode_pending), and its gap scan shifts those in from the left together with the
+// previous chunk's continuation-byte costs and scalar-start mask (propagate_horizontal_unicode_gaps, unicode_gap.rs:110-236); the largest
+// shift is half a chunk, so only the TOP HALF of the previous chunk is ever read.  Here, per chunk:
+//   * the prefix counts of the first form run over [adjacent half | this chunk]: Q = #scalar starts, P = gex * #non-continuation lanes,
+//     both counted from the adjacent half's first lane (QA / Q, PA / P) - the windowed quantities of a step are their differences whether
+//     or not the window crosses the chunk boundary; the adjacent half's counts are recomputed from its bytes (no state to carry);
+//   * per needle row the previous chunk's top half comes back from the scratch slab ([row][dword][thread], as dp_body.h's dp_multi_chunk
+//     parks them: values unbiased - bytes in the u8 class - and the pending mask as bits), is biased with PA and serves the low source
+//     lanes of every step; its last lane is the next row's diagonal into lane 0;
+//   * the last needle row is neither propagated nor parked in ANY chunk: what its scan would produce - here or, through the adjacent
+//     half, in the next chunk's last row - is some unpropagated last-row value minus costs, and only the maximum over the last rows is read.
+// First-form arithmetic (the bias is added before a row's scan and removed after it); preconditions as dp_unicode_single_chunk
+// (LaunchCfg::bias_ok).  tests/test_kernel_math_host.py fuzzes it against the oracle at every lane width.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int SWL>
+__device__ __forceinline__ u32 dp_unicode_multi_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls,
+                                                      u32* __restrict__ scratch, u32 sstride, u32 sidx) {
+    constexpr int NW = SWL / 2;        // score dwords of a chunk
+    constexpr int NB = SWL / 4;        // byte dwords of a chunk
+    constexpr int HT = NW / 2;         // score dwords of the adjacent half
+    constexpr int NCHG = (HT + 7) / 8; // parked words of pending bits (two lanes of a dword 16 bits apart, as dp_cfm.h's gap-open flags)
+    static_assert(HT >= 1 && HT + NCHG <= NW, "a parked row must fit its NW dwords of the slab");
+    const u32 rows = (u32)nd.rows;
+    const u32 ONE = 0x00010001u;
+    const u32 Mv = splat16(nd.match_plus_mismatch), Xv = splat16(nd.mismatch), gexv = splat16(nd.gex), gopmv = splat16(nd.gopm);
+    const u32 casev = splat16(nd.matching_case), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+    const bool u8class = nd.lane_mask == 0xFF;
+    const u32 nchunks = (m + SWL - 1) / SWL;
+    const u32 mv = splat16(m);
+    u32 mx = 0;
+    u32 clsw_prev = 0;  // byte classes of the lane before the current one: carried across chunks (unicode.rs: prev_chunk_*_mask)
+#pragma unroll 1
+    for (u32 ch = 0; ch < nchunks; ch++) {
+        const u32 cbase = ch * SWL;
+        // ---- bytes of the chunk (+ the next chunk's first dword for the shifted views: the reference loads its four byte views at
+        // chunk_start + 0..3 up to the haystack's end) ----
+        u32 hb[NB + 1];
+#pragma unroll
+        for (int k = 0; k <= NB; k++) {
+            const u32 p = cbase + 4 * k;
+            u32 v = 0;
+            if (p < m) {
+                v = load_u32_unaligned(th, p);
+                const u32 rem = m - p;
+                if (rem < 4) v &= (1u << (8 * rem)) - 1;
+            }
+            hb[k] = v;
+        }
+        // ---- scalar-start prefix counts: the adjacent half (every lane valid), then this chunk; bonuses ----
+        u32 QA[HT], Q[NW], bonus[NW];
+        u32 qrun = 0;
+        if (ch) {
+#pragma unroll
+            for (int k = 0; k < NB / 2; k++) {
+                const u32 w = load_u32_unaligned(th, cbase - SWL / 2 + 4 * k);
+                const u32 t = (0x80808080u & ~zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u)) >> 7;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const u32 s0 = h ? (t >> 16) & 1 : t & 1, s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
+                    const u32 q0 = qrun + s0, q1 = q0 + s1;
+                    QA[2 * k + h] = q0 | (q1 << 16);
+                    qrun = q1;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < HT; t++) QA[t] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const u32 w = hb[k];
+            const u32 contf = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u);
+            const u32 p = cbase + 4 * k;
+            const u32 nv = m > p ? min(m - p, 4u) : 0u;
+            const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
+            const u32 t = (validf & ~contf) >> 7;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int d = 2 * k + h;
+                const u32 b0 = h ? (w >> 16) & 0xFF : w & 0xFF;
+                const u32 b1 = h ? w >> 24 : (w >> 8) & 0xFF;
+                const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
+                const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);
+                const u32 cap01 = (clsw >> 1) & sh & ONE;
+                const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;
+                bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+                clsw_prev = clsw;
+                const u32 s0 = h ? (t >> 16) & 1 : t & 1, s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
+                const u32 q0 = qrun + s0, q1 = q0 + s1;
+                Q[d] = q0 | (q1 << 16);
+                qrun = q1;
+            }
+        }
+        if (ch == 0 && include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
+        // P = gex * (Q + #padding lanes up to and including the lane): lanes at or past m are non-continuation lanes that start no scalar
+        auto Pof = [&](int d) {
+            const u32 lanepos1 = (cbase + (u32)(2 * d + 1)) | ((cbase + (u32)(2 * d + 2)) << 16);
+            return p_mul(p_add(Q[d], p_subs(lanepos1, mv)), gexv);
+        };
+        u32 prev[NW], upm[NW];
+#pragma unroll
+        for (int d = 0; d < NW; d++) prev[d] = 0, upm[d] = 0;
+        u32 carry = 0;  // the previous chunk's last lane of the row above (the diagonal into lane 0); row -1 is the zero row
+#pragma unroll 1
+        for (u32 r = 0; r < rows; r++) {
+            const u32 cl = nd.ulen[r];
+            const u8* uc = nd.uc[r];
+            const u8* uf = nd.uf[r];
+            const bool two = (uc[0] != uf[0]) || (uc[1] != uf[1]) || (uc[2] != uf[2]) || (uc[3] != uf[3]);
+#pragma unroll
+            for (int d = 0; d < NW; d++) FZB_OPAQUE_V(Q[d]);  // (see dp_unicode_single_chunk: keeps what derives from Q / hb out of the loop-invariant set)
+#pragma unroll
+            for (int k = 0; k <= NB; k++) FZB_OPAQUE_V(hb[k]);
+            u32 row[NW], pend[NW];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+                const u32 w0 = hb[k];
+                const u32 w1 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 1);
+                const u32 w2 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 2);
+                const u32 w3 = __builtin_amdgcn_alignbyte(hb[k + 1], hb[k], 3);
+                const u32 wl = cl == 1 ? w0 : cl == 2 ? w1 : cl == 3 ? w2 : w3;
+                u32 fe = zflag4(wl ^ (uc[cl - 1] * 0x01010101u));
+                if (cl > 1) fe &= zflag4(w0 ^ (uc[0] * 0x01010101u));
+                if (cl > 2) fe &= zflag4(w1 ^ (uc[1] * 0x01010101u));
+                if (cl > 3) fe &= zflag4(w2 ^ (uc[2] * 0x01010101u));
+                u32 fm = fe;
+                if (two) {
+                    u32 ff = zflag4(wl ^ (uf[cl - 1] * 0x01010101u));
+                    if (cl > 1) ff &= zflag4(w0 ^ (uf[0] * 0x01010101u));
+                    if (cl > 2) ff &= zflag4(w1 ^ (uf[1] * 0x01010101u));
+                    if (cl > 3) ff &= zflag4(w2 ^ (uf[2] * 0x01010101u));
+                    fm |= ff;
+                }
+                const u32 te = fe >> 7, tm = fm >> 7;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int d = 2 * k + h;
+                    const u32 sel = h ? 0x0c030c02u : 0x0c010c00u;
+                    const u32 e01 = __builtin_amdgcn_perm(0u, te, sel) & ONE;
+                    const u32 m01 = __builtin_amdgcn_perm(0u, tm, sel) & ONE;
+                    const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : QA[HT - 1], 16);
+                    const u32 sst = p_neg_mask(p_sub(qs, Q[d]));  // scalar-start lanes (the count grows there)
+                    const u32 exm = p_sub(0u, e01) & sst, mmk = p_sub(0u, m01) & sst;
+                    const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : (carry << 16), 16);
+                    u32 t = p_add(sh, mmk & bonus[d]);
+                    t = p_subs(t, Xv);
+                    const u32 diag = p_add(t, exm & casev);
+                    const u32 up = p_subs(p_subs(prev[d], gexv), upm[d] & gopmv);
+                    row[d] = p_max(diag, up) & sst;
+                    pend[d] = mmk;
+                    upm[d] = mmk;
+                }
+            }
+            if (r + 1 == rows) {  // the last row: only its maximum is read, in every chunk
+#pragma unroll
+                for (int d = 0; d < NW; d++) mx = p_max(mx, row[d]);
+                break;
+            }
+            // ---- the previous chunk's top half of this row: biased values, pending masks; its last lane feeds the next row's diagonal ----
+            u32 ca[HT], apend[HT];
+            u32* srow = scratch + (size_t)(r * NW) * sstride + sidx;
+            u32 carry_next = 0;
+            if (ch) {
+                u32 arow[HT];
+                if (u8class) {
+#pragma unroll
+                    for (int t = 0; t < HT / 2; t++) {
+                        const u32 pk = srow[(size_t)t * sstride];
+                        arow[2 * t] = __builtin_amdgcn_perm(0u, pk, 0x0c010c00u);
+                        arow[2 * t + 1] = __builtin_amdgcn_perm(0u, pk, 0x0c030c02u);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HT; t++) arow[t] = srow[(size_t)t * sstride];
+                }
+                u32 pch[NCHG];
+#pragma unroll
+                for (int a = 0; a < NCHG; a++) pch[a] = srow[(size_t)(HT + a) * sstride];
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    ca[t] = p_add(arow[t], p_mul(QA[t], gexv));
+                    apend[t] = p_sub(0u, (pch[t / 8] >> (2 * (t % 8))) & ONE);
+                }
+                carry_next = arow[HT - 1] >> 16;
+            } else {
+#pragma unroll
+                for (int t = 0; t < HT; t++) ca[t] = 0u, apend[t] = 0u;
+            }
+            // ---- propagate_horizontal_unicode_gaps in the biased domain over [adjacent half | chunk] ----
+#pragma unroll
+            for (int d = 0; d < NW; d++) row[d] = p_add(row[d], Pof(d));
+#pragma unroll
+            for (int d = NW - 1; d >= 0; d--) {  // shift by one lane; in place from the top: entry d reads entries <= d, still unchanged
+                const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : ca[HT - 1], 16);
+                const u32 ps = __builtin_amdgcn_alignbit(pend[d], d ? pend[d - 1] : apend[HT - 1], 16);
+                const u32 qs = __builtin_amdgcn_alignbit(Q[d], d ? Q[d - 1] : QA[HT - 1], 16);
+                const u32 fl = p_neg_mask(p_sub(qs, Q[d]));  // a scalar start lies in (L-1, L]
+                row[d] = p_max(row[d], p_subs(bs, ps & fl & gopmv));
+                pend[d] = pend[d] | (ps & ~fl);
+            }
+#pragma unroll
+            for (int off = 1; off < NW; off *= 2) {  // shifts of 2, 4, ..., SWL/2 lanes
+#pragma unroll
+                for (int d = NW - 1; d >= 0; d--) {
+                    const bool adj = d < off;
+                    const int si = adj ? HT + d - off : d - off;
+                    const u32 rs = adj ? ca[si] : row[si], psrc = adj ? apend[si] : pend[si], qsrc = adj ? QA[si] : Q[si];
+                    const u32 fl = p_neg_mask(p_sub(qsrc, Q[d]));
+                    row[d] = p_max(row[d], p_subs(rs, psrc & fl & gopmv));
+                    pend[d] = pend[d] | (psrc & ~fl);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NW; d++) prev[d] = p_sub(row[d], Pof(d));
+            // ---- park the top half for the next chunk ----
+            if (ch + 1 < nchunks) {
+                if (u8class) {
+#pragma unroll
+                    for (int t = 0; t < HT / 2; t++) srow[(size_t)t * sstride] = __builtin_amdgcn_perm(prev[HT + 2 * t + 1], prev[HT + 2 * t], 0x06040200u);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HT; t++) srow[(size_t)t * sstride] = prev[HT + t];
+                }
+                u32 chg[NCHG] = {};
+#pragma unroll
+                for (int t = 0; t < HT; t++) chg[t / 8] |= (pend[HT + t] & ONE) << (2 * (t % 8));
+#pragma unroll
+                for (int a = 0; a < NCHG; a++) srow[(size_t)(HT + a) * sstride] = chg[a];
+            }
+            carry = carry_next;
+        }
+    }
+    return max(mx & 0xFFFF, mx >> 16);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
 // The same scorer in dp_cf.h's manner (round 3): BIASED THROUGHOUT.  T(i, L) = S(i, L) + P[L] + (i + 1) * e, with P as above (e per
 // non-continuation lane up to and including L) and one gap-extend per row, is what the registers hold from the first row to the last:
 //   * up:    S(i-1, L) (-) e (-) g   becomes   T(i-1, L) (-) g            (the row bias pays the e; g = gop' where the cell above matched)

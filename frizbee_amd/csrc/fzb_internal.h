@@ -225,7 +225,10 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
 // kernels_unicode.hip
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
-                           int grid, hipStream_t st, int tform = 0);
+                           int grid, hipStream_t st, int tform = 0, int multi_front = 0);
+// windows of sw_lanes < m <= 1024 bytes queued by fzb_launch_dp_unicode (front of `overflow`, count in counters[3]); `scratch` as the ASCII multi-chunk scorer's
+void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes,
+                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from = 0);  // runs only when *n_list_ptr >= only_from
 // kernels_sort.hip
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st, int passes = 2);
 void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, u32* cut_flag, hipStream_t st);
@@ -243,7 +246,8 @@ void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, c
                               u32 capacity, u32* dev_count, u32* tpos, u32* tnpos, u32 tstride, int grid, hipStream_t st);
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
-                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st);
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st,
+                        int list_forward = 0, u32 only_below = 0);  // list_forward: entry q at list + 4 q; only_below: run only while *n_list_ptr < only_below
 size_t fzb_trace_scratch_words(const NeedleDev& nd, int grid);
 // long needles (NeedleLongDev): kernels_window.hip / kernels_generic.hip / kernels_literal.hip
 size_t fzb_window_long_scratch_bytes(const NeedleLongDev& nd, int grid);

@@ -183,6 +183,8 @@ FzbKnobs parse_knobs() {
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
+    k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
+    k.generic_wgs = std::max(1, num("FZB_GENERIC_WGS", 12));
     k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
     k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");
@@ -1187,11 +1189,25 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
                                  trace->npos, trace->stride, tgrid, st);
         FZB_STAGE("generic(trace)");
     } else if (nd.unicode && lc.bias_ok) {
-        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st, lc.cfu_ok);
+        // Windows wider than a chunk: up to 1024 bytes into the FRONT of the queue, beyond that (greedy fallback) into its back.  The front
+        // has two takers, chosen on the device by its length: the thread-per-haystack multi-chunk scorer (k2u_dp_unicode_multi: ~ 8x fewer
+        // instructions, but one wave per SIMD and ~ 20 us per chunk - a fixed ~ 150 us, then 0.5 ns per window) from `umin` windows on, the
+        // wave-per-haystack kernel (1.6 - 2.7 ns per window, no fixed cost) below.  Measured: 45 k windows (Arabic-shaped list, All Scores)
+        // 0.213 vs 0.239 ms, 361 k windows 1.285 vs 0.907 ms (tools/exp_unicode_wide.py).  FZB_UNICODE_MULTI=0 / 1: never / always.
+        const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : (u32)cus * 512u;
+        const int ugrid = cus * 2;  // multi-chunk unicode scorer: one wave per SIMD (two-wave workgroups)
+        if (umin != 0xFFFFFFFFu && (rc = ensure_dp_scratch(m, ugrid))) return rc;  // first use only (or fzb_matcher_reserve)
+        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st, lc.cfu_ok, 1);
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
-            fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * 2, st);
-            FZB_STAGE("generic(unicode, queued)");
+            if (umin != 0xFFFFFFFFu) fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, st, umin);
+            // (the wave-per-haystack kernel's LDS follows the needle's rows: for short needles its registers decide how many workgroups a CU holds)
+            if (umin != 0u) fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, st, 1, umin);
+            FZB_STAGE("dp(unicode, wide windows)");
+            if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {
+                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus / 4 + 1, st);
+                FZB_STAGE("generic(unicode, greedy)");
+            }
         }
     } else if (nd.unicode) {
         fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, cnt_c, cus * 4, st);
@@ -1277,6 +1293,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     if (rc) return rc;
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
     if (!m->long_needle && !m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
+    if (!m->long_needle && !m->literal_mode && m->nd.unicode && m->lc.bias_ok && !no_wide && fzb_knobs().unicode_multi != 0 && (rc = ensure_dp_scratch(m, m->lc.num_cus * 2))) return rc;
     if (c->dev.vbytes && !m->literal_mode && !m->long_needle && !m->nd.unicode && m->lc.filter_mode == 1 && m->lc.cf_ok && (rc = ensure_stage(m, n))) return rc;
     if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;

@@ -99,6 +99,12 @@ struct TraceArgs {
     u32* npos;    // per output record: how many
     u32 stride;
 };
+// list mode only: run over the list iff lo <= *count < hi (nullptr: always) and read it forwards (entry q at list + 4 q) instead of downwards
+struct GateArgs {
+    const u32* count;
+    u32 lo, hi;
+    int forward;
+};
 #define TRACE_W (FZB_MAX_HAYSTACK_LEN + 2 * 64)  // columns: the zero chunk + up to 1024 bytes rounded up to a chunk
 
 template <int SWL, bool UNICODE, bool TRACE, typename ET, typename ND = NeedleDev>
@@ -106,16 +112,22 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                                                               const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
                                                               const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const ND nd,
                                                               fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters,
-                                                              const TraceArgs trace, u16* __restrict__ long_adj) {
+                                                              const TraceArgs trace, u16* __restrict__ long_adj, const GateArgs gate) {
+    if (gate.count) {  // (uniform) this launch serves the list only when its length is in [lo, hi): another kernel takes it otherwise
+        const u32 gn = *gate.count;
+        if (gn < gate.lo || gn >= gate.hi) return;
+    }
     // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row - in LDS for needles
     // that fit NeedleDev, in the wave's slab of `long_adj` ((rows + 1) x SWL x 2 entries) for long ones
+    // (the LDS form is sized by the needle's actual rows - dynamic shared memory, fzb_generic_lds_bytes: sized for the 63 rows the
+    // by-value needle can have it was 64 KB per workgroup, two workgroups = eight waves per CU whatever the needle; a two-row needle
+    // needs 3 KB and the kernel's registers decide the occupancy)
     constexpr bool LONG = ND::kLong;
-    __shared__ u16 s_adj_row[LONG ? 1 : GEN_WAVES][LONG ? 1 : FZB_MAX_ROWS + 1][SWL];
-    __shared__ u16 s_adj_aux[LONG ? 1 : GEN_WAVES][LONG ? 1 : FZB_MAX_ROWS + 1][SWL];
+    extern __shared__ __attribute__((aligned(16))) u16 s_adj[];
     const int lane = lane_id();
     const int wv = threadIdx.x >> 6;
-    u16* const adj_row_base = LONG ? long_adj + (size_t)(blockIdx.x * GEN_WAVES + wv) * 2 * (size_t)(nd.rows + 1) * SWL : &s_adj_row[LONG ? 0 : wv][0][0];
-    u16* const adj_aux_base = LONG ? adj_row_base + (size_t)(nd.rows + 1) * SWL : &s_adj_aux[LONG ? 0 : wv][0][0];
+    u16* const adj_row_base = LONG ? long_adj + (size_t)(blockIdx.x * GEN_WAVES + wv) * 2 * (size_t)(nd.rows + 1) * SWL : s_adj + (size_t)wv * 2 * (size_t)(nd.rows + 1) * SWL;
+    u16* const adj_aux_base = adj_row_base + (size_t)(nd.rows + 1) * SWL;
     const u32 nlist = *n_list_ptr;
     if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = nlist < capacity ? nlist : capacity; dev_count[1] = nlist; }
     const u32 LM = (u32)nd.lane_mask;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
     for (u32 q = blockIdx.x * GEN_WAVES + wv; q < nlist; q += gridDim.x * GEN_WAVES) {
         // list entries: (output position, window start, window end, local haystack index) queued by the single-chunk kernel
         // list mode: the queue grows downwards from `list` (the end of the chunk's queue slice): entry q is at list - 4 (q + 1)
-        const u32* le = list ? list - 4 * (size_t)(q + 1) : nullptr;
+        const u32* le = list ? (gate.forward ? list + 4 * (size_t)q : list - 4 * (size_t)(q + 1)) : nullptr;
         const u32 j = list ? le[0] : q;          // rank inside this chunk (direct mode) / absolute output position (list mode)
         const u32 opos = j;
         if (opos >= capacity) continue;
@@ -393,10 +405,16 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
     }
 }
 
+// dynamic LDS of the by-value-needle form: per wave two vectors (row, match / pending mask) of sw_lanes u16 per needle row (+ the zero row)
+static size_t generic_lds_bytes(const NeedleDev& nd, int sw_lanes) { return (size_t)GEN_WAVES * 2 * (size_t)(nd.rows + 1) * (size_t)sw_lanes * sizeof(u16); }
+
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
-                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st) {
+                        const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st,
+                        int list_forward, u32 only_below) {
     const TraceArgs none{nullptr, nullptr, nullptr, 0};
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none, (u16*)nullptr)
+    const GateArgs gate{only_below ? n_list_ptr : nullptr, 0u, only_below, list_forward};
+    const size_t lds = generic_lds_bytes(nd, sw_lanes);
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false, ET>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none, (u16*)nullptr, gate)
 #define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
 #define FZB_K2C_U(SWL) do { if (unicode) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
     switch (sw_lanes) {
@@ -416,7 +434,8 @@ void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, c
                               int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u32* cells, u32* pos, u32* npos, u32 stride,
                               int grid, hipStream_t st) {
     const TraceArgs tr{cells, pos, npos, stride};
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, (u16*)nullptr)
+    const size_t lds = generic_lds_bytes(nd, sw_lanes);
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, (u16*)nullptr, GateArgs{nullptr, 0u, 0u, 0})
     switch (sw_lanes) {
         case 64: FZB_K2C_U(64); break;
         case 32: FZB_K2C_U(32); break;
@@ -436,7 +455,7 @@ void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, co
                              hipStream_t st) {
     const TraceArgs tr{(u32*)cells, pos, npos, stride};
     const bool trace = cells != nullptr;
-#define FZB_K2C_L(SWL, U, T, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj)
+#define FZB_K2C_L(SWL, U, T, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 0})
 #define FZB_K2C_L_ET(SWL, U, T) do { if (c.ends_u64) FZB_K2C_L(SWL, U, T, u64); else FZB_K2C_L(SWL, U, T, u32); } while (0)
 #define FZB_K2C_L_T(SWL, U) do { if (trace) FZB_K2C_L_ET(SWL, U, true); else FZB_K2C_L_ET(SWL, U, false); } while (0)
 #define FZB_K2C_L_U(SWL) do { if (nd.unicode) FZB_K2C_L_T(SWL, true); else FZB_K2C_L_T(SWL, false); } while (0)

@@ -1,6 +1,7 @@
-// gfx950 kernels, stage 2b (unicode): thread-per-haystack single-chunk unicode Smith-Waterman (dp_unicode.h) over the
-// survivors of the lane-exact unicode prefilter.  Windows wider than one chunk (or > 1024 bytes) are queued for the
-// generic wave-per-haystack kernel (kernels_generic.hip), exactly like the ASCII single-chunk kernel does.
+// gfx950 kernels, stage 2b (unicode): thread-per-haystack unicode Smith-Waterman (dp_unicode.h) over the survivors of the unicode
+// prefilter.  Windows wider than one chunk are queued: up to 1024 bytes from the FRONT of the queue for k2u_dp_unicode_multi (thread per
+// haystack, chunk by chunk; round 4), beyond that from the back for the generic wave-per-haystack kernel (kernels_generic.hip: the greedy
+// fallback), exactly like the ASCII kernels do.
 #include "dp_unicode.h"
 #include <cstdlib>
 
@@ -9,7 +10,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
                                                       const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                       const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity,
                                                       u32* __restrict__ dev_count, u32* __restrict__ overflow, u32 qcap,
-                                                      u32* __restrict__ counters, u32 ulen) {
+                                                      u32* __restrict__ counters, u32 ulen, u32 multi_front) {
     __shared__ u8 cls[256];
     build_cls_table(cls);
     __syncthreads();
@@ -71,8 +72,13 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             const bool include_exact = sp == 0 && we == L;
             const u32 m = we - sp;
             if (m > (u32)SWL) {
-                const u32 slot = atomicAdd(&counters[4], 1u);
-                u32* qe = overflow + 4 * (size_t)(qcap - 1 - slot);  // back of the queue slice: consumed by the generic kernel
+                // multi-chunk windows from the front (counters[3]: k2u_dp_unicode_multi), > 1024 bytes from the back (counters[4]: generic, greedy)
+                const bool greedy = !multi_front || m > FZB_MAX_HAYSTACK_LEN;  // (multi_front == 0: every wide window to the generic kernel)
+                // (two atomics with a uniform address each: the compiler turns those into one per wave; with the counter chosen per lane the
+                // 45 k wide windows of the Arabic-shaped list cost 0.35 ms of serialised returning atomics)
+                u32* qe;
+                if (greedy) { const u32 slot = atomicAdd(&counters[4], 1u); qe = overflow + 4 * (size_t)(qcap - 1 - slot); }
+                else { const u32 slot = atomicAdd(&counters[3], 1u); qe = overflow + 4 * (size_t)slot; }
                 qe[0] = (u32)j;
                 qe[1] = ws;
                 qe[2] = we;
@@ -125,8 +131,8 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
 
 #define FZB_K2U_PARAMS const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win, \
     const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ overflow, \
-    u32 qcap, u32* __restrict__ counters, u32 ulen
-#define FZB_K2U_ARGS bytes, ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, ulen
+    u32 qcap, u32* __restrict__ counters, u32 ulen, u32 multi_front
+#define FZB_K2U_ARGS bytes, ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, ulen, multi_front
 template <int SWL, bool TF, typename ET>
 __global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, TF, ET>(FZB_K2U_ARGS); }
 // every haystack of the list fits the low half of a chunk (host-known: corpus max_len <= SWL / 2): the general form is compiled out,
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(128, 2) void k2u_dp_unicode_half_w2(FZB_K2U_PARAMS)
 
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
-                           int grid, hipStream_t st, int tform) {
+                           int grid, hipStream_t st, int tform, int multi_front) {
     // `grid` = number of CUs: the kernel is persistent, launch exactly the resident workgroups
     const bool half_only = sw_lanes >= 16 && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2;
     // the biased-throughout form wants ~250 registers: at two waves per SIMD it runs without spills (C5: 0.152 ms; capped at 168 registers /
@@ -152,13 +158,13 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
         if (half_only && w2) {                                                                                                         \
             static int per_cu_w2 = 0;                                                                                                  \
             if (!per_cu_w2 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w2, k2u_dp_unicode_half_w2<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_w2 < 1)) per_cu_w2 = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half_w2<SWL, TF, ET>), dim3(grid * per_cu_w2), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
+            hipLaunchKernelGGL((k2u_dp_unicode_half_w2<SWL, TF, ET>), dim3(grid * per_cu_w2), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
         } else if (half_only) {                                                                                                        \
             if (!per_cu_half && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_half, k2u_dp_unicode_half<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_half < 1)) per_cu_half = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, TF, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
+            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, TF, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
         } else {                                                                                                                       \
             if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
-            hipLaunchKernelGGL((k2u_dp_unicode<SWL, TF, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len); \
+            hipLaunchKernelGGL((k2u_dp_unicode<SWL, TF, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
         }                                                                                                                              \
     } while (0)
 #define FZB_K2U_TF(SWL, ET) do { if (tform) FZB_K2U(SWL, true, ET); else FZB_K2U(SWL, false, ET); } while (0)
@@ -169,4 +175,55 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
         case 16: FZB_K2U_ET(16); break;
         default: FZB_K2U_ET(8); break;
     }
+}
+
+// ---- windows of SWL < m <= 1024 bytes: one thread per queued window, chunk by chunk (dp_unicode_multi_chunk) -------------------------------
+// The function keeps a chunk's row, previous row, pending and up masks, prefix counts and bonuses in registers (~ 300 live values at 64
+// lanes): one wave per SIMD, the accumulation registers as spill space - still 64 haystacks per wavefront where the generic kernel takes one.
+template <int SWL, typename ET>
+__global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ list,
+                                                            const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
+                                                            u32* __restrict__ scratch, u32 only_from) {
+    const u32 nlist = *n_list_ptr;
+    if (nlist < only_from) return;  // a short queue is the wave-per-haystack kernel's (launched behind this one with the complementary test)
+    __shared__ u8 cls[256];
+    build_cls_table(cls);
+    __syncthreads();
+    const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u32 q = gtid; q < nlist; q += nthreads) {
+        const u32 opos = list[4 * q], ws = list[4 * q + 1], we = list[4 * q + 2], li = list[4 * q + 3];
+        if (opos >= capacity) continue;
+        u64 s;
+        u32 L;
+        haystack_span(ends, first + li, s, L);
+        const u8* hay = bytes + s;
+        const u32 sp = ws ? ws - 1 : 0;
+        const bool include_exact = sp == 0 && we == L;
+        const u32 m = we - sp;
+        u32 score = nd.rows > 0 ? dp_unicode_multi_chunk<SWL>(nd, hay + sp, m, sp == 0, cls, scratch, nthreads, gtid) : 0u;
+        bool exact = include_exact && m == (u32)nd.nbytes;
+        if (exact)
+            for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+        if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+        fzb_match_rec rec;
+        rec.index = index_offset + li;
+        rec.score = (u16)score;
+        rec.exact = exact ? 1 : 0;
+        rec.valid = 0;
+        out[opos] = rec;
+    }
+}
+
+void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes,
+                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from) {
+#define FZB_K2UM(SWL, ET) hipLaunchKernelGGL((k2u_dp_unicode_multi<SWL, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, only_from)
+#define FZB_K2UM_ET(SWL) do { if (c.ends_u64) FZB_K2UM(SWL, u64); else FZB_K2UM(SWL, u32); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2UM_ET(64); break;
+        case 32: FZB_K2UM_ET(32); break;
+        case 16: FZB_K2UM_ET(16); break;
+        default: FZB_K2UM_ET(8); break;
+    }
+#undef FZB_K2UM_ET
+#undef FZB_K2UM
 }

@@ -292,7 +292,8 @@ int fzb_last_timings(fzb_matcher* m, float out_ms[4]);
  * [3]=whole pipeline, [4]=calls averaged, [5]=how many of them ran a streaming filter kernel (the filter figure is their mean) */
 int fzb_last_stage_timings(fzb_matcher* m, float out_ms[6]);
 /* counters of the last call: out[0]=survivors of the filter stage, [1]=kept by the lane-exact prefilter,
- * [2]=windows scored by the generic wave-per-haystack kernel, [3]=windows scored by the multi-chunk kernel */
+ * [2]=windows queued for the wave-per-haystack kernel's back queue (beyond 1024 bytes: the greedy fallback; unicode scorings outside the
+ * thread-per-haystack kernels' preconditions), [3]=multi-chunk windows (one chunk < window <= 1024 bytes) */
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]);
 
 /* test hook, host only: the byte-level DFA of the unicode 0-typo prefilter run over one haystack (1 / 0), -1 if the matcher has none */

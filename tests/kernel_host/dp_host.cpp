@@ -108,6 +108,15 @@ static int run_unicode(const NeedleDev& nd, const u8* hay, u32 m, int include_pr
     return -2;
 }
 
+// a unicode window wider than one chunk (swl < m <= 1024) through dp_unicode_multi_chunk (thread-per-haystack, rows parked per chunk)
+template <int SWL>
+static int run_unicode_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, const u8* cls) {
+    static u32 scratch[(FZB_MAX_ROWS + 1) * (SWL / 2) + 64];
+    std::vector<u8> buf(m + 96, 0);
+    memcpy(buf.data(), hay, m);
+    return (int)dp_unicode_multi_chunk<SWL>(nd, buf.data(), m, include_prefix != 0, cls, scratch, 1, 0);
+}
+
 extern "C" {
 // form: 0 = dp_single_chunk biased, 1 = literal (unbiased) scan, 2 = its padded-half form, 3 = dp_single_chunk_cf with `real` dwords,
 // 4 = dp_single_chunk_cf_tab (LDS-table set-up, swl/4 dwords).
@@ -240,6 +249,30 @@ int kh_dp_multi(const u8* needle, int n, int case_sensitive, int is_u8, const u1
         case 32: return run_multi<32>(nd, hay, (u32)m, include_prefix, form, cls);
         case 16: return run_multi<16>(nd, hay, (u32)m, include_prefix, form, cls);
         case 8: return run_multi<8>(nd, hay, (u32)m, include_prefix, form, cls);
+    }
+    return -1;
+}
+
+int kh_dp_unicode_multi(const u8* uc, const u8* uf, const u8* ulen, int rows, int is_u8, const u16* sc, const u8* hay, int m, int include_prefix, int swl) {
+    if (rows < 1 || rows > FZB_MAX_ROWS || m <= swl || m > 1024) return -1;
+    NeedleDev nd;
+    const u8 dummy[1] = {0};
+    fill_needle(nd, dummy, 0, 1, sc);
+    nd.rows = rows;
+    nd.unicode = 1;
+    nd.lane_mask = is_u8 ? 0xFF : 0xFFFF;
+    for (int r = 0; r < rows; r++) {
+        memcpy(nd.uc[r], uc + 4 * r, 4);
+        memcpy(nd.uf[r], uf + 4 * r, 4);
+        nd.ulen[r] = ulen[r];
+    }
+    static u8 cls[256];
+    build_cls_table(cls);
+    switch (swl) {
+        case 64: return run_unicode_multi<64>(nd, hay, (u32)m, include_prefix, cls);
+        case 32: return run_unicode_multi<32>(nd, hay, (u32)m, include_prefix, cls);
+        case 16: return run_unicode_multi<16>(nd, hay, (u32)m, include_prefix, cls);
+        case 8: return run_unicode_multi<8>(nd, hay, (u32)m, include_prefix, cls);
     }
     return -1;
 }

@@ -67,6 +67,15 @@ def dp_unicode(rows, hay, scoring, include_prefix=True, swl=64, real=None, form=
     return lib().kh_dp_unicode(uc, uf, ul, len(rows), sc, hay, len(hay), int(include_prefix), swl, swl // 2 if real is None else real, form)
 
 
+def dp_unicode_multi(rows, hay, scoring, include_prefix=True, swl=64, is_u8=True):
+    """score of a unicode window wider than one chunk (swl < len(hay) <= 1024) by dp_unicode_multi_chunk"""
+    sc = (C.c_uint16 * 9)(*scoring)
+    uc = b"".join(r[0] for r in rows)
+    uf = b"".join(r[1] for r in rows)
+    ul = bytes(r[2] for r in rows)
+    return lib().kh_dp_unicode_multi(uc, uf, ul, len(rows), int(is_u8), sc, hay, len(hay), int(include_prefix), swl)
+
+
 def unicode_window(rows, hay):
     """(start, end) of the 0-typo unicode window as the unicode scorer finds it for an accepted haystack"""
     out = (C.c_uint32 * 2)()

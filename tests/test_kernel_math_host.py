@@ -358,6 +358,55 @@ def test_unicode_scorer_matches_the_oracle(swl):
     assert checked > 700 and checked_t > 400, (checked, checked_t)
 
 
+@pytest.mark.parametrize("swl", [64, 32, 16, 8])
+def test_unicode_multi_chunk_scorer_matches_the_oracle(swl):
+    """dp_unicode_multi_chunk (dp_unicode.h; windows of swl < m <= 1024 bytes, thread per haystack, the previous chunk's top half parked
+    per needle row) against score_haystack_unicode over its chunks (src/smith_waterman/algo/unicode.rs:10-217, unicode_gap.rs:110-236):
+    UTF-8 text of one- to four-byte scalars, runs of continuation bytes (not UTF-8: the scorers work on bytes), windows that end
+    anywhere in their last chunk, both score classes' parking formats, random scorings."""
+    rng = random.Random(4100 + swl)
+    alphabets = [list("abcAB_ -"), list("abéÉñÑüÜß/_ "), list("aب人äÄé_. 語"), list("إنماÉé_-ab "), list("a😀é人_b")]
+    checked = 0
+    for it in range(700):
+        alpha = rng.choice(alphabets)
+        n = rng.randint(1, 6)
+        needle = "".join(rng.choice(alpha) for _ in range(n))
+        cs = rng.random() < 0.3
+        sc = DEF
+        if rng.random() < 0.4:
+            sc = [rng.randint(0, 30), rng.randint(0, 16), rng.randint(0, 16), rng.randint(0, 5), rng.randint(0, 20), rng.randint(0, 10), rng.randint(0, 10),
+                  rng.randint(0, 16), rng.randint(0, 10)]
+        hi = rng.choice([2 * swl, 3 * swl, min(1024, 6 * swl), min(1024, 17 * swl)])
+        nbytes = rng.randint(swl + 1, max(swl + 1, hi))
+        hay = _rnd_utf8(rng, nbytes, alpha)
+        if rng.random() < 0.7:
+            chars = hay.decode()
+            if len(chars) >= n:
+                lst = list(chars)
+                for q, c in zip(sorted(rng.sample(range(len(chars)), n)), needle):
+                    lst[q] = c if rng.random() < 0.7 else c.swapcase() if len(c.swapcase().encode()) == len(c.encode()) else c
+                cand = "".join(lst).encode()
+                if swl < len(cand) <= 1024:
+                    hay = cand
+        if it % 5 == 4:
+            hb_ = bytearray(hay)
+            for _ in range(rng.randint(1, 4)):
+                q = rng.randrange(len(hb_))
+                for t in range(q, min(len(hb_), q + rng.randint(4, 12))):
+                    hb_[t] = rng.choice((0x80, 0x9F, 0xBF, 0xA9))
+            hay = bytes(hb_)
+        if len(hay) <= swl:
+            continue
+        ip = rng.random() < 0.5
+        rows = O.case_needle_unicode(needle, cs)
+        for u8 in {_fits(len(rows), sc), False}:  # the class the matcher would choose, and the u16 class (unpacked parking) anyway
+            want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, unicode=True, lanes=swl, is_u8=u8)
+            got = K.dp_unicode_multi(rows, hay, sc, ip, swl, is_u8=u8)
+            assert got == want, (needle, hay, sc, cs, ip, swl, u8, got, want)
+            checked += 1
+    assert checked > 800, checked
+
+
 def test_ascii_window_of_any_length_equals_the_reference_prefilter_window():
     """window_first_last (dp_body.h: 32-byte blocks, one compare per case-folded needle byte, positions masked behind the haystack's end)
     against the window the reference's ASCII prefilter returns for an accepted haystack (src/prefilter/algo/ascii.rs:6-72), haystacks of
