@@ -219,7 +219,9 @@ impl MatcherHip {
     }
 
     /// `Matcher::match_list_parallel(haystacks, threads)` (src/matcher/parallel.rs:18-89) with the GPUs of the node as workers:
-    /// per shard pipeline + device sort on its GPU, k-way merge of the runs on this thread.  Same result as `match_list`.
+    /// per shard the pipeline on its GPU (records in index order), the runs copied device to device into one list on the current
+    /// device, ordered there once (shard order is index order, so this is `match_list`'s post-step), one copy back.  Same result as
+    /// `match_list` - what the per-run sort + k-way merge of parallel.rs:66-87 returns, without a host-side merge.
     pub fn match_list_parallel_sharded(&mut self, corpus: &ShardedCorpus) -> Vec<Match> {
         let (mut out, mut n) = (std::ptr::null_mut(), 0usize);
         check(unsafe { fzb_match_list_parallel_sharded(self.handle, corpus.handle, &mut out, &mut n) });
