@@ -329,6 +329,12 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
     // (how it is tested on one GPU).
     bool pull = !fzb_knobs().shard_gather_copy;
     for (size_t g = 0; g < ns; g++) pull = pull && sc->device[g] == root;
+    const int inline_mode = fzb_knobs().shard_inline;  // -1 = decide here, 0 = always the workers, 1 = always the calling thread (pull form only)
+    const bool inline_enqueue = pull && (inline_mode == 1 || inline_mode < 0);
+    // A single shard runs on the root's own stream (no event to record and wait for: 0.252 -> 0.240 ms).  SEVERAL shards keep a stream each:
+    // their stages are launch-bound kernels of a few microseconds, and one behind the other on ONE stream eight pipelines take 0.40 ms where
+    // eight streams take 0.31 (measured; the device overlaps the small kernels' latencies).
+    const bool one_stream = inline_enqueue && ns == 1;
     // counts[g]: shard g's number of records, published by its worker as soon as it is known (-1 before); worker g starts its copy
     // when the counts of the shards below it are in - the prefix is where its run starts in the gathered list
     std::vector<std::atomic<int64_t>> counts(ns);
@@ -353,8 +359,9 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         if (rc_) return rc_;
         // the shard's records in INDEX order, numbered from the shard's first index (what a worker of match_list_parallel pushes,
         // parallel.rs:55-63) - unsorted: the root orders the whole list
-        rc_ = fzb_match_list_device(cm, c, 0, count, (uint32_t)sc->bounds[g], (fzb_match*)cm->out_dev, cm->out_cap, cm->count_dev, cm->shard_stream);
+        rc_ = fzb_match_list_device(cm, c, 0, count, (uint32_t)sc->bounds[g], (fzb_match*)cm->out_dev, cm->out_cap, cm->count_dev, one_stream ? m->shard_stream : cm->shard_stream);
         if (rc_) return rc_;
+        if (one_stream) return FZB_OK;  // the concatenation follows on the same stream
         if (pull) {
             HIPCHK(hipEventRecord(cm->shard_event, cm->shard_stream));
             copied[g] = 1;
@@ -383,8 +390,7 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
     // Shards that share the root device are enqueued by the CALLING thread, one after the other: launches from several host threads onto
     // one device serialise inside the runtime anyway (measured with 8 shards on one GPU: 0.35 ms through the workers, see bench.py
     // `sharded`), and nothing waits between them in the pull form.  Shards on other devices go through their workers.
-    const int inline_mode = fzb_knobs().shard_inline;  // -1 = decide here, 0 = always the workers, 1 = always the calling thread (pull form only)
-    if (pull && (inline_mode == 1 || inline_mode < 0)) {
+    if (inline_enqueue) {
         rc = FZB_OK;
         for (size_t g = 0; g < ns && !rc; g++) {
             rc = shard_job(g);

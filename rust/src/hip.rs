@@ -82,6 +82,12 @@ extern "C" {
     fn fzb_sharded_corpus_free(sc: *mut c_void);
     fn fzb_match_list_parallel_sharded(m: *mut c_void, sc: *const c_void, out: *mut *mut FzbMatch, out_len: *mut usize) -> c_int;
     fn fzb_device_count(out: *mut c_int) -> c_int;
+    // (bound by hosts that move the per-shard runs themselves / hold the list in HBM already; not used by the wrappers below)
+    #[allow(dead_code)]
+    fn fzb_merge_shard_runs(m: *mut c_void, dev_runs: *const *const c_void, dev_counts: *const *const u32, run_caps: *const usize, nruns: usize, stream: *mut c_void,
+                            out: *mut *mut FzbMatch, out_len: *mut usize) -> c_int;
+    #[allow(dead_code)]
+    fn fzb_corpus_build_view(c: *mut c_void, out_built: *mut c_int) -> c_int;
 }
 
 /// The reference panics (`assert!`) where the ABI returns FZB_ERR_PANIC, with the same text; every other code is a backend
