@@ -880,7 +880,9 @@ static int ensure_sort_buffers(fzb_matcher* m, size_t cap) {  // ping-pong buffe
     if (w.sort_hist) HIPCHK(hipFree(w.sort_hist));
     w.sort_tmp = nullptr; w.sort_hist = nullptr; w.sort_cap = 0;
     HIPCHK(dev_alloc((void**)&w.sort_tmp, (cap + 16) * sizeof(fzb_match_rec)));
-    HIPCHK(dev_alloc((void**)&w.sort_hist, (size_t)2 * 256 * (cap / 2048 + 2) * 4));  // tile histograms + their scan
+    const size_t hist_words = (size_t)2 * 256 * (cap / 2048 + 2);  // tile histograms + their scan; behind them two sets of digit totals + the phase word
+    HIPCHK(dev_alloc((void**)&w.sort_hist, (hist_words + 1024) * 4));
+    HIPCHK(hipMemset(w.sort_hist + hist_words, 0, 1024 * 4));
     w.sort_cap = cap;
     return FZB_OK;
 }
@@ -1910,7 +1912,9 @@ int fzb_multi_match_list(fzb_multi_matcher* mm, const fzb_corpus* c, fzb_match**
             if (mm->sort_hist) (void)hipFree(mm->sort_hist);
             mm->sort_tmp = nullptr; mm->sort_hist = nullptr; mm->sort_cap = 0;
             HIPCHK(dev_alloc((void**)&mm->sort_tmp, (count + 16) * sizeof(fzb_match_rec)));
-            HIPCHK(dev_alloc((void**)&mm->sort_hist, (size_t)2 * 256 * (count / 2048 + 2) * 4));
+            const size_t hist_words = (size_t)2 * 256 * (count / 2048 + 2);  // (+ the digit totals and the phase word: kernels_sort.hip)
+            HIPCHK(dev_alloc((void**)&mm->sort_hist, (hist_words + 1024) * 4));
+            HIPCHK(hipMemset(mm->sort_hist + hist_words, 0, 1024 * 4));
             mm->sort_cap = count;
         }
         fzb_launch_sort(mm->out_dev, mm->sort_tmp, mm->count_dev, mm->sort_hist, (u32)(mm->sort_cap / 2048 + 2), reversed, by_score, mm->num_cus * 2, nullptr);

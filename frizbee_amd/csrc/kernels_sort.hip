@@ -16,57 +16,50 @@
 
 __device__ __forceinline__ u32 sort_digit(const fzb_match_rec& r, int shift) { return 255u - ((r.score >> shift) & 0xFFu); }
 
-// hist[d * ntiles_cap + tile] = number of records of tile with digit' d
+// hist[d * ntiles_cap + tile] = number of records of tile with digit' d.  The per-digit TOTALS are accumulated on the way (one atomic per
+// digit and tile into dtot[phase]) so that the scan kernel does not have to reduce the whole histogram in every one of its workgroups
+// first (12.2 -> see DESIGN.md): dtot = two sets of 256 counters + a phase word behind them; a pass accumulates into set `phase`, clears the
+// other one (the next pass's), and the scatter kernel - which runs when nobody reads the counters any more - flips the phase.
 __global__ __launch_bounds__(256) void k_sort_hist(const fzb_match_rec* __restrict__ in, const u32* __restrict__ n_ptr, int shift, u32* __restrict__ hist,
-                                                   u32 ntiles_cap) {
+                                                   u32 ntiles_cap, u32* __restrict__ dtot) {
     __shared__ u32 h[256];
     const u32 n = *n_ptr;
     const u32 ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const u32 phase = dtot[512] & 1u;
+    u32* const mine = dtot + 256 * phase;
+    if (blockIdx.x == 0) dtot[256 * (phase ^ 1u) + threadIdx.x] = 0;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         h[threadIdx.x] = 0;
         __syncthreads();
         const u32 lo = tile * SORT_TILE, hi = min(lo + SORT_TILE, n);
         for (u32 i = lo + threadIdx.x; i < hi; i += 256) atomicAdd(&h[sort_digit(in[i], shift)], 1u);
         __syncthreads();
-        hist[threadIdx.x * ntiles_cap + tile] = h[threadIdx.x];
+        const u32 c = h[threadIdx.x];
+        hist[threadIdx.x * ntiles_cap + tile] = c;
+        if (c) atomicAdd(&mine[threadIdx.x], c);
         __syncthreads();
     }
 }
 
 // exclusive scan of the digit-major histogram (256 rows of `ntiles` live entries, row stride ntiles_cap) into `offs` (same layout)
-__global__ __launch_bounds__(1024) void k_sort_scan(const u32* __restrict__ hist, u32* __restrict__ offs, const u32* __restrict__ n_ptr, u32 ntiles_cap) {
+__global__ __launch_bounds__(1024) void k_sort_scan(const u32* __restrict__ hist, u32* __restrict__ offs, const u32* __restrict__ n_ptr, u32 ntiles_cap,
+                                                    const u32* __restrict__ dtot) {
     // Exclusive scan of the digit-major tile histogram, element (digit d, tile t) at hist[d * ntiles_cap + t], in the order
-    // (d, t) lexicographic.  16 workgroups of 16 waves.  Every workgroup computes (1) all 256 per-digit totals itself (a wave owns 16
-    // digits, lanes stride over the tiles: coalesced, no index arithmetic per element - the first version linearised (d, t) and paid a
-    // division and a modulo per element, 59 us for 244 tiles) and (2) their scan; then (3) workgroup b scans the tiles of ITS 16 digits,
-    // one digit per wave, from the digit's base.  With one workgroup doing (3) for all 256 digits - 16 per wave, 96 dependent shuffles
-    // per chunk of 64 tiles - the kernel took 32 us; the redundant (1) costs reads of an L2-resident 250 KB.  Not in place: another
-    // workgroup may still be reducing the rows this one scans.
-    __shared__ u32 dtot[256];
+    // (d, t) lexicographic.  16 workgroups of 16 waves.  Every workgroup (1) reads the 256 per-digit totals the histogram kernel
+    // accumulated (rounds 2-3 had every workgroup reduce the whole histogram itself: 250 KB of L2 reads and 96 shuffles per wave before
+    // anything else could start) and (2) scans them; then (3) workgroup b scans the tiles of ITS 16 digits, one digit per wave, from the
+    // digit's base.  Not in place: another workgroup may still be reading the rows this one scans.
+    __shared__ u32 dtot_s[256];
+    u32* const dtotv = dtot_s;
     const u32 n = *n_ptr;
     const u32 ntiles = (n + SORT_TILE - 1) / SORT_TILE;
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    {  // (1) the 16 digits of a wave together: 16 independent loads in flight per lane and chunk, then 16 reductions
-        u32 sum[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) sum[k] = 0;
-        for (u32 t0 = 0; t0 < ntiles; t0 += 64) {
-            const u32 t = t0 + lane;
-#pragma unroll
-            for (int k = 0; k < 16; k++) sum[k] += t < ntiles ? hist[(size_t)(wave * 16 + k) * ntiles_cap + t] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            u32 v = sum[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) dtot[wave * 16 + k] = v;
-        }
-    }
+    if (threadIdx.x < 256) dtotv[threadIdx.x] = dtot[256 * (dtot[512] & 1u) + threadIdx.x];  // (1)
     __syncthreads();
     if (wave == 0) {  // (2) exclusive scan of the 256 digit totals: 4 per lane
         u32 v[4], s4 = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { v[k] = dtot[lane * 4 + k]; s4 += v[k]; }
+        for (int k = 0; k < 4; k++) { v[k] = dtotv[lane * 4 + k]; s4 += v[k]; }
         u32 incl = s4;
         for (int off = 1; off < 64; off <<= 1) {
             const u32 t = __shfl_up(incl, off);
@@ -74,12 +67,12 @@ __global__ __launch_bounds__(1024) void k_sort_scan(const u32* __restrict__ hist
         }
         u32 run = incl - s4;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { dtot[lane * 4 + k] = run; run += v[k]; }
+        for (int k = 0; k < 4; k++) { dtotv[lane * 4 + k] = run; run += v[k]; }
     }
     __syncthreads();
     {  // (3) this workgroup's digits, one per wave: a wave scan over the digit's tiles from its base
         const u32 d = blockIdx.x * 16 + wave;
-        u32 carry = dtot[d];
+        u32 carry = dtotv[d];
         for (u32 t0 = 0; t0 < ntiles; t0 += 64) {  // uniform trip count: every lane takes part in the shuffles
             const u32 t = t0 + lane;
             const u32 v = t < ntiles ? hist[(size_t)d * ntiles_cap + t] : 0u;
@@ -95,7 +88,8 @@ __global__ __launch_bounds__(1024) void k_sort_scan(const u32* __restrict__ hist
 }
 
 __global__ __launch_bounds__(256) void k_sort_scatter(const fzb_match_rec* __restrict__ in, fzb_match_rec* __restrict__ out, const u32* __restrict__ n_ptr,
-                                                      int shift, const u32* __restrict__ offs, u32 ntiles_cap) {
+                                                      int shift, const u32* __restrict__ offs, u32 ntiles_cap, u32* __restrict__ dtot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) dtot[512] ^= 1u;  // the digit totals of this pass have been read: the next pass takes the other set
     __shared__ u32 wave_hist[4][256];
     __shared__ u32 run[256];
     const u32 n = *n_ptr;
@@ -209,16 +203,17 @@ void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u
     if (reverse_first) hipLaunchKernelGGL(k_reverse, dim3(grid), dim3(256), 0, st, passes == -1 ? tmp : buf, n_ptr);
     if (!by_score) return;
     u32* offs = hist + (size_t)256 * ntiles_cap;  // the scanned histogram (second half of the buffer)
+    u32* dtot = hist + (size_t)512 * ntiles_cap;  // behind both: two sets of 256 digit totals + the phase word (FZB_SORT_HIST_WORDS)
     if (passes == -1) {
-        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, tmp, n_ptr, 0, hist, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, tmp, buf, n_ptr, 0, offs, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, tmp, n_ptr, 0, hist, ntiles_cap, dtot);
+        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap, dtot);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, tmp, buf, n_ptr, 0, offs, ntiles_cap, dtot);
         return;
     }
     if (passes == 1) {
-        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, buf, n_ptr, 0, hist, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, buf, tmp, n_ptr, 0, offs, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, buf, n_ptr, 0, hist, ntiles_cap, dtot);
+        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap, dtot);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, buf, tmp, n_ptr, 0, offs, ntiles_cap, dtot);
         hipLaunchKernelGGL(k_sort_copy_back, dim3(grid), dim3(256), 0, st, tmp, buf, n_ptr);
         return;
     }
@@ -226,8 +221,8 @@ void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u
         const fzb_match_rec* src = pass == 0 ? buf : tmp;
         fzb_match_rec* dst = pass == 0 ? tmp : buf;
         const int shift = pass * 8;
-        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, src, n_ptr, shift, hist, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap);
-        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, src, dst, n_ptr, shift, offs, ntiles_cap);
+        hipLaunchKernelGGL(k_sort_hist, dim3(grid), dim3(256), 0, st, src, n_ptr, shift, hist, ntiles_cap, dtot);
+        hipLaunchKernelGGL(k_sort_scan, dim3(16), dim3(1024), 0, st, hist, offs, n_ptr, ntiles_cap, dtot);
+        hipLaunchKernelGGL(k_sort_scatter, dim3(grid), dim3(256), 0, st, src, dst, n_ptr, shift, offs, ntiles_cap, dtot);
     }
 }
