@@ -107,7 +107,7 @@ struct GateArgs {
 };
 #define TRACE_W (FZB_MAX_HAYSTACK_LEN + 2 * 64)  // columns: the zero chunk + up to 1024 bytes rounded up to a chunk
 
-template <int SWL, bool UNICODE, bool TRACE, typename ET, typename ND = NeedleDev>
+template <int SWL, bool UNICODE, bool TRACE, typename ET, typename ND = NeedleDev, bool SLAB = ND::kLong>
 __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                               const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
                                                               const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const ND nd,
@@ -117,12 +117,11 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
         const u32 gn = *gate.count;
         if (gn < gate.lo || gn >= gate.hi) return;
     }
-    // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row - in LDS for needles
-    // that fit NeedleDev, in the wave's slab of `long_adj` ((rows + 1) x SWL x 2 entries) for long ones
-    // (the LDS form is sized by the needle's actual rows - dynamic shared memory, fzb_generic_lds_bytes: sized for the 63 rows the
-    // by-value needle can have it was 64 KB per workgroup, two workgroups = eight waves per CU whatever the needle; a two-row needle
-    // needs 3 KB and the kernel's registers decide the occupancy)
-    constexpr bool LONG = ND::kLong;
+    // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row - in LDS (sized by the
+    // needle's actual rows: dynamic shared memory; sized for the 63 rows the by-value needle can have it was 64 KB per workgroup, two
+    // workgroups = eight waves per CU whatever the needle), or - SLAB: a long needle whose vectors do not fit LDS - in the wave's slab of
+    // `long_adj` ((rows + 1) x SWL x 2 entries, global memory).  A long needle of up to 127 rows at 32 lanes still fits LDS (round 4).
+    constexpr bool LONG = SLAB;
     extern __shared__ __attribute__((aligned(16))) u16 s_adj[];
     const int lane = lane_id();
     const int wv = threadIdx.x >> 6;
@@ -455,7 +454,11 @@ void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, co
                              hipStream_t st) {
     const TraceArgs tr{(u32*)cells, pos, npos, stride};
     const bool trace = cells != nullptr;
-#define FZB_K2C_L(SWL, U, T, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev>), dim3(grid), dim3(GEN_WAVES * 64), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 0})
+    // the previous-chunk vectors in LDS when they fit (60 KB per four-wave workgroup: up to 127 rows at 32 lanes), in the slab otherwise
+    const size_t lds = (size_t)GEN_WAVES * 2 * (size_t)(nd.rows + 1) * (size_t)sw_lanes * sizeof(u16);
+    const bool in_lds = lds <= (size_t)60 * 1024;
+#define FZB_K2C_LS(SWL, U, T, ET, SLAB) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev, SLAB>), dim3(grid), dim3(GEN_WAVES * 64), SLAB ? 0 : lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 0})
+#define FZB_K2C_L(SWL, U, T, ET) do { if (in_lds) FZB_K2C_LS(SWL, U, T, ET, false); else FZB_K2C_LS(SWL, U, T, ET, true); } while (0)
 #define FZB_K2C_L_ET(SWL, U, T) do { if (c.ends_u64) FZB_K2C_L(SWL, U, T, u64); else FZB_K2C_L(SWL, U, T, u32); } while (0)
 #define FZB_K2C_L_T(SWL, U) do { if (trace) FZB_K2C_L_ET(SWL, U, true); else FZB_K2C_L_ET(SWL, U, false); } while (0)
 #define FZB_K2C_L_U(SWL) do { if (nd.unicode) FZB_K2C_L_T(SWL, true); else FZB_K2C_L_T(SWL, false); } while (0)
@@ -466,4 +469,5 @@ void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, co
         default: FZB_K2C_L_U(8); break;
     }
 #undef FZB_K2C_L
+#undef FZB_K2C_LS
 }
