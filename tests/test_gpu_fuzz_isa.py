@@ -145,3 +145,42 @@ def test_random_triples_unicode_scorer(lanes):
                 data, ends = make_unicode_list(rng, needle, 9000, max_chars)
                 total += check(needle, data, ends, lanes, (lanes, what, needle, typos, max_chars), max_typos=typos, scoring=sc)
     assert total >= 1_000_000, total
+
+
+@pytest.fixture
+def forced_round4_paths():
+    """The two data paths round 4 added that the lists above are too small (or too long) to reach by default: the filter -> scorer
+    handoff over the interleaved view (FZB_HANDOFF_MIN_TILES=0: shipped for lists of 4096 tiles and more) and the thread-per-haystack
+    multi-chunk unicode scorer (FZB_UNICODE_MULTI=1: shipped from 131 072 queued windows on)."""
+    import os
+    os.environ["FZB_HANDOFF_MIN_TILES"] = "0"
+    os.environ["FZB_UNICODE_MULTI"] = "1"
+    F.lib().fzb_debug_reload_knobs()
+    yield
+    os.environ.pop("FZB_HANDOFF_MIN_TILES", None)
+    os.environ.pop("FZB_UNICODE_MULTI", None)
+    F.lib().fzb_debug_reload_knobs()
+
+
+@pytest.mark.parametrize("lanes", [64, 32, 16])
+def test_random_triples_through_the_view_handoff_and_the_unicode_multi_chunk_scorer(lanes, forced_round4_paths):
+    rng = np.random.default_rng(3000 + lanes)
+    total = 0
+    # lists whose longest haystack is 33..256 bytes get the interleaved view; with the handoff forced the view filter stages the accepted
+    # haystacks (LDS block, its overflow into direct stores, tiles whose 16 KB block runs out: every second haystack carries the needle)
+    view_pool = np.array([0, 2, 9, 30, 33, 48, 64, 65, 70, 100, 127, 128, 129, 200, 255, 256])
+    for si, (sc, what) in enumerate(SCORINGS):
+        for ni, needle in enumerate(NEEDLES):
+            if (si + ni) % 3:
+                continue
+            data, ends = make_list(rng, needle, 30_000, view_pool)
+            casing = "Respect" if (si + ni) % 5 == 4 else "Smart"
+            total += check(needle, data, ends, lanes, (lanes, "view + handoff", what, needle, casing), max_typos=0, scoring=sc, casing=casing)
+    assert total >= 900_000, total
+    utotal = 0
+    for sc, what in (SCORINGS[0], SCORINGS[1], SCORINGS[2], SCORINGS[4], SCORINGS[5], SCORINGS[6]):
+        for needle in ("إنما", "éa", "中文字", "aЖ"):
+            for typos, max_chars in ((0, 120), (None, 90), (1, 200)):
+                data, ends = make_unicode_list(rng, needle, 4000, max_chars)
+                utotal += check(needle, data, ends, lanes, (lanes, "unicode multi-chunk", what, needle, typos, max_chars), max_typos=typos, scoring=sc)
+    assert utotal >= 250_000, utotal
