@@ -157,7 +157,9 @@ struct LaunchCfg {
     u32 dead_byte;      // a byte value no needle row can match (used to neutralise bytes past a haystack's end in the DFA filter)
 };
 
+#ifndef FZB_STAGE_UNITS
 #define FZB_STAGE_UNITS 1024  // 16 KB of staged vectors per 1024-haystack tile (the C4 list needs ~ 4 KB on average, the paths list ~ 7)
+#endif
 #define FZB_STAGE_LDS_UNITS 512  // of which the first 8 KB are collected in LDS and written out coalesced
 struct StageOut {
     u8* stage;
