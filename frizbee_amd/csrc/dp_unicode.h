@@ -751,6 +751,255 @@ __device__ __forceinline__ u32 dp_unicode_single_chunk_tr(const NeedleDev& nd, u
     return all_of(!run4) ? unicode_rows_t<SWL, REAL, true>(nd, hb, sflag, Qp, bonus) : unicode_rows_t<SWL, REAL, false>(nd, hb, sflag, Qp, bonus);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Windows wider than one chunk in the BIASED-THROUGHOUT form (round 4, second step): dp_unicode_multi_chunk's chunk walk with
+// unicode_rows_t's arithmetic.  T(i, L) = S(i, L) + e * Qp[L] + (i + 1) * e, where Qp counts scalar starts and padding lanes from the
+// ADJACENT HALF's first lane on (QpA over lanes -SWL/2 .. -1, Qp over the chunk): P is continuous across the chunk boundary, so the diagonal
+// into lane 0 ("P grows by e on a scalar-start lane"), the crossing tests (Qp differs) and the biased steps hold unchanged when a source lane
+// lies in the adjacent half.  Per row the parked top half of the previous chunk (unbiased values; pending as bits) is biased with
+// e * QpA + (r + 1) * e and its pending bits become gop' masks; T(r - 1, lane -1) = carry + e * QpA[last] + r * e.  Parked again: the top half
+// minus its bias, pending as "pendg != 0" (with gop' = 0 a pending charge is 0 anyway).  The last needle row is neither propagated nor parked
+// in any chunk (see dp_unicode_multi_chunk).  UTF8 (the caller's wave-uniform vote over the WHOLE window, unicode_window_has_cont_run4): no four
+// continuation bytes in a row anywhere, so every window of >= 4 lanes - across the boundary too - holds a scalar start or padding: the
+// 4-lane and wider steps are a subtract and a max.  Preconditions: LaunchCfg::cfu_ok.  Fuzzed against the oracle and the first form
+// (tests/test_kernel_math_host.py).
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool unicode_window_has_cont_run4(const u8* __restrict__ th, u32 m) {
+    u32 run4 = 0, cont_prev = 0;
+    for (u32 p = 0; p < m; p += 4) {
+        const u32 w = load_u32_unaligned(th, p);
+        const u32 nv = min(m - p, 4u);
+        const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
+        const u32 cv = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u) & validf;
+        run4 |= cv & __builtin_amdgcn_alignbyte(cv, cont_prev, 1) & __builtin_amdgcn_alignbyte(cv, cont_prev, 2) & __builtin_amdgcn_alignbyte(cv, cont_prev, 3);
+        cont_prev = cv;
+    }
+    return run4 != 0;
+}
+
+template <int SWL, bool UTF8>
+__device__ __forceinline__ u32 dp_unicode_multi_chunk_t(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls,
+                                                        u32* __restrict__ scratch, u32 sstride, u32 sidx) {
+    constexpr int NW = SWL / 2, NB = SWL / 4, HT = NW / 2;
+    constexpr int NCHG = (HT + 7) / 8;
+    static_assert(HT >= 1 && HT + NCHG <= NW, "a parked row must fit its NW dwords of the slab");
+    const u32 rows = (u32)nd.rows;
+    const u32 ONE = 0x00010001u;
+    const u32 e = nd.gex;
+    const u32 Mv = splat16(nd.match_plus_mismatch), capv = splat16(nd.capitalization), delimv = splat16(nd.delimiter);
+    const u32 xqv = splat16(nd.mismatch - 2 * e), gexv = splat16(e), gopmv = splat16(nd.gopm), casev = splat16(nd.matching_case);
+    const bool u8class = nd.lane_mask == 0xFF;
+    const u32 nchunks = (m + SWL - 1) / SWL;
+    const u32 mv = splat16(m);
+    u32 mx = 0;
+    u32 clsw_prev = 0;
+#pragma unroll 1
+    for (u32 ch = 0; ch < nchunks; ch++) {
+        const u32 cbase = ch * SWL;
+        u32 hb[NB + 1];
+#pragma unroll
+        for (int k = 0; k <= NB; k++) {
+            const u32 p = cbase + 4 * k;
+            u32 v = 0;
+            if (p < m) {
+                v = load_u32_unaligned(th, p);
+                const u32 rem = m - p;
+                if (rem < 4) v &= (1u << (8 * rem)) - 1;
+            }
+            hb[k] = v;
+        }
+        // ---- prefix counts over [adjacent half | chunk], scalar-start flags, bonuses ----
+        u32 QpA[HT], Qp[NW], bonus[NW], sflag[NB];
+        u32 qrun = 0;
+        if (ch) {
+#pragma unroll
+            for (int k = 0; k < NB / 2; k++) {
+                const u32 w = load_u32_unaligned(th, cbase - SWL / 2 + 4 * k);
+                const u32 t = (0x80808080u & ~zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u)) >> 7;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const u32 s0 = h ? (t >> 16) & 1 : t & 1, s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
+                    const u32 q0 = qrun + s0, q1 = q0 + s1;
+                    QpA[2 * k + h] = q0 | (q1 << 16);
+                    qrun = q1;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < HT; t++) QpA[t] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; k++) {
+            const u32 w = hb[k];
+            const u32 contf = zflag4((w & 0xC0C0C0C0u) ^ 0x80808080u);
+            const u32 p = cbase + 4 * k;
+            const u32 nv = m > p ? min(m - p, 4u) : 0u;
+            const u32 validf = nv >= 4 ? 0x80808080u : (0x80808080u & ((1u << (8 * nv)) - 1));
+            sflag[k] = validf & ~contf;
+            const u32 t = sflag[k] >> 7;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int d = 2 * k + h;
+                const u32 b0 = h ? (w >> 16) & 0xFF : w & 0xFF;
+                const u32 b1 = h ? w >> 24 : (w >> 8) & 0xFF;
+                const u32 clsw = (u32)cls[b0] | ((u32)cls[b1] << 16);
+                const u32 sh = __builtin_amdgcn_alignbit(clsw, clsw_prev, 16);
+                const u32 cap01 = (clsw >> 1) & sh & ONE;
+                const u32 dl01 = (sh >> 2) & ~(clsw >> 2) & ONE;
+                bonus[d] = p_add(p_add(p_mul(dl01, delimv), p_mul(cap01, capv)), Mv);
+                clsw_prev = clsw;
+                const u32 s0 = h ? (t >> 16) & 1 : t & 1, s1 = h ? (t >> 24) & 1 : (t >> 8) & 1;
+                const u32 q0 = qrun + s0, q1 = q0 + s1;
+                const u32 lanepos1 = (cbase + (u32)(2 * d + 1)) | ((cbase + (u32)(2 * d + 2)) << 16);
+                Qp[d] = p_add(q0 | (q1 << 16), p_subs(lanepos1, mv));  // + padding lanes up to and including the lane
+                qrun = q1;
+            }
+        }
+        if (ch == 0 && include_prefix) bonus[0] = p_add(bonus[0], (u32)nd.prefix);
+        u32 prev[NW], upg[NW];
+#pragma unroll
+        for (int d = 0; d < NW; d++) prev[d] = p_mul(Qp[d], gexv), upg[d] = 0;  // T(-1, L) = P[L]: the zero row
+        u32 carry = 0;
+#pragma unroll 1
+        for (u32 r = 0; r < rows; r++) {
+            const u32 ucw = ((const u32*)nd.uc)[r], ufw = ((const u32*)nd.uf)[r];
+            const u32 cl = (((const u32*)nd.ulen)[r >> 2] >> (8 * (r & 3))) & 0xFF;
+            const bool two = ucw != ufw;
+            const u32 rbv = splat16((r + 1) * e);
+#pragma unroll
+            for (int d = 0; d < NW; d++) FZB_OPAQUE_V(Qp[d]);
+#pragma unroll
+            for (int k = 0; k <= NB; k++) FZB_OPAQUE_V(hb[k]);
+#pragma unroll
+            for (int k = 0; k < NB; k++) FZB_OPAQUE_V(sflag[k]);
+            u32 fe01[NB], fm01[NB];
+            switch (two ? cl + 4 : cl) {
+                case 1: unicode_row_flags<NB, 1, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+                case 2: unicode_row_flags<NB, 2, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+                case 3: unicode_row_flags<NB, 3, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+                case 5: unicode_row_flags<NB, 1, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+                case 6: unicode_row_flags<NB, 2, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+                case 7: unicode_row_flags<NB, 3, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+                case 8: unicode_row_flags<NB, 4, true>(hb, sflag, ucw, ufw, fe01, fm01); break;
+                default: unicode_row_flags<NB, 4, false>(hb, sflag, ucw, ufw, fe01, fm01); break;
+            }
+            // T(r-1, lane -1): the previous chunk's last lane of the row above, biased (chunk 0: the zero column, r * e)
+            const u32 z = (carry + e * (QpA[HT - 1] >> 16) + r * e) << 16;
+            u32 row[NW], pendg[NW];
+#pragma unroll
+            for (int k = 0; k < NB; k++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const int d = 2 * k + h;
+                    const u32 sel01 = h ? 0x0c030c02u : 0x0c010c00u;
+                    const u32 ex01 = __builtin_amdgcn_perm(0u, fe01[k], sel01);
+                    const u32 mm01 = __builtin_amdgcn_perm(0u, fm01[k], sel01);
+                    const u32 sst = p_neg_mask(__builtin_amdgcn_perm(0u, sflag[k], h ? 0x03030202u : 0x01010000u));
+                    const u32 sh = __builtin_amdgcn_alignbit(prev[d], d ? prev[d - 1] : z, 16);
+                    const u32 t = p_subs(p_mad(mm01, bonus[d], sh), xqv);
+                    const u32 diag = p_mad(ex01, casev, t);
+                    const u32 up = p_subs(prev[d], upg[d]);
+                    const u32 Bd = p_mad(Qp[d], gexv, rbv);
+                    const u32 v = p_max(p_max(diag, up), Bd);
+                    row[d] = (v & sst) | (Bd & ~sst);
+                    pendg[d] = upg[d] = p_mul(mm01, gopmv);
+                }
+                if (k & 1) FZB_SCHED_FENCE();
+            }
+            if (r + 1 == rows) {  // the last row: its maximum, unbiased, in every chunk
+#pragma unroll
+                for (int d = 0; d < NW; d++) mx = p_max(mx, p_sub(row[d], p_mad(Qp[d], gexv, rbv)));
+                break;
+            }
+            // ---- the previous chunk's top half of this row, biased; its pending bits as gop' masks ----
+            u32 ca[HT], apendg[HT];
+            u32* srow = scratch + (size_t)(r * NW) * sstride + sidx;
+            u32 carry_next = 0;
+            if (ch) {
+                u32 arow[HT];
+                if (u8class) {
+#pragma unroll
+                    for (int t = 0; t < HT / 2; t++) {
+                        const u32 pk = srow[(size_t)t * sstride];
+                        arow[2 * t] = __builtin_amdgcn_perm(0u, pk, 0x0c010c00u);
+                        arow[2 * t + 1] = __builtin_amdgcn_perm(0u, pk, 0x0c030c02u);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HT; t++) arow[t] = srow[(size_t)t * sstride];
+                }
+                u32 pch[NCHG];
+#pragma unroll
+                for (int a = 0; a < NCHG; a++) pch[a] = srow[(size_t)(HT + a) * sstride];
+#pragma unroll
+                for (int t = 0; t < HT; t++) {
+                    ca[t] = p_add(arow[t], p_mad(QpA[t], gexv, rbv));
+                    apendg[t] = p_mul((pch[t / 8] >> (2 * (t % 8))) & ONE, gopmv);
+                }
+                carry_next = arow[HT - 1] >> 16;
+            } else {
+#pragma unroll
+                for (int t = 0; t < HT; t++) ca[t] = 0u, apendg[t] = 0u;
+            }
+            // ---- the gap scan, in place from the highest dword down ----
+#pragma unroll
+            for (int d = NW - 1; d >= 0; d--) {
+                const u32 bs = __builtin_amdgcn_alignbit(row[d], d ? row[d - 1] : ca[HT - 1], 16);
+                const u32 ps = __builtin_amdgcn_alignbit(pendg[d], d ? pendg[d - 1] : apendg[HT - 1], 16);
+                const u32 fl = p_neg_mask(__builtin_amdgcn_perm(0u, sflag[d >> 1], (d & 1) ? 0x03030202u : 0x01010000u));
+                row[d] = p_max(row[d], p_subs(bs, ps & fl));
+                pendg[d] = pendg[d] | (ps & ~fl);
+                if ((d & 1) == 0) FZB_SCHED_FENCE();
+            }
+#pragma unroll
+            for (int off = 1; off < NW; off *= 2) {
+                if (UTF8 && off >= 2) {
+#pragma unroll
+                    for (int d = NW - 1; d >= 0; d--) {
+                        const bool adj = d < off;
+                        const int si = adj ? HT + d - off : d - off;
+                        row[d] = p_max(row[d], p_subs(adj ? ca[si] : row[si], adj ? apendg[si] : pendg[si]));
+                    }
+                    FZB_SCHED_FENCE();
+                    continue;
+                }
+#pragma unroll
+                for (int d = NW - 1; d >= 0; d--) {
+                    const bool adj = d < off;
+                    const int si = adj ? HT + d - off : d - off;
+                    const u32 rs = adj ? ca[si] : row[si], psrc = adj ? apendg[si] : pendg[si], qsrc = adj ? QpA[si] : Qp[si];
+                    const u32 fl = p_neg_mask(p_sub(qsrc, Qp[d]));
+                    row[d] = p_max(row[d], p_subs(rs, psrc & fl));
+                    pendg[d] = pendg[d] | (psrc & ~fl);
+                    if ((d & 3) == 0) FZB_SCHED_FENCE();
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < NW; d++) prev[d] = row[d];
+            // ---- park the top half (unbiased) and its pending bits for the next chunk ----
+            if (ch + 1 < nchunks) {
+                u32 top[HT];
+#pragma unroll
+                for (int t = 0; t < HT; t++) top[t] = p_sub(row[HT + t], p_mad(Qp[HT + t], gexv, rbv));
+                if (u8class) {
+#pragma unroll
+                    for (int t = 0; t < HT / 2; t++) srow[(size_t)t * sstride] = __builtin_amdgcn_perm(top[2 * t + 1], top[2 * t], 0x06040200u);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < HT; t++) srow[(size_t)t * sstride] = top[t];
+                }
+                u32 chg[NCHG] = {};
+#pragma unroll
+                for (int t = 0; t < HT; t++) chg[t / 8] |= p_min(pendg[HT + t], ONE) << (2 * (t % 8));
+#pragma unroll
+                for (int a = 0; a < NCHG; a++) srow[(size_t)(HT + a) * sstride] = chg[a];
+            }
+            carry = carry_next;
+        }
+    }
+    return max(mx & 0xFFFF, mx >> 16);
+}
+
 // ---- 0-typo unicode window of a haystack of at most 32 bytes held in two vectors (the kernel for short corpora) --------------------------
 // The same window as unicode_window_first_last (src/prefilter/algo/unicode.rs:118-219), found with SWAR compares: 0x80 in every byte at
 // which the CL bytes of the scalar `cw` start, all eight dwords merged into one word with bit 8j + k = byte j of dword k (position 4k + j).

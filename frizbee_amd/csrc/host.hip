@@ -1192,17 +1192,18 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("generic(trace)");
     } else if (nd.unicode && lc.bias_ok) {
         // Windows wider than a chunk: up to 1024 bytes into the FRONT of the queue, beyond that (greedy fallback) into its back.  The front
-        // has two takers, chosen on the device by its length: the thread-per-haystack multi-chunk scorer (k2u_dp_unicode_multi: ~ 8x fewer
-        // instructions, but one wave per SIMD and ~ 20 us per chunk - a fixed ~ 150 us, then 0.5 ns per window) from `umin` windows on, the
-        // wave-per-haystack kernel (1.6 - 2.7 ns per window, no fixed cost) below.  Measured: 45 k windows (Arabic-shaped list, All Scores)
-        // 0.213 vs 0.239 ms, 361 k windows 1.285 vs 0.907 ms (tools/exp_unicode_wide.py).  FZB_UNICODE_MULTI=0 / 1: never / always.
-        const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : (u32)cus * 512u;
+        // has two takers, chosen on the device by its length: the thread-per-haystack multi-chunk scorer (k2u_dp_unicode_multi: several times
+        // fewer instructions, but one wave per SIMD and ~ 10-20 us per chunk - a fixed latency of ~ 100 us, then 0.3 ns per window) from
+        // `umin` windows on, the wave-per-haystack kernel (1.6 - 2.7 ns per window, no fixed cost) below.  Measured (tools/exp_unicode_wide.py):
+        // 45 k windows (Arabic-shaped list, All Scores) 0.215 ms wave per haystack / 0.204 thread per haystack, 361 k windows 1.285 / 0.815.
+        // FZB_UNICODE_MULTI=0 / 1: never / always.
+        const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : (u32)cus * 128u;
         const int ugrid = cus * 2;  // multi-chunk unicode scorer: one wave per SIMD (two-wave workgroups)
         if (umin != 0xFFFFFFFFu && (rc = ensure_dp_scratch(m, ugrid))) return rc;  // first use only (or fzb_matcher_reserve)
         fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st, lc.cfu_ok, 1);
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
-            if (umin != 0xFFFFFFFFu) fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, st, umin);
+            if (umin != 0xFFFFFFFFu) fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, st, umin, lc.cfu_ok);
             // (the wave-per-haystack kernel's LDS follows the needle's rows: for short needles its registers decide how many workgroups a CU holds)
             if (umin != 0u) fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, st, 1, umin);
             FZB_STAGE("dp(unicode, wide windows)");

@@ -180,7 +180,7 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
 // ---- windows of SWL < m <= 1024 bytes: one thread per queued window, chunk by chunk (dp_unicode_multi_chunk) -------------------------------
 // The function keeps a chunk's row, previous row, pending and up masks, prefix counts and bonuses in registers (~ 300 live values at 64
 // lanes): one wave per SIMD, the accumulation registers as spill space - still 64 haystacks per wavefront where the generic kernel takes one.
-template <int SWL, typename ET>
+template <int SWL, bool TF, typename ET>
 __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ list,
                                                             const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
                                                             u32* __restrict__ scratch, u32 only_from) {
@@ -200,7 +200,16 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict
         const u32 sp = ws ? ws - 1 : 0;
         const bool include_exact = sp == 0 && we == L;
         const u32 m = we - sp;
-        u32 score = nd.rows > 0 ? dp_unicode_multi_chunk<SWL>(nd, hay + sp, m, sp == 0, cls, scratch, nthreads, gtid) : 0u;
+        u32 score = 0;
+        if (nd.rows > 0) {
+            if (TF) {  // the biased-throughout form (LaunchCfg::cfu_ok); its UTF-8 shortcut when no window of the wave has four continuation bytes in a row
+                const bool utf8 = __all((int)!unicode_window_has_cont_run4(hay + sp, m)) != 0;
+                score = utf8 ? dp_unicode_multi_chunk_t<SWL, true>(nd, hay + sp, m, sp == 0, cls, scratch, nthreads, gtid)
+                             : dp_unicode_multi_chunk_t<SWL, false>(nd, hay + sp, m, sp == 0, cls, scratch, nthreads, gtid);
+            } else {
+                score = dp_unicode_multi_chunk<SWL>(nd, hay + sp, m, sp == 0, cls, scratch, nthreads, gtid);
+            }
+        }
         bool exact = include_exact && m == (u32)nd.nbytes;
         if (exact)
             for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
@@ -215,9 +224,10 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict
 }
 
 void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes,
-                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from) {
-#define FZB_K2UM(SWL, ET) hipLaunchKernelGGL((k2u_dp_unicode_multi<SWL, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, only_from)
-#define FZB_K2UM_ET(SWL) do { if (c.ends_u64) FZB_K2UM(SWL, u64); else FZB_K2UM(SWL, u32); } while (0)
+                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from, int tform) {
+#define FZB_K2UM(SWL, TF, ET) hipLaunchKernelGGL((k2u_dp_unicode_multi<SWL, TF, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, only_from)
+#define FZB_K2UM_TF(SWL, ET) do { if (tform) FZB_K2UM(SWL, true, ET); else FZB_K2UM(SWL, false, ET); } while (0)
+#define FZB_K2UM_ET(SWL) do { if (c.ends_u64) FZB_K2UM_TF(SWL, u64); else FZB_K2UM_TF(SWL, u32); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2UM_ET(64); break;
         case 32: FZB_K2UM_ET(32); break;
@@ -225,5 +235,6 @@ void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset
         default: FZB_K2UM_ET(8); break;
     }
 #undef FZB_K2UM_ET
+#undef FZB_K2UM_TF
 #undef FZB_K2UM
 }

@@ -109,12 +109,17 @@ static int run_unicode(const NeedleDev& nd, const u8* hay, u32 m, int include_pr
 }
 
 // a unicode window wider than one chunk (swl < m <= 1024) through dp_unicode_multi_chunk (thread-per-haystack, rows parked per chunk)
+// form 0 = dp_unicode_multi_chunk (first form); 1 = dp_unicode_multi_chunk_t with the UTF-8 shortcut where the window allows it (as the
+// kernel chooses), 2 = its general steps
 template <int SWL>
-static int run_unicode_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, const u8* cls) {
+static int run_unicode_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_prefix, const u8* cls, int form) {
     static u32 scratch[(FZB_MAX_ROWS + 1) * (SWL / 2) + 64];
     std::vector<u8> buf(m + 96, 0);
     memcpy(buf.data(), hay, m);
-    return (int)dp_unicode_multi_chunk<SWL>(nd, buf.data(), m, include_prefix != 0, cls, scratch, 1, 0);
+    if (form == 0) return (int)dp_unicode_multi_chunk<SWL>(nd, buf.data(), m, include_prefix != 0, cls, scratch, 1, 0);
+    const bool utf8 = form == 1 && !unicode_window_has_cont_run4(buf.data(), m);
+    return utf8 ? (int)dp_unicode_multi_chunk_t<SWL, true>(nd, buf.data(), m, include_prefix != 0, cls, scratch, 1, 0)
+                : (int)dp_unicode_multi_chunk_t<SWL, false>(nd, buf.data(), m, include_prefix != 0, cls, scratch, 1, 0);
 }
 
 extern "C" {
@@ -253,7 +258,7 @@ int kh_dp_multi(const u8* needle, int n, int case_sensitive, int is_u8, const u1
     return -1;
 }
 
-int kh_dp_unicode_multi(const u8* uc, const u8* uf, const u8* ulen, int rows, int is_u8, const u16* sc, const u8* hay, int m, int include_prefix, int swl) {
+int kh_dp_unicode_multi(const u8* uc, const u8* uf, const u8* ulen, int rows, int is_u8, const u16* sc, const u8* hay, int m, int include_prefix, int swl, int form) {
     if (rows < 1 || rows > FZB_MAX_ROWS || m <= swl || m > 1024) return -1;
     NeedleDev nd;
     const u8 dummy[1] = {0};
@@ -269,10 +274,10 @@ int kh_dp_unicode_multi(const u8* uc, const u8* uf, const u8* ulen, int rows, in
     static u8 cls[256];
     build_cls_table(cls);
     switch (swl) {
-        case 64: return run_unicode_multi<64>(nd, hay, (u32)m, include_prefix, cls);
-        case 32: return run_unicode_multi<32>(nd, hay, (u32)m, include_prefix, cls);
-        case 16: return run_unicode_multi<16>(nd, hay, (u32)m, include_prefix, cls);
-        case 8: return run_unicode_multi<8>(nd, hay, (u32)m, include_prefix, cls);
+        case 64: return run_unicode_multi<64>(nd, hay, (u32)m, include_prefix, cls, form);
+        case 32: return run_unicode_multi<32>(nd, hay, (u32)m, include_prefix, cls, form);
+        case 16: return run_unicode_multi<16>(nd, hay, (u32)m, include_prefix, cls, form);
+        case 8: return run_unicode_multi<8>(nd, hay, (u32)m, include_prefix, cls, form);
     }
     return -1;
 }

@@ -67,13 +67,14 @@ def dp_unicode(rows, hay, scoring, include_prefix=True, swl=64, real=None, form=
     return lib().kh_dp_unicode(uc, uf, ul, len(rows), sc, hay, len(hay), int(include_prefix), swl, swl // 2 if real is None else real, form)
 
 
-def dp_unicode_multi(rows, hay, scoring, include_prefix=True, swl=64, is_u8=True):
-    """score of a unicode window wider than one chunk (swl < len(hay) <= 1024) by dp_unicode_multi_chunk"""
+def dp_unicode_multi(rows, hay, scoring, include_prefix=True, swl=64, is_u8=True, form=0):
+    """score of a unicode window wider than one chunk (swl < len(hay) <= 1024): form 0 = dp_unicode_multi_chunk (first form), 1 =
+    dp_unicode_multi_chunk_t with the UTF-8 shortcut where the window allows it, 2 = its general steps"""
     sc = (C.c_uint16 * 9)(*scoring)
     uc = b"".join(r[0] for r in rows)
     uf = b"".join(r[1] for r in rows)
     ul = bytes(r[2] for r in rows)
-    return lib().kh_dp_unicode_multi(uc, uf, ul, len(rows), int(is_u8), sc, hay, len(hay), int(include_prefix), swl)
+    return lib().kh_dp_unicode_multi(uc, uf, ul, len(rows), int(is_u8), sc, hay, len(hay), int(include_prefix), swl, form)
 
 
 def unicode_window(rows, hay):

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["wave_per_haystack", "thread_per_haystack"])
 def wide_mode(request):
     """Who scores the windows of 65..1024 bytes: the wave-per-haystack kernel (FZB_UNICODE_MULTI=0; also what the default chooses on the
-    device for queues as short as these) or k2u_dp_unicode_multi (FZB_UNICODE_MULTI=1; the default's choice from 131 072 windows on)"""
+    device for queues as short as these) or k2u_dp_unicode_multi (FZB_UNICODE_MULTI=1; the default's choice from 32 768 windows on)"""
     import os
     os.environ["FZB_UNICODE_MULTI"] = "1" if request.param == "thread_per_haystack" else "0"
     F.lib().fzb_debug_reload_knobs()
@@ -70,7 +70,7 @@ def test_wide_unicode_windows_against_the_oracle(pf, wide_mode):
 
 def test_default_chooses_by_queue_length():
     """No knob: the device picks the scorer by the queue's length - the wave-per-haystack kernel for this list's few hundred wide windows,
-    k2u_dp_unicode_multi beyond 131 072 (a list of 150 000 wide windows)."""
+    k2u_dp_unicode_multi beyond 32 768 (a list of 150 000 wide windows)."""
     import os
     os.environ.pop("FZB_UNICODE_MULTI", None)
     F.lib().fzb_debug_reload_knobs()

@@ -366,7 +366,7 @@ def test_unicode_multi_chunk_scorer_matches_the_oracle(swl):
     anywhere in their last chunk, both score classes' parking formats, random scorings."""
     rng = random.Random(4100 + swl)
     alphabets = [list("abcAB_ -"), list("abéÉñÑüÜß/_ "), list("aب人äÄé_. 語"), list("إنماÉé_-ab "), list("a😀é人_b")]
-    checked = 0
+    checked = checked_t = 0
     for it in range(700):
         alpha = rng.choice(alphabets)
         n = rng.randint(1, 6)
@@ -404,7 +404,12 @@ def test_unicode_multi_chunk_scorer_matches_the_oracle(swl):
             got = K.dp_unicode_multi(rows, hay, sc, ip, swl, is_u8=u8)
             assert got == want, (needle, hay, sc, cs, ip, swl, u8, got, want)
             checked += 1
-    assert checked > 800, checked
+            if 2 * sc[3] <= sc[1]:  # the biased-throughout form's precondition (LaunchCfg::cfu_ok)
+                for form in (1, 2):
+                    got_t = K.dp_unicode_multi(rows, hay, sc, ip, swl, is_u8=u8, form=form)
+                    assert got_t == want, ("T form", form, needle, hay, sc, cs, ip, swl, u8, got_t, want)
+                checked_t += 1
+    assert checked > 800 and checked_t > 500, (checked, checked_t)
 
 
 def test_ascii_window_of_any_length_equals_the_reference_prefilter_window():
