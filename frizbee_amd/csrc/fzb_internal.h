@@ -85,6 +85,11 @@ struct CorpusDev {
     const u16* vlen;   // per sorted haystack
     const u16* vperm;  // per sorted haystack
     u32 view_nv;       // the view's widest member in 16-byte vectors (<= 16): read from the lengths when the view is built, not a caller's hint
+    // OUTLIERS: the (few) haystacks beyond 256 bytes are not in the view (vlen = 0xFFFF, no vectors); the filter decides them from the
+    // canonical layout in a small follow-up launch over this list of their indices (k1_cdfa_outliers).  Without it one 300-byte path
+    // would cost a million-item list its view.
+    const u32* vlong;
+    u32 n_long;
 };
 
 struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between kernels (0 in final output)

@@ -1141,7 +1141,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // the tile's closing work - copy-out, header, three barriers - sits on the one chain of latencies the kernel consists of (filter 32 ->
         // 44 us there, the scorers gain 8); FZB_HANDOFF_MIN_TILES overrides the threshold (0: always)
         const u32 ntiles_f = (cnt + FZB_TILE - 1) / FZB_TILE;
-        const bool want_stage = !kn.no_handoff && !trace && lc.filter_mode == 1 && lc.filter_exact && lc.window_mode == 1 && !nd.unicode && cd.vbytes && lc.cf_ok &&
+        const bool want_stage = !kn.no_handoff && !trace && lc.filter_mode == 1 && lc.filter_exact && lc.window_mode == 1 && !nd.unicode && cd.vbytes && cd.n_long == 0 && lc.cf_ok &&
                                 !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2) && ntiles_f >= (u32)kn.handoff_min_tiles;
         if (want_stage && (rc = ensure_stage(m, count))) return rc;  // first use only (or fzb_matcher_reserve)
         const StageOut so{want_stage ? w.stage : nullptr, want_stage ? w.stage_hdr : nullptr};
@@ -1297,7 +1297,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
     if (!m->long_needle && !m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
     if (!m->long_needle && !m->literal_mode && m->nd.unicode && m->lc.bias_ok && !no_wide && fzb_knobs().unicode_multi != 0 && (rc = ensure_dp_scratch(m, m->lc.num_cus * 2))) return rc;
-    if (c->dev.vbytes && !m->literal_mode && !m->long_needle && !m->nd.unicode && m->lc.filter_mode == 1 && m->lc.cf_ok && (rc = ensure_stage(m, n))) return rc;
+    if (c->dev.vbytes && c->dev.n_long == 0 && !m->literal_mode && !m->long_needle && !m->nd.unicode && m->lc.filter_mode == 1 && m->lc.cf_ok && (rc = ensure_stage(m, n))) return rc;
     if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;
     return FZB_OK;

@@ -25,7 +25,7 @@ struct fzb_corpus {
     CorpusDev dev{};
     void* own_bytes = nullptr;
     void* own_ends = nullptr;
-    void* own_view[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // the filter's view: vbytes, vgofs, vgnv, vlen, vperm (CorpusDev)
+    void* own_view[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // the filter's view: vbytes, vgofs, vgnv, vlen, vperm, vlong (CorpusDev)
 };
 
 // what the synchronous entry points remember between two results (fetch_records, host.hip)

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_build(const u8* __restrict__ 
 #define FV_CLASSES 18  // vector counts 0..16 (haystacks up to 256 bytes) and a guard class
 template <typename ET>
 __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restrict__ ends, u64 n, u16* __restrict__ vperm, u16* __restrict__ vlen, u8* __restrict__ vgnv,
-                                                             u64* __restrict__ tile_units, UpStats* __restrict__ stats) {
+                                                             u64* __restrict__ tile_units, UpStats* __restrict__ stats, u32* __restrict__ vlong, u32 long_cap) {
     __shared__ u32 s_len[UP_TILE];
     __shared__ u16 s_inv[UP_TILE];
     __shared__ u32 s_hist[FV_CLASSES], s_base[FV_CLASSES];
@@ -205,9 +205,14 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restric
         cls[k] = rk[k] = 0;
         if (j < nt) {
             const ET st = (i0 + j) ? (ends[i0 + j - 1] + (ET)15) & ~(ET)15 : (ET)0;
-            const u32 len = (u32)min((u64)(ends[i0 + j] - st), (u64)0xFFFFu);  // (beyond 256 bytes there is no view: the guard class reports it)
+            u32 len = (u32)min((u64)(ends[i0 + j] - st), (u64)0xFFFFu);
+            if (len > 256u) {  // an OUTLIER: not in the view (no vectors, sorted last, vlen = 0xFFFF) - listed for the filter's follow-up launch
+                const u32 slot = (u32)atomicAdd((unsigned long long*)&stats->bad, 1ull);  // (bad = the outlier count here)
+                if (slot < long_cap) vlong[slot] = (u32)(i0 + j);
+                len = 0xFFFFu;
+            }
             s_len[j] = len;
-            cls[k] = min((len + 15u) >> 4, (u32)FV_CLASSES - 1);
+            cls[k] = len == 0xFFFFu ? 0u : min((len + 15u) >> 4, (u32)FV_CLASSES - 1);
             rk[k] = atomicAdd(&s_hist[cls[k]], 1u);
         }
     }
@@ -240,7 +245,8 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restric
     }
     if (tid < UP_TILE / 64) {  // the tile's 16 groups: vectors per member = the group's first (longest) member's count
         const u32 p0 = tid * 64;
-        const u32 nv = p0 < nt ? (s_len[s_inv[p0]] + 15u) >> 4 : 0u;
+        const u32 l0 = p0 < nt ? s_len[s_inv[p0]] : 0u;
+        const u32 nv = l0 == 0xFFFFu ? 0u : (l0 + 15u) >> 4;
         vgnv[i0 / 64 + tid] = (u8)nv;
         s_base[tid] = nv * 64;  // 16-byte units of the group's block (FV_CLASSES >= 16 entries)
     }
@@ -272,6 +278,7 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restric
     for (u32 p = tid >> 2; p < nt; p += UP_THREADS / 4) {
         const u64 j = i0 + vperm[i0 + p];
         const ET st = j ? (ends[j - 1] + (ET)15) & ~(ET)15 : (ET)0;
+        if (ends[j] - st > (ET)256) continue;  // an outlier has no vectors in the view
         const u32 nv = (u32)((ends[j] - st + (ET)15) >> 4);
         const uint4* src = (const uint4*)(bytes + st);
         uint4* dst = (uint4*)(vbytes + (size_t)s_gofs[p >> 6] * 16 + (size_t)(p & 63) * 16);
@@ -377,8 +384,9 @@ hipError_t h2d_all(const std::vector<H2DJob>& jobs, int device) {
 }  // namespace
 
 // The streaming filter's view of a corpus whose canonical layout is resident (uploaded or borrowed), on the CURRENT device.  Sets
-// c->dev.v* and view_nv on success; leaves the corpus without a view (and returns FZB_OK) when the list does not call for one - a
-// haystack beyond 256 bytes, nothing beyond 32, a uniform-length list - or when the device has no room: the view is an accelerator,
+// c->dev.v* and view_nv on success; leaves the corpus without a view (and returns FZB_OK) when the list does not call for one - more
+// than one haystack in 256 (+64) beyond 256 bytes (the few that are become OUTLIERS: listed in vlong, decided by k1_cdfa_outliers from
+// the canonical layout), nothing beyond 32, a uniform-length list - or when the device has no room: the view is an accelerator,
 // not part of the corpus (the filter then streams the canonical layout).  Any other error is reported.
 int fzb_build_filter_view(fzb_corpus* c) {
     const bool want_view = !fzb_knobs().no_filter_view;
@@ -388,12 +396,14 @@ int fzb_build_filter_view(fzb_corpus* c) {
     const size_t ngroups = (size_t)ntiles * (UP_TILE / 64);
     u64* d_vt = nullptr;
     UpStats* d_stats = nullptr;
+    // outliers (haystacks beyond 256 bytes) the view tolerates: one in 256, at least 64 - more, and the list is not a short-haystack list
+    const u32 long_cap = (u32)std::min<u64>(n / 256 + 64, 0x7FFFFFFFu);
     auto drop_view = [&]() {
         if (d_vt) (void)hipFree(d_vt);
         if (d_stats) (void)hipFree(d_stats);
         d_vt = nullptr;
         d_stats = nullptr;
-        for (int q = 0; q < 5; q++) { if (c->own_view[q]) (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
+        for (int q = 0; q < 6; q++) { if (c->own_view[q]) (void)hipFree(c->own_view[q]); c->own_view[q] = nullptr; }
         (void)hipGetLastError();
     };
     auto bail = [&](hipError_t e) {
@@ -404,6 +414,7 @@ int fzb_build_filter_view(fzb_corpus* c) {
     if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[4], n * 2);
     if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[2], ngroups);
     if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[1], ngroups * 4);
+    if (e == hipSuccess) e = fzb_dev_alloc(&c->own_view[5], (size_t)long_cap * 4);
     if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_vt, (size_t)ntiles * 8);
     if (e == hipSuccess) e = fzb_dev_alloc((void**)&d_stats, sizeof(UpStats));
     if (e == hipErrorOutOfMemory) { drop_view(); return FZB_OK; }
@@ -412,16 +423,16 @@ int fzb_build_filter_view(fzb_corpus* c) {
     e = hipMemcpy(d_stats, &init, sizeof(init), hipMemcpyHostToDevice);
     if (e != hipSuccess) return bail(e);
     if (c->dev.ends_u64)
-        hipLaunchKernelGGL((k_up_view_sort<u64>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u64*)c->dev.ends, n, (u16*)c->own_view[4], (u16*)c->own_view[3], (u8*)c->own_view[2], d_vt, d_stats);
+        hipLaunchKernelGGL((k_up_view_sort<u64>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u64*)c->dev.ends, n, (u16*)c->own_view[4], (u16*)c->own_view[3], (u8*)c->own_view[2], d_vt, d_stats, (u32*)c->own_view[5], long_cap);
     else
-        hipLaunchKernelGGL((k_up_view_sort<u32>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u32*)c->dev.ends, n, (u16*)c->own_view[4], (u16*)c->own_view[3], (u8*)c->own_view[2], d_vt, d_stats);
+        hipLaunchKernelGGL((k_up_view_sort<u32>), dim3((unsigned)ntiles), dim3(UP_THREADS), 0, nullptr, (const u32*)c->dev.ends, n, (u16*)c->own_view[4], (u16*)c->own_view[3], (u8*)c->own_view[2], d_vt, d_stats, (u32*)c->own_view[5], long_cap);
     hipLaunchKernelGGL(k_up_scan, dim3(1), dim3(1024), 0, nullptr, d_vt, ntiles, d_stats);  // total_padded = the view's size in 16-byte units
     UpStats vst{0, 0, 0, 0};
     e = hipMemcpy(&vst, d_stats, sizeof(vst), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return bail(e);
-    // (min_len / max_len are in VECTORS here) no view: a member beyond 256 bytes (the guard class), nothing beyond 32 bytes (the short
-    // kernels serve that list), or group offsets beyond 32 bits of 16-byte units (64 GB)
-    if (vst.max_len > 16 || vst.max_len <= 2 || vst.total_padded > 0xFFFFFFF0ull) { drop_view(); return FZB_OK; }
+    // (min_len / max_len are in VECTORS here, outliers excluded; bad = the number of outliers) no view: more outliers beyond 256 bytes than
+    // the list holds, nothing beyond 32 bytes (the short kernels serve that list), or group offsets beyond 32 bits of 16-byte units (64 GB)
+    if (vst.bad > long_cap || vst.max_len > 16 || vst.max_len <= 2 || vst.total_padded > 0xFFFFFFF0ull) { drop_view(); return FZB_OK; }
     const u64 view_bytes = vst.total_padded * 16;
     e = fzb_dev_alloc(&c->own_view[0], view_bytes + 1024);
     if (e == hipErrorOutOfMemory) { drop_view(); return FZB_OK; }
@@ -442,6 +453,8 @@ int fzb_build_filter_view(fzb_corpus* c) {
     c->dev.vlen = (const u16*)c->own_view[3];
     c->dev.vperm = (const u16*)c->own_view[4];
     c->dev.view_nv = (u32)vst.max_len;
+    c->dev.vlong = (const u32*)c->own_view[5];
+    c->dev.n_long = (u32)vst.bad;
     return FZB_OK;
 }
 
@@ -530,7 +543,7 @@ int fzb_corpus_upload_impl(const uint8_t* bytes, const uint64_t* end_offsets, si
     c->dev.ends = c->own_ends;
     // the streaming filter's view (CorpusDev::vbytes): ragged lists whose haystacks are 33..256 bytes.  A second copy of the bytes (+ ~5 %
     // for the zero vectors behind shorter group members, + 4.2 bytes per haystack); FZB_FILTER_VIEW=0 turns it off.
-    if (n && !c->dev.uniform_len && c->dev.max_len > 32 && c->dev.max_len <= 256) {
+    if (n && !c->dev.uniform_len && c->dev.max_len > 32) {  // (a list with more than a few haystacks beyond 256 bytes gets none: the builder decides)
         int rc = fzb_build_filter_view(c);
         if (rc) {
             const std::string msg = fzb_last_error();

@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
                     for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);
                 }
             }
-            if (p < count && hl >= min_len && st >= acc_lo) {
+            if (p < count && hl != 0xFFFFu && hl >= min_len && st >= acc_lo) {  // (0xFFFF: an outlier beyond 256 bytes - k1_cdfa_outliers decides it)
                 atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
                 if (STAGE) {
                     // the vectors go to the tile's block through LDS (the first FZB_STAGE_LDS_UNITS units: written out below by the whole
@@ -684,6 +684,71 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
         __syncthreads();
         if (tid == 0) tile_counts[tile] = s_cnt;
         __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The view's OUTLIERS (CorpusDev::vlong: the few haystacks beyond 256 bytes, which have no vectors in the view): one thread each over the
+// canonical layout with the same class-composite automaton, its decision OR-ed into the bitmap the view kernel wrote and added to the
+// tile's count.  Launched behind k1_cdfa_view on the same stream; a list without outliers does not launch it.
+// ---------------------------------------------------------------------------------------------------
+template <typename ET, bool SAN, int G>
+__global__ __launch_bounds__(256) void k1_cdfa_outliers(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count, const u32* __restrict__ vlong, u32 n_long,
+                                                        const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG, u32 min_len, u32 dead, u32 acc_lo,
+                                                        u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    const u32 tab_bytes = (cdfa_bytes + 15u) & ~15u;
+    const int tid = threadIdx.x;
+    dfa_require_lds_base0(lds);
+    for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
+    __syncthreads();
+    const u32 deadv = dead * 0x01010101u;
+    auto cls_of = [](u32 b) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)b; };
+    auto comp_at = [](u32 a) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)(256u + a); };
+    for (u32 j = blockIdx.x * 256u + tid; j < n_long; j += gridDim.x * 256u) {
+        const u64 gi = vlong[j];
+        if (gi < first || gi >= first + count) continue;
+        const u32 li = (u32)(gi - first);
+        u64 hs;
+        u32 hl;
+        haystack_span(ends, gi, hs, hl);
+        const uint4* vp = (const uint4*)(bytes + hs);
+        u32 st = 0;
+        for (u32 v = 0; 16 * v < hl; v++) {
+            const uint4 q = vp[v];
+            u32 w[4] = {q.x, q.y, q.z, q.w};
+            if (SAN) {
+                const u32 rem = hl - 16 * v;
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const u32 nvb = rem > 4u * t ? rem - 4u * t : 0u;
+                    const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
+                    w[t] = (w[t] & mask) | (deadv & ~mask);
+                }
+            }
+            u32 c[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                c[t][0] = cls_of(w[t] & 0xFF);
+                c[t][1] = cls_of((w[t] >> 8) & 0xFF);
+                c[t][2] = cls_of((w[t] >> 16) & 0xFF);
+                c[t][3] = cls_of(w[t] >> 24);
+            }
+            if (G == 4) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) st = comp_at(st * KG + c[t][0] + K * (c[t][1] + K * (c[t][2] + K * c[t][3])));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    st = comp_at(st * KG + c[t][0] + K * c[t][1]);
+                    st = comp_at(st * KG + c[t][2] + K * c[t][3]);
+                }
+            }
+        }
+        if (hl >= min_len && st >= acc_lo) {
+            atomicOr((unsigned long long*)&bitmap[li >> 6], 1ull << (li & 63));
+            atomicAdd(&tile_counts[li / FZB_TILE], 1u);
+        }
     }
 }
 
@@ -980,7 +1045,7 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             const int vwg = kn.view_wgs;  // (C4 shard: 8 -> 190 us, 6 -> 187, 4 -> 194)
             if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2) && c.vbytes && !no_view && first % FZB_TILE == 0 && (first + count == c.n || count % FZB_TILE == 0) &&
                 c.view_nv != 0 && c.view_nv <= 16) {
-                const bool stg = so && so->stage && so->hdr;
+                const bool stg = so && so->stage && so->hdr && c.n_long == 0;  // (an outlier's survivor would have no header entry: no handoff on such a list)
                 const size_t lds_v = ((cdfa_bytes + 15) & ~(size_t)15) + 16 + 128 + (stg ? 128 + 4 * FZB_TILE + 16 * FZB_STAGE_LDS_UNITS : 0);
                 const int g = std::max(1, std::min<int>((grid / 8) * vwg, (int)ntiles));
                 u32 kg = 1;
@@ -995,6 +1060,16 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #undef FZB_K1V_NV
 #undef FZB_K1V_S
 #undef FZB_K1V
+                if (c.n_long) {  // the haystacks beyond 256 bytes: decided from the canonical layout, OR-ed into the view kernel's bitmap
+                    const size_t lds_o = ((cdfa_bytes + 15) & ~(size_t)15) + 16;
+                    const int go = (int)std::max<u32>(1u, std::min<u32>((c.n_long + 255u) / 256u, 1024u));
+#define FZB_K1O(ET, SAN, G) hipLaunchKernelGGL((k1_cdfa_outliers<ET, SAN, G>), dim3(go), dim3(256), lds_o, st, c.bytes, (const ET*)c.ends, first, count, c.vlong, c.n_long, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts)
+#define FZB_K1O_G(ET, SAN) do { if (cdfa_G == 4) FZB_K1O(ET, SAN, 4); else FZB_K1O(ET, SAN, 2); } while (0)
+                    if (c.ends_u64) { if (nul_safe) FZB_K1O_G(u64, false); else FZB_K1O_G(u64, true); }
+                    else            { if (nul_safe) FZB_K1O_G(u32, false); else FZB_K1O_G(u32, true); }
+#undef FZB_K1O_G
+#undef FZB_K1O
+                }
                 return stg && !kn.cdfa_nodfa;
             }
             if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2)) {

@@ -154,3 +154,56 @@ def test_borrowed_corpus_gets_the_view_and_ignores_a_wrong_length_hint(max_len):
     assert F.Matcher("deadbeef", F.Config(pf_lanes=64, sw_lanes=64)).match_list(up).tolist() == want.tolist()
     short = F.Corpus.from_device(d_bytes.data_ptr(), d_ends.data_ptr(), 5, d_bytes.numel(), keep=(d_bytes, d_ends))
     assert isinstance(short.build_view(), bool)
+
+
+def _plant(rng, L, needle, alphabet, where=None):
+    s = [rng.choice(alphabet) for _ in range(L)]
+    lo, hi = where if where else (0, L)
+    for q, c in zip(sorted(rng.sample(range(lo, hi), len(needle))), needle):
+        s[q] = c
+    return "".join(s)
+
+
+@pytest.mark.parametrize("n_out", [1, 40])
+def test_a_few_haystacks_beyond_256_bytes_do_not_cost_the_list_its_view(n_out):
+    """The view holds haystacks up to 256 bytes; a list with a FEW longer ones (up to n/256 + 64) keeps it - they are listed as outliers
+    and decided by k1_cdfa_outliers over the canonical layout.  Outliers at tile and group boundaries, matching only beyond byte 256,
+    matching nowhere, beyond 1024 bytes (the generic scorer's territory), under every automaton; sub-range queries see only their own."""
+    rng = random.Random(4242 + n_out)
+    alphabet = "abcdefghijklmnDEAB_-/. 01xyz"
+    for needle, cfg in NEEDLES + [("é人", dict())]:
+        abc = alphabet.replace(needle[0].lower(), "").replace(needle[0].upper(), "")  # filler that cannot complete the needle by chance
+        n = 1024 * 5 + 333
+        hs = _list(rng, n, 120, needle, alphabet)
+        spots = [0, 1023, 1024, 2047 + 64, n - 1][:n_out] + rng.sample(range(n), max(0, n_out - 5))
+        for k, i in enumerate(spots):
+            L = rng.choice([257, 300, 1000, 1025, 3000])
+            kind = k % 3
+            if kind == 0:
+                hs[i] = _plant(rng, L, needle, abc, where=(257, L)) if L - 257 >= len(needle) else _plant(rng, L, needle, abc)
+            elif kind == 1:
+                hs[i] = "".join(rng.choice(abc) for _ in range(L))  # cannot match
+            else:
+                hs[i] = _plant(rng, L, needle, alphabet)
+        assert F.Corpus(hs).build_view(), "the list lost its view to a few outliers"
+        got, want, _ = both(needle, hs, **cfg)
+        assert len(want) > 0
+        assert_same(got, want, f"{needle!r} {cfg} outliers={n_out}")
+        outl = set(spots)
+        assert any(int(i) in outl for i in want["index"]) or n_out == 1
+        if not cfg:  # tile-aligned sub-ranges of the same corpus (the view's precondition): each sees only its own outliers
+            cp = F.Corpus(hs)
+            fm = F.Matcher(needle, F.Config(sort=F.SortStrategy.IndexAsc))
+            whole = fm.match_list(cp)
+            for first, cnt in ((0, 1024), (1024, 2048), (2048, n - 2048)):
+                part = fm.match_list_into(cp, first=first, count=cnt, index_offset=first)
+                sl = whole[(whole["index"] >= first) & (whole["index"] < first + cnt)]
+                assert sorted(part.tolist()) == sorted(sl.tolist()), (needle, first)
+
+
+def test_a_list_of_mostly_long_haystacks_gets_no_view():
+    rng = random.Random(7)
+    hs = ["".join(rng.choice("abcdef") for _ in range(rng.randint(200, 400))) for _ in range(3000)]
+    assert not F.Corpus(hs).build_view()
+    got, want, _ = both("fade", hs)
+    assert_same(got, want, "long list")
