@@ -27,20 +27,21 @@ constexpr bool cfm_entry_lane(int k, int s, int P) { return s == 1 ? k == P - 1 
 // column they would walk down instead ends in the previous chunk's last row, which the maximum covers).  Needs a needle without NUL (pad_ok).
 template <int SWL, bool UPPER, int R>
 __device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, u32 ch, bool last_chunk_rt, bool include_prefix, const CfTables& tab,
-                                          u32* __restrict__ scratch, u32 sstride, u32 sidx, u32& mx, u32& cprev) {
+                                          u32* __restrict__ scratch, u32 sstride, u32 sidx, u32 rpitch, u32& mx, u32& cprev) {
     constexpr int NW = SWL / 2;
     constexpr int HT = NW / 2;  // parked dwords per vector (top half)
     constexpr int P = 2 * R;
     constexpr bool PAD = R < NW;
-    constexpr int NCHG = (HT + 7) / 8;  // parked words of gap-open flags (one bit per lane, two lanes of a dword 16 bits apart)
+    constexpr int NCHG = 1;  // parked word of gap-open flags: dword HT+t's two lanes at bits t and 16 + t (HT <= 16)
     static_assert(R >= 1 && R <= NW, "R");
-    static_assert(HT + NCHG <= NW, "a parked row must fit its NW dwords of the slab");
+    static_assert(HT <= 16 && HT + NCHG <= NW, "a parked row must fit its NW dwords of the slab");
     static_assert(!PAD || 4 * P <= 3 * SWL, "padding entries must land inside the chunk");
     const bool last_chunk = PAD ? true : last_chunk_rt;
     const u32 rows = (u32)nd.rows;
     const u32 e = nd.gex, x = nd.mismatch, o = nd.gopm;
     const u32 ev = splat16(e), gopmv = splat16(o), casev = splat16(nd.matching_case), xqv = splat16(x - 2 * e);
     const bool u8class = nd.lane_mask == 0xFF;  // score values of the u8 class fit a byte (score_fits_in_u8)
+    const u32 flg = u8class ? HT / 2 : HT;  // where a parked row keeps its flag word: behind the dwords it uses (a row is flg + 1 dwords)
     const u32 cbase = ch * SWL;
     u32 hw[R], bonus[R];
 #pragma unroll
@@ -93,8 +94,8 @@ __device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restr
                 const u32 U = p_subs(T[d], g[d]);
                 b[d] = p_max3_s(D, U, bias);  // (all three below 0x7C00: cfm_ok)
                 gn[d] = p_mul(mm, gopmv);
-                if constexpr (!PAD)  // the top half's match flags for the next chunk (they are its gap-open charges): dword HT+t -> bits 2t', 16+2t' of word t/8
-                    if (d >= HT) chg[(d - HT) / 8] |= mm << (2 * ((d - HT) % 8));
+                if constexpr (!PAD)  // the top half's match flags for the next chunk (they are its gap-open charges): dword HT+t -> bits t, 16+t
+                    if (d >= HT) chg[0] |= mm << (d - HT);
             }
         }
         if (last_chunk && r + 1 == rows) {  // only the row's maximum is read: no propagation
@@ -107,7 +108,7 @@ __device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restr
         // the previous chunk's parked vectors for this row, biased as lanes -SWL/2 .. -1 of this chunk and already charged (what a gap step
         // reads); zero for the first chunk: nothing can flow in (0 < every bias)
         u32 ca[HT];
-        u32* srow = scratch + (size_t)(r * NW) * sstride + sidx;
+        u32* srow = scratch + (size_t)r * rpitch + sidx;
         u32 carry_next = 0;
         if (ch) {
             u32 arow[HT];
@@ -123,12 +124,11 @@ __device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restr
                 for (int t = 0; t < HT; t++) arow[t] = srow[(size_t)t * sstride];
             }
             u32 pch[NCHG];
-#pragma unroll
-            for (int a = 0; a < NCHG; a++) pch[a] = srow[(size_t)(HT + a) * sstride];
+            pch[0] = srow[(size_t)flg * sstride];
             u32 bias = (u32)(SWL / 2) * e + (((u32)(SWL / 2) + 1) * e << 16) + rb;
 #pragma unroll
             for (int t = 0; t < HT; t++, bias = fzb_sadd(bias, 2 * ev)) {
-                const u32 ag = p_mul((pch[t / 8] >> (2 * (t % 8))) & 0x00010001u, gopmv);
+                const u32 ag = p_mul((pch[0] >> t) & 0x00010001u, gopmv);
                 ca[t] = p_subs(p_add(arow[t], bias), ag);
             }
             carry_next = arow[HT - 1] >> 16;
@@ -196,8 +196,7 @@ __device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restr
 #pragma unroll
                 for (int t = 0; t < HT; t++) srow[(size_t)t * sstride] = top[t];
             }
-#pragma unroll
-            for (int a = 0; a < NCHG; a++) srow[(size_t)(HT + a) * sstride] = chg[a];
+            srow[(size_t)flg * sstride] = chg[0];
         }
         if (r + 1 == rows) {  // last row of a chunk that is not the last: its maximum, unbiased
             u32 bias = (u32)SWL * e + (((u32)SWL + 1) * e << 16) + rb;
@@ -214,31 +213,31 @@ __device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restr
 // computed lanes.  One copy of the full chunk's code serves every class.
 template <int SWL, bool UPPER>
 __device__ __forceinline__ u32 dp_multi_chunk_tc(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const CfTables& tab, u32* __restrict__ scratch,
-                                                 u32 sstride, u32 sidx, u32 wcls) {
+                                                 u32 sstride, u32 sidx, u32 rpitch, u32 wcls) {
     constexpr int NW = SWL / 2, Q = NW / 4;
     const u32 nchunks = (m + SWL - 1) / SWL;
     const u32 nfull = wcls >= 3 ? nchunks : nchunks - 1;
     u32 mx = 0;
     u32 cprev = 0;
 #pragma unroll 1
-    for (u32 ch = 0; ch < nfull; ch++) cfm_chunk<SWL, UPPER, NW>(nd, th, m, ch, ch + 1 == nchunks, include_prefix, tab, scratch, sstride, sidx, mx, cprev);
-    if (wcls == 2) cfm_chunk<SWL, UPPER, 3 * Q>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, mx, cprev);
-    else if (wcls == 1) cfm_chunk<SWL, UPPER, 2 * Q>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, mx, cprev);
-    else if (wcls == 0) cfm_chunk<SWL, UPPER, Q>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, mx, cprev);
+    for (u32 ch = 0; ch < nfull; ch++) cfm_chunk<SWL, UPPER, NW>(nd, th, m, ch, ch + 1 == nchunks, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
+    if (wcls == 2) cfm_chunk<SWL, UPPER, 3 * Q>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
+    else if (wcls == 1) cfm_chunk<SWL, UPPER, 2 * Q>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
+    else if (wcls == 0) cfm_chunk<SWL, UPPER, Q>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
     return max(mx & 0xFFFF, mx >> 16);
 }
 
 // RL = computed dwords of the LAST chunk (SWL/2: all of it; less: the caller guarantees m - (nchunks - 1) * SWL <= 2 * RL and a needle without NUL)
 template <int SWL, bool UPPER, int RL = SWL / 2>
 __device__ __forceinline__ u32 dp_multi_chunk_t(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const CfTables& tab,
-                                                u32* __restrict__ scratch, u32 sstride, u32 sidx) {
+                                                u32* __restrict__ scratch, u32 sstride, u32 sidx, u32 rpitch) {
     constexpr int NW = SWL / 2;
     const u32 nchunks = (m + SWL - 1) / SWL;
     const u32 nfull = RL < NW ? nchunks - 1 : nchunks;
     u32 mx = 0;
     u32 cprev = 0;  // class (x 2) of the previous chunk's last lane; lane -1 of chunk 0: no delimiter, no lowercase letter
 #pragma unroll 1
-    for (u32 ch = 0; ch < nfull; ch++) cfm_chunk<SWL, UPPER, NW>(nd, th, m, ch, ch + 1 == nchunks, include_prefix, tab, scratch, sstride, sidx, mx, cprev);
-    if (RL < NW) cfm_chunk<SWL, UPPER, RL>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, mx, cprev);
+    for (u32 ch = 0; ch < nfull; ch++) cfm_chunk<SWL, UPPER, NW>(nd, th, m, ch, ch + 1 == nchunks, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
+    if (RL < NW) cfm_chunk<SWL, UPPER, RL>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
     return max(mx & 0xFFFF, mx >> 16);
 }

@@ -185,6 +185,7 @@ FzbKnobs parse_knobs() {
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
     k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
     k.generic_wgs = std::max(1, num("FZB_GENERIC_WGS", 12));
+    k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
     k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
     k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");

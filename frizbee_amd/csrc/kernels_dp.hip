@@ -525,16 +525,28 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi(const u8* __restrict__ by
     }
 }
 
+// Where a thread of the dp_cfm.h kernels parks its rows between two chunks: its workgroup's LDS when the launch gave it room (`park_dw` =
+// dwords per parked row, fzb_park_lds_dwords: needles of a few rows), else its column of the global slab.  In LDS a row's round trip costs
+// an LDS access instead of an L2 one - with one or two waves per SIMD and a dependent load per needle row and chunk that latency is the
+// kernel (paths-shaped list: the multi-chunk slice alone 44.6 us for 27 k windows of two or three chunks).
+struct ParkAt { u32* base; u32 sstride, sidx, rpitch; };
+__device__ __forceinline__ ParkAt park_at(u32* scratch, u32 nthreads, u32 gtid, u32 park_dw, u32 nw) {
+    extern __shared__ __attribute__((aligned(16))) u32 s_park[];
+    if (park_dw) return ParkAt{s_park, blockDim.x, threadIdx.x, park_dw * blockDim.x};
+    return ParkAt{scratch, nthreads, gtid, nw * nthreads};
+}
+
 // the same list through dp_cfm.h's form (LaunchCfg::cfm_ok); bonuses from the LDS tables as in the other dp_cf.h kernels
 template <int SWL, bool UPPER, typename ET>
 __global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
                                                       const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
-                                                      fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
+                                                      fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch, u32 park_dw) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
     const u32 nlist = *n_list_ptr;
     const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const ParkAt pk = park_at(scratch, nthreads, gtid, park_dw, SWL / 2);
     for (u32 q = gtid; q < nlist; q += nthreads) {
         const u32 opos = list[4 * q], ws = list[4 * q + 1], we = list[4 * q + 2], li = list[4 * q + 3];
         if (opos >= capacity) continue;
@@ -545,7 +557,7 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ 
         const u32 sp = ws ? ws - 1 : 0;
         const bool include_exact = sp == 0 && we == L;
         const u32 m = we - sp;
-        u32 score = dp_multi_chunk_t<SWL, UPPER>(nd, hay + sp, m, sp == 0, tab, scratch, nthreads, gtid);
+        u32 score = dp_multi_chunk_t<SWL, UPPER>(nd, hay + sp, m, sp == 0, tab, pk.base, pk.sstride, pk.sidx, pk.rpitch);
         bool exact = include_exact && m == (u32)nd.nbytes;
         if (exact)
             for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
@@ -565,11 +577,13 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ 
 template <int SWL, bool UPPER>
 __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock, u32 vgrid, u32 index_offset,
                                                  const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists, u32 list_stride,
-                                                 const u32* __restrict__ counts, const NeedleDev& nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
+                                                 const u32* __restrict__ counts, const NeedleDev& nd, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch,
+                                                 u32 park_dw) {
     // positions [0, e3) class 3 (the whole last chunk), [e3, e2) class 2, [e2, e1) class 1, [e1, e0) class 0
     const u32 e3 = __builtin_amdgcn_readfirstlane(counts[3]), e2 = e3 + __builtin_amdgcn_readfirstlane(counts[2]), e1 = e2 + __builtin_amdgcn_readfirstlane(counts[1]),
               e0 = e1 + __builtin_amdgcn_readfirstlane(counts[0]);
     const u32 nthreads = vgrid * blockDim.x, gtid = vblock * blockDim.x + threadIdx.x;
+    const ParkAt pk = park_at(scratch, nthreads, gtid, park_dw, SWL / 2);
     for (u32 q = gtid; q < e0; q += nthreads) {
         const u32 cls = q < e3 ? 3u : q < e2 ? 2u : q < e1 ? 1u : 0u;
         const u32 base = cls == 3 ? 0u : cls == 2 ? e3 : cls == 1 ? e2 : e1;
@@ -582,7 +596,7 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
         const bool include_exact = (w.y >> 31) != 0;
         const u32 m = (w.y & 0x7FFFFFFFu) - sp;
         const u32 wcls = __builtin_amdgcn_readfirstlane(cls);  // lanes are in position order: the first active lane holds the widest class
-        u32 score = dp_multi_chunk_tc<SWL, UPPER>(nd, hay + sp, m, sp == 0, tab, scratch, nthreads, gtid, wcls);
+        u32 score = dp_multi_chunk_tc<SWL, UPPER>(nd, hay + sp, m, sp == 0, tab, pk.base, pk.sstride, pk.sidx, pk.rpitch, wcls);
         bool exact = include_exact && m == (u32)nd.nbytes;
         if (exact)
             for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
@@ -599,11 +613,11 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
 template <int SWL, bool UPPER>
 __global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
                                                        u32 list_stride, const u32* __restrict__ counts, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                       u32* __restrict__ scratch) {
+                                                       u32* __restrict__ scratch, u32 park_dw) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
-    dp_multi_tc_body<SWL, UPPER>(tab, blockIdx.x, gridDim.x, index_offset, items, meta, lists, list_stride, counts, nd, out, capacity, scratch);
+    dp_multi_tc_body<SWL, UPPER>(tab, blockIdx.x, gridDim.x, index_offset, items, meta, lists, list_stride, counts, nd, out, capacity, scratch, park_dw);
 }
 
 // Small lists: the three single-chunk classes and the multi-chunk tail classes in ONE launch - the grid is cut into four slices, a workgroup
@@ -613,12 +627,12 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(u32 index_offset, cons
 template <int SWL, bool UPPER>
 __global__ __launch_bounds__(128, 2) void k2_classes_all(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
                                                       u32 list_stride, const u32* __restrict__ counters, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                      u32* __restrict__ scratch, u32 gm, u32 gc) {
+                                                      u32* __restrict__ scratch, u32 gm, u32 gc, u32 park_dw) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
     u32 b = blockIdx.x;
-    if (b < gm) { dp_multi_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch); return; }
+    if (b < gm) { dp_multi_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch, park_dw); return; }
     b -= gm;
     if (b < gc) { dp_class_body<SWL, UPPER, SWL / 2>(tab, b, gc, index_offset, items, meta, lists + 2 * (size_t)list_stride, &counters[10], nd, out); return; }
     b -= gc;
@@ -627,12 +641,23 @@ __global__ __launch_bounds__(128, 2) void k2_classes_all(u32 index_offset, const
     dp_class_body<SWL, UPPER, SWL / 4>(tab, b, gc, index_offset, items, meta, lists, &counters[8], nd, out);
 }
 
+// dwords per parked row when the dp_cfm.h kernels (128 threads) keep a needle's parked rows in LDS, 0 when they go to the global slab: a row
+// is the top half of a chunk's final vector (SWL/4 dwords, or half of that packed to bytes when the scores fit a byte) and one word of
+// flags; the budget (FZB_PARK_LDS_KB, default 37: four workgroups per CU beside their tables) holds 8 rows of byte scores at 64 lanes.
+static u32 fzb_park_lds_dwords(const NeedleDev& nd, int sw_lanes) {
+    const u32 ht = (u32)sw_lanes / 4;
+    const u32 dw = (nd.lane_mask == 0xFF ? ht / 2 : ht) + 1;
+    const size_t bytes = (size_t)nd.rows * dw * 128 * 4;
+    return bytes <= (size_t)fzb_knobs().park_lds_kb * 1024 ? dw : 0u;
+}
+
 // gm workgroups for the multi-chunk lists (the scratch slab is sized for them: ensure_dp_scratch), gc for each single-chunk class
 void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* lists, u32 list_stride, const u32* counters,
                             const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int gm, int gc, hipStream_t st) {
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-#define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), 0, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc)
+    const u32 park_dw = fzb_park_lds_dwords(nd, sw_lanes);
+#define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), (size_t)nd.rows * park_dw * 128 * 4, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc, park_dw)
 #define FZB_K2A_U(SWL) do { if (upper) FZB_K2A(SWL, true); else FZB_K2A(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2A_U(64); break;
@@ -646,7 +671,8 @@ void fzb_launch_dp_multi_classes(const CorpusDev& c, u64 first, u32 index_offset
                                  const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st) {
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-#define FZB_K2TC(SWL, U) hipLaunchKernelGGL((k2d_dp_multi_tc<SWL, U>), dim3(grid), dim3(128), 0, st, index_offset, items, (const uint4*)win, lists, list_stride, counts, nd, out, capacity, scratch)
+    const u32 park_dw = fzb_park_lds_dwords(nd, sw_lanes);
+#define FZB_K2TC(SWL, U) hipLaunchKernelGGL((k2d_dp_multi_tc<SWL, U>), dim3(grid), dim3(128), (size_t)nd.rows * park_dw * 128 * 4, st, index_offset, items, (const uint4*)win, lists, list_stride, counts, nd, out, capacity, scratch, park_dw)
 #define FZB_K2TC_U(SWL) do { if (upper) FZB_K2TC(SWL, true); else FZB_K2TC(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2TC_U(64); break;
@@ -663,7 +689,8 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
     if (mode == 2) {
         bool upper = false;
         for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-#define FZB_K2T(SWL, U, ET) hipLaunchKernelGGL((k2d_dp_multi_t<SWL, U, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch)
+        const u32 park_dw = fzb_park_lds_dwords(nd, sw_lanes);
+#define FZB_K2T(SWL, U, ET) hipLaunchKernelGGL((k2d_dp_multi_t<SWL, U, ET>), dim3(grid), dim3(128), (size_t)nd.rows * park_dw * 128 * 4, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, park_dw)
 #define FZB_K2T_ET(SWL, U) do { if (c.ends_u64) FZB_K2T(SWL, U, u64); else FZB_K2T(SWL, U, u32); } while (0)
 #define FZB_K2T_U(SWL) do { if (upper) FZB_K2T_ET(SWL, true); else FZB_K2T_ET(SWL, false); } while (0)
         switch (sw_lanes) {

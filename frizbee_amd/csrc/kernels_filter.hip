@@ -688,64 +688,75 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The view's OUTLIERS (CorpusDev::vlong: the few haystacks beyond 256 bytes, which have no vectors in the view): one thread each over the
-// canonical layout with the same class-composite automaton, its decision OR-ed into the bitmap the view kernel wrote and added to the
-// tile's count.  Launched behind k1_cdfa_view on the same stream; a list without outliers does not launch it.
+// The view's OUTLIERS (CorpusDev::vlong: the few haystacks beyond 256 bytes, which have no vectors in the view): decided from the canonical
+// layout with the same class-composite automaton, the decision OR-ed into the bitmap the view kernel wrote and added to the tile's count.
+// Launched behind k1_cdfa_view on the same stream; a list without outliers does not launch it.
+// One WAVE per outlier, because a thread walking 600 bytes alone is a chain of 38 loads and 150 dependent lookups (12 us for the 71
+// outliers of the Arabic-shaped list, half of what the view kernel takes for the other 285 516 haystacks): lane k takes vector k and
+// runs it from EVERY start state (ns x G/4.. independent lookups - the transition function of its 16 bytes, ns bytes in LDS), then the
+// wave composes the 64 functions in order: one dependent LDS byte per vector instead of a load and four lookups.
 // ---------------------------------------------------------------------------------------------------
 template <typename ET, bool SAN, int G>
 __global__ __launch_bounds__(256) void k1_cdfa_outliers(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count, const u32* __restrict__ vlong, u32 n_long,
-                                                        const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG, u32 min_len, u32 dead, u32 acc_lo,
+                                                        const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG, u32 ns, u32 min_len, u32 dead, u32 acc_lo,
                                                         u64* __restrict__ bitmap, u32* __restrict__ tile_counts) {
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 tab_bytes = (cdfa_bytes + 15u) & ~15u;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     dfa_require_lds_base0(lds);
-    for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
+    for (u32 i = tid * 4; i < tab_bytes; i += blockDim.x * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
     __syncthreads();
+    u8* fn = lds + tab_bytes + (size_t)wave * ns * 64;  // fn[s * 64 + k]: where vector k of the current round takes state s
     const u32 deadv = dead * 0x01010101u;
     auto cls_of = [](u32 b) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)b; };
     auto comp_at = [](u32 a) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)(256u + a); };
-    for (u32 j = blockIdx.x * 256u + tid; j < n_long; j += gridDim.x * 256u) {
+    const u32 wpw = blockDim.x >> 6;  // waves per workgroup: 4, or 1 when four waves' function tables do not fit
+    for (u32 j = blockIdx.x * wpw + wave; j < n_long; j += gridDim.x * wpw) {
         const u64 gi = vlong[j];
-        if (gi < first || gi >= first + count) continue;
+        if (gi < first || gi >= first + count) continue;  // wave-uniform
         const u32 li = (u32)(gi - first);
         u64 hs;
         u32 hl;
         haystack_span(ends, gi, hs, hl);
         const uint4* vp = (const uint4*)(bytes + hs);
+        const u32 nvec = (hl + 15u) >> 4;
         u32 st = 0;
-        for (u32 v = 0; 16 * v < hl; v++) {
-            const uint4 q = vp[v];
-            u32 w[4] = {q.x, q.y, q.z, q.w};
-            if (SAN) {
-                const u32 rem = hl - 16 * v;
+        for (u32 base = 0; base < nvec; base += 64) {
+            const u32 v = base + lane;
+            if (v < nvec) {
+                const uint4 q = vp[v];
+                u32 w[4] = {q.x, q.y, q.z, q.w};
+                if (SAN) {
+                    const u32 rem = hl - 16 * v;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const u32 nvb = rem > 4u * t ? rem - 4u * t : 0u;
+                        const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
+                        w[t] = (w[t] & mask) | (deadv & ~mask);
+                    }
+                }
+                u32 off[G == 4 ? 4 : 8];
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
-                    const u32 nvb = rem > 4u * t ? rem - 4u * t : 0u;
-                    const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
-                    w[t] = (w[t] & mask) | (deadv & ~mask);
+                    const u32 c0 = cls_of(w[t] & 0xFF), c1 = cls_of((w[t] >> 8) & 0xFF), c2 = cls_of((w[t] >> 16) & 0xFF), c3 = cls_of(w[t] >> 24);
+                    if (G == 4) off[t] = c0 + K * (c1 + K * (c2 + K * c3));
+                    else off[2 * t] = c0 + K * c1, off[2 * t + 1] = c2 + K * c3;
+                }
+                for (u32 s0 = 0; s0 < ns; s0++) {
+                    u32 t = s0;
+#pragma unroll
+                    for (int q4 = 0; q4 < (G == 4 ? 4 : 8); q4++) t = comp_at(t * KG + off[q4]);
+                    fn[s0 * 64 + lane] = (u8)t;
                 }
             }
-            u32 c[4][4];
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-                c[t][0] = cls_of(w[t] & 0xFF);
-                c[t][1] = cls_of((w[t] >> 8) & 0xFF);
-                c[t][2] = cls_of((w[t] >> 16) & 0xFF);
-                c[t][3] = cls_of(w[t] >> 24);
-            }
-            if (G == 4) {
-#pragma unroll
-                for (int t = 0; t < 4; t++) st = comp_at(st * KG + c[t][0] + K * (c[t][1] + K * (c[t][2] + K * c[t][3])));
-            } else {
-#pragma unroll
-                for (int t = 0; t < 4; t++) {
-                    st = comp_at(st * KG + c[t][0] + K * c[t][1]);
-                    st = comp_at(st * KG + c[t][2] + K * c[t][3]);
-                }
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const u32 steps = min(64u, nvec - base);
+            for (u32 k = 0; k < steps; k++) st = fn[st * 64 + k];  // (every lane walks the same chain: broadcast reads)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
-        if (hl >= min_len && st >= acc_lo) {
+        if (lane == 0 && hl >= min_len && st >= acc_lo) {
             atomicOr((unsigned long long*)&bitmap[li >> 6], 1ull << (li & 63));
             atomicAdd(&tile_counts[li / FZB_TILE], 1u);
         }
@@ -1061,9 +1072,11 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #undef FZB_K1V_S
 #undef FZB_K1V
                 if (c.n_long) {  // the haystacks beyond 256 bytes: decided from the canonical layout, OR-ed into the view kernel's bitmap
-                    const size_t lds_o = ((cdfa_bytes + 15) & ~(size_t)15) + 16;
-                    const int go = (int)std::max<u32>(1u, std::min<u32>((c.n_long + 255u) / 256u, 1024u));
-#define FZB_K1O(ET, SAN, G) hipLaunchKernelGGL((k1_cdfa_outliers<ET, SAN, G>), dim3(go), dim3(256), lds_o, st, c.bytes, (const ET*)c.ends, first, count, c.vlong, c.n_long, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts)
+                    const u32 ns_o = (cdfa_bytes - 256u) / kg;  // the automaton's states (the table is padded to 16 bytes: at most a phantom state more)
+                    const u32 wpw = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)4 * 64 * ns_o + 16 <= 60 * 1024 ? 4u : 1u;
+                    const size_t lds_o = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)wpw * 64 * ns_o + 16;
+                    const int go = (int)std::max<u32>(1u, std::min<u32>((c.n_long + wpw - 1) / wpw, 4096u));
+#define FZB_K1O(ET, SAN, G) hipLaunchKernelGGL((k1_cdfa_outliers<ET, SAN, G>), dim3(go), dim3(64 * wpw), lds_o, st, c.bytes, (const ET*)c.ends, first, count, c.vlong, c.n_long, cdfa, cdfa_bytes, (u32)cdfa_K, kg, ns_o, min_len, dead, acc, bitmap, tile_counts)
 #define FZB_K1O_G(ET, SAN) do { if (cdfa_G == 4) FZB_K1O(ET, SAN, 4); else FZB_K1O(ET, SAN, 2); } while (0)
                     if (c.ends_u64) { if (nul_safe) FZB_K1O_G(u64, false); else FZB_K1O_G(u64, true); }
                     else            { if (nul_safe) FZB_K1O_G(u32, false); else FZB_K1O_G(u32, true); }

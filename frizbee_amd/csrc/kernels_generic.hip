@@ -195,10 +195,28 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
             u32 maxs = 0;
             bool prev_last_lower = false, prev_last_delim = false;  // previous chunk's last lane (ascii.rs:55-56, 78, 95)
             u32 prev_cont = 0, prev_sm = 0;                         // unicode: previous chunk's continuation-gex / scalar-start vectors
+            // the chunk's bytes are requested one chunk ahead: a window of ten chunks is otherwise a chain of ten exposed load latencies (the
+            // longest window of a short queue IS the kernel's duration: 385 windows of the Arabic-shaped list, 15 us)
+            u32 nx0 = (active && (u32)lane < m) ? th[lane] : 0, nx1 = 0, nx2 = 0, nx3 = 0;
+            if (UNICODE) {
+                nx1 = (active && lane + 1u < m) ? th[lane + 1] : 0;
+                nx2 = (active && lane + 2u < m) ? th[lane + 2] : 0;
+                nx3 = (active && lane + 3u < m) ? th[lane + 3] : 0;
+            }
             for (u32 ch = 0; ch < nchunks; ch++) {
                 const u32 base = ch * SWL;
                 const u32 pos = base + lane;
-                const u32 b0 = (active && pos < m) ? th[pos] : 0;
+                const u32 b0 = nx0;
+                const u32 pb1 = nx1, pb2 = nx2, pb3 = nx3;
+                if (ch + 1 < nchunks) {
+                    const u32 np = pos + SWL;
+                    nx0 = (active && np < m) ? th[np] : 0;
+                    if (UNICODE) {
+                        nx1 = (active && np + 1 < m) ? th[np + 1] : 0;
+                        nx2 = (active && np + 2 < m) ? th[np + 2] : 0;
+                        nx3 = (active && np + 3 < m) ? th[np + 3] : 0;
+                    }
+                }
                 const bool lower = b0 >= 'a' && b0 <= 'z', upper = b0 >= 'A' && b0 <= 'Z', digit = b0 >= '0' && b0 <= '9';
                 const bool delim = !(lower || upper || digit || b0 > 127);
                 bool pl = __shfl_up((int)lower, 1), pd = __shfl_up((int)delim, 1);
@@ -216,9 +234,9 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                 u32 contgex = 0, smask = 0;
                 u32 cont_k[6], sm_k[6];
                 if (UNICODE) {
-                    b1 = (active && pos + 1 < m) ? th[pos + 1] : 0;
-                    b2 = (active && pos + 2 < m) ? th[pos + 2] : 0;
-                    b3 = (active && pos + 3 < m) ? th[pos + 3] : 0;
+                    b1 = pb1;
+                    b2 = pb2;
+                    b3 = pb3;
                     const bool valid = active && pos < m;
                     const bool cont = b0 > 0x7f && b0 < 0xc0 && valid;
                     sstart = !cont && valid;

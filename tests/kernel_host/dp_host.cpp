@@ -76,13 +76,15 @@ static int run_multi(const NeedleDev& nd, const u8* hay, u32 m, int include_pref
     CfTables tab;
     for (unsigned t = 0; t < 16; t++) { threadIdx.x = t; if (upper) cf_build_tables<true>(nd, tab); else cf_build_tables<false>(nd, tab); }
     threadIdx.x = 0;
+    u32 rp = (u32)(SWL / 2);  // the global slab's row pitch; forms 16 / 17 / 18 = 6 / 7 / 8 with the LDS layout's pitch (fzb_park_lds_dwords)
+    if (form >= 16) { rp = (nd.lane_mask == 0xFF ? SWL / 8 : SWL / 4) + 1; form -= 10; }
     if (form == 7 || form == 8) {  // the last chunk's NUL lanes in closed form: dp_multi_chunk_tc with the narrowest class that holds the tail (7) / one class wider (8)
         const u32 tail = m - ((m + SWL - 1) / SWL - 1) * SWL;  // bytes in the last chunk, 1 ..= SWL
         int cls = (int)((tail - 1) / (SWL / 4)) + (form == 8 ? 1 : 0);
         if (cls > 3) cls = 3;
-        return upper ? (int)dp_multi_chunk_tc<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, (u32)cls) : (int)dp_multi_chunk_tc<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, (u32)cls);
+        return upper ? (int)dp_multi_chunk_tc<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, rp, (u32)cls) : (int)dp_multi_chunk_tc<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, rp, (u32)cls);
     }
-    return upper ? (int)dp_multi_chunk_t<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0) : (int)dp_multi_chunk_t<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0);
+    return upper ? (int)dp_multi_chunk_t<SWL, true>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, rp) : (int)dp_multi_chunk_t<SWL, false>(nd, buf.data(), m, include_prefix, tab, scratch, 1, 0, rp);
 }
 
 // the unicode single-chunk scorer (dp_unicode.h): rows are needle scalars (bytes, flipped bytes, UTF-8 length per row)

@@ -194,7 +194,7 @@ def test_multi_chunk_windows_both_forms_match_the_oracle(swl):
         ip = rng.random() < 0.5
         u8 = _fits(n, sc)
         want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, lanes=swl, is_u8=u8)
-        for form in (5, 6, 7, 8):
+        for form in (5, 6, 7, 8, 16, 17, 18):  # 16..18: 6..8 with the parked rows at the LDS layout's pitch
             got = K.dp_multi(needle, hay, sc, cs, ip, swl, form, u8)
             assert got == want, (needle, hay, sc, cs, ip, swl, form, got, want)
 
@@ -241,7 +241,7 @@ def test_multi_chunk_last_chunk_padding_in_closed_form(swl):
         ip = rng.random() < 0.5
         u8 = _fits(n, sc)
         want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, lanes=swl, is_u8=u8)
-        for form in (6, 7, 8):
+        for form in (6, 7, 8, 17):
             got = K.dp_multi(needle, hay, sc, cs, ip, swl, form, u8)
             assert got == want, (needle, hay, sc, cs, ip, swl, form, got, want)
         checked += 1
