@@ -100,14 +100,6 @@ struct fzb_match_rec {  // == fzb_match; `_pad` carries the valid flag between k
 };
 
 // Per-call device workspace (owned by the matcher, grown on demand)
-// Compaction INSIDE the streaming filter (k1_dfa: lists of haystacks up to 32 bytes; kernels_filter.hip "Compaction inside k1_dfa"): tiles
-// are handed out in index order by a ticket counter, every tile publishes its survivor count, and the workgroup writes its tile's survivor
-// indices itself - k_compact1's launch (6 us of the 100 us C2 step) goes away.  `lookback` = the ticket counter (first 64 bytes), one u64
-// per tile (published prefixes), one u32 per tile (published counts); all epoch-tagged, so nothing is cleared between launches; epoch and
-// ticket_base advance with every launch.
-struct FusedCompactState { u64* lookback; u32 epoch, ticket_base, ntiles_cap; };
-struct FusedCompactOut { u32* out_idx; u32* total_out; u32* total_out2; FusedCompactState* state; };  // total_out(2) = reset_counters + 0 (+ 1, or null)
-struct FusedCompactDev { u32* out_idx; u32* total_out; u32* total_out2; u64* status; u32* acount; u32* ticket; u32 ticket_base, epoch; };
 struct Workspace {
     u64* bitmap;        // count/64 words: filter decisions
     u32* tile_counts;   // ntiles
@@ -139,7 +131,6 @@ struct Workspace {
     // filter -> scorer handoff on ragged lists (k1_cdfa_view writes, k2w_classify reads; DESIGN.md section 3 "Handoff"): per 1024-haystack
     // tile FZB_STAGE_UNITS 16-byte units of the accepted haystacks' vectors (packed from the front in arrival order) and one header entry per
     // survivor in INDEX order (unit offset inside the tile | length << 16; 0xFFFF = not staged: the tile's units ran out)
-    FusedCompactState fused;  // compaction inside k1_dfa: ticket counter + per-tile look-back words (sized with tile_counts), the launch counters
     u8* stage;
     u32* stage_hdr;
     u32* tile_prefix;   // survivors before each tile (written by k_compact1): a survivor's rank inside its tile = its rank - tile_prefix[tile]
@@ -203,13 +194,10 @@ struct RejectOut {
 #include <hip/hip_runtime.h>
 // kernels_filter.hip
 // returns true when the kernel that ran also staged the accepted haystacks' vectors into `so` (only the view kernel does)
-#define FZB_FILTER_STAGED 1u
-#define FZB_FILTER_COMPACTED 2u
-// returns FZB_FILTER_* bits: what the launched kernel did beyond the bitmap and the tile counts
-u32 fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
+bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m = nullptr, u32* tile_counts_m = nullptr,
                        u64* reject_bits = nullptr, u32* tile_rejects = nullptr, int nul_safe = 0, int acc_lo = -1, const u8* cdfa = nullptr, u32 cdfa_bytes = 0,
-                       int cdfa_K = 0, int cdfa_G = 0, const StageOut* so = nullptr, const FusedCompactOut* fco = nullptr);
+                       int cdfa_K = 0, int cdfa_G = 0, const StageOut* so = nullptr);
 void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* reject_count, u32* rej_prefix, hipStream_t st);
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st,
                          u32* tile_prefix_out = nullptr, u32* total_out2 = nullptr);

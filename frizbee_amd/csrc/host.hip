@@ -180,13 +180,12 @@ FzbKnobs parse_knobs() {
     k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
     k.debug_sync = set("FZB_DEBUG_SYNC");
     k.no_handoff = set("FZB_NO_HANDOFF");
-    k.no_fused_compact = set("FZB_NO_FUSED_COMPACT");
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
     k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
     k.generic_wgs = std::max(1, num("FZB_GENERIC_WGS", 12));
-    k.dfa_wgs = std::max(1, std::min(8, num("FZB_DFA_WGS", 8)));
+    k.dfa_wgs = std::max(1, std::min(8, num("FZB_DFA_WGS", 6)));
     k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
     k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
@@ -226,7 +225,7 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa, w.stage, w.stage_hdr, w.tile_prefix, w.fused.lookback};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa, w.stage, w.stage_hdr, w.tile_prefix};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
@@ -791,10 +790,6 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 2;
     HIPCHK(dev_alloc((void**)&w.bitmap, (cap / 64 + 17) * 8));
     HIPCHK(dev_alloc((void**)&w.tile_counts, ntiles * 4));
-    HIPCHK(dev_alloc((void**)&w.fused.lookback, 64 + ntiles * 12));  // compaction inside k1_dfa: ticket counter + per tile a prefix word and a count word, epoch-tagged (cleared once)
-    HIPCHK(hipMemset(w.fused.lookback, 0, 64 + ntiles * 12));
-    w.fused.epoch = w.fused.ticket_base = 0;
-    w.fused.ntiles_cap = (u32)ntiles;
     HIPCHK(dev_alloc((void**)&w.surv_idx, cap * 4));
     HIPCHK(dev_alloc((void**)&w.overflow, cap * 16));
     HIPCHK(dev_alloc((void**)&w.counters, 64));
@@ -1046,7 +1041,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
         u32* cnt_c = w.counters;
         if (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode && !items_in)  // the streaming DFA filter over the needle's KMP automaton
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * kn.dfa_wgs, st, nullptr, nullptr, nullptr, nullptr, lc.pad_ok,
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr, nullptr, nullptr, lc.pad_ok,
                               -1, m->cdfa_src == 1 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         else
             fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
@@ -1105,19 +1100,17 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // 1.3e8 random single-chunk cases without a deviation).  Then nothing is marginal and the decide pass is not launched.
         const bool single_chunk = cd.max_len <= (u32)lc.pf_lanes;
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        const FusedCompactOut fco{w.surv_idx, &cnt_c[0], nullptr, &w.fused};
-        u32 fdone = 0;
         if (single_chunk && m->lcs_states)  // the LCS criterion as an automaton in the streaming DFA kernel
-            fdone = fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * kn.dfa_wgs, st, nullptr,
-                                      nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, nullptr, &fco);
+            fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
+                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         else if (single_chunk)
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * kn.dfa_wgs, st);
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
         else
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * kn.dfa_wgs, st, w.bitmap_m,
+            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, w.bitmap_m,
                               w.tile_counts_m, w.reject_bits, w.tile_rejects);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter(lcs)");
-        if (!(fdone & FZB_FILTER_COMPACTED)) fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
         if (!single_chunk) {
             fzb_launch_compact1(w.bitmap_m, w.tile_counts_m, cnt, nullptr, nullptr, w.marg_list, &cnt_c[5], cus * 4, st);
             FZB_STAGE("compact1 x2");
@@ -1134,13 +1127,11 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     } else if (m->uni_dfa_states && lc.bias_ok && !trace) {
         // unicode path, 0 typos: the exact prefilter as a byte-level DFA in the streaming filter; the scorer finds the window itself
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        // (kept by the exact prefilter = the filter's survivors: whoever compacts writes the total to both counters)
-        const FusedCompactOut fco{w.surv_idx, &cnt_c[0], &cnt_c[1], &w.fused};
-        const u32 fdone = fzb_launch_filter(cd, first, cnt, w.table, w.uni_dfa, lc.dead_byte, m->uni_dfa_states - 1, 1, 0, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * kn.dfa_wgs, st,
-                                            nullptr, nullptr, nullptr, nullptr, lc.pad_ok, -1, m->cdfa_src == 2 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, nullptr, &fco);
+        fzb_launch_filter(cd, first, cnt, w.table, w.uni_dfa, lc.dead_byte, m->uni_dfa_states - 1, 1, 0, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
+                          nullptr, nullptr, nullptr, lc.pad_ok, -1, m->cdfa_src == 2 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter(unicode dfa)");
-        if (!(fdone & FZB_FILTER_COMPACTED)) fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st, nullptr, &cnt_c[1]);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st, nullptr, &cnt_c[1]);  // (kept by the exact prefilter = the filter's survivors)
         FZB_STAGE("compact1");
         items = w.surv_idx;
         uni_exact = true;
@@ -1157,18 +1148,15 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         if (want_stage && (rc = ensure_stage(m, count))) return rc;  // first use only (or fzb_matcher_reserve)
         const StageOut so{want_stage ? w.stage : nullptr, want_stage ? w.stage_hdr : nullptr};
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        const FusedCompactOut fco{w.surv_idx, &cnt_c[0], nullptr, &w.fused};
-        u32 fdone;
         if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
-            fdone = fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * kn.dfa_wgs, st, nullptr,
-                                      nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, nullptr, &fco);
+            fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
+                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         else
-            fdone = fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * kn.dfa_wgs, st, nullptr, nullptr,
-                                      nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, want_stage ? &so : nullptr, &fco);
-        staged = (fdone & FZB_FILTER_STAGED) != 0;
+            staged = fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
+                                       nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, want_stage ? &so : nullptr);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
         FZB_STAGE("filter");
-        if (!(fdone & FZB_FILTER_COMPACTED)) fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * kn.compact_grid_mul, st, staged ? w.tile_prefix : nullptr);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * kn.compact_grid_mul, st, staged ? w.tile_prefix : nullptr);
         FZB_STAGE("compact1");
         items = w.surv_idx;
     }

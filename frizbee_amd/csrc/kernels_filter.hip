@@ -135,118 +135,24 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
 // from HBM up front.  The table has (rows + 1) * 256 bytes; 4 byte values share a dword, so the
 // alphanumerics of one state row spread over distinct LDS banks.
 // ---------------------------------------------------------------------------------------------------
-// Compaction inside k1_dfa (FusedCompactDev): every tile publishes its survivor count (u32: the launch's epoch << 11 | count) as soon as it
-// is filtered, and - one tile LATER, when every tile before it has long been counted - finds "survivors before me" as the published
-// prefix of the tile FZB_LB_WINDOW before it (u64: epoch << 32 | survivors up to and including that tile) plus the counts of the tiles in
-// between, read with one round of loads.  No tile waits for a NEIGHBOUR's prefix: the chain of a classic decoupled look-back (measured
-// first: with 2048 workgroups finishing their tiles in lockstep every round of tiles walked back 32 windows one after the other, filter
-// 56 -> 184 us) does not exist.  The window covers every tile that can be in flight (workgroups resident on the chip).
-#define FZB_LB_WINDOW 2048u
-#define FZB_LB_SPINS (1u << 22)  // ~ seconds: a count that is never published is a bug - trap (the launch fails loudly) instead of hanging the device
-__device__ __forceinline__ u64 lb_load64(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ u32 lb_load32(const u32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void lb_store64(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void lb_store32(u32* p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-template <typename ET, bool FC>
+template <typename ET>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                               const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
-                                              u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 ulen, const FusedCompactDev fc) {
+                                              u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 ulen) {
     // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
-    // compaction kernel reads it (FC: the totals this kernel's last tile writes - counters 0 and, if asked for, 1 - are left alone)
-    if (blockIdx.x == 0 && threadIdx.x < 16 && (!FC || threadIdx.x >= (fc.total_out2 ? 2u : 1u))) reset_counters[threadIdx.x] = 0;
+    // compaction kernel reads it
+    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
     // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
     u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
-    // FC: the next tile's ticket, and per tile parity (a tile's survivors are written while the next tile is already filtered) the tile's
-    // count, its 16 decision words and their popcount prefix; a reduction's partial sums and result
-    u32& s_next = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows) + 4);
-    u32* const s_tc = (u32*)(dfa + FZB_DFA_LDS_BYTES(rows) + 8);
-    u64* const s_words = (u64*)(dfa + FZB_DFA_LDS_BYTES(rows) + 16);
-    u32* const s_wpre = (u32*)(dfa + FZB_DFA_LDS_BYTES(rows) + 16 + 2 * 16 * 8);
-    u32* const s_red = (u32*)(dfa + FZB_DFA_LDS_BYTES(rows) + 16 + 2 * 16 * 8 + 2 * 16 * 4);  // [4] partial sums, [4] = survivors before the tile
     const int tid = threadIdx.x;
     dfa_require_lds_base0(dfa);
     dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    u32 nxt = 0;
-    u32 prev = 0xFFFFFFFFu;  // FC: the tile whose survivors are still to be written (parity: the other one), and its decision words
-    u64 sb[4] = {0, 0, 0, 0};
-    // the previous tile's survivors: "survivors before it" from the published counts, then the index list
-    auto flush = [&](u32 t, u32 par) {
-        const int lane = lane_id(), wave = tid >> 6;
-        const u32 start = t >= FZB_LB_WINDOW ? t - FZB_LB_WINDOW + 1 : 0u;  // the counts of tiles [start, t): at most FZB_LB_WINDOW - 1 = 8 per thread,
-        const u32 n = t - start;                                            // all requested together
-        const u32 etag = fc.epoch;
-        u32 part = 0;
-        for (u32 spins = 0;; spins++) {
-            u32 v[8];
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const u32 k = (u32)tid + 256u * j;
-                v[j] = k < n ? lb_load32(&fc.acount[start + k]) : (etag << 11);
-            }
-            part = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                ok = ok && (v[j] >> 11) == etag;
-                part += v[j] & 0x7FFu;
-            }
-            if (ok) break;
-            if (spins > FZB_LB_SPINS) __builtin_trap();
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (tid == 0 && t >= FZB_LB_WINDOW) {
-            u64 pv;
-            for (u32 spins = 0; ((pv = lb_load64(&fc.status[t - FZB_LB_WINDOW])) >> 32) != (u64)etag; spins++) {
-                if (spins > FZB_LB_SPINS) __builtin_trap();
-                __builtin_amdgcn_s_sleep(2);
-            }
-            part += (u32)pv;
-        }
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-        if (lane == 0) s_red[wave] = part;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
         __syncthreads();
-        const u32 excl = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-        const u32 tc = s_tc[par];
-        if (tid == 0) {
-            lb_store64(&fc.status[t], ((u64)etag << 32) | (u64)(excl + tc));
-            if (t + 1 == ntiles) {  // the last tile publishes the total (what k_compact1's last workgroup did)
-                *fc.total_out = excl + tc;
-                if (fc.total_out2) *fc.total_out2 = excl + tc;
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++)
-            if ((sb[p] >> lane) & 1) fc.out_idx[excl + s_wpre[par * 16 + p * 4 + wave] + (u32)__popcll(sb[p] & ((1ull << lane) - 1))] = t * FZB_TILE + p * 256 + tid;
-        __syncthreads();
-    };
-    if (FC) {
-        if (tid == 0) { s_cnt = 0; s_next = fc.ticket ? atomicAdd(fc.ticket, 1u) - fc.ticket_base : 0u; }
-        __syncthreads();
-    }
-    u32 it = 0;
-    for (;; it++) {
-        u32 tile;
-        if (FC) {
-            // tiles in ticket order: whoever holds a tile is running, so every tile before it is held by a running workgroup too and the
-            // look-back below cannot wait for a workgroup that has no slot; the NEXT ticket is drawn now and its round trip hides behind this tile
-            if (fc.ticket) {
-                tile = s_next;
-                if (tile >= ntiles) break;
-                if (tid == 0) nxt = atomicAdd(fc.ticket, 1u) - fc.ticket_base;
-            } else {  // EXPERIMENT (FZB_FUSED_STATIC=1): static assignment - safe only while every workgroup of the grid is resident
-                tile = blockIdx.x + it * gridDim.x;
-                if (tile >= ntiles) break;
-            }
-        } else {
-            tile = blockIdx.x + it * gridDim.x;
-            if (tile >= ntiles) break;
-            if (tid == 0) s_cnt = 0;
-            __syncthreads();
-        }
         u64 hs[4];
         u32 hl[4];
         uint4 v0[4], v1[4];
@@ -288,56 +194,23 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
             for (int p = 0; p < 4; p++)
                 if (hl[p] > 16) st[p] = dfa_partial(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
         }
-        const int lane = lane_id(), wave = tid >> 6;
-        const u32 par = it & 1u;
         u32 cnt = 0;
-        u64 bb[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             const u32 L = hl[p];
             const u32 li = tile * FZB_TILE + p * 256 + tid;
             const bool matched = li < count && L >= min_len && st[p] >= acc_lo;
             const u64 b = __ballot(matched);
-            bb[p] = b;
-            if (lane == 0) {
+            if (lane_id() == 0) {
                 bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
                 cnt += __popcll(b);
-                if (FC) s_words[par * 16 + p * 4 + wave] = b;
             }
         }
-        if (lane == 0 && cnt) atomicAdd(&s_cnt, cnt);
+        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
         __syncthreads();
-        if (!FC) {
-            if (tid == 0) tile_counts[tile] = s_cnt;
-            __syncthreads();
-            continue;
-        }
-        if (wave == 0) {
-            const u32 tc = s_cnt;
-            // the words' popcount prefix (a survivor's rank inside the tile = its word's prefix + the set bits below it)
-            const u32 wc = lane < 16 ? (u32)__popcll(s_words[par * 16 + lane]) : 0u;
-            u32 incl = wc;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const u32 v = __shfl_up(incl, off);
-                if (lane >= off) incl += v;
-            }
-            if (lane < 16) s_wpre[par * 16 + lane] = incl - wc;
-            if (lane == 0) {
-                lb_store32(&fc.acount[tile], (fc.epoch << 11) | tc);  // published before anything is waited for
-                s_tc[par] = tc;
-                s_cnt = 0;
-                s_next = nxt;
-                tile_counts[tile] = tc;
-            }
-        }
-        if (prev != 0xFFFFFFFFu) flush(prev, par ^ 1u);  // (its first barrier also orders the LDS writes above)
-        else __syncthreads();
-        prev = tile;
-#pragma unroll
-        for (int p = 0; p < 4; p++) sb[p] = bb[p];
+        if (tid == 0) tile_counts[tile] = s_cnt;
+        __syncthreads();
     }
-    if (FC && prev != 0xFFFFFFFFu) flush(prev, (it & 1u) ^ 1u);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1156,39 +1029,24 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // ---------------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from host.hip)
 // ---------------------------------------------------------------------------------------------------
-u32 fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
-                      u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe,
-                      int acc_lo, const u8* cdfa, u32 cdfa_bytes, int cdfa_K, int cdfa_G, const StageOut* so, const FusedCompactOut* fco) {
+bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
+                       u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe,
+                       int acc_lo, const u8* cdfa, u32 cdfa_bytes, int cdfa_K, int cdfa_G, const StageOut* so) {
     // mode 1: `dfa` has rows + 1 states, start state 0, and accepts in the states >= acc (the subsequence / unicode / KMP automata: the last
     // state; the LCS automaton of a typo configuration: every state whose LCS reaches the need)
     const u32 acc = acc_lo < 0 ? (u32)rows : (u32)acc_lo;
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
+    // (`grid` = 8 workgroups per CU = every wave slot; k1_dfa streams a little faster when it leaves some free: 6 per CU 54.3 us, 8 55.1,
+    // 5 56.4, 4 59.0 on the C2 list - FZB_DFA_WGS)
+    const int grid_dfa = std::max(1, std::min<int>(grid * fzb_knobs().dfa_wgs / 8, (int)ntiles));
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     if (mode == 1) {
         const size_t lds = (size_t)(rows + 1) * FZB_DFA_STRIDE + 16;  // table + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
-            FusedCompactDev fc{};
-            const bool fused = fco && fco->state && fco->state->lookback && ntiles <= fco->state->ntiles_cap && !fzb_knobs().no_fused_compact && fco->total_out == reset_counters &&
-                               (!fco->total_out2 || fco->total_out2 == reset_counters + 1);
-            if (fused) {
-                FusedCompactState& fs = *fco->state;
-                if (++fs.epoch >= (1u << 21)) {  // the counts' epoch tag has 21 bits: start over on clean words
-                    (void)hipMemsetAsync(fs.lookback, 0, 64 + (size_t)fs.ntiles_cap * 12, st);
-                    fs.epoch = 1;
-                    fs.ticket_base = 0;
-                }
-                fc = FusedCompactDev{fco->out_idx, fco->total_out, fco->total_out2, fs.lookback + 8, (u32*)(fs.lookback + 8 + fs.ntiles_cap), (u32*)fs.lookback, fs.ticket_base, fs.epoch};
-                fs.ticket_base += ntiles + (u32)grid;  // every tile draws one ticket, every workgroup one more to learn that it is done
-                if (getenv("FZB_FUSED_STATIC")) { fc.ticket = nullptr; fs.ticket_base -= ntiles + (u32)grid; }
-            }
-            const size_t lds_k = lds + (fused ? 16 + 2 * 16 * 8 + 2 * 16 * 4 + 32 : 0);
-#define FZB_K1D(ET, FC) hipLaunchKernelGGL((k1_dfa<ET, FC>), dim3(grid), dim3(256), lds_k, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len, fc)
-            if (c.ends_u64) { if (fused) FZB_K1D(u64, true); else FZB_K1D(u64, false); }
-            else            { if (fused) FZB_K1D(u32, true); else FZB_K1D(u32, false); }
-#undef FZB_K1D
-            if (fused) return FZB_FILTER_COMPACTED;
+            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid_dfa), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len);
+            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid_dfa), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len);
         } else {
             // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
             // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times).
@@ -1232,7 +1090,7 @@ u32 fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table
 #undef FZB_K1O_G
 #undef FZB_K1O
                 }
-                return (stg && !kn.cdfa_nodfa) ? FZB_FILTER_STAGED : 0u;
+                return stg && !kn.cdfa_nodfa;
             }
             if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2)) {
                 const size_t lds_c = ((cdfa_bytes + 15) & ~(size_t)15) + 16;
@@ -1246,7 +1104,7 @@ u32 fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table
                 else            { if (nul_safe) FZB_K1CD_G(u32, false); else FZB_K1CD_G(u32, true); }
 #undef FZB_K1CD_G
 #undef FZB_K1CD
-                return 0u;
+                return false;
             }
             const bool burst = kn.ragged_burst;  // false = the rolling form, for comparison
             const int bwgs = kn.ragged_wgs;
@@ -1256,14 +1114,14 @@ u32 fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table
                 if (c.ends_u64) { if (nul_safe) FZB_K1B(u64, false); else FZB_K1B(u64, true); }
                 else            { if (nul_safe) FZB_K1B(u32, false); else FZB_K1B(u32, true); }
 #undef FZB_K1B
-                return 0u;
+                return false;
             }
 #define FZB_K1R(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged<ET, 1, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
             if (c.ends_u64) { if (nul_safe) FZB_K1R(u64, false); else FZB_K1R(u64, true); }
             else            { if (nul_safe) FZB_K1R(u32, false); else FZB_K1R(u32, true); }
 #undef FZB_K1R
         }
-        return 0u;
+        return false;
     }
     const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
     if (mode == 2 && bitmap_m) {  // LCS filter with the "nothing to spare" bit (typo configurations on the short-haystack path)
@@ -1272,7 +1130,7 @@ u32 fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table
         if (c.ends_u64) { if (w64) FZB_K1M(u64, u64); else FZB_K1M(u32, u64); }
         else            { if (w64) FZB_K1M(u64, u32); else FZB_K1M(u32, u32); }
 #undef FZB_K1M
-        return 0u;
+        return false;
     }
 #define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, MargOut{}, c.uniform_len)
     if (c.ends_u64) {
@@ -1283,7 +1141,7 @@ u32 fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table
         else           { if (w64) FZB_K1(u64, 2, u32); else FZB_K1(u32, 2, u32); }
     }
 #undef FZB_K1
-    return 0u;
+    return false;
 }
 
 // Exclusive prefix of the per-tile reject counts (decide form of k2a_window) - only when something was rejected at all, which on

@@ -18,7 +18,6 @@ struct FzbKnobs {
     bool cdfa_nodfa = false;         // FZB_CDFA_NODFA=1       MEASUREMENT ONLY: the ragged filter's loads without the automaton (results meaningless)
     bool ragged_burst = true;        // FZB_RAGGED_BURST=0     rolling form of the canonical-layout ragged filter
     bool debug_sync = false;         // FZB_DEBUG_SYNC=1       synchronise and report after every stage of the pipeline
-    bool no_fused_compact = false;   // FZB_NO_FUSED_COMPACT=1 short lists: k_compact1 behind the streaming filter instead of the compaction inside k1_dfa
     bool no_handoff = false;         // FZB_NO_HANDOFF=1       ragged lists: classifier and scorers gather the survivors' bytes from the corpus (no staging)
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device
     bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint
@@ -34,7 +33,7 @@ struct FzbKnobs {
     int compact_grid_mul = 4;        // FZB_COMPACT_GRID_MUL   workgroups per CU of k_compact1
     int classify_per = 2;            // FZB_CLASSIFY_PER=1|4   survivors per thread of k2w_classify
     int dp_wgs_per_cu = 0;           // FZB_DP_WGS_PER_CU      fewer resident workgroups of the short scorer (0 = occupancy)
-    int dfa_wgs = 8;                 // FZB_DFA_WGS            workgroups per CU of the streaming filter on short / uniform lists (k1_dfa)
+    int dfa_wgs = 6;                 // FZB_DFA_WGS            workgroups per CU of the streaming filter on short / uniform lists (k1_dfa; 8 = every wave slot)
     int cdfa_wgs = 5;                // FZB_CDFA_WGS           workgroups per CU, class-composite filter on the canonical layout
     int view_wgs = 6;                // FZB_VIEW_WGS           workgroups per CU, filter over the view
     int ragged_wgs = 8;              // FZB_RAGGED_WGS         workgroups per CU, burst filter

@@ -53,8 +53,8 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_NO_TAIL_CLASSES": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),                      # four scorer launches on two streams
     ({"FZB_SMALL_LIST": "0", "FZB_NO_OVERLAP": "1"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_NO_FUSED_COMPACT": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=1)), ("uni", "éa", dict())]),  # k_compact1 behind k1_dfa
     ({"FZB_DFA_WGS": "3"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),
+    ({"FZB_DFA_WGS": "8"}, [("short", "deadbe", dict()), ("uni", "éa", dict())]),
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab
     ({"FZB_PARK_LDS_KB": "0", "FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_NO_HANDOFF": "1"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),
