@@ -185,7 +185,7 @@ FzbKnobs parse_knobs() {
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
     k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
     k.generic_wgs = std::max(1, num("FZB_GENERIC_WGS", 12));
-    k.dfa_wgs = std::max(1, std::min(8, num("FZB_DFA_WGS", 6)));
+    k.dfa_wgs = std::max(1, std::min(8, num("FZB_DFA_WGS", 8)));
     k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
     k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
     k.shard_inline = num("FZB_SHARD_INLINE", -1);

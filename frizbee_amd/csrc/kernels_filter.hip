@@ -1036,8 +1036,8 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
     // state; the LCS automaton of a typo configuration: every state whose LCS reaches the need)
     const u32 acc = acc_lo < 0 ? (u32)rows : (u32)acc_lo;
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    // (`grid` = 8 workgroups per CU = every wave slot; k1_dfa streams a little faster when it leaves some free: 6 per CU 54.3 us, 8 55.1,
-    // 5 56.4, 4 59.0 on the C2 list - FZB_DFA_WGS)
+    // (`grid` = 8 workgroups per CU = every wave slot; FZB_DFA_WGS: 6 per CU 54.3 us, 8 55.1, 5 56.4, 4 59.0 on the C2 list, but the unicode
+    // automaton's list - C5 - takes 1 us more at 6: the default stays 8)
     const int grid_dfa = std::max(1, std::min<int>(grid * fzb_knobs().dfa_wgs / 8, (int)ntiles));
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;

@@ -33,7 +33,7 @@ struct FzbKnobs {
     int compact_grid_mul = 4;        // FZB_COMPACT_GRID_MUL   workgroups per CU of k_compact1
     int classify_per = 2;            // FZB_CLASSIFY_PER=1|4   survivors per thread of k2w_classify
     int dp_wgs_per_cu = 0;           // FZB_DP_WGS_PER_CU      fewer resident workgroups of the short scorer (0 = occupancy)
-    int dfa_wgs = 6;                 // FZB_DFA_WGS            workgroups per CU of the streaming filter on short / uniform lists (k1_dfa; 8 = every wave slot)
+    int dfa_wgs = 8;                 // FZB_DFA_WGS            workgroups per CU of the streaming filter on short / uniform lists (k1_dfa; 8 = every wave slot)
     int cdfa_wgs = 5;                // FZB_CDFA_WGS           workgroups per CU, class-composite filter on the canonical layout
     int view_wgs = 6;                // FZB_VIEW_WGS           workgroups per CU, filter over the view
     int ragged_wgs = 8;              // FZB_RAGGED_WGS         workgroups per CU, burst filter

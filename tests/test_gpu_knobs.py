@@ -32,7 +32,8 @@ def lists():
     short = [s.ljust(32, "q")[:32] for s in short]                       # a uniform 32-byte list: the short-haystack kernels
     ragged = _ragged(rng, 40000, 128, "deadbeef", "deabfxyz_-/ 01DEAB")  # view, classes, multi-chunk tail classes
     uni = _ragged(rng, 20000, 24, "éa", list("abéÉñ_ -/xyzü"))
-    return {"short": (short, F.Corpus(short)), "ragged": (ragged, F.Corpus(ragged)), "uni": (uni, F.Corpus(uni))}
+    wide = _ragged(rng, 30000, 230, "deadbeef", "deabfxyz_-/ 01DEAB")         # haystacks beyond 128 bytes: the view's 16-vector groups
+    return {"short": (short, F.Corpus(short)), "ragged": (ragged, F.Corpus(ragged)), "uni": (uni, F.Corpus(uni)), "wide": (wide, F.Corpus(wide))}
 
 
 def _same(lists, which, needle, **cfg):
@@ -53,6 +54,7 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_NO_TAIL_CLASSES": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),                      # four scorer launches on two streams
     ({"FZB_SMALL_LIST": "0", "FZB_NO_OVERLAP": "1"}, [("ragged", "deadbeef", dict())]),
+    ({"FZB_HANDOFF_MIN_TILES": "0"}, [("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),  # the 16-vector view kernel, staging
     ({"FZB_DFA_WGS": "3"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),
     ({"FZB_DFA_WGS": "8"}, [("short", "deadbe", dict()), ("uni", "éa", dict())]),
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab
