@@ -199,6 +199,7 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                        u64* reject_bits = nullptr, u32* tile_rejects = nullptr, int nul_safe = 0, int acc_lo = -1, const u8* cdfa = nullptr, u32 cdfa_bytes = 0,
                        int cdfa_K = 0, int cdfa_G = 0, const StageOut* so = nullptr);
 void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* reject_count, u32* rej_prefix, hipStream_t st);
+void fzb_launch_init_counters(u32* counters, u32 n0, hipStream_t st);  // the 16-word counter block: [0] = n0, the rest 0
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st,
                          u32* tile_prefix_out = nullptr, u32* total_out2 = nullptr);
 void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,
@@ -230,9 +231,12 @@ void fzb_launch_dp_multi_classes(const CorpusDev& c, u64 first, u32 index_offset
 void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int mode,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_unicode.hip
+// wmode 2 (the window is the whole haystack): queue the windows wider than a chunk ahead of the single-chunk scorer (which then gets multi_front = 2)
+void fzb_launch_unicode_split_wide(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, int sw_lanes, u32 capacity, u32* overflow, u32 qcap, u32* counters,
+                                   int grid, hipStream_t st);
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
-                           int grid, hipStream_t st, int tform = 0, int multi_front = 0);
+                           int grid, hipStream_t st, int tform = 0, int multi_front = 0, int one_round_wgs = 0);
 // windows of sw_lanes < m <= 1024 bytes queued by fzb_launch_dp_unicode (front of `overflow`, count in counters[3]); `scratch` as the ASCII multi-chunk scorer's
 void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes,
                                  fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from = 0, int tform = 0);  // runs only when *n_list_ptr >= only_from; tform: dp_unicode_multi_chunk_t

@@ -1031,7 +1031,11 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     } while (0)
     // the streaming filter kernels clear the counter block themselves (one launch less on the hot path)
     const bool filter_resets = count != 0 && !items_in && !m->long_needle && (m->literal_mode ? (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode) : lc.filter_mode != 0);
-    if (!filter_resets) HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
+    // nothing filtered (max_typos = None or >= rows): the survivors are the identity list - the counter block is cleared and its first word set
+    // to the range's size by ONE small kernel (a memset and a 32-bit fill were two fill kernels with a dispatch gap each: ~ 20 us of a step)
+    const bool identity_list = count != 0 && !items_in && !m->long_needle && !m->literal_mode && lc.filter_mode == 0;
+    if (identity_list) fzb_launch_init_counters(w.counters, cnt, st);
+    else if (!filter_resets) HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
     if (count == 0) {
         HIPCHK(hipMemsetAsync(dev_count, 0, 8, st));
         return FZB_OK;
@@ -1085,8 +1089,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             items = w.surv_idx;
         }
     } else if (lc.filter_mode == 0) {
-        // nothing filtered (max_typos = None or >= rows): the survivors are the identity list
-        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&cnt_c[0], (int)cnt, 1, st));
+        // nothing filtered (max_typos = None or >= rows): the survivors are the identity list (counters[0] = the range's size: set above)
     } else if (typo_fast_path_configured(m) && !trace && fzb_dp_short_applies(cd, lc.sw_lanes, 2)) {
         // ---- typo configuration, every haystack fits half a chunk: LCS filter with the "nothing to spare" bit -> survivors;
         // the marginal ones are re-decided at the exact lane width (a reject sets a bit), the scorer computes the windows ----
@@ -1201,16 +1204,41 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : (u32)cus * 128u;
         const int ugrid = cus * 2;  // multi-chunk unicode scorer: one wave per SIMD (two-wave workgroups)
         if (umin != 0xFFFFFFFFu && (rc = ensure_dp_scratch(m, ugrid))) return rc;  // first use only (or fzb_matcher_reserve)
-        fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st, lc.cfu_ok, 1);
+        // Whole-haystack windows (max_typos: None): the wide ones are known from the end offsets, so they are queued FIRST and their scorers run
+        // on the second stream beside the single-chunk scorer (Arabic-shaped list, All Scores: the two took 90 + 100 us one after the other)
+        bool presplit = wmode == 2 && !items && !no_wide && !kn.no_overlap && !kn.debug_sync;  // (no item list: the number of windows is the range's size)
+        if (presplit && ensure_aux_stream(m) != FZB_OK) {  // no second stream: the scorer queues them itself (the error text is dropped with the fallback)
+            presplit = false;
+            fzb_clear_error();
+        }
+        hipStream_t wst = st;  // the stream of the wide windows' scorers
+        if (presplit) {
+            fzb_launch_unicode_split_wide(cd, first, items, n_items_ptr, lc.sw_lanes, cap32, w.overflow, qcap, cnt_c, (int)std::min<u32>((cnt + 2047u) / 2048u, (u32)cus * 4u), st);
+            HIPCHK(hipEventRecord(m->ev_fork, st));
+            HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
+            wst = m->aux_stream;
+        }
+        // (presplit: the wide windows' kernels are enqueued FIRST - a few hundred long-running waves that take their SIMDs and keep them - and the
+        // single-chunk scorer runs as one short-lived workgroup per 128 items, which fills the rest of the chip and every SIMD a wide wave frees)
+        auto launch_single = [&]() {
+            fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st, lc.cfu_ok, presplit ? 2 : 1,
+                                  presplit ? (int)((cnt + 127) / 128) : 0);
+        };
+        if (!presplit) launch_single();
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
-            if (umin != 0xFFFFFFFFu) fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, st, umin, lc.cfu_ok);
+            if (umin != 0xFFFFFFFFu) fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, wst, umin, lc.cfu_ok);
             // (the wave-per-haystack kernel's LDS follows the needle's rows: for short needles its registers decide how many workgroups a CU holds)
-            if (umin != 0u) fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, st, 1, umin);
+            if (umin != 0u) fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, wst, 1, umin);
             FZB_STAGE("dp(unicode, wide windows)");
             if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {
-                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus / 4 + 1, st);
+                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus / 4 + 1, wst);
                 FZB_STAGE("generic(unicode, greedy)");
+            }
+            if (presplit) launch_single();
+            if (presplit) {
+                HIPCHK(hipEventRecord(m->ev_join, m->aux_stream));
+                HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
             }
         }
     } else if (nd.unicode) {
@@ -1298,6 +1326,7 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     const bool no_wide = c->dev.max_len != 0 && c->dev.max_len <= (u32)m->lc.sw_lanes;
     if (!m->long_needle && !m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
     if (!m->long_needle && !m->literal_mode && m->nd.unicode && m->lc.bias_ok && !no_wide && fzb_knobs().unicode_multi != 0 && (rc = ensure_dp_scratch(m, m->lc.num_cus * 2))) return rc;
+    if (!m->long_needle && !m->literal_mode && m->nd.unicode && m->lc.bias_ok && !no_wide && m->nd.max_typos < 0 && (rc = ensure_aux_stream(m))) return rc;  // whole-haystack windows: the wide ones on the second stream
     if (c->dev.vbytes && c->dev.n_long == 0 && !m->literal_mode && !m->long_needle && !m->nd.unicode && m->lc.filter_mode == 1 && m->lc.cf_ok && (rc = ensure_stage(m, n))) return rc;
     if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;

@@ -1180,6 +1180,11 @@ void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, cons
     hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, n_items_ptr, src, out_idx, total_out, tile_prefix_out, total_out2);
 }
 
+__global__ void k_init_counters(u32* __restrict__ counters, u32 n0) {
+    if (threadIdx.x < 16) counters[threadIdx.x] = threadIdx.x == 0 ? n0 : 0u;
+}
+void fzb_launch_init_counters(u32* counters, u32 n0, hipStream_t st) { hipLaunchKernelGGL(k_init_counters, dim3(1), dim3(64), 0, st, counters, n0); }
+
 void fzb_launch_compact2(const u64* bitmap, const u32* counts, const u32* n_items_ptr, const u32* in_idx, const u32* in_win, u32* out_idx, u32* out_win, u32* total_out,
                          int grid, hipStream_t st) {
     hipLaunchKernelGGL(k_compact2, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items_ptr, in_idx, in_win, out_idx, out_win, total_out);

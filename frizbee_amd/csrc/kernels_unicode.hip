@@ -72,6 +72,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             const bool include_exact = sp == 0 && we == L;
             const u32 m = we - sp;
             if (m > (u32)SWL) {
+                if (multi_front == 2) break;  // (queued before this kernel started: k2u_split_wide)
                 // multi-chunk windows from the front (counters[3]: k2u_dp_unicode_multi), > 1024 bytes from the back (counters[4]: generic, greedy)
                 const bool greedy = !multi_front || m > FZB_MAX_HAYSTACK_LEN;  // (multi_front == 0: every wide window to the generic kernel)
                 // (two atomics with a uniform address each: the compiler turns those into one per wave; with the counter chosen per lane the
@@ -129,6 +130,56 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
     }
 }
 
+// When the window is the whole haystack (max_typos: None scores everything, wmode 2) its width is known from the end offsets alone: the
+// wide windows are queued by this kernel BEFORE the single-chunk scorer runs (which then skips them: multi_front == 2), so that the queue's
+// scorer can run beside it on a second stream instead of behind it - both are one-wave-per-SIMD kernels whose last round leaves most of the
+// chip idle.  Queue entries as k2u_body writes them: (output position, window start, window end, haystack).
+// (pushes are collected per workgroup in LDS and take ONE atomic on the queue's counter per 2048 items: an atomic per wave - 4.4 k of them on
+// one address for the Arabic-shaped list - is served one at a time, 8 ns each, and made this kernel 53 us long)
+#define FZB_SPLIT_CHUNK 2048u
+template <typename ET>
+__global__ __launch_bounds__(256) void k2u_split_wide(const ET* __restrict__ ends, u64 first, const u32* __restrict__ items, const u32* __restrict__ n_items_ptr, u32 ulen, u32 swl,
+                                                      u32 capacity, u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters) {
+    __shared__ uint4 s_buf[FZB_SPLIT_CHUNK];
+    __shared__ u32 s_n, s_base;
+    const u32 M = min(*n_items_ptr, capacity);
+    const u32 nchunks = (M + FZB_SPLIT_CHUNK - 1) / FZB_SPLIT_CHUNK;
+    for (u32 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < FZB_SPLIT_CHUNK / 256; k++) {
+            const u32 j = ch * FZB_SPLIT_CHUNK + k * 256 + threadIdx.x;
+            if (j >= M) continue;
+            const u32 li = items ? items[j] : j;
+            u64 s;
+            u32 L;
+            haystack_span_u(ends, ulen, first + li, s, L);
+            if (L <= swl) continue;
+            const uint4 e = make_uint4(j, 0u, L, li);
+            if (L > FZB_MAX_HAYSTACK_LEN) {  // the greedy fallback's end of the queue: rare, pushed directly
+                const u32 slot = atomicAdd(&counters[4], 1u);
+                *(uint4*)(overflow + 4 * (size_t)(qcap - 1 - slot)) = e;
+            } else {
+                s_buf[atomicAdd(&s_n, 1u)] = e;
+            }
+        }
+        __syncthreads();
+        const u32 n = s_n;
+        if (threadIdx.x == 0 && n) s_base = atomicAdd(&counters[3], n);
+        __syncthreads();
+        const u32 base = s_base;
+        for (u32 k = threadIdx.x; k < n; k += 256) *(uint4*)(overflow + 4 * (size_t)(base + k)) = s_buf[k];
+        __syncthreads();
+    }
+}
+
+void fzb_launch_unicode_split_wide(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, int sw_lanes, u32 capacity, u32* overflow, u32 qcap, u32* counters,
+                                   int grid, hipStream_t st) {
+    if (c.ends_u64) hipLaunchKernelGGL((k2u_split_wide<u64>), dim3(grid), dim3(256), 0, st, (const u64*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters);
+    else hipLaunchKernelGGL((k2u_split_wide<u32>), dim3(grid), dim3(256), 0, st, (const u32*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters);
+}
+
 #define FZB_K2U_PARAMS const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win, \
     const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ overflow, \
     u32 qcap, u32* __restrict__ counters, u32 ulen, u32 multi_front
@@ -145,7 +196,9 @@ __global__ __launch_bounds__(128, 2) void k2u_dp_unicode_half_w2(FZB_K2U_PARAMS)
 
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
-                           int grid, hipStream_t st, int tform, int multi_front) {
+                           int grid, hipStream_t st, int tform, int multi_front, int one_round_wgs) {
+    // one_round_wgs > 0: that many workgroups instead of the resident ones (one item per thread) - the caller runs another one-wave-per-SIMD
+    // kernel beside this one, and short-lived workgroups take over the SIMDs that one frees; a persistent grid would hold what it got first
     // `grid` = number of CUs: the kernel is persistent, launch exactly the resident workgroups
     const bool half_only = sw_lanes >= 16 && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2;
     // the biased-throughout form wants ~250 registers: at two waves per SIMD it runs without spills (C5: 0.152 ms; capped at 168 registers /
@@ -158,13 +211,13 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
         if (half_only && w2) {                                                                                                         \
             static int per_cu_w2 = 0;                                                                                                  \
             if (!per_cu_w2 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w2, k2u_dp_unicode_half_w2<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_w2 < 1)) per_cu_w2 = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half_w2<SWL, TF, ET>), dim3(grid * per_cu_w2), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
+            hipLaunchKernelGGL((k2u_dp_unicode_half_w2<SWL, TF, ET>), dim3(one_round_wgs > 0 ? one_round_wgs : grid * per_cu_w2), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
         } else if (half_only) {                                                                                                        \
             if (!per_cu_half && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_half, k2u_dp_unicode_half<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_half < 1)) per_cu_half = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, TF, ET>), dim3(grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
+            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, TF, ET>), dim3(one_round_wgs > 0 ? one_round_wgs : grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
         } else {                                                                                                                       \
             if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
-            hipLaunchKernelGGL((k2u_dp_unicode<SWL, TF, ET>), dim3(grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
+            hipLaunchKernelGGL((k2u_dp_unicode<SWL, TF, ET>), dim3(one_round_wgs > 0 ? one_round_wgs : grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
         }                                                                                                                              \
     } while (0)
 #define FZB_K2U_TF(SWL, ET) do { if (tform) FZB_K2U(SWL, true, ET); else FZB_K2U(SWL, false, ET); } while (0)

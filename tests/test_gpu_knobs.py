@@ -33,7 +33,8 @@ def lists():
     ragged = _ragged(rng, 40000, 128, "deadbeef", "deabfxyz_-/ 01DEAB")  # view, classes, multi-chunk tail classes
     uni = _ragged(rng, 20000, 24, "éa", list("abéÉñ_ -/xyzü"))
     wide = _ragged(rng, 30000, 230, "deadbeef", "deabfxyz_-/ 01DEAB")         # haystacks beyond 128 bytes: the view's 16-vector groups
-    return {"short": (short, F.Corpus(short)), "ragged": (ragged, F.Corpus(ragged)), "uni": (uni, F.Corpus(uni)), "wide": (wide, F.Corpus(wide))}
+    uniwide = _ragged(rng, 8000, 150, "éa", list("abéÉñ_ -/xyzü")) + ["é" + "x" * 1100 + "a", "ñ" * 600 + "éa"]  # unicode windows beyond a chunk / beyond 1024 bytes
+    return {"short": (short, F.Corpus(short)), "ragged": (ragged, F.Corpus(ragged)), "uni": (uni, F.Corpus(uni)), "wide": (wide, F.Corpus(wide)), "uniwide": (uniwide, F.Corpus(uniwide))}
 
 
 def _same(lists, which, needle, **cfg):
@@ -55,6 +56,9 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),                      # four scorer launches on two streams
     ({"FZB_SMALL_LIST": "0", "FZB_NO_OVERLAP": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_HANDOFF_MIN_TILES": "0"}, [("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),  # the 16-vector view kernel, staging
+    ({"FZB_NO_OVERLAP": "1"}, [("uniwide", "éa", dict(max_typos=None))]),      # whole-haystack unicode windows: the scorer queues the wide ones itself, one stream
+    ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict(max_typos=None))]),   # ... queued ahead (default), thread per haystack beside the single-chunk scorer
+    ({"FZB_UNICODE_MULTI": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),
     ({"FZB_DFA_WGS": "3"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),
     ({"FZB_DFA_WGS": "8"}, [("short", "deadbe", dict()), ("uni", "éa", dict())]),
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab

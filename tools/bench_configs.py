@@ -142,7 +142,7 @@ if "PATHSVAR" in which:
     for label, mt in (("All Scores (max_typos None)", None), ("1 typo", 1), ("2 typos", 2), ("3 typos", 3)):
         run(f"paths-shaped 1.4M 'linux' {label}", "linux", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, npaths, steps=5)
     del cp
-if "ARABIC" in which or "ARABICDEF" in which:
+if "ARABIC" in which or "ARABICDEF" in which or "ARABICALL" in which:
     # the shape of the reference's UTF-8 benchmark (BENCHMARKS.md "Arabic": 285 587 sentences, needle of two Arabic letters)
     t0 = time.perf_counter(); data, ends = synth.arabic_corpus(); tgen = time.perf_counter() - t0
     cp = F.Corpus(packed=(data, ends))
@@ -150,5 +150,6 @@ if "ARABIC" in which or "ARABICDEF" in which:
     print(json.dumps(dict(config="arabic-shaped list", items=int(len(ends)), total_bytes=int(ends[-1]), median_len=float(np.median(lens)), mean_len=float(lens.mean()), std_len=float(lens.std()), gen_s=tgen)), flush=True)
     for label, mt in (("typos0", 0), ("All Scores (max_typos None)", None), ("1 typo", 1)):
         if "ARABICDEF" in which and mt != 0: continue  # (profiling the default column alone)
+        if "ARABICALL" in which and mt is not None: continue
         run(f"arabic-shaped 285k {label}", "إن", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, int(len(ends)), steps=5)
     del cp
