@@ -142,8 +142,7 @@ static int merge_runs_on_device(fzb_matcher* m, const void* const* dev_runs, con
     if ((rc = fzb_order_begin(m, cap, m->out_dev, &plan))) return rc;
     // count_dev: two blocks of four words, alternating between batches of FZB_MAX_RUNS runs - [0] records written so far, [1] matches
     // found, [2] "a run was truncated by its producer" (sticky: every batch writes into the same word)
-    u32* words = m->count_dev;
-    HIPCHK(hipMemsetAsync(words, 0, 32, st));
+    u32* words = m->count_dev;  // (every word read below is assigned by the concatenation launches: no clearing fill in the stream)
     const u32* base = nullptr;
     u32* tot = words;
     for (size_t g0 = 0; g0 < nruns; g0 += FZB_MAX_RUNS) {

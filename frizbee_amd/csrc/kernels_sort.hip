@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void k_concat_runs(RunSet rs, const u32* __res
         const u32 c = tid < rs.n ? min(rs.count[tid][0], rs.cap[tid]) : 0u;
         // a run whose producer found more matches than its buffer holds (fzb_match_list_device: count[1] > capacity) is reported, not merged
         const bool cut = tid < rs.n && rs.count[tid][1] > rs.cap[tid];
-        if (__ballot(cut) && tid == 0 && blockIdx.x == 0) *cut_flag = 1u;
+        // (the first batch - no base - ASSIGNS the flag, later ones only raise it: nothing has to clear the word before the launch)
+        const bool any_cut = __ballot(cut) != 0;
+        if (tid == 0 && blockIdx.x == 0 && (any_cut || !base_in)) *cut_flag = any_cut ? 1u : 0u;
         u32 incl = c;
         for (int off = 1; off < 64; off <<= 1) {
             const u32 t = __shfl_up(incl, off);
