@@ -108,7 +108,7 @@ int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len);
 /* Optional accelerator for borrowed RAGGED corpora (fzb_corpus_upload builds it itself): the streaming filter's view of the list - a
  * second copy of the bytes, every 1024-haystack tile sorted by length and stored interleaved in groups of 64, so that a wavefront's
  * loads are contiguous.  The lengths are read from the end offsets (no hint is trusted).  A list that does not
- * call for a view (nothing beyond 32 bytes, something beyond 256, uniform length) or a device without room leaves the corpus as it
+ * call for a view (nothing beyond 32 bytes, more than one haystack in 256 beyond 256 bytes, uniform length) or a device without room leaves the corpus as it
  * is: *out_built (optional) = 1 when the corpus has a view when the call returns.  The corpus' bytes must not change afterwards. */
 int fzb_corpus_build_view(fzb_corpus* c, int* out_built);
 /* Optional promise for borrowed corpora: EVERY haystack has exactly `len` bytes (so haystack i starts at i * roundup16(len)); the hot
