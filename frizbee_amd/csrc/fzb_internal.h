@@ -208,7 +208,7 @@ void fzb_launch_compact2(const u64* bitmap, const u32* counts, const u32* n_item
                          int grid, hipStream_t st);
 // kernels_window.hip
 void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
-                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide = nullptr);
+                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide = nullptr, u32 max_items = 0);
 // kernels_dp.hip
 void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                    int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st,

@@ -180,6 +180,7 @@ FzbKnobs parse_knobs() {
     k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
     k.debug_sync = set("FZB_DEBUG_SYNC");
     k.no_handoff = set("FZB_NO_HANDOFF");
+    k.window_four_pass = set("FZB_WINDOW_FOUR_PASS");
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
@@ -1167,7 +1168,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         wmode = 1;
     } else if (!lc.filter_exact) {
         // the stream stage was a superset: re-decide every survivor with the reference's chunked algorithm at its exact lane width
-        fzb_launch_window(cd, first, items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, cus * 4, st);
+        fzb_launch_window(cd, first, items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, cus * 4, st, nullptr, items_in ? 0u : cnt);
         FZB_STAGE("window");
         fzb_launch_compact2(w.bitmap2, w.tile_counts2, &cnt_c[0], items, w.win, w.items2, w.win2, &cnt_c[1], cus * 2, st);
         FZB_STAGE("compact2");

@@ -174,7 +174,7 @@ struct Win {
 // ---- end scans --------------------------------------------------------------------------------
 // find_end_pos_with_typos (ascii_typos.rs:375-397)
 template <int PFL, typename ND>
-__device__ u32 ascii_end_pos(AsciiSrc<PFL, ND>& src, u32 max_typos) {
+__device__ __forceinline__ u32 ascii_end_pos(AsciiSrc<PFL, ND>& src, u32 max_typos) {
     const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
     u32 start = (len - 1) / PFL * PFL;
     for (;;) {
@@ -190,7 +190,7 @@ __device__ u32 ascii_end_pos(AsciiSrc<PFL, ND>& src, u32 max_typos) {
 }
 // find_end_pos_with_unicode_typos (unicode_typos.rs:479-508)
 template <int PFL, typename ND>
-__device__ u32 unicode_end_pos(UnicodeSrc<PFL, ND>& src, u32 max_typos) {
+__device__ __forceinline__ u32 unicode_end_pos(UnicodeSrc<PFL, ND>& src, u32 max_typos) {
     const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
     u32 start = len >= (u32)PFL ? len - PFL : 0;
     for (;;) {
@@ -213,7 +213,7 @@ __device__ __forceinline__ u32 end_pos(UnicodeSrc<PFL, ND>& s, u32 k) { return u
 
 // ---- 1 typo (ascii_typos.rs:15-110 / unicode_typos.rs:15-141) -----------------------------------
 template <int PFL, typename Src>
-__device__ Win prefilter_1_typo(Src& src) {
+__device__ __forceinline__ Win prefilter_1_typo(Src& src) {
     const u32 n = src.rows(), len = src.len;
     if (n <= 1) return {true, 0, len};
     if (len == 0) return {false, 0, 0};
@@ -256,7 +256,7 @@ __device__ Win prefilter_1_typo(Src& src) {
 
 // ---- 2 typos (ascii_typos.rs:113-251 / unicode_typos.rs:144-330) --------------------------------
 template <int PFL, typename Src>
-__device__ Win prefilter_2_typos(Src& src) {
+__device__ __forceinline__ Win prefilter_2_typos(Src& src) {
     const u32 n = src.rows(), len = src.len;
     if (n <= 2) return {true, 0, len};
     if (len == 0) return {false, 0, 0};
@@ -336,7 +336,7 @@ struct GlobalPaths {
 };
 
 template <int PFL, typename Src, typename Paths>
-__device__ Win prefilter_many_typos(Src& src, u32 max_typos, Paths& paths) {
+__device__ __forceinline__ Win prefilter_many_typos(Src& src, u32 max_typos, Paths& paths) {
     const u32 n = src.rows(), len = src.len;
     if (n <= max_typos) return {true, 0, len};
     if (len == 0) return {false, 0, 0};
@@ -380,7 +380,7 @@ __device__ Win prefilter_many_typos(Src& src, u32 max_typos, Paths& paths) {
 // filter and their window comes from the scorer.  Chunk by chunk like the reference; its result is lane-free (accept <=> ordered
 // subsequence; start = first occurrence of needle[0]; end = one past the last occurrence of needle[n-1]) -------------------------
 template <int PFL, typename ND>
-__device__ Win prefilter_ascii_0(AsciiSrc<PFL, ND>& src) {
+__device__ __forceinline__ Win prefilter_ascii_0(AsciiSrc<PFL, ND>& src) {
     const u32 n = src.rows(), len = src.len;
     if (len == 0) return {false, 0, 0};
     bool can_skip = true;
@@ -413,7 +413,7 @@ __device__ Win prefilter_ascii_0(AsciiSrc<PFL, ND>& src) {
 
 // ---- unicode 0 typos (unicode.rs:119-219) + back scan (unicode.rs:222-276) -----------------------
 template <int PFL, typename ND>
-__device__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL, ND>& src, u32 row, u32 sub_start) {
+__device__ __forceinline__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL, ND>& src, u32 row, u32 sub_start) {
     // operates on haystack[sub_start..]; positions returned are relative to sub_start
     const ND& nd = src.nd;
     const u32 cl = nd.ulen[row];
@@ -440,7 +440,7 @@ __device__ u32 find_last_unicode_char_pos(UnicodeSrc<PFL, ND>& src, u32 row, u32
 }
 
 template <int PFL, typename ND>
-__device__ Win prefilter_unicode_0(UnicodeSrc<PFL, ND>& src) {
+__device__ __forceinline__ Win prefilter_unicode_0(UnicodeSrc<PFL, ND>& src) {
     const ND& nd = src.nd;
     const u32 len = src.len, n = src.rows();
     if (len == 0) return {false, 0, 0};
@@ -513,8 +513,11 @@ struct ManyScratch {
 // `rej.bits`, bumps its tile's count and the total.
 // min_len: haystacks shorter than this are rejected first (`original_len >= self.min_haystack_len`, src/matcher/algo.rs:88) - the
 // streaming filter does it on the usual path; for a long needle this kernel is the first stage.
-template <int PFL, int ALG, bool DECIDE = false, typename ND = NeedleDev>
-__global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
+// TPB = threads per workgroup: a 1024-haystack tile takes 1024 / TPB passes.  256 for lists whose tiles fill the chip several times over;
+// 1024 - one pass - for the lists a typo query usually sees: with a few hundred tiles every workgroup is resident at once and the kernel
+// lasts as long as ONE tile, four dependent passes of a latency-bound scan (Arabic-shaped list, 1 typo: 105 tiles, 163 us of a 248 us step).
+template <int PFL, int ALG, bool DECIDE = false, typename ND = NeedleDev, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
                                                   const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const ND nd,
                                                   u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, int use_cache, RejectOut rej, u32 min_len,
                                                   ManyScratch many) {
@@ -528,8 +531,8 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
         __syncthreads();
         u32 cnt = 0;
 #pragma unroll 1
-        for (int p = 0; p < FZB_TILE / 256; p++) {
-            const u32 j = tile * FZB_TILE + p * 256 + tid;
+        for (int p = 0; p < FZB_TILE / TPB; p++) {
+            const u32 j = tile * FZB_TILE + p * TPB + tid;
             bool keep = false;
             if (j < M) {
                 const u32 li = surv_idx ? surv_idx[j] : j;
@@ -547,7 +550,7 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
                     else if (ALG == ALG_UNI_1) w = prefilter_1_typo<PFL>(src);
                     else if (ALG == ALG_UNI_2) w = prefilter_2_typos<PFL>(src);
                     else if (ND::kLong) {
-                        GlobalPaths paths{many.idx, many.nmask, gridDim.x * 256u, blockIdx.x * 256u + (u32)tid};
+                        GlobalPaths paths{many.idx, many.nmask, gridDim.x * (u32)TPB, blockIdx.x * (u32)TPB + (u32)tid};
                         w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos, paths);
                     } else {
                         LocalPaths paths;
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
                     else if (ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
                     else if (ALG == ALG_ASCII_2) w = prefilter_2_typos<PFL>(src);
                     else if (ND::kLong) {
-                        GlobalPaths paths{many.idx, many.nmask, gridDim.x * 256u, blockIdx.x * 256u + (u32)tid};
+                        GlobalPaths paths{many.idx, many.nmask, gridDim.x * (u32)TPB, blockIdx.x * (u32)TPB + (u32)tid};
                         w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos, paths);
                     } else {
                         LocalPaths paths;
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
             if (!DECIDE) {
                 const u64 b = __ballot(keep);
                 if (lane_id() == 0) {
-                    bitmap2[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = b;
+                    bitmap2[(tile * FZB_TILE + p * TPB) / 64 + (tid >> 6)] = b;
                     cnt += __popcll(b);
                 }
             }
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, 
 
 template <int PFL>
 static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, u32* win, u64* bitmap2,
-                              u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide) {
+                              u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, bool one_pass) {
     const int k = nd.max_typos;
     const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
     // occurrence-mask cache in LDS for the ASCII algorithms: rows x 2 KB per workgroup, up to 16 rows
@@ -611,7 +614,11 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 #undef FZB_K2A_D
         return;
     }
-#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none)
+#define FZB_K2A(ALG)                                                                                                                                                          \
+    do {                                                                                                                                                                      \
+        if (one_pass && ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0) hipLaunchKernelGGL((k2a_window<PFL, (ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0) ? ALG : ALG_UNI_1, false, NeedleDev, 1024>), dim3(grid), dim3(1024), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none); \
+        else hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none);                                   \
+    } while (0)
     switch (alg) {
         case ALG_ASCII_1: FZB_K2A(ALG_ASCII_1); break;
         case ALG_ASCII_2: FZB_K2A(ALG_ASCII_2); break;
@@ -625,10 +632,14 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 }
 
 void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
-                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide) {
-    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
-    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
-    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide);
+                       u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide, u32 max_items) {
+    // max_items: an upper bound of *n_surv_ptr known on the host (the range's size; 0 = unknown): up to 3 x 1024 haystacks per CU the
+    // one-pass form (grid / 4 = CUs: callers pass four workgroups per CU)
+    const bool one_pass = !decide && nd.unicode && max_items != 0 && !fzb_knobs().window_four_pass &&  // (unicode algorithms: the ASCII ones keep a per-thread mask cache sized for 256 threads)
+                          (u64)max_items <= (u64)(grid / 4 > 0 ? grid / 4 : 1) * 1024u * 3u;
+    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
+    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
+    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
 }
 
 // ---- long needles: this kernel is the FIRST stage (length test + the reference's prefilter at the exact lane width, every typo
