@@ -100,7 +100,7 @@ struct AsciiSrc {
     u64 valid;  // chunk_mask from load_window
     // The typo algorithms ask for the occurrence mask of a needle row again every time a path advances (~20 times for a
     // 6-row needle), each one a 16-dword SWAR compare plus two per-thread byte loads of the needle.  With a cache (LDS,
-    // [row][thread], this thread's column only - no barriers) every row's mask is computed once per chunk, rows in a
+    // [row][thread of the workgroup], this thread's column only - no barriers) every row's mask is computed once per chunk, rows in a
     // wave-uniform loop (scalar needle loads), and a request is one ds_read_b64.
     u64* cache;
     u32 loaded;  // chunk start the cache / chunk belong to
@@ -111,9 +111,9 @@ struct AsciiSrc {
         load_chunk<PFL>(chunk, hay, start, len);
         valid = m_first_n<PFL>(len - start);
         if (cache)
-            for (int r = 0; r < nd.rows; r++) cache[r * 256 + threadIdx.x] = occ_mask<PFL>(chunk, nd.c[r], nd.f[r]);
+            for (int r = 0; r < nd.rows; r++) cache[r * blockDim.x + threadIdx.x] = occ_mask<PFL>(chunk, nd.c[r], nd.f[r]);
     }
-    __device__ __forceinline__ u64 mask(u32 idx) const { return cache ? cache[idx * 256 + threadIdx.x] : occ_mask<PFL>(chunk, nd.c[idx], nd.f[idx]); }
+    __device__ __forceinline__ u64 mask(u32 idx) const { return cache ? cache[idx * blockDim.x + threadIdx.x] : occ_mask<PFL>(chunk, nd.c[idx], nd.f[idx]); }
     __device__ __forceinline__ u64 init_mask() const { return valid; }  // ASCII path masks start as chunk_mask
     __device__ __forceinline__ u32 rows() const { return (u32)nd.rows; }
 };
@@ -602,9 +602,10 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
                               u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, bool one_pass) {
     const int k = nd.max_typos;
     const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
-    // occurrence-mask cache in LDS for the ASCII algorithms: rows x 2 KB per workgroup, up to 16 rows
-    const int use_cache = !nd.unicode && nd.rows <= 16;
-    const size_t lds = use_cache ? (size_t)nd.rows * 256 * 8 : 0;
+    // occurrence-mask cache in LDS for the ASCII algorithms: rows x 2 KB per 256-thread workgroup, up to 16 rows (one-pass form: rows x 8 KB, up to 7)
+    const int tpb = (one_pass && !decide) ? 1024 : 256;
+    const int use_cache = !nd.unicode && nd.rows <= 16 && (size_t)nd.rows * tpb * 8 <= 60 * 1024;
+    const size_t lds = use_cache ? (size_t)nd.rows * tpb * 8 : 0;
     const ManyScratch none{nullptr, nullptr};
     if (decide) {  // ASCII typo algorithms only (the unicode path keeps the full form)
 #define FZB_K2A_D(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG, true>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, *decide, 0u, none)
@@ -616,7 +617,7 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
     }
 #define FZB_K2A(ALG)                                                                                                                                                          \
     do {                                                                                                                                                                      \
-        if (one_pass && ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0) hipLaunchKernelGGL((k2a_window<PFL, (ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0) ? ALG : ALG_UNI_1, false, NeedleDev, 1024>), dim3(grid), dim3(1024), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none); \
+        if (one_pass) hipLaunchKernelGGL((k2a_window<PFL, ALG, false, NeedleDev, 1024>), dim3(grid), dim3(1024), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none); \
         else hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none);                                   \
     } while (0)
     switch (alg) {
@@ -633,10 +634,11 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 
 void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
                        u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide, u32 max_items) {
-    // max_items: an upper bound of *n_surv_ptr known on the host (the range's size; 0 = unknown): up to 3 x 1024 haystacks per CU the
-    // one-pass form (grid / 4 = CUs: callers pass four workgroups per CU)
-    const bool one_pass = !decide && nd.unicode && max_items != 0 && !fzb_knobs().window_four_pass &&  // (unicode algorithms: the ASCII ones keep a per-thread mask cache sized for 256 threads)
-                          (u64)max_items <= (u64)(grid / 4 > 0 ? grid / 4 : 1) * 1024u * 3u;
+    // max_items: an upper bound of *n_surv_ptr known on the host (the range's size; 0 = unknown).  Up to 8 x 1024 haystacks per CU the one-pass
+    // form (grid / 4 = CUs: callers pass four workgroups per CU): the survivors of a typo filter are a fraction of the range (paths-shaped
+    // list, 1.4 M items: 169 k / 225 k / 281 k for 1 / 2 / 3 typos = 165-274 tiles, every workgroup resident at once), and in a kernel that is
+    // one chain of dependent passes per tile a 1024-thread workgroup is never behind four 256-thread passes even when every haystack survives
+    const bool one_pass = !decide && max_items != 0 && !fzb_knobs().window_four_pass && (u64)max_items <= (u64)(grid / 4 > 0 ? grid / 4 : 1) * 1024u * 8u;
     if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
     else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
     else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
