@@ -320,7 +320,29 @@ def other_configs(F, synth, dev, steps):
         tq.append(time.perf_counter() - t0)
     res[name]["match_list_ms_median"] = _median(tq) * 1e3  # what a caller sees: pipeline + device sort + D2H of the ordered records
     res[name]["reference_published_ms"] = {"sequential": 22.36, "parallel_x8": 3.48, "where": "BENCHMARKS.md:62-65, Ryzen 9950X3D, the real Chromium list"}
+    # the other columns of that table on the same list (All Scores = max_typos None; typo budgets 1 / 2 / 3): device pipeline per query
+    cols = {}
+    for label, mt, ref in (("all_scores", None, (84.64, 13.81)), ("typos_1", 1, (60.76, 9.50)), ("typos_2", 2, (99.15, 15.58)), ("typos_3", 3, (142.39, 20.29))):
+        key = f"paths list, column {label}"
+        run(key, "linux", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, npaths, int(ep[-1]), steps=5)
+        cols[label] = {"ms_per_step": res[key]["ms_per_step"], "matches": res[key]["matches"], "reference_published_ms": {"sequential": ref[0], "parallel_x8": ref[1]}}
+        del res[key]
+    res[name]["other_columns"] = cols
     del cp, dp, ep, mq, rq
+    # the reference's UTF-8 benchmark shape (BENCHMARKS.md "Arabic": 285 587 sentences, median 37 bytes, a needle of two Arabic letters), synthetic
+    da, ea = synth.arabic_corpus()
+    cp = F.Corpus(packed=(da, ea))
+    namea = "arabic-shaped: 285,587 UTF-8 sentences (median 37 B, lognormal, up to 600 B), two-letter needle (the Arabic shape of BENCHMARKS.md, synthetic)"
+    run(namea, "إن", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, int(len(ea)), int(ea[-1]), steps=5)
+    cols = {}
+    for label, mt, ref in (("all_scores", None, (15.13, 2.65)), ("typos_1", 1, (11.46, 1.97))):
+        key = f"arabic list, column {label}"
+        run(key, "إن", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, int(len(ea)), int(ea[-1]), steps=5)
+        cols[label] = {"ms_per_step": res[key]["ms_per_step"], "matches": res[key]["matches"], "reference_published_ms": {"sequential": ref[0], "parallel_x8": ref[1]}}
+        del res[key]
+    res[namea]["other_columns"] = cols
+    res[namea]["reference_published_ms"] = {"sequential": 2.60, "parallel_x8": 0.481, "where": "BENCHMARKS.md:59-95, Ryzen 9950X3D, the real list"}
+    del cp, da, ea
     # a LONG needle (beyond the 64 bytes / 63 rows the by-value kernels take): the lane-exact prefilter as first stage,
     # the wave-per-haystack scorer as the only scorer, per-wave slabs in global memory.  Correct for every accepted length
     # (tests/test_gpu_long_needles.py); this row puts a number on "nothing here is tuned"
