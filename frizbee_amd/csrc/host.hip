@@ -180,6 +180,7 @@ FzbKnobs parse_knobs() {
     k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
     k.debug_sync = set("FZB_DEBUG_SYNC");
     k.no_handoff = set("FZB_NO_HANDOFF");
+    k.window_no_mask_cache = set("FZB_WINDOW_NO_MASK_CACHE");
     k.window_four_pass = set("FZB_WINDOW_FOUR_PASS");
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);

@@ -127,7 +127,9 @@ struct UnicodeSrc {
     Chunk<PFL> w0;  // window at start+0
     u32 guard;      // the 4 bytes after it: the windows at start+1 .. start+3 are byte shifts of (w0, guard), formed on demand
                     // (keeping four chunks and indexing them with a per-thread scalar length put the whole set into scratch memory)
-    __device__ UnicodeSrc(const ND& n, const u8* h, u32 l) : nd(n), hay(h), len(l), start(0), guard(0) {}
+    u64* cache;     // as AsciiSrc: [row][thread of the workgroup] in LDS, every row's mask computed once per chunk (a mask is 2 variants x up to
+                    // 4 byte positions x 16 dwords of SWAR compares, and the typo algorithms ask for a row again every time a path advances)
+    __device__ UnicodeSrc(const ND& n, const u8* h, u32 l, u64* cache_ = nullptr) : nd(n), hay(h), len(l), start(0), guard(0), cache(cache_) {}
     __device__ __forceinline__ void load(u32 s) {
         start = s;
         load_chunk<PFL>(w0, hay, s, len);
@@ -137,6 +139,8 @@ struct UnicodeSrc {
             guard = load_u32_unaligned(hay, p);
             if (len - p < 4) guard &= (1u << (8 * (len - p))) - 1;
         }
+        if (cache)
+            for (int r = 0; r < nd.rows; r++) cache[r * blockDim.x + threadIdx.x] = compute_mask((u32)r);
     }
     // window at start + o, o in 0..3 (v_alignbyte_b32 takes the shift from a register)
     __device__ __forceinline__ Chunk<PFL> at(u32 o) const {
@@ -155,8 +159,9 @@ struct UnicodeSrc {
         }
         return m;
     }
+    __device__ __forceinline__ u64 mask(u32 idx) const { return cache ? cache[idx * blockDim.x + threadIdx.x] : compute_mask(idx); }
     // unicode_char_mask (unicode.rs:74-117)
-    __device__ __forceinline__ u64 mask(u32 idx) const {
+    __device__ __forceinline__ u64 compute_mask(u32 idx) const {
         const u32 cl = nd.ulen[idx];
         if (start + cl > len) return 0;
         const u64 valid = m_first_n<PFL>(len - (start + cl - 1));
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, 
                 if (L < min_len) {
                     // too short for this needle and typo budget
                 } else if (ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0) {
-                    UnicodeSrc<PFL, ND> src(nd, hay, L);
+                    UnicodeSrc<PFL, ND> src(nd, hay, L, use_cache ? mask_cache : nullptr);
                     if (ALG == ALG_UNI_0) w = prefilter_unicode_0<PFL>(src);
                     else if (ALG == ALG_UNI_1) w = prefilter_1_typo<PFL>(src);
                     else if (ALG == ALG_UNI_2) w = prefilter_2_typos<PFL>(src);
@@ -602,9 +607,9 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
                               u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, bool one_pass) {
     const int k = nd.max_typos;
     const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
-    // occurrence-mask cache in LDS for the ASCII algorithms: rows x 2 KB per 256-thread workgroup, up to 16 rows (one-pass form: rows x 8 KB, up to 7)
+    // occurrence-mask cache in LDS (ASCII and, since round 4, unicode algorithms): rows x 2 KB per 256-thread workgroup, up to 16 rows (one-pass form: rows x 8 KB, up to 7)
     const int tpb = (one_pass && !decide) ? 1024 : 256;
-    const int use_cache = !nd.unicode && nd.rows <= 16 && (size_t)nd.rows * tpb * 8 <= 60 * 1024;
+    const int use_cache = nd.rows <= 16 && (size_t)nd.rows * tpb * 8 <= 60 * 1024 && !fzb_knobs().window_no_mask_cache;
     const size_t lds = use_cache ? (size_t)nd.rows * tpb * 8 : 0;
     const ManyScratch none{nullptr, nullptr};
     if (decide) {  // ASCII typo algorithms only (the unicode path keeps the full form)

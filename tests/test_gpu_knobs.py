@@ -60,6 +60,8 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict(max_typos=None))]),   # ... queued ahead (default), thread per haystack beside the single-chunk scorer
     ({"FZB_UNICODE_MULTI": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),
     ({"FZB_WINDOW_FOUR_PASS": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=1))]),  # the lane-exact window kernel, 256-thread form
+    ({"FZB_WINDOW_NO_MASK_CACHE": "1"}, [("ragged", "deadbe", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=2))]),  # row masks recomputed at every request
+    ({"FZB_WINDOW_NO_MASK_CACHE": "1", "FZB_WINDOW_FOUR_PASS": "1"}, [("uniwide", "éa", dict(max_typos=1))]),
     ({"FZB_DFA_WGS": "3"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),
     ({"FZB_DFA_WGS": "8"}, [("short", "deadbe", dict()), ("uni", "éa", dict())]),
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab
