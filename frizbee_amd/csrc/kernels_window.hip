@@ -165,7 +165,11 @@ struct UnicodeSrc {
         const u32 cl = nd.ulen[idx];
         if (start + cl > len) return 0;
         const u64 valid = m_first_n<PFL>(len - (start + cl - 1));
-        return variant(nd.uc[idx], cl, valid) | variant(nd.uf[idx], cl, valid);
+        // (a scalar without a second case - every Arabic letter, digits, punctuation - has uf == uc: one variant, wave-uniform test)
+        bool same = true;
+        for (u32 k = 0; k < cl; k++) same = same && nd.uc[idx][k] == nd.uf[idx][k];
+        const u64 m = variant(nd.uc[idx], cl, valid);
+        return same ? m : (m | variant(nd.uf[idx], cl, valid));
     }
     __device__ __forceinline__ u64 init_mask() const { return m_all<PFL>(); }  // unicode path masks start as all()
     __device__ __forceinline__ u32 rows() const { return (u32)nd.rows; }
