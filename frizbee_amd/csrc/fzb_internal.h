@@ -239,7 +239,8 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
                            int grid, hipStream_t st, int tform = 0, int multi_front = 0, int one_round_wgs = 0);
 // windows of sw_lanes < m <= 1024 bytes queued by fzb_launch_dp_unicode (front of `overflow`, count in counters[3]); `scratch` as the ASCII multi-chunk scorer's
 void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes,
-                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from = 0, int tform = 0);  // runs only when *n_list_ptr >= only_from; tform: dp_unicode_multi_chunk_t
+                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from = 0, int tform = 0, u32* counters = nullptr,
+                                 u32* back_end = nullptr, u32 fwd_cap = 0);  // fwd_cap > 0: windows beyond four chunks handed on to the queue's back (counters[4], [7])  // runs only when *n_list_ptr >= only_from; tform: dp_unicode_multi_chunk_t
 // kernels_sort.hip
 void fzb_launch_sort(fzb_match_rec* buf, fzb_match_rec* tmp, const u32* n_ptr, u32* hist, u32 ntiles_cap, int reverse_first, int by_score, int grid, hipStream_t st, int passes = 2);
 void fzb_launch_concat_runs(const RunSet& rs, const u32* base_in, u32* total_out, fzb_match_rec* out, u32 capacity, int grid, u32* cut_flag, hipStream_t st);

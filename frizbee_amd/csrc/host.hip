@@ -180,6 +180,7 @@ FzbKnobs parse_knobs() {
     k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
     k.debug_sync = set("FZB_DEBUG_SYNC");
     k.no_handoff = set("FZB_NO_HANDOFF");
+    { const char* e = getenv("FZB_UNICODE_FWD"); k.no_unicode_fwd = e && e[0] == '0'; }
     k.window_no_mask_cache = set("FZB_WINDOW_NO_MASK_CACHE");
     k.window_four_pass = set("FZB_WINDOW_FOUR_PASS");
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
@@ -1229,13 +1230,18 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         if (!presplit) launch_single();
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
-            if (umin != 0xFFFFFFFFu) fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, wst, umin, lc.cfu_ok);
+            // (the thread-per-haystack scorer hands windows beyond four chunks - up to 4096 of them - on to the queue's back: FZB_UNICODE_FWD=0 keeps them)
+            const u32 fwd_cap = (umin != 0xFFFFFFFFu && !kn.no_unicode_fwd) ? 4096u : 0u;
+            if (umin != 0xFFFFFFFFu)
+                fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, wst, umin, lc.cfu_ok, cnt_c, w.overflow + 4 * (size_t)qcap, fwd_cap);
             // (the wave-per-haystack kernel's LDS follows the needle's rows: for short needles its registers decide how many workgroups a CU holds)
             if (umin != 0u) fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, wst, 1, umin);
             FZB_STAGE("dp(unicode, wide windows)");
-            if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {
-                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus / 4 + 1, wst);
-                FZB_STAGE("generic(unicode, greedy)");
+            const bool may_fwd = fwd_cap != 0 && !(cd.max_len != 0 && cd.max_len <= 4u * (u32)lc.sw_lanes);
+            if (may_fwd || !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // the queue's back: handed-on stragglers (DP) and windows beyond 1024 bytes (greedy)
+                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c,
+                                   may_fwd ? cus * 4 : cus / 4 + 1, wst);
+                FZB_STAGE("generic(unicode, stragglers + greedy)");
             }
             if (presplit) launch_single();
             if (presplit) {
@@ -2230,7 +2236,10 @@ int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {
         HIPCHK(hipMemcpy(all, m->ws.counters, sizeof(all), hipMemcpyDeviceToHost));
         m->last_counters[0] = all[0];
         m->last_counters[1] = all[1];
-        m->last_counters[2] = all[4];
+        // (unicode: windows of 65..1024 bytes that the thread-per-haystack scorer handed on to the queue's back are in BOTH counts - all[7] claims,
+        // at most 4096 granted: they stay "multi-chunk" here, and the greedy fallback's count is the back minus them)
+        const u32 fwd = std::min<u32>(all[7], 4096u);
+        m->last_counters[2] = all[4] >= fwd && m->nd.unicode ? all[4] - fwd : all[4];
         m->last_counters[3] = all[3] + all[12] + all[13] + all[14] + all[15];  // multi-chunk windows: the queue, or the four tail-class lists
     }
     memcpy(out, m->last_counters, 16);

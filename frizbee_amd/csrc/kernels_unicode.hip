@@ -236,7 +236,12 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
 template <int SWL, bool TF, typename ET>
 __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ list,
                                                             const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                            u32* __restrict__ scratch, u32 only_from) {
+                                                            u32* __restrict__ scratch, u32 only_from, u32* __restrict__ counters, u32* __restrict__ back_end, u32 fwd_cap) {
+    // STRAGGLERS: a window of ten chunks keeps its thread - and the kernel - for ten times the latency of a chunk (Arabic-shaped list, All
+    // Scores: 113 us for 45 k windows of which a few dozen are that long), while the wave-per-haystack kernel walks the same window in
+    // ~ 15 us.  Windows beyond four chunks are therefore handed on - appended to the BACK of the queue (counters[4]; the generic kernel
+    // behind this one scores whatever is there: by DP up to 1024 bytes, greedily beyond) - as long as fewer than fwd_cap have been
+    // (counters[7] counts the claims: a list whose windows are all long keeps them here, where the throughput is)
     const u32 nlist = *n_list_ptr;
     if (nlist < only_from) return;  // a short queue is the wave-per-haystack kernel's (launched behind this one with the complementary test)
     __shared__ u8 cls[256];
@@ -253,6 +258,16 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict
         const u32 sp = ws ? ws - 1 : 0;
         const bool include_exact = sp == 0 && we == L;
         const u32 m = we - sp;
+        if (m > 4u * (u32)SWL && fwd_cap) {
+            if (atomicAdd(&counters[7], 1u) < fwd_cap) {
+                u32* qe = back_end - 4 * (size_t)(atomicAdd(&counters[4], 1u) + 1u);
+                qe[0] = opos;
+                qe[1] = ws;
+                qe[2] = we;
+                qe[3] = li;
+                continue;
+            }
+        }
         u32 score = 0;
         if (nd.rows > 0) {
             if (TF) {  // the biased-throughout form (LaunchCfg::cfu_ok); its UTF-8 shortcut when no window of the wave has four continuation bytes in a row
@@ -277,8 +292,8 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict
 }
 
 void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes,
-                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from, int tform) {
-#define FZB_K2UM(SWL, TF, ET) hipLaunchKernelGGL((k2u_dp_unicode_multi<SWL, TF, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, only_from)
+                                 fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from, int tform, u32* counters, u32* back_end, u32 fwd_cap) {
+#define FZB_K2UM(SWL, TF, ET) hipLaunchKernelGGL((k2u_dp_unicode_multi<SWL, TF, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, only_from, counters, back_end, fwd_cap)
 #define FZB_K2UM_TF(SWL, ET) do { if (tform) FZB_K2UM(SWL, true, ET); else FZB_K2UM(SWL, false, ET); } while (0)
 #define FZB_K2UM_ET(SWL) do { if (c.ends_u64) FZB_K2UM_TF(SWL, u64); else FZB_K2UM_TF(SWL, u32); } while (0)
     switch (sw_lanes) {

@@ -20,6 +20,7 @@ struct FzbKnobs {
     bool debug_sync = false;         // FZB_DEBUG_SYNC=1       synchronise and report after every stage of the pipeline
     bool window_four_pass = false;   // FZB_WINDOW_FOUR_PASS=1 lane-exact window kernel on small lists: 256-thread workgroups, four passes per tile (instead of 1024 threads, one pass)
     bool window_no_mask_cache = false;  // FZB_WINDOW_NO_MASK_CACHE=1 lane-exact window kernel: a needle row's occurrence mask recomputed at every request (no LDS cache)
+    bool no_unicode_fwd = false;     // FZB_UNICODE_FWD=0      the thread-per-haystack unicode multi-chunk scorer keeps its windows beyond four chunks (default: hands up to 4096 on to the wave-per-haystack kernel)
     bool no_handoff = false;         // FZB_NO_HANDOFF=1       ragged lists: classifier and scorers gather the survivors' bytes from the corpus (no staging)
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device
     bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint

@@ -33,7 +33,7 @@ def lists():
     ragged = _ragged(rng, 40000, 128, "deadbeef", "deabfxyz_-/ 01DEAB")  # view, classes, multi-chunk tail classes
     uni = _ragged(rng, 20000, 24, "éa", list("abéÉñ_ -/xyzü"))
     wide = _ragged(rng, 30000, 230, "deadbeef", "deabfxyz_-/ 01DEAB")         # haystacks beyond 128 bytes: the view's 16-vector groups
-    uniwide = _ragged(rng, 8000, 150, "éa", list("abéÉñ_ -/xyzü")) + ["é" + "x" * 1100 + "a", "ñ" * 600 + "éa"]  # unicode windows beyond a chunk / beyond 1024 bytes
+    uniwide = _ragged(rng, 8000, 150, "éa", list("abéÉñ_ -/xyzü")) + ["é" + "x" * 1100 + "a", "ñ" * 600 + "éa", "é" + "xü" * 150 + "a", "_é" + "y" * 700 + "a_", "ü" * 200 + "éa" + "x" * 300]  # unicode windows beyond a chunk / four chunks / 1024 bytes
     return {"short": (short, F.Corpus(short)), "ragged": (ragged, F.Corpus(ragged)), "uni": (uni, F.Corpus(uni)), "wide": (wide, F.Corpus(wide)), "uniwide": (uniwide, F.Corpus(uniwide))}
 
 
@@ -59,6 +59,8 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_NO_OVERLAP": "1"}, [("uniwide", "éa", dict(max_typos=None))]),      # whole-haystack unicode windows: the scorer queues the wide ones itself, one stream
     ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict(max_typos=None))]),   # ... queued ahead (default), thread per haystack beside the single-chunk scorer
     ({"FZB_UNICODE_MULTI": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),
+    ({"FZB_UNICODE_MULTI": "1", "FZB_UNICODE_FWD": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),  # the thread-per-haystack scorer keeps its stragglers
+    ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict()), ("uniwide", "éa", dict(max_typos=1))]),                               # ... hands them on (default)
     ({"FZB_WINDOW_FOUR_PASS": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=1))]),  # the lane-exact window kernel, 256-thread form
     ({"FZB_WINDOW_NO_MASK_CACHE": "1"}, [("ragged", "deadbe", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=2))]),  # row masks recomputed at every request
     ({"FZB_WINDOW_NO_MASK_CACHE": "1", "FZB_WINDOW_FOUR_PASS": "1"}, [("uniwide", "éa", dict(max_typos=1))]),
