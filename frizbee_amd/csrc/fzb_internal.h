@@ -259,7 +259,7 @@ void fzb_launch_literal_score(const CorpusDev& c, u64 first, u32 index_offset, c
 // kernels_generic.hip
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st,
-                        int list_forward = 0, u32 only_below = 0);  // list_forward: entry q at list + 4 q; only_below: run only while *n_list_ptr < only_below
+                        int list_forward = 0, u32 only_below = 0, const u32* alt_list = nullptr, const u32* alt_count = nullptr);  // only_below + alt_list: from only_below entries on the launch walks the alternative list (downwards) instead of returning  // list_forward: entry q at list + 4 q; only_below: run only while *n_list_ptr < only_below
 size_t fzb_trace_scratch_words(const NeedleDev& nd, int grid);
 // long needles (NeedleLongDev): kernels_window.hip / kernels_generic.hip / kernels_literal.hip
 size_t fzb_window_long_scratch_bytes(const NeedleLongDev& nd, int grid);

@@ -1235,10 +1235,16 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             if (umin != 0xFFFFFFFFu)
                 fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, wst, umin, lc.cfu_ok, cnt_c, w.overflow + 4 * (size_t)qcap, fwd_cap);
             // (the wave-per-haystack kernel's LDS follows the needle's rows: for short needles its registers decide how many workgroups a CU holds)
-            if (umin != 0u) fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, wst, 1, umin);
-            FZB_STAGE("dp(unicode, wide windows)");
+            // The queue's back - handed-on stragglers (DP) and windows beyond 1024 bytes (greedy) - has a launch of its own only where windows
+            // beyond 1024 bytes can exist; otherwise the front's wave-per-haystack launch, which has nothing to do exactly when the
+            // thread-per-haystack scorer ran, walks the back then (no third launch on the lists that never need one)
+            const bool back_launch = !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN);
             const bool may_fwd = fwd_cap != 0 && !(cd.max_len != 0 && cd.max_len <= 4u * (u32)lc.sw_lanes);
-            if (may_fwd || !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // the queue's back: handed-on stragglers (DP) and windows beyond 1024 bytes (greedy)
+            if (umin != 0u)
+                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, wst, 1, umin,
+                                   (may_fwd && !back_launch) ? w.overflow + 4 * (size_t)qcap : nullptr, &cnt_c[4]);
+            FZB_STAGE("dp(unicode, wide windows)");
+            if (back_launch || (may_fwd && umin == 0u)) {
                 fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c,
                                    may_fwd ? cus * 4 : cus / 4 + 1, wst);
                 FZB_STAGE("generic(unicode, stragglers + greedy)");

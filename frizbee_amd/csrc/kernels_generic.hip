@@ -104,6 +104,8 @@ struct GateArgs {
     const u32* count;
     u32 lo, hi;
     int forward;
+    const u32* alt_list;   // outside [lo, hi): walk this list instead (entry q at alt_list - 4 (q + 1)), *alt_count entries; nullptr: return
+    const u32* alt_count;
 };
 #define TRACE_W (FZB_MAX_HAYSTACK_LEN + 2 * 64)  // columns: the zero chunk + up to 1024 bytes rounded up to a chunk
 
@@ -113,9 +115,17 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
                                                               const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const ND nd,
                                                               fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters,
                                                               const TraceArgs trace, u16* __restrict__ long_adj, const GateArgs gate) {
-    if (gate.count) {  // (uniform) this launch serves the list only when its length is in [lo, hi): another kernel takes it otherwise
-        const u32 gn = *gate.count;
-        if (gn < gate.lo || gn >= gate.hi) return;
+    const u32* lst = list;  // the list this launch walks, its length, its direction
+    const u32* nptr = n_list_ptr;
+    int fwd = gate.forward;
+    if (gate.count) {  // (uniform) this launch serves the list only when its length is in [lo, hi): another kernel takes it otherwise -
+        const u32 gn = *gate.count;  // and this launch then walks the alternative list, if it was given one (read downwards)
+        if (gn < gate.lo || gn >= gate.hi) {
+            if (!gate.alt_list) return;
+            lst = gate.alt_list;
+            nptr = gate.alt_count;
+            fwd = 0;
+        }
     }
     // per wave: previous chunk's row / match mask (ASCII) or pending mask (unicode), one vector per needle row - in LDS (sized by the
     // needle's actual rows: dynamic shared memory; sized for the 63 rows the by-value needle can have it was 64 KB per workgroup, two
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
     const int wv = threadIdx.x >> 6;
     u16* const adj_row_base = LONG ? long_adj + (size_t)(blockIdx.x * GEN_WAVES + wv) * 2 * (size_t)(nd.rows + 1) * SWL : s_adj + (size_t)wv * 2 * (size_t)(nd.rows + 1) * SWL;
     u16* const adj_aux_base = adj_row_base + (size_t)(nd.rows + 1) * SWL;
-    const u32 nlist = *n_list_ptr;
-    if (!list && dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = nlist < capacity ? nlist : capacity; dev_count[1] = nlist; }
+    const u32 nlist = *nptr;
+    if (!lst && dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = nlist < capacity ? nlist : capacity; dev_count[1] = nlist; }
     const u32 LM = (u32)nd.lane_mask;
     const u32 rows = (u32)nd.rows;
     const u32 Mc = nd.match_plus_mismatch & LM, X = nd.mismatch & LM, gex = nd.gex & LM, gopm = nd.gopm & LM;
@@ -138,18 +148,18 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
 
     for (u32 q = blockIdx.x * GEN_WAVES + wv; q < nlist; q += gridDim.x * GEN_WAVES) {
         // list entries: (output position, window start, window end, local haystack index) queued by the single-chunk kernel
-        // list mode: the queue grows downwards from `list` (the end of the chunk's queue slice): entry q is at list - 4 (q + 1)
-        const u32* le = list ? (gate.forward ? list + 4 * (size_t)q : list - 4 * (size_t)(q + 1)) : nullptr;
-        const u32 j = list ? le[0] : q;          // rank inside this chunk (direct mode) / absolute output position (list mode)
+        // list mode: the queue grows downwards from `lst` (the end of the chunk's queue slice): entry q is at lst - 4 (q + 1)
+        const u32* le = lst ? (fwd ? lst + 4 * (size_t)q : lst - 4 * (size_t)(q + 1)) : nullptr;
+        const u32 j = lst ? le[0] : q;          // rank inside this chunk (direct mode) / absolute output position (list mode)
         const u32 opos = j;
         if (opos >= capacity) continue;
-        const u32 li = list ? le[3] : (items ? items[j] : j);
+        const u32 li = lst ? le[3] : (items ? items[j] : j);
         u64 s;
         u32 L;
         haystack_span(ends, first + li, s, L);
         const u8* hay = bytes + s;
         u32 ws, we;
-        if (list) { ws = le[1]; we = le[2]; }
+        if (lst) { ws = le[1]; we = le[2]; }
         else if (wmode == 2) { ws = 0; we = L; }
         else if (TRACE && wmode == 1) {
             // 0-typo ASCII window in its lane-free form (src/prefilter/algo/ascii.rs:6-72): first occurrence of the first needle
@@ -427,9 +437,9 @@ static size_t generic_lds_bytes(const NeedleDev& nd, int sw_lanes) { return (siz
 
 void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* list, const u32* n_list_ptr,
                         const NeedleDev& nd, int sw_lanes, int unicode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, int grid, hipStream_t st,
-                        int list_forward, u32 only_below) {
+                        int list_forward, u32 only_below, const u32* alt_list, const u32* alt_count) {
     const TraceArgs none{nullptr, nullptr, nullptr, 0};
-    const GateArgs gate{only_below ? n_list_ptr : nullptr, 0u, only_below, list_forward};
+    const GateArgs gate{only_below ? n_list_ptr : nullptr, 0u, only_below, list_forward, only_below ? alt_list : nullptr, alt_count};
     const size_t lds = generic_lds_bytes(nd, sw_lanes);
 #define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false, ET>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none, (u16*)nullptr, gate)
 #define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
@@ -452,7 +462,7 @@ void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, c
                               int grid, hipStream_t st) {
     const TraceArgs tr{cells, pos, npos, stride};
     const size_t lds = generic_lds_bytes(nd, sw_lanes);
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, (u16*)nullptr, GateArgs{nullptr, 0u, 0u, 0})
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, (u16*)nullptr, GateArgs{nullptr, 0u, 0u, 0, nullptr, nullptr})
     switch (sw_lanes) {
         case 64: FZB_K2C_U(64); break;
         case 32: FZB_K2C_U(32); break;
@@ -475,7 +485,7 @@ void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, co
     // the previous-chunk vectors in LDS when they fit (60 KB per four-wave workgroup: up to 127 rows at 32 lanes), in the slab otherwise
     const size_t lds = (size_t)GEN_WAVES * 2 * (size_t)(nd.rows + 1) * (size_t)sw_lanes * sizeof(u16);
     const bool in_lds = lds <= (size_t)60 * 1024;
-#define FZB_K2C_LS(SWL, U, T, ET, SLAB) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev, SLAB>), dim3(grid), dim3(GEN_WAVES * 64), SLAB ? 0 : lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 0})
+#define FZB_K2C_LS(SWL, U, T, ET, SLAB) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev, SLAB>), dim3(grid), dim3(GEN_WAVES * 64), SLAB ? 0 : lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 0, nullptr, nullptr})
 #define FZB_K2C_L(SWL, U, T, ET) do { if (in_lds) FZB_K2C_LS(SWL, U, T, ET, false); else FZB_K2C_LS(SWL, U, T, ET, true); } while (0)
 #define FZB_K2C_L_ET(SWL, U, T) do { if (c.ends_u64) FZB_K2C_L(SWL, U, T, u64); else FZB_K2C_L(SWL, U, T, u32); } while (0)
 #define FZB_K2C_L_T(SWL, U) do { if (trace) FZB_K2C_L_ET(SWL, U, true); else FZB_K2C_L_ET(SWL, U, false); } while (0)
