@@ -1204,7 +1204,8 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // `umin` windows on, the wave-per-haystack kernel (1.6 - 2.7 ns per window, no fixed cost) below.  Measured (tools/exp_unicode_wide.py):
         // 45 k windows (Arabic-shaped list, All Scores) 0.215 ms wave per haystack / 0.204 thread per haystack, 361 k windows 1.285 / 0.815.
         // FZB_UNICODE_MULTI=0 / 1: never / always.
-        const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : (u32)cus * 128u;
+        // (a range smaller than the switch point cannot queue that many windows: the thread-per-haystack scorer is not even launched)
+        const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : cnt < (u32)cus * 128u ? 0xFFFFFFFFu : (u32)cus * 128u;
         const int ugrid = cus * 2;  // multi-chunk unicode scorer: one wave per SIMD (two-wave workgroups)
         if (umin != 0xFFFFFFFFu && (rc = ensure_dp_scratch(m, ugrid))) return rc;  // first use only (or fzb_matcher_reserve)
         // Whole-haystack windows (max_typos: None): the wide ones are known from the end offsets, so they are queued FIRST and their scorers run
