@@ -368,6 +368,118 @@ def other_configs(F, synth, dev, steps):
     return res
 
 
+def c4_sharded_block(F, synth, dist, dev, rank, world, total, steps, stream):
+    """BASELINE.json configs[3] at N ranks: needle 'deadbeef' (8 chars) vs `total` mixed-length (8..128 byte) haystacks, max_typos=0, cut into
+    BYTE-balanced contiguous index ranges (frizbee_amd.distributed.shard_ranges_by_bytes; the reference's shape: contiguous chunks with a
+    global index offset, src/matcher/parallel.rs:35-87), one range per rank.  The list is defined globally - one seeded length vector every
+    rank derives identically - and each rank builds only its own shard.  Timed like the headline: K steps of the rank's pipeline writing
+    into the exchange buffer + the asynchronous double-buffered gather to rank 0, barrier + synchronize on both sides, max over ranks.
+    Beside it the ORDERED query (`ShardExchange.ordered_query`: gather, one device-side concatenation / radix sort on the root, one D2H,
+    grow-and-retry if a shard outgrows the exchange).  Checks (untimed): the ranges partition the list; every shard's first items equal the
+    CPU oracle's records and every record's index lies in its shard's range; merged length == sum of the shard counts; merged order ==
+    (score desc, index asc).  Every rank calls this (collectives inside); rank 0 returns the row."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from frizbee_amd.distributed import ShardExchange, shard_ranges_by_bytes
+
+    g = torch.Generator()
+    g.manual_seed(12346)
+    lengths = torch.randint(8, 129, (total,), generator=g)  # the global list's lengths, identical on every rank
+    ends_all = np.cumsum(lengths.numpy().astype(np.uint64), dtype=np.uint64)
+    ranges = shard_ranges_by_bytes(ends_all, world)
+    lo, hi = ranges[rank]
+    n_loc = hi - lo
+    parts, chunk = [], 1 << 22  # this rank's haystacks, content seeded per shard and chunk (bounded temporaries: 4 M rows of 128 B at a time)
+    for ci, a in enumerate(range(lo, hi, chunk)):
+        b = min(a + chunk, hi)
+        L = lengths[a:b].to(dev)
+        rows_c = synth.make_rows(b"deadbeef", b - a, 128, lengths=L, seed=12345 + 7919 * rank + ci, device=dev)
+        parts.append(rows_c[torch.arange(128, device=dev)[None, :] < L[:, None]].cpu().numpy())
+        del rows_c, L
+    packed = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    del parts
+    ends = ends_all[lo:hi] - (ends_all[lo - 1] if lo else np.uint64(0))
+    t0 = time.perf_counter()
+    corpus = F.Corpus(packed=(packed, ends))
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    m = F.Matcher("deadbeef", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64))
+    out = torch.zeros(n_loc * 8 + 64, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(4, dtype=torch.int32, device=dev)
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    m.match_list_device(corpus, out.data_ptr(), n_loc, cnt.data_ptr(), stream=stream, index_offset=lo)
+    torch.cuda.synchronize(dev)
+    k_local = int(cnt[0].item())
+    # this shard's head against the CPU oracle (checker), index order, global indices
+    c = min(200_000, n_loc)
+    got = out[: k_local * 8].cpu().numpy().view(F.MATCH_DTYPE)
+    if c:
+        want = O.Matcher("deadbeef", lanes=(64, 64, 32), max_typos=0, sort="IndexAsc").match_packed(np.concatenate([packed[: int(ends[c - 1])], np.zeros(64, np.uint8)]), ends[:c])
+        want["index"] += np.uint32(lo)
+        shard_ok = got[got["index"] < lo + c].tolist() == want.tolist() and bool(((got["index"] >= lo) & (got["index"] < hi)).all())
+    else:
+        shard_ok = len(got) == 0
+    ex = ShardExchange(ShardExchange.plan(k_local, margin=1.25, device=None if dist.get_backend() != "nccl" else dev), dev)
+    step_no = [0]
+
+    def step():
+        slot = step_no[0] & 1
+        step_no[0] += 1
+        ex.wait(slot)
+        m.match_list_device(corpus, ex.records_ptr(slot), ex.cap, ex.count_ptr(slot), stream=stream, index_offset=lo)
+        ex.post(slot)
+
+    for _ in range(4):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    t_score = (time.perf_counter() - t0) / steps
+    ex.collect(0)
+    ex.collect(1)
+    merged = None
+    for _ in range(2):
+        merged = ex.ordered_query(lambda rp, cap, cp: m.match_list_device(corpus, rp, cap, cp, stream=stream, index_offset=lo), m, stream=stream)
+    k_e2e = max(3, min(10, steps))
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(k_e2e):
+        merged = ex.ordered_query(lambda rp, cap, cp: m.match_list_device(corpus, rp, cap, cp, stream=stream, index_offset=lo), m, stream=stream)
+    fence()
+    t_e2e = (time.perf_counter() - t0) / k_e2e
+    ctl = torch.device("cpu") if dist.get_backend() != "nccl" else dev
+    oks = torch.tensor([int(shard_ok), k_local], dtype=torch.int64, device=ctl)
+    allv = [torch.zeros_like(oks) for _ in range(world)]
+    dist.all_gather(allv, oks)
+    t = torch.tensor([t_score, t_e2e], dtype=torch.float64, device=ctl)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    row = None
+    if rank == 0:
+        total_matches = int(sum(int(v[1]) for v in allv))
+        key = (0xFFFF - merged["score"].astype(np.int64)) * (1 << 32) + merged["index"].astype(np.int64)
+        sum_len = int(ends_all[-1]) if total else 0
+        bytes_ = sum_len + 4 * total + 8 * total_matches
+        row = {"haystacks": total, "n_gpus": world, "bytes": sum_len,
+               "shards": [{"range": [int(a), int(b)], "bytes": (int(ends_all[b - 1]) if b else 0) - (int(ends_all[a - 1]) if a else 0)} for a, b in ranges],
+               "ms_per_step": float(t[0]) * 1e3, "haystacks_per_s": total / float(t[0]), "matches": total_matches,
+               "roofline_step": {"bytes": bytes_, "GBps": bytes_ / float(t[0]) / 1e9, "frac_of_all_gpus_hbm": bytes_ / float(t[0]) / 1e9 / (HBM_PEAK_GBS * world),
+                                 "what": "SURVEY 8(d) bytes of the WHOLE list (sum len + 4 N + 8 M) / step time / (8 TB/s x ranks)"},
+               "e2e_ordered_list_on_rank0_ms": float(t[1]) * 1e3, "exchange_capacity_records": ex.cap, "exchange_grown": ex.grown, "upload_ms_rank0": upload_ms,
+               "checks": {"ranges_partition_the_list": bool(ranges[0][0] == 0 and ranges[-1][1] == total and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))),
+                          "every_shard_head_equals_oracle_and_indices_in_range": all(int(v[0]) == 1 for v in allv), "oracle_items_per_shard": c,
+                          "merged_len_equals_sum_of_shard_counts": int(len(merged)) == total_matches,
+                          "merged_order_is_score_desc_then_index_asc": bool((np.diff(key) > 0).all()) if len(key) > 1 else True},
+               "what": "BASELINE.json configs[3]: 'deadbeef' vs mixed-length 8..128 B haystacks, max_typos=0, byte-balanced contiguous shards, one per rank; "
+                       "timed like the headline (pipeline + asynchronous double-buffered gather to rank 0, max over ranks)"}
+    del corpus, m, out, cnt, ex
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,7 +494,13 @@ def main():
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-streams throughput figure")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child runs; report the stored traffic figure")
     ap.add_argument("--fast", action="store_true", help="= --no-cpu-baseline --no-configs --no-check --no-two-in-flight (profiling runs)")
+    ap.add_argument("--c4-total", type=int, default=-1,
+                    help="N > 1: haystacks of the BASELINE configs[3] row (100M ragged, byte-balanced shards); -1 = 100,000,000 when more than one rank runs, 0 = skip the row")
     args = ap.parse_args()
+    # FZB_BENCH_BACKEND=gloo: the rank-count REHEARSAL of the N > 1 path on a box with fewer GPUs than ranks - ranks share the visible GPU(s),
+    # the exchange moves CPU tensors (ShardExchange stages them), everything else is the code an RCCL run executes.  Labelled in the line.
+    backend = os.environ.get("FZB_BENCH_BACKEND", "nccl")
+    rehearsal = backend != "nccl"
     if args.fast:
         args.no_cpu_baseline = args.no_configs = args.no_check = args.no_two_in_flight = args.no_live_traffic = args.no_sharded = True
 
@@ -390,7 +508,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the product path)")
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
-    if torch.cuda.device_count() < args.gpus:
+    if torch.cuda.device_count() < args.gpus and not rehearsal:
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node - refusing to run fewer ranks than asked for")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # invoked as plain `python bench.py --gpus N`: start the N ranks ourselves, exactly the way the driver would
@@ -415,8 +533,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count() if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     # FZB_BENCH_FORCE_DIST=1 runs the N > 1 code path (process group, exchange) with a single rank: a self-test of that
     # path on a 1-GPU box, not a benchmark configuration
@@ -425,7 +544,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ctl_dev = torch.device("cpu") if rehearsal else dev  # where the small control tensors of the collectives live
 
     import frizbee_amd as F
     import synth
@@ -456,7 +579,9 @@ def main():
         # set-up (untimed): one synchronous pass sizes the exchange buffers every rank agrees on
         m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=stream, index_offset=index_offset)
         torch.cuda.synchronize(dev)
-        ex = ShardExchange(ShardExchange.plan(int(cnt[0].item()), margin=1.05, device=dev), dev)  # (the bench repeats ONE query: the count does not move)
+        # (the timed loop repeats ONE query without looking at the counts, so its exchange is sized from this first count; a caller whose queries
+        # differ uses ShardExchange.ordered_query - below, `e2e_sorted_merge` - which re-sizes the exchange and repeats the query when a shard outgrows it)
+        ex = ShardExchange(ShardExchange.plan(int(cnt[0].item()), margin=1.25, device=ctl_dev), dev)
         # (still set-up: RCCL builds its channels and rings lazily on the first few collectives of a communicator - several
         # milliseconds each - so a handful of exchanges is run here, before the W warm-up steps of the contract)
         for s_ in range(8):
@@ -502,7 +627,7 @@ def main():
     st = m.last_stage_timings_ms()
     m.set_profiling(False)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -525,21 +650,51 @@ def main():
         # Round 3 sorted per rank and k-merged on the root's host: 4.1 ms per step with one rank.
         k_e2e = max(3, min(10, args.steps))
         merged2 = None
+
+        def run_into(records_ptr, capacity, count_ptr):
+            m.match_list_device(corpus, records_ptr, capacity, count_ptr, stream=stream, index_offset=index_offset)
+
+        # the first ordered query starts from an exchange that is deliberately too small: ordered_query must re-size it and repeat the query
+        ex_small = ShardExchange(4096, dev)
+        merged_grow = ex_small.ordered_query(run_into, m, stream=stream)
+        grew = ex_small.grown
+        del ex_small
         for _ in range(2):  # (untimed: the root's staging / sort buffers and the pinned result buffer are allocated on first use)
-            m.match_list_device(corpus, ex.records_ptr(0), ex.cap, ex.count_ptr(0), stream=stream, index_offset=index_offset)
-            ex.post(0)
-            merged2 = ex.collect_merged(0, m, stream=stream)
+            merged2 = ex.ordered_query(run_into, m, stream=stream)
         fence()
         t0 = time.perf_counter()
         for _ in range(k_e2e):
-            m.match_list_device(corpus, ex.records_ptr(0), ex.cap, ex.count_ptr(0), stream=stream, index_offset=index_offset)
-            ex.post(0)
-            merged2 = ex.collect_merged(0, m, stream=stream)
+            merged2 = ex.ordered_query(run_into, m, stream=stream)
         fence()
         e2e_multi = {"ms_per_step": (time.perf_counter() - t0) / k_e2e * 1e3, "steps": k_e2e,
-                     "what": "per-rank pipeline (index order, global indices) + synchronous RCCL gather into rank 0's HBM + ONE device-side concatenation / stable radix sort + one D2H, every step",
+                     "what": "ShardExchange.ordered_query, every step: per-rank pipeline (index order, global indices) + gather into rank 0's memory + ONE concatenation / stable radix sort "
+                             "(on the device with RCCL; on the host in the gloo rehearsal) + one D2H + an 8-byte broadcast that tells every rank the exchange held every run (grow-and-retry otherwise)",
                      "merged_len": int(len(merged2)) if rank == 0 else None,
-                     "equals_host_merge": bool(merged2.tobytes() == merged.tobytes()) if rank == 0 else None}
+                     "equals_host_merge": bool(merged2.tobytes() == merged.tobytes()) if rank == 0 else None,
+                     "grow_and_retry": {"exchange_started_at_records": 4096, "times_grown": grew,
+                                        "result_equals": bool(merged_grow.tobytes() == merged.tobytes()) if rank == 0 else None}}
+        # every rank: the first items of ITS shard against the CPU oracle (checker, untimed), records in index order with global indices
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        n_chk = min(n, 1_000_000)
+        m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr(), stream=stream, index_offset=index_offset, count=n_chk)
+        torch.cuda.synchronize(dev)
+        got_s = out[: int(cnt[0].item()) * 8].cpu().numpy().view(F.MATCH_DTYPE)
+        want_s = O.Matcher(NEEDLE.decode(), lanes=(64, 64, 32), max_typos=args.max_typos, sort="IndexAsc").match_packed(
+            np.concatenate([rows[:n_chk].reshape(-1).cpu().numpy(), np.zeros(64, np.uint8)]), np.arange(1, n_chk + 1, dtype=np.uint64) * np.uint64(HAY_LEN))
+        want_s["index"] += np.uint32(index_offset)
+        okt = torch.tensor([int(got_s.tolist() == want_s.tolist())], dtype=torch.int64, device=ctl_dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        e2e_multi["every_shard_head_equals_oracle"] = {"items_per_shard": n_chk, "equal_on_every_rank": bool(int(okt.item()) == 1)}
+        if n * world <= 4_000_000:
+            # small totals (the rehearsal): the WHOLE merged list against the oracle's ordered list - rank 0 regenerates every shard's rows (seeded)
+            if rank == 0:
+                allrows = torch.cat([synth.make_rows(NEEDLE, n, HAY_LEN, seed=12345 + r_, device=dev) for r_ in range(world)]).reshape(-1).cpu().numpy()
+                want_all = O.Matcher(NEEDLE.decode(), lanes=(64, 64, 32), max_typos=args.max_typos, sort="ScoreThenIndexAsc").match_packed(
+                    np.concatenate([allrows, np.zeros(64, np.uint8)]), np.arange(1, n * world + 1, dtype=np.uint64) * np.uint64(HAY_LEN))
+                e2e_multi["merged_equals_oracle_list"] = bool(merged2.tolist() == want_all.tolist())
+        c4_total = args.c4_total if args.c4_total >= 0 else (100_000_000 if world > 1 else 0)
+        c4_row = c4_sharded_block(F, synth, dist, dev, rank, world, c4_total, max(3, min(10, args.steps)), stream) if c4_total else None
     counters = m.last_counters()
     if rank == 0:
         total = n * world
@@ -575,7 +730,9 @@ def main():
                        "haystacks_per_gpu": n, "haystack_len": HAY_LEN, "max_typos": args.max_typos,
                        "emulated_reference_backend": "AVX-512 (prefilter 64 lanes, Smith-Waterman 64 x u8)",
                        "sharding": f"contiguous index ranges over {world} GPU(s); per step an asynchronous, double-buffered RCCL gather of the match records to rank 0" if world > 1 else "single GPU",
-                       "ranks_seen": (dist.get_world_size() if use_dist else 1), "backend": ("nccl (RCCL)" if use_dist else "none (single process)"),
+                       "ranks_seen": (dist.get_world_size() if use_dist else 1),
+                       "backend": ((f"{backend} - REHEARSAL of the N > 1 path: {world} rank(s) share {torch.cuda.device_count()} GPU(s), the exchange moves CPU tensors; not a scaling measurement"
+                                    if rehearsal else "nccl (RCCL)") if use_dist else "none (single process)"),
                        "matches_per_shard": n_matches, "filter_survivors": counters["filter_survivors"], "exchange": gathered},
             "roofline": {"bound": "hbm", "kernel": "k1_dfa", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": tr.get("k1_filter_hbm_bytes_per_launch"),
@@ -588,6 +745,8 @@ def main():
         }
         if e2e_multi:
             res["e2e_sorted_merge"] = e2e_multi
+            if c4_row is not None:
+                res["configs"] = {f"C4 sharded over {world} GPU(s): {c4_row['haystacks']:,} ragged 8..128 B, 'deadbeef', max_typos=0 (BASELINE.json configs[3])": c4_row}
         if world == 1:
             # what `Matcher::match_list` hands a caller: ordered records in host memory (pipeline + device sort + D2H), per call
             torch.cuda.set_stream(torch.cuda.default_stream(dev))

@@ -115,7 +115,7 @@ SYMBOLS = [
     "fzb_match_list_indices_into", "fzb_multi_match_list_into", "fzb_multi_match_list_indices_into",
     "fzb_device_count", "fzb_shard_ranges", "fzb_corpus_upload_sharded", "fzb_sharded_corpus_free", "fzb_sharded_corpus_len", "fzb_sharded_corpus_shards",
     "fzb_sharded_corpus_shard", "fzb_match_list_parallel_sharded", "fzb_debug_lcs_dfa_accepts", "fzb_debug_cdfa_state",
-    "fzb_merge_shard_runs", "fzb_corpus_build_view", "fzb_debug_reload_knobs",
+    "fzb_merge_shard_runs", "fzb_corpus_build_view", "fzb_debug_reload_knobs", "fzb_matcher_shard_report",
 ]
 
 
@@ -178,6 +178,8 @@ def lib():
         l.fzb_sharded_corpus_shards.argtypes = [C.c_void_p]
         l.fzb_sharded_corpus_shard.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
         l.fzb_match_list_parallel_sharded.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_matcher_shard_report.argtypes = [C.c_void_p]
+        l.fzb_matcher_shard_report.restype = C.c_char_p
         l.fzb_merge_shard_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzb_corpus_build_view.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         l.fzb_debug_lcs_dfa_accepts.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
@@ -238,10 +240,11 @@ class Corpus:
         self.h = C.c_void_p()
         self._keep = keep
         _check(lib().fzb_corpus_from_device(dev_bytes_ptr, dev_ends_ptr, int(ends_are_u64), n, total_bytes, C.byref(self.h)))
-        if max_len:
-            _check(lib().fzb_corpus_set_max_len(self.h, max_len))
+        # (both promises are verified on the device against the end offsets when they are made; the uniform length first: it implies its bound)
         if uniform_len:
             _check(lib().fzb_corpus_set_uniform_len(self.h, uniform_len))
+        if max_len and max_len != uniform_len:
+            _check(lib().fzb_corpus_set_max_len(self.h, max_len))
         return self
 
     def build_view(self):
@@ -530,6 +533,11 @@ class Matcher(_IterApi):
         out, n = C.c_void_p(), C.c_size_t()
         _check(lib().fzb_match_list_parallel_sharded(self.h, sharded.h, C.byref(out), C.byref(n)))
         return _take(out, n, copy)
+
+    def shard_report(self):
+        """How the runs of the last `match_list_parallel_sharded` reached the root (fzb_matcher_shard_report): gather form and, per shard,
+        same device / peer access enabled / peer access refused (the runtime then stages the copy through host memory)."""
+        return lib().fzb_matcher_shard_report(self.h).decode()
 
     @staticmethod
     def merge_args(run_ptrs, count_ptrs, run_caps):

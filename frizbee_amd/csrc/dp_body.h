@@ -19,6 +19,9 @@ __device__ __forceinline__ u32 p_max3_s(u32 a, u32 b, u32 s) {
 #ifdef FZB_HOST_SHIM
     return p_max(p_max(a, b), s);
 #else
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "p_max3_s is v_pk_maximum3_f16: gfx950 (MI355X) only - this library is built for that one target (csrc/Makefile refuses any other ARCH)"
+#endif
     u32 r;
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(s));
     return r;

@@ -11,6 +11,7 @@ typedef uint64_t u64;
 #define FZB_MAX_ROWS 63        // needle rows of the by-value NeedleDev (bytes on the ASCII path, scalars on the unicode path); longer needles: NeedleLongDev
 #define FZB_MAX_NEEDLE_BYTES 64
 #define FZB_MAX_HAYSTACK_LEN 1024  // reference: src/smith_waterman/algo/mod.rs:18 (beyond this the greedy fallback scores)
+#define FZB_UNICODE_FWD_CAP 4096u  // windows beyond four chunks the thread-per-haystack unicode scorer hands on per query (and the room the queue's back keeps for them)
 #define FZB_TILE 1024          // haystacks per filter tile (one bitmap group + one count)
 
 // Needle + scoring constants, passed BY VALUE as a kernel argument (wave-uniform -> SGPR loads).

@@ -192,6 +192,7 @@ FzbKnobs parse_knobs() {
     k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
     k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
+    k.verify_promises = num("FZB_VERIFY_PROMISES", 1) != 0;
     k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");
     k.small_list = getenv("FZB_SMALL_LIST") ? (uint32_t)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
     k.compact_grid_mul = std::max(1, num("FZB_COMPACT_GRID_MUL", 4));
@@ -689,6 +690,56 @@ int fzb_matcher_info(const fzb_matcher* m, int32_t out[6]) {
 }
 
 // ---- corpus (fzb_corpus_upload: host_upload.hip) -------------------------------------------------------
+}  // extern "C"
+// A promise about BORROWED memory (uniform length / longest haystack) selects kernels that compute spans instead of reading the end
+// offsets, or that skip launches: a wrong one would silently mis-span every haystack.  One pass over the end offsets checks it when it is
+// made (a set-up call: it synchronises): offsets non-decreasing in the padded-16 layout and inside the buffer, every length == uniform_len
+// (when given), every length <= max_len (when given).  out[0] = number of violations, out[1] = the first offending index.
+template <typename ET>
+__global__ __launch_bounds__(256) void k_verify_promise(const ET* __restrict__ ends, u64 n, u64 total_bytes, u32 uniform_len, u32 max_len, unsigned long long* __restrict__ out) {
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    u32 bad = 0;
+    u64 first_bad = ~0ull;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const u64 e = (u64)ends[i];
+        const u64 s = i ? (((u64)ends[i - 1] + 15ull) & ~15ull) : 0ull;
+        bool ok = e >= s && e <= total_bytes;
+        const u64 len = e - s;
+        if (uniform_len) ok = ok && len == (u64)uniform_len;
+        if (max_len) ok = ok && len <= (u64)max_len;
+        if (!ok) {
+            bad++;
+            first_bad = first_bad < i ? first_bad : i;
+        }
+    }
+    if (bad) {
+        atomicAdd(&out[0], (unsigned long long)bad);
+        atomicMin(&out[1], (unsigned long long)first_bad);
+    }
+}
+static int verify_promise(const fzb_corpus* c, u32 uniform_len, u32 max_len, const char* what) {
+    if (!fzb_knobs().verify_promises || !c->dev.n || (!uniform_len && !max_len)) return FZB_OK;
+    unsigned long long* d = nullptr;
+    HIPCHK(hipDeviceSynchronize());  // the caller may have filled the buffers on any stream
+    HIPCHK(hipMalloc((void**)&d, 16));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    hipError_t e = hipMemcpy(d, init, 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const int grid = (int)std::min<u64>((c->dev.n + 255) / 256, 4096);
+        if (c->dev.ends_u64) hipLaunchKernelGGL((k_verify_promise<u64>), dim3(grid), dim3(256), 0, 0, (const u64*)c->dev.ends, c->dev.n, c->dev.total_bytes, uniform_len, max_len, d);
+        else hipLaunchKernelGGL((k_verify_promise<u32>), dim3(grid), dim3(256), 0, 0, (const u32*)c->dev.ends, c->dev.n, c->dev.total_bytes, uniform_len, max_len, d);
+        e = hipGetLastError();
+    }
+    unsigned long long got[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(got, d, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(FZB_ERR_HIP, std::string("verifying the corpus promise: ") + hipGetErrorString(e));
+    if (got[0])
+        return fail(FZB_ERR_INVALID, std::string(what) + ": the end offsets contradict it for " + std::to_string(got[0]) + " haystack(s), first at index " + std::to_string(got[1]) +
+                                         " (checked on the device; FZB_VERIFY_PROMISES=0 skips the check)");
+    return FZB_OK;
+}
+extern "C" {
 int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends_are_u64, size_t n, uint64_t total_bytes, fzb_corpus** out) {
     if (!out || (n && (!dev_bytes || !dev_ends))) return fail(FZB_ERR_INVALID, "null argument");
     if (((uintptr_t)dev_bytes & 15) != 0) return fail(FZB_ERR_INVALID, "dev_bytes must be 16-byte aligned");
@@ -722,6 +773,10 @@ int fzb_corpus_set_uniform_len(fzb_corpus* c, uint32_t len) {
                                          ", 0 = not uniform); the promise can only be made for borrowed device memory");
     }
     if (len && (u64)((len + 15u) & ~15u) * (c->dev.n ? c->dev.n - 1 : 0) + len > c->dev.total_bytes) return fail(FZB_ERR_INVALID, "uniform length does not fit the corpus buffer");
+    if (len) {  // the promise is checked against the end offsets before any kernel relies on it
+        const int vrc = verify_promise(c, len, 0, ("a uniform length of " + std::to_string(len) + " bytes was promised").c_str());
+        if (vrc) return vrc;
+    }
     if (!len && c->dev.uniform_len && c->dev.max_len == c->dev.uniform_len) c->dev.max_len = 0;  // clearing the promise also clears the bound it implied
     c->dev.uniform_len = len;
     if (len) c->dev.max_len = len;  // (overwrites an earlier fzb_corpus_set_max_len)
@@ -738,6 +793,10 @@ int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
                                          std::to_string(max_len) + " is not an upper bound");
     }
     if (c->dev.uniform_len && max_len != c->dev.uniform_len) return fail(FZB_ERR_INVALID, "the corpus promises a uniform length of " + std::to_string(c->dev.uniform_len) + " bytes");
+    if (max_len && max_len != c->dev.uniform_len) {  // (a uniform length already verified implies its own bound)
+        const int vrc = verify_promise(c, 0, max_len, ("a longest haystack of " + std::to_string(max_len) + " bytes was promised").c_str());
+        if (vrc) return vrc;
+    }
     c->dev.max_len = max_len;
     return FZB_OK;
 }
@@ -1181,7 +1240,11 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     }
     if (pev) HIPCHK(hipEventRecord(pev[4], st));
     fzb_match_rec* outp = (fzb_match_rec*)dev_out;
-    const u32 qcap = cnt;  // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back
+    // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back.  Every item is queued at
+    // most once by its scorer (front + back <= cnt), and the thread-per-haystack unicode scorer may hand up to 4096 of the front's windows on
+    // to the back WHILE the front is still being read: the back gets 4096 entries of room of its own below the front's reach (the allocation
+    // holds count + count/8 + 4096 entries), so a forwarded entry can never land on a front slot that has not been consumed yet
+    const u32 qcap = cnt + FZB_UNICODE_FWD_CAP;
     const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
     if (trace) {
         // matched indices: one traced generic scorer for every window width, ASCII and unicode (kernels_generic.hip)
@@ -1232,7 +1295,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         FZB_STAGE("dp(unicode)");
         if (!no_wide) {
             // (the thread-per-haystack scorer hands windows beyond four chunks - up to 4096 of them - on to the queue's back: FZB_UNICODE_FWD=0 keeps them)
-            const u32 fwd_cap = (umin != 0xFFFFFFFFu && !kn.no_unicode_fwd) ? 4096u : 0u;
+            const u32 fwd_cap = (umin != 0xFFFFFFFFu && !kn.no_unicode_fwd) ? FZB_UNICODE_FWD_CAP : 0u;
             if (umin != 0xFFFFFFFFu)
                 fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, wst, umin, lc.cfu_ok, cnt_c, w.overflow + 4 * (size_t)qcap, fwd_cap);
             // (the wave-per-haystack kernel's LDS follows the needle's rows: for short needles its registers decide how many workgroups a CU holds)

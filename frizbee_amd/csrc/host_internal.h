@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <string>
 #include <vector>
 
@@ -93,6 +94,11 @@ struct fzb_matcher {
     hipEvent_t shard_event = nullptr;    // on a clone: "the run has arrived on the root"
     u32* shard_count_host = nullptr;     // on a clone: page-locked landing place of its record count
     int shard_device = -1;
+    // on the parent: peer access between the root and every other device a shard lived on, decided once per (root, device) pair
+    // (1 = enabled in both directions: runs travel device to device over xGMI; 0 = refused by the runtime: hipMemcpyPeerAsync stages
+    // them through host memory), and the last query's report of how every shard's run reached the root (fzb_matcher_shard_report)
+    std::vector<std::array<int, 3>> shard_peers;  // {root, device, state}
+    std::string shard_report;
 };
 
 

@@ -56,6 +56,8 @@ int for_shards(size_t nshards, F fn) {
 class ShardWorkers {
 public:
     explicit ShardWorkers(size_t n) : res_(n) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        spin_ok_ = hw == 0 || n <= (size_t)hw / 2;
         for (size_t g = 1; g < n; g++) th_.emplace_back([this, g] { loop(g); });
     }
     ~ShardWorkers() {
@@ -97,10 +99,14 @@ private:
         uint64_t seen = 0;
         for (;;) {
             uint64_t now;
-            for (unsigned spin = 0; (now = gen_.load(std::memory_order_acquire)) == seen && spin < 20000; spin++) {
+            // (polling only pays while every worker has a core to itself: with more shards than half the host's hardware threads the
+            // pollers would take the cores of the very workers being waited for - they go to sleep at once then)
+            const unsigned spin_max = spin_ok_ ? 20000u : 0u;
+            for (unsigned spin = 0; (now = gen_.load(std::memory_order_acquire)) == seen && spin < spin_max; spin++) {
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif
+                if ((spin & 1023u) == 1023u) std::this_thread::yield();
             }
             if (now == seen) {
                 std::unique_lock<std::mutex> l(mu_);
@@ -122,6 +128,7 @@ private:
     const std::function<int(size_t)>* fn_ = nullptr;
     size_t n_ = 0;
     bool stop_ = false;
+    bool spin_ok_ = true;
 };
 }  // namespace
 
@@ -321,6 +328,28 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
             }
         }
     }
+    // Peer access, once per (root, device) pair: with it hipMemcpyPeerAsync moves a run device to device over xGMI (SDMA); without it the
+    // runtime stages the copy through host memory - still correct, several times slower, and reported (fzb_matcher_shard_report), never
+    // silent.  hipDeviceEnablePeerAccess is per direction and per current device: both directions are asked for.
+    for (size_t g = 0; g < ns; g++) {
+        const int d = sc->device[g];
+        if (d == root) continue;
+        bool known = false;
+        for (const auto& pr : m->shard_peers) known = known || (pr[0] == root && pr[1] == d);
+        if (known) continue;
+        int can_rd = 0, can_dr = 0;
+        if (hipDeviceCanAccessPeer(&can_rd, root, d) != hipSuccess) can_rd = 0;
+        if (hipDeviceCanAccessPeer(&can_dr, d, root) != hipSuccess) can_dr = 0;
+        int state = 0;
+        if (can_rd && can_dr) {
+            hipError_t e1 = hipSetDevice(root) == hipSuccess ? hipDeviceEnablePeerAccess(d, 0) : hipErrorInvalidDevice;
+            hipError_t e2 = hipSetDevice(d) == hipSuccess ? hipDeviceEnablePeerAccess(root, 0) : hipErrorInvalidDevice;
+            state = ((e1 == hipSuccess || e1 == hipErrorPeerAccessAlreadyEnabled) && (e2 == hipSuccess || e2 == hipErrorPeerAccessAlreadyEnabled)) ? 1 : 0;
+        }
+        (void)hipGetLastError();  // a refusal is a state, not an error of this query
+        (void)hipSetDevice(root);
+        m->shard_peers.push_back({root, d, state});
+    }
     // How the runs reach the root.  PULL (every shard lives on the root device - one GPU holding several shards): the workers only enqueue
     // their pipelines; the root's stream waits for them and ONE kernel concatenates the runs, reading their lengths on the device - no
     // host round trip before the final list.  COPY (shards on other devices): each worker reads its count back (8 bytes) and copies its
@@ -404,16 +433,38 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
         rc = pool->run(ns, shard_job);
     }
     (void)hipSetDevice(root);
-    if (rc) {  // let the copies that were started finish before anything else touches the buffers
+    // Every failure from here on leaves through `drained`: the copies (and pipelines) the shards have in flight write into this matcher's
+    // buffers, so they are waited for before the caller can retry or free anything (the message of the failure is kept)
+    auto drained = [&](int code) -> int {
+        const std::string msg = fzb_last_error();
         for (size_t g = 0; g < ns; g++)
             if (copied[g]) (void)hipEventSynchronize(m->shard_clones[g]->shard_event);
-        return rc;
+        (void)hipStreamSynchronize(m->shard_stream);
+        (void)hipGetLastError();
+        return fzb_fail(code, msg);
+    };
+    if (rc) return drained(rc);
+    {   // how every run travelled (fzb_matcher_shard_report)
+        std::string rep = "root device " + std::to_string(root) + "; gather " + (pull ? "pull (one concatenation kernel reads the runs)" : "copy (count to the host, run copied to its place)");
+        for (size_t g = 0; g < ns; g++) {
+            const int d = sc->device[g];
+            rep += "; shard " + std::to_string(g) + " on device " + std::to_string(d) + ": ";
+            if (d == root) { rep += "same device"; continue; }
+            int state = 0;
+            for (const auto& pr : m->shard_peers)
+                if (pr[0] == root && pr[1] == d) state = pr[2];
+            rep += state ? "peer access enabled (device to device over xGMI)" : "peer access REFUSED by the runtime (hipMemcpyPeerAsync stages the run through host memory)";
+        }
+        m->shard_report = rep;
     }
     size_t total = 0;
     u32 agg[4] = {0, 0, 0, 0};
     for (size_t g = 0; g < ns; g++) {
         total += (size_t)std::max<int64_t>(counts[g].load(std::memory_order_acquire), 0);
-        if (copied[g]) HIPCHK(hipStreamWaitEvent(m->shard_stream, m->shard_clones[g]->shard_event, 0));
+        if (copied[g]) {
+            hipError_t e_ = hipStreamWaitEvent(m->shard_stream, m->shard_clones[g]->shard_event, 0);
+            if (e_ != hipSuccess) return drained(fzb_fail(FZB_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e_)));
+        }
         for (int k = 0; k < 4; k++) agg[k] += m->shard_clones[g]->last_counters[k];
     }
     memcpy(m->last_counters, agg, sizeof(agg));  // fzb_last_counters on the parent = the sum over the shards
@@ -426,14 +477,18 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
             cnts[g] = m->shard_clones[g]->count_dev;
             caps[g] = (size_t)sc->shard[g]->dev.n;
         }
-        return merge_runs_on_device(m, runs.data(), cnts.data(), caps.data(), ns, m->shard_stream, out, out_len);
+        rc = merge_runs_on_device(m, runs.data(), cnts.data(), caps.data(), ns, m->shard_stream, out, out_len);
+        return rc ? drained(rc) : FZB_OK;
     }
     if (!total) return FZB_OK;
     // the whole list's count -> device memory (the sort reads it there), reverse / stable radix sort ONCE, one copy to the host
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)m->count_dev, (int)(u32)total, 1, m->shard_stream));
-    if ((rc = fzb_order_finish(m, plan, m->out_dev, m->count_dev, m->shard_stream))) return rc;
+    {
+        hipError_t e_ = hipMemsetD32Async((hipDeviceptr_t)m->count_dev, (int)(u32)total, 1, m->shard_stream);
+        if (e_ != hipSuccess) return drained(fzb_fail(FZB_ERR_HIP, std::string("hipMemsetD32Async: ") + hipGetErrorString(e_)));
+    }
+    if ((rc = fzb_order_finish(m, plan, m->out_dev, m->count_dev, m->shard_stream))) return drained(rc);
     fzb_match* r = (fzb_match*)fzb_pinned_get(total * sizeof(fzb_match));
-    if (!r) return fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
+    if (!r) return drained(fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list"));
     const fzb_match_rec* final_dev = (plan.reversed || plan.by_score) ? m->out_dev : gather;
     hipError_t e = hipMemcpyAsync(r, final_dev, total * sizeof(fzb_match), hipMemcpyDeviceToHost, m->shard_stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->shard_stream);
@@ -445,6 +500,8 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
     *out_len = total;
     return FZB_OK;
 }
+
+const char* fzb_matcher_shard_report(const fzb_matcher* m) { return m ? m->shard_report.c_str() : ""; }
 
 // The same combine for runs that are already on ONE device (frizbee_amd.distributed: the root rank after the RCCL gather of the
 // per-rank buffers): concatenation in run order -> reverse / stable radix sort -> one copy to the host.  dev_counts[g] points at run

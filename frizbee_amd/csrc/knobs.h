@@ -24,6 +24,7 @@ struct FzbKnobs {
     bool no_handoff = false;         // FZB_NO_HANDOFF=1       ragged lists: classifier and scorers gather the survivors' bytes from the corpus (no staging)
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device
     bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint
+    bool verify_promises = true;     // FZB_VERIFY_PROMISES=0  fzb_corpus_set_uniform_len / _set_max_len on BORROWED memory accepted without the device pass over the end offsets
     int shard_inline = -1;           // FZB_SHARD_INLINE=0|1   multi-device query, shards on the root device: 0 = through the worker threads, 1 = enqueued by the caller
     int handoff_min_tiles = 4096;    // FZB_HANDOFF_MIN_TILES  the handoff only for lists of at least this many 1024-haystack tiles (0: always)
     int unicode_multi = -1;          // FZB_UNICODE_MULTI=0|1  unicode windows of 65..1024 bytes: never / always thread per haystack (k2u_dp_unicode_multi); default: by the queue's length

@@ -76,17 +76,37 @@ class ShardExchange:
 
     HEADER = 8
 
-    def __init__(self, capacity_records, device, group=None, root=0, slots=2):
+    def __init__(self, capacity_records, device, group=None, root=0, slots=2, host_staged=None):
         self.group, self.root = group, root
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.device = torch.device(device)
+        self.slots = slots
+        backend = dist.get_backend(group)
+        # A backend without device collectives (gloo: the rank-count rehearsal on one GPU, `FZB_BENCH_BACKEND=gloo bench.py --gpus 2`) moves
+        # CPU tensors: the pipeline still writes into a device buffer, `post` copies it to the host first (a synchronising copy) and the
+        # root combines on the host.  With RCCL nothing is staged.
+        self.host_staged = (self.device.type == "cuda" and backend != "nccl") if host_staged is None else bool(host_staged)
+        # only RCCL's completion query is trusted to stand in for wait(): on other backends wait() is what surfaces a failed collective
+        self._skip_completed_wait = backend == "nccl"
+        self.grown = 0  # how often `grow` re-sized the exchange (ordered_query)
+        self._alloc(int(capacity_records))
+
+    def _alloc(self, capacity_records):
         self.cap = int(capacity_records)
         nbytes = self.HEADER + self.cap * 8
-        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(slots)]
-        self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=device) for _ in range(self.world)] if self.rank == root else None for _ in range(slots)]
-        self.work = [None] * slots
-        self._merge_args = [None] * slots
-        # only RCCL's completion query is trusted to stand in for wait(): on other backends wait() is what surfaces a failed collective
-        self._skip_completed_wait = dist.get_backend(group) == "nccl"
+        xdev = torch.device("cpu") if self.host_staged else self.device
+        self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
+        self.send_x = [torch.zeros(nbytes, dtype=torch.uint8, device=xdev) for _ in range(self.slots)] if self.host_staged else self.send
+        self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=xdev) for _ in range(self.world)] if self.rank == self.root else None for _ in range(self.slots)]
+        self.work = [None] * self.slots
+        self._merge_args = [None] * self.slots
+
+    def grow(self, capacity_records):
+        """Every rank, together: re-size the exchange (all pending exchanges are drained first).  The buffers move: cached addresses are dropped."""
+        for s in range(self.slots):
+            self.wait(s)
+        self._alloc(max(int(capacity_records), self.cap))
+        self.grown += 1
 
     @staticmethod
     def plan(local_count, group=None, margin=1.25, device=None):
@@ -119,7 +139,49 @@ class ShardExchange:
 
     def post(self, slot):
         self.wait(slot)
-        self.work[slot] = dist.gather(self.send[slot], gather_list=self.recv[slot], dst=self.root, group=self.group, async_op=True)
+        if self.host_staged:
+            self.send_x[slot].copy_(self.send[slot])  # device -> host, behind the pipeline on the current stream (synchronises)
+        self.work[slot] = dist.gather(self.send_x[slot], gather_list=self.recv[slot], dst=self.root, group=self.group, async_op=True)
+
+    def max_found(self, slot):
+        """Root only, after wait(slot): the largest `matches found` any shard reported in this exchange (what the capacity has to hold)."""
+        hdr = torch.stack([b[: self.HEADER] for b in self.recv[slot]]).cpu().numpy().view(np.uint32).reshape(self.world, 2)
+        return int(hdr.max())
+
+    def ordered_query(self, run, matcher, slot=0, stream=None, copy=False, max_retries=6):
+        """One query, every rank together, the ordered list on the root (None elsewhere) - `match_list_parallel`'s result
+        (src/matcher/parallel.rs:18-89) whatever the number of matches: `run(records_ptr, capacity, count_ptr)` enqueues this rank's
+        pipeline (fzb_match_list_device with its global index_offset) into the exchange buffer; the runs are gathered to the root and
+        combined there (`collect_merged`); then the root tells every rank, with ONE 8-byte broadcast, whether every shard's run fitted
+        the exchange.  If one did not (its `matches found` exceeds the capacity: the capacity was planned from an earlier query), every rank
+        re-sizes the exchange to 1.25 x the largest run and the query is repeated - a second query with more matches than the first can
+        never fail with FZB_ERR_CAPACITY or return a shorter list."""
+        ctl_dev = torch.device("cpu") if (self.host_staged or self.device.type != "cuda") else self.device
+        for _ in range(max_retries + 1):
+            self.wait(slot)
+            run(self.records_ptr(slot), self.cap, self.count_ptr(slot))
+            self.post(slot)
+            merged, need, err = None, 0, None
+            if self.rank == self.root:
+                try:  # (a truncated run makes the combine fail - FZB_ERR_CAPACITY on the device, RuntimeError on the host - and only then are the headers read)
+                    merged = self.collect_merged(slot, matcher, stream=stream, copy=copy)
+                except Exception as e:  # noqa: BLE001 - anything else is re-raised below, after the other ranks have been told
+                    found = self.max_found(slot)
+                    if found > self.cap:
+                        need = found
+                    else:
+                        need, err = -1, e
+            else:
+                self.wait(slot)
+            t = torch.tensor([need], dtype=torch.int64, device=ctl_dev)
+            dist.broadcast(t, src=self.root, group=self.group)
+            need = int(t.item())
+            if need == 0:
+                return merged
+            if need < 0:
+                raise err if err is not None else RuntimeError("ordered_query: the root rank failed to combine the runs")
+            self.grow(int(need * 1.25) + 4096)
+        raise RuntimeError("ordered_query: the exchange kept overflowing (a shard's match count grows between retries?)")
 
     def collect(self, slot):
         """Root only, synchronising: the per-rank runs of the exchange posted on `slot` as numpy MATCH_DTYPE arrays."""
@@ -143,7 +205,7 @@ class ShardExchange:
             out.append((cnt, total))
         return out
 
-    def collect_merged(self, slot, matcher, stream=0, copy=False):
+    def collect_merged(self, slot, matcher, stream=None, copy=False):
         """Root only, synchronising: the exchange posted on `slot` as ONE list in `matcher.config.sort` order - what
         `match_list_parallel` returns (parallel.rs:66-87).  The gathered runs never leave the root's HBM unordered: concatenation in rank
         order (= ascending index order) + reverse / stable radix sort on the device (fzb_merge_shard_runs), one copy to the host.
@@ -152,6 +214,10 @@ class ShardExchange:
         if self.rank != self.root:
             return None
         bufs = self.recv[slot]
+        if stream is None and bufs[0].is_cuda:
+            # wait() ordered TORCH'S CURRENT stream behind the gather: the concatenation must be launched on that stream (the legacy null
+            # stream is not ordered after the collective when the caller's current stream is a non-blocking one)
+            stream = torch.cuda.current_stream(bufs[0].device).cuda_stream
         if not bufs[0].is_cuda:
             return merge_shard_runs(self.collect(slot), matcher.config.sort)
         if self._merge_args[slot] is None:  # the buffers never move: their addresses are marshalled once

@@ -103,7 +103,10 @@ int fzb_corpus_upload(const uint8_t* bytes, const uint64_t* end_offsets, size_t 
  * (A list of 32-byte haystacks stored back to back already has this layout.) */
 int fzb_corpus_from_device(const void* dev_bytes, const void* dev_ends, int ends_are_u64, size_t n, uint64_t total_bytes, fzb_corpus** out);
 /* Optional hint for borrowed corpora: the longest haystack in bytes.  Must be an upper bound; 0 = unknown.  fzb_corpus_upload measures
- * it: on a corpus it uploaded a looser value (or 0) is ignored and a value below the measured one is refused (FZB_ERR_INVALID). */
+ * it: on a corpus it uploaded a looser value (or 0) is ignored and a value below the measured one is refused (FZB_ERR_INVALID).  On
+ * borrowed memory the bound is CHECKED when it is given: one device pass over the end offsets (a set-up call: it synchronises the
+ * device); a haystack longer than max_len, or offsets that decrease / leave the buffer, make the call fail with FZB_ERR_INVALID and name
+ * the first offending index.  FZB_VERIFY_PROMISES=0 in the environment skips the pass. */
 int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len);
 /* Optional accelerator for borrowed RAGGED corpora (fzb_corpus_upload builds it itself): the streaming filter's view of the list - a
  * second copy of the bytes, every 1024-haystack tile sorted by length and stored interleaved in groups of 64, so that a wavefront's
@@ -115,7 +118,8 @@ int fzb_corpus_build_view(fzb_corpus* c, int* out_built);
  * kernels then compute the spans instead of reading the end offsets (a tenth of the filter's traffic on 32-byte records and one
  * dependent load less per survivor).  fzb_corpus_upload detects it by itself, and on a corpus it uploaded only the detected value is
  * accepted (FZB_ERR_INVALID otherwise).  A non-zero `len` also becomes the corpus' max_len (overwriting fzb_corpus_set_max_len);
- * 0 clears the promise and the bound it implied. */
+ * 0 clears the promise and the bound it implied.  On borrowed memory the promise is CHECKED against the end offsets when it is made (one
+ * device pass, as for fzb_corpus_set_max_len): a wrong promise would mis-span every haystack, so it is refused with FZB_ERR_INVALID. */
 int fzb_corpus_set_uniform_len(fzb_corpus* c, uint32_t len);
 void fzb_corpus_free(fzb_corpus* c);
 size_t fzb_corpus_len(const fzb_corpus* c);
@@ -193,6 +197,12 @@ int fzb_sharded_corpus_shard(const fzb_sharded_corpus* sc, int g, uint64_t* lo, 
  * is the root (the matcher binds to it like on any first query).  fzb_last_counters on `m` afterwards = the sum over the shards.
  * Free the result with fzb_matches_free. */
 int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc, fzb_match** out, size_t* out_len);
+/* How the runs of the last fzb_match_list_parallel_sharded on `m` reached the root, as text: the gather form and, per shard, "same
+ * device", "peer access enabled (device to device over xGMI)" or "peer access REFUSED ..." (hipDeviceCanAccessPeer /
+ * hipDeviceEnablePeerAccess are asked once per (root, device) pair; without peer access the runtime stages hipMemcpyPeerAsync through
+ * host memory - correct, slower, and said here rather than silently).  The reference has no counterpart: its workers share one address
+ * space (src/matcher/parallel.rs:43-64).  The string lives until the next sharded query on `m` or fzb_matcher_free. */
+const char* fzb_matcher_shard_report(const fzb_matcher* m);
 /* The combine step alone, for callers that moved the per-shard runs themselves (one process per GPU: the root rank after an RCCL
  * gather - frizbee_amd.distributed): run g = dev_runs[g], index-ordered records of shard g as fzb_match_list_device wrote them,
  * dev_counts[g] -> the two uint32 that call wrote in DEVICE memory (records written, matches found), run_caps[g] = the run's buffer size

@@ -321,6 +321,8 @@ class Matcher {  // src/matcher/mod.rs:77-222
         check(fzb_match_list_parallel_sharded(single_.get(), corpus.raw(), &out, &n));
         return take(out, n);
     }
+    // how the runs of that call reached the root device (fzb_matcher_shard_report: gather form, peer access per shard)
+    std::string shard_report() const { return single_ ? std::string(fzb_matcher_shard_report(single_.get())) : std::string(); }
 
   private:
     static bool plain(const Pattern& p) {

@@ -82,6 +82,7 @@ extern "C" {
     fn fzb_sharded_corpus_free(sc: *mut c_void);
     fn fzb_match_list_parallel_sharded(m: *mut c_void, sc: *const c_void, out: *mut *mut FzbMatch, out_len: *mut usize) -> c_int;
     fn fzb_device_count(out: *mut c_int) -> c_int;
+    fn fzb_matcher_shard_report(m: *const c_void) -> *const std::os::raw::c_char;
     // (bound by hosts that move the per-shard runs themselves / hold the list in HBM already; not used by the wrappers below)
     #[allow(dead_code)]
     fn fzb_merge_shard_runs(m: *mut c_void, dev_runs: *const *const c_void, dev_counts: *const *const u32, run_caps: *const usize, nruns: usize, stream: *mut c_void,
@@ -234,6 +235,12 @@ impl MatcherHip {
         let mut v = Vec::with_capacity(n);
         copy_out(out, n, &mut v);
         v
+    }
+
+    /// How the runs of the last `match_list_parallel_sharded` reached the root device: gather form and, per shard, same device /
+    /// peer access enabled (xGMI, device to device) / peer access refused (the runtime stages the copy through host memory).
+    pub fn shard_report(&self) -> String {
+        unsafe { std::ffi::CStr::from_ptr(fzb_matcher_shard_report(self.handle)) }.to_string_lossy().into_owned()
     }
 
     /// `Matcher::match_list_indices` for the listed haystacks of a resident corpus (typically the top of a `match_list` result).

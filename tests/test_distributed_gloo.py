@@ -94,6 +94,38 @@ def _worker(rank, world, port, q):
         merged = merge_shard_runs(runs, SortStrategy[sort])
         want = O.Matcher("deadbeef", max_typos=0, sort=sort).match_packed(data4, ends4)
         ok = ok and merged.tolist() == want.tolist() and len(want) > 500
+    # ---- ordered_query: the exchange was planned from a query with FEW matches; a second query with many more must grow it and succeed ----
+    lo, hi = shard_range(n, rank, world)
+
+    def local_run(k):
+        loc = O.Matcher("deadbe", max_typos=k, sort="IndexAsc").match_packed(data[lo * 32 :], ends[lo:hi] - np.uint64(lo * 32))
+        loc["index"] += lo
+        return loc
+
+    few, many = local_run(0), local_run(None)  # max_typos None: every haystack matches
+    ex2 = ShardExchange(ShardExchange.plan(len(few), margin=1.0), torch.device("cpu"))  # agreed by every rank; holds the first query only
+    ok = ok and ex2.cap < len(many)
+
+    def writer(loc):
+        def run(records_ptr, capacity, count_ptr):  # stands in for fzb_match_list_device: writes min(found, capacity) records + both counters
+            buf = ex2.send[0].numpy()
+            w = min(len(loc), capacity)
+            buf[:8] = np.array([w, len(loc)], np.uint32).view(np.uint8)
+            buf[ex2.HEADER : ex2.HEADER + w * 8] = loc[:w].view(np.uint8)
+        return run
+
+    class _S:
+        class config:
+            sort = SortStrategy.ScoreThenIndexAsc
+    r1 = ex2.ordered_query(writer(few), _S)
+    ok = ok and ex2.grown == 0
+    r2 = ex2.ordered_query(writer(many), _S)
+    ok = ok and ex2.grown == 1 and ex2.cap >= len(many)
+    if rank == 0:
+        ok = ok and r1.tolist() == O.Matcher("deadbe", max_typos=0, sort="ScoreThenIndexAsc").match_packed(data, ends).tolist()
+        ok = ok and r2.tolist() == O.Matcher("deadbe", max_typos=None, sort="ScoreThenIndexAsc").match_packed(data, ends).tolist() and len(r2) == n
+    else:
+        ok = ok and r1 is None and r2 is None
     q.put((rank, ok))
     dist.destroy_process_group()
 

@@ -51,6 +51,8 @@ def test_sharded_match_list_parallel_equals_match_list_for_every_sort_and_shard_
                 m = F.Matcher("deadbe", F.Config(max_typos=typos, sort=F.SortStrategy[sort], pf_lanes=64, sw_lanes=64))
                 want = O.Matcher("deadbe", lanes=(64, 64, 32), max_typos=typos, sort=sort).match_packed(odata, ends)
                 got = m.match_list_parallel_sharded(sc)
+                rep = m.shard_report()  # how the runs reached the root: on one GPU every shard shares the root device
+                assert rep.startswith("root device") and rep.count("shard ") == ndev and (have > 1 or rep.count("same device") == ndev), rep
                 assert got.tolist() == want.tolist(), (ndev, sort, typos, len(got), len(want))
                 assert m.match_list_parallel_sharded(sc).tolist() == want.tolist()  # again: the clones' workspaces are reused
         del sc
@@ -191,3 +193,28 @@ def test_bench_refuses_more_ranks_than_gpus():
     have = F.device_count()
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "visible" in (r.stderr + r.stdout), (r.stdout[-500:], r.stderr[-500:])
+
+
+def test_two_rank_rehearsal_of_the_bench_on_one_gpu():
+    """`FZB_BENCH_BACKEND=gloo python bench.py --gpus 2`: the N > 1 path of the driver's bench with TWO real ranks on a box with one GPU -
+    bench.py starts the ranks under torch.distributed.run itself, both score their shard on the visible GPU with a global index offset,
+    the exchange moves CPU tensors (gloo), rank 0 combines.  Everything an RCCL run executes except the transport: the rank bookkeeping,
+    the double-buffered exchange, ordered_query's grow-and-retry, the per-shard oracle check, and BASELINE configs[3] cut into
+    byte-balanced shards.  The line must be valid JSON with ranks_seen == 2 and the merged list equal to the oracle's."""
+    import json
+    env = dict(os.environ, FZB_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--per-gpu", "1000000", "--steps", "5", "--warmup", "2", "--c4-total", "2000000"],
+                       capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and "REHEARSAL" in j["config"]["backend"]
+    assert j["value"] > 0 and j["scaling"] == "weak" and j["config"]["exchange"]["merged_len"] == j["config"]["exchange"]["matches_all_shards"]
+    e = j["e2e_sorted_merge"]
+    assert e["equals_host_merge"] and e["merged_equals_oracle_list"] and e["every_shard_head_equals_oracle"]["equal_on_every_rank"]
+    assert e["grow_and_retry"]["times_grown"] >= 1 and e["grow_and_retry"]["result_equals"]
+    (name, c4), = j["configs"].items()
+    assert "configs[3]" in name and c4["n_gpus"] == 2 and c4["haystacks"] == 2_000_000 and all(v is True for k, v in c4["checks"].items() if k != "oracle_items_per_shard"), c4["checks"]
+    assert abs(c4["shards"][0]["bytes"] - c4["shards"][1]["bytes"]) <= 256 and c4["shards"][0]["range"][1] == c4["shards"][1]["range"][0]

@@ -98,3 +98,19 @@ def test_all_scores_over_an_arabic_shaped_list():
         got, want, fm = both("إن", None, pf=64, packed=(data, ends), **cfg)
         assert len(want) > 1000
         assert_same(got, want, f"arabic {cfg}")
+
+
+def test_forwarded_stragglers_never_land_on_unread_front_entries(wide_mode):
+    """More wide windows than the thread-per-haystack scorer has threads (256 CUs x 256 = 65 536: entries beyond that are read AFTER
+    earlier iterations have forwarded their stragglers), every haystack wider than a chunk and a few thousand wider than four: front +
+    forwarded > the list's size, so before the back of the queue got 4096 entries of its own the forwarded entries could overwrite front
+    entries that had not been scored yet (round 4 advisor finding, host.hip `qcap`)."""
+    rng = random.Random(77)
+    base = [_sentence(rng, rng.choice([80, 100, 130, 200, 300, 400]), "éa", rng.random() < 0.5) for _ in range(4000)]
+    many = base * 40  # 160 000 windows under All Scores, all beyond 64 bytes, about half of them beyond 256
+    assert min(len(s.encode()) for s in base) > 64
+    got, want, fm = both("éa", many, pf=64, max_typos=None)
+    assert len(want) == len(many)
+    assert_same(got, want, "queue front vs forwarded back")
+    if wide_mode != "wave_per_haystack":
+        assert fm.last_counters()["multi_chunk_scored"] >= len(many) - 4096
