@@ -123,7 +123,7 @@ def cpu_baseline(rows_dev, n_sample, max_typos):
                                 "what": "the reference's published 1.15e8 haystacks/s/thread (BENCHMARKS.md:123, Ryzen 9950X3D, same length and mix) x physical cores"}}
 
 
-def _pmc_child(counters, kernel_substr):
+def _pmc_child(counters, kernel_substr, extra=()):
     """One child run of this script under `rocprofv3 --pmc <counters>` (counters only, no trace domains); returns {counter: (average per
     dispatch of the kernels whose name contains kernel_substr, dispatches)}."""
     import csv
@@ -134,7 +134,7 @@ def _pmc_child(counters, kernel_substr):
 
     tmp = tempfile.mkdtemp(prefix="fzb_pmc_", dir="/tmp")
     try:
-        cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--fast", "--steps", "3", "--warmup", "1"]
+        cmd = ["rocprofv3", "--pmc", *counters, "--output-format", "csv", "-d", tmp, "-o", "p", "--", sys.executable, os.path.abspath(__file__), "--fast", "--steps", "3", "--warmup", "1", *extra]
         subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         acc = {}
         for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
@@ -171,6 +171,11 @@ def live_counters():
         if "SQ_INSTS_VALU" in q:
             out["scorer"] = {k: v[0] for k, v in q.items()}
             out["scorer"]["dispatches"] = q["SQ_INSTS_VALU"][1]
+        # the All Match mix is integer-VALU-bound - its scorer's wave-instructions, from a child run over that list
+        qa = _pmc_child(["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_ACTIVE_INST_ANY"], "k2b_dp", extra=("--mix", "all"))
+        if "SQ_INSTS_VALU" in qa:
+            out["scorer_all_match"] = {k: v[0] for k, v in qa.items()}
+            out["scorer_all_match"]["dispatches"] = qa["SQ_INSTS_VALU"][1]
         return out, None
     except Exception as e:
         return None, f"{type(e).__name__}: {e}"
@@ -284,7 +289,17 @@ def other_configs(F, synth, dev, steps):
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * HAY_LEN).to(torch.int32)
     cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=HAY_LEN, uniform_len=HAY_LEN)
     run("C3 10M x 32 B, 'deadbe', max_typos=2", "deadbe", F.Config(max_typos=2, pf_lanes=64, sw_lanes=64), cp, n, n * HAY_LEN, ends_read=False)
-    del cp, flat, ends
+    del cp
+    # the other two mixes of the reference's generator on the same shape (benches/lib.rs:60-64) - All Match (every haystack
+    # scored: integer-VALU-bound, the HBM fraction means nothing there; `scorer_issue` is added from the live counters) and No Match (the filter alone)
+    for label, full, partial in (("All Match", 1.0, 0.0), ("No Match", 0.0, 0.0)):
+        flat[: n * HAY_LEN].view(n, HAY_LEN).copy_(synth.make_rows(NEEDLE, n, HAY_LEN, seed=12345, device=dev, full=full, partial=partial))
+        cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=HAY_LEN, uniform_len=HAY_LEN)
+        key = f"C2 shape, mix {label} (benches/lib.rs:60-64): 10M x 32 B, 'deadbe', max_typos=0"
+        run(key, "deadbe", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n, n * HAY_LEN, ends_read=False, steps=5)
+        res[key]["bound"] = "integer VALU issue (every haystack is scored)" if full == 1.0 else "HBM (the streaming filter alone)"
+        del cp
+    del flat, ends
     n4 = 12_500_000
     data, e4 = synth.ragged_corpus(b"deadbeef", n4, device=dev)
     cp = F.Corpus(packed=(data, e4))
@@ -494,6 +509,8 @@ def main():
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the two-streams throughput figure")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the two rocprofv3 --pmc child runs; report the stored traffic figure")
     ap.add_argument("--fast", action="store_true", help="= --no-cpu-baseline --no-configs --no-check --no-two-in-flight (profiling runs)")
+    ap.add_argument("--mix", choices=("partial", "all", "none"), default="partial",
+                    help="haystack classes of the list (benches/lib.rs:60-64): partial = 5%% full / 20%% partial / 75%% none (the headline), all = All Match, none = No Match (profiling child runs)")
     ap.add_argument("--c4-total", type=int, default=-1,
                     help="N > 1: haystacks of the BASELINE configs[3] row (100M ragged, byte-balanced shards); -1 = 100,000,000 when more than one rank runs, 0 = skip the row")
     args = ap.parse_args()
@@ -558,7 +575,8 @@ def main():
     # ---- synthetic shard, generated directly in HBM (padded-16 layout == back-to-back 32-byte rows) ----
     flat = torch.zeros(n * HAY_LEN + 256, dtype=torch.uint8, device=dev)
     rows = flat[: n * HAY_LEN].view(n, HAY_LEN)
-    rows.copy_(synth.make_rows(NEEDLE, n, HAY_LEN, seed=12345 + rank, device=dev))
+    mix_full, mix_partial = {"partial": (0.05, 0.20), "all": (1.0, 0.0), "none": (0.0, 0.0)}[args.mix]
+    rows.copy_(synth.make_rows(NEEDLE, n, HAY_LEN, seed=12345 + rank, device=dev, full=mix_full, partial=mix_partial))
     ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * HAY_LEN).to(torch.int32)
     # every haystack has exactly HAY_LEN bytes: declared to the library (an uploaded list is detected), whose hot kernels then compute the
     # spans instead of reading the end offsets
@@ -726,7 +744,7 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": f"needle 'deadbe' (6 chars) vs {n:,} x {HAY_LEN}-byte ASCII haystacks per GPU, max_typos={args.max_typos}, "
-                                   "mix 5% full / 20% partial / 75% none, seed 12345 (BASELINE.json configs[1])",
+                                   + ("mix 5% full / 20% partial / 75% none, seed 12345 (BASELINE.json configs[1])" if args.mix == "partial" else f"mix {args.mix.upper()} MATCH (not the headline mix)"),
                        "haystacks_per_gpu": n, "haystack_len": HAY_LEN, "max_typos": args.max_typos,
                        "emulated_reference_backend": "AVX-512 (prefilter 64 lanes, Smith-Waterman 64 x u8)",
                        "sharding": f"contiguous index ranges over {world} GPU(s); per step an asynchronous, double-buffered RCCL gather of the match records to rank 0" if world > 1 else "single GPU",
@@ -831,6 +849,17 @@ def main():
                                     "issue_frac": lc_["scorer"]["SQ_INSTS_VALU"] * 4 / (4 * 256 * st["scorers"] * 1e-3 * clk * 1e9),
                                     "issue_frac_all_instructions": (lc_["scorer"]["SQ_ACTIVE_INST_ANY"] * 4 / (4 * 256 * st["scorers"] * 1e-3 * clk * 1e9)) if "SQ_ACTIVE_INST_ANY" in lc_["scorer"] else None,
                                     "counters_source": f"MEASURED in this run: child run `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY` of `bench.py --fast --steps 3 --warmup 1`, {lc_['scorer']['dispatches']} scorer dispatches averaged"})
+                    if "scorer_all_match" in lc_ and "configs" in res:
+                        clk = (stored_json("latest_sq.json") or {}).get("shader_clock_GHz", 2.25)
+                        for key, row in res["configs"].items():
+                            if "mix All Match" in key and row["stages_ms"].get("scorers"):
+                                t_sc = row["stages_ms"]["scorers"] * 1e-3
+                                a_ = lc_["scorer_all_match"]
+                                row["scorer_issue"] = {"valu_wave_instructions_per_launch": a_["SQ_INSTS_VALU"], "salu_wave_instructions_per_launch": a_.get("SQ_INSTS_SALU"),
+                                                       "valu_issue_frac": a_["SQ_INSTS_VALU"] * 4 / (4 * 256 * t_sc * clk * 1e9),
+                                                       "issue_frac_all_instructions": (a_["SQ_ACTIVE_INST_ANY"] * 4 / (4 * 256 * t_sc * clk * 1e9)) if "SQ_ACTIVE_INST_ANY" in a_ else None,
+                                                       "assumes": f"4 cycles per wave64 VALU instruction, 1024 SIMDs, {clk} GHz",
+                                                       "counters_source": f"MEASURED in this run: child run `rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY` of `bench.py --fast --mix all --steps 3 --warmup 1`, {a_['dispatches']} scorer dispatches averaged"}
                 else:
                     res["roofline"]["traffic_source"] += "; live collection failed: " + why
             if not args.no_cpu_baseline:

@@ -1000,8 +1000,20 @@ static int ensure_long_needle(fzb_matcher* m, size_t scratch_bytes) {  // the ne
 // the kernels that take the needle from device memory:  [length test + the reference's prefilter at the exact lane width ->
 // order-preserving compaction] -> the wave-per-haystack scorer (every window width; match_greedy beyond 1024 bytes; traced form for the
 // matched-indices entry points) - or the two literal kernels.
+// (profiling: [0] start, [2]..[3] around the first stage - the lane-exact prefilter over every haystack, when there is one -, [4] before the
+// scorer, [1] end: the same five events fzb_last_stage_timings reads for the short-needle pipeline)
 static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, const u32* items_in, const u32* n_items_in,
                              fzb_match* dev_out, u32 cap32, uint32_t* dev_count, hipStream_t st, const TraceOut* trace) {
+    hipEvent_t* pev = nullptr;
+    if (m->profiling) {
+        const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);
+        pev = m->evring[slot];
+        m->ev_filter[slot] = (!m->literal_mode && m->lc.window_mode == 0) ? 1 : 0;
+        m->prof_calls++;
+        for (int i = 0; i < 5; i++)
+            if (!pev[i]) HIPCHK(hipEventCreate(&pev[i]));
+        HIPCHK(hipEventRecord(pev[0], st));
+    }
     Workspace& w = m->ws;
     const CorpusDev& cd = c->dev;
     const int cus = m->lc.num_cus;
@@ -1013,8 +1025,10 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
         if (rc) return rc;
         fzb_launch_literal_filter_long(cd, first, cnt, items_in, n_items_in, m->ndl, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, items_in ? n_items_in : nullptr, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
+        if (pev) HIPCHK(hipEventRecord(pev[4], st));
         fzb_launch_literal_score_long(cd, first, index_offset, w.surv_idx, &cnt_c[0], m->ndl, m->literal_mode, (fzb_match_rec*)dev_out, cap32, dev_count, trace ? trace->pos : nullptr,
                                       trace ? trace->npos : nullptr, trace ? trace->stride : 0u, cus * 4, st);
+        if (pev) HIPCHK(hipEventRecord(pev[1], st));
         HIPCHK(hipGetLastError());
         return FZB_OK;
     }
@@ -1045,7 +1059,9 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     if (items_in) HIPCHK(hipMemcpyAsync(&cnt_c[0], n_items_in, 4, hipMemcpyDeviceToDevice, st));
     else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&cnt_c[0], (int)cnt, 1, st));
     if (prefilter) {
+        if (pev) HIPCHK(hipEventRecord(pev[2], st));
         fzb_launch_window_long(cd, first, items_in, &cnt_c[0], m->ndl, m->lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, m->long_scratch, wgrid, st);
+        if (pev) HIPCHK(hipEventRecord(pev[3], st));
         fzb_launch_compact2(w.bitmap2, w.tile_counts2, &cnt_c[0], items_in, w.win, w.items2, w.win2, &cnt_c[1], cus * 2, st);
         items = w.items2;
         win = w.win2;
@@ -1054,8 +1070,10 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     } else {
         HIPCHK(hipMemcpyAsync(&cnt_c[1], &cnt_c[0], 4, hipMemcpyDeviceToDevice, st));
     }
+    if (pev) HIPCHK(hipEventRecord(pev[4], st));
     fzb_launch_generic_long(cd, first, index_offset, items, win, wmode, n_items_ptr, m->ndl, m->lc.sw_lanes, (fzb_match_rec*)dev_out, cap32, dev_count, cnt_c, (u16*)m->long_scratch,
                             trace ? (const u32*)((u8*)m->long_scratch + front) : nullptr, trace ? trace->pos : nullptr, trace ? trace->npos : nullptr, trace ? trace->stride : 0u, ggrid, st);
+    if (pev) HIPCHK(hipEventRecord(pev[1], st));
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }

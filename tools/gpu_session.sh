@@ -20,6 +20,7 @@ for s in $STEPS; do
     cfg) timeout 900 python tools/bench_configs.py C3 C4 C5 > $OUT/cfg.log 2>&1; cat $OUT/cfg.log;;
     pmcsq) for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE GRBM_COUNT"; do n=$(echo $c | tr ' ' '_'); (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$n -o p -- python $OLDPWD/bench.py --steps 5 --warmup 2 --fast > $OUT/pmc_$n.log 2>&1); done; for d in $OUT/pmc_*/; do python tools/pmc_summary.py $d; done > $OUT/pmc_sq.txt 2>&1; cat $OUT/pmc_sq.txt; python tools/pmc_sq_json.py $OUT/pmc_sq.txt $OUT/sq.json; rm -rf $OUT/pmc_*/;;
     pmctraffic) for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 300 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python $OLDPWD/bench.py --steps 5 --warmup 2 --fast > $OUT/pmc_$c.log 2>&1); done; python tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/traffic.json; rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE;;
+    pmcc4) bash tools/pmc_c4_traffic.sh $OUT/pmc_c4 > $OUT/pmc_c4_traffic.txt 2>&1; cat $OUT/pmc_c4_traffic.txt; rm -rf $OUT/pmc_c4;;
     ubench) timeout 120 tools/ubench/valu_rate > $OUT/valu_rate.txt 2>&1; cat $OUT/valu_rate.txt;;
     probe) { echo "== cargo/rustc probe on the GPU box"; which cargo rustc 2>&1; cargo --version 2>&1; rustc --version 2>&1; ls ~/.cargo 2>&1 | head -3; echo "== cpu"; lscpu | egrep "Model name|^CPU\(s\)|Socket|Thread|Core|MHz|Flags" | cut -c1-400; echo "== gpu"; rocm-smi --showclocks 2>&1 | head -30; } > $OUT/probe.txt 2>&1; head -40 $OUT/probe.txt;;
     *) if [ -f "$s" ]; then timeout 900 python $s > $OUT/$(basename $s .py).log 2>&1; tail -30 $OUT/$(basename $s .py).log; else echo "unknown step $s"; fi;;
