@@ -379,6 +379,8 @@ def other_configs(F, synth, dev, steps):
     e5 = np.arange(1, n5 * reps + 1, dtype=np.uint64) * np.uint64(HAY_LEN)
     cp = F.Corpus(packed=(d5, e5))
     run("C5 10M x 32 B UTF-8 (2M distinct x 5), 4-scalar Arabic needle, max_typos=0", "إنما", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n5 * reps, n5 * reps * HAY_LEN, ends_read=False)  # uploaded list of uniform length: detected by fzb_corpus_upload
+    # ... and the same list with a typo budget: superset filter (scalar-level LCS) -> the reference's chunked multi-path scan at its exact lane width for every survivor
+    run("C5 shape with max_typos=1: 10M x 32 B UTF-8, 4-scalar Arabic needle", "إنما", F.Config(max_typos=1, pf_lanes=64, sw_lanes=64), cp, n5 * reps, n5 * reps * HAY_LEN, ends_read=False, steps=5)
     del cp
     return res
 

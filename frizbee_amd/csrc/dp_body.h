@@ -354,8 +354,10 @@ __device__ __forceinline__ bool exact_match(const NeedleDev& nd, bool include_ex
 // dwords of gap-open charges in a global scratch slab laid out [row][dword][thread] (coalesced across the wave).
 // In the biased domain the adjacent lanes are simply positions -SWL/2..-1 of one longer vector (bias (p + SWL) * gex).
 // ---------------------------------------------------------------------------------------------------------------
-template <int SWL, bool BIAS>
-__device__ __forceinline__ u32 dp_multi_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls,
+// ND: NeedleDev (by value: up to 63 rows) or NeedleLongDev (the same members, the rows' bytes behind pointers into the matcher's device blob:
+// any needle the reference's overflow guard accepts - k2d_dp_long)
+template <int SWL, bool BIAS, typename ND = NeedleDev>
+__device__ __forceinline__ u32 dp_multi_chunk(const ND& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls,
                                               u32* __restrict__ scratch, u32 sstride, u32 sidx) {
     constexpr int NW = SWL / 2;
     constexpr int NB = SWL / 4;

@@ -179,10 +179,15 @@ FzbKnobs parse_knobs() {
     k.cdfa_nodfa = set("FZB_CDFA_NODFA");
     k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
     k.debug_sync = set("FZB_DEBUG_SYNC");
-    k.no_handoff = set("FZB_NO_HANDOFF");
+    // the filter -> scorer handoff is OFF unless asked for (round 5: on the C4 shard it costs the streaming filter 30-40 us - 52 MB of stores
+    // inside a kernel that runs at the memory system's ceiling - and returns the scorers 10; DESIGN.md section 3 "Handoff"): FZB_HANDOFF=1
+    // turns it on for lists of FZB_HANDOFF_MIN_TILES tiles and more, naming a threshold does too; FZB_NO_HANDOFF=1 wins over both
+    k.no_handoff = set("FZB_NO_HANDOFF") || !(on("FZB_HANDOFF") || set("FZB_HANDOFF_MIN_TILES"));
     { const char* e = getenv("FZB_UNICODE_FWD"); k.no_unicode_fwd = e && e[0] == '0'; }
     k.window_no_mask_cache = set("FZB_WINDOW_NO_MASK_CACHE");
     k.window_four_pass = set("FZB_WINDOW_FOUR_PASS");
+    k.window_no_pre = set("FZB_WINDOW_NO_PRE");
+    k.long_generic_only = set("FZB_LONG_GENERIC_ONLY");
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
@@ -328,7 +333,9 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
         lc.filter_mode = 0;
         lc.filter_exact = 0;  // (sizes the second-level arrays the lane-exact prefilter writes)
         lc.window_mode = (k < 0 || k >= m->rows) ? 2 : 0;
-        lc.pad_ok = lc.bias_ok = lc.cf_ok = lc.cfm_ok = 0;
+        lc.pad_ok = lc.cf_ok = lc.cfm_ok = 0;
+        // (the biased gap scan of dp_multi_chunk, as for short needles below: the largest biased value stays inside 16 bits)
+        lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
         m->table.assign(256, 0);
         *out = m;
         return FZB_OK;
@@ -1045,8 +1052,18 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
         ggrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)ggrid, budget / std::max<size_t>(per_block, 1)));
         if (trace) ggrid = std::min(ggrid, (int)std::max<size_t>(1, (count + 3) / 4));
     }
+    // ASCII windows of up to 1024 bytes: one THREAD per window (k2d_dp_long) when the parked-row slab lets enough of them run (a needle of
+    // thousands of rows leaves room for a few thousand threads only: the wave-per-haystack kernel keeps those); matched indices and unicode
+    // stay with the wave-per-haystack kernel, which also takes what k2d_dp_long queues (windows beyond 1024 bytes: match_greedy)
+    const size_t dpl_words = fzb_dp_long_scratch_words_per_thread(m->ndl, m->lc.sw_lanes);
+    const size_t dfit = std::min<size_t>((size_t)cus * 8, budget / std::max<size_t>(dpl_words * 4 * 128, 1));  // 128-thread workgroups the slab has room for
+    const int dgrid = (int)std::max<size_t>(1, std::min<size_t>(dfit, (count + 127) / 128));
+    const bool thread_per_window = !trace && !m->ndl.unicode && !fzb_knobs().long_generic_only && dfit >= (size_t)std::max(1, cus / 2);
+    const size_t dpl_bytes = thread_per_window ? dpl_words * 4 * 128 * (size_t)dgrid : 0;
+    const bool greedy_possible = !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN);
+    if (thread_per_window && !greedy_possible) ggrid = 1;  // (no launch of the wave-per-haystack kernel: its slab is not needed)
     const size_t win_bytes = prefilter ? fzb_window_long_scratch_bytes(m->ndl, wgrid) : 0;
-    const size_t adj_bytes = fzb_generic_long_adj_bytes(m->ndl, m->lc.sw_lanes, ggrid);
+    const size_t adj_bytes = std::max(fzb_generic_long_adj_bytes(m->ndl, m->lc.sw_lanes, ggrid), dpl_bytes);
     const size_t cell_bytes = trace ? fzb_trace_scratch_words_long(m->ndl, ggrid) * 4 : 0;
     // (the prefilter's path state and the scorer's vectors are never live at the same time: they share the front of the scratch)
     const size_t front = (std::max(win_bytes, adj_bytes) + 255) & ~(size_t)255;
@@ -1071,6 +1088,14 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
         HIPCHK(hipMemcpyAsync(&cnt_c[1], &cnt_c[0], 4, hipMemcpyDeviceToDevice, st));
     }
     if (pev) HIPCHK(hipEventRecord(pev[4], st));
+    if (thread_per_window) {
+        fzb_launch_dp_long(cd, first, index_offset, items, win, wmode, n_items_ptr, m->ndl, m->lc.sw_lanes, m->lc.bias_ok, (fzb_match_rec*)dev_out, cap32, dev_count, (u32*)m->long_scratch,
+                           w.overflow, cnt_c, dgrid, st);
+        // (the queue's entries are read after the slab's last use: the two kernels are one behind the other on the stream and share the scratch)
+        if (greedy_possible)
+            fzb_launch_generic_long(cd, first, index_offset, items, win, wmode, &cnt_c[3], m->ndl, m->lc.sw_lanes, (fzb_match_rec*)dev_out, cap32, nullptr, cnt_c, (u16*)m->long_scratch,
+                                    nullptr, nullptr, nullptr, 0u, std::max(1, std::min(ggrid, cus / 4 + 1)), st, w.overflow);
+    } else
     fzb_launch_generic_long(cd, first, index_offset, items, win, wmode, n_items_ptr, m->ndl, m->lc.sw_lanes, (fzb_match_rec*)dev_out, cap32, dev_count, cnt_c, (u16*)m->long_scratch,
                             trace ? (const u32*)((u8*)m->long_scratch + front) : nullptr, trace ? trace->pos : nullptr, trace ? trace->npos : nullptr, trace ? trace->stride : 0u, ggrid, st);
     if (pev) HIPCHK(hipEventRecord(pev[1], st));

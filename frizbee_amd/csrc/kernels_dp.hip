@@ -525,6 +525,77 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi(const u8* __restrict__ by
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// k2d_dp_long: LONG needles (NeedleLongDev: beyond 64 bytes / 63 rows, any length the reference's guard accepts), ASCII.  Round 3-4 scored
+// them with the wave-per-haystack kernel only (a lane per DP column, half the lanes idle at the u16 class' 32-lane chunks, a shuffle per
+// gap step): 9.0 ms for the 50 k windows of the bench's 80-byte needle, 37 x the per-cell cost of the thread-per-haystack scorers.
+// dp_multi_chunk never needed the needle by value - it reads one row's bytes per iteration - so the same body runs here with the rows read
+// from the matcher's device blob: one THREAD per window of up to 1024 bytes (every window width: a single-chunk window is a one-chunk
+// walk), the parked rows in a global slab [row][dword][thread].  Windows beyond 1024 bytes (match_greedy, src/smith_waterman/greedy.rs)
+// are queued - (output position, window, haystack) entries, counters[3] - for the wave-per-haystack kernel behind this one.
+// Records are written at the items' list positions (index order), the two counters by the first thread.
+// ---------------------------------------------------------------------------------------------------------------
+template <int SWL, bool BIAS, typename ET>
+__global__ __launch_bounds__(128) void k2d_dp_long(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
+                                                   const u32* __restrict__ win, int wmode, const u32* __restrict__ n_items_ptr, const NeedleLongDev nd,
+                                                   fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ scratch, u32* __restrict__ queue,
+                                                   u32* __restrict__ counters) {
+    __shared__ u8 cls[256];
+    build_cls_table(cls);
+    __syncthreads();
+    const u32 n = *n_items_ptr;
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = n < capacity ? n : capacity; dev_count[1] = n; }
+    const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (u32 q = gtid; q < n; q += nthreads) {
+        if (q >= capacity) continue;
+        const u32 li = items ? items[q] : q;
+        u64 s;
+        u32 L;
+        haystack_span(ends, first + li, s, L);
+        const u8* hay = bytes + s;
+        u32 ws = 0, we = L;
+        if (wmode != 2) { ws = win[2 * q]; we = win[2 * q + 1]; }
+        const u32 sp = ws ? ws - 1 : 0;
+        const bool include_exact = sp == 0 && we == L;
+        const u32 m = we - sp;
+        if (m > FZB_MAX_HAYSTACK_LEN) {  // the greedy fallback: the wave-per-haystack kernel's
+            u32* qe = queue + 4 * (size_t)atomicAdd(&counters[3], 1u);
+            qe[0] = q; qe[1] = ws; qe[2] = we; qe[3] = li;
+            continue;
+        }
+        u32 score = dp_multi_chunk<SWL, BIAS, NeedleLongDev>(nd, hay + sp, m, sp == 0, cls, scratch, nthreads, gtid);
+        bool exact = include_exact && m == (u32)nd.nbytes;
+        if (exact)
+            for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+        if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+        fzb_match_rec rec;
+        rec.index = index_offset + li;
+        rec.score = (u16)score;
+        rec.exact = exact ? 1 : 0;
+        rec.valid = 0;
+        out[q] = rec;
+    }
+}
+
+// dwords of the parked-row slab per THREAD of k2d_dp_long (dp_multi_chunk's layout: [row][SWL / 2 dwords][thread])
+size_t fzb_dp_long_scratch_words_per_thread(const NeedleLongDev& nd, int sw_lanes) { return (size_t)nd.rows * (size_t)(sw_lanes / 2); }
+
+void fzb_launch_dp_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd, int sw_lanes,
+                        int bias_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* scratch, u32* queue, u32* counters, int grid, hipStream_t st) {
+#define FZB_K2L(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_long<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
+#define FZB_K2L_ET(SWL, B) do { if (c.ends_u64) FZB_K2L(SWL, B, u64); else FZB_K2L(SWL, B, u32); } while (0)
+#define FZB_K2L_B(SWL) do { if (bias_ok) FZB_K2L_ET(SWL, true); else FZB_K2L_ET(SWL, false); } while (0)
+    switch (sw_lanes) {
+        case 64: FZB_K2L_B(64); break;
+        case 32: FZB_K2L_B(32); break;
+        case 16: FZB_K2L_B(16); break;
+        default: FZB_K2L_B(8); break;
+    }
+#undef FZB_K2L_B
+#undef FZB_K2L_ET
+#undef FZB_K2L
+}
+
 // Where a thread of the dp_cfm.h kernels parks its rows between two chunks: its workgroup's LDS when the launch gave it room (`park_dw` =
 // dwords per parked row, fzb_park_lds_dwords: needles of a few rows), else its column of the global slab.  In LDS a row's round trip costs
 // an LDS access instead of an L2 one - with one or two waves per SIMD and a dependent load per needle row and chunk that latency is the

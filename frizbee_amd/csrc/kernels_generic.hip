@@ -477,15 +477,17 @@ void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, c
 size_t fzb_generic_long_adj_bytes(const NeedleLongDev& nd, int sw_lanes, int grid) { return (size_t)grid * GEN_WAVES * 2 * (size_t)(nd.rows + 1) * (size_t)sw_lanes * sizeof(u16); }
 size_t fzb_trace_scratch_words_long(const NeedleLongDev& nd, int grid) { return (size_t)grid * GEN_WAVES * (size_t)(nd.rows + 1) * TRACE_W; }
 
+// list (optional): the launch walks a queue of (output position, window start, window end, haystack) entries, *n_items_ptr of them, read
+// upwards - what k2d_dp_long leaves for it (windows beyond 1024 bytes); the records' counters are then the queueing kernel's business
 void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd,
                              int sw_lanes, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u16* adj, const u32* cells, u32* pos, u32* npos, u32 stride, int grid,
-                             hipStream_t st) {
+                             hipStream_t st, const u32* list) {
     const TraceArgs tr{(u32*)cells, pos, npos, stride};
     const bool trace = cells != nullptr;
     // the previous-chunk vectors in LDS when they fit (60 KB per four-wave workgroup: up to 127 rows at 32 lanes), in the slab otherwise
     const size_t lds = (size_t)GEN_WAVES * 2 * (size_t)(nd.rows + 1) * (size_t)sw_lanes * sizeof(u16);
     const bool in_lds = lds <= (size_t)60 * 1024;
-#define FZB_K2C_LS(SWL, U, T, ET, SLAB) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev, SLAB>), dim3(grid), dim3(GEN_WAVES * 64), SLAB ? 0 : lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 0, nullptr, nullptr})
+#define FZB_K2C_LS(SWL, U, T, ET, SLAB) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev, SLAB>), dim3(grid), dim3(GEN_WAVES * 64), SLAB ? 0 : lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 1, nullptr, nullptr})
 #define FZB_K2C_L(SWL, U, T, ET) do { if (in_lds) FZB_K2C_LS(SWL, U, T, ET, false); else FZB_K2C_LS(SWL, U, T, ET, true); } while (0)
 #define FZB_K2C_L_ET(SWL, U, T) do { if (c.ends_u64) FZB_K2C_L(SWL, U, T, u64); else FZB_K2C_L(SWL, U, T, u32); } while (0)
 #define FZB_K2C_L_T(SWL, U) do { if (trace) FZB_K2C_L_ET(SWL, U, true); else FZB_K2C_L_ET(SWL, U, false); } while (0)

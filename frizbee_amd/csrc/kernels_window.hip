@@ -10,7 +10,11 @@
 //
 // Output per survivor: win[2j] = start, win[2j+1] = end (start = 0xFFFFFFFF if rejected) and a keep-bit
 // (wave ballot) + per-tile keep counts for the second-level compaction.
+#include <algorithm>
+#include <type_traits>
+
 #include "kernels_common.h"
+#include "knobs.h"
 
 template <int PFL>
 struct Chunk {
@@ -93,6 +97,7 @@ __device__ __forceinline__ u64 occ_mask(const Chunk<PFL>& c, u32 a, u32 b) {
 // ------------------------------------------------------------------------------------------------
 template <int PFL, typename ND = NeedleDev>
 struct AsciiSrc {
+    static constexpr bool kUnicode = false;
     const ND& nd;
     const u8* hay;
     u32 len;
@@ -120,6 +125,7 @@ struct AsciiSrc {
 
 template <int PFL, typename ND = NeedleDev>
 struct UnicodeSrc {
+    static constexpr bool kUnicode = true;
     const ND& nd;
     const u8* hay;
     u32 len;
@@ -182,8 +188,8 @@ struct Win {
 
 // ---- end scans --------------------------------------------------------------------------------
 // find_end_pos_with_typos (ascii_typos.rs:375-397)
-template <int PFL, typename ND>
-__device__ __forceinline__ u32 ascii_end_pos(AsciiSrc<PFL, ND>& src, u32 max_typos) {
+template <int PFL, typename S>
+__device__ __forceinline__ u32 ascii_end_pos(S& src, u32 max_typos) {
     const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
     u32 start = (len - 1) / PFL * PFL;
     for (;;) {
@@ -198,8 +204,8 @@ __device__ __forceinline__ u32 ascii_end_pos(AsciiSrc<PFL, ND>& src, u32 max_typ
     return len;
 }
 // find_end_pos_with_unicode_typos (unicode_typos.rs:479-508)
-template <int PFL, typename ND>
-__device__ __forceinline__ u32 unicode_end_pos(UnicodeSrc<PFL, ND>& src, u32 max_typos) {
+template <int PFL, typename S>
+__device__ __forceinline__ u32 unicode_end_pos(S& src, u32 max_typos) {
     const u32 n = src.rows(), first = n - 1 - max_typos, len = src.len;
     u32 start = len >= (u32)PFL ? len - PFL : 0;
     for (;;) {
@@ -215,10 +221,54 @@ __device__ __forceinline__ u32 unicode_end_pos(UnicodeSrc<PFL, ND>& src, u32 max
     }
     return len;
 }
-template <int PFL, typename ND>
-__device__ __forceinline__ u32 end_pos(AsciiSrc<PFL, ND>& s, u32 k) { return ascii_end_pos<PFL>(s, k); }
-template <int PFL, typename ND>
-__device__ __forceinline__ u32 end_pos(UnicodeSrc<PFL, ND>& s, u32 k) { return unicode_end_pos<PFL>(s, k); }
+template <int PFL, typename S>
+__device__ __forceinline__ u32 end_pos(S& s, u32 k) {
+    if constexpr (S::kUnicode) return unicode_end_pos<PFL>(s, k);
+    else return ascii_end_pos<PFL>(s, k);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Occurrence masks computed AHEAD, by the whole workgroup (k2a_window's PRE form).  The typo algorithms walk a haystack chunk by chunk at
+// the fixed starts 0, PFL, 2 PFL, ... and what costs is a chunk's occurrence masks (a unicode scalar: two case variants x up to four byte
+// positions x 16 dwords of SWAR compares), not the walk.  One thread per haystack makes the longest haystack of a tile the tile's duration
+// (Arabic-shaped list, 1 typo: ten chunks one after the other = 89 us of a 177 us step, while the median haystack has one).  In the PRE form
+// the tile's (haystack, chunk) pairs are dealt out evenly to the workgroup's threads, which leave every needle row's mask in LDS
+// ([pair][row]); the walk then only reads.  `Real` computes what was not laid out ahead: the end scan's unaligned windows (unicode) and
+// the haystacks of a tile whose pairs did not fit the buffer.
+// ------------------------------------------------------------------------------------------------
+template <int PFL, typename Real>
+struct PreSrc {
+    static constexpr bool kUnicode = Real::kUnicode;
+    Real real;
+    const decltype(real.nd)& nd;
+    const u8* hay;
+    u32 len;
+    const u64* buf;  // this haystack's masks, [chunk][row]
+    u32 nch;         // chunks laid out ahead (0: none - every request goes to `real`)
+    u32 cur;
+    bool direct;
+    u64 valid;
+    template <typename ND>
+    __device__ PreSrc(const ND& n, const u8* h, u32 l, const u64* b, u32 nch_) : real(n, h, l, nullptr), nd(real.nd), hay(h), len(l), buf(b), nch(nch_), cur(0), direct(true), valid(0) {}
+    __device__ __forceinline__ void load(u32 start) {
+        const u32 c = start / PFL;
+        if (start % PFL == 0 && c < nch) {
+            cur = c;
+            direct = false;
+            valid = m_first_n<PFL>(len - start);
+        } else {
+            real.load(start);
+            direct = true;
+            if constexpr (!kUnicode) valid = real.valid;
+        }
+    }
+    __device__ __forceinline__ u64 mask(u32 idx) const { return direct ? real.mask(idx) : buf[(size_t)cur * (u32)nd.rows + idx]; }
+    __device__ __forceinline__ u64 init_mask() const {
+        if constexpr (kUnicode) return m_all<PFL>();
+        else return valid;
+    }
+    __device__ __forceinline__ u32 rows() const { return (u32)nd.rows; }
+};
 
 // ---- 1 typo (ascii_typos.rs:15-110 / unicode_typos.rs:15-141) -----------------------------------
 template <int PFL, typename Src>
@@ -606,6 +656,93 @@ __global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, 
     }
 }
 
+// The PRE form of the kernel above for the typo algorithms over short needles (NeedleDev), one 1024-haystack tile per 1024-thread
+// workgroup: (1) every thread notes its haystack's span and number of PFL-byte chunks, a workgroup scan gives each haystack its place in
+// the mask buffer; (2) the tile's (haystack, chunk) pairs are dealt out round-robin - a thread finds a pair's owner by bisection over
+// the scan - and every needle row's occurrence mask goes to LDS; (3) thread per haystack, the reference's walk over PreSrc.  Pairs beyond
+// the buffer (cap_pairs) are not laid out: their haystacks compute on demand, as in the plain form.  Same results bit for bit (the masks
+// are the same function of the same bytes): tests/test_gpu_knobs.py runs both forms against the oracle (FZB_WINDOW_NO_PRE=1).
+template <int PFL, int ALG>
+__global__ __launch_bounds__(1024) void k2a_window_pre(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
+                                                       const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
+                                                       u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32 cap_pairs) {
+    constexpr int TPB = 1024;
+    constexpr bool UNI = ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0;
+    using Real = typename std::conditional<UNI, UnicodeSrc<PFL, NeedleDev>, AsciiSrc<PFL, NeedleDev>>::type;
+    extern __shared__ __attribute__((aligned(16))) u64 mask_buf[];  // [pair][row]
+    __shared__ u32 s_s16[TPB], s_len[TPB], s_base[TPB + 1], s_wsum[TPB / 64], s_cnt;
+    const u32 M = *n_surv_ptr;
+    const u32 ntiles = (M + FZB_TILE - 1) / FZB_TILE;
+    const int tid = threadIdx.x;
+    const u32 rows = (u32)nd.rows;
+    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        if (tid == 0) s_cnt = 0;
+        const u32 j = tile * FZB_TILE + tid;
+        u64 s = 0;
+        u32 L = 0;
+        if (j < M) {
+            const u32 li = surv_idx ? surv_idx[j] : j;
+            if (ends_u64) haystack_span((const u64*)ends_v, first + li, s, L);
+            else haystack_span((const u32*)ends_v, first + li, s, L);
+        }
+        const u32 nch = (j < M) ? (L + PFL - 1) / PFL : 0;
+        s_s16[tid] = (u32)(s >> 4);  // (padded-16 layout: every haystack starts on a 16-byte boundary; the launcher checks the corpus is below 64 GiB)
+        s_len[tid] = L;
+        // exclusive scan of nch over the workgroup: inclusive scan inside the wave, then the wave totals
+        u32 inc = nch;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 up = __shfl_up(inc, d, 64);
+            if (lane_id() >= d) inc += up;
+        }
+        if (lane_id() == 63) s_wsum[tid >> 6] = inc;
+        __syncthreads();
+        u32 wbase = 0;
+        for (int w = 0; w < (tid >> 6); w++) wbase += s_wsum[w];
+        const u32 base = wbase + inc - nch;
+        s_base[tid] = base;
+        if (tid == TPB - 1) s_base[TPB] = base + nch;
+        __syncthreads();
+        const u32 T = min(s_base[TPB], cap_pairs);
+        for (u32 q = tid; q < T; q += TPB) {
+            u32 lo = 0, hi = TPB - 1;  // the last t with s_base[t] <= q (haystacks without chunks share their successor's base and are skipped)
+            while (lo < hi) {
+                const u32 mid = (lo + hi + 1) >> 1;
+                if (s_base[mid] <= q) lo = mid;
+                else hi = mid - 1;
+            }
+            const u32 c = q - s_base[lo];
+            Real r(nd, bytes + ((u64)s_s16[lo] << 4), s_len[lo], nullptr);
+            r.load(c * PFL);
+            for (u32 row = 0; row < rows; row++) mask_buf[(size_t)q * rows + row] = r.mask(row);
+        }
+        __syncthreads();
+        bool keep = false;
+        if (j < M) {
+            const u32 ahead = base + nch <= T ? nch : 0;  // a haystack is laid out whole or not at all
+            PreSrc<PFL, Real> src(nd, bytes + s, L, mask_buf + (size_t)base * rows, ahead);
+            Win w;
+            if (ALG == ALG_UNI_1 || ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
+            else if (ALG == ALG_UNI_2 || ALG == ALG_ASCII_2) w = prefilter_2_typos<PFL>(src);
+            else {
+                LocalPaths paths;
+                w = prefilter_many_typos<PFL>(src, (u32)nd.max_typos, paths);
+            }
+            keep = w.matched;
+            win[2 * j] = keep ? w.start : 0xFFFFFFFFu;
+            win[2 * j + 1] = w.end;
+        }
+        const u64 b = __ballot(keep);
+        if (lane_id() == 0) {
+            bitmap2[(tile * FZB_TILE) / 64 + (tid >> 6)] = b;
+            if (b) atomicAdd(&s_cnt, (u32)__popcll(b));
+        }
+        __syncthreads();
+        if (tid == 0) tile_counts2[tile] = s_cnt;
+        __syncthreads();
+    }
+}
+
 template <int PFL>
 static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, u32* win, u64* bitmap2,
                               u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, bool one_pass) {
@@ -622,6 +759,40 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
         else if (alg == ALG_ASCII_2) FZB_K2A_D(ALG_ASCII_2);
         else FZB_K2A_D(ALG_ASCII_N);
 #undef FZB_K2A_D
+        return;
+    }
+    // the PRE form (masks laid out ahead by the whole workgroup): one-pass launches of the typo algorithms over a corpus below 64 GiB;
+    // the buffer takes what the device gives a workgroup beyond the kernel's 12.3 KB of static LDS (asked for once per instantiation)
+    if (one_pass && alg != ALG_UNI_0 && !fzb_knobs().window_no_pre && c.total_bytes < ((u64)1 << 36)) {
+        static const size_t lds_max = [] {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 64 * 1024;
+            (void)hipGetLastError();
+            return (size_t)std::max(v, 64 * 1024);
+        }();
+        size_t dyn = std::min<size_t>(lds_max, 144 * 1024) - 13 * 1024;
+#define FZB_K2A_P(ALG)                                                                                                                                          \
+    do {                                                                                                                                                        \
+        static size_t granted = 0;                                                                                                                              \
+        if (!granted) {                                                                                                                                         \
+            granted = 51 * 1024;                                                                                                                                \
+            if (dyn > granted && hipFuncSetAttribute((const void*)k2a_window_pre<PFL, ALG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) \
+                granted = dyn;                                                                                                                                  \
+            (void)hipGetLastError();                                                                                                                            \
+        }                                                                                                                                                       \
+        const size_t use = std::min(dyn, granted);                                                                                                              \
+        hipLaunchKernelGGL((k2a_window_pre<PFL, ALG>), dim3(grid), dim3(1024), use, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, \
+                           (u32)(use / 8 / (size_t)std::max(nd.rows, 1)));                                                                                      \
+    } while (0)
+        switch (alg) {
+            case ALG_ASCII_1: FZB_K2A_P(ALG_ASCII_1); break;
+            case ALG_ASCII_2: FZB_K2A_P(ALG_ASCII_2); break;
+            case ALG_ASCII_N: FZB_K2A_P(ALG_ASCII_N); break;
+            case ALG_UNI_1: FZB_K2A_P(ALG_UNI_1); break;
+            case ALG_UNI_2: FZB_K2A_P(ALG_UNI_2); break;
+            default: FZB_K2A_P(ALG_UNI_N); break;
+        }
+#undef FZB_K2A_P
         return;
     }
 #define FZB_K2A(ALG)                                                                                                                                                          \

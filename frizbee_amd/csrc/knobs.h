@@ -20,8 +20,10 @@ struct FzbKnobs {
     bool debug_sync = false;         // FZB_DEBUG_SYNC=1       synchronise and report after every stage of the pipeline
     bool window_four_pass = false;   // FZB_WINDOW_FOUR_PASS=1 lane-exact window kernel on small lists: 256-thread workgroups, four passes per tile (instead of 1024 threads, one pass)
     bool window_no_mask_cache = false;  // FZB_WINDOW_NO_MASK_CACHE=1 lane-exact window kernel: a needle row's occurrence mask recomputed at every request (no LDS cache)
+    bool long_generic_only = false;  // FZB_LONG_GENERIC_ONLY=1 long needles scored by the wave-per-haystack kernel alone (rounds 3-4) instead of one thread per window (k2d_dp_long)
+    bool window_no_pre = false;      // FZB_WINDOW_NO_PRE=1    lane-exact window kernel, one-pass form: every thread computes its own haystack's occurrence masks chunk by chunk (round 4's form) instead of the workgroup laying them out ahead
     bool no_unicode_fwd = false;     // FZB_UNICODE_FWD=0      the thread-per-haystack unicode multi-chunk scorer keeps its windows beyond four chunks (default: hands up to 4096 on to the wave-per-haystack kernel)
-    bool no_handoff = false;         // FZB_NO_HANDOFF=1       ragged lists: classifier and scorers gather the survivors' bytes from the corpus (no staging)
+    bool no_handoff = true;          // FZB_HANDOFF=1 (or naming FZB_HANDOFF_MIN_TILES) turns the filter -> scorer handoff ON; default since round 5 and FZB_NO_HANDOFF=1: classifier and scorers gather the survivors' bytes from the corpus (no staging)
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device
     bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint
     bool verify_promises = true;     // FZB_VERIFY_PROMISES=0  fzb_corpus_set_uniform_len / _set_max_len on BORROWED memory accepted without the device pass over the end offsets

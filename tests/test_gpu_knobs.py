@@ -69,6 +69,8 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab
     ({"FZB_PARK_LDS_KB": "0", "FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_NO_HANDOFF": "1"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),
+    ({"FZB_HANDOFF": "1", "FZB_HANDOFF_MIN_TILES": "8"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict())]),  # the handoff switched on (off by default since round 5), from 8 tiles
+    ({"FZB_WINDOW_NO_PRE": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=2)), ("uni", "éa", dict(max_typos=1))]),  # the window kernel's threads compute their own masks (round 4's one-pass form)
     ({"FZB_HANDOFF_MIN_TILES": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "DeadBeef", dict())]),  # the handoff on a small list (default: big lists only)
     ({"FZB_HANDOFF_MIN_TILES": "0", "FZB_VIEW_PLAIN_LOADS": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_NO_CDFA": "1"}, [("ragged", "deadbeef", dict())]),                         # the burst filter over the byte automaton

@@ -12,6 +12,20 @@ pytestmark = pytest.mark.gpu
 LANES = {64: (64, 64, 32), 16: (16, 16, 8)}
 
 
+@pytest.fixture(autouse=True, params=["thread_per_window", "wave_per_haystack_only"])
+def long_scorer(request):
+    """Who scores a long needle's ASCII windows of up to 1024 bytes: one thread per window (k2d_dp_long, round 5: needles whose parked rows
+    leave room for at least 128 workgroups' worth of threads - up to 256 rows at 32 lanes) or the wave-per-haystack kernel alone
+    (FZB_LONG_GENERIC_ONLY=1: rounds 3-4; still what unicode, matched indices and needles of thousands of rows take)."""
+    import os
+    if request.param == "wave_per_haystack_only":
+        os.environ["FZB_LONG_GENERIC_ONLY"] = "1"
+    F.lib().fzb_debug_reload_knobs()
+    yield request.param
+    os.environ.pop("FZB_LONG_GENERIC_ONLY", None)
+    F.lib().fzb_debug_reload_knobs()
+
+
 def rand_text(rng, n, alpha=b"abcdef_/ABC-. 01"):
     return bytes(alpha[int(x)] for x in rng.integers(0, len(alpha), n))
 
@@ -151,3 +165,28 @@ def test_needle_at_the_guard_bound_and_long_haystacks():
     hs2 = haystacks_for(rng, n2, 80)
     for typos in (0, 5, None):
         assert F.Matcher(n2, F.Config(max_typos=typos, pf_lanes=64)).match_list(hs2).tolist() == O.Matcher(n2, max_typos=typos).match_list(hs2).tolist(), typos
+
+
+def test_long_needle_windows_beyond_1024_bytes_are_handed_to_the_greedy_kernel():
+    """A 100-byte needle whose windows reach beyond 1024 bytes (whole-haystack windows and typo windows over long haystacks): the
+    thread-per-window scorer queues them for the wave-per-haystack kernel (match_greedy, src/smith_waterman/greedy.rs:7-91), the rest it
+    scores itself - every record against the oracle, both score classes."""
+    rng = np.random.default_rng(11)
+    needle = rand_text(rng, 100, b"abcdefgh_/")
+    hs = haystacks_for(rng, needle, 120)
+    for L in (1000, 1024, 1025, 1500, 2100):
+        for _ in range(3):
+            body = bytearray(rand_text(rng, L))
+            at = sorted(rng.choice(L, size=len(needle), replace=False).tolist())
+            for q, ch in zip(at, needle):
+                body[q] = ch
+            hs.append(bytes(body))
+        hs.append(rand_text(rng, L))
+    cp = F.Corpus(hs)
+    for sc in (None, [1, 1, 1, 0, 0, 0, 0, 0, 0]):
+        for typos in (None, 0, 3):
+            kw = dict(scoring=sc) if sc else {}
+            want = O.Matcher(needle, max_typos=typos, **kw).match_list(hs)
+            got = F.Matcher(needle, F.Config(max_typos=typos, pf_lanes=64, **({"scoring": F.Scoring(*sc)} if sc else {}))).match_list(cp)
+            assert got.tolist() == want.tolist(), (sc, typos, len(got), len(want))
+            assert len(want) >= 20

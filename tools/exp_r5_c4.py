@@ -40,7 +40,7 @@ def one(label, env):
 which = sys.argv[1:] or ["knobs", "two"]
 if "knobs" in which:
     one("default", {})
-    one("no handoff", {"FZB_NO_HANDOFF": "1"})
+    one("handoff on (round 4's default)", {"FZB_HANDOFF": "1"})
     for w in ("4", "5", "8"): one(f"view filter at {w} workgroups per CU", {"FZB_VIEW_WGS": w})
     one("parked rows in the global slab (round 4's PMC profile predates the LDS parking)", {"FZB_PARK_LDS_KB": "0"})
     one("four scorer launches on two streams instead of k2_classes_all", {"FZB_SMALL_LIST": "0"})
