@@ -554,7 +554,24 @@ __global__ __launch_bounds__(128) void k2d_dp_long(const u8* __restrict__ bytes,
         haystack_span(ends, first + li, s, L);
         const u8* hay = bytes + s;
         u32 ws = 0, we = L;
-        if (wmode != 2) { ws = win[2 * q]; we = win[2 * q + 1]; }
+        if (wmode == 1) {
+            // the 0-typo window in its lane-free form (src/prefilter/algo/ascii.rs:6-72): first occurrence of the first needle byte, one past
+            // the last occurrence of the last one, either case; the haystack passed the exact filter, so both exist (haystacks are 16-byte
+            // aligned in the padded layout: whole dwords, bytes beyond L masked)
+            const u32 c0 = (u32)nd.c[0] * 0x01010101u, f0 = (u32)nd.f[0] * 0x01010101u;
+            const u32 cl = (u32)nd.c[nd.rows - 1] * 0x01010101u, fl = (u32)nd.f[nd.rows - 1] * 0x01010101u;
+            ws = 0xFFFFFFFFu;
+            we = 0;
+            for (u32 p = 0; p < L; p += 4) {
+                const u32 w = *(const u32*)(hay + p);
+                const u32 vm = L - p >= 4 ? 0xFu : ((1u << (L - p)) - 1u);
+                const u32 mf = (zero_bytes4_dp(w ^ c0) | zero_bytes4_dp(w ^ f0)) & vm;
+                const u32 ml = (zero_bytes4_dp(w ^ cl) | zero_bytes4_dp(w ^ fl)) & vm;
+                if (mf && ws == 0xFFFFFFFFu) ws = p + (u32)__builtin_ctz(mf);
+                if (ml) we = p + 32u - (u32)__builtin_clz(ml);
+            }
+            if (ws == 0xFFFFFFFFu) ws = 0;
+        } else if (wmode != 2) { ws = win[2 * q]; we = win[2 * q + 1]; }
         const u32 sp = ws ? ws - 1 : 0;
         const bool include_exact = sp == 0 && we == L;
         const u32 m = we - sp;
