@@ -199,6 +199,9 @@ FzbKnobs parse_knobs() {
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
     k.verify_promises = num("FZB_VERIFY_PROMISES", 1) != 0;
     k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");
+    k.view_read_len = set("FZB_VIEW_READ_LEN");
+    k.dfa_general = set("FZB_DFA_GENERAL");
+    k.dfa_stride256 = set("FZB_DFA_STRIDE256");
     k.small_list = getenv("FZB_SMALL_LIST") ? (uint32_t)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
     k.compact_grid_mul = std::max(1, num("FZB_COMPACT_GRID_MUL", 4));
     { const int v = num("FZB_CLASSIFY_PER", 2); k.classify_per = (v == 1 || v == 4) ? v : 2; }

@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
 // from HBM up front.  The table has (rows + 1) * 256 bytes; 4 byte values share a dword, so the
 // alphanumerics of one state row spread over distinct LDS banks.
 // ---------------------------------------------------------------------------------------------------
-template <typename ET>
+// UNI32 (round 5): the list was declared (or detected) uniform with exactly 32 bytes per haystack - the headline shape.  No per-lane
+// lengths, no zero-initialised vectors, no partial-vector walks, no length test (min_len <= 32 is checked by the launcher): every haystack
+// is two unconditional 16-byte loads and 32 table steps.  STRIDE: the table's row pitch in LDS (dfa_lds.h).
+template <typename ET, bool UNI32 = false, u32 STRIDE = FZB_DFA_STRIDE>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                               const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                               u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 ulen) {
@@ -145,14 +148,48 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
     // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
+    u32& s_cnt = *(u32*)(dfa + ((u32)rows + 1u) * STRIDE);
     const int tid = threadIdx.x;
     dfa_require_lds_base0(dfa);
-    dfa_load_lds(dfa, dfa_g, rows);
+    dfa_load_lds<STRIDE>(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (tid == 0) s_cnt = 0;
         __syncthreads();
+        if (UNI32) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const u32 li = min(tile * FZB_TILE + p * 256 + tid, count - 1);  // (the last tile's spare lanes re-read the last haystack; their bit is masked below)
+                const uint4* vp = (const uint4*)(bytes + (first + li) * 32ull);
+                a[p] = vp[0];
+                b[p] = vp[1];
+            }
+            u32 st[4] = {0, 0, 0, 0};
+            { const u32 w[4] = {a[0].x, a[1].x, a[2].x, a[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {a[0].y, a[1].y, a[2].y, a[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {a[0].z, a[1].z, a[2].z, a[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {a[0].w, a[1].w, a[2].w, a[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {b[0].x, b[1].x, b[2].x, b[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {b[0].y, b[1].y, b[2].y, b[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {b[0].z, b[1].z, b[2].z, b[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {b[0].w, b[1].w, b[2].w, b[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            u32 cnt = 0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const u32 li = tile * FZB_TILE + p * 256 + tid;
+                const u64 bal = __ballot(li < count && st[p] >= acc_lo);
+                if (lane_id() == 0) {
+                    bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = bal;
+                    cnt += __popcll(bal);
+                }
+            }
+            if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
+            __syncthreads();
+            if (tid == 0) tile_counts[tile] = s_cnt;
+            __syncthreads();
+            continue;
+        }
         u64 hs[4];
         u32 hl[4];
         uint4 v0[4], v1[4];
@@ -176,23 +213,23 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
         u32 st[4] = {0, 0, 0, 0};
         // short haystacks (<= 32 bytes): both vectors are already in flight
         if (hl[0] >= 16 && hl[1] >= 16 && hl[2] >= 16 && hl[3] >= 16) {
-            { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; p++) st[p] = dfa_partial(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
+            for (int p = 0; p < 4; p++) st[p] = dfa_partial<true, STRIDE>(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
         }
         if (hl[0] >= 32 && hl[1] >= 32 && hl[2] >= 32 && hl[3] >= 32) {
-            { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4(st, w, dfa); }
-            { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4(st, w, dfa); }
+            { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
         } else {
 #pragma unroll
             for (int p = 0; p < 4; p++)
-                if (hl[p] > 16) st[p] = dfa_partial(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
+                if (hl[p] > 16) st[p] = dfa_partial<true, STRIDE>(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
         }
         u32 cnt = 0;
 #pragma unroll
@@ -520,7 +557,12 @@ __global__ __launch_bounds__(256) void k1_cdfa_ragged(const u8* __restrict__ byt
 // tile's header, one entry per survivor in index order - the order of the survivor list, so k2w_classify finds survivor j's entry at
 // rank(j) - survivors-before-its-tile.  What the classifier and the scorers then read is ~ 4 KB of contiguous lines per tile instead of
 // 49 haystacks spread over 80 KB of the corpus (140 MB of cold lines for 43 MB of survivor bytes on the C4 shard).
-template <bool SAN, int G, int NV, bool STAGE>
+// LEN: the kernel reads the haystacks' lengths (vlen: 2 of the view's ~83 bytes per haystack on the C4 shard).  They are needed to sanitise a
+// last vector (SAN), for the stage's header (STAGE), to skip an outlier's lane (0xFFFF) and for `length >= min_len` - but with the zero fill
+// harmless (!SAN) an outlier's lane holds zero vectors and cannot leave state 0, and every automaton the view kernel runs accepts only
+// haystacks of at least min_len bytes (subsequence / unicode: the needle's bytes all occurred; LCS >= rows - k bytes matched): without SAN
+// and STAGE the launcher passes LEN = false and the array is not touched.
+template <bool SAN, int G, int NV, bool STAGE, bool LEN = true>
 __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
                                                     const u16* __restrict__ vperm, u64 first, u32 count, const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG,
                                                     u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters,
@@ -556,7 +598,7 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
             const u32 nv = __builtin_amdgcn_readfirstlane((u32)vgnv[g_first + gl]);
             const u8* base = vbytes + (size_t)__builtin_amdgcn_readfirstlane(vgofs[g_first + gl]) * 16 + (u32)lane * 16;
             u32 hl = 0, orig = 0;
-            if (p < count) { hl = vlen[first + p]; orig = vperm[first + p]; }
+            if (p < count) { hl = LEN ? (u32)vlen[first + p] : 0u; orig = vperm[first + p]; }
             uint4 q[NV];
             // (non-temporal: a wave's load covers whole lines that nothing reads again - the stream no longer displaces what the later stages
             // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison)
@@ -607,7 +649,7 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
                     for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);
                 }
             }
-            if (p < count && hl != 0xFFFFu && hl >= min_len && st >= acc_lo) {  // (0xFFFF: an outlier beyond 256 bytes - k1_cdfa_outliers decides it)
+            if (p < count && (!LEN || (hl != 0xFFFFu && hl >= min_len)) && st >= acc_lo) {  // (0xFFFF: an outlier beyond 256 bytes - k1_cdfa_outliers decides it)
                 atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
                 if (STAGE) {
                     // the vectors go to the tile's block through LDS (the first FZB_STAGE_LDS_UNITS units: written out below by the whole
@@ -1045,8 +1087,17 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         const size_t lds = (size_t)(rows + 1) * FZB_DFA_STRIDE + 16;  // table + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
-            if (c.ends_u64) hipLaunchKernelGGL((k1_dfa<u64>), dim3(grid_dfa), dim3(256), lds, st, c.bytes, (const u64*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len);
-            else hipLaunchKernelGGL((k1_dfa<u32>), dim3(grid_dfa), dim3(256), lds, st, c.bytes, (const u32*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len);
+            // a uniform list of 32-byte haystacks (the headline shape): the instantiation without per-lane lengths; FZB_DFA_GENERAL=1 compares.
+            // FZB_DFA_STRIDE256=1: the table at a 256-byte row pitch (one VALU instruction per byte instead of two; more LDS bank conflicts)
+            const bool uni32 = c.uniform_len == 32 && min_len <= 32 && count != 0 && !fzb_knobs().dfa_general;
+            const size_t lds256 = (size_t)(rows + 1) * 256 + 16;
+#define FZB_K1D(ET, U, S, L) hipLaunchKernelGGL((k1_dfa<ET, U, S>), dim3(grid_dfa), dim3(256), L, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len)
+#define FZB_K1D_S(ET, U) do { if (fzb_knobs().dfa_stride256) FZB_K1D(ET, U, 256u, lds256); else FZB_K1D(ET, U, FZB_DFA_STRIDE, lds); } while (0)
+#define FZB_K1D_U(ET) do { if (uni32) FZB_K1D_S(ET, true); else FZB_K1D_S(ET, false); } while (0)
+            if (c.ends_u64) FZB_K1D_U(u64); else FZB_K1D_U(u32);
+#undef FZB_K1D_U
+#undef FZB_K1D_S
+#undef FZB_K1D
         } else {
             // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
             // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times).
@@ -1069,8 +1120,11 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 u32 kg = 1;
                 for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
                 if (kn.cdfa_nodfa) cdfa_K = 0xFFFF;
+                // (the lengths are not read when nothing needs them: acc >= 1 = the start state does not accept; FZB_VIEW_READ_LEN=1 compares)
+                const bool len_free = nul_safe && acc >= 1 && !kn.view_read_len;
+#define FZB_K1VN(SAN, G, NV) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, false, false>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, (u8*)nullptr, (u32*)nullptr, (u32)kn.stage_dbg | (kn.view_plain_loads ? 0u : 8u))
 #define FZB_K1V(SAN, G, NV, STG) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, STG>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, stg ? so->stage : nullptr, stg ? so->hdr : nullptr, (u32)kn.stage_dbg | (kn.view_plain_loads ? 0u : 8u))
-#define FZB_K1V_S(SAN, G, NV) do { if (stg) FZB_K1V(SAN, G, NV, true); else FZB_K1V(SAN, G, NV, false); } while (0)
+#define FZB_K1V_S(SAN, G, NV) do { if (stg) FZB_K1V(SAN, G, NV, true); else if (!SAN && len_free) FZB_K1VN(SAN, G, NV); else FZB_K1V(SAN, G, NV, false); } while (0)
 #define FZB_K1V_NV(SAN, G) do { if (c.view_nv <= 8) FZB_K1V_S(SAN, G, 8); else FZB_K1V_S(SAN, G, 16); } while (0)
 #define FZB_K1V_G(SAN) do { if (cdfa_G == 4) FZB_K1V_NV(SAN, 4); else FZB_K1V_NV(SAN, 2); } while (0)
                 if (nul_safe) FZB_K1V_G(false); else FZB_K1V_G(true);
@@ -1078,6 +1132,7 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #undef FZB_K1V_NV
 #undef FZB_K1V_S
 #undef FZB_K1V
+#undef FZB_K1VN
                 if (c.n_long) {  // the haystacks beyond 256 bytes: decided from the canonical layout, OR-ed into the view kernel's bitmap
                     const u32 ns_o = (cdfa_bytes - 256u) / kg;  // the automaton's states (the table is padded to 16 bytes: at most a phantom state more)
                     const u32 wpw = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)4 * 64 * ns_o + 16 <= 60 * 1024 ? 4u : 1u;

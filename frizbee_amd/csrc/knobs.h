@@ -25,6 +25,9 @@ struct FzbKnobs {
     bool no_unicode_fwd = false;     // FZB_UNICODE_FWD=0      the thread-per-haystack unicode multi-chunk scorer keeps its windows beyond four chunks (default: hands up to 4096 on to the wave-per-haystack kernel)
     bool no_handoff = true;          // FZB_HANDOFF=1 (or naming FZB_HANDOFF_MIN_TILES) turns the filter -> scorer handoff ON; default since round 5 and FZB_NO_HANDOFF=1: classifier and scorers gather the survivors' bytes from the corpus (no staging)
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device
+    bool dfa_general = false;        // FZB_DFA_GENERAL=1      k1_dfa's general form (per-lane lengths) on a uniform list of 32-byte haystacks too (round 4's form)
+    bool dfa_stride256 = false;      // FZB_DFA_STRIDE256=1    k1_dfa's table at a 256-byte row pitch: the v_perm result is the address (one VALU instruction per byte), more LDS bank conflicts
+    bool view_read_len = false;      // FZB_VIEW_READ_LEN=1    the view filter reads the haystacks' lengths even when nothing needs them (round 4's form)
     bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint
     bool verify_promises = true;     // FZB_VERIFY_PROMISES=0  fzb_corpus_set_uniform_len / _set_max_len on BORROWED memory accepted without the device pass over the end offsets
     int shard_inline = -1;           // FZB_SHARD_INLINE=0|1   multi-device query, shards on the root device: 0 = through the worker threads, 1 = enqueued by the caller

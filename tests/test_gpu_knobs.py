@@ -65,6 +65,9 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_WINDOW_NO_MASK_CACHE": "1"}, [("ragged", "deadbe", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=2))]),  # row masks recomputed at every request
     ({"FZB_WINDOW_NO_MASK_CACHE": "1", "FZB_WINDOW_FOUR_PASS": "1"}, [("uniwide", "éa", dict(max_typos=1))]),
     ({"FZB_DFA_WGS": "3"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),
+    ({"FZB_DFA_GENERAL": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=1))]),        # k1_dfa with per-lane lengths on the uniform 32-byte list (round 4's form)
+    ({"FZB_DFA_STRIDE256": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),      # the table at a 256-byte row pitch (v_perm result = address)
+    ({"FZB_DFA_STRIDE256": "1", "FZB_DFA_GENERAL": "1"}, [("short", "deadbe", dict())]),
     ({"FZB_DFA_WGS": "8"}, [("short", "deadbe", dict()), ("uni", "éa", dict())]),
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab
     ({"FZB_PARK_LDS_KB": "0", "FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),
@@ -73,6 +76,7 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_WINDOW_NO_PRE": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=2)), ("uni", "éa", dict(max_typos=1))]),  # the window kernel's threads compute their own masks (round 4's one-pass form)
     ({"FZB_HANDOFF_MIN_TILES": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "DeadBeef", dict())]),  # the handoff on a small list (default: big lists only)
     ({"FZB_HANDOFF_MIN_TILES": "0", "FZB_VIEW_PLAIN_LOADS": "1"}, [("ragged", "deadbeef", dict())]),
+    ({"FZB_VIEW_READ_LEN": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict())]),  # the view filter reads the lengths it does not need (round 4's form)
     ({"FZB_NO_CDFA": "1"}, [("ragged", "deadbeef", dict())]),                         # the burst filter over the byte automaton
     ({"FZB_NO_CDFA": "1", "FZB_RAGGED_BURST": "0"}, [("ragged", "deadbeef", dict())]),  # ... and its rolling form
     ({"FZB_DEBUG_SYNC": "1"}, [("short", "deadbe", dict())]),
