@@ -408,25 +408,6 @@ __device__ __forceinline__ u32 dp_multi_chunk(const ND& nd, const u8* __restrict
 #pragma unroll
         for (int d = 0; d < NW; d++) prev[d] = 0, gprev[d] = 0;
         u32 carry = 0;  // S(r-1, previous chunk) top dword (its high half is the last lane), unbiased
-        // The previous chunk's parked vectors are requested ONE ROW AHEAD (round 5): row r's were written a whole chunk ago, so row r + 1's
-        // can be in flight while row r is computed - with one wave per SIMD and hundreds of rows (long needles, k2d_dp_long: 80 rows x 5
-        // chunks = 400 dependent L2 round trips per window, 1.33 of the bench row's 1.42 ms) the round trip was the kernel.  `pre` holds the
-        // raw dwords of the row about to be computed; the slot it came from is overwritten (this chunk's row r) only after it was read.
-        constexpr int NPK = HT + 1;  // u8 class: HT / 2 packed dwords + the flag word; else HT + the flag word (pre[HT] is the flag word either way)
-        u32 pre[NPK];
-#pragma unroll
-        for (int t = 0; t < NPK; t++) pre[t] = 0u;
-        if (ch && rows) {
-            const u32* s0 = scratch + sidx;
-            if (u8class) {
-#pragma unroll
-                for (int t = 0; t < HT / 2; t++) pre[t] = s0[(size_t)t * sstride];
-            } else {
-#pragma unroll
-                for (int t = 0; t < HT; t++) pre[t] = s0[(size_t)t * sstride];
-            }
-            pre[HT] = s0[(size_t)HT * sstride];
-        }
 #pragma unroll 1
         for (u32 r = 0; r < rows; r++) {
             const u32 c = (((const u32*)nd.c)[r >> 2] >> (8 * (r & 3))) & 0xFF, f = (((const u32*)nd.f)[r >> 2] >> (8 * (r & 3))) & 0xFF;  // scalar loads
@@ -443,28 +424,17 @@ __device__ __forceinline__ u32 dp_multi_chunk(const ND& nd, const u8* __restrict
                 if (u8class) {
 #pragma unroll
                     for (int t = 0; t < HT / 2; t++) {
-                        const u32 pk = pre[t];
+                        const u32 pk = srow[(size_t)t * sstride];
                         arow[2 * t] = __builtin_amdgcn_perm(0u, pk, 0x0c010c00u);
                         arow[2 * t + 1] = __builtin_amdgcn_perm(0u, pk, 0x0c030c02u);
                     }
                 } else {
 #pragma unroll
-                    for (int t = 0; t < HT; t++) arow[t] = pre[t];
+                    for (int t = 0; t < HT; t++) arow[t] = srow[(size_t)t * sstride];
                 }
-                const u32 bits = pre[HT];
+                const u32 bits = srow[(size_t)HT * sstride];
 #pragma unroll
                 for (int t = 0; t < HT; t++) ag[t] = p_mul(((bits >> (2 * t)) & 1u) | (((bits >> (2 * t + 1)) & 1u) << 16), gopmv);
-                if (r + 1 < rows) {  // the next row's request (a different slot than the one this row stores to below)
-                    const u32* sn = srow + (size_t)NW * sstride;
-                    if (u8class) {
-#pragma unroll
-                        for (int t = 0; t < HT / 2; t++) pre[t] = sn[(size_t)t * sstride];
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < HT; t++) pre[t] = sn[(size_t)t * sstride];
-                    }
-                    pre[HT] = sn[(size_t)HT * sstride];
-                }
             } else {
 #pragma unroll
                 for (int t = 0; t < HT; t++) arow[t] = 0u, ag[t] = 0u;

@@ -191,6 +191,7 @@ FzbKnobs parse_knobs() {
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
     k.stage_dbg = num("FZB_STAGE_DBG", 0);
+    k.window_dbg = num("FZB_WINDOW_DBG", 0);
     k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
     k.generic_wgs = std::max(1, num("FZB_GENERIC_WGS", 12));
     k.dfa_wgs = std::max(1, std::min(8, num("FZB_DFA_WGS", 8)));

@@ -665,7 +665,9 @@ __global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, 
 template <int PFL, int ALG>
 __global__ __launch_bounds__(1024) void k2a_window_pre(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
                                                        const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
-                                                       u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32 cap_pairs) {
+                                                       u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32 cap_pairs, u32 dbg) {
+    // (dbg: MEASUREMENT ONLY, FZB_WINDOW_DBG - bit 0: no masks laid out (phase 2 skipped), 1: no walk (phase 3 skipped), 2: the walk without its
+    // end scan; results meaningless)
     constexpr int TPB = 1024;
     constexpr bool UNI = ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0;
     using Real = typename std::conditional<UNI, UnicodeSrc<PFL, NeedleDev>, AsciiSrc<PFL, NeedleDev>>::type;
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(1024) void k2a_window_pre(const u8* __restrict__ by
         if (tid == TPB - 1) s_base[TPB] = base + nch;
         __syncthreads();
         const u32 T = min(s_base[TPB], cap_pairs);
-        for (u32 q = tid; q < T; q += TPB) {
+        for (u32 q = tid; q < ((dbg & 1u) ? 0u : T); q += TPB) {
             u32 lo = 0, hi = TPB - 1;  // the last t with s_base[t] <= q (haystacks without chunks share their successor's base and are skipped)
             while (lo < hi) {
                 const u32 mid = (lo + hi + 1) >> 1;
@@ -718,9 +720,9 @@ __global__ __launch_bounds__(1024) void k2a_window_pre(const u8* __restrict__ by
         }
         __syncthreads();
         bool keep = false;
-        if (j < M) {
+        if (j < M && !(dbg & 2u)) {
             const u32 ahead = base + nch <= T ? nch : 0;  // a haystack is laid out whole or not at all
-            PreSrc<PFL, Real> src(nd, bytes + s, L, mask_buf + (size_t)base * rows, ahead);
+            PreSrc<PFL, Real> src(nd, bytes + s, (dbg & 4u) ? min(L, (u32)PFL) : L, mask_buf + (size_t)base * rows, ahead);
             Win w;
             if (ALG == ALG_UNI_1 || ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
             else if (ALG == ALG_UNI_2 || ALG == ALG_ASCII_2) w = prefilter_2_typos<PFL>(src);
@@ -782,7 +784,7 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
         }                                                                                                                                                       \
         const size_t use = std::min(dyn, granted);                                                                                                              \
         hipLaunchKernelGGL((k2a_window_pre<PFL, ALG>), dim3(grid), dim3(1024), use, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, \
-                           (u32)(use / 8 / (size_t)std::max(nd.rows, 1)));                                                                                      \
+                           (u32)(use / 8 / (size_t)std::max(nd.rows, 1)), (u32)fzb_knobs().window_dbg);                                                                                      \
     } while (0)
         switch (alg) {
             case ALG_ASCII_1: FZB_K2A_P(ALG_ASCII_1); break;

@@ -35,6 +35,7 @@ struct FzbKnobs {
     int unicode_multi = -1;          // FZB_UNICODE_MULTI=0|1  unicode windows of 65..1024 bytes: never / always thread per haystack (k2u_dp_unicode_multi); default: by the queue's length
     int generic_wgs = 12;            // FZB_GENERIC_WGS        workgroups per CU of the wave-per-haystack kernel over a queue of wide unicode windows
     int park_lds_kb = 37;            // FZB_PARK_LDS_KB        multi-chunk scorer: parked rows in LDS when they fit this many KB per workgroup (0: always the global slab)
+    int window_dbg = 0;              // FZB_WINDOW_DBG=bits    MEASUREMENT ONLY: phases of the window kernel's PRE form switched off (results meaningless)
     int stage_dbg = 0;               // FZB_STAGE_DBG=bits     MEASUREMENT ONLY: parts of the view kernel's staging switched off (results meaningless)
     int k2u_waves = 0;               // FZB_K2U_WAVES=3        unicode scorer's biased form capped at three waves per SIMD (spills)
     uint32_t small_list = 0xFFFFFFFFu;  // FZB_SMALL_LIST=n   lists of n haystacks and more: four scorer launches on two streams instead of k2_classes_all

@@ -29,6 +29,11 @@ def timed(label, needle, cfg, cp, n, env, steps=10):
 
 
 which = sys.argv[1:] or ["arabic", "paths", "long"]
+if "arabic1" in which:  # the 1-typo column alone (measurement runs under FZB_WINDOW_DBG)
+    da, ea = synth.arabic_corpus()
+    cp = F.Corpus(packed=(da, ea))
+    timed("arabic-shaped 285k, max_typos=1", "إن", F.Config(max_typos=1, pf_lanes=64, sw_lanes=64), cp, int(len(ea)), {}, steps=5)
+    del cp
 if "arabic" in which:
     da, ea = synth.arabic_corpus()
     cp = F.Corpus(packed=(da, ea))
