@@ -187,6 +187,7 @@ FzbKnobs parse_knobs() {
     k.window_no_mask_cache = set("FZB_WINDOW_NO_MASK_CACHE");
     k.window_four_pass = set("FZB_WINDOW_FOUR_PASS");
     k.window_no_pre = set("FZB_WINDOW_NO_PRE");
+    k.window_whole_tiles = set("FZB_WINDOW_WHOLE_TILES");
     k.long_generic_only = set("FZB_LONG_GENERIC_ONLY");
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.k2u_waves = num("FZB_K2U_WAVES", 0);
@@ -201,7 +202,7 @@ FzbKnobs parse_knobs() {
     k.verify_promises = num("FZB_VERIFY_PROMISES", 1) != 0;
     k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");
     k.view_read_len = set("FZB_VIEW_READ_LEN");
-    k.dfa_general = set("FZB_DFA_GENERAL");
+    k.dfa_general = !on("FZB_DFA_UNI32");
     k.dfa_stride256 = set("FZB_DFA_STRIDE256");
     k.small_list = getenv("FZB_SMALL_LIST") ? (uint32_t)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
     k.compact_grid_mul = std::max(1, num("FZB_COMPACT_GRID_MUL", 4));

@@ -1087,7 +1087,7 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         const size_t lds = (size_t)(rows + 1) * FZB_DFA_STRIDE + 16;  // table + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
-            // a uniform list of 32-byte haystacks (the headline shape): the instantiation without per-lane lengths; FZB_DFA_GENERAL=1 compares.
+            // a uniform list of 32-byte haystacks (the headline shape): FZB_DFA_UNI32=1 = the instantiation without per-lane lengths (round 5: same 57 us).
             // FZB_DFA_STRIDE256=1: the table at a 256-byte row pitch (one VALU instruction per byte instead of two; more LDS bank conflicts)
             const bool uni32 = c.uniform_len == 32 && min_len <= 32 && count != 0 && !fzb_knobs().dfa_general;
             const size_t lds256 = (size_t)(rows + 1) * 256 + 16;

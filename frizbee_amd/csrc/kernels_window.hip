@@ -662,24 +662,29 @@ __global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, 
 // the scan - and every needle row's occurrence mask goes to LDS; (3) thread per haystack, the reference's walk over PreSrc.  Pairs beyond
 // the buffer (cap_pairs) are not laid out: their haystacks compute on demand, as in the plain form.  Same results bit for bit (the masks
 // are the same function of the same bytes): tests/test_gpu_knobs.py runs both forms against the oracle (FZB_WINDOW_NO_PRE=1).
-template <int PFL, int ALG>
-__global__ __launch_bounds__(1024) void k2a_window_pre(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
-                                                       const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
-                                                       u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32 cap_pairs, u32 dbg) {
+template <int PFL, int ALG, int TPB>
+__global__ __launch_bounds__(TPB) void k2a_window_pre(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
+                                                      const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
+                                                      u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32 cap_pairs, u32 dbg) {
     // (dbg: MEASUREMENT ONLY, FZB_WINDOW_DBG - bit 0: no masks laid out (phase 2 skipped), 1: no walk (phase 3 skipped), 2: the walk without its
     // end scan; results meaningless)
-    constexpr int TPB = 1024;
+    // TPB < 1024: a workgroup owns a PART of a 1024-haystack tile (NQ = 1024 / TPB parts per tile, one unit of work each) and ADDS its count to
+    // the tile's (the launcher zeroes the counts).  What the measurement bits showed on the Arabic-shaped 1-typo query (105 tiles, 1024-thread
+    // workgroups: 96 us for the stage): the masks laid out ahead are 10 us of it, the WALK 66 - sixteen waves of divergent per-haystack
+    // loops sharing four SIMDs on 105 of the 256 CUs.  As quarter tiles the same walks run on every CU, one or two waves per SIMD.
+    constexpr int NQ = FZB_TILE / TPB;
     constexpr bool UNI = ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0;
     using Real = typename std::conditional<UNI, UnicodeSrc<PFL, NeedleDev>, AsciiSrc<PFL, NeedleDev>>::type;
     extern __shared__ __attribute__((aligned(16))) u64 mask_buf[];  // [pair][row]
     __shared__ u32 s_s16[TPB], s_len[TPB], s_base[TPB + 1], s_wsum[TPB / 64], s_cnt;
     const u32 M = *n_surv_ptr;
-    const u32 ntiles = (M + FZB_TILE - 1) / FZB_TILE;
+    const u32 nunits = ((M + FZB_TILE - 1) / FZB_TILE) * NQ;
     const int tid = threadIdx.x;
     const u32 rows = (u32)nd.rows;
-    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (u32 unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+        const u32 tile = unit / NQ, part = unit % NQ;
         if (tid == 0) s_cnt = 0;
-        const u32 j = tile * FZB_TILE + tid;
+        const u32 j = tile * FZB_TILE + part * TPB + tid;
         u64 s = 0;
         u32 L = 0;
         if (j < M) {
@@ -736,18 +741,21 @@ __global__ __launch_bounds__(1024) void k2a_window_pre(const u8* __restrict__ by
         }
         const u64 b = __ballot(keep);
         if (lane_id() == 0) {
-            bitmap2[(tile * FZB_TILE) / 64 + (tid >> 6)] = b;
+            bitmap2[(tile * FZB_TILE + part * TPB) / 64 + (tid >> 6)] = b;
             if (b) atomicAdd(&s_cnt, (u32)__popcll(b));
         }
         __syncthreads();
-        if (tid == 0) tile_counts2[tile] = s_cnt;
+        if (tid == 0) {
+            if (NQ == 1) tile_counts2[tile] = s_cnt;
+            else if (s_cnt) atomicAdd(&tile_counts2[tile], s_cnt);
+        }
         __syncthreads();
     }
 }
 
 template <int PFL>
 static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, u32* win, u64* bitmap2,
-                              u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, bool one_pass) {
+                              u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, bool one_pass, u32 max_items) {
     const int k = nd.max_typos;
     const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
     // occurrence-mask cache in LDS (ASCII and, since round 4, unicode algorithms): rows x 2 KB per 256-thread workgroup, up to 16 rows (one-pass form: rows x 8 KB, up to 7)
@@ -772,19 +780,28 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
             (void)hipGetLastError();
             return (size_t)std::max(v, 64 * 1024);
         }();
-        size_t dyn = std::min<size_t>(lds_max, 144 * 1024) - 13 * 1024;
+        // quarter tiles (256-thread workgroups, four per tile, counts added to the zeroed tile counts) unless FZB_WINDOW_WHOLE_TILES=1
+        const bool quarters = !fzb_knobs().window_whole_tiles && max_items != 0;
+        const u32 ntiles_max = (max_items + FZB_TILE - 1) / FZB_TILE;
+        if (quarters) (void)hipMemsetAsync(tile_counts2, 0, (size_t)ntiles_max * 4, st);
+        const size_t dyn = quarters ? (size_t)40 * 1024 : std::min<size_t>(lds_max, 144 * 1024) - 13 * 1024;
 #define FZB_K2A_P(ALG)                                                                                                                                          \
     do {                                                                                                                                                        \
+        if (quarters) {                                                                                                                                         \
+            hipLaunchKernelGGL((k2a_window_pre<PFL, ALG, 256>), dim3(std::max<u32>(1u, ntiles_max * 4u)), dim3(256), dyn, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, \
+                               bitmap2, tile_counts2, (u32)(dyn / 8 / (size_t)std::max(nd.rows, 1)), (u32)fzb_knobs().window_dbg);                            \
+            break;                                                                                                                                              \
+        }                                                                                                                                                       \
         static size_t granted = 0;                                                                                                                              \
         if (!granted) {                                                                                                                                         \
             granted = 51 * 1024;                                                                                                                                \
-            if (dyn > granted && hipFuncSetAttribute((const void*)k2a_window_pre<PFL, ALG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) \
+            if (dyn > granted && hipFuncSetAttribute((const void*)k2a_window_pre<PFL, ALG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) \
                 granted = dyn;                                                                                                                                  \
             (void)hipGetLastError();                                                                                                                            \
         }                                                                                                                                                       \
         const size_t use = std::min(dyn, granted);                                                                                                              \
-        hipLaunchKernelGGL((k2a_window_pre<PFL, ALG>), dim3(grid), dim3(1024), use, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, \
-                           (u32)(use / 8 / (size_t)std::max(nd.rows, 1)), (u32)fzb_knobs().window_dbg);                                                                                      \
+        hipLaunchKernelGGL((k2a_window_pre<PFL, ALG, 1024>), dim3(grid), dim3(1024), use, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, \
+                           (u32)(use / 8 / (size_t)std::max(nd.rows, 1)), (u32)fzb_knobs().window_dbg);                                                        \
     } while (0)
         switch (alg) {
             case ALG_ASCII_1: FZB_K2A_P(ALG_ASCII_1); break;
@@ -821,9 +838,9 @@ void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const
     // list, 1.4 M items: 169 k / 225 k / 281 k for 1 / 2 / 3 typos = 165-274 tiles, every workgroup resident at once), and in a kernel that is
     // one chain of dependent passes per tile a 1024-thread workgroup is never behind four 256-thread passes even when every haystack survives
     const bool one_pass = !decide && max_items != 0 && !fzb_knobs().window_four_pass && (u64)max_items <= (u64)(grid / 4 > 0 ? grid / 4 : 1) * 1024u * 8u;
-    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
-    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
-    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass);
+    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass, max_items);
+    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass, max_items);
+    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass, max_items);
 }
 
 // ---- long needles: this kernel is the FIRST stage (length test + the reference's prefilter at the exact lane width, every typo

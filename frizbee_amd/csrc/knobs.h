@@ -21,11 +21,12 @@ struct FzbKnobs {
     bool window_four_pass = false;   // FZB_WINDOW_FOUR_PASS=1 lane-exact window kernel on small lists: 256-thread workgroups, four passes per tile (instead of 1024 threads, one pass)
     bool window_no_mask_cache = false;  // FZB_WINDOW_NO_MASK_CACHE=1 lane-exact window kernel: a needle row's occurrence mask recomputed at every request (no LDS cache)
     bool long_generic_only = false;  // FZB_LONG_GENERIC_ONLY=1 long needles scored by the wave-per-haystack kernel alone (rounds 3-4) instead of one thread per window (k2d_dp_long)
+    bool window_whole_tiles = false; // FZB_WINDOW_WHOLE_TILES=1 the PRE form as one 1024-thread workgroup per tile instead of four 256-thread workgroups per tile
     bool window_no_pre = false;      // FZB_WINDOW_NO_PRE=1    lane-exact window kernel, one-pass form: every thread computes its own haystack's occurrence masks chunk by chunk (round 4's form) instead of the workgroup laying them out ahead
     bool no_unicode_fwd = false;     // FZB_UNICODE_FWD=0      the thread-per-haystack unicode multi-chunk scorer keeps its windows beyond four chunks (default: hands up to 4096 on to the wave-per-haystack kernel)
     bool no_handoff = true;          // FZB_HANDOFF=1 (or naming FZB_HANDOFF_MIN_TILES) turns the filter -> scorer handoff ON; default since round 5 and FZB_NO_HANDOFF=1: classifier and scorers gather the survivors' bytes from the corpus (no staging)
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device
-    bool dfa_general = false;        // FZB_DFA_GENERAL=1      k1_dfa's general form (per-lane lengths) on a uniform list of 32-byte haystacks too (round 4's form)
+    bool dfa_general = true;         // FZB_DFA_UNI32=1        k1_dfa's instantiation without per-lane lengths on a uniform list of 32-byte haystacks (round 5 experiment: same time); default: the general form
     bool dfa_stride256 = false;      // FZB_DFA_STRIDE256=1    k1_dfa's table at a 256-byte row pitch: the v_perm result is the address (one VALU instruction per byte), more LDS bank conflicts
     bool view_read_len = false;      // FZB_VIEW_READ_LEN=1    the view filter reads the haystacks' lengths even when nothing needs them (round 4's form)
     bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint

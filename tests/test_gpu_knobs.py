@@ -65,9 +65,10 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_WINDOW_NO_MASK_CACHE": "1"}, [("ragged", "deadbe", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=2))]),  # row masks recomputed at every request
     ({"FZB_WINDOW_NO_MASK_CACHE": "1", "FZB_WINDOW_FOUR_PASS": "1"}, [("uniwide", "éa", dict(max_typos=1))]),
     ({"FZB_DFA_WGS": "3"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),
-    ({"FZB_DFA_GENERAL": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=1))]),        # k1_dfa with per-lane lengths on the uniform 32-byte list (round 4's form)
+    ({"FZB_DFA_UNI32": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=1))]),          # k1_dfa without per-lane lengths on the uniform 32-byte list
     ({"FZB_DFA_STRIDE256": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),      # the table at a 256-byte row pitch (v_perm result = address)
-    ({"FZB_DFA_STRIDE256": "1", "FZB_DFA_GENERAL": "1"}, [("short", "deadbe", dict())]),
+    ({"FZB_DFA_STRIDE256": "1", "FZB_DFA_UNI32": "1"}, [("short", "deadbe", dict())]),
+    ({"FZB_WINDOW_WHOLE_TILES": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=3))]),  # the PRE window kernel as one 1024-thread workgroup per tile
     ({"FZB_DFA_WGS": "8"}, [("short", "deadbe", dict()), ("uni", "éa", dict())]),
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab
     ({"FZB_PARK_LDS_KB": "0", "FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),

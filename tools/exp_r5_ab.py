@@ -38,14 +38,14 @@ if "arabic" in which:
     da, ea = synth.arabic_corpus()
     cp = F.Corpus(packed=(da, ea))
     for mt in (1, 2):
-        for env in ({}, {"FZB_WINDOW_NO_PRE": "1"}):
+        for env in ({}, {"FZB_WINDOW_WHOLE_TILES": "1"}, {"FZB_WINDOW_NO_PRE": "1"}):
             timed(f"arabic-shaped 285k, max_typos={mt}", "إن" if mt == 1 else "إنما", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, int(len(ea)), env, steps=5)
     del cp
 if "paths" in which:
     dp, ep = synth.paths_corpus(b"linux", 1_406_941, device=dev)
     cp = F.Corpus(packed=(dp, ep))
     for mt in (1, 2, 3):
-        for env in ({}, {"FZB_WINDOW_NO_PRE": "1"}):
+        for env in ({}, {"FZB_WINDOW_WHOLE_TILES": "1"}, {"FZB_WINDOW_NO_PRE": "1"}):
             timed(f"paths-shaped 1.4M 'linux', max_typos={mt}", "linux", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, 1_406_941, env, steps=5)
     del cp
 if "long" in which:
