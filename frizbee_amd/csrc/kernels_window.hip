@@ -773,7 +773,10 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
     }
     // the PRE form (masks laid out ahead by the whole workgroup): one-pass launches of the typo algorithms over a corpus below 64 GiB;
     // the buffer takes what the device gives a workgroup beyond the kernel's 12.3 KB of static LDS (asked for once per instantiation)
-    if (one_pass && alg != ALG_UNI_0 && !fzb_knobs().window_no_pre && c.total_bytes < ((u64)1 << 36)) {
+    // (the quarter-tile form walks its units with a grid-stride loop: lists of any size; the whole-tile form keeps round 4's one-pass bound;
+    // FZB_WINDOW_FOUR_PASS=1 and FZB_WINDOW_NO_PRE=1 are the older forms)
+    const bool quarters_any = !decide && max_items != 0 && !fzb_knobs().window_whole_tiles && !fzb_knobs().window_four_pass;
+    if ((one_pass || quarters_any) && alg != ALG_UNI_0 && !fzb_knobs().window_no_pre && c.total_bytes < ((u64)1 << 36)) {
         static const size_t lds_max = [] {
             int dev = 0, v = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 64 * 1024;
@@ -788,7 +791,7 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 #define FZB_K2A_P(ALG)                                                                                                                                          \
     do {                                                                                                                                                        \
         if (quarters) {                                                                                                                                         \
-            hipLaunchKernelGGL((k2a_window_pre<PFL, ALG, 256>), dim3(std::max<u32>(1u, ntiles_max * 4u)), dim3(256), dyn, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, \
+            hipLaunchKernelGGL((k2a_window_pre<PFL, ALG, 256>), dim3(std::max<u32>(1u, std::min<u32>(ntiles_max * 4u, (u32)grid * 8u))), dim3(256), dyn, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, \
                                bitmap2, tile_counts2, (u32)(dyn / 8 / (size_t)std::max(nd.rows, 1)), (u32)fzb_knobs().window_dbg);                            \
             break;                                                                                                                                              \
         }                                                                                                                                                       \

@@ -45,12 +45,15 @@ def test_c2_c3_ten_million_len32(max_typos):
     _check("deadbe", rows.cpu().numpy().reshape(-1), ends, max_typos=max_typos)
 
 
-def test_c5_ten_million_utf8():
+@pytest.mark.parametrize("max_typos", [0, 1])
+def test_c5_ten_million_utf8(max_typos):
     # the UTF-8 generator is a host-side Python loop: 1 M distinct haystacks, tiled to the full 10 M
+    # (max_typos=1: the unicode typo path at full size - superset filter, then the reference's chunked multi-path prefilter at its exact lane
+    # width for every one of the ~1 M survivors: the window kernel's quarter-tile form with a grid-stride loop over ~4 000 units)
     data, ends = synth.utf8_corpus(1_000_000, 32)
     data = np.tile(data, 10)
     ends = np.arange(1, 10_000_001, dtype=np.uint64) * np.uint64(32)
-    _check("إنما", data, ends, max_typos=0)
+    _check("إنما", data, ends, max_typos=max_typos)
 
 
 def test_c4_one_shard_ragged():
