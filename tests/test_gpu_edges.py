@@ -221,3 +221,32 @@ def test_wrong_promises_about_borrowed_memory_are_refused(u64):
     finally:
         os.environ.pop("FZB_VERIFY_PROMISES", None)
         F.lib().fzb_debug_reload_knobs()
+
+
+@pytest.mark.parametrize("pf", [64, 16])
+def test_window_kernel_mask_buffer_overflow_and_long_walks(pf):
+    """The lane-exact window kernel's PRE form lays a quarter tile's (haystack, chunk) occurrence masks out in 40 KB of LDS; haystacks whose
+    pairs do not fit compute their masks on demand inside the walk.  Long haystacks (600..1000 bytes = 10..16 chunks of 64, 38..63 of 16) with
+    a 7-row and a 2-scalar needle make most of every part overflow; short ones in between keep the laid-out path busy in the same workgroup.
+    ASCII and unicode, 1 / 2 / 3 typos, against the oracle."""
+    rng = np.random.default_rng(900 + pf)
+    alpha = b"deadbfxyz_-/ 01DEAB"
+    hs = []
+    for i in range(5000):
+        L = int(rng.integers(600, 1001)) if i % 3 else int(rng.integers(0, 90))
+        body = bytearray(alpha[int(x)] for x in rng.integers(0, len(alpha), L))
+        if rng.random() < 0.5 and L >= 7:
+            for q, ch in zip(sorted(rng.choice(L, size=7, replace=False).tolist()), b"deadbef"):
+                body[q] = ch
+        hs.append(bytes(body))
+    cp = F.Corpus(hs)
+    lanes = {64: (64, 64, 32), 16: (16, 16, 8)}[pf]
+    for needle, typos in (("deadbef", 1), ("deadbef", 2), ("deadbef", 3), ("da", 1)):
+        want = O.Matcher(needle, lanes=lanes, max_typos=typos).match_list(hs)
+        got = F.Matcher(needle, F.Config(max_typos=typos, pf_lanes=pf)).match_list(cp)
+        assert got.tolist() == want.tolist() and len(want) > 100, (needle, typos, pf, len(got), len(want))
+    uni = ["".join("éaxüñ_ "[int(x)] for x in rng.integers(0, 7, int(rng.integers(300, 700)) if i % 2 else int(rng.integers(0, 40)))) for i in range(3000)]
+    for needle, typos in (("éa", 1), ("éañ", 2)):
+        want = O.Matcher(needle, lanes=lanes, max_typos=typos).match_list(uni)
+        got = F.Matcher(needle, F.Config(max_typos=typos, pf_lanes=pf)).match_list(uni)
+        assert got.tolist() == want.tolist() and len(want) > 100, (needle, typos, pf)
