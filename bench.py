@@ -646,6 +646,7 @@ def main():
     fence()
     st = m.last_stage_timings_ms()
     m.set_profiling(False)
+    counters = m.last_counters()  # (of a full step: the untimed checks further down query sub-ranges)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -715,7 +716,6 @@ def main():
                 e2e_multi["merged_equals_oracle_list"] = bool(merged2.tolist() == want_all.tolist())
         c4_total = args.c4_total if args.c4_total >= 0 else (100_000_000 if world > 1 else 0)
         c4_row = c4_sharded_block(F, synth, dist, dev, rank, world, c4_total, max(3, min(10, args.steps)), stream) if c4_total else None
-    counters = m.last_counters()
     if rank == 0:
         total = n * world
         # algorithmic bytes of one filter launch (this rank's shard): payload once + 1 decision bit per haystack (no end offsets: uniform length)
