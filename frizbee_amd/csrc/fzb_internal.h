@@ -75,14 +75,15 @@ struct CorpusDev {
     // otherwise; every other stage reads the canonical layout).  What bounds the thread-per-haystack filter on such a list is the access
     // pattern itself - 64 lanes x 16 bytes from 64 different lines per load instruction: 215 us for the 0.9 GB of the C4 shard with the
     // automaton switched off (FZB_CDFA_NODFA=1) - so the view stores the bytes the way the lanes read them:
-    //   * every 1024-haystack tile sorted by DESCENDING number of 16-byte vectors (vperm[p] = position inside its tile the haystack at
+    //   * every 1024-haystack tile sorted by DESCENDING length (round 5; rounds 3-4: by number of 16-byte vectors) (vperm[p] = position inside its tile the haystack at
     //     sorted position p came from, vlen[p] = its length);
     //   * every GROUP of 64 consecutive sorted haystacks (one wave's worth) interleaved by vector: vector v of the group's member j lives
     //     at vbytes + 16 * vgofs[group] + 1024 * v + 16 * j, for v < vgnv[group] = the group's longest member (zero vectors behind a
     //     shorter one) - so a wave's load of "vector v of my haystack" is ONE fully coalesced 1 KiB access, like a copy kernel's.
     const u8* vbytes;
     const u32* vgofs;  // per group: offset of its block in 16-byte units
-    const u8* vgnv;    // per group: vectors per member (<= 16)
+    const u8* vgnv;    // per group: vectors per member (<= 16) | (bytes per member in the LAST vector's row / 4 - 1) << 5: rows 0 .. nv-2 are 1 KiB (16 B per
+                       // member), the last row holds 4 / 8 / 12 / 16 bytes per member - as narrow as the group's longest member's tail allows (round 5)
     const u16* vlen;   // per sorted haystack
     const u16* vperm;  // per sorted haystack
     u32 view_nv;       // the view's widest member in 16-byte vectors (<= 16): read from the lengths when the view is built, not a caller's hint

@@ -186,17 +186,21 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_build(const u8* __restrict__ 
 //   (k_up_scan: exclusive scan of the tile sizes - the same kernel the canonical layout uses)
 //   k_up_view_fill   writes the groups' block offsets and copies every vector to its interleaved position (the buffer was cleared: the
 //                    zero vectors behind a group's shorter members are already there)
-#define FV_CLASSES 18  // vector counts 0..16 (haystacks up to 256 bytes) and a guard class
+#define FV_CLASSES 258  // sort key = the haystack's LENGTH, 0..256 bytes (round 5; rounds 3-4: its vector count, 18 classes), and a guard class
+// Round 5: a group's LAST vector row is stored as narrow as its longest member's tail allows - 4, 8, 12 or 16 bytes per member instead of 16
+// (vgnv[group] = vectors per member | (tail bytes / 4 - 1) << 5) - and the tile is sorted by exact length, so that the 64 members of a group end
+// within a few bytes of each other: the view of the C4 shard shrinks from 1.19 to 1.12 x the haystack bytes (padded-16 alone costs 1.106).
 template <typename ET>
 __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restrict__ ends, u64 n, u16* __restrict__ vperm, u16* __restrict__ vlen, u8* __restrict__ vgnv,
                                                              u64* __restrict__ tile_units, UpStats* __restrict__ stats, u32* __restrict__ vlong, u32 long_cap) {
     __shared__ u32 s_len[UP_TILE];
     __shared__ u16 s_inv[UP_TILE];
     __shared__ u32 s_hist[FV_CLASSES], s_base[FV_CLASSES];
+    __shared__ u32 s_gunits[UP_TILE / 64];
     const u64 i0 = (u64)blockIdx.x * UP_TILE;
     const u32 nt = (u32)min((u64)UP_TILE, n - i0);
     const int tid = threadIdx.x;
-    if (tid < FV_CLASSES) s_hist[tid] = 0;
+    for (int c = tid; c < FV_CLASSES; c += UP_THREADS) s_hist[c] = 0;
     __syncthreads();
     u32 cls[4], rk[4];
 #pragma unroll
@@ -212,20 +216,20 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restric
                 len = 0xFFFFu;
             }
             s_len[j] = len;
-            cls[k] = len == 0xFFFFu ? 0u : min((len + 15u) >> 4, (u32)FV_CLASSES - 1);
+            cls[k] = len == 0xFFFFu ? 0u : min(len, (u32)FV_CLASSES - 1);
             rk[k] = atomicAdd(&s_hist[cls[k]], 1u);
         }
     }
     __syncthreads();
-    if (tid == 0) {  // descending: the longest class first
+    if (tid == 0) {  // descending: the longest haystacks first
         u32 run = 0, top = 0, low = FV_CLASSES;
         for (int c = FV_CLASSES - 1; c >= 0; c--) {
             s_base[c] = run;
             run += s_hist[c];
             if (s_hist[c]) { top = max(top, (u32)c); low = min(low, (u32)c); }
         }
-        atomicMax((unsigned long long*)&stats->max_len, (unsigned long long)top);  // in VECTORS here: the view's widest / narrowest member
-        atomicMin((unsigned long long*)&stats->min_len, (unsigned long long)low);
+        atomicMax((unsigned long long*)&stats->max_len, (unsigned long long)((top + 15u) >> 4));  // in VECTORS: the view's widest / narrowest member
+        atomicMin((unsigned long long*)&stats->min_len, (unsigned long long)((low + 15u) >> 4));
     }
     __syncthreads();
 #pragma unroll
@@ -243,17 +247,19 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restric
             vlen[i0 + p] = (u16)s_len[j];
         }
     }
-    if (tid < UP_TILE / 64) {  // the tile's 16 groups: vectors per member = the group's first (longest) member's count
+    if (tid < UP_TILE / 64) {  // the tile's 16 groups: vectors per member and tail width = the group's first (longest) member's
         const u32 p0 = tid * 64;
         const u32 l0 = p0 < nt ? s_len[s_inv[p0]] : 0u;
-        const u32 nv = l0 == 0xFFFFu ? 0u : (l0 + 15u) >> 4;
-        vgnv[i0 / 64 + tid] = (u8)nv;
-        s_base[tid] = nv * 64;  // 16-byte units of the group's block (FV_CLASSES >= 16 entries)
+        const u32 len0 = l0 == 0xFFFFu ? 0u : l0;
+        const u32 nv = (len0 + 15u) >> 4;
+        const u32 tw = nv ? ((len0 - 16u * (nv - 1) + 3u) & ~3u) : 0u;  // 4, 8, 12 or 16 bytes of the last vector are stored per member
+        vgnv[i0 / 64 + tid] = (u8)(nv ? (nv | ((tw / 4 - 1) << 5)) : 0u);
+        s_gunits[tid] = nv ? (nv - 1) * 64 + tw * 4 : 0u;  // 16-byte units of the group's block: nv - 1 rows of 1 KiB + 64 tails of tw bytes
     }
     __syncthreads();
     if (tid == 0) {
         u64 t = 0;
-        for (int g = 0; g < UP_TILE / 64; g++) t += s_base[g];
+        for (int g = 0; g < UP_TILE / 64; g++) t += s_gunits[g];
         tile_units[blockIdx.x] = t;
     }
 }
@@ -261,28 +267,43 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_sort(const ET* __restric
 template <typename ET>
 __global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 n, const u16* __restrict__ vperm,
                                                              const u8* __restrict__ vgnv, const u64* __restrict__ tile_base_units, u8* __restrict__ vbytes, u32* __restrict__ vgofs) {
-    __shared__ u32 s_gofs[UP_TILE / 64];
+    __shared__ u32 s_gofs[UP_TILE / 64], s_gnv[UP_TILE / 64], s_gtw[UP_TILE / 64];
     const u64 i0 = (u64)blockIdx.x * UP_TILE;
     const u32 nt = (u32)min((u64)UP_TILE, n - i0);
     const int tid = threadIdx.x;
     if (tid == 0) {
         u64 run = tile_base_units[blockIdx.x];
         for (int g = 0; g < UP_TILE / 64; g++) {
+            const u32 code = vgnv[i0 / 64 + g], nv = code & 31u, tw = nv ? ((code >> 5) + 1u) * 4u : 0u;
             s_gofs[g] = (u32)run;
+            s_gnv[g] = nv;
+            s_gtw[g] = tw;
             vgofs[i0 / 64 + g] = (u32)run;
-            run += (u64)vgnv[i0 / 64 + g] * 64;
+            run += nv ? (u64)(nv - 1) * 64 + (u64)tw * 4 : 0;
         }
     }
     __syncthreads();
-    // four threads per sorted haystack, each copying every fourth vector
+    // four threads per sorted haystack, each copying every fourth vector; the group's last row holds `tw` bytes per member
     for (u32 p = tid >> 2; p < nt; p += UP_THREADS / 4) {
         const u64 j = i0 + vperm[i0 + p];
         const ET st = j ? (ends[j - 1] + (ET)15) & ~(ET)15 : (ET)0;
         if (ends[j] - st > (ET)256) continue;  // an outlier has no vectors in the view
         const u32 nv = (u32)((ends[j] - st + (ET)15) >> 4);
+        const u32 gnv = s_gnv[p >> 6], gtw = s_gtw[p >> 6];
         const uint4* src = (const uint4*)(bytes + st);
-        uint4* dst = (uint4*)(vbytes + (size_t)s_gofs[p >> 6] * 16 + (size_t)(p & 63) * 16);
-        for (u32 v = tid & 3; v < nv; v += 4) dst[(size_t)v * 64] = src[v];
+        u8* gblock = vbytes + (size_t)s_gofs[p >> 6] * 16;
+        for (u32 v = tid & 3; v < nv; v += 4) {
+            const uint4 q = src[v];
+            if (v + 1 < gnv) {
+                *(uint4*)(gblock + (size_t)v * 1024 + (size_t)(p & 63) * 16) = q;
+            } else {  // (a member as long in vectors as its group's longest: its last vector goes to the narrow row; bytes beyond `gtw` are zero)
+                u32* dst = (u32*)(gblock + (size_t)(gnv - 1) * 1024 + (size_t)(p & 63) * gtw);
+                dst[0] = q.x;
+                if (gtw > 4) dst[1] = q.y;
+                if (gtw > 8) dst[2] = q.z;
+                if (gtw > 12) dst[3] = q.w;
+            }
+        }
     }
 }
 

@@ -38,6 +38,26 @@ __device__ __forceinline__ u32 load_u32_unaligned(const u8* __restrict__ base, u
     return __builtin_amdgcn_alignbyte(hi, lo, (u32)(p & 3));
 }
 
+// 4 / 8 / 12 bytes of a once-read stream (the narrow tail rows of the filter view: lane * width, so 8 bytes are 8-aligned and 12 bytes only
+// 4-aligned), with or without the non-temporal hint; the upper dwords of the result are zero
+__device__ __forceinline__ uint4 load_narrow_stream(const u8* p, u32 width, bool nt) {
+    typedef u32 v2u __attribute__((ext_vector_type(2)));
+    typedef u32 v3u4 __attribute__((ext_vector_type(3), aligned(4)));
+    uint4 r = make_uint4(0, 0, 0, 0);
+#ifndef FZB_HOST_SHIM
+    if (nt) {
+        if (width == 12) { const v3u4 t = __builtin_nontemporal_load((const v3u4*)p); r.x = t.x; r.y = t.y; r.z = t.z; }
+        else if (width == 8) { const v2u t = __builtin_nontemporal_load((const v2u*)p); r.x = t.x; r.y = t.y; }
+        else r.x = __builtin_nontemporal_load((const u32*)p);
+        return r;
+    }
+#endif
+    if (width == 12) { const v3u4 t = *(const v3u4*)p; r.x = t.x; r.y = t.y; r.z = t.z; }
+    else if (width == 8) { const v2u t = *(const v2u*)p; r.x = t.x; r.y = t.y; }
+    else r.x = *(const u32*)p;
+    return r;
+}
+
 // A 16-byte load of data that is read ONCE by a streaming kernel: the non-temporal hint keeps the stream from displacing what later
 // stages re-read from the caches (measured on the view filter: 190 -> 183 us on the C4 shard).
 template <bool NT>

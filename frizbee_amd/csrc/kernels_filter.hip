@@ -595,19 +595,30 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
             const u32 p = tile * FZB_TILE + (u32)(gi * 4 + wave) * 64 + lane;  // sorted position (relative to `first`)
             const u32 gl = tile * (FZB_TILE / 64) + (u32)(gi * 4 + wave);       // its group
             if (gl * 64 >= count) continue;
-            const u32 nv = __builtin_amdgcn_readfirstlane((u32)vgnv[g_first + gl]);
-            const u8* base = vbytes + (size_t)__builtin_amdgcn_readfirstlane(vgofs[g_first + gl]) * 16 + (u32)lane * 16;
+            // vgnv: vectors per member | (bytes stored per member of the LAST row / 4 - 1) << 5 (round 5: the group's last row is as narrow as
+            // its longest member's tail allows - 4, 8, 12 or 16 bytes per lane, a contiguous 256..1024 bytes for the wave)
+            const u32 code = __builtin_amdgcn_readfirstlane((u32)vgnv[g_first + gl]);
+            const u32 nv = code & 31u, tw = ((code >> 5) + 1u) * 4u;
+            const u8* gblock = vbytes + (size_t)__builtin_amdgcn_readfirstlane(vgofs[g_first + gl]) * 16;
+            const u8* base = gblock + (u32)lane * 16;
             u32 hl = 0, orig = 0;
             if (p < count) { hl = LEN ? (u32)vlen[first + p] : 0u; orig = vperm[first + p]; }
             uint4 q[NV];
+            uint4 tail = make_uint4(0, 0, 0, 0);
+            if (nv) {  // (wave-uniform width: one load instruction of the width the group was stored with)
+                const u8* tp = gblock + (size_t)(nv - 1) * 1024 + (size_t)lane * tw;
+                const bool nt_ = (stage_dbg & 8) != 0;
+                if (tw == 16) tail = nt_ ? load16_stream<true>((const uint4*)tp) : *(const uint4*)tp;
+                else tail = load_narrow_stream(tp, tw, nt_);
+            }
             // (non-temporal: a wave's load covers whole lines that nothing reads again - the stream no longer displaces what the later stages
             // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison)
             if (stage_dbg & 8) {
 #pragma unroll
-                for (int k = 0; k < NV; k++) q[k] = (u32)k < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
             } else {
 #pragma unroll
-                for (int k = 0; k < NV; k++) q[k] = (u32)k < nv ? *(const uint4*)(base + (size_t)k * 1024) : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? *(const uint4*)(base + (size_t)k * 1024) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
             }
             u32 st = 0;
 #pragma unroll
