@@ -198,7 +198,6 @@ FzbKnobs parse_knobs() {
     k.dfa_wgs = std::max(1, std::min(8, num("FZB_DFA_WGS", 8)));
     k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
     k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
-    k.view_groups_max_tiles = std::max(0, num("FZB_VIEW_GROUPS_MAX_TILES", 4096));
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
     k.verify_promises = num("FZB_VERIFY_PROMISES", 1) != 0;
     k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");

@@ -557,84 +557,6 @@ __global__ __launch_bounds__(256) void k1_cdfa_ragged(const u8* __restrict__ byt
 // tile's header, one entry per survivor in index order - the order of the survivor list, so k2w_classify finds survivor j's entry at
 // rank(j) - survivors-before-its-tile.  What the classifier and the scorers then read is ~ 4 KB of contiguous lines per tile instead of
 // 49 haystacks spread over 80 KB of the corpus (140 MB of cold lines for 43 MB of survivor bytes on the C4 shard).
-// One GROUP of the view (64 haystacks, interleaved by vector) on one wave: the group's loads issued back to back, then the class-composite
-// automaton over the vectors the lane holds.  Returns the automaton's final state; `q` keeps the lane's vectors (the staging form stores
-// them), `hl` / `orig` are the lane's length (LEN) and its position inside its tile.  Shared by the tile-per-workgroup kernel and the
-// group-per-wave kernel of small lists.
-template <bool SAN, int G, int NV, bool LEN>
-__device__ __forceinline__ u32 cdfa_view_group(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
-                                               const u16* __restrict__ vperm, u64 first, u32 count, u64 g_first, u32 gl, u32 p, int lane, u32 K, u32 KG, u32 deadv,
-                                               u32 stage_dbg, uint4 (&q)[NV], u32& hl, u32& orig) {
-    auto cls_of = [](u32 b) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)b; };
-    auto comp_at = [](u32 a) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)(256u + a); };
-    // vgnv: vectors per member | (bytes stored per member of the LAST row / 4 - 1) << 5 (round 5: the group's last row is as narrow as
-    // its longest member's tail allows - 4, 8, 12 or 16 bytes per lane, a contiguous 256..1024 bytes for the wave)
-    const u32 code = __builtin_amdgcn_readfirstlane((u32)vgnv[g_first + gl]);
-    const u32 nv = code & 31u, tw = ((code >> 5) + 1u) * 4u;
-    const u8* gblock = vbytes + (size_t)__builtin_amdgcn_readfirstlane(vgofs[g_first + gl]) * 16;
-    const u8* base = gblock + (u32)lane * 16;
-    hl = 0;
-    orig = 0;
-    if (p < count) { hl = LEN ? (u32)vlen[first + p] : 0u; orig = vperm[first + p]; }
-    uint4 tail = make_uint4(0, 0, 0, 0);
-    if (nv) {  // (wave-uniform width: one load instruction of the width the group was stored with)
-        const u8* tp = gblock + (size_t)(nv - 1) * 1024 + (size_t)lane * tw;
-        const bool nt_ = (stage_dbg & 8) != 0;
-        if (tw == 16) tail = nt_ ? load16_stream<true>((const uint4*)tp) : *(const uint4*)tp;
-        else tail = load_narrow_stream(tp, tw, nt_);
-    }
-    // (non-temporal: a wave's load covers whole lines that nothing reads again - the stream no longer displaces what the later stages
-    // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison)
-    if (stage_dbg & 8) {
-#pragma unroll
-        for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? *(const uint4*)(base + (size_t)k * 1024) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
-    }
-    u32 st = 0;
-#pragma unroll
-    for (int k = 0; k < NV; k++) {
-        if ((u32)k >= nv) continue;  // wave-uniform
-        u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
-        if (K == 0xFFFFu) {  // measurement knob (FZB_CDFA_NODFA=1, results meaningless): the loads alone
-            st ^= w[0] ^ w[1] ^ w[2] ^ w[3];
-            continue;
-        }
-        if (SAN) {
-            const u32 rem = hl > 16u * k ? hl - 16u * k : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
-                const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
-                w[j] = (w[j] & mask) | (deadv & ~mask);
-            }
-        }
-        u32 c[4][4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            c[j][0] = cls_of(w[j] & 0xFF);
-            c[j][1] = cls_of((w[j] >> 8) & 0xFF);
-            c[j][2] = cls_of((w[j] >> 16) & 0xFF);
-            c[j][3] = cls_of(w[j] >> 24);
-        }
-        if (G == 4) {
-            u32 off[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) off[j] = c[j][0] + K * (c[j][1] + K * (c[j][2] + K * c[j][3]));
-#pragma unroll
-            for (int j = 0; j < 4; j++) st = comp_at(st * KG + off[j]);
-        } else {
-            u32 off[8];
-#pragma unroll
-            for (int j = 0; j < 4; j++) off[2 * j] = c[j][0] + K * c[j][1], off[2 * j + 1] = c[j][2] + K * c[j][3];
-#pragma unroll
-            for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);
-        }
-    }
-    return st;
-}
-
 // LEN: the kernel reads the haystacks' lengths (vlen: 2 of the view's ~83 bytes per haystack on the C4 shard).  They are needed to sanitise a
 // last vector (SAN), for the stage's header (STAGE), to skip an outlier's lane (0xFFFF) and for `length >= min_len` - but with the zero fill
 // harmless (!SAN) an outlier's lane holds zero vectors and cannot leave state 0, and every automaton the view kernel runs accepts only
@@ -673,9 +595,71 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
             const u32 p = tile * FZB_TILE + (u32)(gi * 4 + wave) * 64 + lane;  // sorted position (relative to `first`)
             const u32 gl = tile * (FZB_TILE / 64) + (u32)(gi * 4 + wave);       // its group
             if (gl * 64 >= count) continue;
+            // vgnv: vectors per member | (bytes stored per member of the LAST row / 4 - 1) << 5 (round 5: the group's last row is as narrow as
+            // its longest member's tail allows - 4, 8, 12 or 16 bytes per lane, a contiguous 256..1024 bytes for the wave)
+            const u32 code = __builtin_amdgcn_readfirstlane((u32)vgnv[g_first + gl]);
+            const u32 nv = code & 31u, tw = ((code >> 5) + 1u) * 4u;
+            const u8* gblock = vbytes + (size_t)__builtin_amdgcn_readfirstlane(vgofs[g_first + gl]) * 16;
+            const u8* base = gblock + (u32)lane * 16;
+            u32 hl = 0, orig = 0;
+            if (p < count) { hl = LEN ? (u32)vlen[first + p] : 0u; orig = vperm[first + p]; }
             uint4 q[NV];
-            u32 hl, orig;
-            const u32 st = cdfa_view_group<SAN, G, NV, LEN>(vbytes, vgofs, vgnv, vlen, vperm, first, count, g_first, gl, p, lane, K, KG, deadv, stage_dbg, q, hl, orig);
+            uint4 tail = make_uint4(0, 0, 0, 0);
+            if (nv) {  // (wave-uniform width: one load instruction of the width the group was stored with)
+                const u8* tp = gblock + (size_t)(nv - 1) * 1024 + (size_t)lane * tw;
+                const bool nt_ = (stage_dbg & 8) != 0;
+                if (tw == 16) tail = nt_ ? load16_stream<true>((const uint4*)tp) : *(const uint4*)tp;
+                else tail = load_narrow_stream(tp, tw, nt_);
+            }
+            // (non-temporal: a wave's load covers whole lines that nothing reads again - the stream no longer displaces what the later stages
+            // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison)
+            if (stage_dbg & 8) {
+#pragma unroll
+                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? *(const uint4*)(base + (size_t)k * 1024) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
+            }
+            u32 st = 0;
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if ((u32)k >= nv) continue;  // wave-uniform
+                u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+                if (K == 0xFFFFu) {  // measurement knob (FZB_CDFA_NODFA=1, results meaningless): the loads alone
+                    st ^= w[0] ^ w[1] ^ w[2] ^ w[3];
+                    continue;
+                }
+                if (SAN) {
+                    const u32 rem = hl > 16u * k ? hl - 16u * k : 0u;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
+                        const u32 mask = nvb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nvb)) - 1);
+                        w[j] = (w[j] & mask) | (deadv & ~mask);
+                    }
+                }
+                u32 c[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    c[j][0] = cls_of(w[j] & 0xFF);
+                    c[j][1] = cls_of((w[j] >> 8) & 0xFF);
+                    c[j][2] = cls_of((w[j] >> 16) & 0xFF);
+                    c[j][3] = cls_of(w[j] >> 24);
+                }
+                if (G == 4) {
+                    u32 off[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) off[j] = c[j][0] + K * (c[j][1] + K * (c[j][2] + K * c[j][3]));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) st = comp_at(st * KG + off[j]);
+                } else {
+                    u32 off[8];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) off[2 * j] = c[j][0] + K * c[j][1], off[2 * j + 1] = c[j][2] + K * c[j][3];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);
+                }
+            }
             if (p < count && (!LEN || (hl != 0xFFFFu && hl >= min_len)) && st >= acc_lo) {  // (0xFFFF: an outlier beyond 256 bytes - k1_cdfa_outliers decides it)
                 atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
                 if (STAGE) {
@@ -753,49 +737,6 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
         __syncthreads();
         if (tid == 0) tile_counts[tile] = s_cnt;
         __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Small lists (round 5): ONE GROUP PER WAVE.  In k1_cdfa_view a workgroup owns a tile and each of its four waves walks four groups one after
-// the other - on a list of a few hundred tiles (Arabic-shaped: 279, paths-shaped: 1 374) every workgroup has ONE tile and the kernel lasts as
-// long as that chain of four load-and-scan rounds (21-31 us whatever the chip does around it) on a fraction of its wave slots.  Here the list's
-// groups are dealt out to waves (grid-stride, four independent waves per workgroup, no barrier after the table load): sixteen times the
-// parallelism of the one chain.  A tile's bits then come from up to sixteen waves: accepting lanes OR their bit into the (zeroed) bitmap and
-// the wave adds its count to the tile's (zeroed) count - ~ 5 % of the lanes, a few atomics per wave.  k_zero_filter_out clears both arrays
-// in front of it (one small launch).  Everything behind the filter sees the same bitmap and counts.
-// ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_zero_filter_out(u64* __restrict__ bitmap, u32 nwords, u32* __restrict__ tile_counts, u32 ntiles) {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    for (u32 k = i; k < nwords; k += stride) bitmap[k] = 0;
-    for (u32 k = i; k < ntiles; k += stride) tile_counts[k] = 0;
-}
-
-template <bool SAN, int G, int NV, bool LEN>
-__global__ __launch_bounds__(256) void k1_cdfa_view_groups(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
-                                                           const u16* __restrict__ vperm, u64 first, u32 count, const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG,
-                                                           u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts,
-                                                           u32* __restrict__ reset_counters, u32 stage_dbg) {
-    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
-    extern __shared__ __attribute__((aligned(16))) u8 lds[];
-    const u32 tab_bytes = (cdfa_bytes + 15u) & ~15u;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    dfa_require_lds_base0(lds);
-    for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
-    __syncthreads();
-    const u32 ngroups = (count + 63) / 64;
-    const u32 deadv = dead * 0x01010101u;
-    const u64 g_first = first / 64;  // `first` is a multiple of the tile size
-    for (u32 gl = blockIdx.x * 4 + (u32)wave; gl < ngroups; gl += gridDim.x * 4) {
-        const u32 p = gl * 64 + (u32)lane;  // sorted position (relative to `first`)
-        uint4 q[NV];
-        u32 hl, orig;
-        const u32 st = cdfa_view_group<SAN, G, NV, LEN>(vbytes, vgofs, vgnv, vlen, vperm, first, count, g_first, gl, p, lane, K, KG, deadv, stage_dbg, q, hl, orig);
-        const bool accepted = p < count && (!LEN || (hl != 0xFFFFu && hl >= min_len)) && st >= acc_lo;  // (0xFFFF: an outlier - k1_cdfa_outliers decides it)
-        const u32 tile = gl / (FZB_TILE / 64);
-        if (accepted) atomicOr((unsigned long long*)&bitmap[(size_t)tile * (FZB_TILE / 64) + (orig >> 6)], 1ull << (orig & 63));
-        const u64 b = __ballot(accepted);
-        if (lane == 0 && b) atomicAdd(&tile_counts[tile], (u32)__popcll(b));
     }
 }
 
@@ -1192,23 +1133,6 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
                 if (kn.cdfa_nodfa) cdfa_K = 0xFFFF;
                 // (the lengths are not read when nothing needs them: acc >= 1 = the start state does not accept; FZB_VIEW_READ_LEN=1 compares)
                 const bool len_free = nul_safe && acc >= 1 && !kn.view_read_len;
-                // small lists (fewer tiles than FZB_VIEW_GROUPS_MAX_TILES, default 4096; 0: never): a group per wave (k1_cdfa_view_groups)
-                const bool groups = !stg && kn.view_groups_max_tiles > 0 && ntiles < (u32)kn.view_groups_max_tiles;
-                if (groups) {
-                    const u32 nwords = ntiles * (FZB_TILE / 64), ngroups = (count + 63) / 64;
-                    hipLaunchKernelGGL(k_zero_filter_out, dim3(std::max<u32>(1u, std::min<u32>((nwords + 255) / 256, 256u))), dim3(256), 0, st, bitmap, nwords, tile_counts, ntiles);
-                    const int gg = (int)std::max<u32>(1u, std::min<u32>((ngroups + 3) / 4, (u32)grid));
-                    const size_t lds_g = (cdfa_bytes + 15) & ~(size_t)15;
-#define FZB_K1G(SAN, G, NV, LEN) hipLaunchKernelGGL((k1_cdfa_view_groups<SAN, G, NV, LEN>), dim3(gg), dim3(256), lds_g, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, (u32)(kn.view_plain_loads ? 0u : 8u))
-#define FZB_K1G_L(SAN, G, NV) do { if (!SAN && len_free) FZB_K1G(SAN, G, NV, false); else FZB_K1G(SAN, G, NV, true); } while (0)
-#define FZB_K1G_NV(SAN, G) do { if (c.view_nv <= 8) FZB_K1G_L(SAN, G, 8); else FZB_K1G_L(SAN, G, 16); } while (0)
-#define FZB_K1G_G(SAN) do { if (cdfa_G == 4) FZB_K1G_NV(SAN, 4); else FZB_K1G_NV(SAN, 2); } while (0)
-                    if (nul_safe) FZB_K1G_G(false); else FZB_K1G_G(true);
-#undef FZB_K1G_G
-#undef FZB_K1G_NV
-#undef FZB_K1G_L
-#undef FZB_K1G
-                } else {
 #define FZB_K1VN(SAN, G, NV) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, false, false>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, (u8*)nullptr, (u32*)nullptr, (u32)kn.stage_dbg | (kn.view_plain_loads ? 0u : 8u))
 #define FZB_K1V(SAN, G, NV, STG) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, STG>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, stg ? so->stage : nullptr, stg ? so->hdr : nullptr, (u32)kn.stage_dbg | (kn.view_plain_loads ? 0u : 8u))
 #define FZB_K1V_S(SAN, G, NV) do { if (stg) FZB_K1V(SAN, G, NV, true); else if (!SAN && len_free) FZB_K1VN(SAN, G, NV); else FZB_K1V(SAN, G, NV, false); } while (0)
@@ -1220,7 +1144,6 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
 #undef FZB_K1V_S
 #undef FZB_K1V
 #undef FZB_K1VN
-                }
                 if (c.n_long) {  // the haystacks beyond 256 bytes: decided from the canonical layout, OR-ed into the view kernel's bitmap
                     const u32 ns_o = (cdfa_bytes - 256u) / kg;  // the automaton's states (the table is padded to 16 bytes: at most a phantom state more)
                     const u32 wpw = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)4 * 64 * ns_o + 16 <= 60 * 1024 ? 4u : 1u;

@@ -32,7 +32,6 @@ struct FzbKnobs {
     bool view_plain_loads = false;   // FZB_VIEW_PLAIN_LOADS=1 the view filter's loads without the non-temporal hint
     bool verify_promises = true;     // FZB_VERIFY_PROMISES=0  fzb_corpus_set_uniform_len / _set_max_len on BORROWED memory accepted without the device pass over the end offsets
     int shard_inline = -1;           // FZB_SHARD_INLINE=0|1   multi-device query, shards on the root device: 0 = through the worker threads, 1 = enqueued by the caller
-    int view_groups_max_tiles = 4096;  // FZB_VIEW_GROUPS_MAX_TILES lists of fewer 1024-haystack tiles run the view filter as one group per wave (k1_cdfa_view_groups); 0: never
     int handoff_min_tiles = 4096;    // FZB_HANDOFF_MIN_TILES  the handoff only for lists of at least this many 1024-haystack tiles (0: always)
     int unicode_multi = -1;          // FZB_UNICODE_MULTI=0|1  unicode windows of 65..1024 bytes: never / always thread per haystack (k2u_dp_unicode_multi); default: by the queue's length
     int generic_wgs = 12;            // FZB_GENERIC_WGS        workgroups per CU of the wave-per-haystack kernel over a queue of wide unicode windows

@@ -77,8 +77,6 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_WINDOW_NO_PRE": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=2)), ("uni", "éa", dict(max_typos=1))]),  # the window kernel's threads compute their own masks (round 4's one-pass form)
     ({"FZB_HANDOFF_MIN_TILES": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "DeadBeef", dict())]),  # the handoff on a small list (default: big lists only)
     ({"FZB_HANDOFF_MIN_TILES": "0", "FZB_VIEW_PLAIN_LOADS": "1"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_VIEW_GROUPS_MAX_TILES": "0"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict())]),  # the view filter as a tile per workgroup on a small list too (big lists' form)
-    ({"FZB_VIEW_GROUPS_MAX_TILES": "0", "FZB_VIEW_READ_LEN": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_VIEW_READ_LEN": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict())]),  # the view filter reads the lengths it does not need (round 4's form)
     ({"FZB_NO_CDFA": "1"}, [("ragged", "deadbeef", dict())]),                         # the burst filter over the byte automaton
     ({"FZB_NO_CDFA": "1", "FZB_RAGGED_BURST": "0"}, [("ragged", "deadbeef", dict())]),  # ... and its rolling form
