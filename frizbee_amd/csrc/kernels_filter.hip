@@ -612,25 +612,25 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
                 else tail = load_narrow_stream(tp, tw, nt_);
             }
             // (non-temporal: a wave's load covers whole lines that nothing reads again - the stream no longer displaces what the later stages
-            // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison)
+            // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison).  The FULL rows land in q[0 .. nv-2]; the narrow last row stays
+            // in `tail` and is the automaton's last step (selecting it into q[nv-1] cost a chain of scalar branches and a full wait per vector)
             if (stage_dbg & 8) {
 #pragma unroll
-                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : make_uint4(0, 0, 0, 0);
             } else {
 #pragma unroll
-                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? *(const uint4*)(base + (size_t)k * 1024) : (u32)k + 1 == nv ? tail : make_uint4(0, 0, 0, 0);
+                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? *(const uint4*)(base + (size_t)k * 1024) : make_uint4(0, 0, 0, 0);
             }
             u32 st = 0;
-#pragma unroll
-            for (int k = 0; k < NV; k++) {
-                if ((u32)k >= nv) continue;  // wave-uniform
-                u32 w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+            // one vector of the lane's haystack through the class-composite automaton (vector index kk: only the sanitising form needs it)
+            auto step = [&](const uint4& v, u32 kk) {
+                u32 w[4] = {v.x, v.y, v.z, v.w};
                 if (K == 0xFFFFu) {  // measurement knob (FZB_CDFA_NODFA=1, results meaningless): the loads alone
                     st ^= w[0] ^ w[1] ^ w[2] ^ w[3];
-                    continue;
+                    return;
                 }
                 if (SAN) {
-                    const u32 rem = hl > 16u * k ? hl - 16u * k : 0u;
+                    const u32 rem = hl > 16u * kk ? hl - 16u * kk : 0u;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
                         const u32 nvb = rem > 4u * j ? rem - 4u * j : 0u;
@@ -659,6 +659,17 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
 #pragma unroll
                     for (int j = 0; j < 8; j++) st = comp_at(st * KG + off[j]);
                 }
+            };
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                if ((u32)k + 1 >= nv) continue;  // wave-uniform
+                step(q[k], (u32)k);
+            }
+            if (nv) step(tail, nv - 1);
+            if (STAGE) {  // (the staging form stores the lane's vectors: the last one joins them)
+#pragma unroll
+                for (int k = 0; k < NV; k++)
+                    if ((u32)k + 1 == nv) q[k] = tail;
             }
             if (p < count && (!LEN || (hl != 0xFFFFu && hl >= min_len)) && st >= acc_lo) {  // (0xFFFF: an outlier beyond 256 bytes - k1_cdfa_outliers decides it)
                 atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
