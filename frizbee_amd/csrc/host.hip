@@ -1323,7 +1323,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     // most once by its scorer (front + back <= cnt), and the thread-per-haystack unicode scorer may hand up to 4096 of the front's windows on
     // to the back WHILE the front is still being read: the back gets 4096 entries of room of its own below the front's reach (the allocation
     // holds count + count/8 + 4096 entries), so a forwarded entry can never land on a front slot that has not been consumed yet
-    const u32 qcap = cnt + FZB_UNICODE_FWD_CAP;
+    const u32 qcap = (u32)std::min<u64>((u64)cnt + FZB_UNICODE_FWD_CAP, 0xFFFFFFFFull);
     const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
     if (trace) {
         // matched indices: one traced generic scorer for every window width, ASCII and unicode (kernels_generic.hip)
