@@ -11,7 +11,6 @@ typedef uint64_t u64;
 #define FZB_MAX_ROWS 63        // needle rows of the by-value NeedleDev (bytes on the ASCII path, scalars on the unicode path); longer needles: NeedleLongDev
 #define FZB_MAX_NEEDLE_BYTES 64
 #define FZB_MAX_HAYSTACK_LEN 1024  // reference: src/smith_waterman/algo/mod.rs:18 (beyond this the greedy fallback scores)
-#define FZB_WINDOW_TO_FIND 0xFFFFFFFFu  // a queued window whose start says "not found yet": its scorer computes the 0-typo lane-free window itself
 #define FZB_UNICODE_FWD_CAP 4096u  // windows beyond four chunks the thread-per-haystack unicode scorer hands on per query (and the room the queue's back keeps for them)
 #define FZB_TILE 1024          // haystacks per filter tile (one bitmap group + one count)
 
@@ -236,7 +235,7 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
 // kernels_unicode.hip
 // wmode 2 (the window is the whole haystack): queue the windows wider than a chunk ahead of the single-chunk scorer (which then gets multi_front = 2)
 void fzb_launch_unicode_split_wide(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, int sw_lanes, u32 capacity, u32* overflow, u32 qcap, u32* counters,
-                                   int grid, hipStream_t st, u32 ws_mark = 0);
+                                   int grid, hipStream_t st);
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
                            int grid, hipStream_t st, int tform = 0, int multi_front = 0, int one_round_wgs = 0);

@@ -187,7 +187,6 @@ FzbKnobs parse_knobs() {
     k.window_no_mask_cache = set("FZB_WINDOW_NO_MASK_CACHE");
     k.window_four_pass = set("FZB_WINDOW_FOUR_PASS");
     k.window_no_pre = set("FZB_WINDOW_NO_PRE");
-    { const char* e = getenv("FZB_UNICODE_PRESPLIT_FILTERED"); k.no_unicode_presplit_filtered = e && e[0] == '0'; }
     k.window_whole_tiles = set("FZB_WINDOW_WHOLE_TILES");
     k.long_generic_only = set("FZB_LONG_GENERIC_ONLY");
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
@@ -1353,20 +1352,14 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         if (umin != 0xFFFFFFFFu && (rc = ensure_dp_scratch(m, ugrid))) return rc;  // first use only (or fzb_matcher_reserve)
         // Whole-haystack windows (max_typos: None): the wide ones are known from the end offsets, so they are queued FIRST and their scorers run
         // on the second stream beside the single-chunk scorer (Arabic-shaped list, All Scores: the two took 90 + 100 us one after the other)
-        // Round 5: the same for the FILTERED 0-typo query (the exact unicode filter's survivors, window found by the scorer): survivors whose
-        // HAYSTACK is wider than a chunk are queued by length with the window left to find (FZB_WINDOW_TO_FIND) - their window may still fit a chunk,
-        // the queue's scorers take any width - so that the wave-per-haystack launch no longer waits behind the single-chunk scorer (Arabic-shaped
-        // list, default query: 22 + 4.5 + 15 us one after the other).  FZB_UNICODE_PRESPLIT_FILTERED=0: the scorer queues its wide windows itself.
-        const bool presplit_filtered = wmode == 1 && uni_exact && !items_in && !kn.no_unicode_presplit_filtered;
-        bool presplit = ((wmode == 2 && !items) || presplit_filtered) && !no_wide && !kn.no_overlap && !kn.debug_sync;  // (whole-haystack windows: no item list - the number of windows is the range's size)
+        bool presplit = wmode == 2 && !items && !no_wide && !kn.no_overlap && !kn.debug_sync;  // (no item list: the number of windows is the range's size)
         if (presplit && ensure_aux_stream(m) != FZB_OK) {  // no second stream: the scorer queues them itself (the error text is dropped with the fallback)
             presplit = false;
             fzb_clear_error();
         }
         hipStream_t wst = st;  // the stream of the wide windows' scorers
         if (presplit) {
-            fzb_launch_unicode_split_wide(cd, first, items, n_items_ptr, lc.sw_lanes, cap32, w.overflow, qcap, cnt_c, (int)std::min<u32>((cnt + 2047u) / 2048u, (u32)cus * 4u), st,
-                                          presplit_filtered ? FZB_WINDOW_TO_FIND : 0u);
+            fzb_launch_unicode_split_wide(cd, first, items, n_items_ptr, lc.sw_lanes, cap32, w.overflow, qcap, cnt_c, (int)std::min<u32>((cnt + 2047u) / 2048u, (u32)cus * 4u), st);
             HIPCHK(hipEventRecord(m->ev_fork, st));
             HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
             wst = m->aux_stream;

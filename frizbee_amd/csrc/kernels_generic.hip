@@ -10,7 +10,6 @@
 // Arithmetic is done per lane in 32-bit registers and wrapped to the emulated lane type (u8 / u16) after
 // every add, so it follows the reference's wrapping add / saturating sub literally.
 #include "kernels_common.h"
-#include "dp_unicode.h"  // unicode_window_first_last: the 0-typo lane-free window of a queued haystack (FZB_WINDOW_TO_FIND)
 
 #define GEN_WAVES 4
 
@@ -160,13 +159,7 @@ __global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restri
         haystack_span(ends, first + li, s, L);
         const u8* hay = bytes + s;
         u32 ws, we;
-        if (lst) {
-            ws = le[1];
-            we = le[2];
-            if constexpr (UNICODE && !ND::kLong) {  // queued by LENGTH ahead of the single-chunk scorer (k2u_split_wide): the window is found here,
-                if (ws == FZB_WINDOW_TO_FIND) unicode_window_first_last(nd, hay, L, ws, we);  // by every lane alike (a few SWAR blocks per haystack)
-            }
-        }
+        if (lst) { ws = le[1]; we = le[2]; }
         else if (wmode == 2) { ws = 0; we = L; }
         else if (TRACE && wmode == 1) {
             // 0-typo ASCII window in its lane-free form (src/prefilter/algo/ascii.rs:6-72): first occurrence of the first needle

@@ -63,9 +63,6 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             const u32 li = li_c, L = L_c;
             const u8* hay = bytes + s_c;
             u32 ws = ws_c, we = we_c;
-            // (windows queued ahead of this kernel, k2u_split_wide: every haystack beyond one chunk - whole-haystack windows are that wide, and a
-            // filtered query's haystacks beyond a chunk go to the queue's scorers with the window left for them to find)
-            if (multi_front == 2 && L > (u32)SWL) break;
             if (wmode == 2) { ws = 0; we = L; }
             else if (wmode == 1) {
                 if (REGS) unicode_window_regs(nd, q0_c, q1_c, L, ws, we);
@@ -140,11 +137,9 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
 // (pushes are collected per workgroup in LDS and take ONE atomic on the queue's counter per 2048 items: an atomic per wave - 4.4 k of them on
 // one address for the Arabic-shaped list - is served one at a time, 8 ns each, and made this kernel 53 us long)
 #define FZB_SPLIT_CHUNK 2048u
-// ws_mark: what an entry's window start says - 0 (whole-haystack windows) or FZB_WINDOW_TO_FIND (a filtered 0-typo query: the entry's scorer
-// finds the lane-free window itself, unicode_window_first_last; the haystack is wider than a chunk, its window may or may not be)
 template <typename ET>
 __global__ __launch_bounds__(256) void k2u_split_wide(const ET* __restrict__ ends, u64 first, const u32* __restrict__ items, const u32* __restrict__ n_items_ptr, u32 ulen, u32 swl,
-                                                      u32 capacity, u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters, u32 ws_mark) {
+                                                      u32 capacity, u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters) {
     __shared__ uint4 s_buf[FZB_SPLIT_CHUNK];
     __shared__ u32 s_n, s_base;
     const u32 M = min(*n_items_ptr, capacity);
@@ -161,7 +156,7 @@ __global__ __launch_bounds__(256) void k2u_split_wide(const ET* __restrict__ end
             u32 L;
             haystack_span_u(ends, ulen, first + li, s, L);
             if (L <= swl) continue;
-            const uint4 e = make_uint4(j, ws_mark, L, li);
+            const uint4 e = make_uint4(j, 0u, L, li);
             if (L > FZB_MAX_HAYSTACK_LEN) {  // the greedy fallback's end of the queue: rare, pushed directly
                 const u32 slot = atomicAdd(&counters[4], 1u);
                 *(uint4*)(overflow + 4 * (size_t)(qcap - 1 - slot)) = e;
@@ -180,9 +175,9 @@ __global__ __launch_bounds__(256) void k2u_split_wide(const ET* __restrict__ end
 }
 
 void fzb_launch_unicode_split_wide(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, int sw_lanes, u32 capacity, u32* overflow, u32 qcap, u32* counters,
-                                   int grid, hipStream_t st, u32 ws_mark) {
-    if (c.ends_u64) hipLaunchKernelGGL((k2u_split_wide<u64>), dim3(grid), dim3(256), 0, st, (const u64*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters, ws_mark);
-    else hipLaunchKernelGGL((k2u_split_wide<u32>), dim3(grid), dim3(256), 0, st, (const u32*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters, ws_mark);
+                                   int grid, hipStream_t st) {
+    if (c.ends_u64) hipLaunchKernelGGL((k2u_split_wide<u64>), dim3(grid), dim3(256), 0, st, (const u64*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters);
+    else hipLaunchKernelGGL((k2u_split_wide<u32>), dim3(grid), dim3(256), 0, st, (const u32*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters);
 }
 
 #define FZB_K2U_PARAMS const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win, \
@@ -254,14 +249,12 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict
     __syncthreads();
     const u32 nthreads = gridDim.x * blockDim.x, gtid = blockIdx.x * blockDim.x + threadIdx.x;
     for (u32 q = gtid; q < nlist; q += nthreads) {
-        const u32 opos = list[4 * q], li = list[4 * q + 3];
-        u32 ws = list[4 * q + 1], we = list[4 * q + 2];
+        const u32 opos = list[4 * q], ws = list[4 * q + 1], we = list[4 * q + 2], li = list[4 * q + 3];
         if (opos >= capacity) continue;
         u64 s;
         u32 L;
         haystack_span(ends, first + li, s, L);
         const u8* hay = bytes + s;
-        if (ws == FZB_WINDOW_TO_FIND) unicode_window_first_last(nd, hay, L, ws, we);  // (queued by length ahead of the single-chunk scorer)
         const u32 sp = ws ? ws - 1 : 0;
         const bool include_exact = sp == 0 && we == L;
         const u32 m = we - sp;

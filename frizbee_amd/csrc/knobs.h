@@ -23,7 +23,6 @@ struct FzbKnobs {
     bool long_generic_only = false;  // FZB_LONG_GENERIC_ONLY=1 long needles scored by the wave-per-haystack kernel alone (rounds 3-4) instead of one thread per window (k2d_dp_long)
     bool window_whole_tiles = false; // FZB_WINDOW_WHOLE_TILES=1 the PRE form as one 1024-thread workgroup per tile instead of four 256-thread workgroups per tile
     bool window_no_pre = false;      // FZB_WINDOW_NO_PRE=1    lane-exact window kernel, one-pass form: every thread computes its own haystack's occurrence masks chunk by chunk (round 4's form) instead of the workgroup laying them out ahead
-    bool no_unicode_presplit_filtered = false;  // FZB_UNICODE_PRESPLIT_FILTERED=0 filtered 0-typo unicode query: the single-chunk scorer queues its wide windows itself (round 4) instead of the haystacks beyond a chunk being queued ahead of it
     bool no_unicode_fwd = false;     // FZB_UNICODE_FWD=0      the thread-per-haystack unicode multi-chunk scorer keeps its windows beyond four chunks (default: hands up to 4096 on to the wave-per-haystack kernel)
     bool no_handoff = true;          // FZB_HANDOFF=1 (or naming FZB_HANDOFF_MIN_TILES) turns the filter -> scorer handoff ON; default since round 5 and FZB_NO_HANDOFF=1: classifier and scorers gather the survivors' bytes from the corpus (no staging)
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy  multi-device query: counts to the host + hipMemcpyPeerAsync even when every shard shares the root device

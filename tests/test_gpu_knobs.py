@@ -58,8 +58,6 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_HANDOFF_MIN_TILES": "0"}, [("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),  # the 16-vector view kernel, staging
     ({"FZB_NO_OVERLAP": "1"}, [("uniwide", "éa", dict(max_typos=None))]),      # whole-haystack unicode windows: the scorer queues the wide ones itself, one stream
     ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict(max_typos=None))]),   # ... queued ahead (default), thread per haystack beside the single-chunk scorer
-    ({"FZB_UNICODE_PRESPLIT_FILTERED": "0"}, [("uniwide", "éa", dict()), ("uni", "éa", dict())]),  # filtered 0-typo query: the scorer queues its wide windows itself (round 4's flow)
-    ({"FZB_UNICODE_PRESPLIT_FILTERED": "0", "FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict())]),
     ({"FZB_UNICODE_MULTI": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),
     ({"FZB_UNICODE_MULTI": "1", "FZB_UNICODE_FWD": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),  # the thread-per-haystack scorer keeps its stragglers
     ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict()), ("uniwide", "éa", dict(max_typos=1))]),                               # ... hands them on (default)
