@@ -768,7 +768,7 @@ def main():
         if e2e_multi:
             res["e2e_sorted_merge"] = e2e_multi
             if c4_row is not None:
-                res["configs"] = {f"C4 sharded over {world} GPU(s): {c4_row['haystacks']:,} ragged 8..128 B, 'deadbeef', max_typos=0 (BASELINE.json configs[3])": c4_row}
+                res.setdefault("configs", {})[f"C4 sharded over {world} GPU(s): {c4_row['haystacks']:,} ragged 8..128 B, 'deadbeef', max_typos=0 (BASELINE.json configs[3])"] = c4_row
         if world == 1:
             # what `Matcher::match_list` hands a caller: ordered records in host memory (pipeline + device sort + D2H), per call
             torch.cuda.set_stream(torch.cuda.default_stream(dev))
@@ -838,7 +838,7 @@ def main():
                 res["check"] = oracle_check(F, m2, corpus, rows, min(n, 1_000_000), args.max_typos, dev)
             del m2
             if not args.no_configs:
-                res["configs"] = other_configs(F, synth, dev, 10)
+                res.setdefault("configs", {}).update(other_configs(F, synth, dev, 10))
             if not args.no_live_traffic:
                 torch.cuda.synchronize(dev)
                 lc_, why = live_counters()

@@ -751,7 +751,19 @@ __global__ __launch_bounds__(256) void k_verify_promise(const ET* __restrict__ e
 static int verify_promise(const fzb_corpus* c, u32 uniform_len, u32 max_len, const char* what) {
     if (!fzb_knobs().verify_promises || !c->dev.n || (!uniform_len && !max_len)) return FZB_OK;
     unsigned long long* d = nullptr;
-    HIPCHK(hipDeviceSynchronize());  // the caller may have filled the buffers on any stream
+    // the borrowed buffers may live on another device than the caller's current one: the check runs where the end offsets are
+    int prev_dev = 0, own_dev = 0;
+    HIPCHK(hipGetDevice(&prev_dev));
+    own_dev = prev_dev;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, c->dev.ends) == hipSuccess && attr.type == hipMemoryTypeDevice) own_dev = attr.device;
+    else (void)hipGetLastError();
+    struct DeviceGuard {
+        int prev, cur;
+        ~DeviceGuard() { if (cur != prev) (void)hipSetDevice(prev); }
+    } guard{prev_dev, own_dev};
+    if (own_dev != prev_dev) HIPCHK(hipSetDevice(own_dev));
+    HIPCHK(hipDeviceSynchronize());  // the caller may have filled the buffers on any stream of that device
     HIPCHK(hipMalloc((void**)&d, 16));
     const unsigned long long init[2] = {0ull, ~0ull};
     hipError_t e = hipMemcpy(d, init, 16, hipMemcpyHostToDevice);
@@ -823,7 +835,10 @@ int fzb_corpus_set_max_len(fzb_corpus* c, uint32_t max_len) {
         return fail(FZB_ERR_INVALID, "the corpus was uploaded by fzb_corpus_upload, which measured its longest haystack (" + std::to_string(c->dev.max_len) + " bytes); " +
                                          std::to_string(max_len) + " is not an upper bound");
     }
-    if (c->dev.uniform_len && max_len != c->dev.uniform_len) return fail(FZB_ERR_INVALID, "the corpus promises a uniform length of " + std::to_string(c->dev.uniform_len) + " bytes");
+    if (c->dev.uniform_len) {  // a (verified) uniform length implies its own, tighter bound: a looser one is accepted and changes nothing
+        if (max_len == 0 || max_len >= c->dev.uniform_len) return FZB_OK;
+        return fail(FZB_ERR_INVALID, "the corpus promises a uniform length of " + std::to_string(c->dev.uniform_len) + " bytes; " + std::to_string(max_len) + " is not an upper bound");
+    }
     if (max_len && max_len != c->dev.uniform_len) {  // (a uniform length already verified implies its own bound)
         const int vrc = verify_promise(c, 0, max_len, ("a longest haystack of " + std::to_string(max_len) + " bytes was promised").c_str());
         if (vrc) return vrc;
@@ -867,7 +882,9 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     const bool need_l2 = !m->lc.filter_exact;
     const bool need_marg = typo_fast_path_configured(m);
     const bool need_cls = !m->literal_mode && !m->empty && !m->nd.unicode && m->lc.cf_ok;  // classified scoring (fzb_launch_dp_classes)
-    if (w.cap_items >= count && (!need_l2 || w.cap_level2 >= count) && (!need_marg || w.cap_marg >= count) && (!need_cls || w.cap_cls >= count) && w.counters) {
+    // (cap_items >= count + FZB_UNICODE_FWD_CAP: run_pipeline anchors the queue's back at count + FZB_UNICODE_FWD_CAP entries - a workspace
+    // allocated for a smaller range holds count0 + count0/8 + 4096 entries and must not be reused for a range within 4096 of that)
+    if (w.cap_items >= count + FZB_UNICODE_FWD_CAP && (!need_l2 || w.cap_level2 >= count) && (!need_marg || w.cap_marg >= count) && (!need_cls || w.cap_cls >= count) && w.counters) {
         if (w.tables_stale) {  // fzb_matcher_set_pattern / set_config kept the device buffers: only the two small tables change
             HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
             if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
@@ -1243,6 +1260,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         // good (tests/test_oracle_reference_properties.py::test_single_chunk_typo_prefilter_is_the_lcs_criterion;
         // 1.3e8 random single-chunk cases without a deviation).  Then nothing is marginal and the decide pass is not launched.
         const bool single_chunk = cd.max_len <= (u32)lc.pf_lanes;
+        if (m->gate_wait) HIPCHK(hipStreamWaitEvent(st, m->gate_wait, 0));
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         if (single_chunk && m->lcs_states)  // the LCS criterion as an automaton in the streaming DFA kernel
             fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
@@ -1253,6 +1271,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, w.bitmap_m,
                               w.tile_counts_m, w.reject_bits, w.tile_rejects);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
+        if (m->gate_record) HIPCHK(hipEventRecord(m->gate_record, st));
         FZB_STAGE("filter(lcs)");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
         if (!single_chunk) {
@@ -1270,10 +1289,12 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
         return FZB_OK;
     } else if (m->uni_dfa_states && lc.bias_ok && !trace) {
         // unicode path, 0 typos: the exact prefilter as a byte-level DFA in the streaming filter; the scorer finds the window itself
+        if (m->gate_wait) HIPCHK(hipStreamWaitEvent(st, m->gate_wait, 0));
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         fzb_launch_filter(cd, first, cnt, w.table, w.uni_dfa, lc.dead_byte, m->uni_dfa_states - 1, 1, 0, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
                           nullptr, nullptr, nullptr, lc.pad_ok, -1, m->cdfa_src == 2 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
+        if (m->gate_record) HIPCHK(hipEventRecord(m->gate_record, st));
         FZB_STAGE("filter(unicode dfa)");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st, nullptr, &cnt_c[1]);  // (kept by the exact prefilter = the filter's survivors)
         FZB_STAGE("compact1");
@@ -1291,6 +1312,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
                                 !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2) && ntiles_f >= (u32)kn.handoff_min_tiles;
         if (want_stage && (rc = ensure_stage(m, count))) return rc;  // first use only (or fzb_matcher_reserve)
         const StageOut so{want_stage ? w.stage : nullptr, want_stage ? w.stage_hdr : nullptr};
+        if (m->gate_wait) HIPCHK(hipStreamWaitEvent(st, m->gate_wait, 0));
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
             fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
@@ -1299,6 +1321,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
             staged = fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
                                        nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, want_stage ? &so : nullptr);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
+        if (m->gate_record) HIPCHK(hipEventRecord(m->gate_record, st));
         FZB_STAGE("filter");
         fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * kn.compact_grid_mul, st, staged ? w.tile_prefix : nullptr);
         FZB_STAGE("compact1");
@@ -2378,6 +2401,12 @@ int fzb_debug_cdfa_state(const fzb_matcher* m, const uint8_t* bytes, size_t len,
     return st >= acc ? 1 : 0;
 }
 
+int fzb_debug_set_gate(fzb_matcher* m, void* wait_before_filter, void* record_after_filter) {  // experiment hook: see fzb_matcher::gate_wait
+    if (!m) return fail(FZB_ERR_INVALID, "null argument");
+    m->gate_wait = (hipEvent_t)wait_before_filter;
+    m->gate_record = (hipEvent_t)record_after_filter;
+    return FZB_OK;
+}
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {
     if (!m || !out) return fail(FZB_ERR_INVALID, "null argument");
     if (m->ws.counters) {
