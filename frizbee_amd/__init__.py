@@ -115,7 +115,7 @@ SYMBOLS = [
     "fzb_match_list_indices_into", "fzb_multi_match_list_into", "fzb_multi_match_list_indices_into",
     "fzb_device_count", "fzb_shard_ranges", "fzb_corpus_upload_sharded", "fzb_sharded_corpus_free", "fzb_sharded_corpus_len", "fzb_sharded_corpus_shards",
     "fzb_sharded_corpus_shard", "fzb_match_list_parallel_sharded", "fzb_debug_lcs_dfa_accepts", "fzb_debug_cdfa_state",
-    "fzb_merge_shard_runs", "fzb_corpus_build_view", "fzb_debug_reload_knobs", "fzb_matcher_shard_report", "fzb_debug_set_gate",
+    "fzb_merge_shard_runs", "fzb_corpus_build_view", "fzb_debug_reload_knobs", "fzb_matcher_shard_report",
 ]
 
 
@@ -184,7 +184,6 @@ def lib():
         l.fzb_corpus_build_view.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         l.fzb_debug_lcs_dfa_accepts.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
         l.fzb_debug_cdfa_state.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
-        l.fzb_debug_set_gate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
 

@@ -1,4 +1,4 @@
-// Lookups of the ordered-subsequence DFA table in LDS (kernels_filter.hip, kernels_fused.hip).
+// Lookups of the streaming filter's DFA table in LDS (kernels_filter.hip).
 // ABS = true: the table starts at LDS address 0 (the kernel's only LDS object, dynamic); ABS = false: the table is a static __shared__
 // array, whose compile-time address folds into the ds_read's offset field.  Either way a lookup is v_perm + ds_read_u8.
 #pragma once
@@ -18,47 +18,44 @@
 __device__ __forceinline__ void dfa_require_lds_base0(const u8* lds) {
     if ((u32)(uintptr_t)(const __attribute__((address_space(3))) u8*)lds != 0u) __builtin_trap();
 }
-template <u32 STRIDE = FZB_DFA_STRIDE>
 __device__ __forceinline__ void dfa_load_lds(u8* lds, const u8* __restrict__ dfa_g, int rows) {  // every thread of the workgroup; sync afterwards
-    for (u32 i = threadIdx.x * 4; i < ((u32)rows + 1) * 256; i += blockDim.x * 4) *(u32*)(lds + (i >> 8) * STRIDE + (i & 255)) = *(const u32*)(dfa_g + i);
+    for (u32 i = threadIdx.x * 4; i < ((u32)rows + 1) * 256; i += blockDim.x * 4) *(u32*)(lds + (i >> 8) * FZB_DFA_STRIDE + (i & 255)) = *(const u32*)(dfa_g + i);
 }
 
-// STRIDE = 256 (k1_dfa<.., 256>, FZB_DFA_STRIDE256=1): the v_perm result IS the address - ONE VALU instruction per byte instead of two, at
-// the price of the bank conflicts the 288-byte stride removed (which never showed in the memory-bound kernel's time: DESIGN.md section 3)
-template <int K, bool ABS = true, u32 STRIDE = FZB_DFA_STRIDE>
+template <int K, bool ABS = true>
 __device__ __forceinline__ u32 dfa_step(u32 st, u32 w, const u8* dfa) {
     // address = st * 288 + byte K of w: (st << 8) | byte by v_perm_b32 (byte0 <- w.byteK, byte1 <- st.byte0, bytes 2,3 <- 0), + st * 32
     // The table is the kernel's only LDS object and starts at LDS address 0 (see the kernels), so the perm result IS the address.
     // Spelled as an integer-to-LDS-pointer cast because the address of an extern __shared__ array is a link-time symbol: indexing
     // `dfa` costs a v_add of that symbol (of 0) per lookup.
-    const u32 addr = __builtin_amdgcn_perm(st, w, 0x0c0c0400u | (u32)K) + st * (STRIDE - 256u);  // st * stride + byte
+    const u32 addr = __builtin_amdgcn_perm(st, w, 0x0c0c0400u | (u32)K) + st * (FZB_DFA_STRIDE - 256u);  // st * stride + byte
     if (!ABS) return dfa[addr];
     return *(const __attribute__((address_space(3))) u8*)(uintptr_t)addr;
 }
 // s_waitcnt lgkmcnt(0) (vmcnt / expcnt untouched): ONE wait for a round of interleaved lookups instead of the compiler's one per use
 // (lgkmcnt(3), (2), (1), (0)) - on this chip a wait takes an issue slot like any other instruction (issue model)
 #define FZB_WAIT_LDS() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)  // the barriers keep the next round's v_perm behind the wait
-template <bool ABS = true, u32 STRIDE = FZB_DFA_STRIDE>
+template <bool ABS = true>
 __device__ __forceinline__ void dfa_word4(u32 (&st)[4], const u32 (&w)[4], const u8* dfa) {
 #pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<0, ABS, STRIDE>(st[p], w[p], dfa);
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<0, ABS>(st[p], w[p], dfa);
     FZB_WAIT_LDS();
 #pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<1, ABS, STRIDE>(st[p], w[p], dfa);
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<1, ABS>(st[p], w[p], dfa);
     FZB_WAIT_LDS();
 #pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<2, ABS, STRIDE>(st[p], w[p], dfa);
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<2, ABS>(st[p], w[p], dfa);
     FZB_WAIT_LDS();
 #pragma unroll
-    for (int p = 0; p < 4; p++) st[p] = dfa_step<3, ABS, STRIDE>(st[p], w[p], dfa);
+    for (int p = 0; p < 4; p++) st[p] = dfa_step<3, ABS>(st[p], w[p], dfa);
     FZB_WAIT_LDS();
 }
-template <bool ABS = true, u32 STRIDE = FZB_DFA_STRIDE>
+template <bool ABS = true>
 __device__ __forceinline__ u32 dfa_partial(u32 st, const uint4& q, u32 nbytes, const u8* dfa) {
     const u32 w4[4] = {q.x, q.y, q.z, q.w};
     for (u32 k = 0; k < nbytes; k++) {
         const u32 b = (w4[k >> 2] >> (8 * (k & 3))) & 0xFF;
-        st = ABS ? *(const __attribute__((address_space(3))) u8*)(uintptr_t)(st * STRIDE + b) : dfa[st * STRIDE + b];
+        st = ABS ? *(const __attribute__((address_space(3))) u8*)(uintptr_t)(st * FZB_DFA_STRIDE + b) : dfa[st * FZB_DFA_STRIDE + b];
     }
     return st;
 }

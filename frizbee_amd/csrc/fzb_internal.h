@@ -74,7 +74,7 @@ struct CorpusDev {
     // The streaming filter's VIEW of a ragged list (fzb_corpus_upload builds it for lists whose haystacks are 33..256 bytes; nullptr
     // otherwise; every other stage reads the canonical layout).  What bounds the thread-per-haystack filter on such a list is the access
     // pattern itself - 64 lanes x 16 bytes from 64 different lines per load instruction: 215 us for the 0.9 GB of the C4 shard with the
-    // automaton switched off (FZB_CDFA_NODFA=1) - so the view stores the bytes the way the lanes read them:
+    // automaton switched off (round 3's measurement) - so the view stores the bytes the way the lanes read them:
     //   * every 1024-haystack tile sorted by DESCENDING length (round 5; rounds 3-4: by number of 16-byte vectors) (vperm[p] = position inside its tile the haystack at
     //     sorted position p came from, vlen[p] = its length);
     //   * every GROUP of 64 consecutive sorted haystacks (one wave's worth) interleaved by vector: vector v of the group's member j lives
@@ -130,13 +130,6 @@ struct Workspace {
                         //   "the window is the whole haystack" flag, 64-bit address of the haystack's bytes), three class lists
     u32* cls_lists;     //   [7][cap]; class counts in counters[8..10], multi-chunk tail classes in counters[12..15]
     size_t cap_cls;
-    // filter -> scorer handoff on ragged lists (k1_cdfa_view writes, k2w_classify reads; DESIGN.md section 3 "Handoff"): per 1024-haystack
-    // tile FZB_STAGE_UNITS 16-byte units of the accepted haystacks' vectors (packed from the front in arrival order) and one header entry per
-    // survivor in INDEX order (unit offset inside the tile | length << 16; 0xFFFF = not staged: the tile's units ran out)
-    u8* stage;
-    u32* stage_hdr;
-    u32* tile_prefix;   // survivors before each tile (written by k_compact1): a survivor's rank inside its tile = its rank - tile_prefix[tile]
-    size_t cap_stage;   // haystacks the three are sized for (0 = not allocated)
     u64* table;         // 256 x u64 filter table (device)
     u8* dfa;            // (rows + 1) x 256 next-state table of the ordered-subsequence DFA (device)
     u8* uni_dfa;        // unicode path, 0 typos: states x 256 table of the exact prefilter's byte-level DFA (device)
@@ -164,15 +157,6 @@ struct LaunchCfg {
     u32 dead_byte;      // a byte value no needle row can match (used to neutralise bytes past a haystack's end in the DFA filter)
 };
 
-#ifndef FZB_STAGE_UNITS
-#define FZB_STAGE_UNITS 1024  // 16 KB of staged vectors per 1024-haystack tile (the C4 list needs ~ 4 KB on average, the paths list ~ 7)
-#endif
-#define FZB_STAGE_LDS_UNITS 512  // of which the first 8 KB are collected in LDS and written out coalesced
-struct StageOut {
-    u8* stage;
-    u32* hdr;
-};
-
 // Index-ordered record runs of contiguous shards, all readable from the current device (k_concat_runs); count[g] points at the pair
 // fzb_match_list_device writes (records written, matches found), cap[g] is the run's buffer size in records
 #define FZB_MAX_RUNS 64
@@ -195,15 +179,14 @@ struct RejectOut {
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>
 // kernels_filter.hip
-// returns true when the kernel that ran also staged the accepted haystacks' vectors into `so` (only the view kernel does)
-bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m = nullptr, u32* tile_counts_m = nullptr,
                        u64* reject_bits = nullptr, u32* tile_rejects = nullptr, int nul_safe = 0, int acc_lo = -1, const u8* cdfa = nullptr, u32 cdfa_bytes = 0,
-                       int cdfa_K = 0, int cdfa_G = 0, const StageOut* so = nullptr);
+                       int cdfa_K = 0, int cdfa_G = 0);
 void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* reject_count, u32* rej_prefix, hipStream_t st);
 void fzb_launch_init_counters(u32* counters, u32 n0, hipStream_t st);  // the 16-word counter block: [0] = n0, the rest 0
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st,
-                         u32* tile_prefix_out = nullptr, u32* total_out2 = nullptr);
+                         u32* total_out2 = nullptr);
 void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, const u64* table, int rows, int mode, int need, u32 min_len,
                              u64* bitmap, u32* tile_counts, int grid, hipStream_t st);
 void fzb_launch_compact2(const u64* bitmap, const u32* counts, const u32* n_items_ptr, const u32* in_idx, const u32* in_win, u32* out_idx, u32* out_win, u32* total_out,
@@ -216,20 +199,11 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
                    int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st,
                    const RejectOut* rejects = nullptr);
 bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
-// `staged` (optional): the filter's handoff - stage, header and the per-tile survivor prefix (StagedIn); the classifier then reads the
-// survivors' bytes from the stage instead of gathering them from the corpus
-struct StagedIn {
-    const u8* stage;
-    const u32* hdr;
-    const u32* tile_prefix;
-};
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
-                           int num_cus, hipStream_t st, int part = 0, int split_multi = 0, const StagedIn* staged = nullptr);
+                           int num_cus, hipStream_t st, int part = 0, int split_multi = 0);
 void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* lists, u32 list_stride, const u32* counters,
                             const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int gm, int gc, hipStream_t st);
-void fzb_launch_dp_multi_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* lists, u32 list_stride, const u32* counts,
-                                 const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes, int mode,
                          fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st);
 // kernels_unicode.hip

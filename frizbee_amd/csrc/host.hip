@@ -167,52 +167,19 @@ FzbKnobs parse_knobs() {
     auto on = [](const char* name) { const char* e = getenv(name); return e != nullptr && atoi(e) != 0; };
     auto set = [](const char* name) { return getenv(name) != nullptr; };
     auto num = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    k.no_lcs_dfa = set("FZB_NO_LCS_DFA");
-    k.no_dp_cfu = set("FZB_NO_DP_CFU");
-    k.typo_exact_window = on("FZB_TYPO_EXACT_WINDOW");
-    k.no_dp_classes = set("FZB_NO_DP_CLASSES");
-    k.no_overlap = set("FZB_NO_OVERLAP");
-    k.no_dp_cfm = set("FZB_NO_DP_CFM");
-    k.no_tail_classes = set("FZB_NO_TAIL_CLASSES");
-    k.no_cdfa = set("FZB_NO_CDFA");
-    k.no_filter_view = getenv("FZB_FILTER_VIEW") != nullptr && atoi(getenv("FZB_FILTER_VIEW")) == 0;
-    k.cdfa_nodfa = set("FZB_CDFA_NODFA");
-    k.ragged_burst = num("FZB_RAGGED_BURST", 1) != 0;
     k.debug_sync = set("FZB_DEBUG_SYNC");
-    // the filter -> scorer handoff is OFF unless asked for (round 5: on the C4 shard it costs the streaming filter 30-40 us - 52 MB of stores
-    // inside a kernel that runs at the memory system's ceiling - and returns the scorers 10; DESIGN.md section 3 "Handoff"): FZB_HANDOFF=1
-    // turns it on for lists of FZB_HANDOFF_MIN_TILES tiles and more, naming a threshold does too; FZB_NO_HANDOFF=1 wins over both
-    k.no_handoff = set("FZB_NO_HANDOFF") || !(on("FZB_HANDOFF") || set("FZB_HANDOFF_MIN_TILES"));
-    { const char* e = getenv("FZB_UNICODE_FWD"); k.no_unicode_fwd = e && e[0] == '0'; }
-    k.window_no_mask_cache = set("FZB_WINDOW_NO_MASK_CACHE");
-    k.window_four_pass = set("FZB_WINDOW_FOUR_PASS");
-    k.window_no_pre = set("FZB_WINDOW_NO_PRE");
-    k.window_whole_tiles = set("FZB_WINDOW_WHOLE_TILES");
-    k.long_generic_only = set("FZB_LONG_GENERIC_ONLY");
-    k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
-    k.k2u_waves = num("FZB_K2U_WAVES", 0);
-    k.stage_dbg = num("FZB_STAGE_DBG", 0);
-    k.window_dbg = num("FZB_WINDOW_DBG", 0);
-    k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
-    k.generic_wgs = std::max(1, num("FZB_GENERIC_WGS", 12));
-    k.dfa_wgs = std::max(1, std::min(8, num("FZB_DFA_WGS", 8)));
-    k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
-    k.handoff_min_tiles = std::max(0, num("FZB_HANDOFF_MIN_TILES", 4096));
-    k.shard_inline = num("FZB_SHARD_INLINE", -1);
+    k.typo_exact_window = on("FZB_TYPO_EXACT_WINDOW");
+    k.no_filter_view = getenv("FZB_FILTER_VIEW") != nullptr && atoi(getenv("FZB_FILTER_VIEW")) == 0;
     k.verify_promises = num("FZB_VERIFY_PROMISES", 1) != 0;
-    k.view_plain_loads = set("FZB_VIEW_PLAIN_LOADS");
-    k.view_read_len = set("FZB_VIEW_READ_LEN");
-    k.dfa_general = !on("FZB_DFA_UNI32");
-    k.dfa_stride256 = set("FZB_DFA_STRIDE256");
-    k.small_list = getenv("FZB_SMALL_LIST") ? (uint32_t)atol(getenv("FZB_SMALL_LIST")) : 0xFFFFFFFFu;
-    k.compact_grid_mul = std::max(1, num("FZB_COMPACT_GRID_MUL", 4));
-    { const int v = num("FZB_CLASSIFY_PER", 2); k.classify_per = (v == 1 || v == 4) ? v : 2; }
-    k.dp_wgs_per_cu = std::max(0, num("FZB_DP_WGS_PER_CU", 0));
-    k.cdfa_wgs = std::max(1, num("FZB_CDFA_WGS", 5));
-    k.view_wgs = std::max(1, num("FZB_VIEW_WGS", 6));
-    k.ragged_wgs = std::max(1, num("FZB_RAGGED_WGS", 8));
-    if (const char* e = getenv("FZB_UPLOAD_MODE")) k.upload_mode = !strcmp(e, "register") ? 1 : !strcmp(e, "staged") ? 0 : 2;
-    k.upload_threads = std::max(0, num("FZB_UPLOAD_THREADS", 0));
+    k.no_lcs_dfa = set("FZB_NO_LCS_DFA");
+    k.no_cdfa = set("FZB_NO_CDFA");
+    k.no_dp_classes = set("FZB_NO_DP_CLASSES");
+    k.no_dp_cfm = set("FZB_NO_DP_CFM");
+    k.no_dp_cfu = set("FZB_NO_DP_CFU");
+    k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
+    k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
+    k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
+    k.shard_inline = num("FZB_SHARD_INLINE", -1);
     return k;
 }
 FzbKnobs& knobs_storage() {
@@ -239,59 +206,23 @@ void fzb_config_default(fzb_config* out) {
 
 static void free_workspace(Workspace& w) {
     void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa, w.stage, w.stage_hdr, w.tile_prefix};
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     w = Workspace{};
 }
 
-int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, size_t needle_len, fzb_matcher** out) {
-    if (!config || !out || (!needle_utf8 && needle_len)) return fail(FZB_ERR_INVALID, "null argument");
-    if (config->casing < 0 || config->casing > 2 || config->unicode < 0 || config->unicode > 2 || config->sort < 0 || config->sort > 3 || config->max_typos < -1 ||
-        config->max_typos > 0xFFFF)
-        return fail(FZB_ERR_INVALID, "config enum/range out of bounds");
-    std::vector<u32> cps;
-    if (!decode_utf8(needle_utf8, needle_len, cps)) return fail(FZB_ERR_INVALID, "needle is not valid UTF-8");
-    auto m = new fzb_matcher();
-    m->config = *config;
-    m->needle.assign((const char*)needle_utf8, needle_len);
-    m->empty = needle_len == 0;
-    const fzb_scoring& sc = config->scoring;
-    m->use_u8 = fits_in_u8(needle_len, sc);  // byte length (src/matcher/mod.rs:453)
-    int pf = config->pf_lanes, sw = config->sw_lanes;
-    if (pf == 0 && sw == 0) detect_host_lanes(m->use_u8, pf, sw);
-    else if (sw == 0) sw = m->use_u8 ? pf : pf / 2;  // the score width of the ISA family whose prefilter has pf lanes (64: AVX-512, 32: AVX2, 16: SSE/scalar)
-    if (!(pf == 16 || pf == 32 || pf == 64) || !(sw == 8 || sw == 16 || sw == 32 || sw == 64)) {
-        delete m;
-        return fail(FZB_ERR_INVALID, "pf_lanes must be 16/32/64 and sw_lanes 8/16/32/64 (or both 0 = auto)");
-    }
-    m->lc.pf_lanes = pf;
-    m->lc.sw_lanes = sw;
-    if (m->empty) {  // CompiledPatterns::Empty (src/matcher/mod.rs:194-196)
-        *out = m;
-        return FZB_OK;
-    }
-    // CaseMatching::respects_case_for (src/lib.rs:370-376), UnicodeMatching::respects_unicode_for (:394-400)
-    bool any_upper = false, ascii = true;
-    for (u32 cp : cps) { any_upper |= is_uppercase(cp); ascii &= cp < 0x80; }
-    m->case_sensitive = config->casing == FZB_CASE_RESPECT || (config->casing == FZB_CASE_SMART && any_upper);
-    m->unicode = config->unicode == FZB_UNICODE_ALWAYS || (config->unicode == FZB_UNICODE_SMART && !ascii);
-    m->rows = (int)(m->unicode ? cps.size() : needle_len);
-    if (config->matching < FZB_MATCH_FUZZY || config->matching > FZB_MATCH_SUBSTRING) { delete m; return fail(FZB_ERR_INVALID, "bad matching mode"); }
-    m->literal_mode = config->matching;
-    // guard_against_score_overflow: fuzzy src/matcher/algo.rs:311-325 (rows); literal src/literal/algo.rs:33, 314-322 (needle bytes, its own per-char bonus)
-    std::string perr = m->literal_mode ? overflow_guard(sc, needle_len, sadd16(std::max(sc.capitalization_bonus, sc.delimiter_bonus), sc.matching_case_bonus), 0)
-                                       : overflow_guard(sc, (size_t)m->rows);
-    if (!perr.empty()) { delete m; return fail(FZB_ERR_PANIC, perr); }
-    // beyond NeedleDev's by-value arrays: the needle's arrays go to device memory (NeedleLongDev) and the query runs through the
-    // kernels that take it from there (run_pipeline_long) - any length the reference's guard above accepted
-    m->long_needle = needle_len > FZB_MAX_NEEDLE_BYTES || m->rows > FZB_MAX_ROWS;
+// ---- fzb_matcher_create, piece by piece ------------------------------------------------------------------------------------------
+// NeedleDev's scalars: what `Prefilter::new` / `SmithWaterman::new` precompute (src/prefilter/algo/mod.rs:30-42, src/smith_waterman/algo/mod.rs:21-42)
+static void fill_needle_scalars(fzb_matcher* m, size_t needle_len, size_t n_scalars) {
+    const fzb_config& config = m->config;
+    const fzb_scoring& sc = config.scoring;
     NeedleDev& nd = m->nd;
     memset(&nd, 0, sizeof(nd));
     nd.rows = m->rows;
     nd.nbytes = (int)needle_len;
-    nd.max_typos = config->max_typos;
-    nd.min_haystack_len = config->max_typos < 0 ? 0 : (int)(cps.size() > (size_t)config->max_typos ? cps.size() - (size_t)config->max_typos : 0);  // algo.rs:62-65
+    nd.max_typos = config.max_typos;
+    nd.min_haystack_len = config.max_typos < 0 ? 0 : (int)(n_scalars > (size_t)config.max_typos ? n_scalars - (size_t)config.max_typos : 0);  // algo.rs:62-65
     nd.unicode = m->unicode;
     nd.lane_mask = m->use_u8 ? 0xFF : 0xFFFF;
     nd.match_plus_mismatch = sadd16(sc.match_score, sc.mismatch_penalty);
@@ -305,279 +236,290 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     nd.delimiter = sc.delimiter_bonus;
     nd.match_score = sc.match_score;
     nd.gap_open = sc.gap_open_penalty;
-    auto flip_ascii = [&](u8 c) { return m->case_sensitive ? c : (c >= 'a' && c <= 'z') ? (u8)(c - 32) : (c >= 'A' && c <= 'Z') ? (u8)(c + 32) : c; };
-    if (m->long_needle) {
-        // [raw | c | f | uc | uf | ulen], 16-byte aligned sections (device pointers are set when the blob is uploaded)
-        auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
-        const size_t nb = needle_len, nr = cps.size();
-        m->long_off_c = al(nb);
-        m->long_off_f = m->long_off_c + al(nb);
-        m->long_off_uc = m->long_off_f + al(nb);
-        m->long_off_uf = m->long_off_uc + al(4 * nr);
-        m->long_off_ulen = m->long_off_uf + al(4 * nr);
-        m->long_blob_host.assign(m->long_off_ulen + al(nr) + 16, 0);
-        u8* blob = m->long_blob_host.data();
-        for (size_t i = 0; i < nb; i++) {  // case_needle (src/prefilter/mod.rs:49-65)
-            blob[i] = needle_utf8[i];
-            blob[m->long_off_c + i] = needle_utf8[i];
-            blob[m->long_off_f + i] = flip_ascii(needle_utf8[i]);
-        }
-        for (size_t i = 0; i < nr; i++) {  // case_needle_unicode (src/prefilter/mod.rs:71-96)
-            blob[m->long_off_ulen + i] = (u8)encode_utf8(cps[i], blob + m->long_off_uc + 4 * i);
-            encode_utf8(m->case_sensitive ? cps[i] : flip_same_width(cps[i]), blob + m->long_off_uf + 4 * i);
-        }
-        NeedleLongDev& l = m->ndl;
-        memset(&l, 0, sizeof(l));
-        l.rows = nd.rows; l.nbytes = nd.nbytes; l.max_typos = nd.max_typos; l.min_haystack_len = nd.min_haystack_len; l.unicode = nd.unicode; l.lane_mask = nd.lane_mask;
-        l.match_plus_mismatch = nd.match_plus_mismatch; l.mismatch = nd.mismatch; l.gex = nd.gex; l.gopm = nd.gopm;
-        l.prefix = nd.prefix; l.capitalization = nd.capitalization; l.matching_case = nd.matching_case; l.exact_bonus = nd.exact_bonus; l.delimiter = nd.delimiter;
-        l.match_score = nd.match_score; l.gap_open = nd.gap_open;
-        // stage configuration: no streaming filter; either no prefilter at all or the lane-exact prefilter kernel as the first stage
-        const int k = config->max_typos;
-        LaunchCfg& lc = m->lc;
-        lc.filter_mode = 0;
-        lc.filter_exact = 0;  // (sizes the second-level arrays the lane-exact prefilter writes)
-        lc.window_mode = (k < 0 || k >= m->rows) ? 2 : 0;
-        lc.pad_ok = lc.cf_ok = lc.cfm_ok = 0;
-        // (the biased gap scan of dp_multi_chunk, as for short needles below: the largest biased value stays inside 16 bits)
-        lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
-        m->table.assign(256, 0);
-        // 0 typos, ASCII: accept <=> the needle is a case-folded ordered subsequence (src/prefilter/algo/ascii.rs:6-54; lane-width independent),
-        // and that automaton has rows + 1 states whatever the needle's length: up to 200 rows its table fits a workgroup's LDS (58 KB) and the
-        // STREAMING filter decides the list (round 5; rounds 3-4 ran the chunked prefilter over every haystack: 0.75 of the bench row's 9.7 ms)
-        if (!m->unicode && !m->literal_mode && k == 0 && m->rows <= 200) {
-            m->long_dfa = true;
-            bool used[256] = {false};
-            lc.pad_ok = 1;
-            for (size_t i = 0; i < nb; i++) {
-                used[blob[m->long_off_c + i]] = used[blob[m->long_off_f + i]] = true;
-                if (needle_utf8[i] == 0) lc.pad_ok = 0;
-            }
-            lc.dead_byte = 0;
-            for (int b = 255; b >= 0; b--)
-                if (!used[b]) { lc.dead_byte = (u32)b; break; }
-            m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
-            for (int st = 0; st <= m->rows; st++)
-                for (int b = 0; b < 256; b++)
-                    m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && (b == blob[m->long_off_c + (size_t)st] || b == blob[m->long_off_f + (size_t)st])) ? st + 1 : st);
-        }
-        *out = m;
-        return FZB_OK;
+}
+static u8 flip_ascii_byte(const fzb_matcher* m, u8 c) { return m->case_sensitive ? c : (c >= 'a' && c <= 'z') ? (u8)(c - 32) : (c >= 'A' && c <= 'Z') ? (u8)(c + 32) : c; }
+
+// A needle beyond NeedleDev's by-value arrays: the arrays go to one host blob (uploaded on first use), the scalars to NeedleLongDev, and the
+// stage configuration is "lane-exact prefilter kernel (or the streaming subsequence automaton) first, wave- or thread-per-window scorer"
+static void build_long_needle(fzb_matcher* m, const uint8_t* needle_utf8, size_t needle_len, const std::vector<u32>& cps) {
+    const fzb_config* config = &m->config;
+    const fzb_scoring& sc = config->scoring;
+    NeedleDev& nd = m->nd;
+    auto flip_ascii = [&](u8 c) { return flip_ascii_byte(m, c); };
+    // [raw | c | f | uc | uf | ulen], 16-byte aligned sections (device pointers are set when the blob is uploaded)
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t nb = needle_len, nr = cps.size();
+    m->long_off_c = al(nb);
+    m->long_off_f = m->long_off_c + al(nb);
+    m->long_off_uc = m->long_off_f + al(nb);
+    m->long_off_uf = m->long_off_uc + al(4 * nr);
+    m->long_off_ulen = m->long_off_uf + al(4 * nr);
+    m->long_blob_host.assign(m->long_off_ulen + al(nr) + 16, 0);
+    u8* blob = m->long_blob_host.data();
+    for (size_t i = 0; i < nb; i++) {  // case_needle (src/prefilter/mod.rs:49-65)
+        blob[i] = needle_utf8[i];
+        blob[m->long_off_c + i] = needle_utf8[i];
+        blob[m->long_off_f + i] = flip_ascii(needle_utf8[i]);
     }
-    for (size_t i = 0; i < needle_len; i++) {  // case_needle (src/prefilter/mod.rs:49-65)
-        u8 c = needle_utf8[i];
-        nd.raw[i] = c;
-        nd.c[i] = c;
-        nd.f[i] = flip_ascii(c);
+    for (size_t i = 0; i < nr; i++) {  // case_needle_unicode (src/prefilter/mod.rs:71-96)
+        blob[m->long_off_ulen + i] = (u8)encode_utf8(cps[i], blob + m->long_off_uc + 4 * i);
+        encode_utf8(m->case_sensitive ? cps[i] : flip_same_width(cps[i]), blob + m->long_off_uf + 4 * i);
     }
-    if (cps.size() <= FZB_MAX_ROWS) {
-        for (size_t i = 0; i < cps.size(); i++) {  // case_needle_unicode (src/prefilter/mod.rs:71-96)
-            nd.ulen[i] = (u8)encode_utf8(cps[i], nd.uc[i]);
-            encode_utf8(m->case_sensitive ? cps[i] : flip_same_width(cps[i]), nd.uf[i]);
-        }
-    }
-    // ---- filter-stage configuration --------------------------------------------------------------
+    NeedleLongDev& l = m->ndl;
+    memset(&l, 0, sizeof(l));
+    l.rows = nd.rows; l.nbytes = nd.nbytes; l.max_typos = nd.max_typos; l.min_haystack_len = nd.min_haystack_len; l.unicode = nd.unicode; l.lane_mask = nd.lane_mask;
+    l.match_plus_mismatch = nd.match_plus_mismatch; l.mismatch = nd.mismatch; l.gex = nd.gex; l.gopm = nd.gopm;
+    l.prefix = nd.prefix; l.capitalization = nd.capitalization; l.matching_case = nd.matching_case; l.exact_bonus = nd.exact_bonus; l.delimiter = nd.delimiter;
+    l.match_score = nd.match_score; l.gap_open = nd.gap_open;
+    // stage configuration: no streaming filter; either no prefilter at all or the lane-exact prefilter kernel as the first stage
     const int k = config->max_typos;
     LaunchCfg& lc = m->lc;
-    if (k < 0 || k >= m->rows) {        // NO_PREFILTER, or `needle_len <= max_typos => (true, 0, len)`
-        lc.filter_mode = 0; lc.filter_exact = 1; lc.window_mode = 2;
-    } else if (!m->unicode && k == 0) { // exact: ordered subsequence; window = first/last occurrence
-        lc.filter_mode = 1; lc.filter_exact = 1; lc.window_mode = 1;
-    } else {                            // superset filter, lane-exact prefilter re-decides
-        lc.filter_mode = k == 0 ? 1 : 2; lc.filter_exact = 0; lc.window_mode = 0;
-    }
+    lc.filter_mode = 0;
+    lc.filter_exact = 0;  // (sizes the second-level arrays the lane-exact prefilter writes)
+    lc.window_mode = (k < 0 || k >= m->rows) ? 2 : 0;
+    lc.pad_ok = lc.cf_ok = lc.cfm_ok = 0;
+    // (the biased gap scan of dp_multi_chunk, as for short needles below: the largest biased value stays inside 16 bits)
+    lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
     m->table.assign(256, 0);
-    for (int r = 0; r < m->rows; r++) {
-        if (m->unicode) {  // a scalar can only match where its LAST byte matches (either case): conservative
-            m->table[nd.uc[r][nd.ulen[r] - 1]] |= (u64)1 << r;
-            m->table[nd.uf[r][nd.ulen[r] - 1]] |= (u64)1 << r;
-        } else {
-            m->table[nd.c[r]] |= (u64)1 << r;
-            m->table[nd.f[r]] |= (u64)1 << r;
+    // 0 typos, ASCII: accept <=> the needle is a case-folded ordered subsequence (src/prefilter/algo/ascii.rs:6-54; lane-width independent),
+    // and that automaton has rows + 1 states whatever the needle's length: up to 200 rows its table fits a workgroup's LDS (58 KB) and the
+    // STREAMING filter decides the list (round 5; rounds 3-4 ran the chunked prefilter over every haystack: 0.75 of the bench row's 9.7 ms)
+    if (!m->unicode && !m->literal_mode && k == 0 && m->rows <= 200) {
+        m->long_dfa = true;
+        bool used[256] = {false};
+        lc.pad_ok = 1;
+        for (size_t i = 0; i < nb; i++) {
+            used[blob[m->long_off_c + i]] = used[blob[m->long_off_f + i]] = true;
+            if (needle_utf8[i] == 0) lc.pad_ok = 0;
         }
+        lc.dead_byte = 0;
+        for (int b = 255; b >= 0; b--)
+            if (!used[b]) { lc.dead_byte = (u32)b; break; }
+        m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
+        for (int st = 0; st <= m->rows; st++)
+            for (int b = 0; b < 256; b++)
+                m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && (b == blob[m->long_off_c + (size_t)st] || b == blob[m->long_off_f + (size_t)st])) ? st + 1 : st);
     }
-    lc.dead_byte = 0;
-    for (int b = 255; b >= 0; b--)
-        if (m->table[b] == 0) { lc.dead_byte = (u32)b; break; }
-    // ordered-subsequence DFA: state s = rows matched so far; a byte that can match row s advances it
-    m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
-    for (int st = 0; st <= m->rows; st++)
-        for (int b = 0; b < 256; b++) m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && ((m->table[b] >> st) & 1)) ? st + 1 : st);
-    if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) {
-        // Substring accept on the ASCII path = "the text drives the needle's Knuth-Morris-Pratt automaton into its final state":
-        // the same table shape, so the streaming DFA filter kernels run it unchanged.  Position k matches byte b iff b is
-        // needle[k] or its case flip; both case forms of a needle byte take the automaton to the same state (the flip is
-        // an involution on every position's byte set), so the usual single restart state works for the folded alphabet.
-        const int n = m->rows;
-        auto hit = [&](int k, int b) { return b == nd.c[k] || b == nd.f[k]; };
-        for (int b = 0; b < 256; b++) m->dfa[b] = (u8)(hit(0, b) ? 1 : 0);
-        int x = 0;  // restart state: where the automaton is after reading needle[1..k)
-        for (int k = 1; k < n; k++) {
-            for (int b = 0; b < 256; b++) m->dfa[(size_t)k * 256 + b] = (u8)(hit(k, b) ? k + 1 : m->dfa[(size_t)x * 256 + b]);
-            x = m->dfa[(size_t)x * 256 + nd.c[k]];
-        }
-        for (int b = 0; b < 256; b++) m->dfa[(size_t)n * 256 + b] = (u8)n;  // found: absorbing
+}
+
+// The streaming filter's byte tables: `table[b]` = needle rows byte b can match (the LCS filter's M), the dead byte, the ordered-subsequence
+// DFA (state s = rows matched so far) - or, for the literal substring mode on the ASCII path, the needle's Knuth-Morris-Pratt automaton
+static void build_filter_tables(fzb_matcher* m) {
+    const NeedleDev& nd = m->nd;
+    LaunchCfg& lc = m->lc;
+m->table.assign(256, 0);
+for (int r = 0; r < m->rows; r++) {
+    if (m->unicode) {  // a scalar can only match where its LAST byte matches (either case): conservative
+        m->table[nd.uc[r][nd.ulen[r] - 1]] |= (u64)1 << r;
+        m->table[nd.uf[r][nd.ulen[r] - 1]] |= (u64)1 << r;
+    } else {
+        m->table[nd.c[r]] |= (u64)1 << r;
+        m->table[nd.f[r]] |= (u64)1 << r;
     }
-    // Unicode path, 0 typos: the prefilter accepts iff the needle's scalars occur, in order, at increasing byte positions, each as its own
-    // bytes or as the bytes of its same-width case flip (src/prefilter/algo/unicode.rs:118-219; the same at 16 / 32 / 64 lanes - checked
-    // against the oracle by tests/test_host_abi.py::test_unicode_dfa_is_the_unicode_prefilter).  That is a byte-level DFA: state = (scalars
-    // matched, bytes of the current scalar matched, which of the two variants are still alive); a mismatch inside a scalar falls back to
-    // "is this byte the scalar's first byte" (UTF-8 lead bytes never occur inside a scalar, so no longer border exists).  With <= 226
-    // states it runs in the streaming DFA filter kernels unchanged and replaces superset filter + lane-exact window pass + second compaction.
-    m->uni_dfa_states = 0;
-    if (m->unicode && !m->literal_mode && config->max_typos == 0 && m->rows >= 1 && lc.filter_mode == 1) {
-        struct St { int i, k, alive; };
-        std::vector<St> states;
-        auto find = [&](int i, int k, int alive) {
-            for (size_t q = 0; q < states.size(); q++)
-                if (states[q].i == i && states[q].k == k && states[q].alive == alive) return (int)q;
-            states.push_back(St{i, k, alive});
-            return (int)states.size() - 1;
-        };
-        std::vector<std::vector<int>> trans;
-        find(0, 0, 3);
-        bool ok = true;
-        for (size_t q = 0; q < states.size() && ok; q++) {
-            const St cur = states[q];
-            std::vector<int> row(256, (int)q);
-            if (cur.i < m->rows) {
-                const u8* va = nd.uc[cur.i];
-                const u8* vb = nd.uf[cur.i];
-                const int len = nd.ulen[cur.i];
-                auto from_start = [&](int b) {  // state (i, 0) reading b
-                    const int alive = (va[0] == b ? 1 : 0) | (vb[0] == b ? 2 : 0);
-                    if (!alive) return find(cur.i, 0, 3);
-                    return len == 1 ? find(cur.i + 1, 0, 3) : find(cur.i, 1, alive);
-                };
-                for (int b = 0; b < 256; b++) {
-                    if (cur.k == 0) { row[b] = from_start(b); continue; }
-                    const int alive = ((cur.alive & 1) && va[cur.k] == b ? 1 : 0) | ((cur.alive & 2) && vb[cur.k] == b ? 2 : 0);
-                    if (alive) row[b] = cur.k + 1 == len ? find(cur.i + 1, 0, 3) : find(cur.i, cur.k + 1, alive);
-                    else row[b] = from_start(b);
-                }
-            }  // i == rows: accepting, absorbing
-            trans.push_back(row);
-            if (states.size() > 226) ok = false;  // 226 x 288 bytes (dfa_lds.h's row stride) + the tile counter fit the 64 KiB of dynamic LDS
-        }
-        if (ok) {
-            // renumber so that the accepting state is the LAST one (the kernels test `state == number of states - 1`)
-            const int ns = (int)states.size();
-            int acc = -1;
-            for (int q = 0; q < ns; q++)
-                if (states[q].i == m->rows) acc = q;
-            std::vector<int> renum(ns);
-            for (int q = 0, nx = 0; q < ns; q++) renum[q] = q == acc ? ns - 1 : nx++;
-            m->uni_dfa.assign((size_t)ns * 256, 0);
-            for (int q = 0; q < ns; q++)
-                for (int b = 0; b < 256; b++) m->uni_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[trans[q][b]];
-            m->uni_dfa_states = ns;  // start state 0 = (0, 0): first created, never the accepting one (rows >= 1)
-        }
+}
+lc.dead_byte = 0;
+for (int b = 255; b >= 0; b--)
+    if (m->table[b] == 0) { lc.dead_byte = (u32)b; break; }
+// ordered-subsequence DFA: state s = rows matched so far; a byte that can match row s advances it
+m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
+for (int st = 0; st <= m->rows; st++)
+    for (int b = 0; b < 256; b++) m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && ((m->table[b] >> st) & 1)) ? st + 1 : st);
+if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) {
+    // Substring accept on the ASCII path = "the text drives the needle's Knuth-Morris-Pratt automaton into its final state":
+    // the same table shape, so the streaming DFA filter kernels run it unchanged.  Position k matches byte b iff b is
+    // needle[k] or its case flip; both case forms of a needle byte take the automaton to the same state (the flip is
+    // an involution on every position's byte set), so the usual single restart state works for the folded alphabet.
+    const int n = m->rows;
+    auto hit = [&](int k, int b) { return b == nd.c[k] || b == nd.f[k]; };
+    for (int b = 0; b < 256; b++) m->dfa[b] = (u8)(hit(0, b) ? 1 : 0);
+    int x = 0;  // restart state: where the automaton is after reading needle[1..k)
+    for (int k = 1; k < n; k++) {
+        for (int b = 0; b < 256; b++) m->dfa[(size_t)k * 256 + b] = (u8)(hit(k, b) ? k + 1 : m->dfa[(size_t)x * 256 + b]);
+        x = m->dfa[(size_t)x * 256 + nd.c[k]];
     }
-    // Typo configurations: the streaming filter's LCS criterion `LCS(needle, haystack) >= rows - k` (Hyyro's bit-vector recurrence
-    // V' = (V + (V & M)) | (V & ~M), M = the rows byte b can match) as a table-driven automaton over its REACHABLE bit-vectors - 40-odd
-    // states for a 6-row needle - so that the filter is the same v_perm + ds_read_u8 per byte as the 0-typo one (k1_dfa: 55 us on the
-    // 10 M x 32 B list) instead of a table lookup + four vector operations (k1_filter: 71 us).  States are numbered by ascending LCS, so
-    // "accepts" is one compare; the start state (LCS 0, only reachable as itself) is state 0.  More than 226 states (long needles with
-    // many distinct letters): the bit-vector kernel stays.  FZB_NO_LCS_DFA=1 keeps it for comparison.
-    m->lcs_states = 0;
-    if (lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !fzb_knobs().no_lcs_dfa) {
-        const u64 mask = m->rows >= 64 ? ~(u64)0 : (((u64)1 << m->rows) - 1);
-        std::vector<u64> masks;  // distinct M over the 256 byte values
-        std::vector<int> mask_of(256);
-        for (int b = 0; b < 256; b++) {
-            const u64 mb = m->table[b] & mask;
-            size_t q = 0;
-            while (q < masks.size() && masks[q] != mb) q++;
-            if (q == masks.size()) masks.push_back(mb);
-            mask_of[b] = (int)q;
-        }
-        std::vector<u64> states{mask};  // V0: all ones in the low `rows` bits
-        std::unordered_map<u64, int> id{{mask, 0}};
-        std::vector<std::vector<int>> next;
-        bool ok = true;
-        for (size_t q = 0; q < states.size() && ok; q++) {
-            const u64 v = states[q];
-            std::vector<int> row(masks.size());
-            for (size_t t = 0; t < masks.size(); t++) {
-                const u64 u = v & masks[t];
-                const u64 nv = ((v + u) | (v & ~masks[t])) & mask;
-                auto it = id.find(nv);
-                if (it == id.end()) {
-                    it = id.emplace(nv, (int)states.size()).first;
-                    states.push_back(nv);
-                    if (states.size() > 226) ok = false;
-                }
-                row[t] = it->second;
-            }
-            next.push_back(row);
-        }
-        if (ok) {
-            const int ns = (int)states.size();
-            const int need = m->rows - k;
-            std::vector<int> lcs(ns), order(ns), renum(ns);
-            for (int q = 0; q < ns; q++) lcs[q] = __builtin_popcountll(~states[q] & mask), order[q] = q;
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lcs[a] < lcs[b]; });  // V0 (LCS 0, first created) stays first
-            int acc = ns;
-            for (int pos = 0; pos < ns; pos++) {
-                renum[order[pos]] = pos;
-                if (lcs[order[pos]] >= need && acc == ns) acc = pos;
-            }
-            m->lcs_dfa.assign((size_t)ns * 256, 0);
-            for (int q = 0; q < ns; q++)
-                for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[q][mask_of[b]]];
-            m->lcs_states = ns;
-            m->lcs_acc_lo = acc;
-        }
-    }
-    // The class-composite form of the automaton the streaming filter runs (ragged lists: kernels_filter.hip, k1_cdfa_ragged): bytes with
-    // identical columns are one class (K of them), G transitions are composed into one table indexed by
-    // state * K^G + c0 + K c1 + ... (c0 = the class of the FIRST byte), G = 4 if states * K^4 <= 16 KB, else 2, else none.
-    m->cdfa.clear();
-    m->cdfa_src = m->cdfa_K = m->cdfa_G = 0;
-    {
-        const std::vector<u8>* fa = nullptr;
-        int fstates = 0, src = 0;
-        if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
-        else if (m->literal_mode) {}
-        else if (m->uni_dfa_states) { fa = &m->uni_dfa; fstates = m->uni_dfa_states; src = 2; }
-        else if (lc.filter_mode == 2 && m->lcs_states) { fa = &m->lcs_dfa; fstates = m->lcs_states; src = 3; }
-        else if (lc.filter_mode == 1) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
-        if (fa && fstates >= 1 && fstates <= 255) {
-            std::vector<int> cls(256, -1);
-            std::vector<int> rep;  // a representative byte per class
+    for (int b = 0; b < 256; b++) m->dfa[(size_t)n * 256 + b] = (u8)n;  // found: absorbing
+}
+}
+
+static void build_unicode_dfa(fzb_matcher* m) {
+    const fzb_config* config = &m->config;
+    const NeedleDev& nd = m->nd;
+    const LaunchCfg& lc = m->lc;
+// Unicode path, 0 typos: the prefilter accepts iff the needle's scalars occur, in order, at increasing byte positions, each as its own
+// bytes or as the bytes of its same-width case flip (src/prefilter/algo/unicode.rs:118-219; the same at 16 / 32 / 64 lanes - checked
+// against the oracle by tests/test_host_abi.py::test_unicode_dfa_is_the_unicode_prefilter).  That is a byte-level DFA: state = (scalars
+// matched, bytes of the current scalar matched, which of the two variants are still alive); a mismatch inside a scalar falls back to
+// "is this byte the scalar's first byte" (UTF-8 lead bytes never occur inside a scalar, so no longer border exists).  With <= 226
+// states it runs in the streaming DFA filter kernels unchanged and replaces superset filter + lane-exact window pass + second compaction.
+m->uni_dfa_states = 0;
+if (m->unicode && !m->literal_mode && config->max_typos == 0 && m->rows >= 1 && lc.filter_mode == 1) {
+    struct St { int i, k, alive; };
+    std::vector<St> states;
+    auto find = [&](int i, int k, int alive) {
+        for (size_t q = 0; q < states.size(); q++)
+            if (states[q].i == i && states[q].k == k && states[q].alive == alive) return (int)q;
+        states.push_back(St{i, k, alive});
+        return (int)states.size() - 1;
+    };
+    std::vector<std::vector<int>> trans;
+    find(0, 0, 3);
+    bool ok = true;
+    for (size_t q = 0; q < states.size() && ok; q++) {
+        const St cur = states[q];
+        std::vector<int> row(256, (int)q);
+        if (cur.i < m->rows) {
+            const u8* va = nd.uc[cur.i];
+            const u8* vb = nd.uf[cur.i];
+            const int len = nd.ulen[cur.i];
+            auto from_start = [&](int b) {  // state (i, 0) reading b
+                const int alive = (va[0] == b ? 1 : 0) | (vb[0] == b ? 2 : 0);
+                if (!alive) return find(cur.i, 0, 3);
+                return len == 1 ? find(cur.i + 1, 0, 3) : find(cur.i, 1, alive);
+            };
             for (int b = 0; b < 256; b++) {
-                for (size_t q = 0; q < rep.size() && cls[b] < 0; q++) {
-                    bool same = true;
-                    for (int stt = 0; stt < fstates && same; stt++) same = (*fa)[(size_t)stt * 256 + b] == (*fa)[(size_t)stt * 256 + rep[q]];
-                    if (same) cls[b] = (int)q;
-                }
-                if (cls[b] < 0) { cls[b] = (int)rep.size(); rep.push_back(b); }
+                if (cur.k == 0) { row[b] = from_start(b); continue; }
+                const int alive = ((cur.alive & 1) && va[cur.k] == b ? 1 : 0) | ((cur.alive & 2) && vb[cur.k] == b ? 2 : 0);
+                if (alive) row[b] = cur.k + 1 == len ? find(cur.i + 1, 0, 3) : find(cur.i, cur.k + 1, alive);
+                else row[b] = from_start(b);
             }
-            const size_t K = rep.size();
-            int G = 0;
-            if ((size_t)fstates * K * K * K * K <= 16384) G = 4;
-            else if ((size_t)fstates * K * K <= 16384) G = 2;
-            if (G) {
-                size_t KG = 1;
-                for (int i = 0; i < G; i++) KG *= K;
-                m->cdfa.assign(((256 + (size_t)fstates * KG) + 15) & ~(size_t)15, 0);
-                for (int b = 0; b < 256; b++) m->cdfa[b] = (u8)cls[b];
-                for (int stt = 0; stt < fstates; stt++)
-                    for (size_t off = 0; off < KG; off++) {
-                        int cur = stt;
-                        size_t rest = off;
-                        for (int i = 0; i < G; i++) {  // c0 (the least significant digit) is consumed first
-                            cur = (*fa)[(size_t)cur * 256 + rep[rest % K]];
-                            rest /= K;
-                        }
-                        m->cdfa[256 + (size_t)stt * KG + off] = (u8)cur;
+        }  // i == rows: accepting, absorbing
+        trans.push_back(row);
+        if (states.size() > 226) ok = false;  // 226 x 288 bytes (dfa_lds.h's row stride) + the tile counter fit the 64 KiB of dynamic LDS
+    }
+    if (ok) {
+        // renumber so that the accepting state is the LAST one (the kernels test `state == number of states - 1`)
+        const int ns = (int)states.size();
+        int acc = -1;
+        for (int q = 0; q < ns; q++)
+            if (states[q].i == m->rows) acc = q;
+        std::vector<int> renum(ns);
+        for (int q = 0, nx = 0; q < ns; q++) renum[q] = q == acc ? ns - 1 : nx++;
+        m->uni_dfa.assign((size_t)ns * 256, 0);
+        for (int q = 0; q < ns; q++)
+            for (int b = 0; b < 256; b++) m->uni_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[trans[q][b]];
+        m->uni_dfa_states = ns;  // start state 0 = (0, 0): first created, never the accepting one (rows >= 1)
+    }
+}
+}
+
+static void build_lcs_dfa(fzb_matcher* m) {
+    const LaunchCfg& lc = m->lc;
+    const int k = m->config.max_typos;
+// Typo configurations: the streaming filter's LCS criterion `LCS(needle, haystack) >= rows - k` (Hyyro's bit-vector recurrence
+// V' = (V + (V & M)) | (V & ~M), M = the rows byte b can match) as a table-driven automaton over its REACHABLE bit-vectors - 40-odd
+// states for a 6-row needle - so that the filter is the same v_perm + ds_read_u8 per byte as the 0-typo one (k1_dfa: 55 us on the
+// 10 M x 32 B list) instead of a table lookup + four vector operations (k1_filter: 71 us).  States are numbered by ascending LCS, so
+// "accepts" is one compare; the start state (LCS 0, only reachable as itself) is state 0.  More than 226 states (long needles with
+// many distinct letters): the bit-vector kernel stays.  FZB_NO_LCS_DFA=1 keeps it for comparison.
+m->lcs_states = 0;
+if (lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !fzb_knobs().no_lcs_dfa) {
+    const u64 mask = m->rows >= 64 ? ~(u64)0 : (((u64)1 << m->rows) - 1);
+    std::vector<u64> masks;  // distinct M over the 256 byte values
+    std::vector<int> mask_of(256);
+    for (int b = 0; b < 256; b++) {
+        const u64 mb = m->table[b] & mask;
+        size_t q = 0;
+        while (q < masks.size() && masks[q] != mb) q++;
+        if (q == masks.size()) masks.push_back(mb);
+        mask_of[b] = (int)q;
+    }
+    std::vector<u64> states{mask};  // V0: all ones in the low `rows` bits
+    std::unordered_map<u64, int> id{{mask, 0}};
+    std::vector<std::vector<int>> next;
+    bool ok = true;
+    for (size_t q = 0; q < states.size() && ok; q++) {
+        const u64 v = states[q];
+        std::vector<int> row(masks.size());
+        for (size_t t = 0; t < masks.size(); t++) {
+            const u64 u = v & masks[t];
+            const u64 nv = ((v + u) | (v & ~masks[t])) & mask;
+            auto it = id.find(nv);
+            if (it == id.end()) {
+                it = id.emplace(nv, (int)states.size()).first;
+                states.push_back(nv);
+                if (states.size() > 226) ok = false;
+            }
+            row[t] = it->second;
+        }
+        next.push_back(row);
+    }
+    if (ok) {
+        const int ns = (int)states.size();
+        const int need = m->rows - k;
+        std::vector<int> lcs(ns), order(ns), renum(ns);
+        for (int q = 0; q < ns; q++) lcs[q] = __builtin_popcountll(~states[q] & mask), order[q] = q;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lcs[a] < lcs[b]; });  // V0 (LCS 0, first created) stays first
+        int acc = ns;
+        for (int pos = 0; pos < ns; pos++) {
+            renum[order[pos]] = pos;
+            if (lcs[order[pos]] >= need && acc == ns) acc = pos;
+        }
+        m->lcs_dfa.assign((size_t)ns * 256, 0);
+        for (int q = 0; q < ns; q++)
+            for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[q][mask_of[b]]];
+        m->lcs_states = ns;
+        m->lcs_acc_lo = acc;
+    }
+}
+}
+
+static void build_cdfa(fzb_matcher* m) {
+    const LaunchCfg& lc = m->lc;
+// The class-composite form of the automaton the streaming filter runs (ragged lists: kernels_filter.hip, k1_cdfa_ragged): bytes with
+// identical columns are one class (K of them), G transitions are composed into one table indexed by
+// state * K^G + c0 + K c1 + ... (c0 = the class of the FIRST byte), G = 4 if states * K^4 <= 16 KB, else 2, else none.
+m->cdfa.clear();
+m->cdfa_src = m->cdfa_K = m->cdfa_G = 0;
+{
+    const std::vector<u8>* fa = nullptr;
+    int fstates = 0, src = 0;
+    if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
+    else if (m->literal_mode) {}
+    else if (m->uni_dfa_states) { fa = &m->uni_dfa; fstates = m->uni_dfa_states; src = 2; }
+    else if (lc.filter_mode == 2 && m->lcs_states) { fa = &m->lcs_dfa; fstates = m->lcs_states; src = 3; }
+    else if (lc.filter_mode == 1) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
+    if (fa && fstates >= 1 && fstates <= 255) {
+        std::vector<int> cls(256, -1);
+        std::vector<int> rep;  // a representative byte per class
+        for (int b = 0; b < 256; b++) {
+            for (size_t q = 0; q < rep.size() && cls[b] < 0; q++) {
+                bool same = true;
+                for (int stt = 0; stt < fstates && same; stt++) same = (*fa)[(size_t)stt * 256 + b] == (*fa)[(size_t)stt * 256 + rep[q]];
+                if (same) cls[b] = (int)q;
+            }
+            if (cls[b] < 0) { cls[b] = (int)rep.size(); rep.push_back(b); }
+        }
+        const size_t K = rep.size();
+        int G = 0;
+        if ((size_t)fstates * K * K * K * K <= 16384) G = 4;
+        else if ((size_t)fstates * K * K <= 16384) G = 2;
+        if (G) {
+            size_t KG = 1;
+            for (int i = 0; i < G; i++) KG *= K;
+            m->cdfa.assign(((256 + (size_t)fstates * KG) + 15) & ~(size_t)15, 0);
+            for (int b = 0; b < 256; b++) m->cdfa[b] = (u8)cls[b];
+            for (int stt = 0; stt < fstates; stt++)
+                for (size_t off = 0; off < KG; off++) {
+                    int cur = stt;
+                    size_t rest = off;
+                    for (int i = 0; i < G; i++) {  // c0 (the least significant digit) is consumed first
+                        cur = (*fa)[(size_t)cur * 256 + rep[rest % K]];
+                        rest /= K;
                     }
-                m->cdfa_src = src;
-                m->cdfa_K = (int)K;
-                m->cdfa_G = G;
-            }
+                    m->cdfa[256 + (size_t)stt * KG + off] = (u8)cur;
+                }
+            m->cdfa_src = src;
+            m->cdfa_K = (int)K;
+            m->cdfa_G = G;
         }
     }
+}
+}
+
+// which forms of the scorers this needle and scoring allow
+static void set_scorer_forms(fzb_matcher* m, const uint8_t* needle_utf8, size_t needle_len) {
+    const fzb_scoring& sc = m->config.scoring;
+    LaunchCfg& lc = m->lc;
     lc.pad_ok = 1;
     for (size_t i = 0; i < needle_len; i++)
         if (needle_utf8[i] == 0) lc.pad_ok = 0;
@@ -590,7 +532,79 @@ int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, siz
     lc.cf_ok = lc.pad_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty &&
                max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 < 0x7C00;
     lc.cfu_ok = lc.bias_ok && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty && !fzb_knobs().no_dp_cfu;  // (knob: the unicode scorer's first form)
-    *out = m;
+}
+
+int fzb_matcher_create(const fzb_config* config, const uint8_t* needle_utf8, size_t needle_len, fzb_matcher** out) {
+    if (!config || !out || (!needle_utf8 && needle_len)) return fail(FZB_ERR_INVALID, "null argument");
+    if (config->casing < 0 || config->casing > 2 || config->unicode < 0 || config->unicode > 2 || config->sort < 0 || config->sort > 3 || config->max_typos < -1 ||
+        config->max_typos > 0xFFFF)
+        return fail(FZB_ERR_INVALID, "config enum/range out of bounds");
+    std::vector<u32> cps;
+    if (!decode_utf8(needle_utf8, needle_len, cps)) return fail(FZB_ERR_INVALID, "needle is not valid UTF-8");
+    std::unique_ptr<fzb_matcher> mp(new fzb_matcher());
+    fzb_matcher* m = mp.get();
+    m->config = *config;
+    m->needle.assign((const char*)needle_utf8, needle_len);
+    m->empty = needle_len == 0;
+    const fzb_scoring& sc = config->scoring;
+    m->use_u8 = fits_in_u8(needle_len, sc);  // byte length (src/matcher/mod.rs:453)
+    int pf = config->pf_lanes, sw = config->sw_lanes;
+    if (pf == 0 && sw == 0) detect_host_lanes(m->use_u8, pf, sw);
+    else if (sw == 0) sw = m->use_u8 ? pf : pf / 2;  // the score width of the ISA family whose prefilter has pf lanes (64: AVX-512, 32: AVX2, 16: SSE/scalar)
+    if (!(pf == 16 || pf == 32 || pf == 64) || !(sw == 8 || sw == 16 || sw == 32 || sw == 64))
+        return fail(FZB_ERR_INVALID, "pf_lanes must be 16/32/64 and sw_lanes 8/16/32/64 (or both 0 = auto)");
+    m->lc.pf_lanes = pf;
+    m->lc.sw_lanes = sw;
+    if (m->empty) {  // CompiledPatterns::Empty (src/matcher/mod.rs:194-196)
+        *out = mp.release();
+        return FZB_OK;
+    }
+    // CaseMatching::respects_case_for (src/lib.rs:370-376), UnicodeMatching::respects_unicode_for (:394-400)
+    bool any_upper = false, ascii = true;
+    for (u32 cp : cps) { any_upper |= is_uppercase(cp); ascii &= cp < 0x80; }
+    m->case_sensitive = config->casing == FZB_CASE_RESPECT || (config->casing == FZB_CASE_SMART && any_upper);
+    m->unicode = config->unicode == FZB_UNICODE_ALWAYS || (config->unicode == FZB_UNICODE_SMART && !ascii);
+    m->rows = (int)(m->unicode ? cps.size() : needle_len);
+    if (config->matching < FZB_MATCH_FUZZY || config->matching > FZB_MATCH_SUBSTRING) return fail(FZB_ERR_INVALID, "bad matching mode");
+    m->literal_mode = config->matching;
+    // guard_against_score_overflow: fuzzy src/matcher/algo.rs:311-325 (rows); literal src/literal/algo.rs:33, 314-322 (needle bytes, its own per-char bonus)
+    std::string perr = m->literal_mode ? overflow_guard(sc, needle_len, sadd16(std::max(sc.capitalization_bonus, sc.delimiter_bonus), sc.matching_case_bonus), 0)
+                                       : overflow_guard(sc, (size_t)m->rows);
+    if (!perr.empty()) return fail(FZB_ERR_PANIC, perr);
+    // beyond NeedleDev's by-value arrays: the needle's arrays go to device memory (NeedleLongDev) and the query runs through the
+    // kernels that take it from there (run_pipeline_long) - any length the reference's guard above accepted
+    m->long_needle = needle_len > FZB_MAX_NEEDLE_BYTES || m->rows > FZB_MAX_ROWS;
+    fill_needle_scalars(m, needle_len, cps.size());
+    if (m->long_needle) {
+        build_long_needle(m, needle_utf8, needle_len, cps);
+        *out = mp.release();
+        return FZB_OK;
+    }
+    NeedleDev& nd = m->nd;
+    for (size_t i = 0; i < needle_len; i++) {  // case_needle (src/prefilter/mod.rs:49-65)
+        nd.raw[i] = nd.c[i] = needle_utf8[i];
+        nd.f[i] = flip_ascii_byte(m, needle_utf8[i]);
+    }
+    for (size_t i = 0; i < cps.size() && cps.size() <= FZB_MAX_ROWS; i++) {  // case_needle_unicode (src/prefilter/mod.rs:71-96)
+        nd.ulen[i] = (u8)encode_utf8(cps[i], nd.uc[i]);
+        encode_utf8(m->case_sensitive ? cps[i] : flip_same_width(cps[i]), nd.uf[i]);
+    }
+    // ---- filter-stage configuration --------------------------------------------------------------
+    const int k = config->max_typos;
+    LaunchCfg& lc = m->lc;
+    if (k < 0 || k >= m->rows) {        // NO_PREFILTER, or `needle_len <= max_typos => (true, 0, len)`
+        lc.filter_mode = 0; lc.filter_exact = 1; lc.window_mode = 2;
+    } else if (!m->unicode && k == 0) { // exact: ordered subsequence; window = first/last occurrence
+        lc.filter_mode = 1; lc.filter_exact = 1; lc.window_mode = 1;
+    } else {                            // superset filter, lane-exact prefilter re-decides
+        lc.filter_mode = k == 0 ? 1 : 2; lc.filter_exact = 0; lc.window_mode = 0;
+    }
+    build_filter_tables(m);
+    build_unicode_dfa(m);
+    build_lcs_dfa(m);
+    build_cdfa(m);
+    set_scorer_forms(m, needle_utf8, needle_len);
+    *out = mp.release();
     return FZB_OK;
 }
 
@@ -971,20 +985,6 @@ static int ensure_dp_scratch(fzb_matcher* m, int mgrid) {  // parked rows of the
     w.dp_scratch_words = words;
     return FZB_OK;
 }
-static int ensure_stage(fzb_matcher* m, size_t count) {  // the filter -> scorer handoff of a ragged list (Workspace::stage)
-    Workspace& w = m->ws;
-    if (w.cap_stage >= count && w.stage) return FZB_OK;
-    for (void* p : {(void*)w.stage, (void*)w.stage_hdr, (void*)w.tile_prefix})
-        if (p) HIPCHK(hipFree(p));
-    w.stage = nullptr; w.stage_hdr = nullptr; w.tile_prefix = nullptr; w.cap_stage = 0;
-    const size_t cap = std::max(count, w.cap_items);
-    const size_t ntiles = (cap + FZB_TILE - 1) / FZB_TILE + 1;
-    HIPCHK(dev_alloc((void**)&w.stage, ntiles * FZB_STAGE_UNITS * 16 + 256));
-    HIPCHK(dev_alloc((void**)&w.stage_hdr, ntiles * FZB_TILE * 4));
-    HIPCHK(dev_alloc((void**)&w.tile_prefix, ntiles * 4));
-    w.cap_stage = cap;
-    return FZB_OK;
-}
 static int ensure_sort_buffers(fzb_matcher* m, size_t cap) {  // ping-pong buffer + tile histograms of the device radix sort
     Workspace& w = m->ws;
     if (w.sort_cap >= cap && w.sort_tmp) return FZB_OK;
@@ -1011,11 +1011,7 @@ int fzb_ensure_out_staging(fzb_matcher* m, size_t count) {  // device-side resul
 }
 extern "C" {
 
-// The pipeline.  items_in == nullptr: the haystacks are the contiguous range [first, first + count).  Otherwise they are the
-// listed ones, items_in[j] = index relative to `first`, *n_items_in of them (a device-side count <= count): the narrowing
-// step of the multi-pattern composition.
-// `trace` != nullptr: the matched-indices form - every record also gets its matched byte positions (the traced generic scorer
-// replaces the fast scorers; literal modes write the needle run).
+// matched-indices form of a query: where the positions go
 struct TraceOut {
     u32* pos;
     u32* npos;
@@ -1099,7 +1095,7 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     const size_t dpl_words = fzb_dp_long_scratch_words_per_thread(m->ndl, m->lc.sw_lanes);
     const size_t dfit = std::min<size_t>((size_t)cus * 8, budget / std::max<size_t>(dpl_words * 4 * 128, 1));  // 128-thread workgroups the slab has room for
     const int dgrid = (int)std::max<size_t>(1, std::min<size_t>(dfit, (count + 127) / 128));
-    const bool thread_per_window = !trace && !m->ndl.unicode && !fzb_knobs().long_generic_only && dfit >= (size_t)std::max(1, cus / 2);
+    const bool thread_per_window = !trace && !m->ndl.unicode && dfit >= (size_t)std::max(1, cus / 2);
     const size_t dpl_bytes = thread_per_window ? dpl_words * 4 * 128 * (size_t)dgrid : 0;
     const bool greedy_possible = !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN);
     if (thread_per_window && !greedy_possible) ggrid = 1;  // (no launch of the wave-per-haystack kernel: its slab is not needed)
@@ -1118,13 +1114,13 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     else HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&cnt_c[0], (int)cnt, 1, st));
     // the streaming filter as first stage (0 typos, ASCII, up to 200 rows: fzb_matcher_create built the automaton) over a contiguous range;
     // the scorer then finds the lane-free window itself (wmode 1), as for short needles
-    const bool use_dfa = m->long_dfa && thread_per_window && !items_in && !fzb_knobs().long_generic_only;
+    const bool use_dfa = m->long_dfa && thread_per_window && !items_in;
     if (use_dfa) {
         if (pev) HIPCHK(hipEventRecord(pev[2], st));
         fzb_launch_filter(cd, first, cnt, w.table, w.dfa, m->lc.dead_byte, m->ndl.rows, 1, m->ndl.rows, (u32)m->ndl.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
-                          nullptr, nullptr, nullptr, m->lc.pad_ok, -1, nullptr, 0u, 0, 0, nullptr);
+                          nullptr, nullptr, nullptr, m->lc.pad_ok, -1, nullptr, 0u, 0, 0);
         if (pev) HIPCHK(hipEventRecord(pev[3], st));
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st, nullptr);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
         items = w.surv_idx;
         n_items_ptr = &cnt_c[0];
         wmode = 1;
@@ -1156,6 +1152,342 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     return FZB_OK;
 }
 
+// ---- the pipeline of a SHORT needle (NeedleDev by value), one function per path ------------------------------------------------------
+// counters: [0]=filter survivors [1]=kept by the lane-exact prefilter [3]=multi-chunk queue [4]=generic (greedy / wide unicode) queue
+// [5]=marginal survivors [6]=rejected marginal survivors [8..10]=single-chunk classes [12..15]=multi-chunk tail classes
+struct Pipe {
+    fzb_matcher* m;
+    const CorpusDev& cd;
+    size_t first;
+    u32 cnt, index_offset;
+    const u32* items_in;     // item list (indices relative to `first`) or nullptr = the contiguous range
+    const u32* n_items_in;
+    fzb_match_rec* out;
+    u32 cap32;
+    uint32_t* dev_count;
+    hipStream_t st;
+    const TraceOut* trace;
+    hipEvent_t* pev;         // profiling events of this call (nullptr: not profiled)
+    int cus;
+    // what the filter stage leaves for the scorers
+    const u32* items = nullptr;
+    const u32* win = nullptr;
+    const u32* n_items_ptr = nullptr;
+    int wmode = 0;
+};
+#define FZB_STAGE(name)                                                                                        \
+    do {                                                                                                       \
+        if (fzb_knobs().debug_sync) { /* debugging aid: synchronise and report after every stage */            \
+            hipError_t e_ = hipStreamSynchronize(p.st);                                                        \
+            fprintf(stderr, "[fzb] stage %s: %s\n", name, hipGetErrorString(e_));                              \
+            if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
+        }                                                                                                      \
+    } while (0)
+#define FZB_PEV(i)                                                    \
+    do {                                                              \
+        if (p.pev) HIPCHK(hipEventRecord(p.pev[i], p.st));            \
+    } while (0)
+
+// literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
+static int pipe_literal(Pipe& p) {
+    fzb_matcher* m = p.m;
+    Workspace& w = m->ws;
+    const NeedleDev& nd = m->nd;
+    u32* cnt_c = w.counters;
+    if (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode && !p.items_in)  // the streaming DFA filter over the needle's KMP automaton
+        fzb_launch_filter(p.cd, p.first, p.cnt, w.table, w.dfa, m->lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, p.cus * 8, p.st, nullptr, nullptr, nullptr, nullptr,
+                          m->lc.pad_ok, -1, m->cdfa_src == 1 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
+    else
+        fzb_launch_literal_filter(p.cd, p.first, p.cnt, p.items_in, p.n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, p.cus * 8, p.st);
+    FZB_STAGE("literal filter");
+    fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, p.items_in ? p.n_items_in : nullptr, p.items_in, w.surv_idx, &cnt_c[0], p.cus * 2, p.st);
+    FZB_STAGE("literal compact");
+    fzb_launch_literal_score(p.cd, p.first, p.index_offset, w.surv_idx, &cnt_c[0], nd, m->literal_mode, p.out, p.cap32, p.dev_count, p.trace ? p.trace->pos : nullptr,
+                             p.trace ? p.trace->npos : nullptr, p.trace ? p.trace->stride : 0u, p.cus * 4, p.st);
+    FZB_STAGE("literal score");
+    HIPCHK(hipGetLastError());
+    return FZB_OK;
+}
+
+// Typo configuration, every haystack fits half a score chunk (C3): the LCS criterion decides in the stream (with the "nothing to spare" bit when
+// haystacks can span several PREFILTER chunks: only those marginal survivors are re-decided at the exact lane width, a reject sets a bit), and
+// the short scorer computes the lane-free window itself (DESIGN.md "Typo configurations").  A haystack that fits ONE prefilter chunk is decided
+// exactly by the criterion: the reference's multi-path scan loses a candidate only when a lower path that found nothing more in the current
+// chunk advances again in a later one (tests/test_oracle_reference_properties.py::test_single_chunk_typo_prefilter_is_the_lcs_criterion).
+static int pipe_typo_fast_path(Pipe& p) {
+    fzb_matcher* m = p.m;
+    Workspace& w = m->ws;
+    const LaunchCfg& lc = m->lc;
+    const NeedleDev& nd = m->nd;
+    u32* cnt_c = w.counters;
+    const int need = nd.rows - nd.max_typos;
+    const u32 ntiles = (p.cnt + FZB_TILE - 1) / FZB_TILE;
+    const RejectOut rej{w.reject_bits, w.tile_rejects, w.rej_prefix, &cnt_c[6]};
+    const bool single_chunk = p.cd.max_len <= (u32)lc.pf_lanes;
+    FZB_PEV(2);
+    if (single_chunk && m->lcs_states)  // the LCS criterion as an automaton in the streaming DFA kernel
+        fzb_launch_filter(p.cd, p.first, p.cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, p.cus * 8, p.st, nullptr,
+                          nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
+    else if (single_chunk)
+        fzb_launch_filter(p.cd, p.first, p.cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, p.cus * 8, p.st);
+    else
+        fzb_launch_filter(p.cd, p.first, p.cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, p.cus * 8, p.st, w.bitmap_m,
+                          w.tile_counts_m, w.reject_bits, w.tile_rejects);
+    FZB_PEV(3);
+    FZB_STAGE("filter(lcs)");
+    fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st);
+    if (!single_chunk) {
+        fzb_launch_compact1(w.bitmap_m, w.tile_counts_m, p.cnt, nullptr, nullptr, w.marg_list, &cnt_c[5], p.cus * 4, p.st);
+        FZB_STAGE("compact1 x2");
+        fzb_launch_window(p.cd, p.first, w.marg_list, &cnt_c[5], nd, lc.pf_lanes, nullptr, nullptr, nullptr, cnt_c, p.cus * 4, p.st, &rej);
+        FZB_STAGE("window(decide)");
+        fzb_launch_scan_rejects(w.tile_rejects, ntiles, &cnt_c[6], w.rej_prefix, p.st);
+    }
+    FZB_PEV(4);
+    fzb_launch_dp(p.cd, p.first, p.index_offset, w.surv_idx, nullptr, &cnt_c[0], nd, lc.sw_lanes, 2, 3, lc.pad_ok, p.out, p.cap32, p.dev_count, w.overflow, p.cnt, cnt_c, p.cus, p.st, &rej);
+    FZB_STAGE("dp(short, typo windows)");
+    return FZB_OK;
+}
+
+// Filter stage of every other fuzzy query: streaming filter (or its item-list form) -> compaction [-> lane-exact window kernel -> second
+// compaction when the stream stage was a superset].  Leaves p.items / p.win / p.n_items_ptr / p.wmode for the scorers.
+static int pipe_filter_stage(Pipe& p) {
+    fzb_matcher* m = p.m;
+    Workspace& w = m->ws;
+    const LaunchCfg& lc = m->lc;
+    const NeedleDev& nd = m->nd;
+    u32* cnt_c = w.counters;
+    p.n_items_ptr = &cnt_c[0];
+    p.wmode = lc.window_mode;
+    const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
+    bool uni_exact = false;  // the unicode DFA filter decided exactly: no lane-exact window pass, the scorer computes the window
+    if (p.items_in) {
+        if (lc.filter_mode == 0) {
+            HIPCHK(hipMemcpyAsync(&cnt_c[0], p.n_items_in, 4, hipMemcpyDeviceToDevice, p.st));
+            p.items = p.items_in;
+        } else {
+            fzb_launch_filter_items(p.cd, p.first, p.items_in, p.n_items_in, w.table, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, p.cus * 4, p.st);
+            FZB_STAGE("filter(items)");
+            fzb_launch_compact1(w.bitmap, w.tile_counts, 0, p.n_items_in, p.items_in, w.surv_idx, &cnt_c[0], p.cus * 2, p.st);
+            FZB_STAGE("compact1(items)");
+            p.items = w.surv_idx;
+        }
+    } else if (lc.filter_mode == 0) {
+        // nothing filtered (max_typos = None or >= rows): the survivors are the identity list (counters[0] = the range's size: set by the caller)
+    } else if (m->uni_dfa_states && lc.bias_ok && !p.trace) {
+        // unicode path, 0 typos: the exact prefilter as a byte-level DFA in the streaming filter; the scorer finds the window itself
+        FZB_PEV(2);
+        fzb_launch_filter(p.cd, p.first, p.cnt, w.table, w.uni_dfa, lc.dead_byte, m->uni_dfa_states - 1, 1, 0, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, p.cus * 8, p.st, nullptr,
+                          nullptr, nullptr, nullptr, lc.pad_ok, -1, m->cdfa_src == 2 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
+        FZB_PEV(3);
+        FZB_STAGE("filter(unicode dfa)");
+        fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st, &cnt_c[1]);  // (kept by the exact prefilter = the filter's survivors)
+        FZB_STAGE("compact1");
+        p.items = w.surv_idx;
+        uni_exact = true;
+    } else {
+        FZB_PEV(2);
+        if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
+            fzb_launch_filter(p.cd, p.first, p.cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, p.cus * 8, p.st, nullptr,
+                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
+        else
+            fzb_launch_filter(p.cd, p.first, p.cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, p.cus * 8, p.st, nullptr, nullptr,
+                              nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
+        FZB_PEV(3);
+        FZB_STAGE("filter");
+        fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st);
+        FZB_STAGE("compact1");
+        p.items = w.surv_idx;
+    }
+    if (uni_exact) {
+        p.wmode = 1;
+    } else if (!lc.filter_exact) {
+        // the stream stage was a superset: re-decide every survivor with the reference's chunked algorithm at its exact lane width
+        fzb_launch_window(p.cd, p.first, p.items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, p.cus * 4, p.st, nullptr, p.items_in ? 0u : p.cnt);
+        FZB_STAGE("window");
+        fzb_launch_compact2(w.bitmap2, w.tile_counts2, &cnt_c[0], p.items, w.win, w.items2, w.win2, &cnt_c[1], p.cus * 2, p.st);
+        FZB_STAGE("compact2");
+        p.items = w.items2;
+        p.win = w.win2;
+        p.n_items_ptr = &cnt_c[1];
+        p.wmode = 0;
+    }
+    return FZB_OK;
+}
+
+// The queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back.  Every item is queued at
+// most once by its scorer (front + back <= cnt), and the thread-per-haystack unicode scorer may hand up to FZB_UNICODE_FWD_CAP of the front's
+// windows on to the back WHILE the front is still being read: the back gets that many entries of room of its own below the front's reach
+// (ensure_workspace: the allocation holds at least count + FZB_UNICODE_FWD_CAP entries)
+static u32 pipe_qcap(const Pipe& p) { return (u32)std::min<u64>((u64)p.cnt + FZB_UNICODE_FWD_CAP, 0xFFFFFFFFull); }
+
+// matched indices: one traced generic scorer for every window width, ASCII and unicode (kernels_generic.hip)
+static int pipe_score_traced(Pipe& p) {
+    fzb_matcher* m = p.m;
+    Workspace& w = m->ws;
+    const int tgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)p.cus / 2, ((size_t)p.cnt + 3) / 4));
+    const size_t words = fzb_trace_scratch_words(m->nd, tgrid);
+    if (w.trace_cells_words < words) {
+        if (w.trace_cells) HIPCHK(hipFree(w.trace_cells));
+        w.trace_cells = nullptr;
+        w.trace_cells_words = 0;
+        HIPCHK(dev_alloc((void**)&w.trace_cells, words * 4));
+        w.trace_cells_words = words;
+    }
+    fzb_launch_generic_trace(p.cd, p.first, p.index_offset, p.items, p.win, p.wmode, p.n_items_ptr, m->nd, m->lc.sw_lanes, m->nd.unicode, p.out, p.cap32, p.dev_count, w.counters, w.trace_cells,
+                             p.trace->pos, p.trace->npos, p.trace->stride, tgrid, p.st);
+    FZB_STAGE("generic(trace)");
+    return FZB_OK;
+}
+
+// Unicode scorers.  Single-chunk windows: k2u_dp_unicode (thread per haystack).  Windows wider than a chunk: up to 1024 bytes into the FRONT of the
+// queue, beyond that (greedy fallback) into its back.  The front has two takers, chosen on the device by its length: the thread-per-haystack
+// multi-chunk scorer (k2u_dp_unicode_multi: several times fewer instructions, but one wave per SIMD and ~ 10-20 us per chunk - a fixed latency of
+// ~ 100 us, then 0.3 ns per window) from `umin` windows on, the wave-per-haystack kernel (1.6 - 2.7 ns per window, no fixed cost) below
+// (45 k windows 0.215 ms wave per haystack / 0.204 thread per haystack, 361 k windows 1.285 / 0.815).  FZB_UNICODE_MULTI=0 / 1: never / always.
+static int pipe_score_unicode(Pipe& p) {
+    fzb_matcher* m = p.m;
+    Workspace& w = m->ws;
+    const LaunchCfg& lc = m->lc;
+    const NeedleDev& nd = m->nd;
+    const FzbKnobs& kn = fzb_knobs();
+    const CorpusDev& cd = p.cd;
+    u32* cnt_c = w.counters;
+    const int cus = p.cus;
+    const u32 qcap = pipe_qcap(p);
+    const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
+    int rc;
+    // (a range smaller than the switch point cannot queue that many windows: the thread-per-haystack scorer is not even launched)
+    const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : p.cnt < (u32)cus * 128u ? 0xFFFFFFFFu : (u32)cus * 128u;
+    const int ugrid = cus * 2;  // multi-chunk unicode scorer: one wave per SIMD (two-wave workgroups)
+    if (umin != 0xFFFFFFFFu && (rc = ensure_dp_scratch(m, ugrid))) return rc;  // first use only (or fzb_matcher_reserve)
+    // Whole-haystack windows (max_typos: None): the wide ones are known from the end offsets, so they are queued FIRST and their scorers run
+    // on the second stream beside the single-chunk scorer (Arabic-shaped list, All Scores: the two took 90 + 100 us one after the other)
+    bool presplit = p.wmode == 2 && !p.items && !no_wide && !kn.debug_sync;  // (no item list: the number of windows is the range's size)
+    if (presplit && ensure_aux_stream(m) != FZB_OK) {  // no second stream: the scorer queues them itself (the error text is dropped with the fallback)
+        presplit = false;
+        fzb_clear_error();
+    }
+    hipStream_t wst = p.st;  // the stream of the wide windows' scorers
+    if (presplit) {
+        fzb_launch_unicode_split_wide(cd, p.first, p.items, p.n_items_ptr, lc.sw_lanes, p.cap32, w.overflow, qcap, cnt_c, (int)std::min<u32>((p.cnt + 2047u) / 2048u, (u32)cus * 4u), p.st);
+        HIPCHK(hipEventRecord(m->ev_fork, p.st));
+        HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
+        wst = m->aux_stream;
+    }
+    // (presplit: the wide windows' kernels are enqueued FIRST - a few hundred long-running waves that take their SIMDs and keep them - and the
+    // single-chunk scorer runs as one short-lived workgroup per 128 items, which fills the rest of the chip and every SIMD a wide wave frees)
+    auto launch_single = [&]() {
+        fzb_launch_dp_unicode(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, p.wmode, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, cus, p.st, lc.cfu_ok,
+                              presplit ? 2 : 1, presplit ? (int)((p.cnt + 127) / 128) : 0);
+    };
+    if (!presplit) launch_single();
+    FZB_STAGE("dp(unicode)");
+    if (no_wide) return FZB_OK;
+    // (the thread-per-haystack scorer hands windows beyond four chunks - up to FZB_UNICODE_FWD_CAP of them - on to the queue's back)
+    const u32 fwd_cap = umin != 0xFFFFFFFFu ? FZB_UNICODE_FWD_CAP : 0u;
+    if (umin != 0xFFFFFFFFu)
+        fzb_launch_dp_unicode_multi(cd, p.first, p.index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, p.out, p.cap32, w.dp_scratch, ugrid, wst, umin, lc.cfu_ok, cnt_c, w.overflow + 4 * (size_t)qcap, fwd_cap);
+    // The queue's back - handed-on stragglers (DP) and windows beyond 1024 bytes (greedy) - has a launch of its own only where windows beyond
+    // 1024 bytes can exist; otherwise the front's wave-per-haystack launch (12 workgroups per CU: its LDS follows the needle's rows, so its
+    // registers decide the occupancy), which has nothing to do exactly when the thread-per-haystack scorer ran, walks the back then
+    const bool back_launch = !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN);
+    const bool may_fwd = fwd_cap != 0 && !(cd.max_len != 0 && cd.max_len <= 4u * (u32)lc.sw_lanes);
+    if (umin != 0u)
+        fzb_launch_generic(cd, p.first, p.index_offset, p.items, p.win, p.wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, p.out, p.cap32, nullptr, cnt_c, cus * 12, wst, 1, umin,
+                           (may_fwd && !back_launch) ? w.overflow + 4 * (size_t)qcap : nullptr, &cnt_c[4]);
+    FZB_STAGE("dp(unicode, wide windows)");
+    if (back_launch || (may_fwd && umin == 0u)) {
+        fzb_launch_generic(cd, p.first, p.index_offset, p.items, p.win, p.wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, p.out, p.cap32, nullptr, cnt_c,
+                           may_fwd ? cus * 4 : cus / 4 + 1, wst);
+        FZB_STAGE("generic(unicode, stragglers + greedy)");
+    }
+    if (presplit) {
+        launch_single();
+        HIPCHK(hipEventRecord(m->ev_join, m->aux_stream));
+        HIPCHK(hipStreamWaitEvent(p.st, m->ev_join, 0));
+    }
+    return FZB_OK;
+}
+
+// ASCII scorers.  Lists whose haystacks fit half a chunk: k2b_dp_short (inside fzb_launch_dp).  Ragged lists under dp_cf.h's preconditions:
+// k2w_classify finds window and class per survivor, then ONE launch (k2_classes_all) scores the three single-chunk classes and the
+// multi-chunk windows by the width of their last chunk's tail (DESIGN.md "Scorers of a ragged list").  Scorings outside dp_cfm.h's preconditions
+// keep the classes but send multi-chunk windows through the queue (k2d_dp_multi on the second stream beside the class launches); scorings
+// outside dp_cf.h's run the per-wave form k2b_dp.  Windows beyond 1024 bytes: the greedy fallback in the wave-per-haystack kernel.
+static int pipe_score_ascii(Pipe& p) {
+    fzb_matcher* m = p.m;
+    Workspace& w = m->ws;
+    const LaunchCfg& lc = m->lc;
+    const NeedleDev& nd = m->nd;
+    const FzbKnobs& kn = fzb_knobs();
+    const CorpusDev& cd = p.cd;
+    u32* cnt_c = w.counters;
+    const int cus = p.cus;
+    const u32 qcap = pipe_qcap(p);
+    const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
+    int rc;
+    const bool classes = lc.cf_ok && !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2);
+    const int mgrid = cus * 4;  // multi-chunk scorer: 2 waves per SIMD (the kernel is capped at 256 VGPRs)
+    const int mmode = (lc.cfm_ok && !kn.no_dp_cfm) ? 2 : lc.bias_ok ? 1 : 0;
+    if (!no_wide && (rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
+    const int split = classes && !no_wide && mmode == 2;  // multi-chunk windows as k2w_classify's tail-class lists (needs dp_cfm.h's form; cf_ok includes pad_ok)
+    bool fork = classes && !no_wide && !split;
+    if (fork && ensure_aux_stream(m) != FZB_OK) {  // no second stream: everything on the caller's stream (the error text is dropped with the fallback)
+        fork = false;
+        fzb_clear_error();
+    }
+    if (split) {
+        fzb_launch_dp_classes(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, p.wmode, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
+                              (u32)w.cap_cls, cus, p.st, 1, split);
+        fzb_launch_classes_all(cd, p.first, p.index_offset, p.items, w.cls_win, w.cls_lists, (u32)w.cap_cls, cnt_c, nd, lc.sw_lanes, p.out, p.cap32, w.dp_scratch, mgrid, cus, p.st);
+    } else if (classes)
+        fzb_launch_dp_classes(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, p.wmode, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
+                              (u32)w.cap_cls, cus, p.st, fork ? 1 : 0, 0);
+    else
+        fzb_launch_dp(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, p.wmode, lc.pad_ok, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, cus, p.st);
+    FZB_STAGE("dp");
+    if (fork) {  // the queued multi-chunk windows on the second stream beside the three class launches (both start from the classifier's output, disjoint records)
+        HIPCHK(hipEventRecord(m->ev_fork, p.st));
+        HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
+        fzb_launch_dp_multi(cd, p.first, p.index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, p.out, p.cap32, w.dp_scratch, mgrid, m->aux_stream);
+        HIPCHK(hipEventRecord(m->ev_join, m->aux_stream));
+        fzb_launch_dp_classes(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, p.wmode, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
+                              (u32)w.cap_cls, cus, p.st, 2, 0);
+        HIPCHK(hipStreamWaitEvent(p.st, m->ev_join, 0));
+        FZB_STAGE("dp classes + dp_multi (second stream)");
+    }
+    if (no_wide) return FZB_OK;
+    if (!fork && !split) {
+        fzb_launch_dp_multi(cd, p.first, p.index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, p.out, p.cap32, w.dp_scratch, mgrid, p.st);
+        FZB_STAGE("dp_multi");
+    }
+    if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
+        fzb_launch_generic(cd, p.first, p.index_offset, p.items, p.win, p.wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, p.out, p.cap32, nullptr, cnt_c, cus / 4 + 1, p.st);
+        FZB_STAGE("generic(greedy)");
+    }
+    return FZB_OK;
+}
+
+// events of a profiled call: [0] start, [2]..[3] around the streaming filter, [4] before the scorers, [1] end
+static int pipe_profile_begin(fzb_matcher* m, bool has_filter, hipStream_t st, hipEvent_t** pev) {
+    *pev = nullptr;
+    if (!m->profiling) return FZB_OK;
+    const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);
+    hipEvent_t* ev = m->evring[slot];
+    m->ev_filter[slot] = has_filter ? 1 : 0;
+    m->prof_calls++;
+    for (int i = 0; i < 5; i++)
+        if (!ev[i]) HIPCHK(hipEventCreate(&ev[i]));
+    HIPCHK(hipEventRecord(ev[0], st));
+    *pev = ev;
+    return FZB_OK;
+}
+
+// The pipeline.  items_in == nullptr: the haystacks are the contiguous range [first, first + count).  Otherwise they are the listed ones,
+// items_in[j] = index relative to `first`, *n_items_in of them (a device-side count <= count): the narrowing step of the multi-pattern
+// composition.  `trace` != nullptr: the matched-indices form - every record also gets its matched byte positions (the traced generic scorer
+// replaces the fast scorers; literal modes write the needle run).
 static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_t count, uint32_t index_offset, const u32* items_in, const u32* n_items_in,
                         fzb_match* dev_out, size_t capacity, uint32_t* dev_count, void* stream, const TraceOut* trace = nullptr) {
     if (!m || !c || !dev_count || (!dev_out && capacity)) return fail(FZB_ERR_INVALID, "null argument");
@@ -1172,324 +1504,41 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     if (rc) return rc;
     Workspace& w = m->ws;
     const LaunchCfg& lc = m->lc;
-    const NeedleDev& nd = m->nd;
-    const CorpusDev& cd = c->dev;
-    const int cus = lc.num_cus;
-    const u32 cnt = (u32)count;
     const u32 cap32 = (u32)std::min<size_t>(capacity, 0xFFFFFFFFu);
-    const FzbKnobs& kn = fzb_knobs();
-    const bool dbg = kn.debug_sync;  // debugging aid: synchronise and report after every stage
-#define FZB_STAGE(name)                                                                                        \
-    do {                                                                                                       \
-        if (dbg) {                                                                                             \
-            hipError_t e_ = hipStreamSynchronize(st);                                                          \
-            fprintf(stderr, "[fzb] stage %s: %s\n", name, hipGetErrorString(e_));                              \
-            if (e_ != hipSuccess) return fail(FZB_ERR_HIP, std::string(name) + ": " + hipGetErrorString(e_)); \
-        }                                                                                                      \
-    } while (0)
     // the streaming filter kernels clear the counter block themselves (one launch less on the hot path)
-    const bool filter_resets = count != 0 && !items_in && !m->long_needle && (m->literal_mode ? (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode) : lc.filter_mode != 0);
+    const bool filter_resets = count != 0 && !items_in && !m->long_needle && (m->literal_mode ? (m->literal_mode == FZB_MATCH_SUBSTRING && !m->nd.unicode) : lc.filter_mode != 0);
     // nothing filtered (max_typos = None or >= rows): the survivors are the identity list - the counter block is cleared and its first word set
     // to the range's size by ONE small kernel (a memset and a 32-bit fill were two fill kernels with a dispatch gap each: ~ 20 us of a step)
     const bool identity_list = count != 0 && !items_in && !m->long_needle && !m->literal_mode && lc.filter_mode == 0;
-    if (identity_list) fzb_launch_init_counters(w.counters, cnt, st);
+    if (identity_list) fzb_launch_init_counters(w.counters, (u32)count, st);
     else if (!filter_resets) HIPCHK(hipMemsetAsync(w.counters, 0, 64, st));
     if (count == 0) {
         HIPCHK(hipMemsetAsync(dev_count, 0, 8, st));
         return FZB_OK;
     }
     if (m->long_needle) return run_pipeline_long(m, c, first, count, index_offset, items_in, n_items_in, dev_out, cap32, dev_count, st, trace);
-    if (m->literal_mode) {
-        // literal modes: accept pass (one bit per haystack) -> compaction -> scoring pass over the survivors (kernels_literal.hip)
-        u32* cnt_c = w.counters;
-        if (m->literal_mode == FZB_MATCH_SUBSTRING && !nd.unicode && !items_in)  // the streaming DFA filter over the needle's KMP automaton
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 1, nd.rows, (u32)nd.nbytes, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr, nullptr, nullptr, lc.pad_ok,
-                              -1, m->cdfa_src == 1 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
-        else
-            fzb_launch_literal_filter(cd, first, cnt, items_in, n_items_in, nd, m->literal_mode, w.bitmap, w.tile_counts, cus * 8, st);
-        FZB_STAGE("literal filter");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, items_in ? n_items_in : nullptr, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
-        FZB_STAGE("literal compact");
-        fzb_launch_literal_score(cd, first, index_offset, w.surv_idx, &cnt_c[0], nd, m->literal_mode, (fzb_match_rec*)dev_out, cap32, dev_count, trace ? trace->pos : nullptr,
-                                 trace ? trace->npos : nullptr, trace ? trace->stride : 0u, cus * 4, st);
-        FZB_STAGE("literal score");
-        HIPCHK(hipGetLastError());
-        return FZB_OK;
-    }
-    hipEvent_t* pev = nullptr;
-    if (m->profiling) {
-        const int slot = (int)(m->prof_calls % fzb_matcher::PROF_SLOTS);
-        pev = m->evring[slot];
-        m->ev_filter[slot] = (lc.filter_mode && !items_in) ? 1 : 0;
-        m->prof_calls++;
-        for (int i = 0; i < 5; i++)
-            if (!pev[i]) HIPCHK(hipEventCreate(&pev[i]));
-        HIPCHK(hipEventRecord(pev[0], st));
-    }
-    // counters: [0]=filter survivors [1]=kept by the lane-exact prefilter [3]=multi-chunk queue [4]=generic (greedy / wide unicode) queue
-    u32* cnt_c = w.counters;
-    const u32* items = nullptr;
-    const u32* win = nullptr;
-    const u32* n_items_ptr = &cnt_c[0];
-    int wmode = lc.window_mode;
-    bool uni_exact = false;  // the unicode DFA filter decided exactly: no lane-exact window pass, the scorer computes the window
-    bool staged = false;     // the filter staged its survivors' vectors (Workspace::stage): the classifier reads them there
-    if (items_in) {
-        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
-        if (lc.filter_mode == 0) {
-            HIPCHK(hipMemcpyAsync(&cnt_c[0], n_items_in, 4, hipMemcpyDeviceToDevice, st));
-            items = items_in;
-        } else {
-            fzb_launch_filter_items(cd, first, items_in, n_items_in, w.table, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, cus * 4, st);
-            FZB_STAGE("filter(items)");
-            fzb_launch_compact1(w.bitmap, w.tile_counts, 0, n_items_in, items_in, w.surv_idx, &cnt_c[0], cus * 2, st);
-            FZB_STAGE("compact1(items)");
-            items = w.surv_idx;
-        }
-    } else if (lc.filter_mode == 0) {
-        // nothing filtered (max_typos = None or >= rows): the survivors are the identity list (counters[0] = the range's size: set above)
-    } else if (typo_fast_path_configured(m) && !trace && fzb_dp_short_applies(cd, lc.sw_lanes, 2)) {
-        // ---- typo configuration, every haystack fits half a chunk: LCS filter with the "nothing to spare" bit -> survivors;
-        // the marginal ones are re-decided at the exact lane width (a reject sets a bit), the scorer computes the windows ----
-        const int need = nd.rows - nd.max_typos;
-        const u32 ntiles = (cnt + FZB_TILE - 1) / FZB_TILE;
-        const RejectOut rej{w.reject_bits, w.tile_rejects, w.rej_prefix, &cnt_c[6]};
-        // A haystack that fits ONE prefilter chunk is decided exactly by the LCS criterion: the reference's multi-path scan loses a
-        // candidate only when a lower path that found nothing more in the current chunk advances again in a later one, after the
-        // path above it has moved more than one needle byte ahead - inside a single chunk a path that cannot advance is stuck for
-        // good (tests/test_oracle_reference_properties.py::test_single_chunk_typo_prefilter_is_the_lcs_criterion;
-        // 1.3e8 random single-chunk cases without a deviation).  Then nothing is marginal and the decide pass is not launched.
-        const bool single_chunk = cd.max_len <= (u32)lc.pf_lanes;
-        if (m->gate_wait) HIPCHK(hipStreamWaitEvent(st, m->gate_wait, 0));
-        if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        if (single_chunk && m->lcs_states)  // the LCS criterion as an automaton in the streaming DFA kernel
-            fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
-                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
-        else if (single_chunk)
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st);
-        else
-            fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, 2, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, w.bitmap_m,
-                              w.tile_counts_m, w.reject_bits, w.tile_rejects);
-        if (pev) HIPCHK(hipEventRecord(pev[3], st));
-        if (m->gate_record) HIPCHK(hipEventRecord(m->gate_record, st));
-        FZB_STAGE("filter(lcs)");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st);
-        if (!single_chunk) {
-            fzb_launch_compact1(w.bitmap_m, w.tile_counts_m, cnt, nullptr, nullptr, w.marg_list, &cnt_c[5], cus * 4, st);
-            FZB_STAGE("compact1 x2");
-            fzb_launch_window(cd, first, w.marg_list, &cnt_c[5], nd, lc.pf_lanes, nullptr, nullptr, nullptr, cnt_c, cus * 4, st, &rej);
-            FZB_STAGE("window(decide)");
-            fzb_launch_scan_rejects(w.tile_rejects, ntiles, &cnt_c[6], w.rej_prefix, st);
-        }
-        if (pev) HIPCHK(hipEventRecord(pev[4], st));
-        fzb_launch_dp(cd, first, index_offset, w.surv_idx, nullptr, &cnt_c[0], nd, lc.sw_lanes, 2, 3, lc.pad_ok, (fzb_match_rec*)dev_out, cap32, dev_count, w.overflow, cnt, cnt_c, cus, st, &rej);
-        FZB_STAGE("dp(short, typo windows)");
-        if (pev) HIPCHK(hipEventRecord(pev[1], st));
-        HIPCHK(hipGetLastError());
-        return FZB_OK;
-    } else if (m->uni_dfa_states && lc.bias_ok && !trace) {
-        // unicode path, 0 typos: the exact prefilter as a byte-level DFA in the streaming filter; the scorer finds the window itself
-        if (m->gate_wait) HIPCHK(hipStreamWaitEvent(st, m->gate_wait, 0));
-        if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        fzb_launch_filter(cd, first, cnt, w.table, w.uni_dfa, lc.dead_byte, m->uni_dfa_states - 1, 1, 0, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
-                          nullptr, nullptr, nullptr, lc.pad_ok, -1, m->cdfa_src == 2 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
-        if (pev) HIPCHK(hipEventRecord(pev[3], st));
-        if (m->gate_record) HIPCHK(hipEventRecord(m->gate_record, st));
-        FZB_STAGE("filter(unicode dfa)");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * 4, st, nullptr, &cnt_c[1]);  // (kept by the exact prefilter = the filter's survivors)
-        FZB_STAGE("compact1");
-        items = w.surv_idx;
-        uni_exact = true;
+    Pipe p{m, c->dev, first, (u32)count, index_offset, items_in, n_items_in, (fzb_match_rec*)dev_out, cap32, dev_count, st, trace, nullptr, lc.num_cus};
+    if (m->literal_mode) return pipe_literal(p);
+    if ((rc = pipe_profile_begin(m, lc.filter_mode && !items_in, st, &p.pev))) return rc;
+    if (!items_in && lc.filter_mode != 0 && typo_fast_path_configured(m) && !trace && fzb_dp_short_applies(c->dev, lc.sw_lanes, 2)) {
+        rc = pipe_typo_fast_path(p);
     } else {
-        const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
-        // filter -> scorer handoff (ragged list with a view, the exact ASCII filter, classified scoring next): the view kernel stores the accepted
-        // haystacks' vectors, which it holds in registers, into the stage; the classifier and the scorers read them there
-        // Only for lists that give every workgroup of the filter several tiles: on a small list (one round of tiles: the 1.4 M-item paths list)
-        // the tile's closing work - copy-out, header, three barriers - sits on the one chain of latencies the kernel consists of (filter 32 ->
-        // 44 us there, the scorers gain 8); FZB_HANDOFF_MIN_TILES overrides the threshold (0: always)
-        const u32 ntiles_f = (cnt + FZB_TILE - 1) / FZB_TILE;
-        const bool want_stage = !kn.no_handoff && !trace && lc.filter_mode == 1 && lc.filter_exact && lc.window_mode == 1 && !nd.unicode && cd.vbytes && cd.n_long == 0 && lc.cf_ok &&
-                                !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2) && ntiles_f >= (u32)kn.handoff_min_tiles;
-        if (want_stage && (rc = ensure_stage(m, count))) return rc;  // first use only (or fzb_matcher_reserve)
-        const StageOut so{want_stage ? w.stage : nullptr, want_stage ? w.stage_hdr : nullptr};
-        if (m->gate_wait) HIPCHK(hipStreamWaitEvent(st, m->gate_wait, 0));
-        if (pev) HIPCHK(hipEventRecord(pev[2], st));
-        if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
-            fzb_launch_filter(cd, first, cnt, w.table, w.lcs_dfa, lc.dead_byte, m->lcs_states - 1, 1, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr,
-                              nullptr, nullptr, nullptr, lc.pad_ok, m->lcs_acc_lo, m->cdfa_src == 3 ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
-        else
-            staged = fzb_launch_filter(cd, first, cnt, w.table, w.dfa, lc.dead_byte, nd.rows, lc.filter_mode, need, (u32)nd.min_haystack_len, w.bitmap, w.tile_counts, w.counters, cus * 8, st, nullptr, nullptr,
-                                       nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G, want_stage ? &so : nullptr);
-        if (pev) HIPCHK(hipEventRecord(pev[3], st));
-        if (m->gate_record) HIPCHK(hipEventRecord(m->gate_record, st));
-        FZB_STAGE("filter");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], cus * kn.compact_grid_mul, st, staged ? w.tile_prefix : nullptr);
-        FZB_STAGE("compact1");
-        items = w.surv_idx;
+        if ((rc = pipe_filter_stage(p))) return rc;
+        FZB_PEV(4);
+        if (trace) rc = pipe_score_traced(p);
+        else if (m->nd.unicode && lc.bias_ok) rc = pipe_score_unicode(p);
+        else if (m->nd.unicode) {
+            fzb_launch_generic(c->dev, first, index_offset, p.items, p.win, p.wmode, nullptr, p.n_items_ptr, m->nd, lc.sw_lanes, 1, p.out, cap32, dev_count, w.counters, lc.num_cus * 4, st);
+            FZB_STAGE("generic(unicode)");
+        } else rc = pipe_score_ascii(p);
     }
-    if (uni_exact) {
-        wmode = 1;
-    } else if (!lc.filter_exact) {
-        // the stream stage was a superset: re-decide every survivor with the reference's chunked algorithm at its exact lane width
-        fzb_launch_window(cd, first, items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, cus * 4, st, nullptr, items_in ? 0u : cnt);
-        FZB_STAGE("window");
-        fzb_launch_compact2(w.bitmap2, w.tile_counts2, &cnt_c[0], items, w.win, w.items2, w.win2, &cnt_c[1], cus * 2, st);
-        FZB_STAGE("compact2");
-        items = w.items2;
-        win = w.win2;
-        n_items_ptr = &cnt_c[1];
-        wmode = 0;
-    }
-    if (pev) HIPCHK(hipEventRecord(pev[4], st));
-    fzb_match_rec* outp = (fzb_match_rec*)dev_out;
-    // queue of windows wider than one chunk: multi-chunk entries from the front, generic-kernel entries from the back.  Every item is queued at
-    // most once by its scorer (front + back <= cnt), and the thread-per-haystack unicode scorer may hand up to 4096 of the front's windows on
-    // to the back WHILE the front is still being read: the back gets 4096 entries of room of its own below the front's reach (the allocation
-    // holds count + count/8 + 4096 entries), so a forwarded entry can never land on a front slot that has not been consumed yet
-    const u32 qcap = (u32)std::min<u64>((u64)cnt + FZB_UNICODE_FWD_CAP, 0xFFFFFFFFull);
-    const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;  // no haystack is longer than a chunk
-    if (trace) {
-        // matched indices: one traced generic scorer for every window width, ASCII and unicode (kernels_generic.hip)
-        const int tgrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)cus / 2, (count + 3) / 4));
-        const size_t words = fzb_trace_scratch_words(nd, tgrid);
-        if (w.trace_cells_words < words) {
-            if (w.trace_cells) HIPCHK(hipFree(w.trace_cells));
-            w.trace_cells = nullptr;
-            w.trace_cells_words = 0;
-            HIPCHK(dev_alloc((void**)&w.trace_cells, words * 4));
-            w.trace_cells_words = words;
-        }
-        fzb_launch_generic_trace(cd, first, index_offset, items, win, wmode, n_items_ptr, nd, lc.sw_lanes, nd.unicode, outp, cap32, dev_count, cnt_c, w.trace_cells, trace->pos,
-                                 trace->npos, trace->stride, tgrid, st);
-        FZB_STAGE("generic(trace)");
-    } else if (nd.unicode && lc.bias_ok) {
-        // Windows wider than a chunk: up to 1024 bytes into the FRONT of the queue, beyond that (greedy fallback) into its back.  The front
-        // has two takers, chosen on the device by its length: the thread-per-haystack multi-chunk scorer (k2u_dp_unicode_multi: several times
-        // fewer instructions, but one wave per SIMD and ~ 10-20 us per chunk - a fixed latency of ~ 100 us, then 0.3 ns per window) from
-        // `umin` windows on, the wave-per-haystack kernel (1.6 - 2.7 ns per window, no fixed cost) below.  Measured (tools/exp_unicode_wide.py):
-        // 45 k windows (Arabic-shaped list, All Scores) 0.215 ms wave per haystack / 0.204 thread per haystack, 361 k windows 1.285 / 0.815.
-        // FZB_UNICODE_MULTI=0 / 1: never / always.
-        // (a range smaller than the switch point cannot queue that many windows: the thread-per-haystack scorer is not even launched)
-        const u32 umin = no_wide ? 0xFFFFFFFFu : kn.unicode_multi == 0 ? 0xFFFFFFFFu : kn.unicode_multi == 1 ? 0u : cnt < (u32)cus * 128u ? 0xFFFFFFFFu : (u32)cus * 128u;
-        const int ugrid = cus * 2;  // multi-chunk unicode scorer: one wave per SIMD (two-wave workgroups)
-        if (umin != 0xFFFFFFFFu && (rc = ensure_dp_scratch(m, ugrid))) return rc;  // first use only (or fzb_matcher_reserve)
-        // Whole-haystack windows (max_typos: None): the wide ones are known from the end offsets, so they are queued FIRST and their scorers run
-        // on the second stream beside the single-chunk scorer (Arabic-shaped list, All Scores: the two took 90 + 100 us one after the other)
-        bool presplit = wmode == 2 && !items && !no_wide && !kn.no_overlap && !kn.debug_sync;  // (no item list: the number of windows is the range's size)
-        if (presplit && ensure_aux_stream(m) != FZB_OK) {  // no second stream: the scorer queues them itself (the error text is dropped with the fallback)
-            presplit = false;
-            fzb_clear_error();
-        }
-        hipStream_t wst = st;  // the stream of the wide windows' scorers
-        if (presplit) {
-            fzb_launch_unicode_split_wide(cd, first, items, n_items_ptr, lc.sw_lanes, cap32, w.overflow, qcap, cnt_c, (int)std::min<u32>((cnt + 2047u) / 2048u, (u32)cus * 4u), st);
-            HIPCHK(hipEventRecord(m->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
-            wst = m->aux_stream;
-        }
-        // (presplit: the wide windows' kernels are enqueued FIRST - a few hundred long-running waves that take their SIMDs and keep them - and the
-        // single-chunk scorer runs as one short-lived workgroup per 128 items, which fills the rest of the chip and every SIMD a wide wave frees)
-        auto launch_single = [&]() {
-            fzb_launch_dp_unicode(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st, lc.cfu_ok, presplit ? 2 : 1,
-                                  presplit ? (int)((cnt + 127) / 128) : 0);
-        };
-        if (!presplit) launch_single();
-        FZB_STAGE("dp(unicode)");
-        if (!no_wide) {
-            // (the thread-per-haystack scorer hands windows beyond four chunks - up to 4096 of them - on to the queue's back: FZB_UNICODE_FWD=0 keeps them)
-            const u32 fwd_cap = (umin != 0xFFFFFFFFu && !kn.no_unicode_fwd) ? FZB_UNICODE_FWD_CAP : 0u;
-            if (umin != 0xFFFFFFFFu)
-                fzb_launch_dp_unicode_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, ugrid, wst, umin, lc.cfu_ok, cnt_c, w.overflow + 4 * (size_t)qcap, fwd_cap);
-            // (the wave-per-haystack kernel's LDS follows the needle's rows: for short needles its registers decide how many workgroups a CU holds)
-            // The queue's back - handed-on stragglers (DP) and windows beyond 1024 bytes (greedy) - has a launch of its own only where windows
-            // beyond 1024 bytes can exist; otherwise the front's wave-per-haystack launch, which has nothing to do exactly when the
-            // thread-per-haystack scorer ran, walks the back then (no third launch on the lists that never need one)
-            const bool back_launch = !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN);
-            const bool may_fwd = fwd_cap != 0 && !(cd.max_len != 0 && cd.max_len <= 4u * (u32)lc.sw_lanes);
-            if (umin != 0u)
-                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow, &cnt_c[3], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c, cus * kn.generic_wgs, wst, 1, umin,
-                                   (may_fwd && !back_launch) ? w.overflow + 4 * (size_t)qcap : nullptr, &cnt_c[4]);
-            FZB_STAGE("dp(unicode, wide windows)");
-            if (back_launch || (may_fwd && umin == 0u)) {
-                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 1, outp, cap32, nullptr, cnt_c,
-                                   may_fwd ? cus * 4 : cus / 4 + 1, wst);
-                FZB_STAGE("generic(unicode, stragglers + greedy)");
-            }
-            if (presplit) launch_single();
-            if (presplit) {
-                HIPCHK(hipEventRecord(m->ev_join, m->aux_stream));
-                HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
-            }
-        }
-    } else if (nd.unicode) {
-        fzb_launch_generic(cd, first, index_offset, items, win, wmode, nullptr, n_items_ptr, nd, lc.sw_lanes, 1, outp, cap32, dev_count, cnt_c, cus * 4, st);
-        FZB_STAGE("generic(unicode)");
-    } else {
-        const bool no_classes = kn.no_dp_classes;  // comparison knob: the per-wave choice of k2b_dp instead
-        const bool no_overlap = kn.no_overlap;     // comparison knob: everything on the caller's stream
-        const bool classes = lc.cf_ok && !no_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2);
-        const int mgrid = cus * 4;  // multi-chunk scorer: 2 waves per SIMD (the kernel is capped at 256 VGPRs)
-        const int mmode = (lc.cfm_ok && !kn.no_dp_cfm) ? 2 : lc.bias_ok ? 1 : 0;
-        if (!no_wide && (rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
-        // The class launches and the multi-chunk scorer both start from k2w_classify's lists and write disjoint records, and each is a persistent
-        // grid whose last round leaves most of the chip idle (the multi-chunk scorer's third round is 4 % full on the C4 shard): the multi-chunk
-        // scorer runs on a second stream, forked after the classifier and joined before the caller's stream continues.
-        // multi-chunk windows by the width of their last chunk's tail (k2w_classify's lists 3-6 -> k2d_dp_multi_tc): needs the classifier, dp_cfm.h's
-        // form and a needle without NUL (cf_ok includes pad_ok)
-        const bool no_tail_classes = kn.no_tail_classes;  // comparison knob: every last chunk computed in full
-        const int split = classes && !no_wide && mmode == 2 && !no_tail_classes;
-        // the three class launches and the multi-chunk scorer as ONE launch (k2_classes_all: the grid cut into four slices) instead of four
-        // launches on two streams: on a list of a million items each of the four is a single round of single items whose latencies and launch
-        // boundaries add up along the stream (paths-shaped list 128 -> 102 us, a 2 M-item ragged list 143 -> 116 us), on the 12.5 M-item shard
-        // the two are equal (0.447 ms).  FZB_SMALL_LIST=n keeps the four launches for lists of n haystacks and more (0: always).
-        const u32 small_list = kn.small_list;
-        const bool all_in_one = split && cnt < small_list;
-        bool fork = classes && !no_wide && !no_overlap && !all_in_one;
-        if (fork && ensure_aux_stream(m) != FZB_OK) {  // no second stream: everything on the caller's stream (the error text is dropped with the fallback)
-            fork = false;
-            fzb_clear_error();
-        }
-        const StagedIn sin{w.stage, w.stage_hdr, w.tile_prefix};
-        const StagedIn* sinp = (staged && classes && items == w.surv_idx) ? &sin : nullptr;
-        if (classes && all_in_one) {
-            fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                                  (u32)w.cap_cls, cus, st, 1, split, sinp);
-            fzb_launch_classes_all(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, cnt_c, nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, cus, st);
-        } else if (classes)
-            fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                                  (u32)w.cap_cls, cus, st, fork ? 1 : 0, split, sinp);
-        else
-            fzb_launch_dp(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, lc.cf_ok ? 2 : lc.bias_ok ? 1 : 0, wmode, lc.pad_ok, outp, cap32, dev_count, w.overflow, qcap, cnt_c, cus, st);
-        FZB_STAGE("dp");
-        if (fork) {
-            HIPCHK(hipEventRecord(m->ev_fork, st));
-            HIPCHK(hipStreamWaitEvent(m->aux_stream, m->ev_fork, 0));
-            if (split) fzb_launch_dp_multi_classes(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, &cnt_c[12], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, m->aux_stream);
-            else fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, m->aux_stream);
-            HIPCHK(hipEventRecord(m->ev_join, m->aux_stream));
-            fzb_launch_dp_classes(cd, first, index_offset, items, win, n_items_ptr, nd, lc.sw_lanes, wmode, outp, cap32, dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                                  (u32)w.cap_cls, cus, st, 2);
-            HIPCHK(hipStreamWaitEvent(st, m->ev_join, 0));
-            FZB_STAGE("dp classes + dp_multi (second stream)");
-        }
-        if (!no_wide) {
-            if (!fork && !all_in_one) {
-                if (split) fzb_launch_dp_multi_classes(cd, first, index_offset, items, w.cls_win, w.cls_lists, (u32)w.cap_cls, &cnt_c[12], nd, lc.sw_lanes, outp, cap32, w.dp_scratch, mgrid, st);
-                else fzb_launch_dp_multi(cd, first, index_offset, w.overflow, &cnt_c[3], nd, lc.sw_lanes, mmode, outp, cap32, w.dp_scratch, mgrid, st);
-                FZB_STAGE("dp_multi");
-            }
-            if (!(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN)) {  // > 1024-byte windows: the greedy fallback
-                fzb_launch_generic(cd, first, index_offset, items, win, wmode, w.overflow + 4 * (size_t)qcap, &cnt_c[4], nd, lc.sw_lanes, 0, outp, cap32, nullptr, cnt_c,
-                                   cus / 4 + 1, st);
-                FZB_STAGE("generic(greedy)");
-            }
-        }
-    }
-#undef FZB_STAGE
-    if (pev) HIPCHK(hipEventRecord(pev[1], st));
+    if (rc) return rc;
+    FZB_PEV(1);
     HIPCHK(hipGetLastError());
     return FZB_OK;
 }
+#undef FZB_STAGE
+#undef FZB_PEV
 
 // Sizes every device buffer a query over `c` can need (range workspace incl. the typo-path arrays, multi-chunk scorer scratch when
 // the corpus has haystacks wider than a chunk, staging + sort buffers of the synchronous / sorted entry points), so that the queries
@@ -1507,7 +1556,6 @@ int fzb_matcher_reserve(fzb_matcher* m, const fzb_corpus* c) {
     if (!m->long_needle && !m->literal_mode && !m->nd.unicode && !no_wide && ((rc = ensure_dp_scratch(m, m->lc.num_cus * 4)) || (rc = ensure_aux_stream(m)))) return rc;
     if (!m->long_needle && !m->literal_mode && m->nd.unicode && m->lc.bias_ok && !no_wide && fzb_knobs().unicode_multi != 0 && (rc = ensure_dp_scratch(m, m->lc.num_cus * 2))) return rc;
     if (!m->long_needle && !m->literal_mode && m->nd.unicode && m->lc.bias_ok && !no_wide && m->nd.max_typos < 0 && (rc = ensure_aux_stream(m))) return rc;  // whole-haystack windows: the wide ones on the second stream
-    if (c->dev.vbytes && c->dev.n_long == 0 && !m->literal_mode && !m->long_needle && !m->nd.unicode && m->lc.filter_mode == 1 && m->lc.cf_ok && (rc = ensure_stage(m, n))) return rc;
     if ((rc = fzb_ensure_out_staging(m, n))) return rc;
     if ((rc = ensure_sort_buffers(m, n))) return rc;
     return FZB_OK;
@@ -2401,12 +2449,6 @@ int fzb_debug_cdfa_state(const fzb_matcher* m, const uint8_t* bytes, size_t len,
     return st >= acc ? 1 : 0;
 }
 
-int fzb_debug_set_gate(fzb_matcher* m, void* wait_before_filter, void* record_after_filter) {  // experiment hook: see fzb_matcher::gate_wait
-    if (!m) return fail(FZB_ERR_INVALID, "null argument");
-    m->gate_wait = (hipEvent_t)wait_before_filter;
-    m->gate_record = (hipEvent_t)record_after_filter;
-    return FZB_OK;
-}
 int fzb_last_counters(fzb_matcher* m, uint32_t out[4]) {
     if (!m || !out) return fail(FZB_ERR_INVALID, "null argument");
     if (m->ws.counters) {

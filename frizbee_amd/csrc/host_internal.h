@@ -65,10 +65,6 @@ struct fzb_matcher {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int ev_filter[PROF_SLOTS] = {};
     u64 prof_calls = 0;
-    // experiment hook (fzb_debug_set_gate, tools/exp_r6_corun.py): the streaming filter of this matcher's next queries waits for `gate_wait` and
-    // `gate_record` is recorded behind it - sub-range pipelines on several streams whose filters run one after the other, each beside the
-    // previous sub-range's scorers
-    hipEvent_t gate_wait = nullptr, gate_record = nullptr;
 
     u32 last_counters[4] = {0, 0, 0, 0};
     // staging for the synchronous API

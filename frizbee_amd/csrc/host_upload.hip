@@ -308,10 +308,8 @@ __global__ __launch_bounds__(UP_THREADS) void k_up_view_fill(const u8* __restric
 }
 
 // ---- host -> device at link speed ---------------------------------------------------------------------------------------------
-// FZB_UPLOAD_MODE: "direct" (default; one hipMemcpy per array straight from the caller's pageable memory; "pageable" is accepted as a
-// synonym), "register" (hipHostRegister the caller's memory, then copy), "staged" (per-thread pinned staging + asynchronous copies)
-int upload_mode() { return fzb_knobs().upload_mode; }
-
+// One hipMemcpy per array straight from the caller's pageable memory: 52-53 GB/s measured (profiles/r03_upload_modes.txt; hipHostRegister
+// first and a pool of threads with pinned staging buffers were both slower there and left with round 6's prune).
 struct H2DJob {
     void* dst;
     const void* src;
@@ -320,85 +318,12 @@ struct H2DJob {
 
 // copies every job; returns hipSuccess or the first error
 hipError_t h2d_all(const std::vector<H2DJob>& jobs, int device) {
-    size_t total = 0;
-    for (const H2DJob& j : jobs) total += j.bytes;
-    if (total == 0) return hipSuccess;
-    const int mode = upload_mode();
-    if (mode == 2 || total < ((size_t)1 << 20)) {
-        for (const H2DJob& j : jobs)
-            if (j.bytes) {
-                hipError_t e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
-                if (e != hipSuccess) return e;
-            }
-        return hipSuccess;
-    }
-    if (mode == 1) {
-        for (const H2DJob& j : jobs) {
-            if (!j.bytes) continue;
-            hipError_t e = hipHostRegister((void*)j.src, j.bytes, hipHostRegisterDefault);
-            if (e != hipSuccess) {  // not registrable (e.g. read-only mapping): the plain copy still works
-                (void)hipGetLastError();
-                e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
-                if (e != hipSuccess) return e;
-                continue;
-            }
-            e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
-            (void)hipHostUnregister((void*)j.src);
+    (void)device;
+    for (const H2DJob& j : jobs)
+        if (j.bytes) {
+            hipError_t e = hipMemcpy(j.dst, j.src, j.bytes, hipMemcpyHostToDevice);
             if (e != hipSuccess) return e;
         }
-        return hipSuccess;
-    }
-    // staged: the concatenation of all jobs is cut into equal slices, one per worker thread
-    constexpr size_t CHUNK = (size_t)4 << 20;
-    const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
-    const size_t env_threads = (size_t)fzb_knobs().upload_threads;
-    const size_t nthreads = std::max<size_t>(1, std::min<size_t>({env_threads ? env_threads : (size_t)12, hw, (total + CHUNK - 1) / CHUNK}));
-    const size_t per = ((total + nthreads - 1) / nthreads + 63) & ~(size_t)63;
-    std::vector<hipError_t> errs(nthreads, hipSuccess);
-    auto worker = [&](size_t t) {
-        hipError_t e = hipSetDevice(device);
-        hipStream_t st = nullptr;
-        hipEvent_t ev[2] = {nullptr, nullptr};
-        void* stage[2] = {nullptr, nullptr};
-        bool used[2] = {false, false};
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        for (int k = 0; k < 2 && e == hipSuccess; k++) {
-            e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
-            if (e == hipSuccess && !(stage[k] = fzb_pinned_get(CHUNK))) e = hipErrorOutOfMemory;
-        }
-        size_t lo = std::min(t * per, total), hi = std::min(lo + per, total);  // this worker's byte range of the concatenation
-        size_t job = 0, job_lo = 0;
-        int slot = 0;
-        while (e == hipSuccess && lo < hi) {
-            while (job < jobs.size() && lo >= job_lo + jobs[job].bytes) job_lo += jobs[job++].bytes;
-            const size_t off = lo - job_lo;
-            const size_t len = std::min({CHUNK, hi - lo, jobs[job].bytes - off});
-            if (used[slot]) e = hipEventSynchronize(ev[slot]);
-            if (e != hipSuccess) break;
-            memcpy(stage[slot], (const u8*)jobs[job].src + off, len);
-            e = hipMemcpyAsync((u8*)jobs[job].dst + off, stage[slot], len, hipMemcpyHostToDevice, st);
-            if (e == hipSuccess) e = hipEventRecord(ev[slot], st);
-            used[slot] = true;
-            slot ^= 1;
-            lo += len;
-        }
-        if (st) {
-            hipError_t e2 = hipStreamSynchronize(st);
-            if (e == hipSuccess) e = e2;
-            (void)hipStreamDestroy(st);
-        }
-        for (int k = 0; k < 2; k++) {
-            if (ev[k]) (void)hipEventDestroy(ev[k]);
-            if (stage[k]) fzb_pinned_put(stage[k]);
-        }
-        errs[t] = e;
-    };
-    std::vector<std::thread> pool;
-    for (size_t t = 1; t < nthreads; t++) pool.emplace_back(worker, t);
-    worker(0);
-    for (auto& th : pool) th.join();
-    for (hipError_t e : errs)
-        if (e != hipSuccess) return e;
     return hipSuccess;
 }
 

@@ -285,17 +285,14 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
 //   k2b_dp_class: persistent thread-per-survivor scorer of one class: window bytes from memory (requested one item ahead), bonuses
 //                 from the LDS tables, dp_cf.h rows with the class's number of computed lanes; registers - and therefore waves per
 //                 SIMD (4 / 3 / 2) - follow the class.
+//                 It writes, per survivor, one 16-byte record (window start, window end | bit 31 = "the window is the whole haystack", the
+//                 64-bit address of the haystack's first byte).  The scorers read that record and nothing else: no end offsets.
 // ---------------------------------------------------------------------------------------------------------------
-//                 It also decides WHERE the scorers read a survivor's bytes: the filter's stage (Workspace::stage; header entry by the
-//                 survivor's rank inside its tile) when the filter staged it, the corpus otherwise - and writes, per survivor, one 16-byte
-//                 record (window start, window end | bit 31 = "the window is the whole haystack", the 64-bit address of the haystack's
-//                 first byte).  The scorers read that record and nothing else: no end offsets, no second gather of cold corpus lines.
 template <typename ET, int PER>
 __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ items,
                                                     const u32* __restrict__ win_in, const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, u32 swl,
                                                     uint4* __restrict__ meta, u32* __restrict__ lists, u32 list_stride, u32* __restrict__ overflow, u32 qcap,
-                                                    u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count, u32 split_multi,
-                                                    const u8* __restrict__ stage, const u32* __restrict__ stage_hdr, const u32* __restrict__ tile_prefix) {
+                                                    u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count, u32 split_multi) {
     // classes: 0-2 single chunk, 3 multi-chunk (queue), 4 greedy (queue, from the back), 5-8 multi-chunk by the width of the LAST chunk's
     // tail (split_multi: lists 3-6, counts in counters[12..15]; k2d_dp_multi_tc computes only that many lanes of the last chunk)
     __shared__ u32 s_cnt[9], s_base[9];
@@ -316,21 +313,9 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
             if (j < M && j < capacity) {
                 li[p] = items ? items[j] : j;
                 u32 L = 0;
-                bool staged = false;
-                if (stage) {  // (kernel argument: uniform) the survivor's header entry: rank inside its tile = rank - survivors before the tile
-                    const u32 tile = li[p] / FZB_TILE;
-                    const u32 ent = stage_hdr[(size_t)tile * FZB_TILE + (j - tile_prefix[tile])];
-                    if ((ent & 0xFFFFu) != 0xFFFFu) {
-                        src[p] = stage + ((size_t)tile * FZB_STAGE_UNITS + (ent & 0xFFFFu)) * 16;
-                        L = ent >> 16;
-                        staged = true;
-                    }
-                }
-                if (!staged) {
-                    u64 s;
-                    haystack_span(ends, first + li[p], s, L);
-                    src[p] = bytes + s;
-                }
+                u64 s;
+                haystack_span(ends, first + li[p], s, L);
+                src[p] = bytes + s;
                 if (wmode == 0) { ws[p] = win_in[2 * j]; we[p] = win_in[2 * j + 1]; }
                 else if (wmode == 2) { ws[p] = 0; we[p] = L; }
                 else window_first_last(nd, src[p], L, ws[p], we[p]);
@@ -461,16 +446,16 @@ __global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3
 
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
-                           int num_cus, hipStream_t st, int part, int split_multi, const StagedIn* staged) {
+                           int num_cus, hipStream_t st, int part, int split_multi) {
     // part: 0 = classify + the three class launches, 1 = classify only, 2 = the class launches only (host.hip runs the multi-chunk scorer on a
     // second stream between the two)
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     if (part != 2) {
-        const int per = fzb_knobs().classify_per;  // tuning knob: survivors per thread
-#define FZB_K2W(ET, PER) hipLaunchKernelGGL((k2w_classify<ET, PER>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, (uint4*)win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi, staged ? staged->stage : nullptr, staged ? staged->hdr : nullptr, staged ? staged->tile_prefix : nullptr)
-#define FZB_K2W_ET(PER) do { if (c.ends_u64) FZB_K2W(u64, PER); else FZB_K2W(u32, PER); } while (0)
-        if (per == 1) FZB_K2W_ET(1); else if (per == 4) FZB_K2W_ET(4); else FZB_K2W_ET(2);
+        // (two survivors per thread: 1 / 2 / 4 gave 0.458 / 0.454 / 0.464 ms for the C4 shard's step)
+#define FZB_K2W(ET) hipLaunchKernelGGL((k2w_classify<ET, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, (uint4*)win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi)
+        if (c.ends_u64) FZB_K2W(u64); else FZB_K2W(u32);
+#undef FZB_K2W
     }
     if (part == 1) return;
 #define FZB_K2C(SWL, U, REAL, CLS)                                                                                                        \
@@ -678,7 +663,7 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
         const u32 j = lists[(size_t)(3 + cls) * list_stride + (q - base)];
         if (j >= capacity) continue;
         const u32 li = items ? items[j] : j;
-        const uint4 w = meta[j];  // the classifier's record: window, "whole haystack" flag, where the bytes are (stage or corpus)
+        const uint4 w = meta[j];  // the classifier's record: window, "whole haystack" flag, where the bytes are
         const u8* hay = (const u8*)(uintptr_t)((u64)w.z | ((u64)w.w << 32));
         const u32 sp = w.x ? w.x - 1 : 0;
         const bool include_exact = (w.y >> 31) != 0;
@@ -698,20 +683,10 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
     }
 }
 
-template <int SWL, bool UPPER>
-__global__ __launch_bounds__(128, 2) void k2d_dp_multi_tc(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
-                                                       u32 list_stride, const u32* __restrict__ counts, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                       u32* __restrict__ scratch, u32 park_dw) {
-    __shared__ CfTables tab;
-    cf_build_tables<UPPER>(nd, tab);
-    __syncthreads();
-    dp_multi_tc_body<SWL, UPPER>(tab, blockIdx.x, gridDim.x, index_offset, items, meta, lists, list_stride, counts, nd, out, capacity, scratch, park_dw);
-}
-
-// Small lists: the three single-chunk classes and the multi-chunk tail classes in ONE launch - the grid is cut into four slices, a workgroup
-// runs the body of its slice (widest work first).  On a list of a million items every one of the four launches is a single round of single
-// items, so their latencies (and launch boundaries) add up along the stream; here they run side by side.  Registers follow the widest body
-// (two waves per SIMD), which a small list does not notice.
+// The three single-chunk classes and the multi-chunk tail classes in ONE launch - the grid is cut into four slices, a workgroup runs the body of
+// its slice (widest work first).  On a list of a million items every one of four separate launches is a single round of single items, so their
+// latencies (and launch boundaries) add up along the stream (paths-shaped list 128 -> 102 us); here they run side by side.  Registers follow the
+// widest body (two waves per SIMD); on the 12.5 M-item shard, where everything is bound by instruction issue, one launch and four are equal.
 template <int SWL, bool UPPER>
 __global__ __launch_bounds__(128, 2) void k2_classes_all(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
                                                       u32 list_stride, const u32* __restrict__ counters, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
@@ -752,21 +727,6 @@ void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, con
         case 32: FZB_K2A_U(32); break;
         case 16: FZB_K2A_U(16); break;
         default: FZB_K2A_U(8); break;
-    }
-}
-
-void fzb_launch_dp_multi_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* lists, u32 list_stride, const u32* counts,
-                                 const NeedleDev& nd, int sw_lanes, fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st) {
-    bool upper = false;
-    for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
-    const u32 park_dw = fzb_park_lds_dwords(nd, sw_lanes);
-#define FZB_K2TC(SWL, U) hipLaunchKernelGGL((k2d_dp_multi_tc<SWL, U>), dim3(grid), dim3(128), (size_t)nd.rows * park_dw * 128 * 4, st, index_offset, items, (const uint4*)win, lists, list_stride, counts, nd, out, capacity, scratch, park_dw)
-#define FZB_K2TC_U(SWL) do { if (upper) FZB_K2TC(SWL, true); else FZB_K2TC(SWL, false); } while (0)
-    switch (sw_lanes) {
-        case 64: FZB_K2TC_U(64); break;
-        case 32: FZB_K2TC_U(32); break;
-        case 16: FZB_K2TC_U(16); break;
-        default: FZB_K2TC_U(8); break;
     }
 }
 
@@ -817,9 +777,7 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
     do {                                                                                                                                \
         static int per_cu = 0;                                                                                                          \
         if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
-        int use_cu = per_cu;                                                                                                            \
-        if (const int v_ = fzb_knobs().dp_wgs_per_cu) { if (v_ >= 1 && v_ < per_cu) use_cu = v_; } /* tuning knob: leave room for a co-resident kernel */ \
-        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * use_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out, c.uniform_len); \
+        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out, c.uniform_len); \
     } while (0)
 #define FZB_K2S_ET(SWL, U) do { if (c.ends_u64) FZB_K2S(SWL, U, u64); else FZB_K2S(SWL, U, u32); } while (0)
 #define FZB_K2S_U(SWL) do { if (upper) FZB_K2S_ET(SWL, true); else FZB_K2S_ET(SWL, false); } while (0)

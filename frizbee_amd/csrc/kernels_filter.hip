@@ -135,10 +135,9 @@ __global__ __launch_bounds__(256) void k1_filter(const u8* __restrict__ bytes, c
 // from HBM up front.  The table has (rows + 1) * 256 bytes; 4 byte values share a dword, so the
 // alphanumerics of one state row spread over distinct LDS banks.
 // ---------------------------------------------------------------------------------------------------
-// UNI32 (round 5): the list was declared (or detected) uniform with exactly 32 bytes per haystack - the headline shape.  No per-lane
-// lengths, no zero-initialised vectors, no partial-vector walks, no length test (min_len <= 32 is checked by the launcher): every haystack
-// is two unconditional 16-byte loads and 32 table steps.  STRIDE: the table's row pitch in LDS (dfa_lds.h).
-template <typename ET, bool UNI32 = false, u32 STRIDE = FZB_DFA_STRIDE>
+// (Round 5 measured an instantiation without per-lane lengths for uniform 32-byte lists and the table at a 256-byte row pitch - 7.5 M instead of
+// 10.7 M VALU instructions per launch, the same 57 us, more LDS bank conflicts; round 6 closed the topic: profiles/r06_corun.txt, profiles/HISTORY.md.)
+template <typename ET>
 __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
                                               const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
                                               u32* __restrict__ tile_counts, u32* __restrict__ reset_counters, u32 ulen) {
@@ -148,48 +147,14 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
     // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
     // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
     extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    u32& s_cnt = *(u32*)(dfa + ((u32)rows + 1u) * STRIDE);
+    u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
     const int tid = threadIdx.x;
     dfa_require_lds_base0(dfa);
-    dfa_load_lds<STRIDE>(dfa, dfa_g, rows);
+    dfa_load_lds(dfa, dfa_g, rows);
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (tid == 0) s_cnt = 0;
         __syncthreads();
-        if (UNI32) {
-            uint4 a[4], b[4];
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const u32 li = min(tile * FZB_TILE + p * 256 + tid, count - 1);  // (the last tile's spare lanes re-read the last haystack; their bit is masked below)
-                const uint4* vp = (const uint4*)(bytes + (first + li) * 32ull);
-                a[p] = vp[0];
-                b[p] = vp[1];
-            }
-            u32 st[4] = {0, 0, 0, 0};
-            { const u32 w[4] = {a[0].x, a[1].x, a[2].x, a[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {a[0].y, a[1].y, a[2].y, a[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {a[0].z, a[1].z, a[2].z, a[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {a[0].w, a[1].w, a[2].w, a[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {b[0].x, b[1].x, b[2].x, b[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {b[0].y, b[1].y, b[2].y, b[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {b[0].z, b[1].z, b[2].z, b[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {b[0].w, b[1].w, b[2].w, b[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            u32 cnt = 0;
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const u32 li = tile * FZB_TILE + p * 256 + tid;
-                const u64 bal = __ballot(li < count && st[p] >= acc_lo);
-                if (lane_id() == 0) {
-                    bitmap[(tile * FZB_TILE + p * 256) / 64 + (tid >> 6)] = bal;
-                    cnt += __popcll(bal);
-                }
-            }
-            if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
-            __syncthreads();
-            if (tid == 0) tile_counts[tile] = s_cnt;
-            __syncthreads();
-            continue;
-        }
         u64 hs[4];
         u32 hl[4];
         uint4 v0[4], v1[4];
@@ -213,23 +178,23 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
         u32 st[4] = {0, 0, 0, 0};
         // short haystacks (<= 32 bytes): both vectors are already in flight
         if (hl[0] >= 16 && hl[1] >= 16 && hl[2] >= 16 && hl[3] >= 16) {
-            { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v0[0].x, v0[1].x, v0[2].x, v0[3].x}; dfa_word4<true>(st, w, dfa); }
+            { const u32 w[4] = {v0[0].y, v0[1].y, v0[2].y, v0[3].y}; dfa_word4<true>(st, w, dfa); }
+            { const u32 w[4] = {v0[0].z, v0[1].z, v0[2].z, v0[3].z}; dfa_word4<true>(st, w, dfa); }
+            { const u32 w[4] = {v0[0].w, v0[1].w, v0[2].w, v0[3].w}; dfa_word4<true>(st, w, dfa); }
         } else {
 #pragma unroll
-            for (int p = 0; p < 4; p++) st[p] = dfa_partial<true, STRIDE>(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
+            for (int p = 0; p < 4; p++) st[p] = dfa_partial<true>(st[p], v0[p], hl[p] >= 16 ? 16u : hl[p], dfa);
         }
         if (hl[0] >= 32 && hl[1] >= 32 && hl[2] >= 32 && hl[3] >= 32) {
-            { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4<true, STRIDE>(st, w, dfa); }
-            { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4<true, STRIDE>(st, w, dfa); }
+            { const u32 w[4] = {v1[0].x, v1[1].x, v1[2].x, v1[3].x}; dfa_word4<true>(st, w, dfa); }
+            { const u32 w[4] = {v1[0].y, v1[1].y, v1[2].y, v1[3].y}; dfa_word4<true>(st, w, dfa); }
+            { const u32 w[4] = {v1[0].z, v1[1].z, v1[2].z, v1[3].z}; dfa_word4<true>(st, w, dfa); }
+            { const u32 w[4] = {v1[0].w, v1[1].w, v1[2].w, v1[3].w}; dfa_word4<true>(st, w, dfa); }
         } else {
 #pragma unroll
             for (int p = 0; p < 4; p++)
-                if (hl[p] > 16) st[p] = dfa_partial<true, STRIDE>(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
+                if (hl[p] > 16) st[p] = dfa_partial<true>(st[p], v1[p], hl[p] >= 32 ? 16u : hl[p] - 16, dfa);
         }
         u32 cnt = 0;
 #pragma unroll
@@ -251,130 +216,9 @@ __global__ __launch_bounds__(256) void k1_dfa(const u8* __restrict__ bytes, cons
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K1-DFA for ragged lists (haystacks longer than the two pre-requested vectors).  Same DFA; P = haystacks a
-// thread runs interleaved (a 1024-haystack tile takes 4 / P sub-passes).  With long haystacks the quantity to
-// control is the cache footprint, not memory-level parallelism: a wave's load touches 64 haystacks = a
-// contiguous ~5 KB of which only 16 B per haystack are consumed, and the rest of those lines must still be in
-// L2 when the lane comes back for its next vector.  Footprint per CU = resident waves x P x ~5 KB, so P and the
-// number of resident workgroups are launch parameters (fzb_launch_filter).
-// ---------------------------------------------------------------------------------------------------
-template <int P>
-__device__ __forceinline__ void dfa_wordP(u32 (&st)[P], const u32 (&w)[P], const u8* dfa) {
-#pragma unroll
-    for (int p = 0; p < P; p++) st[p] = dfa_step<0>(st[p], w[p], dfa);
-    if (P > 1) FZB_WAIT_LDS();
-#pragma unroll
-    for (int p = 0; p < P; p++) st[p] = dfa_step<1>(st[p], w[p], dfa);
-    if (P > 1) FZB_WAIT_LDS();
-#pragma unroll
-    for (int p = 0; p < P; p++) st[p] = dfa_step<2>(st[p], w[p], dfa);
-    if (P > 1) FZB_WAIT_LDS();
-#pragma unroll
-    for (int p = 0; p < P; p++) st[p] = dfa_step<3>(st[p], w[p], dfa);
-    if (P > 1) FZB_WAIT_LDS();
-}
-
-// SAN = false (needle without a NUL byte): the zero fill between a haystack's end and its 16-byte boundary - and the zero vectors a lane
-// sees after its haystack ended - match no needle row, so the vectors go through the DFA unmasked (a third of the loop's instructions).
-template <typename ET, int P, bool SAN = true>
-__global__ __launch_bounds__(256) void k1_dfa_ragged(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 count,
-                                                     const u8* __restrict__ dfa_g, int rows, u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap,
-                                                     u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
-    // the per-call counter block is cleared here (first workgroup) instead of by a separate memset launch: nothing before the
-    // compaction kernel reads it
-    if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
-    // the table is the ONLY LDS object of the kernel and therefore sits at LDS address 0: a lookup's address is the v_perm result itself
-    // (behind a static __shared__ variable every lookup paid a v_add of the table's offset); the tile counter lives behind the table
-    extern __shared__ __attribute__((aligned(16))) u8 dfa[];
-    u32& s_cnt = *(u32*)(dfa + FZB_DFA_LDS_BYTES(rows));
-    const int tid = threadIdx.x;
-    dfa_require_lds_base0(dfa);
-    dfa_load_lds(dfa, dfa_g, rows);
-    const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    const u32 deadv = dead * 0x01010101u;
-    for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tid == 0) s_cnt = 0;
-        __syncthreads();
-        u32 cnt = 0;
-#pragma unroll 1
-        for (int sub = 0; sub < 4 / P; sub++) {
-            const u32 base = tile * FZB_TILE + sub * (256 * P);
-            u64 hs[P];
-            u32 hl[P];
-            uint4 cur[P], nxt[P];
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                const u32 li = base + p * 256 + tid;
-                hs[p] = 0;
-                hl[p] = 0;
-                if (li < count) haystack_span(ends, first + li, hs[p], hl[p]);
-            }
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                cur[p] = make_uint4(0, 0, 0, 0);
-                nxt[p] = make_uint4(0, 0, 0, 0);
-                const uint4* vp = (const uint4*)(bytes + hs[p]);
-                if (hl[p] > 0) cur[p] = vp[0];
-                if (hl[p] > 16) nxt[p] = vp[1];
-            }
-            u32 st[P];
-            u32 nvmax = 0;
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                st[p] = 0;
-                nvmax = max(nvmax, (hl[p] + 15) >> 4);
-            }
-            // Bytes past a haystack's end are replaced by `dead`, a byte value no needle row can match, so every vector runs
-            // the same branch-free unrolled steps.
-            for (u32 v = 0; v < nvmax; v++) {
-                uint4 nn[P];
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    nn[p] = make_uint4(0, 0, 0, 0);
-                    if (hl[p] > 16 * (v + 2)) nn[p] = ((const uint4*)(bytes + hs[p]))[v + 2];
-                }
-                u32 wx[P], wy[P], wz[P], ww[P];
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    const u32 rem = hl[p] > 16 * v ? hl[p] - 16 * v : 0u;  // valid bytes from this vector on
-                    auto san = [&](u32 w, u32 off) {
-                        const u32 nv = rem > off ? rem - off : 0u;
-                        const u32 mask = nv >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nv)) - 1);
-                        return (w & mask) | (deadv & ~mask);
-                    };
-                    wx[p] = SAN ? san(cur[p].x, 0) : cur[p].x;
-                    wy[p] = SAN ? san(cur[p].y, 4) : cur[p].y;
-                    wz[p] = SAN ? san(cur[p].z, 8) : cur[p].z;
-                    ww[p] = SAN ? san(cur[p].w, 12) : cur[p].w;
-                }
-                dfa_wordP<P>(st, wx, dfa);
-                dfa_wordP<P>(st, wy, dfa);
-                dfa_wordP<P>(st, wz, dfa);
-                dfa_wordP<P>(st, ww, dfa);
-#pragma unroll
-                for (int p = 0; p < P; p++) cur[p] = nxt[p], nxt[p] = nn[p];
-            }
-#pragma unroll
-            for (int p = 0; p < P; p++) {
-                const u32 li = base + p * 256 + tid;
-                const bool matched = li < count && hl[p] >= min_len && st[p] >= acc_lo;
-                const u64 b = __ballot(matched);
-                if (lane_id() == 0) {
-                    bitmap[(base + p * 256) / 64 + (tid >> 6)] = b;
-                    cnt += __popcll(b);
-                }
-            }
-        }
-        if (lane_id() == 0 && cnt) atomicAdd(&s_cnt, cnt);
-        __syncthreads();
-        if (tid == 0) tile_counts[tile] = s_cnt;
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // K1-DFA for ragged lists, burst form: a thread requests ALL vectors of its haystack (up to 8 = 128 bytes per round) back to
-// back and only then runs the DFA over them from registers.  In the rolling form above a 128-byte line is touched by ~8 loads
+// back and only then runs the DFA over them from registers.  (SAN = false, a needle without a NUL byte: the zero fill behind a haystack's end matches
+// no needle row and the vectors go through the DFA unmasked.)  In the rolling form of rounds 1-2 (one vector ahead) a 128-byte line was touched by ~8 loads
 // of a wave that are separated by the DFA work of every resident wave, and the CU's footprint (24 waves x 64 haystacks x up to
 // 128 B) is far beyond the vector L1, so most of those touches re-fetch the line from L2; issued back to back they hit.
 // C4 shard: 297 -> 242 us.  (Two or four haystacks per thread as interleaved DFA chains on top of it: 276 / 300 us, and again 281 / 405 us after
@@ -502,10 +346,6 @@ __global__ __launch_bounds__(256) void k1_cdfa_ragged(const u8* __restrict__ byt
                             w[j] = (w[j] & mask) | (deadv & ~mask);
                         }
                     }
-                    if (K == 0xFFFFu) {  // measurement knob (FZB_CDFA_NODFA=1, results meaningless): the loads alone
-                        st ^= w[0] ^ w[1] ^ w[2] ^ w[3];
-                        continue;
-                    }
                     // the vector's sixteen class lookups: independent of the state
                     u32 c[4][4];
 #pragma unroll
@@ -551,33 +391,22 @@ __global__ __launch_bounds__(256) void k1_cdfa_ragged(const u8* __restrict__ byt
 // in its tile (vperm) through an LDS atomic-or, so the bitmap, the per-tile counts and every later stage see nothing of the view.
 // NV = vectors held in registers per haystack (8: lists up to 128 bytes, 16: up to 256).
 // ---------------------------------------------------------------------------------------------------
-// STAGE: the handoff to the scorers (Workspace::stage).  A lane whose haystack is accepted still holds its vectors: it takes `its vector
-// count` units of the tile's stage block with one LDS atomic and stores them there, 16 bytes per instruction, and notes (unit offset | length
-// << 16) under its ORIGINAL tile position in LDS; when the tile is complete the workgroup ranks the set bits and writes the notes as the
-// tile's header, one entry per survivor in index order - the order of the survivor list, so k2w_classify finds survivor j's entry at
-// rank(j) - survivors-before-its-tile.  What the classifier and the scorers then read is ~ 4 KB of contiguous lines per tile instead of
-// 49 haystacks spread over 80 KB of the corpus (140 MB of cold lines for 43 MB of survivor bytes on the C4 shard).
 // LEN: the kernel reads the haystacks' lengths (vlen: 2 of the view's ~83 bytes per haystack on the C4 shard).  They are needed to sanitise a
 // last vector (SAN), for the stage's header (STAGE), to skip an outlier's lane (0xFFFF) and for `length >= min_len` - but with the zero fill
 // harmless (!SAN) an outlier's lane holds zero vectors and cannot leave state 0, and every automaton the view kernel runs accepts only
 // haystacks of at least min_len bytes (subsequence / unicode: the needle's bytes all occurred; LCS >= rows - k bytes matched): without SAN
-// and STAGE the launcher passes LEN = false and the array is not touched.
-template <bool SAN, int G, int NV, bool STAGE, bool LEN = true>
+// the launcher passes LEN = false and the array is not touched.
+// (Rounds 4-5 also had a STAGE form - the accepting lanes copied their vectors into a per-tile block for the classifier and the scorers; the
+// 48 MB copy-out cost the streaming kernel more than the scorers' gathers returned: profiles/HISTORY.md.)
+template <bool SAN, int G, int NV, bool LEN = true>
 __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
                                                     const u16* __restrict__ vperm, u64 first, u32 count, const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG,
-                                                    u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters,
-                                                    u8* __restrict__ stage, u32* __restrict__ stage_hdr, u32 stage_dbg) {
-    // (stage_dbg: MEASUREMENT ONLY, FZB_STAGE_DBG - bit 0: no vector writes into LDS, 1: no copy-out, 2: no header; results meaningless)
+                                                    u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
     extern __shared__ __attribute__((aligned(16))) u8 lds[];
     const u32 tab_bytes = (cdfa_bytes + 15u) & ~15u;
     u32& s_cnt = *(u32*)(lds + tab_bytes);
-    u32& s_used = *(u32*)(lds + tab_bytes + 4);
-    u32& s_top = *(u32*)(lds + tab_bytes + 8);  // STAGE: end of the last allocation that lives in LDS
     u32* const s_bits = (u32*)(lds + tab_bytes + 16);
-    u32* const s_wpre = (u32*)(lds + tab_bytes + 16 + 128);       // STAGE: set bits before each of the 32 words
-    u32* const s_ent = (u32*)(lds + tab_bytes + 16 + 128 + 128);  // STAGE: header entry by original tile position
-    uint4* const s_stage = (uint4*)(lds + tab_bytes + 16 + 128 + 128 + 4 * FZB_TILE);  // STAGE: the first units of the tile's block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     dfa_require_lds_base0(lds);
     for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
@@ -587,9 +416,9 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
     auto comp_at = [](u32 a) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)(256u + a); };
     const u64 g_first = first / 64;  // `first` is a multiple of the tile size
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (tid == 0) { s_cnt = 0; s_used = 0; s_top = 0; }
+        if (tid == 0) s_cnt = 0;
         if (tid < 32) s_bits[tid] = 0;
-        if (STAGE) barrier_lds_only(); else __syncthreads();
+        __syncthreads();
 #pragma unroll 1
         for (int gi = 0; gi < 4; gi++) {
             const u32 p = tile * FZB_TILE + (u32)(gi * 4 + wave) * 64 + lane;  // sorted position (relative to `first`)
@@ -607,28 +436,18 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
             uint4 tail = make_uint4(0, 0, 0, 0);
             if (nv) {  // (wave-uniform width: one load instruction of the width the group was stored with)
                 const u8* tp = gblock + (size_t)(nv - 1) * 1024 + (size_t)lane * tw;
-                const bool nt_ = (stage_dbg & 8) != 0;
-                if (tw == 16) tail = nt_ ? load16_stream<true>((const uint4*)tp) : *(const uint4*)tp;
-                else tail = load_narrow_stream(tp, tw, nt_);
+                if (tw == 16) tail = load16_stream<true>((const uint4*)tp);
+                else tail = load_narrow_stream(tp, tw, true);
             }
             // (non-temporal: a wave's load covers whole lines that nothing reads again - the stream no longer displaces what the later stages
-            // re-read; stage_dbg bit 3 clear = FZB_VIEW_PLAIN_LOADS, for comparison).  The FULL rows land in q[0 .. nv-2]; the narrow last row stays
-            // in `tail` and is the automaton's last step (selecting it into q[nv-1] cost a chain of scalar branches and a full wait per vector)
-            if (stage_dbg & 8) {
+            // re-read: C4 shard 190 -> 183 us).  The FULL rows land in q[0 .. nv-2]; the narrow last row stays in `tail` and is the automaton's
+            // last step (selecting it into q[nv-1] cost a chain of scalar branches and a full wait per vector)
 #pragma unroll
-                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : make_uint4(0, 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? *(const uint4*)(base + (size_t)k * 1024) : make_uint4(0, 0, 0, 0);
-            }
+            for (int k = 0; k < NV; k++) q[k] = (u32)k + 1 < nv ? load16_stream<true>((const uint4*)(base + (size_t)k * 1024)) : make_uint4(0, 0, 0, 0);
             u32 st = 0;
             // one vector of the lane's haystack through the class-composite automaton (vector index kk: only the sanitising form needs it)
             auto step = [&](const uint4& v, u32 kk) {
                 u32 w[4] = {v.x, v.y, v.z, v.w};
-                if (K == 0xFFFFu) {  // measurement knob (FZB_CDFA_NODFA=1, results meaningless): the loads alone
-                    st ^= w[0] ^ w[1] ^ w[2] ^ w[3];
-                    return;
-                }
                 if (SAN) {
                     const u32 rem = hl > 16u * kk ? hl - 16u * kk : 0u;
 #pragma unroll
@@ -666,77 +485,9 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
                 step(q[k], (u32)k);
             }
             if (nv) step(tail, nv - 1);
-            if (STAGE) {  // (the staging form stores the lane's vectors: the last one joins them)
-#pragma unroll
-                for (int k = 0; k < NV; k++)
-                    if ((u32)k + 1 == nv) q[k] = tail;
-            }
             if (p < count && (!LEN || (hl != 0xFFFFu && hl >= min_len)) && st >= acc_lo) {  // (0xFFFF: an outlier beyond 256 bytes - k1_cdfa_outliers decides it)
                 atomicOr(&s_bits[orig >> 5], 1u << (orig & 31));
-                if (STAGE) {
-                    // the vectors go to the tile's block through LDS (the first FZB_STAGE_LDS_UNITS units: written out below by the whole
-                    // workgroup, 256 contiguous vectors per instruction); direct 16-byte stores from the few accepting lanes of a wave cost
-                    // the memory pipeline an instruction per vector and wave (filter 190 -> 227 us on the C4 shard) and stay the overflow path
-                    const u32 nvh = (hl + 15u) >> 4;
-                    const u32 off = atomicAdd(&s_used, nvh);
-                    u32 ent = 0xFFFFu | (hl << 16);
-                    if (off + nvh <= FZB_STAGE_LDS_UNITS) {
-                        ent = off | (hl << 16);
-                        atomicMax(&s_top, off + nvh);
-                        if (!(stage_dbg & 1)) {
-#pragma unroll
-                            for (int k = 0; k < NV; k++)
-                                if ((u32)k < nvh) s_stage[off + k] = q[k];
-                        }
-                    } else if (off + nvh <= FZB_STAGE_UNITS) {
-                        ent = off | (hl << 16);
-                        uint4* dst = (uint4*)(stage + ((size_t)tile * FZB_STAGE_UNITS + off) * 16);
-#pragma unroll
-                        for (int k = 0; k < NV; k++)
-                            if ((u32)k < nvh) dst[k] = q[k];
-                    }
-                    s_ent[orig] = ent;
-                }
             }
-        }
-        if (STAGE) {
-            // Barriers of the staging form order LDS traffic only (barrier_lds_only): __syncthreads() also waits for every outstanding GLOBAL
-            // store, and the tile's copy-out would then expose a store round trip per tile (measured: filter 191 -> 230 us on the C4
-            // shard, 25 us of it the copy-out); what this kernel writes to global memory is read by later kernels only.
-            barrier_lds_only();
-            if (tid < 32) {  // set bits before each word (one wave: 32 lanes take part); the last lane holds the tile's count
-                const u32 c = (u32)__popc(s_bits[tid]);
-                u32 incl = c;
-#pragma unroll
-                for (int off = 1; off < 32; off <<= 1) {
-                    const u32 v = __shfl_up(incl, off);
-                    if (tid >= off) incl += v;
-                }
-                s_wpre[tid] = incl - c;
-                if (tid == 31) tile_counts[tile] = incl;
-            }
-            if (tid >= 64 && tid < 64 + FZB_TILE / 64) {
-                const int t = tid - 64;
-                bitmap[(size_t)tile * (FZB_TILE / 64) + t] = (u64)s_bits[2 * t] | ((u64)s_bits[2 * t + 1] << 32);
-            }
-            if (!(stage_dbg & 2)) {  // the LDS part of the tile's block -> its place in the stage: contiguous 16-byte stores
-                // (an allocation that straddles the LDS limit went to global memory whole: only the units below the last LDS allocation's
-                // end are copied)
-                const u32 live = s_top;
-                uint4* dst = (uint4*)(stage + (size_t)tile * FZB_STAGE_UNITS * 16);
-                for (u32 u = tid; u < live; u += 256) dst[u] = s_stage[u];
-            }
-            barrier_lds_only();
-            if (!(stage_dbg & 4)) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const u32 o = (u32)tid + 256u * k;
-                    const u32 word = s_bits[o >> 5];
-                    if ((word >> (o & 31)) & 1u) stage_hdr[(size_t)tile * FZB_TILE + s_wpre[o >> 5] + (u32)__popc(word & ((1u << (o & 31)) - 1u))] = s_ent[o];
-                }
-            }
-            barrier_lds_only();
-            continue;
         }
         __syncthreads();
         if (tid < FZB_TILE / 64) {
@@ -839,7 +590,7 @@ __global__ __launch_bounds__(256) void k1_cdfa_outliers(const u8* __restrict__ b
 // The last workgroup also publishes the total.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap, const u32* __restrict__ counts, u32 n_items_host, const u32* __restrict__ n_items_ptr,
-                                                  const u32* __restrict__ src, u32* __restrict__ out_idx, u32* __restrict__ total_out, u32* __restrict__ tile_prefix_out,
+                                                  const u32* __restrict__ src, u32* __restrict__ out_idx, u32* __restrict__ total_out,
                                                   u32* __restrict__ total_out2) {
     // n_items_ptr (device) overrides the host count; src, if given, maps a bit position to the value that is listed
     // (the item-list form of the filter: positions in a candidate list -> haystack indices)
@@ -896,7 +647,6 @@ __global__ __launch_bounds__(256) void k_compact1(const u64* __restrict__ bitmap
         u32 wb = 0;
         for (int w = 0; w < wave; w++) wb += red[w];
         pre[tid] = base + wb + incl - c;
-        if (tile_prefix_out && (u32)tid < nt) tile_prefix_out[tb + tid] = base + wb + incl - c;  // survivors before this tile (the handoff's header is per tile)
         const u32 batch_total = red[0] + red[1] + red[2] + red[3];
         __syncthreads();
         // expand the bitmap words of these tiles: the 16 words of a tile sit in 16 consecutive lanes (w0 is a multiple of 16),
@@ -1093,112 +843,77 @@ void fzb_launch_filter_items(const CorpusDev& c, u64 first, const u32* items, co
 // ---------------------------------------------------------------------------------------------------
 // host-side launch wrappers (called from host.hip)
 // ---------------------------------------------------------------------------------------------------
-bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
+void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* table, const u8* dfa, u32 dead, int rows, int mode, int need, u32 min_len,
                        u64* bitmap, u32* tile_counts, u32* reset_counters, int grid, hipStream_t st, u64* bitmap_m, u32* tile_counts_m, u64* reject_bits, u32* tile_rejects, int nul_safe,
-                       int acc_lo, const u8* cdfa, u32 cdfa_bytes, int cdfa_K, int cdfa_G, const StageOut* so) {
+                       int acc_lo, const u8* cdfa, u32 cdfa_bytes, int cdfa_K, int cdfa_G) {
     // mode 1: `dfa` has rows + 1 states, start state 0, and accepts in the states >= acc (the subsequence / unicode / KMP automata: the last
     // state; the LCS automaton of a typo configuration: every state whose LCS reaches the need)
     const u32 acc = acc_lo < 0 ? (u32)rows : (u32)acc_lo;
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
-    // (`grid` = 8 workgroups per CU = every wave slot; FZB_DFA_WGS: 6 per CU 54.3 us, 8 55.1, 5 56.4, 4 59.0 on the C2 list, but the unicode
-    // automaton's list - C5 - takes 1 us more at 6: the default stays 8)
-    const int grid_dfa = std::max(1, std::min<int>(grid * fzb_knobs().dfa_wgs / 8, (int)ntiles));
+    const int cus = std::max(1, grid / 8);  // (`grid` = 8 workgroups per CU = every wave slot)
     if (grid > (int)ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
     if (mode == 1) {
         const size_t lds = (size_t)(rows + 1) * FZB_DFA_STRIDE + 16;  // table + the tile counter
         const bool shortc = c.max_len != 0 && c.max_len <= 32;  // every haystack fits the two pre-requested vectors
         if (shortc) {
-            // a uniform list of 32-byte haystacks (the headline shape): FZB_DFA_UNI32=1 = the instantiation without per-lane lengths (round 5: same 57 us).
-            // FZB_DFA_STRIDE256=1: the table at a 256-byte row pitch (one VALU instruction per byte instead of two; more LDS bank conflicts)
-            const bool uni32 = c.uniform_len == 32 && min_len <= 32 && count != 0 && !fzb_knobs().dfa_general;
-            const size_t lds256 = (size_t)(rows + 1) * 256 + 16;
-#define FZB_K1D(ET, U, S, L) hipLaunchKernelGGL((k1_dfa<ET, U, S>), dim3(grid_dfa), dim3(256), L, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len)
-#define FZB_K1D_S(ET, U) do { if (fzb_knobs().dfa_stride256) FZB_K1D(ET, U, 256u, lds256); else FZB_K1D(ET, U, FZB_DFA_STRIDE, lds); } while (0)
-#define FZB_K1D_U(ET) do { if (uni32) FZB_K1D_S(ET, true); else FZB_K1D_S(ET, false); } while (0)
-            if (c.ends_u64) FZB_K1D_U(u64); else FZB_K1D_U(u32);
-#undef FZB_K1D_U
-#undef FZB_K1D_S
+#define FZB_K1D(ET) hipLaunchKernelGGL((k1_dfa<ET>), dim3(grid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters, c.uniform_len)
+            if (c.ends_u64) FZB_K1D(u64); else FZB_K1D(u32);
 #undef FZB_K1D
-        } else {
-            // ragged lists: one haystack per thread, 6 resident workgroups per CU (measured on the 8..128-byte list: 311 us
-            // vs 498 us for the 4-way kernel at full occupancy, whose L2 footprint re-fetched every line 2-4 times).
-            // Tried in round 2 and dropped: sorting a tile's haystacks by length class in LDS before the DFA (no SIMT length
-            // divergence, no sanitising of the zero fill) - 460-490 us instead of 298: a wave's 64 lanes then touch 64 scattered
-            // 128-byte lines instead of ~34 adjacent ones, and the kernel is bound by cache transactions, not by instruction issue.
-            int rgrid = std::min<int>((grid / 8) * 6, (int)ntiles);
-            if (rgrid < 1) rgrid = 1;
-            // the class-composite automaton of `dfa` (host-built: fzb_matcher_create): one dependent lookup per 4 (or 2) bytes
-            const FzbKnobs& kn = fzb_knobs();
-            const bool no_cdfa = kn.no_cdfa;
-            const int cwg = kn.cdfa_wgs;  // resident workgroups per CU (C4 shard: 8 -> 247 us, 5 -> 232, 4 -> 229)
-            const bool no_view = kn.no_filter_view;
-            const int vwg = kn.view_wgs;  // (C4 shard: 8 -> 190 us, 6 -> 187, 4 -> 194)
-            if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2) && c.vbytes && !no_view && first % FZB_TILE == 0 && (first + count == c.n || count % FZB_TILE == 0) &&
-                c.view_nv != 0 && c.view_nv <= 16) {
-                const bool stg = so && so->stage && so->hdr && c.n_long == 0;  // (an outlier's survivor would have no header entry: no handoff on such a list)
-                const size_t lds_v = ((cdfa_bytes + 15) & ~(size_t)15) + 16 + 128 + (stg ? 128 + 4 * FZB_TILE + 16 * FZB_STAGE_LDS_UNITS : 0);
-                const int g = std::max(1, std::min<int>((grid / 8) * vwg, (int)ntiles));
-                u32 kg = 1;
-                for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
-                if (kn.cdfa_nodfa) cdfa_K = 0xFFFF;
-                // (the lengths are not read when nothing needs them: acc >= 1 = the start state does not accept; FZB_VIEW_READ_LEN=1 compares)
-                const bool len_free = nul_safe && acc >= 1 && !kn.view_read_len;
-#define FZB_K1VN(SAN, G, NV) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, false, false>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, (u8*)nullptr, (u32*)nullptr, (u32)kn.stage_dbg | (kn.view_plain_loads ? 0u : 8u))
-#define FZB_K1V(SAN, G, NV, STG) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, STG>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters, stg ? so->stage : nullptr, stg ? so->hdr : nullptr, (u32)kn.stage_dbg | (kn.view_plain_loads ? 0u : 8u))
-#define FZB_K1V_S(SAN, G, NV) do { if (stg) FZB_K1V(SAN, G, NV, true); else if (!SAN && len_free) FZB_K1VN(SAN, G, NV); else FZB_K1V(SAN, G, NV, false); } while (0)
+            return;
+        }
+        // Ragged lists: one haystack per thread.  Three forms, best first: the class-composite automaton over the corpus' filter VIEW (6 resident
+        // workgroups per CU: C4 shard 8 -> 190 us, 6 -> 187, 4 -> 194), the same automaton over the canonical layout (5 per CU: 8 -> 247 us,
+        // 5 -> 232) when the corpus has no view or the range is not tile-aligned, and the byte automaton in its burst form (8 per CU) when the
+        // composite table does not fit (host.hip: states x K^G <= 16 KB) or FZB_NO_CDFA=1 asks for it.
+        const FzbKnobs& kn = fzb_knobs();
+        const bool composite = cdfa && !kn.no_cdfa && (cdfa_G == 4 || cdfa_G == 2);
+        u32 kg = 1;
+        for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
+        if (composite && c.vbytes && !kn.no_filter_view && first % FZB_TILE == 0 && (first + count == c.n || count % FZB_TILE == 0) && c.view_nv != 0 && c.view_nv <= 16) {
+            const size_t lds_v = ((cdfa_bytes + 15) & ~(size_t)15) + 16 + 128;
+            const int g = std::max(1, std::min<int>(cus * 6, (int)ntiles));
+            // (the lengths are not read when nothing needs them: acc >= 1 = the start state does not accept)
+            const bool len_free = nul_safe && acc >= 1;
+#define FZB_K1V(SAN, G, NV, LEN) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, LEN>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
+#define FZB_K1V_S(SAN, G, NV) do { if (!SAN && len_free) FZB_K1V(SAN, G, NV, false); else FZB_K1V(SAN, G, NV, true); } while (0)
 #define FZB_K1V_NV(SAN, G) do { if (c.view_nv <= 8) FZB_K1V_S(SAN, G, 8); else FZB_K1V_S(SAN, G, 16); } while (0)
 #define FZB_K1V_G(SAN) do { if (cdfa_G == 4) FZB_K1V_NV(SAN, 4); else FZB_K1V_NV(SAN, 2); } while (0)
-                if (nul_safe) FZB_K1V_G(false); else FZB_K1V_G(true);
+            if (nul_safe) FZB_K1V_G(false); else FZB_K1V_G(true);
 #undef FZB_K1V_G
 #undef FZB_K1V_NV
 #undef FZB_K1V_S
 #undef FZB_K1V
-#undef FZB_K1VN
-                if (c.n_long) {  // the haystacks beyond 256 bytes: decided from the canonical layout, OR-ed into the view kernel's bitmap
-                    const u32 ns_o = (cdfa_bytes - 256u) / kg;  // the automaton's states (the table is padded to 16 bytes: at most a phantom state more)
-                    const u32 wpw = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)4 * 64 * ns_o + 16 <= 60 * 1024 ? 4u : 1u;
-                    const size_t lds_o = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)wpw * 64 * ns_o + 16;
-                    const int go = (int)std::max<u32>(1u, std::min<u32>((c.n_long + wpw - 1) / wpw, 4096u));
+            if (c.n_long) {  // the haystacks beyond 256 bytes: decided from the canonical layout, OR-ed into the view kernel's bitmap
+                const u32 ns_o = (cdfa_bytes - 256u) / kg;  // the automaton's states (the table is padded to 16 bytes: at most a phantom state more)
+                const u32 wpw = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)4 * 64 * ns_o + 16 <= 60 * 1024 ? 4u : 1u;
+                const size_t lds_o = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)wpw * 64 * ns_o + 16;
+                const int go = (int)std::max<u32>(1u, std::min<u32>((c.n_long + wpw - 1) / wpw, 4096u));
 #define FZB_K1O(ET, SAN, G) hipLaunchKernelGGL((k1_cdfa_outliers<ET, SAN, G>), dim3(go), dim3(64 * wpw), lds_o, st, c.bytes, (const ET*)c.ends, first, count, c.vlong, c.n_long, cdfa, cdfa_bytes, (u32)cdfa_K, kg, ns_o, min_len, dead, acc, bitmap, tile_counts)
 #define FZB_K1O_G(ET, SAN) do { if (cdfa_G == 4) FZB_K1O(ET, SAN, 4); else FZB_K1O(ET, SAN, 2); } while (0)
-                    if (c.ends_u64) { if (nul_safe) FZB_K1O_G(u64, false); else FZB_K1O_G(u64, true); }
-                    else            { if (nul_safe) FZB_K1O_G(u32, false); else FZB_K1O_G(u32, true); }
+                if (c.ends_u64) { if (nul_safe) FZB_K1O_G(u64, false); else FZB_K1O_G(u64, true); }
+                else            { if (nul_safe) FZB_K1O_G(u32, false); else FZB_K1O_G(u32, true); }
 #undef FZB_K1O_G
 #undef FZB_K1O
-                }
-                return stg && !kn.cdfa_nodfa;
             }
-            if (cdfa && !no_cdfa && (cdfa_G == 4 || cdfa_G == 2)) {
-                const size_t lds_c = ((cdfa_bytes + 15) & ~(size_t)15) + 16;
-                const int g = std::max(1, std::min<int>((grid / 8) * cwg, (int)ntiles));
-                u32 kg = 1;
-                for (int i = 0; i < cdfa_G; i++) kg *= (u32)cdfa_K;
-                if (kn.cdfa_nodfa) cdfa_K = 0xFFFF;
+            return;
+        }
+        if (composite) {
+            const size_t lds_c = ((cdfa_bytes + 15) & ~(size_t)15) + 16;
+            const int g = std::max(1, std::min<int>(cus * 5, (int)ntiles));
 #define FZB_K1CD(ET, SAN, G) hipLaunchKernelGGL((k1_cdfa_ragged<ET, SAN, G>), dim3(g), dim3(256), lds_c, st, c.bytes, (const ET*)c.ends, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
 #define FZB_K1CD_G(ET, SAN) do { if (cdfa_G == 4) FZB_K1CD(ET, SAN, 4); else FZB_K1CD(ET, SAN, 2); } while (0)
-                if (c.ends_u64) { if (nul_safe) FZB_K1CD_G(u64, false); else FZB_K1CD_G(u64, true); }
-                else            { if (nul_safe) FZB_K1CD_G(u32, false); else FZB_K1CD_G(u32, true); }
+            if (c.ends_u64) { if (nul_safe) FZB_K1CD_G(u64, false); else FZB_K1CD_G(u64, true); }
+            else            { if (nul_safe) FZB_K1CD_G(u32, false); else FZB_K1CD_G(u32, true); }
 #undef FZB_K1CD_G
 #undef FZB_K1CD
-                return false;
-            }
-            const bool burst = kn.ragged_burst;  // false = the rolling form, for comparison
-            const int bwgs = kn.ragged_wgs;
-            if (burst) {
-                rgrid = std::max(1, std::min<int>((grid / 8) * bwgs, (int)ntiles));
-#define FZB_K1B(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_burst<ET, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
-                if (c.ends_u64) { if (nul_safe) FZB_K1B(u64, false); else FZB_K1B(u64, true); }
-                else            { if (nul_safe) FZB_K1B(u32, false); else FZB_K1B(u32, true); }
-#undef FZB_K1B
-                return false;
-            }
-#define FZB_K1R(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged<ET, 1, SAN>), dim3(rgrid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
-            if (c.ends_u64) { if (nul_safe) FZB_K1R(u64, false); else FZB_K1R(u64, true); }
-            else            { if (nul_safe) FZB_K1R(u32, false); else FZB_K1R(u32, true); }
-#undef FZB_K1R
+            return;
         }
-        return false;
+#define FZB_K1B(ET, SAN) hipLaunchKernelGGL((k1_dfa_ragged_burst<ET, SAN>), dim3(grid), dim3(256), lds, st, c.bytes, (const ET*)c.ends, first, count, dfa, rows, min_len, dead, acc, bitmap, tile_counts, reset_counters)
+        if (c.ends_u64) { if (nul_safe) FZB_K1B(u64, false); else FZB_K1B(u64, true); }
+        else            { if (nul_safe) FZB_K1B(u32, false); else FZB_K1B(u32, true); }
+#undef FZB_K1B
+        return;
     }
     const bool w64 = (mode == 1) ? rows > 31 : rows > 32;
     if (mode == 2 && bitmap_m) {  // LCS filter with the "nothing to spare" bit (typo configurations on the short-haystack path)
@@ -1207,7 +922,7 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         if (c.ends_u64) { if (w64) FZB_K1M(u64, u64); else FZB_K1M(u32, u64); }
         else            { if (w64) FZB_K1M(u64, u32); else FZB_K1M(u32, u32); }
 #undef FZB_K1M
-        return false;
+        return;
     }
 #define FZB_K1(TW, MODE, ET) hipLaunchKernelGGL((k1_filter<TW, MODE, ET>), dim3(grid), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, count, table, rows, need, min_len, bitmap, tile_counts, reset_counters, MargOut{}, c.uniform_len)
     if (c.ends_u64) {
@@ -1218,7 +933,6 @@ bool fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
         else           { if (w64) FZB_K1(u64, 2, u32); else FZB_K1(u32, 2, u32); }
     }
 #undef FZB_K1
-    return false;
 }
 
 // Exclusive prefix of the per-tile reject counts (decide form of k2a_window) - only when something was rejected at all, which on
@@ -1253,8 +967,8 @@ void fzb_launch_scan_rejects(const u32* tile_rejects, u32 ntiles, const u32* rej
 }
 
 void fzb_launch_compact1(const u64* bitmap, const u32* counts, u32 n_items, const u32* n_items_ptr, const u32* src, u32* out_idx, u32* total_out, int grid, hipStream_t st,
-                         u32* tile_prefix_out, u32* total_out2) {
-    hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, n_items_ptr, src, out_idx, total_out, tile_prefix_out, total_out2);
+                         u32* total_out2) {
+    hipLaunchKernelGGL(k_compact1, dim3(grid), dim3(256), 0, st, bitmap, counts, n_items, n_items_ptr, src, out_idx, total_out, total_out2);
 }
 
 __global__ void k_init_counters(u32* __restrict__ counters, u32 n0) {

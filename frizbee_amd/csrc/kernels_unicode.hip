@@ -202,9 +202,8 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
     // `grid` = number of CUs: the kernel is persistent, launch exactly the resident workgroups
     const bool half_only = sw_lanes >= 16 && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2;
     // the biased-throughout form wants ~250 registers: at two waves per SIMD it runs without spills (C5: 0.152 ms; capped at 168 registers /
-    // three waves it spills inside the row loop: 0.199 ms; the first form at three waves: 0.161 ms).  FZB_K2U_WAVES=3 forces the capped build.
-    const bool w3 = fzb_knobs().k2u_waves == 3;
-    const bool w2 = tform && !w3;
+    // three waves it spills inside the row loop: 0.199 ms; the first form at three waves: 0.161 ms)
+    const bool w2 = tform != 0;
 #define FZB_K2U(SWL, TF, ET)                                                                                                           \
     do {                                                                                                                               \
         static int per_cu = 0, per_cu_half = 0;                                                                                        \

@@ -572,11 +572,10 @@ struct ManyScratch {
 // `rej.bits`, bumps its tile's count and the total.
 // min_len: haystacks shorter than this are rejected first (`original_len >= self.min_haystack_len`, src/matcher/algo.rs:88) - the
 // streaming filter does it on the usual path; for a long needle this kernel is the first stage.
-// TPB = threads per workgroup: a 1024-haystack tile takes 1024 / TPB passes.  256 for lists whose tiles fill the chip several times over;
-// 1024 - one pass - for the lists a typo query usually sees: with a few hundred tiles every workgroup is resident at once and the kernel
-// lasts as long as ONE tile, four dependent passes of a latency-bound scan (Arabic-shaped list, 1 typo: 105 tiles, 163 us of a 248 us step).
-template <int PFL, int ALG, bool DECIDE = false, typename ND = NeedleDev, int TPB = 256>
-__global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
+// 256-thread workgroups, four passes per 1024-haystack tile (item lists, the decide form, long needles, the unicode 0-typo algorithm when its
+// automaton does not fit; contiguous ranges of a typo query take k2a_window_pre below).
+template <int PFL, int ALG, bool DECIDE = false, typename ND = NeedleDev>
+__global__ __launch_bounds__(256) void k2a_window(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
                                                   const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const ND nd,
                                                   u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, int use_cache, RejectOut rej, u32 min_len,
                                                   ManyScratch many) {
@@ -585,6 +584,7 @@ __global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, 
     const u32 M = *n_surv_ptr;
     const u32 ntiles = (M + FZB_TILE - 1) / FZB_TILE;
     const int tid = threadIdx.x;
+    constexpr int TPB = 256;
     for (u32 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         if (tid == 0) s_cnt = 0;
         __syncthreads();
@@ -656,22 +656,21 @@ __global__ __launch_bounds__(TPB) void k2a_window(const u8* __restrict__ bytes, 
     }
 }
 
-// The PRE form of the kernel above for the typo algorithms over short needles (NeedleDev), one 1024-haystack tile per 1024-thread
+// The PRE form of the kernel above for the typo algorithms over short needles (NeedleDev), a QUARTER of a 1024-haystack tile per 256-thread
 // workgroup: (1) every thread notes its haystack's span and number of PFL-byte chunks, a workgroup scan gives each haystack its place in
 // the mask buffer; (2) the tile's (haystack, chunk) pairs are dealt out round-robin - a thread finds a pair's owner by bisection over
 // the scan - and every needle row's occurrence mask goes to LDS; (3) thread per haystack, the reference's walk over PreSrc.  Pairs beyond
 // the buffer (cap_pairs) are not laid out: their haystacks compute on demand, as in the plain form.  Same results bit for bit (the masks
-// are the same function of the same bytes): tests/test_gpu_knobs.py runs both forms against the oracle (FZB_WINDOW_NO_PRE=1).
-template <int PFL, int ALG, int TPB>
-__global__ __launch_bounds__(TPB) void k2a_window_pre(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
+// are the same function of the same bytes).
+template <int PFL, int ALG>
+__global__ __launch_bounds__(256) void k2a_window_pre(const u8* __restrict__ bytes, const void* __restrict__ ends_v, int ends_u64, u64 first,
                                                       const u32* __restrict__ surv_idx, const u32* __restrict__ n_surv_ptr, const NeedleDev nd,
-                                                      u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32 cap_pairs, u32 dbg) {
-    // (dbg: MEASUREMENT ONLY, FZB_WINDOW_DBG - bit 0: no masks laid out (phase 2 skipped), 1: no walk (phase 3 skipped), 2: the walk without its
-    // end scan; results meaningless)
-    // TPB < 1024: a workgroup owns a PART of a 1024-haystack tile (NQ = 1024 / TPB parts per tile, one unit of work each) and ADDS its count to
-    // the tile's (the launcher zeroes the counts).  What the measurement bits showed on the Arabic-shaped 1-typo query (105 tiles, 1024-thread
-    // workgroups: 96 us for the stage): the masks laid out ahead are 10 us of it, the WALK 66 - sixteen waves of divergent per-haystack
-    // loops sharing four SIMDs on 105 of the 256 CUs.  As quarter tiles the same walks run on every CU, one or two waves per SIMD.
+                                                      u32* __restrict__ win, u64* __restrict__ bitmap2, u32* __restrict__ tile_counts2, u32 cap_pairs) {
+    // A workgroup owns a PART of a 1024-haystack tile (NQ = 4 parts per tile, one unit of work each) and ADDS its count to the tile's (the
+    // launcher zeroes the counts).  Round 5 measured the one-tile-per-1024-thread-workgroup form on the Arabic-shaped 1-typo query (105 tiles:
+    // 96 us for the stage): the masks laid out ahead are 10 us of it, the WALK 66 - sixteen waves of divergent per-haystack loops sharing four
+    // SIMDs on 105 of the 256 CUs.  As quarter tiles the same walks run on every CU, one or two waves per SIMD (67 us).
+    constexpr int TPB = 256;
     constexpr int NQ = FZB_TILE / TPB;
     constexpr bool UNI = ALG >= ALG_UNI_0 && ALG != ALG_ASCII_0;
     using Real = typename std::conditional<UNI, UnicodeSrc<PFL, NeedleDev>, AsciiSrc<PFL, NeedleDev>>::type;
@@ -711,7 +710,7 @@ __global__ __launch_bounds__(TPB) void k2a_window_pre(const u8* __restrict__ byt
         if (tid == TPB - 1) s_base[TPB] = base + nch;
         __syncthreads();
         const u32 T = min(s_base[TPB], cap_pairs);
-        for (u32 q = tid; q < ((dbg & 1u) ? 0u : T); q += TPB) {
+        for (u32 q = tid; q < T; q += TPB) {
             u32 lo = 0, hi = TPB - 1;  // the last t with s_base[t] <= q (haystacks without chunks share their successor's base and are skipped)
             while (lo < hi) {
                 const u32 mid = (lo + hi + 1) >> 1;
@@ -725,9 +724,9 @@ __global__ __launch_bounds__(TPB) void k2a_window_pre(const u8* __restrict__ byt
         }
         __syncthreads();
         bool keep = false;
-        if (j < M && !(dbg & 2u)) {
+        if (j < M) {
             const u32 ahead = base + nch <= T ? nch : 0;  // a haystack is laid out whole or not at all
-            PreSrc<PFL, Real> src(nd, bytes + s, (dbg & 4u) ? min(L, (u32)PFL) : L, mask_buf + (size_t)base * rows, ahead);
+            PreSrc<PFL, Real> src(nd, bytes + s, L, mask_buf + (size_t)base * rows, ahead);
             Win w;
             if (ALG == ALG_UNI_1 || ALG == ALG_ASCII_1) w = prefilter_1_typo<PFL>(src);
             else if (ALG == ALG_UNI_2 || ALG == ALG_ASCII_2) w = prefilter_2_typos<PFL>(src);
@@ -745,23 +744,19 @@ __global__ __launch_bounds__(TPB) void k2a_window_pre(const u8* __restrict__ byt
             if (b) atomicAdd(&s_cnt, (u32)__popcll(b));
         }
         __syncthreads();
-        if (tid == 0) {
-            if (NQ == 1) tile_counts2[tile] = s_cnt;
-            else if (s_cnt) atomicAdd(&tile_counts2[tile], s_cnt);
-        }
+        if (tid == 0 && s_cnt) atomicAdd(&tile_counts2[tile], s_cnt);
         __syncthreads();
     }
 }
 
 template <int PFL>
 static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, u32* win, u64* bitmap2,
-                              u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, bool one_pass, u32 max_items) {
+                              u32* tile_counts2, int grid, hipStream_t st, const RejectOut* decide, u32 max_items) {
     const int k = nd.max_typos;
     const int alg = nd.unicode ? (k == 0 ? ALG_UNI_0 : k == 1 ? ALG_UNI_1 : k == 2 ? ALG_UNI_2 : ALG_UNI_N) : (k == 1 ? ALG_ASCII_1 : k == 2 ? ALG_ASCII_2 : ALG_ASCII_N);
-    // occurrence-mask cache in LDS (ASCII and, since round 4, unicode algorithms): rows x 2 KB per 256-thread workgroup, up to 16 rows (one-pass form: rows x 8 KB, up to 7)
-    const int tpb = (one_pass && !decide) ? 1024 : 256;
-    const int use_cache = nd.rows <= 16 && (size_t)nd.rows * tpb * 8 <= 60 * 1024 && !fzb_knobs().window_no_mask_cache;
-    const size_t lds = use_cache ? (size_t)nd.rows * tpb * 8 : 0;
+    // occurrence-mask cache in LDS of the plain form (ASCII and unicode algorithms): rows x 2 KB per 256-thread workgroup, up to 16 rows
+    const int use_cache = nd.rows <= 16;
+    const size_t lds = use_cache ? (size_t)nd.rows * 256 * 8 : 0;
     const ManyScratch none{nullptr, nullptr};
     if (decide) {  // ASCII typo algorithms only (the unicode path keeps the full form)
 #define FZB_K2A_D(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG, true>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, *decide, 0u, none)
@@ -771,41 +766,13 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 #undef FZB_K2A_D
         return;
     }
-    // the PRE form (masks laid out ahead by the whole workgroup): one-pass launches of the typo algorithms over a corpus below 64 GiB;
-    // the buffer takes what the device gives a workgroup beyond the kernel's 12.3 KB of static LDS (asked for once per instantiation)
-    // (the quarter-tile form walks its units with a grid-stride loop: lists of any size; the whole-tile form keeps round 4's one-pass bound;
-    // FZB_WINDOW_FOUR_PASS=1 and FZB_WINDOW_NO_PRE=1 are the older forms)
-    const bool quarters_any = !decide && max_items != 0 && !fzb_knobs().window_whole_tiles && !fzb_knobs().window_four_pass;
-    if ((one_pass || quarters_any) && alg != ALG_UNI_0 && !fzb_knobs().window_no_pre && c.total_bytes < ((u64)1 << 36)) {
-        static const size_t lds_max = [] {
-            int dev = 0, v = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 64 * 1024;
-            (void)hipGetLastError();
-            return (size_t)std::max(v, 64 * 1024);
-        }();
-        // quarter tiles (256-thread workgroups, four per tile, counts added to the zeroed tile counts) unless FZB_WINDOW_WHOLE_TILES=1
-        const bool quarters = !fzb_knobs().window_whole_tiles && max_items != 0;
+    // the PRE form (masks laid out ahead by the whole workgroup, quarter tiles, a grid-stride loop over the units: lists of any size): the typo
+    // algorithms over a range whose size the host knows (the tile counts it adds to are zeroed here) in a corpus below 64 GiB
+    if (max_items != 0 && alg != ALG_UNI_0 && c.total_bytes < ((u64)1 << 36)) {
         const u32 ntiles_max = (max_items + FZB_TILE - 1) / FZB_TILE;
-        if (quarters) (void)hipMemsetAsync(tile_counts2, 0, (size_t)ntiles_max * 4, st);
-        const size_t dyn = quarters ? (size_t)40 * 1024 : std::min<size_t>(lds_max, 144 * 1024) - 13 * 1024;
-#define FZB_K2A_P(ALG)                                                                                                                                          \
-    do {                                                                                                                                                        \
-        if (quarters) {                                                                                                                                         \
-            hipLaunchKernelGGL((k2a_window_pre<PFL, ALG, 256>), dim3(std::max<u32>(1u, std::min<u32>(ntiles_max * 4u, (u32)grid * 8u))), dim3(256), dyn, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, \
-                               bitmap2, tile_counts2, (u32)(dyn / 8 / (size_t)std::max(nd.rows, 1)), (u32)fzb_knobs().window_dbg);                            \
-            break;                                                                                                                                              \
-        }                                                                                                                                                       \
-        static size_t granted = 0;                                                                                                                              \
-        if (!granted) {                                                                                                                                         \
-            granted = 51 * 1024;                                                                                                                                \
-            if (dyn > granted && hipFuncSetAttribute((const void*)k2a_window_pre<PFL, ALG, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess) \
-                granted = dyn;                                                                                                                                  \
-            (void)hipGetLastError();                                                                                                                            \
-        }                                                                                                                                                       \
-        const size_t use = std::min(dyn, granted);                                                                                                              \
-        hipLaunchKernelGGL((k2a_window_pre<PFL, ALG, 1024>), dim3(grid), dim3(1024), use, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, \
-                           (u32)(use / 8 / (size_t)std::max(nd.rows, 1)), (u32)fzb_knobs().window_dbg);                                                        \
-    } while (0)
+        (void)hipMemsetAsync(tile_counts2, 0, (size_t)ntiles_max * 4, st);
+        const size_t dyn = (size_t)40 * 1024;
+#define FZB_K2A_P(ALG) hipLaunchKernelGGL((k2a_window_pre<PFL, ALG>), dim3(std::max<u32>(1u, std::min<u32>(ntiles_max * 4u, (u32)grid * 8u))), dim3(256), dyn, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, (u32)(dyn / 8 / (size_t)std::max(nd.rows, 1)))
         switch (alg) {
             case ALG_ASCII_1: FZB_K2A_P(ALG_ASCII_1); break;
             case ALG_ASCII_2: FZB_K2A_P(ALG_ASCII_2); break;
@@ -817,11 +784,7 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 #undef FZB_K2A_P
         return;
     }
-#define FZB_K2A(ALG)                                                                                                                                                          \
-    do {                                                                                                                                                                      \
-        if (one_pass) hipLaunchKernelGGL((k2a_window<PFL, ALG, false, NeedleDev, 1024>), dim3(grid), dim3(1024), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none); \
-        else hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none);                                   \
-    } while (0)
+#define FZB_K2A(ALG) hipLaunchKernelGGL((k2a_window<PFL, ALG>), dim3(grid), dim3(256), lds, st, c.bytes, c.ends, c.ends_u64, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, use_cache, RejectOut{}, 0u, none)
     switch (alg) {
         case ALG_ASCII_1: FZB_K2A(ALG_ASCII_1); break;
         case ALG_ASCII_2: FZB_K2A(ALG_ASCII_2); break;
@@ -836,14 +799,10 @@ static void launch_window_pfl(const CorpusDev& c, u64 first, const u32* surv_idx
 
 void fzb_launch_window(const CorpusDev& c, u64 first, const u32* surv_idx, const u32* n_surv_ptr, const NeedleDev& nd, int pf_lanes,
                        u32* win, u64* bitmap2, u32* tile_counts2, u32* counters, int grid, hipStream_t st, const RejectOut* decide, u32 max_items) {
-    // max_items: an upper bound of *n_surv_ptr known on the host (the range's size; 0 = unknown).  Up to 8 x 1024 haystacks per CU the one-pass
-    // form (grid / 4 = CUs: callers pass four workgroups per CU): the survivors of a typo filter are a fraction of the range (paths-shaped
-    // list, 1.4 M items: 169 k / 225 k / 281 k for 1 / 2 / 3 typos = 165-274 tiles, every workgroup resident at once), and in a kernel that is
-    // one chain of dependent passes per tile a 1024-thread workgroup is never behind four 256-thread passes even when every haystack survives
-    const bool one_pass = !decide && max_items != 0 && !fzb_knobs().window_four_pass && (u64)max_items <= (u64)(grid / 4 > 0 ? grid / 4 : 1) * 1024u * 8u;
-    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass, max_items);
-    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass, max_items);
-    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, one_pass, max_items);
+    // max_items: an upper bound of *n_surv_ptr known on the host (the range's size; 0 = unknown: item lists)
+    if (pf_lanes == 64) launch_window_pfl<64>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, max_items);
+    else if (pf_lanes == 32) launch_window_pfl<32>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, max_items);
+    else launch_window_pfl<16>(c, first, surv_idx, n_surv_ptr, nd, win, bitmap2, tile_counts2, grid, st, decide, max_items);
 }
 
 // ---- long needles: this kernel is the FIRST stage (length test + the reference's prefilter at the exact lane width, every typo

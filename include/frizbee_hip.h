@@ -322,11 +322,6 @@ int fzb_debug_cdfa_state(const fzb_matcher* m, const uint8_t* bytes, size_t len,
  * read again.  Matchers created before the call keep what was decided when they were created. */
 void fzb_debug_reload_knobs(void);
 
-/* experiment hook (tools/exp_r6_corun.py): the streaming filter of the matcher's following queries waits for the HIP event
- * `wait_before_filter` and `record_after_filter` is recorded on the query's stream right behind it (either may be NULL).  Lets sub-range
- * pipelines on several streams run their filters one after the other, each beside the previous sub-range's scorers. */
-int fzb_debug_set_gate(fzb_matcher* m, void* wait_before_filter, void* record_after_filter);
-
 #ifdef __cplusplus
 }
 #endif

@@ -250,3 +250,48 @@ def test_window_kernel_mask_buffer_overflow_and_long_walks(pf):
         want = O.Matcher(needle, lanes=lanes, max_typos=typos).match_list(uni)
         got = F.Matcher(needle, F.Config(max_typos=typos, pf_lanes=pf)).match_list(uni)
         assert got.tolist() == want.tolist() and len(want) > 100, (needle, typos, pf)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("needle,cfg", [("deadbe", dict()), ("deadbe", dict(max_typos=1)), ("éa", dict(max_typos=None)), ("éa", dict())])
+def test_a_workspace_sized_by_a_small_range_is_not_reused_for_a_range_within_4096_of_its_capacity(needle, cfg):
+    """The queue of windows wider than a chunk is anchored at `count + 4096` entries (the back: windows beyond 1024 bytes and the unicode
+    scorer's handed-on stragglers).  A workspace allocated for 1000 items holds 1000 + 125 + 4096 = 5221 entries: a later range of 5000 items
+    on the same matcher must grow it, not write its back entries at index 9095 of a 5221-entry array (the round-5 advisor's finding)."""
+    import random
+    rng = random.Random(11)
+    alpha = "deabé_-/ xyzDEA"
+    def hay(L):
+        s = [rng.choice(alpha) for _ in range(L)]
+        for q, c in zip(sorted(rng.sample(range(L), len(needle))), needle):
+            s[q] = c
+        return "".join(s)
+    hs = [hay(rng.randint(8, 60)) for _ in range(5000)]
+    for k in rng.sample(range(1000, 5000), 40):
+        hs[k] = hay(rng.choice([1100, 1500, 300, 700]))  # windows beyond 1024 bytes (greedy: the queue's back) and beyond four chunks (handed on)
+    cp = F.Corpus(hs)
+    m = F.Matcher(needle, F.Config(pf_lanes=64, sw_lanes=64, max_typos=cfg.get("max_typos", 0)))
+    om = O.Matcher(needle, lanes=(64, 64, 32), **cfg)
+    head = O.Matcher(needle, lanes=(64, 64, 32), sort="IndexAsc", **cfg).match_list(hs[:1000])  # (index order = what match_list_into returns)
+    assert m.match_list_into(cp, first=0, count=1000).tolist() == head.tolist()
+    got = m.match_list(cp)   # 5000 items on the workspace the first call allocated for 1000
+    assert got.tolist() == om.match_list(hs).tolist()
+    fresh = F.Matcher(needle, F.Config(pf_lanes=64, sw_lanes=64, max_typos=cfg.get("max_typos", 0))).match_list(cp)
+    assert got.tolist() == fresh.tolist()
+
+
+@pytest.mark.gpu
+def test_a_looser_bound_beside_a_uniform_length_is_accepted_and_a_tighter_one_refused():
+    dev = torch.device("cuda", 0)
+    n = 5000
+    rows = synth.make_rows(b"deadbe", n, 32, seed=3, device=dev)
+    flat = torch.zeros(n * 32 + 256, dtype=torch.uint8, device=dev)
+    flat[: n * 32].view(n, 32).copy_(rows)
+    ends = (torch.arange(1, n + 1, dtype=torch.int64, device=dev) * 32).to(torch.int32)
+    cp = F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=64, uniform_len=32)  # 64 >= 32: implied, ignored
+    host = np.concatenate([flat[: n * 32].cpu().numpy(), np.zeros(64, np.uint8)])
+    want = O.Matcher("deadbe").match_packed(host, np.arange(1, n + 1, dtype=np.uint64) * np.uint64(32))
+    assert F.Matcher("deadbe", F.Config(pf_lanes=64)).match_list(cp).tolist() == want.tolist()
+    with pytest.raises(F.FrizbeeError) as e:
+        F.Corpus.from_device(flat.data_ptr(), ends.data_ptr(), n, flat.numel(), keep=(flat, ends), max_len=16, uniform_len=32)
+    assert "not an upper bound" in str(e.value)

@@ -1,5 +1,5 @@
-"""Every environment switch of frizbee_amd/csrc/knobs.h that selects ANOTHER FORM of a stage (the older / literal form of the same
-arithmetic, kept for comparison) produces the oracle's records on the GPU; the tuning switches (grid shapes) leave the records unchanged.
+"""Every environment switch of frizbee_amd/csrc/knobs.h that forces ANOTHER SHIPPING FORM of a stage (the form that serves the needles,
+scorings or corpora outside the fast form's preconditions) produces the oracle's records on the GPU, on ordinary inputs.
 One process: fzb_debug_reload_knobs() re-reads the environment; matchers are created after it (some decisions are taken at creation)."""
 import os
 import random
@@ -46,43 +46,19 @@ def _same(lists, which, needle, **cfg):
 
 
 CASES = [  # (environment, [(list, needle, oracle config)])
-    ({"FZB_NO_LCS_DFA": "1"}, [("short", "deadbe", dict(max_typos=1)), ("ragged", "deadbeef", dict(max_typos=2))]),
-    ({"FZB_TYPO_EXACT_WINDOW": "1"}, [("short", "deadbe", dict(max_typos=2)), ("ragged", "deadbeef", dict(max_typos=1))]),
-    ({"FZB_NO_DP_CFU": "1"}, [("uni", "éa", dict())]),
-    ({"FZB_K2U_WAVES": "3"}, [("uni", "éa", dict())]),
-    ({"FZB_NO_DP_CLASSES": "1"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_NO_DP_CFM": "1"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_NO_TAIL_CLASSES": "1"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),                      # four scorer launches on two streams
-    ({"FZB_SMALL_LIST": "0", "FZB_NO_OVERLAP": "1"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_HANDOFF_MIN_TILES": "0"}, [("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),  # the 16-vector view kernel, staging
-    ({"FZB_NO_OVERLAP": "1"}, [("uniwide", "éa", dict(max_typos=None))]),      # whole-haystack unicode windows: the scorer queues the wide ones itself, one stream
-    ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict(max_typos=None))]),   # ... queued ahead (default), thread per haystack beside the single-chunk scorer
-    ({"FZB_UNICODE_MULTI": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),
-    ({"FZB_UNICODE_MULTI": "1", "FZB_UNICODE_FWD": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),  # the thread-per-haystack scorer keeps its stragglers
-    ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict()), ("uniwide", "éa", dict(max_typos=1))]),                               # ... hands them on (default)
-    ({"FZB_WINDOW_FOUR_PASS": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=1))]),  # the lane-exact window kernel, 256-thread form
-    ({"FZB_WINDOW_NO_MASK_CACHE": "1"}, [("ragged", "deadbe", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uni", "éa", dict(max_typos=2))]),  # row masks recomputed at every request
-    ({"FZB_WINDOW_NO_MASK_CACHE": "1", "FZB_WINDOW_FOUR_PASS": "1"}, [("uniwide", "éa", dict(max_typos=1))]),
-    ({"FZB_DFA_WGS": "3"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),
-    ({"FZB_DFA_UNI32": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=1))]),          # k1_dfa without per-lane lengths on the uniform 32-byte list
-    ({"FZB_DFA_STRIDE256": "1"}, [("short", "deadbe", dict()), ("short", "deadbe", dict(max_typos=2))]),      # the table at a 256-byte row pitch (v_perm result = address)
-    ({"FZB_DFA_STRIDE256": "1", "FZB_DFA_UNI32": "1"}, [("short", "deadbe", dict())]),
-    ({"FZB_WINDOW_WHOLE_TILES": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=3))]),  # the PRE window kernel as one 1024-thread workgroup per tile
-    ({"FZB_DFA_WGS": "8"}, [("short", "deadbe", dict()), ("uni", "éa", dict())]),
-    ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),  # parked rows in the global slab
-    ({"FZB_PARK_LDS_KB": "0", "FZB_SMALL_LIST": "0"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_NO_HANDOFF": "1"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),
-    ({"FZB_HANDOFF": "1", "FZB_HANDOFF_MIN_TILES": "8"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict())]),  # the handoff switched on (off by default since round 5), from 8 tiles
-    ({"FZB_WINDOW_NO_PRE": "1"}, [("ragged", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=2)), ("uni", "éa", dict(max_typos=1))]),  # the window kernel's threads compute their own masks (round 4's one-pass form)
-    ({"FZB_HANDOFF_MIN_TILES": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "DeadBeef", dict())]),  # the handoff on a small list (default: big lists only)
-    ({"FZB_HANDOFF_MIN_TILES": "0", "FZB_VIEW_PLAIN_LOADS": "1"}, [("ragged", "deadbeef", dict())]),
-    ({"FZB_VIEW_READ_LEN": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict())]),  # the view filter reads the lengths it does not need (round 4's form)
-    ({"FZB_NO_CDFA": "1"}, [("ragged", "deadbeef", dict())]),                         # the burst filter over the byte automaton
-    ({"FZB_NO_CDFA": "1", "FZB_RAGGED_BURST": "0"}, [("ragged", "deadbeef", dict())]),  # ... and its rolling form
-    ({"FZB_DEBUG_SYNC": "1"}, [("short", "deadbe", dict())]),
-    ({"FZB_COMPACT_GRID_MUL": "2", "FZB_CLASSIFY_PER": "4", "FZB_DP_WGS_PER_CU": "2", "FZB_VIEW_WGS": "3"}, [("short", "deadbe", dict()), ("ragged", "deadbeef", dict())]),
-    ({"FZB_CLASSIFY_PER": "1", "FZB_CDFA_WGS": "3", "FZB_RAGGED_WGS": "4"}, [("ragged", "deadbeef", dict())]),
+    ({}, [("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict(max_typos=1))]),  # as shipped: the 16-vector view kernel, wide unicode windows
+    ({"FZB_NO_LCS_DFA": "1"}, [("short", "deadbe", dict(max_typos=1)), ("ragged", "deadbeef", dict(max_typos=2))]),           # the bit-vector LCS filter (needles beyond 226 automaton states)
+    ({"FZB_TYPO_EXACT_WINDOW": "1"}, [("short", "deadbe", dict(max_typos=2)), ("ragged", "deadbeef", dict(max_typos=1))]),  # every typo survivor through the lane-exact window kernel
+    ({"FZB_NO_DP_CFU": "1"}, [("uni", "éa", dict()), ("uniwide", "éa", dict(max_typos=None))]),                              # the unicode scorers' first form
+    ({"FZB_NO_DP_CLASSES": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict())]),                            # k2b_dp + the queued multi-chunk scorer (dp_cfm.h form)
+    ({"FZB_NO_DP_CFM": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),                    # classes + the queued multi-chunk scorer (dp_body.h) on the second stream
+    ({"FZB_NO_DP_CLASSES": "1", "FZB_NO_DP_CFM": "1"}, [("ragged", "deadbeef", dict())]),                                    # both first forms, one stream
+    ({"FZB_UNICODE_MULTI": "1"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict()), ("uniwide", "éa", dict(max_typos=1))]),   # wide unicode windows: thread per haystack (hands its stragglers on)
+    ({"FZB_UNICODE_MULTI": "0"}, [("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict())]),                      # ... wave per haystack
+    ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),                 # parked rows in the global slab
+    ({"FZB_PARK_LDS_KB": "0", "FZB_NO_DP_CFM": "1"}, [("ragged", "deadbeef", dict())]),
+    ({"FZB_NO_CDFA": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),                       # the burst filter over the byte automaton
+    ({"FZB_DEBUG_SYNC": "1"}, [("short", "deadbe", dict()), ("ragged", "deadbeef", dict()), ("uniwide", "éa", dict(max_typos=None))]),
 ]
 
 

@@ -12,20 +12,6 @@ pytestmark = pytest.mark.gpu
 LANES = {64: (64, 64, 32), 16: (16, 16, 8)}
 
 
-@pytest.fixture(autouse=True, params=["thread_per_window", "wave_per_haystack_only"])
-def long_scorer(request):
-    """Who scores a long needle's ASCII windows of up to 1024 bytes: one thread per window (k2d_dp_long, round 5: needles whose parked rows
-    leave room for at least 128 workgroups' worth of threads - up to 256 rows at 32 lanes) or the wave-per-haystack kernel alone
-    (FZB_LONG_GENERIC_ONLY=1: rounds 3-4; still what unicode, matched indices and needles of thousands of rows take)."""
-    import os
-    if request.param == "wave_per_haystack_only":
-        os.environ["FZB_LONG_GENERIC_ONLY"] = "1"
-    F.lib().fzb_debug_reload_knobs()
-    yield request.param
-    os.environ.pop("FZB_LONG_GENERIC_ONLY", None)
-    F.lib().fzb_debug_reload_knobs()
-
-
 def rand_text(rng, n, alpha=b"abcdef_/ABC-. 01"):
     return bytes(alpha[int(x)] for x in rng.integers(0, len(alpha), n))
 

@@ -15,21 +15,6 @@ from test_gpu_parity import assert_same, both
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["handoff", "default"])
-def handoff_mode(request):
-    """The filter -> scorer handoff (the view filter stages the accepted haystacks' vectors, the classifier and the scorers read them
-    there) is on by default only for lists of 4096 tiles and more; these lists are small, so every test runs once with the handoff forced
-    (FZB_HANDOFF_MIN_TILES=0: staging through LDS, its overflow into direct stores, the tiles whose stage block runs out and fall back
-    to the corpus) and once as shipped."""
-    import os
-    if request.param == "handoff":
-        os.environ["FZB_HANDOFF_MIN_TILES"] = "0"
-    F.lib().fzb_debug_reload_knobs()
-    yield request.param
-    os.environ.pop("FZB_HANDOFF_MIN_TILES", None)
-    F.lib().fzb_debug_reload_knobs()
-
-
 def _list(rng, n, max_len, needle, alphabet, plant=0.3):
     out = []
     for i in range(n):

@@ -107,11 +107,6 @@ def test_upload_builds_the_device_layout_for_every_length_mix():
             want = O.Matcher(needle, **cfg).match_list(hs)
             fc = F.Config(max_typos=cfg["max_typos"], unicode=F.UnicodeMatching[cfg.get("unicode", "Smart")], pf_lanes=64)
             assert F.Matcher(needle, fc).match_list(cp).tolist() == want.tolist(), (n, needle)
-    for mode in ("register", "staged"):  # the two alternative host-to-device paths give the same corpus
-        code = ("import os,sys,numpy as np; sys.path[:0]=[%r,%r]; import frizbee_amd as F, oracle_lib as O\n"
-                "hs=[('x'*k+'deadbe'+'y'*(k%%7)).encode() for k in range(0,400)]*40\n"
-                "assert F.Matcher('deadbe',F.Config(pf_lanes=64)).match_list(hs).tolist()==O.Matcher('deadbe').match_list(hs).tolist()\n") % (ROOT, os.path.join(ROOT, "tests"))
-        subprocess.run([sys.executable, "-c", code], check=True, env={**os.environ, "FZB_UPLOAD_MODE": mode}, timeout=600)
     with pytest.raises(F.FrizbeeError) as e:
         F.Corpus(packed=(np.zeros(64, np.uint8), np.array([8, 4, 12], np.uint64)))
     assert "non-decreasing" in str(e.value)

@@ -14,19 +14,16 @@ from test_gpu_parity import assert_same, both
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["wave_per_haystack", "thread_per_haystack", "thread_per_haystack_keeps_stragglers"])
+@pytest.fixture(autouse=True, params=["wave_per_haystack", "thread_per_haystack"])
 def wide_mode(request):
     """Who scores the windows of 65..1024 bytes: the wave-per-haystack kernel (FZB_UNICODE_MULTI=0; also what the default chooses on the
     device for queues as short as these) or k2u_dp_unicode_multi (FZB_UNICODE_MULTI=1; the default's choice from 32 768 windows on) -
-    which hands windows beyond four chunks on to the wave-per-haystack kernel, or (FZB_UNICODE_FWD=0) scores those too"""
+    which hands windows beyond four chunks on to the wave-per-haystack kernel"""
     import os
     os.environ["FZB_UNICODE_MULTI"] = "0" if request.param == "wave_per_haystack" else "1"
-    if request.param == "thread_per_haystack_keeps_stragglers":
-        os.environ["FZB_UNICODE_FWD"] = "0"
     F.lib().fzb_debug_reload_knobs()
     yield request.param
     os.environ.pop("FZB_UNICODE_MULTI", None)
-    os.environ.pop("FZB_UNICODE_FWD", None)
     F.lib().fzb_debug_reload_knobs()
 
 
