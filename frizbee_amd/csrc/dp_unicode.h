@@ -66,6 +66,53 @@ __device__ __forceinline__ void unicode_window_first_last(const NeedleDev& nd, c
     we = yz_keep ? 32 * bz + 31u - unicode_first_pos(__builtin_bitreverse32(yz_keep)) + lz : 0u;
 }
 
+// The window of a haystack a unicode TYPO query accepted, in its lane-free form (unicode_typos.rs:15-141 `match_start_pos`, :469-509
+// find_end_pos_with_unicode_typos; tests/test_oracle_reference_properties.py::test_unicode_typo_windows_have_the_same_lane_free_form): start = the
+// earliest occurrence of any of the needle scalars [0 ..= k], end = the end of the latest occurrence of any of the scalars [n-1-k ..] (occurrences
+// never overlap, so the latest start has the latest end), the haystack's length if there is none.  One block of 32 bytes: `head` = OR of the
+// position words of the head rows, `tail_end` = max over the tail rows of (last position + scalar length), 0 if none occurs.
+__device__ __forceinline__ void unicode_typo_block(const NeedleDev& nd, const u32 (&w)[9], u32 Lb, u32 k, u32& head, u32& tail_end) {
+    const u32 n = (u32)nd.rows;
+    head = 0;
+    tail_end = 0;
+    for (u32 j = 0; j <= k && j < n; j++) {  // wave-uniform trip counts
+        const u32 c0 = ((const u32*)nd.uc)[j], c1 = ((const u32*)nd.uf)[j], cl = nd.ulen[j];
+        u32 y = unicode_scalar_positions_cl(w, c0, cl);
+        if (c1 != c0) y |= unicode_scalar_positions_cl(w, c1, cl);
+        head |= y & unicode_valid_positions(Lb, cl);
+    }
+    for (u32 j = n > k + 1 ? n - 1 - k : 0; j < n; j++) {
+        const u32 c0 = ((const u32*)nd.uc)[j], c1 = ((const u32*)nd.uf)[j], cl = nd.ulen[j];
+        u32 y = unicode_scalar_positions_cl(w, c0, cl);
+        if (c1 != c0) y |= unicode_scalar_positions_cl(w, c1, cl);
+        y &= unicode_valid_positions(Lb, cl);
+        if (y) tail_end = max(tail_end, 31u - unicode_first_pos(__builtin_bitreverse32(y)) + cl);
+    }
+}
+__device__ __forceinline__ void unicode_window_typos(const NeedleDev& nd, const u8* __restrict__ hay, u32 L, u32 k, u32& ws, u32& we) {
+    u32 head_keep = 0, bh = 0, end = 0;
+    const uint4* vp = (const uint4*)hay;  // every haystack starts on a 16-byte boundary; >= 80 readable bytes follow the corpus
+    const u32 nblk = (L + 31) >> 5;
+    for (u32 b0 = 0; b0 < nblk; b0 += 4) {
+        uint4 qs[9];  // four blocks + the vector behind them (its first dword completes the last block's shifted views)
+#pragma unroll
+        for (int t = 0; t < 9; t++) qs[t] = 32 * b0 + 16 * t < L + 4 ? vp[2 * b0 + t] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const u32 b = b0 + t;
+            if (b >= nblk) break;
+            const u32 w[9] = {qs[2 * t].x, qs[2 * t].y, qs[2 * t].z, qs[2 * t].w, qs[2 * t + 1].x, qs[2 * t + 1].y, qs[2 * t + 1].z, qs[2 * t + 1].w, qs[2 * t + 2].x};
+            u32 head, tail_end;
+            unicode_typo_block(nd, w, L - 32 * b, k, head, tail_end);
+            if (head_keep == 0 && head) { head_keep = head; bh = b; }
+            if (tail_end) end = 32 * b + tail_end;
+        }
+    }
+    ws = head_keep ? 32 * bh + unicode_first_pos(head_keep) : 0u;
+    we = end ? end : L;
+}
+__device__ __forceinline__ void unicode_window_typos_regs(const NeedleDev& nd, const uint4& q0, const uint4& q1, u32 L, u32 k, u32& ws, u32& we);
+
 template <int SWL, int REAL = SWL / 2>
 __device__ __forceinline__ u32 dp_unicode_single_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const u8* cls) {
     constexpr int NW = SWL / 2;
@@ -1041,5 +1088,13 @@ __device__ __forceinline__ void unicode_window_regs(const NeedleDev& nd, const u
     ws = ya ? unicode_first_pos(ya) : 0u;  // (no occurrence cannot happen for a survivor of the exact filter)
     // last occurrence: reversing the word maps bit 8j + k to 8(3-j) + (7-k), so "first" of the reversed word is 31 - last position
     we = yz ? 31u - unicode_first_pos(__builtin_bitreverse32(yz)) + lz : 0u;
+}
+// ... and a typo query's window (unicode_window_typos) of a haystack held in two vectors
+__device__ __forceinline__ void unicode_window_typos_regs(const NeedleDev& nd, const uint4& q0, const uint4& q1, u32 L, u32 k, u32& ws, u32& we) {
+    const u32 w[9] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, 0u};
+    u32 head, tail_end;
+    unicode_typo_block(nd, w, L, k, head, tail_end);
+    ws = head ? unicode_first_pos(head) : 0u;
+    we = tail_end ? tail_end : L;
 }
 

@@ -20,6 +20,7 @@
 #include <new>
 #include <thread>
 #include <string>
+#include <map>
 #include <unordered_map>
 #include <vector>
 
@@ -307,213 +308,307 @@ static void build_long_needle(fzb_matcher* m, const uint8_t* needle_utf8, size_t
 static void build_filter_tables(fzb_matcher* m) {
     const NeedleDev& nd = m->nd;
     LaunchCfg& lc = m->lc;
-m->table.assign(256, 0);
-for (int r = 0; r < m->rows; r++) {
-    if (m->unicode) {  // a scalar can only match where its LAST byte matches (either case): conservative
-        m->table[nd.uc[r][nd.ulen[r] - 1]] |= (u64)1 << r;
-        m->table[nd.uf[r][nd.ulen[r] - 1]] |= (u64)1 << r;
-    } else {
-        m->table[nd.c[r]] |= (u64)1 << r;
-        m->table[nd.f[r]] |= (u64)1 << r;
+    m->table.assign(256, 0);
+    for (int r = 0; r < m->rows; r++) {
+        if (m->unicode) {  // a scalar can only match where its LAST byte matches (either case): conservative
+            m->table[nd.uc[r][nd.ulen[r] - 1]] |= (u64)1 << r;
+            m->table[nd.uf[r][nd.ulen[r] - 1]] |= (u64)1 << r;
+        } else {
+            m->table[nd.c[r]] |= (u64)1 << r;
+            m->table[nd.f[r]] |= (u64)1 << r;
+        }
     }
-}
-lc.dead_byte = 0;
-for (int b = 255; b >= 0; b--)
-    if (m->table[b] == 0) { lc.dead_byte = (u32)b; break; }
-// ordered-subsequence DFA: state s = rows matched so far; a byte that can match row s advances it
-m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
-for (int st = 0; st <= m->rows; st++)
-    for (int b = 0; b < 256; b++) m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && ((m->table[b] >> st) & 1)) ? st + 1 : st);
-if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) {
-    // Substring accept on the ASCII path = "the text drives the needle's Knuth-Morris-Pratt automaton into its final state":
-    // the same table shape, so the streaming DFA filter kernels run it unchanged.  Position k matches byte b iff b is
-    // needle[k] or its case flip; both case forms of a needle byte take the automaton to the same state (the flip is
-    // an involution on every position's byte set), so the usual single restart state works for the folded alphabet.
-    const int n = m->rows;
-    auto hit = [&](int k, int b) { return b == nd.c[k] || b == nd.f[k]; };
-    for (int b = 0; b < 256; b++) m->dfa[b] = (u8)(hit(0, b) ? 1 : 0);
-    int x = 0;  // restart state: where the automaton is after reading needle[1..k)
-    for (int k = 1; k < n; k++) {
-        for (int b = 0; b < 256; b++) m->dfa[(size_t)k * 256 + b] = (u8)(hit(k, b) ? k + 1 : m->dfa[(size_t)x * 256 + b]);
-        x = m->dfa[(size_t)x * 256 + nd.c[k]];
+    lc.dead_byte = 0;
+    for (int b = 255; b >= 0; b--)
+        if (m->table[b] == 0) { lc.dead_byte = (u32)b; break; }
+    // ordered-subsequence DFA: state s = rows matched so far; a byte that can match row s advances it
+    m->dfa.assign((size_t)(m->rows + 1) * 256, 0);
+    for (int st = 0; st <= m->rows; st++)
+        for (int b = 0; b < 256; b++) m->dfa[(size_t)st * 256 + b] = (u8)((st < m->rows && ((m->table[b] >> st) & 1)) ? st + 1 : st);
+    if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) {
+        // Substring accept on the ASCII path = "the text drives the needle's Knuth-Morris-Pratt automaton into its final state":
+        // the same table shape, so the streaming DFA filter kernels run it unchanged.  Position k matches byte b iff b is
+        // needle[k] or its case flip; both case forms of a needle byte take the automaton to the same state (the flip is
+        // an involution on every position's byte set), so the usual single restart state works for the folded alphabet.
+        const int n = m->rows;
+        auto hit = [&](int k, int b) { return b == nd.c[k] || b == nd.f[k]; };
+        for (int b = 0; b < 256; b++) m->dfa[b] = (u8)(hit(0, b) ? 1 : 0);
+        int x = 0;  // restart state: where the automaton is after reading needle[1..k)
+        for (int k = 1; k < n; k++) {
+            for (int b = 0; b < 256; b++) m->dfa[(size_t)k * 256 + b] = (u8)(hit(k, b) ? k + 1 : m->dfa[(size_t)x * 256 + b]);
+            x = m->dfa[(size_t)x * 256 + nd.c[k]];
+        }
+        for (int b = 0; b < 256; b++) m->dfa[(size_t)n * 256 + b] = (u8)n;  // found: absorbing
     }
-    for (int b = 0; b < 256; b++) m->dfa[(size_t)n * 256 + b] = (u8)n;  // found: absorbing
-}
 }
 
 static void build_unicode_dfa(fzb_matcher* m) {
     const fzb_config* config = &m->config;
     const NeedleDev& nd = m->nd;
     const LaunchCfg& lc = m->lc;
-// Unicode path, 0 typos: the prefilter accepts iff the needle's scalars occur, in order, at increasing byte positions, each as its own
-// bytes or as the bytes of its same-width case flip (src/prefilter/algo/unicode.rs:118-219; the same at 16 / 32 / 64 lanes - checked
-// against the oracle by tests/test_host_abi.py::test_unicode_dfa_is_the_unicode_prefilter).  That is a byte-level DFA: state = (scalars
-// matched, bytes of the current scalar matched, which of the two variants are still alive); a mismatch inside a scalar falls back to
-// "is this byte the scalar's first byte" (UTF-8 lead bytes never occur inside a scalar, so no longer border exists).  With <= 226
-// states it runs in the streaming DFA filter kernels unchanged and replaces superset filter + lane-exact window pass + second compaction.
-m->uni_dfa_states = 0;
-if (m->unicode && !m->literal_mode && config->max_typos == 0 && m->rows >= 1 && lc.filter_mode == 1) {
-    struct St { int i, k, alive; };
-    std::vector<St> states;
-    auto find = [&](int i, int k, int alive) {
-        for (size_t q = 0; q < states.size(); q++)
-            if (states[q].i == i && states[q].k == k && states[q].alive == alive) return (int)q;
-        states.push_back(St{i, k, alive});
-        return (int)states.size() - 1;
-    };
-    std::vector<std::vector<int>> trans;
-    find(0, 0, 3);
-    bool ok = true;
-    for (size_t q = 0; q < states.size() && ok; q++) {
-        const St cur = states[q];
-        std::vector<int> row(256, (int)q);
-        if (cur.i < m->rows) {
-            const u8* va = nd.uc[cur.i];
-            const u8* vb = nd.uf[cur.i];
-            const int len = nd.ulen[cur.i];
-            auto from_start = [&](int b) {  // state (i, 0) reading b
-                const int alive = (va[0] == b ? 1 : 0) | (vb[0] == b ? 2 : 0);
-                if (!alive) return find(cur.i, 0, 3);
-                return len == 1 ? find(cur.i + 1, 0, 3) : find(cur.i, 1, alive);
-            };
-            for (int b = 0; b < 256; b++) {
-                if (cur.k == 0) { row[b] = from_start(b); continue; }
-                const int alive = ((cur.alive & 1) && va[cur.k] == b ? 1 : 0) | ((cur.alive & 2) && vb[cur.k] == b ? 2 : 0);
-                if (alive) row[b] = cur.k + 1 == len ? find(cur.i + 1, 0, 3) : find(cur.i, cur.k + 1, alive);
-                else row[b] = from_start(b);
-            }
-        }  // i == rows: accepting, absorbing
-        trans.push_back(row);
-        if (states.size() > 226) ok = false;  // 226 x 288 bytes (dfa_lds.h's row stride) + the tile counter fit the 64 KiB of dynamic LDS
-    }
-    if (ok) {
-        // renumber so that the accepting state is the LAST one (the kernels test `state == number of states - 1`)
-        const int ns = (int)states.size();
-        int acc = -1;
-        for (int q = 0; q < ns; q++)
-            if (states[q].i == m->rows) acc = q;
-        std::vector<int> renum(ns);
-        for (int q = 0, nx = 0; q < ns; q++) renum[q] = q == acc ? ns - 1 : nx++;
-        m->uni_dfa.assign((size_t)ns * 256, 0);
-        for (int q = 0; q < ns; q++)
-            for (int b = 0; b < 256; b++) m->uni_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[trans[q][b]];
-        m->uni_dfa_states = ns;  // start state 0 = (0, 0): first created, never the accepting one (rows >= 1)
+    // Unicode path, 0 typos: the prefilter accepts iff the needle's scalars occur, in order, at increasing byte positions, each as its own
+    // bytes or as the bytes of its same-width case flip (src/prefilter/algo/unicode.rs:118-219; the same at 16 / 32 / 64 lanes - checked
+    // against the oracle by tests/test_host_abi.py::test_unicode_dfa_is_the_unicode_prefilter).  That is a byte-level DFA: state = (scalars
+    // matched, bytes of the current scalar matched, which of the two variants are still alive); a mismatch inside a scalar falls back to
+    // "is this byte the scalar's first byte" (UTF-8 lead bytes never occur inside a scalar, so no longer border exists).  With <= 226
+    // states it runs in the streaming DFA filter kernels unchanged and replaces superset filter + lane-exact window pass + second compaction.
+    m->uni_dfa_states = 0;
+    if (m->unicode && !m->literal_mode && config->max_typos == 0 && m->rows >= 1 && lc.filter_mode == 1) {
+        struct St { int i, k, alive; };
+        std::vector<St> states;
+        auto find = [&](int i, int k, int alive) {
+            for (size_t q = 0; q < states.size(); q++)
+                if (states[q].i == i && states[q].k == k && states[q].alive == alive) return (int)q;
+            states.push_back(St{i, k, alive});
+            return (int)states.size() - 1;
+        };
+        std::vector<std::vector<int>> trans;
+        find(0, 0, 3);
+        bool ok = true;
+        for (size_t q = 0; q < states.size() && ok; q++) {
+            const St cur = states[q];
+            std::vector<int> row(256, (int)q);
+            if (cur.i < m->rows) {
+                const u8* va = nd.uc[cur.i];
+                const u8* vb = nd.uf[cur.i];
+                const int len = nd.ulen[cur.i];
+                auto from_start = [&](int b) {  // state (i, 0) reading b
+                    const int alive = (va[0] == b ? 1 : 0) | (vb[0] == b ? 2 : 0);
+                    if (!alive) return find(cur.i, 0, 3);
+                    return len == 1 ? find(cur.i + 1, 0, 3) : find(cur.i, 1, alive);
+                };
+                for (int b = 0; b < 256; b++) {
+                    if (cur.k == 0) { row[b] = from_start(b); continue; }
+                    const int alive = ((cur.alive & 1) && va[cur.k] == b ? 1 : 0) | ((cur.alive & 2) && vb[cur.k] == b ? 2 : 0);
+                    if (alive) row[b] = cur.k + 1 == len ? find(cur.i + 1, 0, 3) : find(cur.i, cur.k + 1, alive);
+                    else row[b] = from_start(b);
+                }
+            }  // i == rows: accepting, absorbing
+            trans.push_back(row);
+            if (states.size() > 226) ok = false;  // 226 x 288 bytes (dfa_lds.h's row stride) + the tile counter fit the 64 KiB of dynamic LDS
+        }
+        if (ok) {
+            // renumber so that the accepting state is the LAST one (the kernels test `state == number of states - 1`)
+            const int ns = (int)states.size();
+            int acc = -1;
+            for (int q = 0; q < ns; q++)
+                if (states[q].i == m->rows) acc = q;
+            std::vector<int> renum(ns);
+            for (int q = 0, nx = 0; q < ns; q++) renum[q] = q == acc ? ns - 1 : nx++;
+            m->uni_dfa.assign((size_t)ns * 256, 0);
+            for (int q = 0; q < ns; q++)
+                for (int b = 0; b < 256; b++) m->uni_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[trans[q][b]];
+            m->uni_dfa_states = ns;  // start state 0 = (0, 0): first created, never the accepting one (rows >= 1)
+        }
     }
 }
+
+// Unicode typo configurations: the same criterion over SCALARS.  The reference's unicode typo algorithms (unicode_typos.rs:15-466) are the
+// ASCII ones over occurrence masks of whole scalars - row i occurs at byte position p iff the bytes at p equal the scalar's or its case flip's
+// (unicode.rs:74-117), occurrences never overlap (UTF-8: lead byte, then continuation bytes) - so what they decide on a haystack that fits one
+// prefilter chunk is LCS(needle scalars, the haystack's occurrences) + k >= n, and beyond one chunk they deviate from it only when there is
+// nothing to spare (tests/test_oracle_reference_properties.py::test_single_chunk_unicode_typo_prefilter_is_the_scalar_lcs_criterion,
+// ::test_the_unicode_typo_prefilter_only_ever_deviates_on_marginal_inputs).  As a byte-level automaton: state = (reachable bit-vector V, node of
+// the trie over the needle's distinct scalar byte strings = the bytes of the scalar being read); a byte that completes a string applies the LCS
+// step with M = the rows spelt by it; a byte that does not continue the current string restarts from the root WITH that byte (a lead byte never
+// occurs inside a scalar).  States are numbered by ascending LCS of V (an unfinished scalar counts for nothing), start state first.
+// (Rounds 2-5 ran the byte-level LCS over the scalars' LAST bytes here - a looser superset that needed the lane-exact window kernel for every
+// survivor; with the exact criterion single-chunk lists are decided in the stream: pipe_unicode_typo_fast_path.)
+static bool build_scalar_lcs_dfa(fzb_matcher* m) {
+    const NeedleDev& nd = m->nd;
+    const int rows = m->rows, k = m->config.max_typos;
+    const u64 mask = rows >= 64 ? ~(u64)0 : (((u64)1 << rows) - 1);
+    // trie over the distinct byte strings uc[i] / uf[i]: node 0 = root; term[node] = rows spelt by the complete string ending there (0: internal)
+    struct Node { int child[256]; u64 term; };
+    std::vector<Node> trie(1);
+    for (int b = 0; b < 256; b++) trie[0].child[b] = -1;
+    trie[0].term = 0;
+    auto insert = [&](const u8* str, int len, int row) {
+        int cur = 0;
+        for (int j = 0; j < len; j++) {
+            if (trie[cur].child[str[j]] < 0) {
+                Node nn;
+                for (int b = 0; b < 256; b++) nn.child[b] = -1;
+                nn.term = 0;
+                trie.push_back(nn);
+                trie[cur].child[str[j]] = (int)trie.size() - 1;
+            }
+            cur = trie[cur].child[str[j]];
+        }
+        trie[cur].term |= (u64)1 << row;
+    };
+    for (int r = 0; r < rows; r++) {
+        if (nd.ulen[r] < 1 || nd.ulen[r] > 4) return false;
+        insert(nd.uc[r], nd.ulen[r], r);
+        insert(nd.uf[r], nd.ulen[r], r);
+    }
+    for (const Node& nn : trie)  // (UTF-8 is prefix-free: a complete scalar is never the prefix of another; anything else is not a needle this automaton models)
+        if (nn.term)
+            for (int b = 0; b < 256; b++)
+                if (nn.child[b] >= 0) return false;
+    struct St { u64 v; int node; };
+    std::vector<St> states{St{mask, 0}};
+    auto key = [](u64 v, int node) { return std::make_pair(v, node); };
+    std::map<std::pair<u64, int>, int> id{{key(mask, 0), 0}};
+    auto find = [&](u64 v, int node) {
+        auto it = id.find(key(v, node));
+        if (it != id.end()) return it->second;
+        states.push_back(St{v, node});
+        id.emplace(key(v, node), (int)states.size() - 1);
+        return (int)states.size() - 1;
+    };
+    auto lcs_step = [&](u64 v, u64 mrows) { const u64 u = v & mrows; return ((v + u) | (v & ~mrows)) & mask; };
+    auto from_root = [&](u64 v, int b) {  // state (v, root) reading byte b
+        const int c = trie[0].child[b];
+        if (c < 0) return find(v, 0);
+        return trie[c].term ? find(lcs_step(v, trie[c].term), 0) : find(v, c);
+    };
+    std::vector<std::vector<int>> next;
+    for (size_t q = 0; q < states.size(); q++) {
+        const St cur = states[q];
+        std::vector<int> row(256);
+        for (int b = 0; b < 256; b++) {
+            if (cur.node == 0) { row[b] = from_root(cur.v, b); continue; }
+            const int c = trie[cur.node].child[b];
+            if (c < 0) row[b] = from_root(cur.v, b);
+            else row[b] = trie[c].term ? find(lcs_step(cur.v, trie[c].term), 0) : find(cur.v, c);
+        }
+        next.push_back(row);
+        if (states.size() > 226) return false;  // 226 x 288 bytes (dfa_lds.h's row stride) + the tile counter fit the 64 KiB of dynamic LDS
+    }
+    const int ns = (int)states.size(), need = rows - k;
+    std::vector<int> lcs(ns), order(ns), renum(ns);
+    for (int q = 0; q < ns; q++) lcs[q] = __builtin_popcountll(~states[q].v & mask), order[q] = q;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lcs[a] < lcs[b]; });  // the start state (LCS 0, first created) stays first
+    int acc = ns;
+    for (int pos = 0; pos < ns; pos++) {
+        renum[order[pos]] = pos;
+        if (lcs[order[pos]] >= need && acc == ns) acc = pos;
+    }
+    m->lcs_dfa.assign((size_t)ns * 256, 0);
+    for (int q = 0; q < ns; q++)
+        for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[q][b]];
+    m->lcs_states = ns;
+    m->lcs_acc_lo = acc;
+    m->lcs_scalar = true;
+    return true;
 }
 
 static void build_lcs_dfa(fzb_matcher* m) {
     const LaunchCfg& lc = m->lc;
     const int k = m->config.max_typos;
-// Typo configurations: the streaming filter's LCS criterion `LCS(needle, haystack) >= rows - k` (Hyyro's bit-vector recurrence
-// V' = (V + (V & M)) | (V & ~M), M = the rows byte b can match) as a table-driven automaton over its REACHABLE bit-vectors - 40-odd
-// states for a 6-row needle - so that the filter is the same v_perm + ds_read_u8 per byte as the 0-typo one (k1_dfa: 55 us on the
-// 10 M x 32 B list) instead of a table lookup + four vector operations (k1_filter: 71 us).  States are numbered by ascending LCS, so
-// "accepts" is one compare; the start state (LCS 0, only reachable as itself) is state 0.  More than 226 states (long needles with
-// many distinct letters): the bit-vector kernel stays.  FZB_NO_LCS_DFA=1 keeps it for comparison.
-m->lcs_states = 0;
-if (lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !fzb_knobs().no_lcs_dfa) {
-    const u64 mask = m->rows >= 64 ? ~(u64)0 : (((u64)1 << m->rows) - 1);
-    std::vector<u64> masks;  // distinct M over the 256 byte values
-    std::vector<int> mask_of(256);
-    for (int b = 0; b < 256; b++) {
-        const u64 mb = m->table[b] & mask;
-        size_t q = 0;
-        while (q < masks.size() && masks[q] != mb) q++;
-        if (q == masks.size()) masks.push_back(mb);
-        mask_of[b] = (int)q;
-    }
-    std::vector<u64> states{mask};  // V0: all ones in the low `rows` bits
-    std::unordered_map<u64, int> id{{mask, 0}};
-    std::vector<std::vector<int>> next;
-    bool ok = true;
-    for (size_t q = 0; q < states.size() && ok; q++) {
-        const u64 v = states[q];
-        std::vector<int> row(masks.size());
-        for (size_t t = 0; t < masks.size(); t++) {
-            const u64 u = v & masks[t];
-            const u64 nv = ((v + u) | (v & ~masks[t])) & mask;
-            auto it = id.find(nv);
-            if (it == id.end()) {
-                it = id.emplace(nv, (int)states.size()).first;
-                states.push_back(nv);
-                if (states.size() > 226) ok = false;
+    m->lcs_states = 0;
+    m->lcs_scalar = false;
+    if (m->unicode && !m->literal_mode && lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !fzb_knobs().no_lcs_dfa && build_scalar_lcs_dfa(m)) return;
+    // Typo configurations: the streaming filter's LCS criterion `LCS(needle, haystack) >= rows - k` (Hyyro's bit-vector recurrence
+    // V' = (V + (V & M)) | (V & ~M), M = the rows byte b can match) as a table-driven automaton over its REACHABLE bit-vectors - 40-odd
+    // states for a 6-row needle - so that the filter is the same v_perm + ds_read_u8 per byte as the 0-typo one (k1_dfa: 55 us on the
+    // 10 M x 32 B list) instead of a table lookup + four vector operations (k1_filter: 71 us).  States are numbered by ascending LCS, so
+    // "accepts" is one compare; the start state (LCS 0, only reachable as itself) is state 0.  More than 226 states (long needles with
+    // many distinct letters): the bit-vector kernel stays.  FZB_NO_LCS_DFA=1 keeps it for comparison.
+    m->lcs_states = 0;
+    if (lc.filter_mode == 2 && m->rows >= 1 && m->rows <= 63 && !fzb_knobs().no_lcs_dfa) {
+        const u64 mask = m->rows >= 64 ? ~(u64)0 : (((u64)1 << m->rows) - 1);
+        std::vector<u64> masks;  // distinct M over the 256 byte values
+        std::vector<int> mask_of(256);
+        for (int b = 0; b < 256; b++) {
+            const u64 mb = m->table[b] & mask;
+            size_t q = 0;
+            while (q < masks.size() && masks[q] != mb) q++;
+            if (q == masks.size()) masks.push_back(mb);
+            mask_of[b] = (int)q;
+        }
+        std::vector<u64> states{mask};  // V0: all ones in the low `rows` bits
+        std::unordered_map<u64, int> id{{mask, 0}};
+        std::vector<std::vector<int>> next;
+        bool ok = true;
+        for (size_t q = 0; q < states.size() && ok; q++) {
+            const u64 v = states[q];
+            std::vector<int> row(masks.size());
+            for (size_t t = 0; t < masks.size(); t++) {
+                const u64 u = v & masks[t];
+                const u64 nv = ((v + u) | (v & ~masks[t])) & mask;
+                auto it = id.find(nv);
+                if (it == id.end()) {
+                    it = id.emplace(nv, (int)states.size()).first;
+                    states.push_back(nv);
+                    if (states.size() > 226) ok = false;
+                }
+                row[t] = it->second;
             }
-            row[t] = it->second;
+            next.push_back(row);
         }
-        next.push_back(row);
-    }
-    if (ok) {
-        const int ns = (int)states.size();
-        const int need = m->rows - k;
-        std::vector<int> lcs(ns), order(ns), renum(ns);
-        for (int q = 0; q < ns; q++) lcs[q] = __builtin_popcountll(~states[q] & mask), order[q] = q;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lcs[a] < lcs[b]; });  // V0 (LCS 0, first created) stays first
-        int acc = ns;
-        for (int pos = 0; pos < ns; pos++) {
-            renum[order[pos]] = pos;
-            if (lcs[order[pos]] >= need && acc == ns) acc = pos;
+        if (ok) {
+            const int ns = (int)states.size();
+            const int need = m->rows - k;
+            std::vector<int> lcs(ns), order(ns), renum(ns);
+            for (int q = 0; q < ns; q++) lcs[q] = __builtin_popcountll(~states[q] & mask), order[q] = q;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return lcs[a] < lcs[b]; });  // V0 (LCS 0, first created) stays first
+            int acc = ns;
+            for (int pos = 0; pos < ns; pos++) {
+                renum[order[pos]] = pos;
+                if (lcs[order[pos]] >= need && acc == ns) acc = pos;
+            }
+            m->lcs_dfa.assign((size_t)ns * 256, 0);
+            for (int q = 0; q < ns; q++)
+                for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[q][mask_of[b]]];
+            m->lcs_states = ns;
+            m->lcs_acc_lo = acc;
         }
-        m->lcs_dfa.assign((size_t)ns * 256, 0);
-        for (int q = 0; q < ns; q++)
-            for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[q][mask_of[b]]];
-        m->lcs_states = ns;
-        m->lcs_acc_lo = acc;
     }
-}
 }
 
 static void build_cdfa(fzb_matcher* m) {
     const LaunchCfg& lc = m->lc;
-// The class-composite form of the automaton the streaming filter runs (ragged lists: kernels_filter.hip, k1_cdfa_ragged): bytes with
-// identical columns are one class (K of them), G transitions are composed into one table indexed by
-// state * K^G + c0 + K c1 + ... (c0 = the class of the FIRST byte), G = 4 if states * K^4 <= 16 KB, else 2, else none.
-m->cdfa.clear();
-m->cdfa_src = m->cdfa_K = m->cdfa_G = 0;
-{
-    const std::vector<u8>* fa = nullptr;
-    int fstates = 0, src = 0;
-    if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
-    else if (m->literal_mode) {}
-    else if (m->uni_dfa_states) { fa = &m->uni_dfa; fstates = m->uni_dfa_states; src = 2; }
-    else if (lc.filter_mode == 2 && m->lcs_states) { fa = &m->lcs_dfa; fstates = m->lcs_states; src = 3; }
-    else if (lc.filter_mode == 1) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
-    if (fa && fstates >= 1 && fstates <= 255) {
-        std::vector<int> cls(256, -1);
-        std::vector<int> rep;  // a representative byte per class
-        for (int b = 0; b < 256; b++) {
-            for (size_t q = 0; q < rep.size() && cls[b] < 0; q++) {
-                bool same = true;
-                for (int stt = 0; stt < fstates && same; stt++) same = (*fa)[(size_t)stt * 256 + b] == (*fa)[(size_t)stt * 256 + rep[q]];
-                if (same) cls[b] = (int)q;
-            }
-            if (cls[b] < 0) { cls[b] = (int)rep.size(); rep.push_back(b); }
-        }
-        const size_t K = rep.size();
-        int G = 0;
-        if ((size_t)fstates * K * K * K * K <= 16384) G = 4;
-        else if ((size_t)fstates * K * K <= 16384) G = 2;
-        if (G) {
-            size_t KG = 1;
-            for (int i = 0; i < G; i++) KG *= K;
-            m->cdfa.assign(((256 + (size_t)fstates * KG) + 15) & ~(size_t)15, 0);
-            for (int b = 0; b < 256; b++) m->cdfa[b] = (u8)cls[b];
-            for (int stt = 0; stt < fstates; stt++)
-                for (size_t off = 0; off < KG; off++) {
-                    int cur = stt;
-                    size_t rest = off;
-                    for (int i = 0; i < G; i++) {  // c0 (the least significant digit) is consumed first
-                        cur = (*fa)[(size_t)cur * 256 + rep[rest % K]];
-                        rest /= K;
-                    }
-                    m->cdfa[256 + (size_t)stt * KG + off] = (u8)cur;
+    // The class-composite form of the automaton the streaming filter runs (ragged lists: kernels_filter.hip, k1_cdfa_ragged): bytes with
+    // identical columns are one class (K of them), G transitions are composed into one table indexed by
+    // state * K^G + c0 + K c1 + ... (c0 = the class of the FIRST byte), G = 4 if states * K^4 <= 16 KB, else 2, else none.
+    m->cdfa.clear();
+    m->cdfa_src = m->cdfa_K = m->cdfa_G = 0;
+    {
+        const std::vector<u8>* fa = nullptr;
+        int fstates = 0, src = 0;
+        if (m->literal_mode == FZB_MATCH_SUBSTRING && !m->unicode) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
+        else if (m->literal_mode) {}
+        else if (m->uni_dfa_states) { fa = &m->uni_dfa; fstates = m->uni_dfa_states; src = 2; }
+        else if (lc.filter_mode == 2 && m->lcs_states) { fa = &m->lcs_dfa; fstates = m->lcs_states; src = 3; }
+        else if (lc.filter_mode == 1) { fa = &m->dfa; fstates = m->rows + 1; src = 1; }
+        if (fa && fstates >= 1 && fstates <= 255) {
+            std::vector<int> cls(256, -1);
+            std::vector<int> rep;  // a representative byte per class
+            for (int b = 0; b < 256; b++) {
+                for (size_t q = 0; q < rep.size() && cls[b] < 0; q++) {
+                    bool same = true;
+                    for (int stt = 0; stt < fstates && same; stt++) same = (*fa)[(size_t)stt * 256 + b] == (*fa)[(size_t)stt * 256 + rep[q]];
+                    if (same) cls[b] = (int)q;
                 }
-            m->cdfa_src = src;
-            m->cdfa_K = (int)K;
-            m->cdfa_G = G;
+                if (cls[b] < 0) { cls[b] = (int)rep.size(); rep.push_back(b); }
+            }
+            const size_t K = rep.size();
+            int G = 0;
+            if ((size_t)fstates * K * K * K * K <= 16384) G = 4;
+            else if ((size_t)fstates * K * K <= 16384) G = 2;
+            if (G) {
+                size_t KG = 1;
+                for (int i = 0; i < G; i++) KG *= K;
+                m->cdfa.assign(((256 + (size_t)fstates * KG) + 15) & ~(size_t)15, 0);
+                for (int b = 0; b < 256; b++) m->cdfa[b] = (u8)cls[b];
+                for (int stt = 0; stt < fstates; stt++)
+                    for (size_t off = 0; off < KG; off++) {
+                        int cur = stt;
+                        size_t rest = off;
+                        for (int i = 0; i < G; i++) {  // c0 (the least significant digit) is consumed first
+                            cur = (*fa)[(size_t)cur * 256 + rep[rest % K]];
+                            rest /= K;
+                        }
+                        m->cdfa[256 + (size_t)stt * KG + off] = (u8)cur;
+                    }
+                m->cdfa_src = src;
+                m->cdfa_K = (int)K;
+                m->cdfa_G = G;
+            }
         }
     }
-}
 }
 
 // which forms of the scorers this needle and scoring allow
@@ -1260,7 +1355,11 @@ static int pipe_filter_stage(Pipe& p) {
     p.n_items_ptr = &cnt_c[0];
     p.wmode = lc.window_mode;
     const int need = nd.rows - (nd.max_typos > 0 ? nd.max_typos : 0);
-    bool uni_exact = false;  // the unicode DFA filter decided exactly: no lane-exact window pass, the scorer computes the window
+    int exact_wmode = 0;  // != 0: a unicode automaton decided exactly in the stream - no lane-exact window pass, the scorer computes the window (mode 1: 0 typos, 3: typos)
+    // unicode typo query over a list whose haystacks all fit ONE prefilter chunk: the scalar-level LCS automaton IS the reference's decision
+    // (build_scalar_lcs_dfa); longer lists keep it as the (tight) superset in front of the lane-exact window kernel
+    const bool uni_typo_exact = nd.unicode && lc.filter_mode == 2 && m->lcs_scalar && m->lcs_states && lc.bias_ok && !p.trace && !fzb_knobs().typo_exact_window && p.cd.max_len != 0 &&
+                                p.cd.max_len <= (u32)lc.pf_lanes;
     if (p.items_in) {
         if (lc.filter_mode == 0) {
             HIPCHK(hipMemcpyAsync(&cnt_c[0], p.n_items_in, 4, hipMemcpyDeviceToDevice, p.st));
@@ -1284,7 +1383,7 @@ static int pipe_filter_stage(Pipe& p) {
         fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st, &cnt_c[1]);  // (kept by the exact prefilter = the filter's survivors)
         FZB_STAGE("compact1");
         p.items = w.surv_idx;
-        uni_exact = true;
+        exact_wmode = 1;
     } else {
         FZB_PEV(2);
         if (lc.filter_mode == 2 && m->lcs_states)  // typo configurations: the LCS automaton in the streaming DFA kernels (short and ragged lists)
@@ -1295,12 +1394,13 @@ static int pipe_filter_stage(Pipe& p) {
                               nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         FZB_PEV(3);
         FZB_STAGE("filter");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st);
+        fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st, uni_typo_exact ? &cnt_c[1] : nullptr);
         FZB_STAGE("compact1");
         p.items = w.surv_idx;
+        if (uni_typo_exact) exact_wmode = 3;
     }
-    if (uni_exact) {
-        p.wmode = 1;
+    if (exact_wmode) {
+        p.wmode = exact_wmode;
     } else if (!lc.filter_exact) {
         // the stream stage was a superset: re-decide every survivor with the reference's chunked algorithm at its exact lane width
         fzb_launch_window(p.cd, p.first, p.items, &cnt_c[0], nd, lc.pf_lanes, w.win, w.bitmap2, w.tile_counts2, cnt_c, p.cus * 4, p.st, nullptr, p.items_in ? 0u : p.cnt);

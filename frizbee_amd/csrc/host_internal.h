@@ -51,6 +51,7 @@ struct fzb_matcher {
     // than 226): state 0 = nothing matched, states >= lcs_acc_lo accept (LCS >= rows - max_typos)
     std::vector<u8> lcs_dfa;
     int lcs_states = 0, lcs_acc_lo = 0;
+    bool lcs_scalar = false;  // unicode typo configurations: `lcs_dfa` is the SCALAR-level automaton (exact criterion), not the byte-level one over the table's masks
     // The matcher's streaming automaton (cdfa_src: 1 = `dfa` (subsequence / KMP), 2 = `uni_dfa`, 3 = `lcs_dfa`) with G transitions composed
     // over its K byte classes: [256 bytes: byte -> class][states x K^G: next state], for the ragged filter (kernels_filter.hip,
     // k1_cdfa_ragged).  Empty when states x K^G does not fit 16 KB even for G = 2.

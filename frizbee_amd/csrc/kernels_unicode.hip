@@ -67,6 +67,9 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
             else if (wmode == 1) {
                 if (REGS) unicode_window_regs(nd, q0_c, q1_c, L, ws, we);
                 else unicode_window_first_last(nd, hay, L, ws, we);
+            } else if (wmode == 3) {  // a typo query decided by the scalar-LCS automaton: the lane-free typo window
+                if (REGS) unicode_window_typos_regs(nd, q0_c, q1_c, L, (u32)nd.max_typos, ws, we);
+                else unicode_window_typos(nd, hay, L, (u32)nd.max_typos, ws, we);
             }
             const u32 sp = ws ? ws - 1 : 0;
             const bool include_exact = sp == 0 && we == L;

@@ -47,8 +47,8 @@ def _same(lists, which, needle, **cfg):
 
 CASES = [  # (environment, [(list, needle, oracle config)])
     ({}, [("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("uniwide", "éa", dict(max_typos=None)), ("uniwide", "éa", dict(max_typos=1))]),  # as shipped: the 16-vector view kernel, wide unicode windows
-    ({"FZB_NO_LCS_DFA": "1"}, [("short", "deadbe", dict(max_typos=1)), ("ragged", "deadbeef", dict(max_typos=2))]),           # the bit-vector LCS filter (needles beyond 226 automaton states)
-    ({"FZB_TYPO_EXACT_WINDOW": "1"}, [("short", "deadbe", dict(max_typos=2)), ("ragged", "deadbeef", dict(max_typos=1))]),  # every typo survivor through the lane-exact window kernel
+    ({"FZB_NO_LCS_DFA": "1"}, [("short", "deadbe", dict(max_typos=1)), ("ragged", "deadbeef", dict(max_typos=2)), ("uni", "éa", dict(max_typos=1))]),           # the bit-vector LCS filter (needles beyond 226 automaton states)
+    ({"FZB_TYPO_EXACT_WINDOW": "1"}, [("short", "deadbe", dict(max_typos=2)), ("ragged", "deadbeef", dict(max_typos=1)), ("uni", "éa", dict(max_typos=1))]),  # every typo survivor through the lane-exact window kernel
     ({"FZB_NO_DP_CFU": "1"}, [("uni", "éa", dict()), ("uniwide", "éa", dict(max_typos=None))]),                              # the unicode scorers' first form
     ({"FZB_NO_DP_CLASSES": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict())]),                            # k2b_dp + the queued multi-chunk scorer (dp_cfm.h form)
     ({"FZB_NO_DP_CFM": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),                    # classes + the queued multi-chunk scorer (dp_body.h) on the second stream

@@ -293,6 +293,45 @@ def test_lcs_automaton_is_the_lcs_criterion():
     assert F.lib().fzb_debug_lcs_dfa_accepts(F.Matcher("abcdefghijklmnopqrstuvwxyz012345", F.Config(max_typos=3)).h, b"x", 1, None) == -1
 
 
+def test_scalar_lcs_automaton_is_the_unicode_typo_prefilter_on_single_chunk_haystacks():
+    # unicode typo configurations (round 6): the streaming filter's automaton over (reachable LCS bit-vector, bytes of the scalar being read) -
+    # fzb_matcher_create, build_scalar_lcs_dfa - against (1) LCS(needle scalars, the haystack's scalar occurrences) + k >= n computed directly and
+    # (2) the oracle's unicode typo prefilter at a lane width the haystack fits in ONE chunk of; valid UTF-8 and arbitrary bytes
+    import ctypes as C
+    import pf_second_transcription as P2
+    from test_oracle_reference_properties import scalar_lcs
+    rng = np.random.default_rng(21)
+    alpha = ["a", "B", "_", "é", "É", "ж", "다", "😀", "ن", "إ", "م", "ا", " "]
+    seen, marginal = [], 0
+    for needle, k, casing in (("إنما", 1, "Smart"), ("إنما", 2, "Smart"), ("إن", 1, "Smart"), ("éa", 1, "Ignore"), ("aÉжb", 2, "Ignore"), ("다😀a다", 1, "Respect"), ("жжжж", 2, "Smart"), ("aébécé", 3, "Smart")):
+        m = F.Matcher(needle, F.Config(max_typos=k, casing=F.CaseMatching[casing]))
+        cs = casing == "Respect" or (casing == "Smart" and any(c.isupper() for c in needle))
+        chars = P2.case_needle_unicode(needle, cs)
+        ns = C.c_int32()
+        pool = [c.encode() for c in alpha] + [a for a, _ in chars] + [b for _, b in chars]
+        for it in range(500):
+            ln = int(rng.integers(0, 65))
+            if it % 4 == 3:  # arbitrary bytes: truncated scalars, stray continuation and lead bytes
+                raw = pool + [bytes([int(rng.integers(0, 256))]) for _ in range(4)] + [b"\x80", b"\xd8", b"\xf0\x9f"]
+                h = b"".join(raw[int(rng.integers(0, len(raw)))] for _ in range(ln))[:ln]
+            else:
+                h = b""
+                while True:
+                    c = pool[int(rng.integers(0, len(pool)))]
+                    if len(h) + len(c) > ln:
+                        break
+                    h += c
+            got = F.lib().fzb_debug_lcs_dfa_accepts(m.h, h, len(h), C.byref(ns))
+            assert ns.value > 0 and got in (0, 1), (needle, k, ns.value)
+            slack = scalar_lcs(chars, h) + k - len(chars)
+            marginal += slack == 0
+            assert got == int(slack >= 0), (needle, k, h, slack)
+            assert got == int(O.prefilter(needle, h, k, cs, True, 64)[0]), (needle, k, h)
+        seen.append(ns.value)
+    assert all(0 < n <= 226 for n in seen) and marginal > 300, (seen, marginal)
+    print("scalar LCS automaton states:", seen)
+
+
 def test_class_composite_automaton_equals_the_byte_automaton():
     # the ragged filter's table (G byte transitions composed over the K byte classes, fzb_matcher_create) must decide exactly like the
     # byte-level automaton it was built from: ordered subsequence (0 typos), the LCS criterion (typos), the unicode prefilter, KMP (substring)

@@ -615,3 +615,95 @@ def test_unicode_typo_windows_have_the_same_lane_free_form():
                 assert (w[1], w[2]) == (min(firsts), max(ends) if ends else len(hay)), (needle, hay, k, cs, lanes, w)
                 checked += 1
     assert checked > 5000
+
+
+# ---- unicode typo queries: the scalar-level LCS criterion (round 6: what the streaming filter decides for them) -------------------------
+def scalar_events(chars, hay):
+    """Needle rows that OCCUR at every byte position of `hay`: row i occurs at p iff hay[p : p + len_i] equals the scalar's bytes or its case
+    flip's (unicode_char_mask, src/prefilter/algo/unicode.rs:74-117: a lane is a byte position, nothing asks whether it is a scalar start).
+    Occurrences never overlap (a needle scalar is valid UTF-8: lead byte, then continuation bytes), so the events are a sequence."""
+    ev = []
+    for p in range(len(hay)):
+        rows = frozenset(i for i, (a, b) in enumerate(chars) if hay[p : p + len(a)] in (a, b))
+        if rows:
+            ev.append(rows)
+    return ev
+
+
+def scalar_lcs(chars, hay):
+    ev = scalar_events(chars, hay)
+    return lcs_len(list(range(len(chars))), ev, lambda i, rows: i in rows)
+
+
+UNI_ALPHA = ["a", "b", "A", "_", " ", "é", "É", "ж", "Ж", "다", "😀", "1", "ن", "إ"]
+
+
+def _uni_text(rng, asz, nbytes, exact_len=False):
+    """valid UTF-8 of at most `nbytes` bytes from the first `asz` scalars of the alphabet"""
+    out, size = [], 0
+    while True:
+        c = UNI_ALPHA[int(rng.integers(0, asz))]
+        if size + len(c.encode()) > nbytes:
+            break
+        out.append(c)
+        size += len(c.encode())
+        if not exact_len and rng.random() < 0.03:
+            break
+    return "".join(out).encode()
+
+
+def test_single_chunk_unicode_typo_prefilter_is_the_scalar_lcs_criterion():
+    # The unicode typo algorithms (unicode_typos.rs:15-466) are the ASCII ones over occurrence masks of whole scalars, so the single-chunk
+    # argument of DESIGN.md "Typo configurations" carries over: a haystack that fits ONE prefilter chunk is accepted iff
+    # LCS(needle scalars, haystack's scalar occurrences) + k >= n.  Valid UTF-8 and arbitrary bytes (the C ABI takes any bytes; the
+    # reference compares bytes position by position).  The product uses this to decide unicode typo queries over single-chunk lists
+    # in the streaming filter (host.hip, build_lcs_dfa / pipe_unicode_typo_fast_path).
+    import pf_second_transcription as P2
+    rng = np.random.default_rng(808)
+    marginal = n_cases = 0
+    for it in range(9000):
+        asz = int(rng.integers(3, len(UNI_ALPHA) + 1))
+        needle = "".join(UNI_ALPHA[int(x)] for x in rng.integers(0, asz, int(rng.integers(2, 9))))
+        if needle.isascii():
+            needle += "é"
+        cs, k = bool(rng.integers(0, 3) == 0), int(rng.integers(1, 4))
+        chars = P2.case_needle_unicode(needle, cs)
+        if k >= len(chars):
+            continue
+        for lanes in (16, 32, 64):
+            ln = int(rng.integers(1, lanes + 1)) if rng.integers(0, 3) else lanes - int(rng.integers(0, 3))
+            if it % 5 == 4:  # arbitrary bytes: needle scalars planted between random bytes, continuation bytes without a lead, truncated scalars
+                pool = [a for a, _ in chars] + [bytes([int(rng.integers(0, 256))]) for _ in range(6)] + [b"\x80", b"\xd0", b"\xf0\x9f"]
+                hay = b"".join(pool[int(rng.integers(0, len(pool)))] for _ in range(ln))[:ln]
+            else:
+                hay = _uni_text(rng, asz, ln, exact_len=bool(rng.integers(0, 2)))
+            slack = scalar_lcs(chars, hay) + k - len(chars)
+            marginal += slack == 0
+            n_cases += 1
+            assert O.prefilter(needle, hay, k, cs, True, lanes)[0] == (slack >= 0), (needle, hay, k, cs, lanes, slack)
+    assert marginal > 2500 and n_cases > 20000
+
+
+def test_the_unicode_typo_prefilter_only_ever_deviates_on_marginal_inputs():
+    # multi-chunk haystacks: with one scalar to spare (LCS + k >= n + 1) every width accepts, below the criterion every width rejects
+    import pf_second_transcription as P2
+    rng = np.random.default_rng(909)
+    n_spare = n_reject = 0
+    for _ in range(5000):
+        asz = int(rng.integers(3, len(UNI_ALPHA) + 1))
+        needle = "".join(UNI_ALPHA[int(x)] for x in rng.integers(0, asz, int(rng.integers(2, 10))))
+        if needle.isascii():
+            needle += "ж"
+        cs, k = bool(rng.integers(0, 3) == 0), int(rng.integers(1, 5))
+        chars = P2.case_needle_unicode(needle, cs)
+        if k >= len(chars):
+            continue
+        hay = _uni_text(rng, asz, int(rng.integers(0, 200)), exact_len=True)
+        slack = scalar_lcs(chars, hay) + k - len(chars)
+        if slack == 0:
+            continue
+        for lanes in (16, 32, 64):
+            assert O.prefilter(needle, hay, k, cs, True, lanes)[0] == (slack > 0), (needle, hay, k, cs, lanes, slack)
+        n_spare += slack > 0
+        n_reject += slack < 0
+    assert n_spare > 1000 and n_reject > 300

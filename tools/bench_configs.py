@@ -106,6 +106,9 @@ if "C5" in which:
     data = np.tile(data, reps); ends = np.arange(1, n5 * reps + 1, dtype=np.uint64) * np.uint64(32)
     cp = F.Corpus(packed=(data, ends))
     run("C5 utf8 len32 typos0 (2M distinct x5)", "إنما", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n5 * reps)
+    if "C5T" in which:
+        run("C5 utf8 len32 typos1 (2M distinct x5)", "إنما", F.Config(max_typos=1, pf_lanes=64, sw_lanes=64), cp, n5 * reps)
+        run("C5 utf8 len32 typos2 (2M distinct x5)", "إنما", F.Config(max_typos=2, pf_lanes=64, sw_lanes=64), cp, n5 * reps)
 if "INDICES" in which:
     # matched byte positions for the top K of a sorted match_list over the resident C2 list
     # (host call -> selection upload -> item pipeline -> traced scorer + on-device traceback -> copies -> host ordering)
