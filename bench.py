@@ -624,7 +624,7 @@ def main():
         step_no[0] += 1
         ex.wait(slot)
         m.match_list_device(corpus, ex.records_ptr(slot), ex.cap, ex.count_ptr(slot), stream=stream, index_offset=index_offset)
-        ex.post(slot)
+        ex.post(slot, stream=stream)
 
     def fence():
         if use_dist:
@@ -649,10 +649,39 @@ def main():
     st = m.last_stage_timings_ms()
     m.set_profiling(False)
     counters = m.last_counters()  # (of a full step: the untimed checks further down query sub-ranges)
+    attribution = None
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctl_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # ---- what the exchange costs, so that a scaling loss at N > 1 is attributable (untimed here; same K steps, same fences) -------------
+        # (1) the loop WITHOUT the exchange: the pipeline still writes into the exchange buffers, nothing is posted
+        ex.wait(0)
+        ex.wait(1)
+        fence()
+        t0 = time.perf_counter()
+        for i_ in range(args.steps):
+            m.match_list_device(corpus, ex.records_ptr(i_ & 1), ex.cap, ex.count_ptr(i_ & 1), stream=stream, index_offset=index_offset)
+        fence()
+        t_noex = time.perf_counter() - t0
+        # (2) the exchange ALONE: K posts of the (already filled) buffers, double-buffered like the loop, no pipeline in between
+        t0 = time.perf_counter()
+        for i_ in range(args.steps):
+            ex.post(i_ & 1)
+        ex.wait(0)
+        ex.wait(1)
+        fence()
+        t_ex = time.perf_counter() - t0
+        t = torch.tensor([t_noex, t_ex], dtype=torch.float64, device=ctl_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_noex, t_ex = float(t[0].item()), float(t[1].item())
+        attribution = {"exchange_bytes_per_rank_per_step": ex.bytes_per_rank(), "exchange_bytes_into_root_per_step": ex.bytes_per_rank() * (world - 1),
+                       "transport": ex.transport + (" (nothing travels with one rank: the root's run is in place)" if world == 1 else ""),
+                       "ms_per_step_without_exchange": t_noex / args.steps * 1e3, "value_without_exchange": n * world / (t_noex / args.steps),
+                       "exchange_alone_ms_per_step": t_ex / args.steps * 1e3,
+                       "what": "same K steps, max over ranks: the loop with nothing posted; the posts alone (double-buffered, buffers already filled).  "
+                               "ms_per_step - ms_per_step_without_exchange = what the asynchronous exchange costs the timed loop; exchange_alone >= ms_per_step_without_exchange "
+                               "means the loop is bound by the transport, not by the kernels"}
     ms_per_step = elapsed / args.steps * 1e3
     gathered = None
     e2e_multi = None
@@ -665,7 +694,8 @@ def main():
         n_matches = int(ex.send[last][:4].cpu().numpy().view(np.uint32)[0])
         if rank == 0:
             merged = merge_shard_runs(runs, F.SortStrategy.ScoreThenIndexAsc)  # host form of the combine (the device form is timed below)
-            gathered = {"matches_all_shards": int(sum(len(r) for r in runs)), "merged_len": int(len(merged)), "exchange_capacity_records": ex.cap}
+            gathered = {"matches_all_shards": int(sum(len(r) for r in runs)), "merged_len": int(len(merged)), "exchange_capacity_records": ex.cap,
+                        "capacity_over_records": ex.cap / max(1, max(len(r) for r in runs)), **(attribution or {})}
         # ---- the end-to-end mode (reported beside `value`, never instead of it): every step ends with the ORDERED list on rank 0's
         # host - what match_list_parallel returns (parallel.rs:66-87).  Each rank runs the pipeline unsorted with global indices, a
         # synchronous gather puts the runs into the root's HBM, and the root orders the whole list ONCE on the device (rank order is

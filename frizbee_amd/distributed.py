@@ -69,14 +69,23 @@ class ShardExchange:
 
     Buffer layout per rank and slot: [u32 records written | u32 matches found | capacity x 8-byte records].  The scoring pipeline writes the
     count and the records straight into it (`count_ptr` / `records_ptr` are what `fzb_match_list_device` takes), `post`
-    launches the gather on the backend's own stream (RCCL send/recv over the point-to-point xGMI links: the root
+    starts the transport on the backend's own stream (RCCL send/recv over the point-to-point xGMI links: the root
     receives its world-1 peers' buffers on separate links in parallel), and the next step's kernels overlap it.
     The capacity is agreed once, up front (`plan`), from a first measured count; a shard that later outgrows it is
     reported by `collect`, never truncated silently."""
 
     HEADER = 8
 
-    def __init__(self, capacity_records, device, group=None, root=0, slots=2, host_staged=None):
+    def __init__(self, capacity_records, device, group=None, root=0, slots=2, host_staged=None, transport=None):
+        # transport "p2p" (default): every other rank sends its buffer to the root, the root posts one receive per peer, batched into ONE RCCL
+        # group call (dist.batch_isend_irecv) - the root's own run never travels: its receive slot IS its send buffer, and with one rank
+        # nothing is posted at all.  "gather": dist.gather of the whole list (what rounds 1-5 ran: the same sends and receives plus a
+        # device-to-device copy of the root's own 4 MB on RCCL's stream and its two cross-stream event waits - 18 us per step with one rank).
+        # FZB_EXCHANGE_TRANSPORT overrides the default.
+        import os
+        self.transport = transport or os.environ.get("FZB_EXCHANGE_TRANSPORT", "p2p")
+        if self.transport not in ("p2p", "gather"):
+            raise ValueError(f"ShardExchange transport {self.transport!r}: 'p2p' or 'gather'")
         self.group, self.root = group, root
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.device = torch.device(device)
@@ -98,6 +107,9 @@ class ShardExchange:
         self.send = [torch.zeros(nbytes, dtype=torch.uint8, device=self.device) for _ in range(self.slots)]
         self.send_x = [torch.zeros(nbytes, dtype=torch.uint8, device=xdev) for _ in range(self.slots)] if self.host_staged else self.send
         self.recv = [[torch.zeros(nbytes, dtype=torch.uint8, device=xdev) for _ in range(self.world)] if self.rank == self.root else None for _ in range(self.slots)]
+        if self.rank == self.root and self.transport == "p2p":
+            for s_ in range(self.slots):
+                self.recv[s_][self.root] = self.send_x[s_]  # the root's own run: in place
         self.work = [None] * self.slots
         self._merge_args = [None] * self.slots
 
@@ -125,23 +137,41 @@ class ShardExchange:
         """Order the caller's stream after the exchange that last used `slot` (no host block with RCCL).  An exchange that has already
         completed - the steady state: it is two steps old - needs no ordering at all, and skipping the stream-level wait keeps a barrier
         packet out of the scoring stream and 10 us of host time out of the step (tools/exp_dist_overhead.py)."""
-        w = self.work[slot]
-        if w is not None:
-            done = False
-            if self._skip_completed_wait:
-                try:
-                    done = bool(w.is_completed())
-                except Exception:  # no completion query: order the streams
-                    done = False
-            if not done:
-                w.wait()  # (raises what the collective raised)
+        works = self.work[slot]
+        if works is not None:
+            for w in works:
+                done = False
+                if self._skip_completed_wait:
+                    try:
+                        done = bool(w.is_completed())
+                    except Exception:  # no completion query: order the streams
+                        done = False
+                if not done:
+                    w.wait()  # (raises what the collective raised)
             self.work[slot] = None
 
-    def post(self, slot):
+    def post(self, slot, stream=None):
+        """Start moving this slot's buffer to the root (asynchronous).  `stream` = the raw HIP stream the pipeline was enqueued on when that is
+        not torch's current stream: the exchange (and the host-staged copy in front of it) is ordered behind it."""
         self.wait(slot)
+        if stream is not None and self.device.type == "cuda":
+            ext = torch.cuda.ExternalStream(int(stream), device=self.device)
+            if ext != torch.cuda.current_stream(self.device):
+                torch.cuda.current_stream(self.device).wait_stream(ext)
         if self.host_staged:
             self.send_x[slot].copy_(self.send[slot])  # device -> host, behind the pipeline on the current stream (synchronises)
-        self.work[slot] = dist.gather(self.send_x[slot], gather_list=self.recv[slot], dst=self.root, group=self.group, async_op=True)
+        if self.transport == "gather":
+            self.work[slot] = [dist.gather(self.send_x[slot], gather_list=self.recv[slot], dst=self.root, group=self.group, async_op=True)]
+            return
+        if self.rank == self.root:
+            ops = [dist.P2POp(dist.irecv, self.recv[slot][r], r, self.group) for r in range(self.world) if r != self.root]
+        else:
+            ops = [dist.P2POp(dist.isend, self.send_x[slot], self.root, self.group)]
+        self.work[slot] = dist.batch_isend_irecv(ops) if ops else None
+
+    def bytes_per_rank(self):
+        """what one rank ships per exchange: header + the whole fixed-capacity record buffer"""
+        return self.HEADER + self.cap * 8
 
     def max_found(self, slot):
         """Root only, after wait(slot): the largest `matches found` any shard reported in this exchange (what the capacity has to hold)."""

@@ -52,27 +52,29 @@ def _worker(rank, world, port, q):
             ok = ok and merged.tolist() == want.tolist()
             # the sync-free path bench.py uses at N > 1: fixed-capacity gather to the root, double-buffered, three rounds
             cap = ShardExchange.plan(len(local))
-            ex = ShardExchange(cap, torch.device("cpu"))
-            for step in range(3):
-                slot = step % 2
-                ex.wait(slot)
-                buf = ex.send[slot].numpy()  # stands in for the device pipeline writing count + records in place
-                buf[:8] = np.array([len(local), len(local)], np.uint32).view(np.uint8)  # records written, matches found
-                buf[ex.HEADER : ex.HEADER + len(local) * 8] = local.view(np.uint8)
-                ex.post(slot)
-            runs2 = ex.collect(0)  # steps 0 and 2 used slot 0
-            if rank == 0:
-                ok = ok and merge_shard_runs(runs2, SortStrategy[sort]).tolist() == want.tolist()
-            else:
-                ok = ok and runs2 is None
-            # the one-call form bench.py's ordered mode uses (on the GPU: concatenation + radix sort in the root's HBM, fzb_merge_shard_runs;
-            # CPU tensors: the host combine) - slot 1 was used by step 1
-            class _Sorted:  # what collect_merged reads from a Matcher
-                class config:
-                    pass
-            _Sorted.config.sort = SortStrategy[sort]
-            merged3 = ex.collect_merged(1, _Sorted)
-            ok = ok and ((merged3.tolist() == want.tolist()) if rank == 0 else merged3 is None)
+            for transport in ("p2p", "gather"):  # batched sends / receives with the root's own run in place (default), dist.gather of the whole list
+                ex = ShardExchange(cap, torch.device("cpu"), transport=transport)
+                ok = ok and ex.bytes_per_rank() == 8 + 8 * cap
+                for step in range(3):
+                    slot = step % 2
+                    ex.wait(slot)
+                    buf = ex.send[slot].numpy()  # stands in for the device pipeline writing count + records in place
+                    buf[:8] = np.array([len(local), len(local)], np.uint32).view(np.uint8)  # records written, matches found
+                    buf[ex.HEADER : ex.HEADER + len(local) * 8] = local.view(np.uint8)
+                    ex.post(slot)
+                runs2 = ex.collect(0)  # steps 0 and 2 used slot 0
+                if rank == 0:
+                    ok = ok and merge_shard_runs(runs2, SortStrategy[sort]).tolist() == want.tolist()
+                else:
+                    ok = ok and runs2 is None
+                # the one-call form bench.py's ordered mode uses (on the GPU: concatenation + radix sort in the root's HBM, fzb_merge_shard_runs;
+                # CPU tensors: the host combine) - slot 1 was used by step 1
+                class _Sorted:  # what collect_merged reads from a Matcher
+                    class config:
+                        pass
+                _Sorted.config.sort = SortStrategy[sort]
+                merged3 = ex.collect_merged(1, _Sorted)
+                ok = ok and ((merged3.tolist() == want.tolist()) if rank == 0 else merged3 is None)
     # ---- BASELINE config 4 in miniature: a RAGGED list (8..128 bytes), byte-balanced shards of unequal counts, needle 'deadbeef' ----
     from frizbee_amd.distributed import shard_ranges_by_bytes
 

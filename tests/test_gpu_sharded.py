@@ -180,8 +180,9 @@ for typos in (0, 2):
 dist.barrier(); dist.destroy_process_group()
 print("RCCL-ONE-RANK-OK")
 ''' % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "tools": os.path.join(ROOT, "tools")}
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    for transport in ("p2p", "gather"):  # (with one rank the default transport has nothing to move - the root's run is in place; dist.gather still copies it)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, FZB_EXCHANGE_TRANSPORT=transport))
+        assert r.returncode == 0 and "RCCL-ONE-RANK-OK" in r.stdout, (transport, r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_bench_refuses_more_ranks_than_gpus():
@@ -207,6 +208,9 @@ def test_two_rank_rehearsal_of_the_bench_on_one_gpu():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["ranks_seen"] == 2 and "REHEARSAL" in j["config"]["backend"]
     assert j["value"] > 0 and j["scaling"] == "weak" and j["config"]["exchange"]["merged_len"] == j["config"]["exchange"]["matches_all_shards"]
+    x = j["config"]["exchange"]  # the attribution fields of the N > 1 line (round 6)
+    assert x["exchange_bytes_per_rank_per_step"] == 8 + 8 * x["exchange_capacity_records"] and x["exchange_bytes_into_root_per_step"] == x["exchange_bytes_per_rank_per_step"]
+    assert x["capacity_over_records"] <= 1.1 and x["value_without_exchange"] > 0 and x["exchange_alone_ms_per_step"] > 0 and x["transport"].startswith("p2p")
     e = j["e2e_sorted_merge"]
     assert e["equals_host_merge"] and e["merged_equals_oracle_list"] and e["every_shard_head_equals_oracle"]["equal_on_every_rank"]
     assert e["grow_and_retry"]["times_grown"] >= 1 and e["grow_and_retry"]["result_equals"]
