@@ -676,7 +676,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_noex, t_ex = float(t[0].item()), float(t[1].item())
         attribution = {"exchange_bytes_per_rank_per_step": ex.bytes_per_rank(), "exchange_bytes_into_root_per_step": ex.bytes_per_rank() * (world - 1),
-                       "transport": ex.transport + (" (nothing travels with one rank: the root's run is in place)" if world == 1 else ""),
+                       "transport": ex.transport + ((" (nothing travels with one rank: the root's run is in place)" if ex.transport == "p2p" else " (one rank: RCCL copies the root's own buffer, device to device)") if world == 1 else ""),
                        "ms_per_step_without_exchange": t_noex / args.steps * 1e3, "value_without_exchange": n * world / (t_noex / args.steps),
                        "exchange_alone_ms_per_step": t_ex / args.steps * 1e3,
                        "what": "same K steps, max over ranks: the loop with nothing posted; the posts alone (double-buffered, buffers already filled).  "

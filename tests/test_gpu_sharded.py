@@ -210,7 +210,7 @@ def test_two_rank_rehearsal_of_the_bench_on_one_gpu():
     assert j["value"] > 0 and j["scaling"] == "weak" and j["config"]["exchange"]["merged_len"] == j["config"]["exchange"]["matches_all_shards"]
     x = j["config"]["exchange"]  # the attribution fields of the N > 1 line (round 6)
     assert x["exchange_bytes_per_rank_per_step"] == 8 + 8 * x["exchange_capacity_records"] and x["exchange_bytes_into_root_per_step"] == x["exchange_bytes_per_rank_per_step"]
-    assert x["capacity_over_records"] <= 1.1 and x["value_without_exchange"] > 0 and x["exchange_alone_ms_per_step"] > 0 and x["transport"].startswith("p2p")
+    assert x["exchange_capacity_records"] <= 1.05 * (x["matches_all_shards"] / 2 * 1.1) + 4097 and x["value_without_exchange"] > 0 and x["exchange_alone_ms_per_step"] > 0 and x["transport"].startswith("p2p")
     e = j["e2e_sorted_merge"]
     assert e["equals_host_merge"] and e["merged_equals_oracle_list"] and e["every_shard_head_equals_oracle"]["equal_on_every_rank"]
     assert e["grow_and_retry"]["times_grown"] >= 1 and e["grow_and_retry"]["result_equals"]
