@@ -179,6 +179,7 @@ FzbKnobs parse_knobs() {
     k.no_dp_cfu = set("FZB_NO_DP_CFU");
     k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
     k.park_lds_kb = std::max(0, std::min(60, num("FZB_PARK_LDS_KB", 37)));
+    k.coop_below = num("FZB_COOP_BELOW", -1);
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
     return k;

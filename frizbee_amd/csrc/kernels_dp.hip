@@ -15,6 +15,7 @@
 // plain shift; since every row value is >= 0 the saturating subtract of the reference is preserved exactly
 // (see DESIGN.md).  BIAS=false keeps the literal 3-op form for scorings where the bias could overflow u16.
 #include "dp_cfm.h"
+#include "dp_coop.h"
 #include <cstdlib>
 
 // MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h), 2: biased domain throughout + closed-form
@@ -683,6 +684,46 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
     }
 }
 
+// The same four lists through the sub-wave cooperative scorer (dp_coop.h): sixteen lanes per window, four windows per wavefront, the tail
+// classes ignored (every chunk is computed in full - this form is taken when the queue is SHORT and one wave's instruction latency is the kernel).
+template <int SWL>
+__device__ __forceinline__ void dp_coop_tc_body(u32 vblock, u32 vgrid, u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta,
+                                                const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts, const NeedleDev& nd,
+                                                fzb_match_rec* __restrict__ out, u32 capacity) {
+    extern __shared__ __attribute__((aligned(16))) u32 s_park[];
+    if constexpr (SWL == 64 || SWL == 32) {
+        const u32 e3 = __builtin_amdgcn_readfirstlane(counts[3]), e2 = e3 + __builtin_amdgcn_readfirstlane(counts[2]), e1 = e2 + __builtin_amdgcn_readfirstlane(counts[1]),
+                  e0 = e1 + __builtin_amdgcn_readfirstlane(counts[0]);
+        const u32 ngroups = vgrid * blockDim.x / 16, gid = (vblock * blockDim.x + threadIdx.x) / 16;
+        u32* const park = s_park + threadIdx.x;
+        for (u32 q = gid; q < e0; q += ngroups) {
+            const u32 cls = q < e3 ? 3u : q < e2 ? 2u : q < e1 ? 1u : 0u;
+            const u32 base = cls == 3 ? 0u : cls == 2 ? e3 : cls == 1 ? e2 : e1;
+            const u32 j = lists[(size_t)(3 + cls) * list_stride + (q - base)];
+            if (j >= capacity) continue;
+            const u32 li = items ? items[j] : j;
+            const uint4 w = meta[j];
+            const u8* hay = (const u8*)(uintptr_t)((u64)w.z | ((u64)w.w << 32));
+            const u32 sp = w.x ? w.x - 1 : 0;
+            const bool include_exact = (w.y >> 31) != 0;
+            const u32 m = (w.y & 0x7FFFFFFFu) - sp;
+            u32 score = dp_coop_window<SWL>(nd, hay + sp, m, sp == 0, park, blockDim.x);
+            if ((threadIdx.x & 15u) == 0) {
+                bool exact = include_exact && m == (u32)nd.nbytes;
+                if (exact)
+                    for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+                if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+                fzb_match_rec rec;
+                rec.index = index_offset + li;
+                rec.score = (u16)score;
+                rec.exact = exact ? 1 : 0;
+                rec.valid = 0;
+                out[j] = rec;
+            }
+        }
+    }
+}
+
 // The three single-chunk classes and the multi-chunk tail classes in ONE launch - the grid is cut into four slices, a workgroup runs the body of
 // its slice (widest work first).  On a list of a million items every one of four separate launches is a single round of single items, so their
 // latencies (and launch boundaries) add up along the stream (paths-shaped list 128 -> 102 us); here they run side by side.  Registers follow the
@@ -690,12 +731,18 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
 template <int SWL, bool UPPER>
 __global__ __launch_bounds__(128, 2) void k2_classes_all(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
                                                       u32 list_stride, const u32* __restrict__ counters, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                      u32* __restrict__ scratch, u32 gm, u32 gc, u32 park_dw) {
+                                                      u32* __restrict__ scratch, u32 gm, u32 gc, u32 park_dw, u32 coop_below) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
     u32 b = blockIdx.x;
-    if (b < gm) { dp_multi_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch, park_dw); return; }
+    if (b < gm) {
+        // fewer multi-chunk windows than `coop_below` (0: the needle's parked rows do not fit, or another lane width): sixteen lanes per window
+        const u32 total = __builtin_amdgcn_readfirstlane(counters[12] + counters[13] + counters[14] + counters[15]);
+        if (total < coop_below) dp_coop_tc_body<SWL>(b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity);
+        else dp_multi_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch, park_dw);
+        return;
+    }
     b -= gm;
     if (b < gc) { dp_class_body<SWL, UPPER, SWL / 2>(tab, b, gc, index_offset, items, meta, lists + 2 * (size_t)list_stride, &counters[10], nd, out); return; }
     b -= gc;
@@ -720,7 +767,18 @@ void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, con
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     const u32 park_dw = fzb_park_lds_dwords(nd, sw_lanes);
-#define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), (size_t)nd.rows * park_dw * 128 * 4, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc, park_dw)
+    // the cooperative form of the multi-chunk slice (dp_coop.h): 64- and 32-lane backends, needles whose per-thread parking area fits 48 KB per
+    // workgroup; taken ON THE DEVICE below `coop_below` queued windows.  A thread-per-window wave walks ~ 1 000 instructions per (row, chunk)
+    // whatever the queue's length - 44 us for a window of three chunks and five rows, even when the queue holds one wavefront's worth - while
+    // sixteen lanes per window make that chain ~ 360 instructions and four times as many wavefronts; but the literal, unpacked, DPP-heavy rows
+    // cost ~ 5 x the instructions in total, so the form pays only while the queue fits about one and a half rounds of the slice's resident
+    // groups (8 per workgroup).  Measured (profiles/r06_coop.txt): paths-shaped lists of 100 k / 300 k items (1.9 k / 5.7 k windows) 56.3 ->
+    // 46.8 / 59.0 -> 49.0 us per step; 8.6 k windows (300 k items, 1 typo) 91.0 -> 85.2; 27 k windows (1.4 M items) 97.0 -> 115: above the threshold
+    // the packed closed-form thread-per-window rows stay
+    const size_t coop_lds = (sw_lanes == 64 || sw_lanes == 32) ? (size_t)(nd.rows + 1) * (sw_lanes / 32 + 1) * 128 * 4 : 0;
+    const u32 coop_below = (coop_lds != 0 && coop_lds <= 48 * 1024 && fzb_knobs().coop_below != 0) ? (fzb_knobs().coop_below > 0 ? (u32)fzb_knobs().coop_below : (u32)gm * 12u) : 0u;
+    const size_t dyn_lds = std::max((size_t)nd.rows * park_dw * 128 * 4, coop_below ? coop_lds : (size_t)0);
+#define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), dyn_lds, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc, park_dw, coop_below)
 #define FZB_K2A_U(SWL) do { if (upper) FZB_K2A(SWL, true); else FZB_K2A(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2A_U(64); break;

@@ -137,6 +137,14 @@ if "INDICES" in which:
             print(json.dumps(dict(config=f"C2 list, positions for the top {k} of match_list, max_typos={typos}", selection=k, records=len(r),
                                   c_call_ms=sorted(tc)[2] * 1e3, python_call_ms=sorted(ts)[2] * 1e3, haystacks_per_s=k / sorted(tc)[2])), flush=True)
     del cp, flat, ends
+if "PATHSSMALL" in which:
+    # repositories of ordinary size (the 1.4 M-item row is Chromium): the same shape at 100 k / 300 k items
+    for npaths in (100_000, 300_000):
+        data, ends = synth.paths_corpus(b"linux", npaths, device=dev)
+        cp = F.Corpus(packed=(data, ends))
+        run(f"paths-shaped {npaths // 1000}k 'linux' typos0", "linux", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, npaths)
+        run(f"paths-shaped {npaths // 1000}k 'linux' 1 typo", "linux", F.Config(max_typos=1, pf_lanes=64, sw_lanes=64), cp, npaths, steps=5)
+        del cp
 if "PATHSVAR" in which:
     # the other columns of the reference's Chromium table (BENCHMARKS.md:59-65): All Scores (max_typos None), 1 / 2 / 3 typos
     npaths = 1_406_941
