@@ -343,6 +343,16 @@ def other_configs(F, synth, dev, steps):
         cols[label] = {"ms_per_step": res[key]["ms_per_step"], "matches": res[key]["matches"], "reference_published_ms": {"sequential": ref[0], "parallel_x8": ref[1]}}
         del res[key]
     res[name]["other_columns"] = cols
+    # repositories of ordinary size: the same shape at 100 k / 300 k items (their few thousand multi-chunk windows take sixteen lanes each: dp_coop.h)
+    small = {}
+    for nsmall in (100_000, 300_000):
+        dps, eps = synth.paths_corpus(b"linux", nsmall, device=dev)
+        cps = F.Corpus(packed=(dps, eps))
+        key = f"paths-shaped list of {nsmall // 1000} k items"
+        run(key, "linux", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cps, nsmall, int(eps[-1]))
+        small[f"{nsmall // 1000}k"] = {"ms_per_step": res[key]["ms_per_step"], "matches": res[key]["matches"], "multi_chunk_scored": res[key].get("multi_chunk_scored")}
+        del res[key], cps, dps, eps
+    res[name]["smaller_lists"] = small
     del cp, dp, ep, mq, rq
     # the reference's UTF-8 benchmark shape (BENCHMARKS.md "Arabic": 285 587 sentences, median 37 bytes, a needle of two Arabic letters), synthetic
     da, ea = synth.arabic_corpus()
