@@ -770,13 +770,14 @@ void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, con
     // the cooperative form of the multi-chunk slice (dp_coop.h): 64- and 32-lane backends, needles whose per-thread parking area fits 48 KB per
     // workgroup; taken ON THE DEVICE below `coop_below` queued windows.  A thread-per-window wave walks ~ 1 000 instructions per (row, chunk)
     // whatever the queue's length - 44 us for a window of three chunks and five rows, even when the queue holds one wavefront's worth - while
-    // sixteen lanes per window make that chain ~ 360 instructions and four times as many wavefronts; but the literal, unpacked, DPP-heavy rows
-    // cost ~ 5 x the instructions in total, so the form pays only while the queue fits about one and a half rounds of the slice's resident
-    // groups (8 per workgroup).  Measured (profiles/r06_coop.txt): paths-shaped lists of 100 k / 300 k items (1.9 k / 5.7 k windows) 56.3 ->
-    // 46.8 / 59.0 -> 49.0 us per step; 8.6 k windows (300 k items, 1 typo) 91.0 -> 85.2; 27 k windows (1.4 M items) 97.0 -> 115: above the threshold
-    // the packed closed-form thread-per-window rows stay
+    // sixteen lanes per window make that chain ~ 200 instructions and four times as many wavefronts; but its rows are literal (no biased domain,
+    // no closed-form padding, every shift a v_mov_dpp or two), so the form pays only while the queue fits about two rounds of the slice's
+    // resident groups (8 per workgroup).  Measured (profiles/r06_coop.txt): paths-shaped lists of 100 k / 300 k items (1.9 k / 5.7 k windows)
+    // 56.8 -> 45.5 / 60.0 -> 48.8 us per step; 8.6 k windows 91.5 -> 81.8; 27 k windows (1.4 M items) 100.3 -> 104.0; 40 k: 139.7 -> 150.9.
+    // (As a kernel of its own on the second stream - eight waves per SIMD instead of this kernel's two - it LOST: the fork / join around it
+    // costs more than the residency returns: 100 k items 55.9 -> 64.9 us.)
     const size_t coop_lds = (sw_lanes == 64 || sw_lanes == 32) ? (size_t)(nd.rows + 1) * (sw_lanes / 32 + 1) * 128 * 4 : 0;
-    const u32 coop_below = (coop_lds != 0 && coop_lds <= 48 * 1024 && fzb_knobs().coop_below != 0) ? (fzb_knobs().coop_below > 0 ? (u32)fzb_knobs().coop_below : (u32)gm * 12u) : 0u;
+    const u32 coop_below = (coop_lds != 0 && coop_lds <= 48 * 1024 && fzb_knobs().coop_below != 0) ? (fzb_knobs().coop_below > 0 ? (u32)fzb_knobs().coop_below : (u32)gm * 16u) : 0u;
     const size_t dyn_lds = std::max((size_t)nd.rows * park_dw * 128 * 4, coop_below ? coop_lds : (size_t)0);
 #define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), dyn_lds, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc, park_dw, coop_below)
 #define FZB_K2A_U(SWL) do { if (upper) FZB_K2A(SWL, true); else FZB_K2A(SWL, false); } while (0)

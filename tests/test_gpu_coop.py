@@ -1,6 +1,6 @@
 """The sub-wave cooperative scorer (dp_coop.h: sixteen lanes per window, DPP row shifts for the reference's shift_right_padded) against the oracle:
 multi-chunk ASCII windows of 65..1024 bytes at the 64-lane (u8 class) and 32-lane (u16 class) backends, needles of 1..20 rows, random scorings,
-windows that end exactly on chunk boundaries, typo configurations (windows from the lane-exact prefilter).  It is the DEVICE's choice below 12 288
+windows that end exactly on chunk boundaries, typo configurations (windows from the lane-exact prefilter).  It is the DEVICE's choice below 16 384
 queued windows, so these small lists take it by default; FZB_COOP_BELOW=0 is the thread-per-window form (tests/test_gpu_knobs.py runs both)."""
 import numpy as np
 import pytest
