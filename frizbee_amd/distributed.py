@@ -155,9 +155,9 @@ class ShardExchange:
         not torch's current stream: the exchange (and the host-staged copy in front of it) is ordered behind it."""
         self.wait(slot)
         if stream is not None and self.device.type == "cuda":
-            ext = torch.cuda.ExternalStream(int(stream), device=self.device)
-            if ext != torch.cuda.current_stream(self.device):
-                torch.cuda.current_stream(self.device).wait_stream(ext)
+            cur = torch.cuda.current_stream(self.device)
+            if int(stream) != int(cur.cuda_stream):  # (the usual case - the pipeline's stream IS torch's current stream - costs nothing)
+                cur.wait_stream(torch.cuda.ExternalStream(int(stream), device=self.device))
         if self.host_staged:
             self.send_x[slot].copy_(self.send[slot])  # device -> host, behind the pipeline on the current stream (synchronises)
         if self.transport == "gather":
