@@ -18,6 +18,29 @@ __device__ __forceinline__ void haystack_span(const ET* __restrict__ ends, u64 i
     len = (u32)(e - start);
 }
 
+// End offsets of either width behind ONE kernel instantiation: a wave-uniform branch per read instead of a template parameter that doubled every
+// scorer (round 6: the u32 / u64 twins were 2.6 MB of the library).  The streaming filters, which read one offset per haystack of the whole
+// list, keep the template.
+struct EndsAny {
+    const void* p;
+    int is64;
+    __device__ __forceinline__ u64 operator[](u64 i) const { return is64 ? ((const u64*)p)[i] : (u64)((const u32*)p)[i]; }
+};
+__device__ __forceinline__ void haystack_span(const EndsAny& ends, u64 i, u64& start, u32& len) {
+    u64 e = ends[i];
+    u64 ep = i ? ends[i - 1] : 0;
+    start = (ep + 15) & ~(u64)15;
+    len = (u32)(e - start);
+}
+__device__ __forceinline__ void haystack_span_u(const EndsAny& ends, u32 ulen, u64 i, u64& start, u32& len) {
+    if (ulen) {
+        start = i * (u64)((ulen + 15u) & ~15u);
+        len = ulen;
+    } else {
+        haystack_span(ends, i, start, len);
+    }
+}
+
 // the same when every haystack of the corpus has `ulen` bytes (CorpusDev::uniform_len): no loads, and the haystack's vectors can be
 // requested without waiting for an end offset
 template <typename ET>

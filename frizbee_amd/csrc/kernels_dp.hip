@@ -18,10 +18,10 @@
 #include "dp_coop.h"
 #include <cstdlib>
 
-// MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h), 2: biased domain throughout + closed-form
-// padding (dp_cf.h; LaunchCfg::cf_ok)
-template <int SWL, int MODE, bool UPPER, typename ET>
-__global__ __launch_bounds__(128, 2) void k2b_dp(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+// MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h).  (dp_cf.h's form of this per-wave kernel - rounds 2-5 -
+// only ever ran behind FZB_NO_DP_CLASSES once the classified path existed and left with round 6's prune.)
+template <int SWL, int MODE, bool UPPER>
+__global__ __launch_bounds__(128, 2) void k2b_dp(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset,
                                               const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                               const NeedleDev nd, int wmode, int pad_ok, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count,
                                               u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters) {
@@ -109,18 +109,10 @@ __global__ __launch_bounds__(128, 2) void k2b_dp(const u8* __restrict__ bytes, c
             if (m > 0) {
                 if (inreg) load_window_regs<SWL / 4>(q0_c, q1_c, sp, m, hb);
                 else load_window_mem<SWL / 4>(hay + sp, m, hb);
-                if (MODE == 2) {
-                    // wave-uniform choice of the computed lanes: the widest window of the wave decides (dp_cf.h)
-                    constexpr int NW = SWL / 2;
-                    if (__all((int)(m <= (u32)SWL / 2))) score = dp_single_chunk_cf<SWL, UPPER, NW / 2>(nd, sp == 0, cls, hb);
-                    else if (__all((int)(m <= 3 * (u32)SWL / 4))) score = dp_single_chunk_cf<SWL, UPPER, 3 * NW / 4>(nd, sp == 0, cls, hb);
-                    else score = dp_single_chunk_cf<SWL, UPPER, NW>(nd, sp == 0, cls, hb);
-                } else {
-                    // wave-uniform choice: if every window in this wave fits the low half of the chunk, the upper half is pure padding
-                    const bool half = pad_ok && SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
-                    if (half) score = dp_single_chunk<SWL, MODE == 1, UPPER, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, sp == 0, cls, hb);
-                    else score = dp_single_chunk<SWL, MODE == 1, UPPER>(nd, m, sp == 0, cls, hb);
-                }
+                // wave-uniform choice: if every window in this wave fits the low half of the chunk, the upper half is pure padding
+                const bool half = pad_ok && SWL >= 16 && __all((int)(m <= (u32)SWL / 2));
+                if (half) score = dp_single_chunk<SWL, MODE == 1, UPPER, (SWL >= 16 ? SWL / 4 : SWL / 2)>(nd, m, sp == 0, cls, hb);
+                else score = dp_single_chunk<SWL, MODE == 1, UPPER>(nd, m, sp == 0, cls, hb);
             }
             const bool exact = exact_match<SWL / 4>(nd, include_exact, m, hb);
             if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
@@ -162,8 +154,8 @@ extern "C" int fzb_debug_dp_timing(unsigned long long* host_out) { return (int)h
 #define FZB_TIMING_BEGIN
 #define FZB_TIMING_END
 #endif
-template <int SWL, bool UPPER, typename ET>
-__global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+template <int SWL, bool UPPER>
+__global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset,
                                                     const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                     const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count,
                                                     RejectOut rej, u32* __restrict__ kept_out, u32 ulen) {
@@ -289,8 +281,8 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
 //                 It writes, per survivor, one 16-byte record (window start, window end | bit 31 = "the window is the whole haystack", the
 //                 64-bit address of the haystack's first byte).  The scorers read that record and nothing else: no end offsets.
 // ---------------------------------------------------------------------------------------------------------------
-template <typename ET, int PER>
-__global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, const u32* __restrict__ items,
+template <int PER>
+__global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes, const EndsAny ends, u64 first, const u32* __restrict__ items,
                                                     const u32* __restrict__ win_in, const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, u32 swl,
                                                     uint4* __restrict__ meta, u32* __restrict__ lists, u32 list_stride, u32* __restrict__ overflow, u32 qcap,
                                                     u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count, u32 split_multi) {
@@ -454,8 +446,8 @@ void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, cons
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     if (part != 2) {
         // (two survivors per thread: 1 / 2 / 4 gave 0.458 / 0.454 / 0.464 ms for the C4 shard's step)
-#define FZB_K2W(ET) hipLaunchKernelGGL((k2w_classify<ET, 2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, (const ET*)c.ends, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, (uint4*)win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi)
-        if (c.ends_u64) FZB_K2W(u64); else FZB_K2W(u32);
+#define FZB_K2W(ET) hipLaunchKernelGGL((k2w_classify<2>), dim3(num_cus * 8), dim3(256), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, items, win_in, n_items_ptr, nd, wmode, (u32)sw_lanes, (uint4*)win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi)
+        FZB_K2W(u32);
 #undef FZB_K2W
     }
     if (part == 1) return;
@@ -478,8 +470,8 @@ void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, cons
 // ---------------------------------------------------------------------------------------------------------------
 // k2d: the queued windows of SWL < m <= 1024 bytes, one thread each, chunk by chunk (dp_multi_chunk).
 // ---------------------------------------------------------------------------------------------------------------
-template <int SWL, bool BIAS, typename ET>
-__global__ __launch_bounds__(128, 2) void k2d_dp_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+template <int SWL, bool BIAS>
+__global__ __launch_bounds__(128, 2) void k2d_dp_multi(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset,
                                                     const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
                                                     fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch) {
     __shared__ u8 cls[256];
@@ -521,8 +513,8 @@ __global__ __launch_bounds__(128, 2) void k2d_dp_multi(const u8* __restrict__ by
 // are queued - (output position, window, haystack) entries, counters[3] - for the wave-per-haystack kernel behind this one.
 // Records are written at the items' list positions (index order), the two counters by the first thread.
 // ---------------------------------------------------------------------------------------------------------------
-template <int SWL, bool BIAS, typename ET>
-__global__ __launch_bounds__(128) void k2d_dp_long(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items,
+template <int SWL, bool BIAS>
+__global__ __launch_bounds__(128) void k2d_dp_long(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset, const u32* __restrict__ items,
                                                    const u32* __restrict__ win, int wmode, const u32* __restrict__ n_items_ptr, const NeedleLongDev nd,
                                                    fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ scratch, u32* __restrict__ queue,
                                                    u32* __restrict__ counters) {
@@ -585,8 +577,8 @@ size_t fzb_dp_long_scratch_words_per_thread(const NeedleLongDev& nd, int sw_lane
 
 void fzb_launch_dp_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd, int sw_lanes,
                         int bias_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* scratch, u32* queue, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2L(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_long<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
-#define FZB_K2L_ET(SWL, B) do { if (c.ends_u64) FZB_K2L(SWL, B, u64); else FZB_K2L(SWL, B, u32); } while (0)
+#define FZB_K2L(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_long<SWL, B>), dim3(grid), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
+#define FZB_K2L_ET(SWL, B) FZB_K2L(SWL, B, u32)
 #define FZB_K2L_B(SWL) do { if (bias_ok) FZB_K2L_ET(SWL, true); else FZB_K2L_ET(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2L_B(64); break;
@@ -611,8 +603,8 @@ __device__ __forceinline__ ParkAt park_at(u32* scratch, u32 nthreads, u32 gtid, 
 }
 
 // the same list through dp_cfm.h's form (LaunchCfg::cfm_ok); bonuses from the LDS tables as in the other dp_cf.h kernels
-template <int SWL, bool UPPER, typename ET>
-__global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+template <int SWL, bool UPPER>
+__global__ __launch_bounds__(128, 2) void k2d_dp_multi_t(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset,
                                                       const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const NeedleDev nd,
                                                       fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ scratch, u32 park_dw) {
     __shared__ CfTables tab;
@@ -797,8 +789,8 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
         bool upper = false;
         for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
         const u32 park_dw = fzb_park_lds_dwords(nd, sw_lanes);
-#define FZB_K2T(SWL, U, ET) hipLaunchKernelGGL((k2d_dp_multi_t<SWL, U, ET>), dim3(grid), dim3(128), (size_t)nd.rows * park_dw * 128 * 4, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, park_dw)
-#define FZB_K2T_ET(SWL, U) do { if (c.ends_u64) FZB_K2T(SWL, U, u64); else FZB_K2T(SWL, U, u32); } while (0)
+#define FZB_K2T(SWL, U, ET) hipLaunchKernelGGL((k2d_dp_multi_t<SWL, U>), dim3(grid), dim3(128), (size_t)nd.rows * park_dw * 128 * 4, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, park_dw)
+#define FZB_K2T_ET(SWL, U) FZB_K2T(SWL, U, u32)
 #define FZB_K2T_U(SWL) do { if (upper) FZB_K2T_ET(SWL, true); else FZB_K2T_ET(SWL, false); } while (0)
         switch (sw_lanes) {
             case 64: FZB_K2T_U(64); break;
@@ -808,8 +800,8 @@ void fzb_launch_dp_multi(const CorpusDev& c, u64 first, u32 index_offset, const 
         }
         return;
     }
-#define FZB_K2D(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_multi<SWL, B, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch)
-#define FZB_K2D_ET(SWL, B) do { if (c.ends_u64) FZB_K2D(SWL, B, u64); else FZB_K2D(SWL, B, u32); } while (0)
+#define FZB_K2D(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_multi<SWL, B>), dim3(grid), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch)
+#define FZB_K2D_ET(SWL, B) FZB_K2D(SWL, B, u32)
 #define FZB_K2D_B(SWL) do { if (bias_ok) FZB_K2D_ET(SWL, true); else FZB_K2D_ET(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2D_B(64); break;
@@ -835,10 +827,10 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
 #define FZB_K2S(SWL, U, ET)                                                                                                             \
     do {                                                                                                                                \
         static int per_cu = 0;                                                                                                          \
-        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
-        hipLaunchKernelGGL((k2b_dp_short<SWL, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out, c.uniform_len); \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp_short<SWL, U>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
+        hipLaunchKernelGGL((k2b_dp_short<SWL, U>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, rj, kept_out, c.uniform_len); \
     } while (0)
-#define FZB_K2S_ET(SWL, U) do { if (c.ends_u64) FZB_K2S(SWL, U, u64); else FZB_K2S(SWL, U, u32); } while (0)
+#define FZB_K2S_ET(SWL, U) FZB_K2S(SWL, U, u32)
 #define FZB_K2S_U(SWL) do { if (upper) FZB_K2S_ET(SWL, true); else FZB_K2S_ET(SWL, false); } while (0)
         if (sw_lanes == 64) FZB_K2S_U(64); else FZB_K2S_U(32);
         return;
@@ -847,12 +839,14 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
 #define FZB_K2B(SWL, B, U, ET)                                                                                                          \
     do {                                                                                                                                \
         static int per_cu = 0;                                                                                                          \
-        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp<SWL, B, U, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
-        hipLaunchKernelGGL((k2b_dp<SWL, B, U, ET>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, dev_count, overflow, qcap, counters); \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2b_dp<SWL, B, U>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 4; \
+        hipLaunchKernelGGL((k2b_dp<SWL, B, U>), dim3(num_cus * per_cu), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, n_items_ptr, nd, wmode, pad_ok, out, capacity, dev_count, overflow, qcap, counters); \
     } while (0)
-#define FZB_K2B_ET(SWL, B, U) do { if (c.ends_u64) FZB_K2B(SWL, B, U, u64); else FZB_K2B(SWL, B, U, u32); } while (0)
+#define FZB_K2B_ET(SWL, B, U) FZB_K2B(SWL, B, U, u32)
 #define FZB_K2B_U(SWL, B) do { if (upper) FZB_K2B_ET(SWL, B, true); else FZB_K2B_ET(SWL, B, false); } while (0)
-#define FZB_K2B_B(SWL) do { if (mode == 2) FZB_K2B_U(SWL, 2); else if (mode == 1) FZB_K2B_U(SWL, 1); else FZB_K2B_U(SWL, 0); } while (0)
+    // (mode 2 = dp_cf.h's preconditions hold: lists that qualify took k2b_dp_short above, every other one is scored by the classified path - the
+    // per-wave kernel then only runs under FZB_NO_DP_CLASSES, in its biased first form, which those preconditions include)
+#define FZB_K2B_B(SWL) do { if (mode >= 1) FZB_K2B_U(SWL, 1); else FZB_K2B_U(SWL, 0); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2B_B(64); break;
         case 32: FZB_K2B_B(32); break;

@@ -109,8 +109,8 @@ struct GateArgs {
 };
 #define TRACE_W (FZB_MAX_HAYSTACK_LEN + 2 * 64)  // columns: the zero chunk + up to 1024 bytes rounded up to a chunk
 
-template <int SWL, bool UNICODE, bool TRACE, typename ET, typename ND = NeedleDev, bool SLAB = ND::kLong>
-__global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+template <int SWL, bool UNICODE, bool TRACE, typename ND = NeedleDev, bool SLAB = ND::kLong>
+__global__ __launch_bounds__(GEN_WAVES * 64) void k2c_generic(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset,
                                                               const u32* __restrict__ items, const u32* __restrict__ win, int wmode,
                                                               const u32* __restrict__ list, const u32* __restrict__ n_list_ptr, const ND nd,
                                                               fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ counters,
@@ -441,8 +441,8 @@ void fzb_launch_generic(const CorpusDev& c, u64 first, u32 index_offset, const u
     const TraceArgs none{nullptr, nullptr, nullptr, 0};
     const GateArgs gate{only_below ? n_list_ptr : nullptr, 0u, only_below, list_forward, only_below ? alt_list : nullptr, alt_count};
     const size_t lds = generic_lds_bytes(nd, sw_lanes);
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false, ET>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none, (u16*)nullptr, gate)
-#define FZB_K2C_ET(SWL, U) do { if (c.ends_u64) FZB_K2C(SWL, U, u64); else FZB_K2C(SWL, U, u32); } while (0)
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, false>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, list, n_list_ptr, nd, out, capacity, dev_count, counters, none, (u16*)nullptr, gate)
+#define FZB_K2C_ET(SWL, U) FZB_K2C(SWL, U, )
 #define FZB_K2C_U(SWL) do { if (unicode) FZB_K2C_ET(SWL, true); else FZB_K2C_ET(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2C_U(64); break;
@@ -462,7 +462,7 @@ void fzb_launch_generic_trace(const CorpusDev& c, u64 first, u32 index_offset, c
                               int grid, hipStream_t st) {
     const TraceArgs tr{cells, pos, npos, stride};
     const size_t lds = generic_lds_bytes(nd, sw_lanes);
-#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true, ET>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, (u16*)nullptr, GateArgs{nullptr, 0u, 0u, 0, nullptr, nullptr})
+#define FZB_K2C(SWL, U, ET) hipLaunchKernelGGL((k2c_generic<SWL, U, true>), dim3(grid), dim3(GEN_WAVES * 64), lds, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, (const u32*)nullptr, n_items_ptr, nd, out, capacity, dev_count, counters, tr, (u16*)nullptr, GateArgs{nullptr, 0u, 0u, 0, nullptr, nullptr})
     switch (sw_lanes) {
         case 64: FZB_K2C_U(64); break;
         case 32: FZB_K2C_U(32); break;
@@ -487,9 +487,9 @@ void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, co
     // the previous-chunk vectors in LDS when they fit (60 KB per four-wave workgroup: up to 127 rows at 32 lanes), in the slab otherwise
     const size_t lds = (size_t)GEN_WAVES * 2 * (size_t)(nd.rows + 1) * (size_t)sw_lanes * sizeof(u16);
     const bool in_lds = lds <= (size_t)60 * 1024;
-#define FZB_K2C_LS(SWL, U, T, ET, SLAB) hipLaunchKernelGGL((k2c_generic<SWL, U, T, ET, NeedleLongDev, SLAB>), dim3(grid), dim3(GEN_WAVES * 64), SLAB ? 0 : lds, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, wmode, list, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 1, nullptr, nullptr})
+#define FZB_K2C_LS(SWL, U, T, ET, SLAB) hipLaunchKernelGGL((k2c_generic<SWL, U, T, NeedleLongDev, SLAB>), dim3(grid), dim3(GEN_WAVES * 64), SLAB ? 0 : lds, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, list, n_items_ptr, nd, out, capacity, dev_count, counters, tr, adj, GateArgs{nullptr, 0u, 0u, 1, nullptr, nullptr})
 #define FZB_K2C_L(SWL, U, T, ET) do { if (in_lds) FZB_K2C_LS(SWL, U, T, ET, false); else FZB_K2C_LS(SWL, U, T, ET, true); } while (0)
-#define FZB_K2C_L_ET(SWL, U, T) do { if (c.ends_u64) FZB_K2C_L(SWL, U, T, u64); else FZB_K2C_L(SWL, U, T, u32); } while (0)
+#define FZB_K2C_L_ET(SWL, U, T) FZB_K2C_L(SWL, U, T, )
 #define FZB_K2C_L_T(SWL, U) do { if (trace) FZB_K2C_L_ET(SWL, U, true); else FZB_K2C_L_ET(SWL, U, false); } while (0)
 #define FZB_K2C_L_U(SWL) do { if (nd.unicode) FZB_K2C_L_T(SWL, true); else FZB_K2C_L_T(SWL, false); } while (0)
     switch (sw_lanes) {

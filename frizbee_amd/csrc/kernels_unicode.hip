@@ -5,8 +5,8 @@
 #include "dp_unicode.h"
 #include <cstdlib>
 
-template <int SWL, bool HALFONLY, bool TF, typename ET>
-__device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset,
+template <int SWL, bool HALFONLY, bool TF>
+__device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset,
                                                       const u32* __restrict__ items, const u32* __restrict__ win, const u32* __restrict__ n_items_ptr,
                                                       const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity,
                                                       u32* __restrict__ dev_count, u32* __restrict__ overflow, u32 qcap,
@@ -140,8 +140,7 @@ __device__ __forceinline__ void k2u_body(const u8* __restrict__ bytes, const ET*
 // (pushes are collected per workgroup in LDS and take ONE atomic on the queue's counter per 2048 items: an atomic per wave - 4.4 k of them on
 // one address for the Arabic-shaped list - is served one at a time, 8 ns each, and made this kernel 53 us long)
 #define FZB_SPLIT_CHUNK 2048u
-template <typename ET>
-__global__ __launch_bounds__(256) void k2u_split_wide(const ET* __restrict__ ends, u64 first, const u32* __restrict__ items, const u32* __restrict__ n_items_ptr, u32 ulen, u32 swl,
+__global__ __launch_bounds__(256) void k2u_split_wide(const EndsAny ends, u64 first, const u32* __restrict__ items, const u32* __restrict__ n_items_ptr, u32 ulen, u32 swl,
                                                       u32 capacity, u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters) {
     __shared__ uint4 s_buf[FZB_SPLIT_CHUNK];
     __shared__ u32 s_n, s_base;
@@ -179,23 +178,22 @@ __global__ __launch_bounds__(256) void k2u_split_wide(const ET* __restrict__ end
 
 void fzb_launch_unicode_split_wide(const CorpusDev& c, u64 first, const u32* items, const u32* n_items_ptr, int sw_lanes, u32 capacity, u32* overflow, u32 qcap, u32* counters,
                                    int grid, hipStream_t st) {
-    if (c.ends_u64) hipLaunchKernelGGL((k2u_split_wide<u64>), dim3(grid), dim3(256), 0, st, (const u64*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters);
-    else hipLaunchKernelGGL((k2u_split_wide<u32>), dim3(grid), dim3(256), 0, st, (const u32*)c.ends, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters);
+    hipLaunchKernelGGL(k2u_split_wide, dim3(grid), dim3(256), 0, st, EndsAny{c.ends, c.ends_u64}, first, items, n_items_ptr, c.uniform_len, (u32)sw_lanes, capacity, overflow, qcap, counters);
 }
 
-#define FZB_K2U_PARAMS const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win, \
+#define FZB_K2U_PARAMS const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset, const u32* __restrict__ items, const u32* __restrict__ win, \
     const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ overflow, \
     u32 qcap, u32* __restrict__ counters, u32 ulen, u32 multi_front
 #define FZB_K2U_ARGS bytes, ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, ulen, multi_front
-template <int SWL, bool TF, typename ET>
-__global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, TF, ET>(FZB_K2U_ARGS); }
+template <int SWL, bool TF>
+__global__ __launch_bounds__(128) void k2u_dp_unicode(FZB_K2U_PARAMS) { k2u_body<SWL, false, TF>(FZB_K2U_ARGS); }
 // every haystack of the list fits the low half of a chunk (host-known: corpus max_len <= SWL / 2): the general form is compiled out,
 // which lets the kernel fit 168 VGPRs (a few spills outside the row loop) and run three waves per SIMD
-template <int SWL, bool TF, typename ET>
-__global__ __launch_bounds__(128, 3) void k2u_dp_unicode_half(FZB_K2U_PARAMS) { k2u_body<SWL, true, TF, ET>(FZB_K2U_ARGS); }
+template <int SWL, bool TF>
+__global__ __launch_bounds__(128, 3) void k2u_dp_unicode_half(FZB_K2U_PARAMS) { k2u_body<SWL, true, TF>(FZB_K2U_ARGS); }
 // the same at two waves per SIMD (256 VGPRs: no spills in the row loop of the biased-throughout form); FZB_K2U_WAVES=2
-template <int SWL, bool TF, typename ET>
-__global__ __launch_bounds__(128, 2) void k2u_dp_unicode_half_w2(FZB_K2U_PARAMS) { k2u_body<SWL, true, TF, ET>(FZB_K2U_ARGS); }
+template <int SWL, bool TF>
+__global__ __launch_bounds__(128, 2) void k2u_dp_unicode_half_w2(FZB_K2U_PARAMS) { k2u_body<SWL, true, TF>(FZB_K2U_ARGS); }
 
 void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, const u32* n_items_ptr, const NeedleDev& nd,
                            int sw_lanes, int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters,
@@ -206,37 +204,35 @@ void fzb_launch_dp_unicode(const CorpusDev& c, u64 first, u32 index_offset, cons
     const bool half_only = sw_lanes >= 16 && c.max_len != 0 && c.max_len <= (u32)sw_lanes / 2;
     // the biased-throughout form wants ~250 registers: at two waves per SIMD it runs without spills (C5: 0.152 ms; capped at 168 registers /
     // three waves it spills inside the row loop: 0.199 ms; the first form at three waves: 0.161 ms)
-    const bool w2 = tform != 0;
-#define FZB_K2U(SWL, TF, ET)                                                                                                           \
+    // (the half-only kernels: the biased form at two waves per SIMD, the first form at three - each instantiated for its own form only)
+#define FZB_K2U_LAUNCH(KERNEL, DFLT)                                                                                                   \
     do {                                                                                                                               \
-        static int per_cu = 0, per_cu_half = 0;                                                                                        \
-        if (half_only && w2) {                                                                                                         \
-            static int per_cu_w2 = 0;                                                                                                  \
-            if (!per_cu_w2 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_w2, k2u_dp_unicode_half_w2<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_w2 < 1)) per_cu_w2 = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half_w2<SWL, TF, ET>), dim3(one_round_wgs > 0 ? one_round_wgs : grid * per_cu_w2), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
-        } else if (half_only) {                                                                                                        \
-            if (!per_cu_half && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_half, k2u_dp_unicode_half<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu_half < 1)) per_cu_half = 4; \
-            hipLaunchKernelGGL((k2u_dp_unicode_half<SWL, TF, ET>), dim3(one_round_wgs > 0 ? one_round_wgs : grid * per_cu_half), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
-        } else {                                                                                                                       \
-            if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k2u_dp_unicode<SWL, TF, ET>, 128, 0) != hipSuccess || per_cu < 1)) per_cu = 2; \
-            hipLaunchKernelGGL((k2u_dp_unicode<SWL, TF, ET>), dim3(one_round_wgs > 0 ? one_round_wgs : grid * per_cu), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
-        }                                                                                                                              \
+        static int per_cu = 0;                                                                                                         \
+        if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 128, 0) != hipSuccess || per_cu < 1)) per_cu = DFLT; \
+        hipLaunchKernelGGL(KERNEL, dim3(one_round_wgs > 0 ? one_round_wgs : grid * per_cu), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, n_items_ptr, nd, wmode, out, capacity, dev_count, overflow, qcap, counters, c.uniform_len, (u32)multi_front); \
     } while (0)
-#define FZB_K2U_TF(SWL, ET) do { if (tform) FZB_K2U(SWL, true, ET); else FZB_K2U(SWL, false, ET); } while (0)
-#define FZB_K2U_ET(SWL) do { if (c.ends_u64) FZB_K2U_TF(SWL, u64); else FZB_K2U_TF(SWL, u32); } while (0)
+#define FZB_K2U_SW(SWL)                                                                                                                \
+    do {                                                                                                                               \
+        if (half_only && tform) FZB_K2U_LAUNCH((k2u_dp_unicode_half_w2<SWL, true>), 4);                                            \
+        else if (half_only) FZB_K2U_LAUNCH((k2u_dp_unicode_half<SWL, false>), 4);                                                  \
+        else if (tform) FZB_K2U_LAUNCH((k2u_dp_unicode<SWL, true>), 2);                                                            \
+        else FZB_K2U_LAUNCH((k2u_dp_unicode<SWL, false>), 2);                                                                      \
+    } while (0)
     switch (sw_lanes) {
-        case 64: FZB_K2U_ET(64); break;
-        case 32: FZB_K2U_ET(32); break;
-        case 16: FZB_K2U_ET(16); break;
-        default: FZB_K2U_ET(8); break;
+        case 64: FZB_K2U_SW(64); break;
+        case 32: FZB_K2U_SW(32); break;
+        case 16: FZB_K2U_SW(16); break;
+        default: FZB_K2U_SW(8); break;
     }
+#undef FZB_K2U_SW
+#undef FZB_K2U_LAUNCH
 }
 
 // ---- windows of SWL < m <= 1024 bytes: one thread per queued window, chunk by chunk (dp_unicode_multi_chunk) -------------------------------
 // The function keeps a chunk's row, previous row, pending and up masks, prefix counts and bonuses in registers (~ 300 live values at 64
 // lanes): one wave per SIMD, the accumulation registers as spill space - still 64 haystacks per wavefront where the generic kernel takes one.
-template <int SWL, bool TF, typename ET>
-__global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict__ bytes, const ET* __restrict__ ends, u64 first, u32 index_offset, const u32* __restrict__ list,
+template <int SWL, bool TF>
+__global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset, const u32* __restrict__ list,
                                                             const u32* __restrict__ n_list_ptr, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
                                                             u32* __restrict__ scratch, u32 only_from, u32* __restrict__ counters, u32* __restrict__ back_end, u32 fwd_cap) {
     // STRAGGLERS: a window of ten chunks keeps its thread - and the kernel - for ten times the latency of a chunk (Arabic-shaped list, All
@@ -295,9 +291,8 @@ __global__ __launch_bounds__(128) void k2u_dp_unicode_multi(const u8* __restrict
 
 void fzb_launch_dp_unicode_multi(const CorpusDev& c, u64 first, u32 index_offset, const u32* list, const u32* n_list_ptr, const NeedleDev& nd, int sw_lanes,
                                  fzb_match_rec* out, u32 capacity, u32* scratch, int grid, hipStream_t st, u32 only_from, int tform, u32* counters, u32* back_end, u32 fwd_cap) {
-#define FZB_K2UM(SWL, TF, ET) hipLaunchKernelGGL((k2u_dp_unicode_multi<SWL, TF, ET>), dim3(grid), dim3(128), 0, st, c.bytes, (const ET*)c.ends, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, only_from, counters, back_end, fwd_cap)
-#define FZB_K2UM_TF(SWL, ET) do { if (tform) FZB_K2UM(SWL, true, ET); else FZB_K2UM(SWL, false, ET); } while (0)
-#define FZB_K2UM_ET(SWL) do { if (c.ends_u64) FZB_K2UM_TF(SWL, u64); else FZB_K2UM_TF(SWL, u32); } while (0)
+#define FZB_K2UM(SWL, TF) hipLaunchKernelGGL((k2u_dp_unicode_multi<SWL, TF>), dim3(grid), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, list, n_list_ptr, nd, out, capacity, scratch, only_from, counters, back_end, fwd_cap)
+#define FZB_K2UM_ET(SWL) do { if (tform) FZB_K2UM(SWL, true); else FZB_K2UM(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2UM_ET(64); break;
         case 32: FZB_K2UM_ET(32); break;

@@ -17,7 +17,7 @@ def avg(d, counter, kernel):
 fetch, nf = avg(sys.argv[1], "FETCH_SIZE", "k1_dfa")
 write, nw = avg(sys.argv[2], "WRITE_SIZE", "k1_dfa")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 5 --warmup 2 --fast, MI355X",
-       "kernel": "k1_dfa<unsigned int>", "FETCH_SIZE_KB_avg_per_dispatch_raw": fetch, "WRITE_SIZE_KB_avg_per_dispatch_raw": write, "dispatches": [nf, nw],
+       "kernel": "k1_dfa", "FETCH_SIZE_KB_avg_per_dispatch_raw": fetch, "WRITE_SIZE_KB_avg_per_dispatch_raw": write, "dispatches": [nf, nw],
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced 16 B/lane reads -> doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE taken as is",
        "k1_filter_hbm_bytes_per_launch": (fetch * 2 + write) * 1024 if fetch is not None and write is not None else None,
        "algorithmic_bytes_per_launch": 10_000_000 * 32 + 10_000_000 / 8,
