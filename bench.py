@@ -347,7 +347,7 @@ def other_configs(F, synth, dev, steps):
         cols[label] = {"ms_per_step": res[key]["ms_per_step"], "matches": res[key]["matches"], "reference_published_ms": {"sequential": ref[0], "parallel_x8": ref[1]}}
         del res[key]
     res[name]["other_columns"] = cols
-    # repositories of ordinary size: the same shape at 100 k / 300 k items (their few thousand multi-chunk windows take sixteen lanes each: dp_coop.h)
+    # repositories of ordinary size: the same shape at 100 k / 300 k items (their few thousand multi-chunk windows take four lanes each: dp_quad.h)
     small = {}
     for nsmall in (100_000, 300_000):
         dps, eps = synth.paths_corpus(b"linux", nsmall, device=dev)

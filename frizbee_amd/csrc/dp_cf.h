@@ -61,9 +61,20 @@ struct CfRow {  // wave-uniform per-row constants (scalar registers)
     u32 orv, cmpv, cv;
     bool ci;
 };
-__device__ __forceinline__ CfRow cf_row_consts(const NeedleDev& nd, u32 r) {
-    // needle bytes through aligned dword reads of the by-value argument: wave-uniform, so they are scalar loads
-    const u32 c = (((const u32*)nd.c)[r >> 2] >> (8 * (r & 3))) & 0xFF, f = (((const u32*)nd.f)[r >> 2] >> (8 * (r & 3))) & 0xFF;
+// (a long needle's rows: NeedleLongRows below - k2d_dp_long stages them in LDS, two bytes per row)
+struct NeedleLongRows : NeedleLongDev {
+    const u16* cf;  // [rows] byte as compared | case flip << 8, in the workgroup's LDS
+};
+template <typename ND>
+__device__ __forceinline__ CfRow cf_row_consts(const ND& nd, u32 r) {
+    u32 c, f;
+    if constexpr (ND::kLong) {
+        const u32 cf = nd.cf[r];
+        c = cf & 0xFF, f = cf >> 8;
+    } else {
+        // needle bytes through aligned dword reads of the by-value argument: wave-uniform, so they are scalar loads
+        c = (((const u32*)nd.c)[r >> 2] >> (8 * (r & 3))) & 0xFF, f = (((const u32*)nd.f)[r >> 2] >> (8 * (r & 3))) & 0xFF;
+    }
     CfRow k;
     k.ci = c != f;  // case-folded ASCII letter: (h | 0x20) == (c | 0x20) <=> h in {c, flip(c)}
     k.orv = k.ci ? 0x00200020u : 0u;
@@ -248,8 +259,8 @@ struct CfTables {
     u8 cls2[256];
     u16 bon[16];
 };
-template <bool UPPER>
-__device__ __forceinline__ void cf_build_tables(const NeedleDev& nd, CfTables& t) {
+template <bool UPPER, typename ND = NeedleDev>
+__device__ __forceinline__ void cf_build_tables(const ND& nd, CfTables& t) {
     for (int b = threadIdx.x; b < 256; b += blockDim.x) {
         const bool lower = b >= 'a' && b <= 'z', upper = b >= 'A' && b <= 'Z', digit = b >= '0' && b <= '9';
         const bool delim = !(lower || upper || digit || b > 127);

@@ -10,7 +10,8 @@
 //     after every row's scan as in the first form;
 //   * row 0 needs no special case (T(-1, L) = (L + SWL) * e is the zero row);
 //   * the LAST row of the LAST chunk is not propagated (only its maximum is read; dp_cf.h, 2.).
-// Preconditions (host, LaunchCfg::cfm_ok): 2 * gap_extend <= mismatch_penalty, biased values (up to 192 lanes + 63 rows of e) stay below 0x7C00 (p_max3_s).
+// Preconditions (host, LaunchCfg::cfm_ok): 2 * gap_extend <= mismatch_penalty, biased values (up to 192 lanes + the needle's rows of e) stay below 0x7C00 (p_max3_s).
+// ND = NeedleLongRows: the same rows for a needle of any length (what dp_quad.h runs for k2d_dp_long_quad; here for tests/kernel_host).
 // tests/test_kernel_math_host.py fuzzes it against the oracle and against the first form.
 #pragma once
 #include "dp_cf.h"
@@ -25,8 +26,8 @@ constexpr bool cfm_entry_lane(int k, int s, int P) { return s == 1 ? k == P - 1 
 // dp_cf.h's closed form (3.) with two changes: the bias carries the chunk offset SWL (A = T (-) (target lane + SWL) * e), and for 2R < SWL/2
 // the adjacent half-chunk's lanes [2R - SWL/2, 0) enter the padding directly with the widest step (they are entries like any other: the
 // column they would walk down instead ends in the previous chunk's last row, which the maximum covers).  Needs a needle without NUL (pad_ok).
-template <int SWL, bool UPPER, int R>
-__device__ __forceinline__ void cfm_chunk(const NeedleDev& nd, const u8* __restrict__ th, u32 m, u32 ch, bool last_chunk_rt, bool include_prefix, const CfTables& tab,
+template <int SWL, bool UPPER, int R, typename ND = NeedleDev>
+__device__ __forceinline__ void cfm_chunk(const ND& nd, const u8* __restrict__ th, u32 m, u32 ch, bool last_chunk_rt, bool include_prefix, const CfTables& tab,
                                           u32* __restrict__ scratch, u32 sstride, u32 sidx, u32 rpitch, u32& mx, u32& cprev) {
     constexpr int NW = SWL / 2;
     constexpr int HT = NW / 2;  // parked dwords per vector (top half)
@@ -228,8 +229,8 @@ __device__ __forceinline__ u32 dp_multi_chunk_tc(const NeedleDev& nd, const u8* 
 }
 
 // RL = computed dwords of the LAST chunk (SWL/2: all of it; less: the caller guarantees m - (nchunks - 1) * SWL <= 2 * RL and a needle without NUL)
-template <int SWL, bool UPPER, int RL = SWL / 2>
-__device__ __forceinline__ u32 dp_multi_chunk_t(const NeedleDev& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const CfTables& tab,
+template <int SWL, bool UPPER, int RL = SWL / 2, typename ND = NeedleDev>
+__device__ __forceinline__ u32 dp_multi_chunk_t(const ND& nd, const u8* __restrict__ th, u32 m, bool include_prefix, const CfTables& tab,
                                                 u32* __restrict__ scratch, u32 sstride, u32 sidx, u32 rpitch) {
     constexpr int NW = SWL / 2;
     const u32 nchunks = (m + SWL - 1) / SWL;
@@ -237,7 +238,7 @@ __device__ __forceinline__ u32 dp_multi_chunk_t(const NeedleDev& nd, const u8* _
     u32 mx = 0;
     u32 cprev = 0;  // class (x 2) of the previous chunk's last lane; lane -1 of chunk 0: no delimiter, no lowercase letter
 #pragma unroll 1
-    for (u32 ch = 0; ch < nfull; ch++) cfm_chunk<SWL, UPPER, NW>(nd, th, m, ch, ch + 1 == nchunks, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
-    if (RL < NW) cfm_chunk<SWL, UPPER, RL>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
+    for (u32 ch = 0; ch < nfull; ch++) cfm_chunk<SWL, UPPER, NW, ND>(nd, th, m, ch, ch + 1 == nchunks, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
+    if (RL < NW) cfm_chunk<SWL, UPPER, RL, ND>(nd, th, m, nchunks - 1, true, include_prefix, tab, scratch, sstride, sidx, rpitch, mx, cprev);
     return max(mx & 0xFFFF, mx >> 16);
 }

@@ -246,10 +246,14 @@ size_t fzb_trace_scratch_words_long(const NeedleLongDev& nd, int grid);
 void fzb_launch_generic_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd,
                              int sw_lanes, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* counters, u16* adj, const u32* cells, u32* pos, u32* npos, u32 stride, int grid,
                              hipStream_t st, const u32* list = nullptr);
+#define FZB_LONG_LDS_ROWS 1024  // rows of a long needle k2d_dp_long_quad stages in LDS (longer needles take k2d_dp_long)
 // long needles, ASCII: one thread per window of up to 1024 bytes (kernels_dp.hip, k2d_dp_long); wider windows are queued for the launch above
 size_t fzb_dp_long_scratch_words_per_thread(const NeedleLongDev& nd, int sw_lanes);
 void fzb_launch_dp_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd, int sw_lanes,
                         int bias_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* scratch, u32* queue, u32* counters, int grid, hipStream_t st);
+size_t fzb_dp_long_quad_words_per_block(const NeedleLongDev& nd, int sw_lanes);
+void fzb_launch_dp_long_quad(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd, int sw_lanes,
+                             int upper, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* scratch, u32* queue, u32* counters, int grid, hipStream_t st);
 void fzb_launch_literal_filter_long(const CorpusDev& c, u64 first, u32 count, const u32* items, const u32* n_items_ptr, const NeedleLongDev& nd, int mode, u64* bitmap,
                                     u32* tile_counts, int grid, hipStream_t st);
 void fzb_launch_literal_score_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* n_items_ptr, const NeedleLongDev& nd, int mode, fzb_match_rec* out,

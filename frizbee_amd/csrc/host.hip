@@ -282,6 +282,13 @@ static void build_long_needle(fzb_matcher* m, const uint8_t* needle_utf8, size_t
     lc.pad_ok = lc.cf_ok = lc.cfm_ok = 0;
     // (the biased gap scan of dp_multi_chunk, as for short needles below: the largest biased value stays inside 16 bits)
     lc.bias_ok = max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + 130 * (size_t)sc.gap_extend_penalty + 64 <= 0xFFFF;
+    // dp_cfm.h's arithmetic for the four-lanes-per-window scorer (k2d_dp_long_quad; set_scorer_forms' condition with this needle's rows in the
+    // bias: lanes up to 3/2 chunks + rows + 1 of gap_extend)
+    lc.cfm_ok = !m->unicode && m->rows <= FZB_LONG_LDS_ROWS && 2 * (u32)sc.gap_extend_penalty <= (u32)sc.mismatch_penalty &&
+                max_matrix_score(sc, (size_t)m->rows) + (size_t)sc.mismatch_penalty + (137 + (size_t)m->rows) * (size_t)sc.gap_extend_penalty + 64 < 0x7C00;
+    m->long_upper = false;
+    if (!m->unicode)
+        for (size_t i = 0; i < nb; i++) m->long_upper = m->long_upper || (blob[m->long_off_c + i] >= 'A' && blob[m->long_off_c + i] <= 'Z');
     m->table.assign(256, 0);
     // 0 typos, ASCII: accept <=> the needle is a case-folded ordered subsequence (src/prefilter/algo/ascii.rs:6-54; lane-width independent),
     // and that automaton has rows + 1 states whatever the needle's length: up to 200 rows its table fits a workgroup's LDS (58 KB) and the
@@ -1192,7 +1199,11 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     const size_t dfit = std::min<size_t>((size_t)cus * 8, budget / std::max<size_t>(dpl_words * 4 * 128, 1));  // 128-thread workgroups the slab has room for
     const int dgrid = (int)std::max<size_t>(1, std::min<size_t>(dfit, (count + 127) / 128));
     const bool thread_per_window = !trace && !m->ndl.unicode && dfit >= (size_t)std::max(1, cus / 2);
-    const size_t dpl_bytes = thread_per_window ? dpl_words * 4 * 128 * (size_t)dgrid : 0;
+    // four lanes per window (dp_quad.h) when dp_cfm.h's preconditions hold: a seventh of the slab per window, four times the wavefronts
+    const size_t qwords = fzb_dp_long_quad_words_per_block(m->ndl, m->lc.sw_lanes);
+    const bool quad = thread_per_window && m->lc.cfm_ok && !fzb_knobs().no_dp_cfm && qwords != 0;
+    const int qgrid = quad ? (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)cus * 16, budget / (qwords * 4)), (count + 31) / 32)) : 0;
+    const size_t dpl_bytes = quad ? qwords * 4 * (size_t)qgrid : thread_per_window ? dpl_words * 4 * 128 * (size_t)dgrid : 0;
     const bool greedy_possible = !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN);
     if (thread_per_window && !greedy_possible) ggrid = 1;  // (no launch of the wave-per-haystack kernel: its slab is not needed)
     const size_t win_bytes = prefilter ? fzb_window_long_scratch_bytes(m->ndl, wgrid) : 0;
@@ -1234,6 +1245,10 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     }
     if (pev) HIPCHK(hipEventRecord(pev[4], st));
     if (thread_per_window) {
+        if (quad)
+            fzb_launch_dp_long_quad(cd, first, index_offset, items, win, wmode, n_items_ptr, m->ndl, m->lc.sw_lanes, m->long_upper ? 1 : 0, (fzb_match_rec*)dev_out, cap32, dev_count,
+                                    (u32*)m->long_scratch, w.overflow, cnt_c, qgrid, st);
+        else
         fzb_launch_dp_long(cd, first, index_offset, items, win, wmode, n_items_ptr, m->ndl, m->lc.sw_lanes, m->lc.bias_ok, (fzb_match_rec*)dev_out, cap32, dev_count, (u32*)m->long_scratch,
                            w.overflow, cnt_c, dgrid, st);
         // (the queue's entries are read after the slab's last use: the two kernels are one behind the other on the stream and share the scratch)

@@ -82,6 +82,7 @@ struct fzb_matcher {
     // use), and the global scratch of its kernels (N-typo path state, per-row previous-chunk vectors, traced cells)
     bool long_needle = false;
     bool long_dfa = false;  // a long ASCII needle of up to 200 rows, 0 typos: `dfa` holds its ordered-subsequence automaton and the streaming filter is the first stage
+    bool long_upper = false;  // a long ASCII needle with an uppercase letter among its rows (k2d_dp_long's form)
     NeedleLongDev ndl{};
     std::vector<u8> long_blob_host;
     size_t long_off_c = 0, long_off_f = 0, long_off_uc = 0, long_off_uf = 0, long_off_ulen = 0;

@@ -15,7 +15,7 @@
 // plain shift; since every row value is >= 0 the saturating subtract of the reference is preserved exactly
 // (see DESIGN.md).  BIAS=false keeps the literal 3-op form for scorings where the bias could overflow u16.
 #include "dp_cfm.h"
-#include "dp_coop.h"
+#include "dp_quad.h"
 #include <cstdlib>
 
 // MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h).  (dp_cf.h's form of this per-wave kernel - rounds 2-5 -
@@ -572,14 +572,97 @@ __global__ __launch_bounds__(128) void k2d_dp_long(const u8* __restrict__ bytes,
     }
 }
 
+// The same windows with FOUR lanes each (dp_quad.h; LaunchCfg::cfm_ok, 64- or 32-lane score chunks): sixteen windows per wavefront, the needle's rows
+// staged in LDS, the parked rows in the global slab (a block per window slot of the grid), requested one row ahead.
+template <int SWL, bool UPPER>
+__global__ __launch_bounds__(128) void k2d_dp_long_quad(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset, const u32* __restrict__ items,
+                                                        const u32* __restrict__ win, int wmode, const u32* __restrict__ n_items_ptr, const NeedleLongDev nd,
+                                                        fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ scratch, u32* __restrict__ queue,
+                                                        u32* __restrict__ counters) {
+    __shared__ CfTables tab;
+    __shared__ u16 s_cf[FZB_LONG_LDS_ROWS];
+    NeedleLongRows nr;
+    static_cast<NeedleLongDev&>(nr) = nd;
+    nr.cf = s_cf;
+    cf_build_tables<UPPER, NeedleLongDev>(nd, tab);
+    for (u32 r = threadIdx.x; r < (u32)nd.rows; r += blockDim.x) s_cf[r] = (u16)((u32)nd.c[r] | ((u32)nd.f[r] << 8));
+    __syncthreads();
+    const u32 n = *n_items_ptr;
+    if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = n < capacity ? n : capacity; dev_count[1] = n; }
+    const u32 wpb = blockDim.x / 4, wslot = (threadIdx.x >> 6) * 16 + ((threadIdx.x >> 4) & 3u) * 4 + (threadIdx.x & 3u);
+    const u32 nslots = gridDim.x * wpb, slot = blockIdx.x * wpb + wslot;
+    const bool lane0 = ((threadIdx.x >> 2) & 3u) == 0;
+    for (u32 q = slot; q < n; q += nslots) {
+        if (q >= capacity) continue;
+        const u32 li = items ? items[q] : q;
+        u64 s;
+        u32 L;
+        haystack_span(ends, first + li, s, L);
+        const u8* hay = bytes + s;
+        u32 ws = 0, we = L;
+        if (wmode == 1) {  // the lane-free 0-typo window (as k2d_dp_long; every lane of the quad walks the haystack - the same cache lines)
+            const u32 c0 = (u32)nd.c[0] * 0x01010101u, f0 = (u32)nd.f[0] * 0x01010101u;
+            const u32 cl = (u32)nd.c[nd.rows - 1] * 0x01010101u, fl = (u32)nd.f[nd.rows - 1] * 0x01010101u;
+            ws = 0xFFFFFFFFu;
+            we = 0;
+            for (u32 p = 0; p < L; p += 4) {
+                const u32 w = *(const u32*)(hay + p);
+                const u32 vm = L - p >= 4 ? 0xFu : ((1u << (L - p)) - 1u);
+                const u32 mf = (zero_bytes4_dp(w ^ c0) | zero_bytes4_dp(w ^ f0)) & vm;
+                const u32 ml = (zero_bytes4_dp(w ^ cl) | zero_bytes4_dp(w ^ fl)) & vm;
+                if (mf && ws == 0xFFFFFFFFu) ws = p + (u32)__builtin_ctz(mf);
+                if (ml) we = p + 32u - (u32)__builtin_clz(ml);
+            }
+            if (ws == 0xFFFFFFFFu) ws = 0;
+        } else if (wmode != 2) { ws = win[2 * q]; we = win[2 * q + 1]; }
+        const u32 sp = ws ? ws - 1 : 0;
+        const bool include_exact = sp == 0 && we == L;
+        const u32 m = we - sp;
+        if (m > FZB_MAX_HAYSTACK_LEN) {  // the greedy fallback: the wave-per-haystack kernel's
+            if (lane0) {
+                u32* qe = queue + 4 * (size_t)atomicAdd(&counters[3], 1u);
+                qe[0] = q; qe[1] = ws; qe[2] = we; qe[3] = li;
+            }
+            continue;
+        }
+        constexpr int MAXC = SWL == 32 ? 8 : 4;  // windows of up to 256 bytes: row by row, in registers
+        u32 score;
+        if (m <= (u32)MAXC * SWL) score = dp_quad_rows<SWL, UPPER, MAXC>(nr, hay + sp, m, sp == 0, tab);
+        else score = dp_quad_window<SWL, UPPER, true>(nr, hay + sp, m, sp == 0, tab, scratch + slot, nslots);
+        if (lane0) {
+            bool exact = include_exact && m == (u32)nd.nbytes;
+            if (exact)
+                for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+            if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+            fzb_match_rec rec;
+            rec.index = index_offset + li;
+            rec.score = (u16)score;
+            rec.exact = exact ? 1 : 0;
+            rec.valid = 0;
+            out[q] = rec;
+        }
+    }
+}
+
+// dwords of the slab per 128-thread WORKGROUP of k2d_dp_long_quad ([row][QuadPark::WORDS][32 windows]); 0 = that lane width has no quad form
+size_t fzb_dp_long_quad_words_per_block(const NeedleLongDev& nd, int sw_lanes) {
+    return (sw_lanes == 64 || sw_lanes == 32) ? (size_t)nd.rows * (size_t)(sw_lanes / 4 + 1) * 32 : 0;
+}
+void fzb_launch_dp_long_quad(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd, int sw_lanes,
+                             int upper, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* scratch, u32* queue, u32* counters, int grid, hipStream_t st) {
+#define FZB_K2Q(SWL, U) hipLaunchKernelGGL((k2d_dp_long_quad<SWL, U>), dim3(grid), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
+    if (sw_lanes == 64) { if (upper) FZB_K2Q(64, true); else FZB_K2Q(64, false); }
+    else { if (upper) FZB_K2Q(32, true); else FZB_K2Q(32, false); }
+#undef FZB_K2Q
+}
+
 // dwords of the parked-row slab per THREAD of k2d_dp_long (dp_multi_chunk's layout: [row][SWL / 2 dwords][thread])
 size_t fzb_dp_long_scratch_words_per_thread(const NeedleLongDev& nd, int sw_lanes) { return (size_t)nd.rows * (size_t)(sw_lanes / 2); }
 
 void fzb_launch_dp_long(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd, int sw_lanes,
                         int bias_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* scratch, u32* queue, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2L(SWL, B, ET) hipLaunchKernelGGL((k2d_dp_long<SWL, B>), dim3(grid), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
-#define FZB_K2L_ET(SWL, B) FZB_K2L(SWL, B, u32)
-#define FZB_K2L_B(SWL) do { if (bias_ok) FZB_K2L_ET(SWL, true); else FZB_K2L_ET(SWL, false); } while (0)
+#define FZB_K2L(SWL, B) hipLaunchKernelGGL((k2d_dp_long<SWL, B>), dim3(grid), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
+#define FZB_K2L_B(SWL) do { if (bias_ok) FZB_K2L(SWL, true); else FZB_K2L(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2L_B(64); break;
         case 32: FZB_K2L_B(32); break;
@@ -587,7 +670,6 @@ void fzb_launch_dp_long(const CorpusDev& c, u64 first, u32 index_offset, const u
         default: FZB_K2L_B(8); break;
     }
 #undef FZB_K2L_B
-#undef FZB_K2L_ET
 #undef FZB_K2L
 }
 
@@ -676,18 +758,20 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
     }
 }
 
-// The same four lists through the sub-wave cooperative scorer (dp_coop.h): sixteen lanes per window, four windows per wavefront, the tail
-// classes ignored (every chunk is computed in full - this form is taken when the queue is SHORT and one wave's instruction latency is the kernel).
-template <int SWL>
-__device__ __forceinline__ void dp_coop_tc_body(u32 vblock, u32 vgrid, u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta,
+// The same four lists with FOUR lanes per window (dp_quad.h): sixteen windows per wavefront, dp_cfm.h's arithmetic, the parked rows in LDS
+// ([row][word][window of the workgroup]).
+template <int SWL, bool UPPER>
+__device__ __forceinline__ void dp_quad_tc_body(const CfTables& tab, u32 vblock, u32 vgrid, u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta,
                                                 const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts, const NeedleDev& nd,
                                                 fzb_match_rec* __restrict__ out, u32 capacity) {
     extern __shared__ __attribute__((aligned(16))) u32 s_park[];
     if constexpr (SWL == 64 || SWL == 32) {
         const u32 e3 = __builtin_amdgcn_readfirstlane(counts[3]), e2 = e3 + __builtin_amdgcn_readfirstlane(counts[2]), e1 = e2 + __builtin_amdgcn_readfirstlane(counts[1]),
                   e0 = e1 + __builtin_amdgcn_readfirstlane(counts[0]);
-        const u32 ngroups = vgrid * blockDim.x / 16, gid = (vblock * blockDim.x + threadIdx.x) / 16;
-        u32* const park = s_park + threadIdx.x;
+        // window of the wave: DPP row x its four windows (row-lanes w, w + 4, w + 8, w + 12)
+        const u32 wpb = blockDim.x / 4, wslot = (threadIdx.x >> 6) * 16 + ((threadIdx.x >> 4) & 3u) * 4 + (threadIdx.x & 3u);
+        const u32 ngroups = vgrid * wpb, gid = vblock * wpb + wslot;
+        u32* const park = s_park + wslot;
         for (u32 q = gid; q < e0; q += ngroups) {
             const u32 cls = q < e3 ? 3u : q < e2 ? 2u : q < e1 ? 1u : 0u;
             const u32 base = cls == 3 ? 0u : cls == 2 ? e3 : cls == 1 ? e2 : e1;
@@ -699,8 +783,11 @@ __device__ __forceinline__ void dp_coop_tc_body(u32 vblock, u32 vgrid, u32 index
             const u32 sp = w.x ? w.x - 1 : 0;
             const bool include_exact = (w.y >> 31) != 0;
             const u32 m = (w.y & 0x7FFFFFFFu) - sp;
-            u32 score = dp_coop_window<SWL>(nd, hay + sp, m, sp == 0, park, blockDim.x);
-            if ((threadIdx.x & 15u) == 0) {
+            constexpr int MAXC = SWL == 32 ? 4 : 3;  // windows of up to 128 / 192 bytes: row by row, in registers
+            u32 score;
+            if (m <= (u32)MAXC * SWL) score = dp_quad_rows<SWL, UPPER, MAXC>(nd, hay + sp, m, sp == 0, tab);
+            else score = dp_quad_window<SWL, UPPER, false>(nd, hay + sp, m, sp == 0, tab, park, 0u);
+            if (((threadIdx.x >> 2) & 3u) == 0) {
                 bool exact = include_exact && m == (u32)nd.nbytes;
                 if (exact)
                     for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
@@ -729,9 +816,9 @@ __global__ __launch_bounds__(128, 2) void k2_classes_all(u32 index_offset, const
     __syncthreads();
     u32 b = blockIdx.x;
     if (b < gm) {
-        // fewer multi-chunk windows than `coop_below` (0: the needle's parked rows do not fit, or another lane width): sixteen lanes per window
+        // fewer multi-chunk windows than `coop_below` (0: the needle's parked rows do not fit, or another lane width): four lanes per window
         const u32 total = __builtin_amdgcn_readfirstlane(counters[12] + counters[13] + counters[14] + counters[15]);
-        if (total < coop_below) dp_coop_tc_body<SWL>(b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity);
+        if (total < coop_below) dp_quad_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity);
         else dp_multi_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch, park_dw);
         return;
     }
@@ -759,17 +846,15 @@ void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, con
     bool upper = false;
     for (int r = 0; r < nd.rows; r++) upper = upper || (nd.c[r] >= 'A' && nd.c[r] <= 'Z');
     const u32 park_dw = fzb_park_lds_dwords(nd, sw_lanes);
-    // the cooperative form of the multi-chunk slice (dp_coop.h): 64- and 32-lane backends, needles whose per-thread parking area fits 48 KB per
-    // workgroup; taken ON THE DEVICE below `coop_below` queued windows.  A thread-per-window wave walks ~ 1 000 instructions per (row, chunk)
-    // whatever the queue's length - 44 us for a window of three chunks and five rows, even when the queue holds one wavefront's worth - while
-    // sixteen lanes per window make that chain ~ 200 instructions and four times as many wavefronts; but its rows are literal (no biased domain,
-    // no closed-form padding, every shift a v_mov_dpp or two), so the form pays only while the queue fits about two rounds of the slice's
-    // resident groups (8 per workgroup).  Measured (profiles/r06_coop.txt): paths-shaped lists of 100 k / 300 k items (1.9 k / 5.7 k windows)
-    // 56.8 -> 45.5 / 60.0 -> 48.8 us per step; 8.6 k windows 91.5 -> 81.8; 27 k windows (1.4 M items) 100.3 -> 104.0; 40 k: 139.7 -> 150.9.
-    // (As a kernel of its own on the second stream - eight waves per SIMD instead of this kernel's two - it LOST: the fork / join around it
-    // costs more than the residency returns: 100 k items 55.9 -> 64.9 us.)
-    const size_t coop_lds = (sw_lanes == 64 || sw_lanes == 32) ? (size_t)(nd.rows + 1) * (sw_lanes / 32 + 1) * 128 * 4 : 0;
-    const u32 coop_below = (coop_lds != 0 && coop_lds <= 48 * 1024 && fzb_knobs().coop_below != 0) ? (fzb_knobs().coop_below > 0 ? (u32)fzb_knobs().coop_below : (u32)gm * 16u) : 0u;
+    // four lanes per window for the multi-chunk slice (dp_quad.h): 64- and 32-lane backends; taken ON THE DEVICE below `coop_below` queued windows.
+    // A thread-per-window wave walks ~ 1 000 instructions per (row, chunk) whatever the queue's length - 44 us for a window of three chunks and
+    // five rows even when the queue holds one wavefront's worth; four lanes per window make that chain a quarter as long at the same total, so
+    // the form pays while the thread form would leave SIMDs with at most one wavefront.  Measured on 8..128-byte lists (windows = 2.1 % of the
+    // items; profiles/r06_quad.txt): 10.7 k windows 81.6 -> 61.9 us per step, 21 k 89.2 -> 69.9, 43 k 110.9 -> 104.0, 64 k 128.5 -> 139.5 (the
+    // thread form again); paths-shaped 1.4 M items (27 k windows) 99.8 -> 90.5.  Windows of up to 3 (4) chunks run row by row in registers; wider
+    // ones park their rows in LDS, which is what the 48 KB bound is for (a needle too long for it keeps the thread form for every window).
+    const size_t coop_lds = (sw_lanes == 64 || sw_lanes == 32) ? (size_t)nd.rows * (sw_lanes / 4 + 1) * (128 / 4) * 4 : 0;  // [row][QuadPark::WORDS][window of the workgroup]
+    const u32 coop_below = (coop_lds != 0 && coop_lds <= 48 * 1024 && fzb_knobs().coop_below != 0) ? (fzb_knobs().coop_below > 0 ? (u32)fzb_knobs().coop_below : (u32)gm * 48u) : 0u;
     const size_t dyn_lds = std::max((size_t)nd.rows * park_dw * 128 * 4, coop_below ? coop_lds : (size_t)0);
 #define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), dyn_lds, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc, park_dw, coop_below)
 #define FZB_K2A_U(SWL) do { if (upper) FZB_K2A(SWL, true); else FZB_K2A(SWL, false); } while (0)

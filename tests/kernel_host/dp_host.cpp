@@ -124,6 +124,26 @@ static int run_unicode_multi(const NeedleDev& nd, const u8* hay, u32 m, int incl
                 : (int)dp_unicode_multi_chunk_t<SWL, false>(nd, buf.data(), m, include_prefix != 0, cls, scratch, 1, 0);
 }
 
+// the same two forms for a LONG needle (NeedleLongDev: the rows behind pointers, any number of them - k2d_dp_long): form 5 = dp_multi_chunk, 6 = dp_multi_chunk_t
+template <int SWL>
+static int run_multi_long(const NeedleLongDev& nd, bool upper, const u8* hay, u32 m, int include_prefix, int form, const u8* cls) {
+    std::vector<u32> scratch((size_t)(nd.rows + 1) * (SWL / 2) + 64, 0xDEADBEEFu);
+    std::vector<u8> buf(m + 96, 0);
+    memcpy(buf.data(), hay, m);
+    if (form == 5) return (int)dp_multi_chunk<SWL, true, NeedleLongDev>(nd, buf.data(), m, include_prefix, cls, scratch.data(), 1, 0);
+    CfTables tab;
+    for (unsigned t = 0; t < 16; t++) { threadIdx.x = t; if (upper) cf_build_tables<true, NeedleLongDev>(nd, tab); else cf_build_tables<false, NeedleLongDev>(nd, tab); }
+    threadIdx.x = 0;
+    const u32 rp = (u32)(SWL / 2);
+    std::vector<u16> cf(nd.rows);  // what k2d_dp_long stages in LDS
+    for (int r = 0; r < nd.rows; r++) cf[r] = (u16)(nd.c[r] | (nd.f[r] << 8));
+    NeedleLongRows nr;
+    static_cast<NeedleLongDev&>(nr) = nd;
+    nr.cf = cf.data();
+    return upper ? (int)dp_multi_chunk_t<SWL, true, SWL / 2, NeedleLongRows>(nr, buf.data(), m, include_prefix, tab, scratch.data(), 1, 0, rp)
+                 : (int)dp_multi_chunk_t<SWL, false, SWL / 2, NeedleLongRows>(nr, buf.data(), m, include_prefix, tab, scratch.data(), 1, 0, rp);
+}
+
 extern "C" {
 // form: 0 = dp_single_chunk biased, 1 = literal (unbiased) scan, 2 = its padded-half form, 3 = dp_single_chunk_cf with `real` dwords,
 // 4 = dp_single_chunk_cf_tab (LDS-table set-up, swl/4 dwords).
@@ -256,6 +276,33 @@ int kh_dp_multi(const u8* needle, int n, int case_sensitive, int is_u8, const u1
         case 32: return run_multi<32>(nd, hay, (u32)m, include_prefix, form, cls);
         case 16: return run_multi<16>(nd, hay, (u32)m, include_prefix, form, cls);
         case 8: return run_multi<8>(nd, hay, (u32)m, include_prefix, form, cls);
+    }
+    return -1;
+}
+
+int kh_dp_multi_long(const u8* needle, int n, int case_sensitive, int is_u8, const u16* sc, const u8* hay, int m, int include_prefix, int swl, int form) {
+    if (n < 1 || m < 1 || m > 1024) return -1;
+    std::vector<u8> c(n + 4), f(n + 4);
+    bool upper = false;
+    for (int i = 0; i < n; i++) {
+        c[i] = needle[i];
+        f[i] = case_sensitive ? c[i] : (c[i] >= 'a' && c[i] <= 'z') ? (u8)(c[i] - 32) : (c[i] >= 'A' && c[i] <= 'Z') ? (u8)(c[i] + 32) : c[i];
+        upper = upper || (c[i] >= 'A' && c[i] <= 'Z');
+    }
+    NeedleLongDev nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.rows = n; nd.nbytes = n; nd.lane_mask = is_u8 ? 0xFF : 0xFFFF;
+    nd.match_plus_mismatch = sadd16(sc[0], sc[1]); nd.mismatch = sc[1]; nd.gex = sc[3]; nd.gopm = ssub16(sc[2], sc[3]);
+    nd.prefix = sc[4]; nd.capitalization = sc[5]; nd.matching_case = sc[6]; nd.exact_bonus = sc[7]; nd.delimiter = sc[8];
+    nd.match_score = sc[0]; nd.gap_open = sc[2];
+    nd.raw = c.data(); nd.c = c.data(); nd.f = f.data();
+    static u8 cls[256];
+    build_cls_table(cls);
+    switch (swl) {
+        case 64: return run_multi_long<64>(nd, upper, hay, (u32)m, include_prefix, form, cls);
+        case 32: return run_multi_long<32>(nd, upper, hay, (u32)m, include_prefix, form, cls);
+        case 16: return run_multi_long<16>(nd, upper, hay, (u32)m, include_prefix, form, cls);
+        case 8: return run_multi_long<8>(nd, upper, hay, (u32)m, include_prefix, form, cls);
     }
     return -1;
 }

@@ -40,6 +40,7 @@ def lib():
         _lib.kh_unicode_window.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_unicode_regs.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_multi.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        _lib.kh_dp_multi_long.argtypes = _lib.kh_dp_multi.argtypes
         _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
@@ -98,6 +99,12 @@ def dp_multi(needle, hay, scoring, case_sensitive=False, include_prefix=True, sw
     """score of a window wider than one chunk (swl < len(hay) <= 1024): form 5 = first form (dp_body.h), 6 = dp_cfm.h"""
     sc = (C.c_uint16 * 9)(*scoring)
     return lib().kh_dp_multi(needle, len(needle), int(case_sensitive), int(is_u8), sc, hay, len(hay), int(include_prefix), swl, form)
+
+
+def dp_multi_long(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=32, form=6, is_u8=False):
+    """score of a window of 1..1024 bytes under a LONG needle (any number of rows; NeedleLongDev): form 5 = first form, 6 = dp_cfm.h"""
+    sc = (C.c_uint16 * 9)(*scoring)
+    return lib().kh_dp_multi_long(needle, len(needle), int(case_sensitive), int(is_u8), sc, hay, len(hay), int(include_prefix), swl, form)
 
 
 def window_typos(needle, hay, max_typos, case_sensitive=False):

@@ -58,7 +58,7 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_PARK_LDS_KB": "0"}, [("ragged", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=1))]),                 # parked rows in the global slab
     ({"FZB_PARK_LDS_KB": "0", "FZB_NO_DP_CFM": "1"}, [("ragged", "deadbeef", dict())]),
     ({"FZB_NO_CDFA": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1))]),                       # the burst filter over the byte automaton
-    ({"FZB_COOP_BELOW": "100000000"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("ragged", "DeadBeef", dict())]),  # multi-chunk windows: sixteen lanes per window (the default only below 16 384 queued)
+    ({"FZB_COOP_BELOW": "100000000"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("ragged", "DeadBeef", dict())]),  # multi-chunk windows: four lanes per window (the default below 49 152 queued)
     ({"FZB_COOP_BELOW": "0"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict())]),                                # ... never
     ({"FZB_DEBUG_SYNC": "1"}, [("short", "deadbe", dict()), ("ragged", "deadbeef", dict()), ("uniwide", "éa", dict(max_typos=None))]),
 ]

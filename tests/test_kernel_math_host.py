@@ -199,6 +199,42 @@ def test_multi_chunk_windows_both_forms_match_the_oracle(swl):
             assert got == want, (needle, hay, sc, cs, ip, swl, form, got, want)
 
 
+@pytest.mark.parametrize("swl", [64, 32, 16])
+def test_long_needle_windows_both_forms_match_the_oracle(swl):
+    """k2d_dp_long's two bodies (dp_multi_chunk and, round 6, dp_cfm.h's rows) with the needle's rows read through NeedleLongDev's pointers:
+    needles of 64..230 bytes, windows of one to many chunks (a single-chunk window is a one-chunk walk there), default and random scorings
+    inside LaunchCfg::cfm_ok, both score classes"""
+    rng = random.Random(900 + swl)
+    checked = 0
+    for it in range(160):
+        alpha = rng.choice([b"ab", b"abcA_", b"abcdefABCDEF_-/ 019", bytes(range(33, 127))])
+        n = rng.choice([64, 65, 80, 100, 127, 128, 129, 200, 230]) if it % 3 else rng.randint(64, 230)
+        needle = _rnd(rng, n, alpha)
+        cs = rng.random() < 0.3
+        sc = DEF
+        if rng.random() < 0.4:
+            while True:
+                sc = [rng.randint(0, 40), rng.randint(0, 20), rng.randint(0, 20), rng.randint(0, 6), rng.randint(0, 30), rng.randint(0, 12), rng.randint(0, 12),
+                      rng.randint(0, 20), rng.randint(0, 12)]
+                worst = n * (sc[0] + sc[4] + sc[5] + sc[6] + sc[8]) + sc[1] + (137 + n) * sc[3] + 64
+                if 2 * sc[3] <= sc[1] and worst < 0x7C00:  # build_long_needle's cfm_ok (a bound on max_matrix_score is enough here)
+                    break
+        m = rng.choice([1, swl - 1, swl, swl + 1, 2 * swl, 3 * swl + 5]) if it % 8 == 0 else rng.randint(1, min(1024, swl * rng.choice([1, 2, 3, 5, 9])))
+        hay = _rnd(rng, m, alpha)
+        if rng.random() < 0.6:  # a good part of the needle, in order
+            k = min(n, m)
+            for q, c in zip(sorted(rng.sample(range(m), k)), needle[rng.randint(0, n - k):][:k]):
+                hay = hay[:q] + bytes([c]) + hay[q + 1:]
+        ip = rng.random() < 0.5
+        u8 = _fits(n, sc)
+        want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, lanes=swl, is_u8=u8)
+        for form in (5, 6):
+            got = K.dp_multi_long(needle, hay, sc, cs, ip, swl, form, u8)
+            assert got == want, (needle, hay, sc, cs, ip, swl, form, got, want)
+        checked += 1
+    assert checked == 160
+
+
 @pytest.mark.parametrize("swl", [64, 32, 16, 8])
 def test_multi_chunk_last_chunk_padding_in_closed_form(swl):
     """dp_cfm.h with the last chunk's NUL lanes not computed (forms 7 / 8: the narrowest class of computed lanes that holds the window's tail,

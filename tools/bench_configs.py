@@ -88,7 +88,7 @@ if "E2E" in which:
                           haystacks_per_s_query=n / min(ts))), flush=True)
     del cp
 if "C4" in which:
-    n4 = 12_500_000 if "C4small" not in which else 2_000_000
+    n4 = int(os.environ.get("FZB_N4", 12_500_000 if "C4small" not in which else 2_000_000))
     data, ends = synth.ragged_corpus(b"deadbeef", n4, device=dev)
     cp = F.Corpus(packed=(data, ends))
     run("C4 shard ragged 8..128 typos0", "deadbeef", F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, n4)
@@ -163,4 +163,18 @@ if "ARABIC" in which or "ARABICDEF" in which or "ARABICALL" in which:
         if "ARABICDEF" in which and mt != 0: continue  # (profiling the default column alone)
         if "ARABICALL" in which and mt is not None: continue
         run(f"arabic-shaped 285k {label}", "إن", F.Config(max_typos=mt, pf_lanes=64, sw_lanes=64), cp, int(len(ends)), steps=5)
+    del cp
+if "LONG" in which:
+    # bench.py's long-needle row: 80 bytes vs 1 M haystacks of 100..200 bytes, 5 % contain it (streaming DFA, then one thread per window)
+    nl = 1_000_000
+    long_needle = bytes((b"abcdefghijklmnopqrstuvwxyz0123456789_-" * 3)[:80])
+    gl = torch.Generator(device=dev); gl.manual_seed(99)
+    lens_l = torch.randint(100, 201, (nl,), generator=gl, device=dev)
+    rows_l = synth.make_rows(long_needle, nl, 200, lengths=lens_l, seed=4242, device=dev, chunk=1 << 18)
+    mask_l = torch.arange(200, device=dev)[None, :] < lens_l[:, None]
+    dl, el = rows_l[mask_l].cpu().numpy(), np.cumsum(lens_l.cpu().numpy().astype(np.uint64), dtype=np.uint64)
+    del rows_l, mask_l
+    cp = F.Corpus(packed=(dl, el))
+    run("long needle 80 B vs 1M x 100..200 B typos0", long_needle.decode(), F.Config(max_typos=0, pf_lanes=64, sw_lanes=32), cp, nl, steps=5)
+    run("long needle 80 B, 64-lane score chunks asked for", long_needle.decode(), F.Config(max_typos=0, pf_lanes=64, sw_lanes=64), cp, nl, steps=5)
     del cp
