@@ -759,11 +759,13 @@ __device__ __forceinline__ void dp_multi_tc_body(const CfTables& tab, u32 vblock
 }
 
 // The same four lists with FOUR lanes per window (dp_quad.h): sixteen windows per wavefront, dp_cfm.h's arithmetic, the parked rows in LDS
-// ([row][word][window of the workgroup]).
+// ([row][word][window of the workgroup]).  `singles` (counters[8..10], or null): the three single-chunk lists behind them, widest class first - on
+// a short list EVERY window takes four lanes (one chunk in registers, all of its lanes computed) and every workgroup of the launch walks the one
+// concatenation: the thread-per-window class bodies would otherwise queue up behind this slice at two waves per SIMD.
 template <int SWL, bool UPPER>
 __device__ __forceinline__ void dp_quad_tc_body(const CfTables& tab, u32 vblock, u32 vgrid, u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta,
-                                                const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts, const NeedleDev& nd,
-                                                fzb_match_rec* __restrict__ out, u32 capacity) {
+                                                const u32* __restrict__ lists, u32 list_stride, const u32* __restrict__ counts, const u32* __restrict__ singles,
+                                                const NeedleDev& nd, fzb_match_rec* __restrict__ out, u32 capacity) {
     extern __shared__ __attribute__((aligned(16))) u32 s_park[];
     if constexpr (SWL == 64 || SWL == 32) {
         const u32 e3 = __builtin_amdgcn_readfirstlane(counts[3]), e2 = e3 + __builtin_amdgcn_readfirstlane(counts[2]), e1 = e2 + __builtin_amdgcn_readfirstlane(counts[1]),
@@ -772,10 +774,19 @@ __device__ __forceinline__ void dp_quad_tc_body(const CfTables& tab, u32 vblock,
         const u32 wpb = blockDim.x / 4, wslot = (threadIdx.x >> 6) * 16 + ((threadIdx.x >> 4) & 3u) * 4 + (threadIdx.x & 3u);
         const u32 ngroups = vgrid * wpb, gid = vblock * wpb + wslot;
         u32* const park = s_park + wslot;
-        for (u32 q = gid; q < e0; q += ngroups) {
-            const u32 cls = q < e3 ? 3u : q < e2 ? 2u : q < e1 ? 1u : 0u;
-            const u32 base = cls == 3 ? 0u : cls == 2 ? e3 : cls == 1 ? e2 : e1;
-            const u32 j = lists[(size_t)(3 + cls) * list_stride + (q - base)];
+        const u32 s2 = e0 + (singles ? __builtin_amdgcn_readfirstlane(singles[2]) : 0u), s1 = s2 + (singles ? __builtin_amdgcn_readfirstlane(singles[1]) : 0u),
+                  s0 = s1 + (singles ? __builtin_amdgcn_readfirstlane(singles[0]) : 0u);
+        for (u32 q = gid; q < s0; q += ngroups) {
+            u32 l, base;  // list, first position of it in the concatenation
+            if (q < e0) {
+                const u32 cls = q < e3 ? 3u : q < e2 ? 2u : q < e1 ? 1u : 0u;
+                l = 3 + cls;
+                base = cls == 3 ? 0u : cls == 2 ? e3 : cls == 1 ? e2 : e1;
+            } else {
+                l = q < s2 ? 2u : q < s1 ? 1u : 0u;
+                base = l == 2 ? e0 : l == 1 ? s2 : s1;
+            }
+            const u32 j = lists[(size_t)l * list_stride + (q - base)];
             if (j >= capacity) continue;
             const u32 li = items ? items[j] : j;
             const uint4 w = meta[j];
@@ -810,24 +821,37 @@ __device__ __forceinline__ void dp_quad_tc_body(const CfTables& tab, u32 vblock,
 template <int SWL, bool UPPER>
 __global__ __launch_bounds__(128, 2) void k2_classes_all(u32 index_offset, const u32* __restrict__ items, const uint4* __restrict__ meta, const u32* __restrict__ lists,
                                                       u32 list_stride, const u32* __restrict__ counters, const NeedleDev nd, fzb_match_rec* __restrict__ out, u32 capacity,
-                                                      u32* __restrict__ scratch, u32 gm, u32 gc, u32 park_dw, u32 coop_below) {
+                                                      u32* __restrict__ scratch, u32 gm, u32 gc, u32 park_dw, u32 coop_below, u32 quad_all_below) {
     __shared__ CfTables tab;
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
     u32 b = blockIdx.x;
-    if (b < gm) {
-        // fewer multi-chunk windows than `coop_below` (0: the needle's parked rows do not fit, or another lane width): four lanes per window
-        const u32 total = __builtin_amdgcn_readfirstlane(counters[12] + counters[13] + counters[14] + counters[15]);
-        if (total < coop_below) dp_quad_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity);
-        else dp_multi_tc_body<SWL, UPPER>(tab, b, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch, park_dw);
-        return;
-    }
-    b -= gm;
-    if (b < gc) { dp_class_body<SWL, UPPER, SWL / 2>(tab, b, gc, index_offset, items, meta, lists + 2 * (size_t)list_stride, &counters[10], nd, out); return; }
-    b -= gc;
-    if (b < gc) { dp_class_body<SWL, UPPER, 3 * SWL / 8>(tab, b, gc, index_offset, items, meta, lists + (size_t)list_stride, &counters[9], nd, out); return; }
-    b -= gc;
-    dp_class_body<SWL, UPPER, SWL / 4>(tab, b, gc, index_offset, items, meta, lists, &counters[8], nd, out);
+    // fewer multi-chunk windows than `coop_below` (0: the needle's parked rows do not fit, or another lane width): four lanes per window; fewer
+    // windows of any kind than `quad_all_below`: four lanes for all of them, the whole grid on one list
+    const u32 total = __builtin_amdgcn_readfirstlane(counters[12] + counters[13] + counters[14] + counters[15]);
+    const u32 total_all = total + __builtin_amdgcn_readfirstlane(counters[8] + counters[9] + counters[10]);
+    // which list this workgroup walks (0: the multi-chunk ones, 1-3: the single-chunk classes, widest first) and as which of its workgroups.
+    // Thread form: the grid in slices, widest work first.  Four lanes for the multi-chunk slice: its workgroups are short-lived now and the class
+    // bodies' are the long ones, so the two kinds are dealt out in turns (4 : 3, the classes in turns too) - both are among the first workgroups the
+    // dispatcher places and finish side by side, instead of the classes queueing behind a slice that holds every slot for its ten microseconds
+    // (1.4 M paths 90.9 -> 88.4 us, 8..128-byte list of 2 M items 109.7 -> 102.8).
+    const bool quad = total < coop_below, all = quad && total_all < quad_all_below;
+    u32 kind, vb;
+    if (all) kind = 0, vb = b;
+    else if (quad && gm == 4 * gc) {
+        const u32 grp = b / 7, pos = b % 7;
+        if (pos & 1u) {
+            const u32 cidx = 3 * grp + (pos >> 1);
+            kind = 1 + cidx % 3, vb = cidx / 3;
+        } else kind = 0, vb = 4 * grp + (pos >> 1);
+    } else if (b < gm) kind = 0, vb = b;
+    else kind = 1 + (b - gm) / gc, vb = (b - gm) % gc;
+    if (kind == 0) {
+        if (quad) dp_quad_tc_body<SWL, UPPER>(tab, vb, all ? gridDim.x : gm, index_offset, items, meta, lists, list_stride, &counters[12], all ? &counters[8] : nullptr, nd, out, capacity);
+        else dp_multi_tc_body<SWL, UPPER>(tab, vb, gm, index_offset, items, meta, lists, list_stride, &counters[12], nd, out, capacity, scratch, park_dw);
+    } else if (kind == 1) dp_class_body<SWL, UPPER, SWL / 2>(tab, vb, gc, index_offset, items, meta, lists + 2 * (size_t)list_stride, &counters[10], nd, out);
+    else if (kind == 2) dp_class_body<SWL, UPPER, 3 * SWL / 8>(tab, vb, gc, index_offset, items, meta, lists + (size_t)list_stride, &counters[9], nd, out);
+    else dp_class_body<SWL, UPPER, SWL / 4>(tab, vb, gc, index_offset, items, meta, lists, &counters[8], nd, out);
 }
 
 // dwords per parked row when the dp_cfm.h kernels (128 threads) keep a needle's parked rows in LDS, 0 when they go to the global slab: a row
@@ -855,8 +879,11 @@ void fzb_launch_classes_all(const CorpusDev& c, u64 first, u32 index_offset, con
     // ones park their rows in LDS, which is what the 48 KB bound is for (a needle too long for it keeps the thread form for every window).
     const size_t coop_lds = (sw_lanes == 64 || sw_lanes == 32) ? (size_t)nd.rows * (sw_lanes / 4 + 1) * (128 / 4) * 4 : 0;  // [row][QuadPark::WORDS][window of the workgroup]
     const u32 coop_below = (coop_lds != 0 && coop_lds <= 48 * 1024 && fzb_knobs().coop_below != 0) ? (fzb_knobs().coop_below > 0 ? (u32)fzb_knobs().coop_below : (u32)gm * 48u) : 0u;
+    // ... and below 32 768 windows of ANY kind every window takes four lanes (paths-shaped lists of 100 k / 300 k items, 7.9 k / 23.9 k windows:
+    // 46.4 -> 38.7 / 50.0 -> 43.7 us; 8..128-byte lists: 25 k windows 57.7 -> 54.2, 50 k 66.3 -> 69.3, 112 k (1.4 M paths) 90.9 -> 92.1)
+    const u32 quad_all_below = std::min<u32>(coop_below, (u32)gm * 32u);
     const size_t dyn_lds = std::max((size_t)nd.rows * park_dw * 128 * 4, coop_below ? coop_lds : (size_t)0);
-#define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), dyn_lds, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc, park_dw, coop_below)
+#define FZB_K2A(SWL, U) hipLaunchKernelGGL((k2_classes_all<SWL, U>), dim3(gm + 3 * gc), dim3(128), dyn_lds, st, index_offset, items, (const uint4*)win, lists, list_stride, counters, nd, out, capacity, scratch, (u32)gm, (u32)gc, park_dw, coop_below, quad_all_below)
 #define FZB_K2A_U(SWL) do { if (upper) FZB_K2A(SWL, true); else FZB_K2A(SWL, false); } while (0)
     switch (sw_lanes) {
         case 64: FZB_K2A_U(64); break;

@@ -18,7 +18,7 @@ struct FzbKnobs {
     bool no_dp_cfm = false;          // FZB_NO_DP_CFM=1         multi-chunk scorer in its first form (dp_body.h: scorings outside dp_cfm.h)
     bool no_dp_cfu = false;          // FZB_NO_DP_CFU=1         unicode scorer in its first form (scorings outside dp_unicode.h's biased form)
     int unicode_multi = -1;          // FZB_UNICODE_MULTI=0|1   unicode windows of 65..1024 bytes: never / always thread per haystack (k2u_dp_unicode_multi); default: by the queue's length, on the device
-    int coop_below = -1;             // FZB_COOP_BELOW=n        multi-chunk ASCII windows of a ragged list: four lanes per window (dp_quad.h) when fewer than n are queued (0: never; default: 48 per workgroup of the slice = 49 152 on 256 CUs)
+    int coop_below = -1;             // FZB_COOP_BELOW=n        multi-chunk ASCII windows of a ragged list: four lanes per window (dp_quad.h) when fewer than n are queued (0: never; default: 48 per workgroup of the slice = 49 152 on 256 CUs; below 32 768 windows of any kind the single-chunk ones too)
     int park_lds_kb = 37;            // FZB_PARK_LDS_KB         multi-chunk scorer: parked rows in LDS when they fit this many KB per workgroup (0: always the global slab, as for needles of many rows)
     // --- multi-device form ---
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy   counts to the host + hipMemcpyPeerAsync even when every shard shares the root device (the form shards on other devices take)
