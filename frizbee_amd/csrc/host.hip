@@ -1202,7 +1202,7 @@ static int run_pipeline_long(fzb_matcher* m, const fzb_corpus* c, size_t first, 
     // four lanes per window (dp_quad.h) when dp_cfm.h's preconditions hold: a seventh of the slab per window, four times the wavefronts
     const size_t qwords = fzb_dp_long_quad_words_per_block(m->ndl, m->lc.sw_lanes);
     const bool quad = thread_per_window && m->lc.cfm_ok && !fzb_knobs().no_dp_cfm && qwords != 0;
-    const int qgrid = quad ? (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)cus * 16, budget / (qwords * 4)), (count + 31) / 32)) : 0;
+    const int qgrid = quad ? (int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>((size_t)cus * 8, budget / (qwords * 4)), (count + 63) / 64)) : 0;
     const size_t dpl_bytes = quad ? qwords * 4 * (size_t)qgrid : thread_per_window ? dpl_words * 4 * 128 * (size_t)dgrid : 0;
     const bool greedy_possible = !(cd.max_len != 0 && cd.max_len <= FZB_MAX_HAYSTACK_LEN);
     if (thread_per_window && !greedy_possible) ggrid = 1;  // (no launch of the wave-per-haystack kernel: its slab is not needed)

@@ -575,7 +575,7 @@ __global__ __launch_bounds__(128) void k2d_dp_long(const u8* __restrict__ bytes,
 // The same windows with FOUR lanes each (dp_quad.h; LaunchCfg::cfm_ok, 64- or 32-lane score chunks): sixteen windows per wavefront, the needle's rows
 // staged in LDS, the parked rows in the global slab (a block per window slot of the grid), requested one row ahead.
 template <int SWL, bool UPPER>
-__global__ __launch_bounds__(128) void k2d_dp_long_quad(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset, const u32* __restrict__ items,
+__global__ __launch_bounds__(256) void k2d_dp_long_quad(const u8* __restrict__ bytes, const EndsAny ends, u64 first, u32 index_offset, const u32* __restrict__ items,
                                                         const u32* __restrict__ win, int wmode, const u32* __restrict__ n_items_ptr, const NeedleLongDev nd,
                                                         fzb_match_rec* __restrict__ out, u32 capacity, u32* __restrict__ dev_count, u32* __restrict__ scratch, u32* __restrict__ queue,
                                                         u32* __restrict__ counters) {
@@ -589,68 +589,101 @@ __global__ __launch_bounds__(128) void k2d_dp_long_quad(const u8* __restrict__ b
     __syncthreads();
     const u32 n = *n_items_ptr;
     if (dev_count && blockIdx.x == 0 && threadIdx.x == 0) { dev_count[0] = n < capacity ? n : capacity; dev_count[1] = n; }
-    const u32 wpb = blockDim.x / 4, wslot = (threadIdx.x >> 6) * 16 + ((threadIdx.x >> 4) & 3u) * 4 + (threadIdx.x & 3u);
-    const u32 nslots = gridDim.x * wpb, slot = blockIdx.x * wpb + wslot;
-    const bool lane0 = ((threadIdx.x >> 2) & 3u) == 0;
-    for (u32 q = slot; q < n; q += nslots) {
-        if (q >= capacity) continue;
-        const u32 li = items ? items[q] : q;
-        u64 s;
-        u32 L;
-        haystack_span(ends, first + li, s, L);
-        const u8* hay = bytes + s;
-        u32 ws = 0, we = L;
-        if (wmode == 1) {  // the lane-free 0-typo window (as k2d_dp_long; every lane of the quad walks the haystack - the same cache lines)
-            const u32 c0 = (u32)nd.c[0] * 0x01010101u, f0 = (u32)nd.f[0] * 0x01010101u;
-            const u32 cl = (u32)nd.c[nd.rows - 1] * 0x01010101u, fl = (u32)nd.f[nd.rows - 1] * 0x01010101u;
-            ws = 0xFFFFFFFFu;
-            we = 0;
-            for (u32 p = 0; p < L; p += 4) {
-                const u32 w = *(const u32*)(hay + p);
-                const u32 vm = L - p >= 4 ? 0xFu : ((1u << (L - p)) - 1u);
-                const u32 mf = (zero_bytes4_dp(w ^ c0) | zero_bytes4_dp(w ^ f0)) & vm;
-                const u32 ml = (zero_bytes4_dp(w ^ cl) | zero_bytes4_dp(w ^ fl)) & vm;
-                if (mf && ws == 0xFFFFFFFFu) ws = p + (u32)__builtin_ctz(mf);
-                if (ml) we = p + 32u - (u32)__builtin_clz(ml);
+    // A workgroup takes 64 windows at a time: one thread per window finds it, the 64 are ordered by their number of chunks (a counting sort in
+    // LDS) and dealt to the four wavefronts longest first - a wave lasts as long as its widest window, and sixteen windows drawn at random hold
+    // the list's widest almost every time (100..200-byte haystacks: 6.7 chunk walks per wave; by quartiles 5.6).
+    __shared__ uint4 s_rec[64];  // q | window start | window end (bit 31: the window is the whole haystack) | local haystack index
+    __shared__ u64 s_hay[64];
+    __shared__ u32 s_hist[34];
+    const u32 tid = threadIdx.x;
+    const u32 wslot = (tid >> 6) * 16 + ((tid >> 4) & 3u) * 4 + (tid & 3u);
+    const u32 nslots = gridDim.x * 64, slot = blockIdx.x * 64 + wslot;
+    const bool lane0 = ((tid >> 2) & 3u) == 0;
+    for (u32 base = blockIdx.x * 64; base < n; base += gridDim.x * 64) {  // (the same trip count for every thread of the workgroup)
+        if (tid < 34) s_hist[tid] = 0;
+        __syncthreads();
+        u32 bin = 33, rank = 0;
+        uint4 rec = make_uint4(0xFFFFFFFFu, 0, 0, 0);
+        u64 hptr = 0;
+        if (tid < 64) {
+            const u32 q = base + tid;
+            if (q < n && q < capacity) {
+                const u32 li = items ? items[q] : q;
+                u64 s;
+                u32 L;
+                haystack_span(ends, first + li, s, L);
+                const u8* hay = bytes + s;
+                u32 ws = 0, we = L;
+                if (wmode == 1) {  // the lane-free 0-typo window (as k2d_dp_long)
+                    const u32 c0 = (u32)nd.c[0] * 0x01010101u, f0 = (u32)nd.f[0] * 0x01010101u;
+                    const u32 cl = (u32)nd.c[nd.rows - 1] * 0x01010101u, fl = (u32)nd.f[nd.rows - 1] * 0x01010101u;
+                    ws = 0xFFFFFFFFu;
+                    we = 0;
+                    for (u32 p = 0; p < L; p += 4) {
+                        const u32 w = *(const u32*)(hay + p);
+                        const u32 vm = L - p >= 4 ? 0xFu : ((1u << (L - p)) - 1u);
+                        const u32 mf = (zero_bytes4_dp(w ^ c0) | zero_bytes4_dp(w ^ f0)) & vm;
+                        const u32 ml = (zero_bytes4_dp(w ^ cl) | zero_bytes4_dp(w ^ fl)) & vm;
+                        if (mf && ws == 0xFFFFFFFFu) ws = p + (u32)__builtin_ctz(mf);
+                        if (ml) we = p + 32u - (u32)__builtin_clz(ml);
+                    }
+                    if (ws == 0xFFFFFFFFu) ws = 0;
+                } else if (wmode != 2) { ws = win[2 * q]; we = win[2 * q + 1]; }
+                const u32 sp = ws ? ws - 1 : 0;
+                const u32 m = we - sp;
+                if (m > FZB_MAX_HAYSTACK_LEN) {  // the greedy fallback: the wave-per-haystack kernel's
+                    u32* qe = queue + 4 * (size_t)atomicAdd(&counters[3], 1u);
+                    qe[0] = q; qe[1] = ws; qe[2] = we; qe[3] = li;
+                } else {
+                    rec = make_uint4(q, ws, we | ((sp == 0 && we == L) ? 0x80000000u : 0u), li);
+                    hptr = (u64)(uintptr_t)hay;
+                    bin = 32 - (m + SWL - 1) / SWL;  // widest first (m = 0: bin 32)
+                }
             }
-            if (ws == 0xFFFFFFFFu) ws = 0;
-        } else if (wmode != 2) { ws = win[2 * q]; we = win[2 * q + 1]; }
-        const u32 sp = ws ? ws - 1 : 0;
-        const bool include_exact = sp == 0 && we == L;
-        const u32 m = we - sp;
-        if (m > FZB_MAX_HAYSTACK_LEN) {  // the greedy fallback: the wave-per-haystack kernel's
+            rank = atomicAdd(&s_hist[bin], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            u32 off = 0;
+            for (u32 k = 0; k < bin; k++) off += s_hist[k];
+            s_rec[off + rank] = rec;
+            s_hay[off + rank] = hptr;
+        }
+        __syncthreads();
+        const uint4 w = s_rec[wslot];
+        if (w.x != 0xFFFFFFFFu) {
+            const u8* hay = (const u8*)(uintptr_t)s_hay[wslot];
+            const u32 sp = w.y ? w.y - 1 : 0;
+            const bool include_exact = (w.z >> 31) != 0;
+            const u32 m = (w.z & 0x7FFFFFFFu) - sp;
+            constexpr int MAXC = SWL == 32 ? 8 : 4;  // windows of up to 256 bytes: row by row, in registers
+            u32 score;
+            if (m <= (u32)MAXC * SWL) score = dp_quad_rows<SWL, UPPER, MAXC>(nr, hay + sp, m, sp == 0, tab);
+            else score = dp_quad_window<SWL, UPPER, true>(nr, hay + sp, m, sp == 0, tab, scratch + slot, nslots);
             if (lane0) {
-                u32* qe = queue + 4 * (size_t)atomicAdd(&counters[3], 1u);
-                qe[0] = q; qe[1] = ws; qe[2] = we; qe[3] = li;
+                bool exact = include_exact && m == (u32)nd.nbytes;
+                if (exact)
+                    for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
+                if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
+                fzb_match_rec r;
+                r.index = index_offset + w.w;
+                r.score = (u16)score;
+                r.exact = exact ? 1 : 0;
+                r.valid = 0;
+                out[w.x] = r;
             }
-            continue;
         }
-        constexpr int MAXC = SWL == 32 ? 8 : 4;  // windows of up to 256 bytes: row by row, in registers
-        u32 score;
-        if (m <= (u32)MAXC * SWL) score = dp_quad_rows<SWL, UPPER, MAXC>(nr, hay + sp, m, sp == 0, tab);
-        else score = dp_quad_window<SWL, UPPER, true>(nr, hay + sp, m, sp == 0, tab, scratch + slot, nslots);
-        if (lane0) {
-            bool exact = include_exact && m == (u32)nd.nbytes;
-            if (exact)
-                for (u32 k = 0; k < m; k++) exact = exact && hay[sp + k] == nd.raw[k];
-            if (exact) score = (score + nd.exact_bonus) & 0xFFFF;
-            fzb_match_rec rec;
-            rec.index = index_offset + li;
-            rec.score = (u16)score;
-            rec.exact = exact ? 1 : 0;
-            rec.valid = 0;
-            out[q] = rec;
-        }
+        __syncthreads();  // (s_rec is rewritten by the next 64)
     }
 }
 
-// dwords of the slab per 128-thread WORKGROUP of k2d_dp_long_quad ([row][QuadPark::WORDS][32 windows]); 0 = that lane width has no quad form
+// dwords of the slab per 256-thread WORKGROUP of k2d_dp_long_quad ([row][QuadPark::WORDS][64 windows]); 0 = that lane width has no quad form
 size_t fzb_dp_long_quad_words_per_block(const NeedleLongDev& nd, int sw_lanes) {
-    return (sw_lanes == 64 || sw_lanes == 32) ? (size_t)nd.rows * (size_t)(sw_lanes / 4 + 1) * 32 : 0;
+    return (sw_lanes == 64 || sw_lanes == 32) ? (size_t)nd.rows * (size_t)(sw_lanes / 4 + 1) * 64 : 0;
 }
 void fzb_launch_dp_long_quad(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win, int wmode, const u32* n_items_ptr, const NeedleLongDev& nd, int sw_lanes,
                              int upper, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* scratch, u32* queue, u32* counters, int grid, hipStream_t st) {
-#define FZB_K2Q(SWL, U) hipLaunchKernelGGL((k2d_dp_long_quad<SWL, U>), dim3(grid), dim3(128), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
+#define FZB_K2Q(SWL, U) hipLaunchKernelGGL((k2d_dp_long_quad<SWL, U>), dim3(grid), dim3(256), 0, st, c.bytes, EndsAny{c.ends, c.ends_u64}, first, index_offset, items, win, wmode, n_items_ptr, nd, out, capacity, dev_count, scratch, queue, counters)
     if (sw_lanes == 64) { if (upper) FZB_K2Q(64, true); else FZB_K2Q(64, false); }
     else { if (upper) FZB_K2Q(32, true); else FZB_K2Q(32, false); }
 #undef FZB_K2Q
