@@ -398,8 +398,10 @@ __global__ __launch_bounds__(256) void k1_cdfa_ragged(const u8* __restrict__ byt
 // the launcher passes LEN = false and the array is not touched.
 // (Rounds 4-5 also had a STAGE form - the accepting lanes copied their vectors into a per-tile block for the classifier and the scorers; the
 // 48 MB copy-out cost the streaming kernel more than the scorers' gathers returned: profiles/HISTORY.md.)
-template <bool SAN, int G, int NV, bool LEN = true>
-__global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
+// TPB = 1024 (short lists: the launcher's choice): sixteen waves, ONE group each - a tile is then one load round trip and one walk instead of four
+// in a row, which is what a list of fewer tiles than the chip holds workgroups pays (a fixed ~ 13 us of the 256-thread form).
+template <bool SAN, int G, int NV, bool LEN = true, int TPB = 256>
+__global__ __launch_bounds__(TPB) void k1_cdfa_view(const u8* __restrict__ vbytes, const u32* __restrict__ vgofs, const u8* __restrict__ vgnv, const u16* __restrict__ vlen,
                                                     const u16* __restrict__ vperm, u64 first, u32 count, const u8* __restrict__ cdfa_g, u32 cdfa_bytes, u32 K, u32 KG,
                                                     u32 min_len, u32 dead, u32 acc_lo, u64* __restrict__ bitmap, u32* __restrict__ tile_counts, u32* __restrict__ reset_counters) {
     if (blockIdx.x == 0 && threadIdx.x < 16) reset_counters[threadIdx.x] = 0;
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
     u32* const s_bits = (u32*)(lds + tab_bytes + 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     dfa_require_lds_base0(lds);
-    for (u32 i = tid * 4; i < tab_bytes; i += 256 * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
+    for (u32 i = tid * 4; i < tab_bytes; i += TPB * 4) *(u32*)(lds + i) = i < cdfa_bytes ? *(const u32*)(cdfa_g + i) : 0u;
     const u32 ntiles = (count + FZB_TILE - 1) / FZB_TILE;
     const u32 deadv = dead * 0x01010101u;
     auto cls_of = [](u32 b) -> u32 { return *(const __attribute__((address_space(3))) u8*)(uintptr_t)b; };
@@ -420,9 +422,9 @@ __global__ __launch_bounds__(256) void k1_cdfa_view(const u8* __restrict__ vbyte
         if (tid < 32) s_bits[tid] = 0;
         __syncthreads();
 #pragma unroll 1
-        for (int gi = 0; gi < 4; gi++) {
-            const u32 p = tile * FZB_TILE + (u32)(gi * 4 + wave) * 64 + lane;  // sorted position (relative to `first`)
-            const u32 gl = tile * (FZB_TILE / 64) + (u32)(gi * 4 + wave);       // its group
+        for (int gi = 0; gi < 16 / (TPB / 64); gi++) {
+            const u32 p = tile * FZB_TILE + (u32)(gi * (TPB / 64) + wave) * 64 + lane;  // sorted position (relative to `first`)
+            const u32 gl = tile * (FZB_TILE / 64) + (u32)(gi * (TPB / 64) + wave);       // its group
             if (gl * 64 >= count) continue;
             // vgnv: vectors per member | (bytes stored per member of the LAST row / 4 - 1) << 5 (round 5: the group's last row is as narrow as
             // its longest member's tail allows - 4, 8, 12 or 16 bytes per lane, a contiguous 256..1024 bytes for the wave)
@@ -875,15 +877,23 @@ void fzb_launch_filter(const CorpusDev& c, u64 first, u32 count, const u64* tabl
             const int g = std::max(1, std::min<int>(cus * 6, (int)ntiles));
             // (the lengths are not read when nothing needs them: acc >= 1 = the start state does not accept)
             const bool len_free = nul_safe && acc >= 1;
-#define FZB_K1V(SAN, G, NV, LEN) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, LEN>), dim3(g), dim3(256), lds_v, st, c.vbytes, c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters)
-#define FZB_K1V_S(SAN, G, NV) do { if (!SAN && len_free) FZB_K1V(SAN, G, NV, false); else FZB_K1V(SAN, G, NV, true); } while (0)
+            // short lists (fewer tiles than two per CU, the common form only): 1024-thread workgroups, one group per wave.  Filter / step, us:
+            // 100 k paths 14.5 -> 8.3 / 39.8 -> 34.0, 300 k 16.5 -> 13.7 / 42.9 -> 40.6, 0.5 M 8..128-byte items 18.1 -> 12.7 / 55.3 -> 49.1; from
+            // 1.4 M items (1 374 tiles) on the 256-thread form's six workgroups per CU win (34.5 against 38.3)
+            const bool wide = nul_safe && len_free && ntiles < (u32)cus * 2u;
+#define FZB_K1VA const_cast<const u8*>(c.vbytes), c.vgofs, c.vgnv, c.vlen, c.vperm, first, count, cdfa, cdfa_bytes, (u32)cdfa_K, kg, min_len, dead, acc, bitmap, tile_counts, reset_counters
+#define FZB_K1V(SAN, G, NV, LEN) hipLaunchKernelGGL((k1_cdfa_view<SAN, G, NV, LEN>), dim3(g), dim3(256), lds_v, st, FZB_K1VA)
+#define FZB_K1W(G, NV) hipLaunchKernelGGL((k1_cdfa_view<false, G, NV, false, 1024>), dim3(g), dim3(1024), lds_v, st, FZB_K1VA)
+#define FZB_K1V_S(SAN, G, NV) do { if (!SAN && wide) FZB_K1W(G, NV); else if (!SAN && len_free) FZB_K1V(SAN, G, NV, false); else FZB_K1V(SAN, G, NV, true); } while (0)
 #define FZB_K1V_NV(SAN, G) do { if (c.view_nv <= 8) FZB_K1V_S(SAN, G, 8); else FZB_K1V_S(SAN, G, 16); } while (0)
 #define FZB_K1V_G(SAN) do { if (cdfa_G == 4) FZB_K1V_NV(SAN, 4); else FZB_K1V_NV(SAN, 2); } while (0)
             if (nul_safe) FZB_K1V_G(false); else FZB_K1V_G(true);
 #undef FZB_K1V_G
 #undef FZB_K1V_NV
 #undef FZB_K1V_S
+#undef FZB_K1W
 #undef FZB_K1V
+#undef FZB_K1VA
             if (c.n_long) {  // the haystacks beyond 256 bytes: decided from the canonical layout, OR-ed into the view kernel's bitmap
                 const u32 ns_o = (cdfa_bytes - 256u) / kg;  // the automaton's states (the table is padded to 16 bytes: at most a phantom state more)
                 const u32 wpw = ((cdfa_bytes + 15) & ~(size_t)15) + (size_t)4 * 64 * ns_o + 16 <= 60 * 1024 ? 4u : 1u;

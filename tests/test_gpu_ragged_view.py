@@ -192,3 +192,25 @@ def test_a_list_of_mostly_long_haystacks_gets_no_view():
     assert not F.Corpus(hs).build_view()
     got, want, _ = both("fade", hs)
     assert_same(got, want, "long list")
+
+
+def test_a_list_of_more_tiles_than_the_short_list_form_takes():
+    """below two tiles per CU (512 on MI355X) the view filter runs as 1024-thread workgroups, one 64-haystack group per wave - every other list in
+    this file; this one has 540 000 haystacks of 8..128 bytes (528 tiles): the 256-thread form (four groups in a row per wave, what BASELINE
+    config 4 runs), and the thread-per-window scorers above 49 152 multi-chunk windows are not reached but the class bodies above 32 768 are"""
+    rng = np.random.default_rng(4242)
+    n = 540_000
+    lens = rng.integers(8, 129, n)
+    ends = np.cumsum(lens).astype(np.uint64)
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz_-/. 0123456789", dtype=np.uint8)
+    data = alpha[rng.integers(0, len(alpha), int(ends[-1]))].copy()
+    needle = b"deadbeef"
+    starts = np.concatenate([[0], ends[:-1]]).astype(np.int64)
+    for i in rng.choice(n, n // 12, replace=False):  # the needle as an ordered subsequence of about one haystack in twelve
+        L = int(lens[i])
+        pos = np.sort(rng.choice(L, len(needle), replace=False))
+        data[starts[i] + pos] = np.frombuffer(needle, dtype=np.uint8)
+    got, want, fm = both("deadbeef", None, pf=64, packed=(data, ends))
+    assert len(want) > 40_000
+    assert fm.last_counters()["multi_chunk_scored"] > 10_000
+    assert_same(got, want, "540 k ragged haystacks")
