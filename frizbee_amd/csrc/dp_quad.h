@@ -23,7 +23,11 @@
 // needle row ahead).  (A block per window with 16-byte vectors was slower there - 0.93 against 0.83 ms: sixteen windows, sixteen lines per request.)
 //
 // Every chunk is computed in full (no closed-form padding); the last row of the last chunk is not propagated (dp_cf.h, 2.).
-// Preconditions: LaunchCfg::cfm_ok.  Parity: tests/test_gpu_quad.py, tests/test_gpu_long_needles.py, tests/test_gpu_knobs.py against the oracle.
+// Reference code this computes (as dp_cfm.h): score_haystack, src/smith_waterman/algo/ascii.rs:10-158 (per-chunk loop 91-158, diagonal / up /
+// max 118-133, the row maximum 152-156); propagate_horizontal_gaps with the adjacent chunk's row, ascii_gap.rs:11-105; the per-row columns of
+// score_matrix / match_masks that carry a chunk's last row to the next, src/smith_waterman/matrix.rs.
+// Preconditions: LaunchCfg::cfm_ok.  Parity: tests/test_kernel_math_host.py (four host threads in lockstep against the oracle, no GPU),
+// tests/test_gpu_quad.py, tests/test_gpu_long_needles.py, tests/test_gpu_knobs.py.
 #pragma once
 #include "dp_cf.h"
 

@@ -2,7 +2,9 @@
 // dp_unicode.h) for the host through tests/kernel_host/shim, one "thread" at a time, so that tests can fuzz the exact code the GPU runs
 // against the oracle without a GPU.  Built by tests/kernel_host_lib.py with ROCm's clang++ (-x c++); never part of the product.
 #include <vector>
+#include <thread>
 #include "dp_cfm.h"
+#include "dp_quad.h"
 #include "dp_unicode.h"
 
 static u16 sadd16(u32 a, u32 b) { return (u16)(a + b > 0xFFFF ? 0xFFFF : a + b); }
@@ -142,6 +144,37 @@ static int run_multi_long(const NeedleLongDev& nd, bool upper, const u8* hay, u3
     nr.cf = cf.data();
     return upper ? (int)dp_multi_chunk_t<SWL, true, SWL / 2, NeedleLongRows>(nr, buf.data(), m, include_prefix, tab, scratch.data(), 1, 0, rp)
                  : (int)dp_multi_chunk_t<SWL, false, SWL / 2, NeedleLongRows>(nr, buf.data(), m, include_prefix, tab, scratch.data(), 1, 0, rp);
+}
+
+// dp_quad.h: the window scored by four host threads in lockstep, one per quad lane (shim: fzb_host_update_dpp).  form 0 = row by row in registers
+// (dp_quad_rows, MAXC chunks), 1 = chunk by chunk with the LDS layout of the parked rows, 2 = chunk by chunk with the slab layout (one slot,
+// requested a row ahead).  Every lane returns the score; they must agree.
+template <int SWL, typename ND>
+static int run_quad(const ND& nd, bool upper, const u8* hay, u32 m, int include_prefix, int form) {
+    constexpr int MAXC = 1024 / SWL;
+    std::vector<u8> buf(m + 96, 0);
+    memcpy(buf.data(), hay, m);
+    CfTables tab;
+    for (unsigned t = 0; t < 16; t++) { threadIdx.x = t; if (upper) cf_build_tables<true, ND>(nd, tab); else cf_build_tables<false, ND>(nd, tab); }
+    threadIdx.x = 0;
+    std::vector<u32> park((size_t)(nd.rows + 1) * QuadPark<SWL>::WORDS * 32 + 64, 0xDEADBEEFu);
+    u32 res[4] = {0, 0, 0, 0};
+    auto lane_fn = [&](int lane) {
+        fzb_quad_lane = lane;
+        threadIdx.x = (unsigned)lane << 2;
+        u32 r;
+        if (form == 0) r = upper ? dp_quad_rows<SWL, true, MAXC>(nd, buf.data(), m, include_prefix, tab) : dp_quad_rows<SWL, false, MAXC>(nd, buf.data(), m, include_prefix, tab);
+        else if (form == 1) r = upper ? dp_quad_window<SWL, true, false>(nd, buf.data(), m, include_prefix, tab, park.data(), 0u) : dp_quad_window<SWL, false, false>(nd, buf.data(), m, include_prefix, tab, park.data(), 0u);
+        else r = upper ? dp_quad_window<SWL, true, true>(nd, buf.data(), m, include_prefix, tab, park.data(), 1u) : dp_quad_window<SWL, false, true>(nd, buf.data(), m, include_prefix, tab, park.data(), 1u);
+        res[lane] = r;
+    };
+    std::thread t1(lane_fn, 1), t2(lane_fn, 2), t3(lane_fn, 3);
+    lane_fn(0);
+    t1.join(); t2.join(); t3.join();
+    fzb_quad_lane = 0;
+    threadIdx.x = 0;
+    if (res[0] != res[1] || res[0] != res[2] || res[0] != res[3]) return -3;
+    return (int)res[0];
 }
 
 extern "C" {
@@ -305,6 +338,34 @@ int kh_dp_multi_long(const u8* needle, int n, int case_sensitive, int is_u8, con
         case 8: return run_multi_long<8>(nd, upper, hay, (u32)m, include_prefix, form, cls);
     }
     return -1;
+}
+
+// four lanes per window: a NeedleDev needle (n <= 63) or, with `long_needle`, the same through NeedleLongRows (any n)
+int kh_dp_quad(const u8* needle, int n, int case_sensitive, int is_u8, const u16* sc, const u8* hay, int m, int include_prefix, int swl, int form, int long_needle) {
+    if (n < 1 || m < 1 || m > 1024 || (swl != 64 && swl != 32) || (!long_needle && n > FZB_MAX_ROWS)) return -1;
+    bool upper = false;
+    for (int i = 0; i < n; i++) upper = upper || (needle[i] >= 'A' && needle[i] <= 'Z');
+    if (!long_needle) {
+        NeedleDev nd;
+        fill_needle(nd, needle, n, case_sensitive, sc);
+        nd.lane_mask = is_u8 ? 0xFF : 0xFFFF;
+        return swl == 64 ? run_quad<64>(nd, upper, hay, (u32)m, include_prefix, form) : run_quad<32>(nd, upper, hay, (u32)m, include_prefix, form);
+    }
+    std::vector<u8> c(n + 4), f(n + 4);
+    std::vector<u16> cf(n);
+    for (int i = 0; i < n; i++) {
+        c[i] = needle[i];
+        f[i] = case_sensitive ? c[i] : (c[i] >= 'a' && c[i] <= 'z') ? (u8)(c[i] - 32) : (c[i] >= 'A' && c[i] <= 'Z') ? (u8)(c[i] + 32) : c[i];
+        cf[i] = (u16)(c[i] | (f[i] << 8));
+    }
+    NeedleLongRows nd;
+    memset(&nd, 0, sizeof(nd));
+    nd.rows = n; nd.nbytes = n; nd.lane_mask = is_u8 ? 0xFF : 0xFFFF;
+    nd.match_plus_mismatch = sadd16(sc[0], sc[1]); nd.mismatch = sc[1]; nd.gex = sc[3]; nd.gopm = ssub16(sc[2], sc[3]);
+    nd.prefix = sc[4]; nd.capitalization = sc[5]; nd.matching_case = sc[6]; nd.exact_bonus = sc[7]; nd.delimiter = sc[8];
+    nd.match_score = sc[0]; nd.gap_open = sc[2];
+    nd.raw = c.data(); nd.c = c.data(); nd.f = f.data(); nd.cf = cf.data();
+    return swl == 64 ? run_quad<64>(nd, upper, hay, (u32)m, include_prefix, form) : run_quad<32>(nd, upper, hay, (u32)m, include_prefix, form);
 }
 
 int kh_dp_unicode_multi(const u8* uc, const u8* uf, const u8* ulen, int rows, int is_u8, const u16* sc, const u8* hay, int m, int include_prefix, int swl, int form) {

@@ -17,7 +17,7 @@ struct uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 struct dim3 { unsigned x = 1, y = 1, z = 1; };
-static dim3 threadIdx{0, 0, 0};  // the harness steps it where a kernel fills a table cooperatively
+static thread_local dim3 threadIdx{0, 0, 0};  // the harness steps it where a kernel fills a table cooperatively (thread-local: the four-lane harness below runs a host thread per lane)
 static const dim3 blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
 typedef void* hipStream_t;
 
@@ -61,3 +61,36 @@ static inline void __builtin_amdgcn_s_setprio_host(int) {}
 #define FZB_HOST_SHIM 1
 static inline uint32_t fzb_host_rfl(uint32_t v) { return v; }
 #define __builtin_amdgcn_readfirstlane fzb_host_rfl
+
+// ---- four lanes in lockstep for dp_quad.h (tests/kernel_host/dp_host.cpp: a host thread per quad lane) ------------------------------------
+// __builtin_amdgcn_update_dpp with row_shr:K / row_ror:K, K = 4 or 8, on dp_quad.h's layout (quad lane L = row-lanes w + 4 L): every lane
+// reaches the same call in the same order (the control flow of a window is the same in its four lanes), so a call is: publish my source,
+// wait for the other three, read the source lane's (out of the row: keep `old`; rotate: wrap), wait again before the slots are reused.
+#include <atomic>
+struct FzbQuadBus {
+    std::atomic<int> arrived{0}, gen{0};
+    uint32_t slot[4];
+};
+static FzbQuadBus fzb_quad_bus;
+static thread_local int fzb_quad_lane = 0;
+static inline void fzb_quad_barrier() {
+    const int g = fzb_quad_bus.gen.load(std::memory_order_acquire);
+    if (fzb_quad_bus.arrived.fetch_add(1, std::memory_order_acq_rel) == 3) {
+        fzb_quad_bus.arrived.store(0, std::memory_order_relaxed);
+        fzb_quad_bus.gen.fetch_add(1, std::memory_order_release);
+    } else {
+        while (fzb_quad_bus.gen.load(std::memory_order_acquire) == g) {}
+    }
+}
+static inline int fzb_host_update_dpp(int old, int src, int ctrl, int, int, bool) {
+    fzb_quad_bus.slot[fzb_quad_lane] = (uint32_t)src;
+    fzb_quad_barrier();
+    const bool ror = (ctrl & 0x1F0) == 0x120;
+    int from = fzb_quad_lane - (ctrl & 0xF) / 4;
+    int v = old;
+    if (from >= 0) v = (int)fzb_quad_bus.slot[from];
+    else if (ror) v = (int)fzb_quad_bus.slot[from + 4];
+    fzb_quad_barrier();
+    return v;
+}
+#define __builtin_amdgcn_update_dpp fzb_host_update_dpp

@@ -20,10 +20,10 @@ def available():
 def build():
     so = os.path.join(HERE, "libkernel_host.so")
     srcs = [os.path.join(HERE, "dp_host.cpp"), os.path.join(HERE, "shim", "hip", "hip_runtime.h")] + [
-        os.path.join(CSRC, f) for f in ("dp_body.h", "dp_cf.h", "dp_cfm.h", "dp_unicode.h", "kernels_common.h", "fzb_internal.h")]
+        os.path.join(CSRC, f) for f in ("dp_body.h", "dp_cf.h", "dp_cfm.h", "dp_quad.h", "dp_unicode.h", "kernels_common.h", "fzb_internal.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call([CLANG, "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-I" + os.path.join(HERE, "shim"), "-I" + CSRC,
-                               "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-o", so, os.path.join(HERE, "dp_host.cpp")])
+                               "-I" + os.path.join(ROOT, "include"), "-Wno-unused-function", "-pthread", "-o", so, os.path.join(HERE, "dp_host.cpp")])
     return so
 
 
@@ -41,6 +41,7 @@ def lib():
         _lib.kh_unicode_regs.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_multi.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]
         _lib.kh_dp_multi_long.argtypes = _lib.kh_dp_multi.argtypes
+        _lib.kh_dp_quad.argtypes = _lib.kh_dp_multi.argtypes + [C.c_int]
         _lib.kh_window_typos.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_uint32)]
         _lib.kh_dp_batch.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint16), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     return _lib
@@ -105,6 +106,13 @@ def dp_multi_long(needle, hay, scoring, case_sensitive=False, include_prefix=Tru
     """score of a window of 1..1024 bytes under a LONG needle (any number of rows; NeedleLongDev): form 5 = first form, 6 = dp_cfm.h"""
     sc = (C.c_uint16 * 9)(*scoring)
     return lib().kh_dp_multi_long(needle, len(needle), int(case_sensitive), int(is_u8), sc, hay, len(hay), int(include_prefix), swl, form)
+
+
+def dp_quad(needle, hay, scoring, case_sensitive=False, include_prefix=True, swl=64, form=0, is_u8=True, long_needle=False):
+    """score of a window of 1..1024 bytes by dp_quad.h's four lanes (four host threads in lockstep): form 0 = row by row in registers, 1 = chunk
+    by chunk with the rows parked (LDS layout), 2 = the slab layout requested a row ahead; long_needle: through NeedleLongRows"""
+    sc = (C.c_uint16 * 9)(*scoring)
+    return lib().kh_dp_quad(needle, len(needle), int(case_sensitive), int(is_u8), sc, hay, len(hay), int(include_prefix), swl, form, int(long_needle))
 
 
 def window_typos(needle, hay, max_typos, case_sensitive=False):

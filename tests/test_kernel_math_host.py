@@ -235,6 +235,47 @@ def test_long_needle_windows_both_forms_match_the_oracle(swl):
     assert checked == 160
 
 
+@pytest.mark.parametrize("swl", [64, 32])
+def test_four_lanes_per_window_match_the_oracle(swl):
+    """dp_quad.h - dp_cfm.h's arithmetic spread over four lanes, the reference's shift_right_padded as DPP row shifts whose out-of-row lanes keep the
+    previous chunk's values - run by four host threads in lockstep (the shim's update_dpp): windows of 1..1024 bytes row by row with every
+    chunk in registers (form 0: k2_classes_all, k2d_dp_long_quad up to 3-8 chunks), chunk by chunk with the rows parked in the LDS layout (1)
+    and in the slab layout requested a row ahead (2); short needles by value and long ones through NeedleLongRows; default and random
+    scorings inside LaunchCfg::cfm_ok; windows ending on chunk and quad-lane boundaries"""
+    rng = random.Random(1300 + swl)
+    for it in range(260):
+        alpha = rng.choice([b"ab", b"abcA_", b"abcdefABCDEF_-/ 019", bytes(range(33, 127))])
+        long_needle = it % 4 == 3
+        n = rng.randint(64, 150) if long_needle else rng.randint(1, 20)
+        needle = _rnd(rng, n, alpha)
+        cs = rng.random() < 0.3
+        sc = DEF
+        if rng.random() < 0.45:
+            while True:
+                sc = [rng.randint(0, 40), rng.randint(0, 20), rng.randint(0, 20), rng.randint(0, 6), rng.randint(0, 30), rng.randint(0, 12), rng.randint(0, 12),
+                      rng.randint(0, 20), rng.randint(0, 12)]
+                worst = n * (sc[0] + sc[4] + sc[5] + sc[6] + sc[8]) + sc[1] + (200 + n) * sc[3] + 64
+                if 2 * sc[3] <= sc[1] and worst < 0x7C00:
+                    break
+        if it % 6 == 0:
+            m = rng.choice([1, swl // 4, swl // 4 + 1, swl // 2, swl - 1, swl, swl + 1, 2 * swl, 2 * swl + swl // 4, 3 * swl, 4 * swl + 1, 1024])
+        else:
+            m = rng.randint(1, min(1024, swl * rng.choice([1, 2, 3, 5, 16])))
+        hay = _rnd(rng, m, alpha)
+        if rng.random() < 0.6:
+            k = min(n, m)
+            for q, c in zip(sorted(rng.sample(range(m), k)), needle[rng.randint(0, n - k):][:k]):
+                hay = hay[:q] + bytes([c]) + hay[q + 1:]
+        ip = rng.random() < 0.5
+        u8 = _fits(n, sc)
+        want = O.sw_score(needle, hay, scoring=sc, case_sensitive=cs, include_prefix=ip, lanes=swl, is_u8=u8)
+        for form in (0, 1, 2):
+            if form == 2 and n < 2:  # (the slab form is the long-needle kernel's; with ONE row the host threads have no exchange between a park and its read)
+                continue
+            got = K.dp_quad(needle, hay, sc, cs, ip, swl, form, u8, long_needle)
+            assert got == want, (needle, hay, sc, cs, ip, swl, form, long_needle, got, want)
+
+
 @pytest.mark.parametrize("swl", [64, 32, 16, 8])
 def test_multi_chunk_last_chunk_padding_in_closed_form(swl):
     """dp_cfm.h with the last chunk's NUL lanes not computed (forms 7 / 8: the narrowest class of computed lanes that holds the window's tail,
