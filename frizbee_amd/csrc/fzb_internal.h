@@ -138,6 +138,12 @@ struct Workspace {
     size_t cap_items;   // capacity (in haystacks) of the first-level arrays
     size_t cap_level2;  // capacity of the second-level arrays (0 = not allocated)
     bool tables_stale;  // the matcher's needle / config changed since `table` and `dfa` were uploaded
+    // the five tables above are ONE device allocation (fixed offsets) behind ONE pinned staging buffer: a needle change is one asynchronous
+    // copy on the query's stream instead of up to five synchronous ones (45 -> ~ 8 us of a re-query after fzb_matcher_set_pattern)
+    u8* tables_blob;
+    u8* tables_host;
+    hipEvent_t tables_ev;   // recorded behind the last copy out of `tables_host` (waited for before it is refilled)
+    bool tables_ev_pending;
     // matched-indices path (fzb_match_list_indices)
     u32* trace_cells;   // per-wave score / match matrices of the traced scorer
     size_t trace_cells_words;

@@ -207,11 +207,50 @@ void fzb_config_default(fzb_config* out) {
 }
 
 static void free_workspace(Workspace& w) {
-    void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.table, w.dfa,
-                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists, w.uni_dfa, w.lcs_dfa, w.cdfa};
+    // (table / dfa / uni_dfa / lcs_dfa / cdfa point into tables_blob)
+    void* ptrs[] = {w.bitmap, w.tile_counts, w.surv_idx, w.win, w.overflow, w.dp_scratch, w.sort_tmp, w.sort_hist, w.bitmap2, w.tile_counts2, w.items2, w.win2, w.counters, w.tables_blob,
+                    w.trace_cells, w.bitmap_m, w.tile_counts_m, w.marg_list, w.reject_bits, w.tile_rejects, w.rej_prefix, w.cls_win, w.cls_lists};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (w.tables_ev_pending) (void)hipEventSynchronize(w.tables_ev);
+    if (w.tables_host) (void)hipHostFree(w.tables_host);
+    if (w.tables_ev) (void)hipEventDestroy(w.tables_ev);
     w = Workspace{};
+}
+
+// The matcher's byte tables on the device: [filter table 2 KB | subsequence DFA | unicode DFA | LCS automaton | class-composite automaton], each
+// with room for any needle's (fzb_matcher_set_pattern re-uploads in place).  One copy out of the pinned staging buffer, asynchronous on `st`
+// (the stream the query's kernels follow on) - or synchronous when there is no stream to order it on (fzb_matcher_reserve).
+namespace {
+constexpr size_t TB_TABLE = 0, TB_DFA = 2048, TB_SLOT = 256 * 256 + 128, TB_UNI = TB_DFA + TB_SLOT, TB_LCS = TB_UNI + TB_SLOT, TB_CDFA = TB_LCS + TB_SLOT,
+                 TB_TOTAL = TB_CDFA + 256 + 16384 + 128;
+}
+static int upload_tables(fzb_matcher* m, hipStream_t st, bool have_stream) {
+    Workspace& w = m->ws;
+    if (w.tables_ev_pending) {  // (the previous copy out of the staging buffer: long done unless two needle changes follow each other without a query's end between)
+        HIPCHK(hipEventSynchronize(w.tables_ev));
+        w.tables_ev_pending = false;
+    }
+    size_t end = TB_DFA;
+    memcpy(w.tables_host + TB_TABLE, m->table.data(), 256 * 8);
+    auto put = [&](size_t off, const std::vector<u8>& v) {
+        if (v.empty()) return;
+        memcpy(w.tables_host + off, v.data(), v.size());
+        end = std::max(end, off + v.size());
+    };
+    put(TB_DFA, m->dfa);
+    put(TB_UNI, m->uni_dfa);
+    put(TB_LCS, m->lcs_dfa);
+    put(TB_CDFA, m->cdfa);
+    if (have_stream) {
+        HIPCHK(hipMemcpyAsync(w.tables_blob, w.tables_host, end, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(w.tables_ev, st));
+        w.tables_ev_pending = true;
+    } else {
+        HIPCHK(hipMemcpy(w.tables_blob, w.tables_host, end, hipMemcpyHostToDevice));
+    }
+    w.tables_stale = false;
+    return FZB_OK;
 }
 
 // ---- fzb_matcher_create, piece by piece ------------------------------------------------------------------------------------------
@@ -994,7 +1033,7 @@ static bool typo_fast_path_configured(const fzb_matcher* m) {
     return !m->literal_mode && !m->empty && m->lc.filter_mode == 2 && !m->nd.unicode && m->lc.cf_ok && (m->lc.sw_lanes == 64 || m->lc.sw_lanes == 32);
 }
 
-static int ensure_workspace(fzb_matcher* m, size_t count) {
+static int ensure_workspace(fzb_matcher* m, size_t count, hipStream_t st = nullptr, bool have_stream = false) {
     Workspace& w = m->ws;
     const bool need_l2 = !m->lc.filter_exact;
     const bool need_marg = typo_fast_path_configured(m);
@@ -1002,14 +1041,7 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     // (cap_items >= count + FZB_UNICODE_FWD_CAP: run_pipeline anchors the queue's back at count + FZB_UNICODE_FWD_CAP entries - a workspace
     // allocated for a smaller range holds count0 + count0/8 + 4096 entries and must not be reused for a range within 4096 of that)
     if (w.cap_items >= count + FZB_UNICODE_FWD_CAP && (!need_l2 || w.cap_level2 >= count) && (!need_marg || w.cap_marg >= count) && (!need_cls || w.cap_cls >= count) && w.counters) {
-        if (w.tables_stale) {  // fzb_matcher_set_pattern / set_config kept the device buffers: only the two small tables change
-            HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
-            if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
-            if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
-            if (!m->lcs_dfa.empty()) HIPCHK(hipMemcpy(w.lcs_dfa, m->lcs_dfa.data(), m->lcs_dfa.size(), hipMemcpyHostToDevice));
-            if (!m->cdfa.empty()) HIPCHK(hipMemcpy(w.cdfa, m->cdfa.data(), m->cdfa.size(), hipMemcpyHostToDevice));
-            w.tables_stale = false;
-        }
+        if (w.tables_stale) return upload_tables(m, st, have_stream);  // fzb_matcher_set_pattern / set_config kept the device buffers: only the tables change
         return FZB_OK;
     }
     free_workspace(w);
@@ -1020,16 +1052,19 @@ static int ensure_workspace(fzb_matcher* m, size_t count) {
     HIPCHK(dev_alloc((void**)&w.surv_idx, cap * 4));
     HIPCHK(dev_alloc((void**)&w.overflow, cap * 16));
     HIPCHK(dev_alloc((void**)&w.counters, 64));
-    HIPCHK(dev_alloc((void**)&w.table, 256 * 8));
-    HIPCHK(hipMemcpy(w.table, m->table.data(), 256 * 8, hipMemcpyHostToDevice));
-    HIPCHK(dev_alloc((void**)&w.dfa, (size_t)256 * 256 + 16));  // room for any needle's automaton (short needles: 64 states; a long needle's: up to 201): set_pattern re-uploads in place
-    if (!m->dfa.empty()) HIPCHK(hipMemcpy(w.dfa, m->dfa.data(), m->dfa.size(), hipMemcpyHostToDevice));
-    HIPCHK(dev_alloc((void**)&w.uni_dfa, 256 * 256 + 16));  // room for any unicode DFA (<= 255 states + 1): set_pattern re-uploads in place
-    if (!m->uni_dfa.empty()) HIPCHK(hipMemcpy(w.uni_dfa, m->uni_dfa.data(), m->uni_dfa.size(), hipMemcpyHostToDevice));
-    HIPCHK(dev_alloc((void**)&w.lcs_dfa, 256 * 256 + 16));  // room for any LCS automaton (<= 226 states): set_pattern re-uploads in place
-    if (!m->lcs_dfa.empty()) HIPCHK(hipMemcpy(w.lcs_dfa, m->lcs_dfa.data(), m->lcs_dfa.size(), hipMemcpyHostToDevice));
-    HIPCHK(dev_alloc((void**)&w.cdfa, 256 + 16384 + 64));  // room for any class-composite automaton: set_pattern re-uploads in place
-    if (!m->cdfa.empty()) HIPCHK(hipMemcpy(w.cdfa, m->cdfa.data(), m->cdfa.size(), hipMemcpyHostToDevice));
+    // (room for any needle's automata: short needles 64 states, a long needle's subsequence DFA up to 201, unicode <= 255 + 1, LCS <= 226)
+    HIPCHK(dev_alloc((void**)&w.tables_blob, TB_TOTAL));
+    HIPCHK(hipHostMalloc((void**)&w.tables_host, TB_TOTAL, hipHostMallocDefault));
+    HIPCHK(hipEventCreateWithFlags(&w.tables_ev, hipEventDisableTiming));
+    w.table = (u64*)(w.tables_blob + TB_TABLE);
+    w.dfa = w.tables_blob + TB_DFA;
+    w.uni_dfa = w.tables_blob + TB_UNI;
+    w.lcs_dfa = w.tables_blob + TB_LCS;
+    w.cdfa = w.tables_blob + TB_CDFA;
+    {
+        const int rc_t = upload_tables(m, st, have_stream);
+        if (rc_t) return rc_t;
+    }
     w.cap_items = cap;
     if (need_l2) {
         HIPCHK(dev_alloc((void**)&w.win, cap * 8));
@@ -1616,7 +1651,7 @@ static int run_pipeline(fzb_matcher* m, const fzb_corpus* c, size_t first, size_
     hipStream_t st = (hipStream_t)stream;
     int rc = fzb_bind_device(m);
     if (rc) return rc;
-    rc = ensure_workspace(m, count);
+    rc = ensure_workspace(m, count, st, true);
     if (rc) return rc;
     Workspace& w = m->ws;
     const LaunchCfg& lc = m->lc;
@@ -1698,7 +1733,7 @@ int fzb_sorted_range_device(fzb_matcher* m, const fzb_corpus* c, size_t first, s
     OrderPlan plan;
     int rc;
     // (the range workspace first: growing it releases every workspace buffer, the sort's included)
-    if (!m->empty && count != 0 && ((rc = fzb_bind_device(m)) || (rc = ensure_workspace(m, count)))) return rc;
+    if (!m->empty && count != 0 && ((rc = fzb_bind_device(m)) || (rc = ensure_workspace(m, count, (hipStream_t)stream, true)))) return rc;
     if ((rc = fzb_order_begin(m, m->empty || count == 0 ? 0 : cap, (fzb_match_rec*)dev_out, &plan))) return rc;
     rc = fzb_match_list_device(m, c, first, count, index_offset, (fzb_match*)plan.in, plan.via_tmp ? cap : capacity, dev_count, stream);
     if (rc) return rc;

@@ -20,6 +20,7 @@ struct dim3 { unsigned x = 1, y = 1, z = 1; };
 static thread_local dim3 threadIdx{0, 0, 0};  // the harness steps it where a kernel fills a table cooperatively (thread-local: the four-lane harness below runs a host thread per lane)
 static const dim3 blockIdx{0, 0, 0}, blockDim{1, 1, 1}, gridDim{1, 1, 1};
 typedef void* hipStream_t;
+typedef void* hipEvent_t;
 
 // one-thread "wave": the cross-lane helpers degenerate
 static inline uint64_t __ballot(int p) { return p ? 1ull : 0ull; }
