@@ -148,26 +148,22 @@ def test_random_triples_unicode_scorer(lanes):
 
 
 @pytest.fixture
-def forced_round4_paths():
-    """The two data paths round 4 added that the lists above are too small (or too long) to reach by default: the filter -> scorer
-    handoff over the interleaved view (FZB_HANDOFF_MIN_TILES=0: shipped for lists of 4096 tiles and more) and the thread-per-haystack
-    multi-chunk unicode scorer (FZB_UNICODE_MULTI=1: shipped from 131 072 queued windows on)."""
+def forced_unicode_multi():
+    """The thread-per-haystack multi-chunk unicode scorer, which the lists below are too small to reach by default (FZB_UNICODE_MULTI=1: shipped
+    from 32 768 queued windows on)."""
     import os
-    os.environ["FZB_HANDOFF_MIN_TILES"] = "0"
     os.environ["FZB_UNICODE_MULTI"] = "1"
     F.lib().fzb_debug_reload_knobs()
     yield
-    os.environ.pop("FZB_HANDOFF_MIN_TILES", None)
     os.environ.pop("FZB_UNICODE_MULTI", None)
     F.lib().fzb_debug_reload_knobs()
 
 
 @pytest.mark.parametrize("lanes", [64, 32, 16])
-def test_random_triples_through_the_view_handoff_and_the_unicode_multi_chunk_scorer(lanes, forced_round4_paths):
+def test_random_triples_through_the_view_filter_and_the_unicode_multi_chunk_scorer(lanes, forced_unicode_multi):
     rng = np.random.default_rng(3000 + lanes)
     total = 0
-    # lists whose longest haystack is 33..256 bytes get the interleaved view; with the handoff forced the view filter stages the accepted
-    # haystacks (LDS block, its overflow into direct stores, tiles whose 16 KB block runs out: every second haystack carries the needle)
+    # lists whose longest haystack is 33..256 bytes get the interleaved view (every second haystack carries the needle)
     view_pool = np.array([0, 2, 9, 30, 33, 48, 64, 65, 70, 100, 127, 128, 129, 200, 255, 256])
     for si, (sc, what) in enumerate(SCORINGS):
         for ni, needle in enumerate(NEEDLES):
@@ -175,7 +171,7 @@ def test_random_triples_through_the_view_handoff_and_the_unicode_multi_chunk_sco
                 continue
             data, ends = make_list(rng, needle, 30_000, view_pool)
             casing = "Respect" if (si + ni) % 5 == 4 else "Smart"
-            total += check(needle, data, ends, lanes, (lanes, "view + handoff", what, needle, casing), max_typos=0, scoring=sc, casing=casing)
+            total += check(needle, data, ends, lanes, (lanes, "view filter", what, needle, casing), max_typos=0, scoring=sc, casing=casing)
     assert total >= 900_000, total
     utotal = 0
     for sc, what in (SCORINGS[0], SCORINGS[1], SCORINGS[2], SCORINGS[4], SCORINGS[5], SCORINGS[6]):
