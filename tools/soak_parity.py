@@ -1,6 +1,6 @@
 """Parity soak on a GPU box: random needles, scorings, typo budgets, lane widths and list shapes - fresh seeds every run - HIP path against the
 oracle until the time budget is spent (tests/test_gpu_fuzz_isa.py's generators and checker, which raise with the first differing record and its
-haystack).  Usage: python tools/soak_parity.py [seconds=600] [seed=time]   Prints one line per 50 lists and a summary; exit code 1 on a difference."""
+haystack).  Usage: python tools/soak_parity.py [seconds=600] [seed=time | reuse]   Prints one line per 50 lists and a summary; exit code 1 on a difference."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +8,29 @@ import numpy as np
 import test_gpu_fuzz_isa as T
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
-seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+seed = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2] != "reuse" else int(time.time())
+REUSE = "reuse" in sys.argv[2:]  # one long-lived matcher per lane width, re-targeted by set_config / set_pattern: the workspace and table-upload paths of a session
+if REUSE:
+    import frizbee_amd as F, oracle_lib as O
+    _live = {}
+    def _check_reuse(needle, data, ends, lanes, tag, **cfg):
+        pf, sw8, sw16 = T.LANE_TRIPLES[lanes]
+        om = O.Matcher(needle, lanes=(pf, sw8, sw16), sort="IndexAsc", **cfg)
+        fc = F.Config(max_typos=cfg.get("max_typos", 0), scoring=F.Scoring(*cfg.get("scoring", T.DEFAULT)), pf_lanes=pf,
+                      unicode=F.UnicodeMatching[cfg.get("unicode", "Smart")], casing=F.CaseMatching[cfg.get("casing", "Smart")])
+        fm = _live.get(lanes)
+        if fm is None:
+            fm = _live[lanes] = F.Matcher(needle, fc)
+        else:
+            fm.set_config(fc)
+            fm.set_pattern(needle)
+        want = om.match_packed(data, ends)
+        got = fm.match_list_into(F.Corpus(packed=(data, ends)))
+        if got.tolist() != want.tolist():
+            bad = next((i for i in range(min(len(got), len(want))) if got[i].tolist() != want[i].tolist()), min(len(got), len(want)))
+            raise AssertionError((tag, "records", len(got), len(want), "first difference at", bad, got[bad:bad + 1].tolist(), want[bad:bad + 1].tolist()))
+        return len(ends)
+    T.check = _check_reuse
 rng = np.random.default_rng(seed)
 print(f"soak seed {seed}, {budget:.0f} s", flush=True)
 ALPHA = b"abcdefABCDEF_-/ .019xyzXYZ"
