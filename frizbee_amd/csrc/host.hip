@@ -640,16 +640,22 @@ static void build_cdfa(fzb_matcher* m) {
                 for (int i = 0; i < G; i++) KG *= K;
                 m->cdfa.assign(((256 + (size_t)fstates * KG) + 15) & ~(size_t)15, 0);
                 for (int b = 0; b < 256; b++) m->cdfa[b] = (u8)cls[b];
+                // two transitions composed first (c0, the least significant digit, is consumed first), then - G = 4 - two of those: no division per entry
+                const size_t K2 = K * K;
+                std::vector<u8> t2((size_t)fstates * K2);
                 for (int stt = 0; stt < fstates; stt++)
-                    for (size_t off = 0; off < KG; off++) {
-                        int cur = stt;
-                        size_t rest = off;
-                        for (int i = 0; i < G; i++) {  // c0 (the least significant digit) is consumed first
-                            cur = (*fa)[(size_t)cur * 256 + rep[rest % K]];
-                            rest /= K;
+                    for (size_t c1 = 0; c1 < K; c1++)
+                        for (size_t c0 = 0; c0 < K; c0++)
+                            t2[(size_t)stt * K2 + c0 + K * c1] = (*fa)[(size_t)(*fa)[(size_t)stt * 256 + rep[c0]] * 256 + rep[c1]];
+                u8* comp = m->cdfa.data() + 256;
+                if (G == 2) memcpy(comp, t2.data(), t2.size());
+                else
+                    for (int stt = 0; stt < fstates; stt++)
+                        for (size_t hi = 0; hi < K2; hi++) {
+                            u8* row = comp + (size_t)stt * KG + K2 * hi;
+                            const u8* first = &t2[(size_t)stt * K2];
+                            for (size_t lo = 0; lo < K2; lo++) row[lo] = t2[(size_t)first[lo] * K2 + hi];
                         }
-                        m->cdfa[256 + (size_t)stt * KG + off] = (u8)cur;
-                    }
                 m->cdfa_src = src;
                 m->cdfa_K = (int)K;
                 m->cdfa_G = G;
