@@ -566,24 +566,24 @@ static void build_lcs_dfa(fzb_matcher* m) {
             mask_of[b] = (int)q;
         }
         std::vector<u64> states{mask};  // V0: all ones in the low `rows` bits
-        std::unordered_map<u64, int> id{{mask, 0}};
-        std::vector<std::vector<int>> next;
+        states.reserve(256);
+        const size_t nm = masks.size();
+        std::vector<int> next;  // [state][mask]
+        next.reserve(256 * nm);
         bool ok = true;
         for (size_t q = 0; q < states.size() && ok; q++) {
             const u64 v = states[q];
-            std::vector<int> row(masks.size());
-            for (size_t t = 0; t < masks.size(); t++) {
+            for (size_t t = 0; t < nm; t++) {
                 const u64 u = v & masks[t];
                 const u64 nv = ((v + u) | (v & ~masks[t])) & mask;
-                auto it = id.find(nv);
-                if (it == id.end()) {
-                    it = id.emplace(nv, (int)states.size()).first;
+                size_t id = 0;  // (at most 226 states: a linear search beats a hash table's allocations)
+                while (id < states.size() && states[id] != nv) id++;
+                if (id == states.size()) {
                     states.push_back(nv);
                     if (states.size() > 226) ok = false;
                 }
-                row[t] = it->second;
+                next.push_back((int)id);
             }
-            next.push_back(row);
         }
         if (ok) {
             const int ns = (int)states.size();
@@ -598,7 +598,7 @@ static void build_lcs_dfa(fzb_matcher* m) {
             }
             m->lcs_dfa.assign((size_t)ns * 256, 0);
             for (int q = 0; q < ns; q++)
-                for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[q][mask_of[b]]];
+                for (int b = 0; b < 256; b++) m->lcs_dfa[(size_t)renum[q] * 256 + b] = (u8)renum[next[(size_t)q * nm + mask_of[b]]];
             m->lcs_states = ns;
             m->lcs_acc_lo = acc;
         }
