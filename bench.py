@@ -511,6 +511,35 @@ def c4_sharded_block(F, synth, dist, dev, rank, world, total, steps, stream):
     return row
 
 
+def cabi_rccl_block(F, dist, dev, rank, world, m, corpus, index_offset, merged_ref, k):
+    """`match_list_parallel` with one process per GPU through the C ABI alone: fzb_shard_comm (its own RCCL communicator, created from an id that
+    rank 0 draws and torch.distributed merely carries to the others) + fzb_match_list_parallel_rccl per step - run lengths all-gathered, exactly the
+    records moved to rank 0 in one RCCL group, one device-side ordering, one copy to the host."""
+    from frizbee_amd.distributed import RcclShardComm
+    comm = RcclShardComm(rank, world)
+    got = None
+    for _ in range(2):  # (untimed: exchange buffers, the root's sort buffers and the pinned result are allocated on first use)
+        got = comm.match_list_parallel(m, corpus, index_offset, copy=False)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(k):
+        got = comm.match_list_parallel(m, corpus, index_offset, copy=False)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    sent, received = comm.last_exchange_bytes()
+    row = {"ms_per_step": dt / k * 1e3, "steps": k, "merged_len": int(len(got)) if rank == 0 else None,
+           "equals_host_merge": bool(got.tobytes() == merged_ref.tobytes()) if rank == 0 else None,
+           "record_bytes_into_root_per_step": received if rank == 0 else None,
+           "what": "fzb_match_list_parallel_rccl on every rank, every step (synchronous): pipeline into the communicator's buffer, ncclAllGather of the run lengths (the one "
+                   "host synchronisation before the result), ONE RCCL group of sends / receives of exactly the records to rank 0, concatenation + stable radix sort on rank 0's "
+                   "device, one D2H.  torch.distributed only carried the 128-byte communicator id"}
+    del got
+    comm.close()
+    return row
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -916,6 +945,29 @@ def main():
                 bound = max(res["cpu_baseline"]["value"], res["cpu_baseline"]["linear_bound"]["haystacks_per_s"], res["cpu_baseline"]["published_bound"]["haystacks_per_s"])
                 res["gpu_over_cpu_bound"] = {"ratio": res["value"] / bound,
                                              "against": "the largest of: measured port, single-thread x physical cores, published per-thread x physical cores"}
+    if use_dist and not rehearsal and os.environ.get("FZB_BENCH_CABI_RCCL", "1") != "0":
+        # ---- the ordered query through the C ABI ALONE (fzb_match_list_parallel_rccl, csrc/host_rccl.hip: RCCL opened by the library itself, what a
+        # Rust host with one process per GPU binds) - untimed for `value`, reported beside e2e_sorted_merge.  It has never run on more than one GPU, so it
+        # runs LAST, after everything else of the line exists, under a watchdog: if it has not come back in time every rank leaves and rank 0 prints the
+        # line without it, saying so.
+        import threading
+
+        def bail():
+            if rank == 0:
+                res["e2e_cabi_rccl"] = {"error": "fzb_match_list_parallel_rccl did not return within 120 s (watchdog): everything else in this line was measured before it started"}
+                print(json.dumps(res), file=json_out, flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(120.0, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            cabi = cabi_rccl_block(F, dist, dev, rank, world, m, corpus, index_offset, merged if rank == 0 else None, max(3, min(10, args.steps)))
+        except Exception as ex_:  # reported, never fatal for the line
+            cabi = {"error": repr(ex_)}
+        dog.cancel()
+        if rank == 0:
+            res["e2e_cabi_rccl"] = cabi
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -116,6 +116,8 @@ SYMBOLS = [
     "fzb_device_count", "fzb_shard_ranges", "fzb_corpus_upload_sharded", "fzb_sharded_corpus_free", "fzb_sharded_corpus_len", "fzb_sharded_corpus_shards",
     "fzb_sharded_corpus_shard", "fzb_match_list_parallel_sharded", "fzb_debug_lcs_dfa_accepts", "fzb_debug_cdfa_state",
     "fzb_merge_shard_runs", "fzb_corpus_build_view", "fzb_debug_reload_knobs", "fzb_matcher_shard_report",
+    "fzb_rccl_unique_id", "fzb_shard_comm_create", "fzb_shard_comm_free", "fzb_shard_comm_rank", "fzb_shard_comm_world", "fzb_match_list_parallel_rccl",
+    "fzb_shard_comm_last_exchange",
 ]
 
 
@@ -182,6 +184,13 @@ def lib():
         l.fzb_matcher_shard_report.restype = C.c_char_p
         l.fzb_merge_shard_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         l.fzb_corpus_build_view.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        l.fzb_rccl_unique_id.argtypes = [C.c_void_p]
+        l.fzb_shard_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        l.fzb_shard_comm_free.argtypes = [C.c_void_p]
+        l.fzb_shard_comm_rank.argtypes = [C.c_void_p]
+        l.fzb_shard_comm_world.argtypes = [C.c_void_p]
+        l.fzb_match_list_parallel_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        l.fzb_shard_comm_last_exchange.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         l.fzb_debug_lcs_dfa_accepts.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
         l.fzb_debug_cdfa_state.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32)]
         _lib = l

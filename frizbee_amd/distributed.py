@@ -10,7 +10,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import MATCH_DTYPE, SortStrategy, k_merge_matches, radix_sort_matches
+import ctypes as C
+
+from . import MATCH_DTYPE, SortStrategy, _check, _take, k_merge_matches, lib, radix_sort_matches
 
 
 def shard_range(n_total, rank, world):
@@ -270,3 +272,62 @@ def merge_shard_runs(runs, sort):
             r = radix_sort_matches(r)
         prepared.append(r)
     return k_merge_matches(sort, prepared)
+
+
+class RcclShardComm:
+    """The multi-process form BELOW the C ABI (fzb_shard_comm, csrc/host_rccl.hip): one process per GPU, the runs exchanged by RCCL
+    inside libfrizbee_hip.so itself - what a Rust host binds; torch.distributed is used here only to carry the
+    128-byte communicator id from rank 0 to the other ranks (any channel does).  `match_list_parallel(matcher, shard, index_offset)` is
+    `Matcher::match_list_parallel` (src/matcher/parallel.rs:18-89) over the WHOLE list: the ordered result on rank 0 (every rank with
+    all_ranks=True), an empty array elsewhere."""
+
+    ID_BYTES = 128
+
+    def __init__(self, rank=None, world=None, unique_id=None, group=None):
+        if rank is None or world is None:
+            rank, world = (dist.get_rank(group), dist.get_world_size(group)) if dist.is_initialized() else (0, 1)
+        if unique_id is None:
+            unique_id = self.unique_id() if rank == 0 else bytes(self.ID_BYTES)
+            if world > 1:
+                # the one out-of-band step: rank 0's id to everyone (a CPU tensor for gloo, a device tensor for nccl)
+                on_dev = dist.get_backend(group) == "nccl"
+                t = torch.frombuffer(bytearray(unique_id), dtype=torch.uint8)
+                t = t.cuda() if on_dev else t
+                dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                unique_id = bytes(t.cpu().numpy().tobytes())
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError(f"the communicator id has {self.ID_BYTES} bytes")
+        self.h = C.c_void_p()
+        _check(lib().fzb_shard_comm_create(C.c_char_p(bytes(unique_id)), int(rank), int(world), C.byref(self.h)))  # collective
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        """fzb_rccl_unique_id: 128 opaque bytes, drawn on rank 0."""
+        buf = (C.c_uint8 * RcclShardComm.ID_BYTES)()
+        _check(lib().fzb_rccl_unique_id(buf))
+        return bytes(buf)
+
+    def match_list_parallel(self, matcher, shard, index_offset, all_ranks=False, copy=True):
+        """fzb_match_list_parallel_rccl (collective): `shard` = this rank's resident Corpus, `index_offset` = its first global index."""
+        out, n = C.c_void_p(), C.c_size_t()
+        _check(lib().fzb_match_list_parallel_rccl(matcher.h, shard.h, int(index_offset), self.h, 1 if all_ranks else 0, C.byref(out), C.byref(n)))
+        return _take(out, n, copy)
+
+    def last_exchange_bytes(self):
+        """(sent, received) record bytes of this rank's last query."""
+        b = (C.c_uint64 * 2)()
+        _check(lib().fzb_shard_comm_last_exchange(self.h, b))
+        return int(b[0]), int(b[1])
+
+    def close(self):
+        if self.h:
+            lib().fzb_shard_comm_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+

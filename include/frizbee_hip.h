@@ -212,6 +212,35 @@ const char* fzb_matcher_shard_report(const fzb_matcher* m);
 int fzb_merge_shard_runs(fzb_matcher* m, const void* const* dev_runs, const uint32_t* const* dev_counts, const size_t* run_caps, size_t nruns, void* stream,
                          fzb_match** out, size_t* out_len);
 
+/* `Matcher::match_list_parallel` (src/matcher/parallel.rs:18-89) with ONE PROCESS PER GPU: the workers of parallel.rs:43-64 are the
+ * ranks, each holding its contiguous share of the list as its own corpus (fzb_shard_ranges gives the boundaries), and what the
+ * reference's workers hand back through shared memory (parallel.rs:66-87) travels by RCCL over xGMI below this boundary - nothing above
+ * it (Rust, C++, Python) links a collective library.  RCCL is opened at run time (librccl.so.1): FZB_ERR_HIP with the loader's message
+ * when the process cannot get one.
+ *   fzb_rccl_unique_id       rank 0 draws the communicator's id (ncclGetUniqueId); the HOST moves these 128 bytes to the other ranks by
+ *                            whatever channel started them (environment, file, socket, MPI): the one out-of-band step
+ *   fzb_shard_comm_create    COLLECTIVE (every rank of `world` calls it, ncclCommInitRank) on the rank's current device; owns a stream
+ *                            and the exchange buffers, which grow on demand and are reused by later queries
+ *   fzb_match_list_parallel_rccl   COLLECTIVE: rank g scores `shard` (its share, records numbered from index_offset = the share's first
+ *                            global index), the runs' lengths are all-gathered (8 bytes per rank, the call's one host synchronisation
+ *                            before the result), then ONE RCCL group moves every run - exactly its records, not a capacity - to rank 0
+ *                            (flags = 0), or to every rank (FZB_GATHER_ALL: the all-gather of variable-length runs); a receiver
+ *                            concatenates in rank order (= ascending index order), applies `match_list`'s ordering once on its device
+ *                            (src/matcher/mod.rs:215-221) and copies the list to its host: *out / *out_len = the list
+ *                            `match_list_parallel` returns for the WHOLE list, to be freed with fzb_matches_free; on a rank that does
+ *                            not receive, *out = NULL and *out_len = 0.  Every rank must pass a matcher of the same needle and config.
+ *   fzb_shard_comm_last_exchange   out_bytes[0] / [1] = record bytes this rank sent / received in its last query. */
+#define FZB_RCCL_ID_BYTES 128
+typedef struct fzb_shard_comm fzb_shard_comm;
+enum { FZB_GATHER_ROOT = 0, FZB_GATHER_ALL = 1 };
+int fzb_rccl_unique_id(uint8_t out_id[FZB_RCCL_ID_BYTES]);
+int fzb_shard_comm_create(const uint8_t id[FZB_RCCL_ID_BYTES], int rank, int world, fzb_shard_comm** out);
+void fzb_shard_comm_free(fzb_shard_comm* comm);
+int fzb_shard_comm_rank(const fzb_shard_comm* comm);
+int fzb_shard_comm_world(const fzb_shard_comm* comm);
+int fzb_match_list_parallel_rccl(fzb_matcher* m, const fzb_corpus* shard, uint32_t index_offset, fzb_shard_comm* comm, int flags, fzb_match** out, size_t* out_len);
+int fzb_shard_comm_last_exchange(const fzb_shard_comm* comm, uint64_t out_bytes[2]);
+
 /* `MatchIndices` (src/lib.rs:189-199): a Match plus the haystack byte positions that matched the needle, in reverse
  * order.  positions[positions_begin .. positions_begin + positions_len) of the array returned next to the records. */
 typedef struct fzb_match_indices {

@@ -89,6 +89,12 @@ extern "C" {
                             out: *mut *mut FzbMatch, out_len: *mut usize) -> c_int;
     #[allow(dead_code)]
     fn fzb_corpus_build_view(c: *mut c_void, out_built: *mut c_int) -> c_int;
+    // one process per GPU: the runs travel by RCCL below the boundary (csrc/host_rccl.hip)
+    fn fzb_rccl_unique_id(out_id: *mut u8) -> c_int;
+    fn fzb_shard_comm_create(id: *const u8, rank: c_int, world: c_int, out: *mut *mut c_void) -> c_int;
+    fn fzb_shard_comm_free(comm: *mut c_void);
+    fn fzb_match_list_parallel_rccl(m: *mut c_void, shard: *const c_void, index_offset: u32, comm: *mut c_void, flags: c_int, out: *mut *mut FzbMatch,
+                                    out_len: *mut usize) -> c_int;
 }
 
 /// The reference panics (`assert!`) where the ABI returns FZB_ERR_PANIC, with the same text; every other code is a backend
@@ -237,6 +243,18 @@ impl MatcherHip {
         v
     }
 
+    /// `match_list_parallel` with ONE PROCESS PER GPU: this rank scores `shard` (its contiguous share of the list, first global index
+    /// `index_offset`), the library all-gathers the run lengths and moves the runs by RCCL over xGMI to rank 0 (`to_all`: to every
+    /// rank), a receiver orders the whole list once on its device.  Collective: every rank of the communicator calls it with a matcher
+    /// of the same needle and config.  Returns the whole list's `match_list` result on a receiver, an empty Vec elsewhere.
+    pub fn match_list_parallel_rccl(&mut self, shard: &HipCorpus, index_offset: u32, comm: &mut ShardComm, to_all: bool) -> Vec<Match> {
+        let (mut out, mut n) = (std::ptr::null_mut(), 0usize);
+        check(unsafe { fzb_match_list_parallel_rccl(self.handle, shard.handle, index_offset, comm.handle, to_all as c_int, &mut out, &mut n) });
+        let mut v = Vec::with_capacity(n);
+        copy_out(out, n, &mut v);
+        v
+    }
+
     /// How the runs of the last `match_list_parallel_sharded` reached the root device: gather form and, per shard, same device /
     /// peer access enabled (xGMI, device to device) / peer access refused (the runtime stages the copy through host memory).
     pub fn shard_report(&self) -> String {
@@ -267,3 +285,30 @@ impl Drop for MatcherHip {
 }
 // `Matcher: Send` in the reference; the handle owns device buffers and is used from one thread at a time (`&mut self`)
 unsafe impl Send for MatcherHip {}
+
+
+/// The communicator of the one-process-per-GPU form (`fzb_shard_comm`: an RCCL communicator, a stream and the exchange buffers on the
+/// rank's current device).  `ShardComm::unique_id()` on rank 0, the 128 bytes to the other ranks by whatever started them (environment,
+/// file, socket, MPI), then `ShardComm::new(&id, rank, world)` on every rank (collective).
+pub struct ShardComm {
+    handle: *mut c_void,
+}
+
+impl ShardComm {
+    pub fn unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        check(unsafe { fzb_rccl_unique_id(id.as_mut_ptr()) });
+        id
+    }
+    pub fn new(id: &[u8; 128], rank: usize, world: usize) -> Self {
+        let mut handle = std::ptr::null_mut();
+        check(unsafe { fzb_shard_comm_create(id.as_ptr(), rank as c_int, world as c_int, &mut handle) });
+        ShardComm { handle }
+    }
+}
+
+impl Drop for ShardComm {
+    fn drop(&mut self) {
+        unsafe { fzb_shard_comm_free(self.handle) }
+    }
+}

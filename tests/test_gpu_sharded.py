@@ -217,3 +217,133 @@ def test_two_rank_rehearsal_of_the_bench_on_one_gpu():
     (name, c4), = j["configs"].items()
     assert "configs[3]" in name and c4["n_gpus"] == 2 and c4["haystacks"] == 2_000_000 and all(v is True for k, v in c4["checks"].items() if k != "oracle_items_per_shard"), c4["checks"]
     assert abs(c4["shards"][0]["bytes"] - c4["shards"][1]["bytes"]) <= 256 and c4["shards"][0]["range"][1] == c4["shards"][1]["range"][0]
+
+
+# ---- one process per GPU BELOW the C ABI: fzb_shard_comm / fzb_match_list_parallel_rccl (csrc/host_rccl.hip) ------------------------------
+
+_RCCL_CODE = r'''
+import os, sys, threading, time, faulthandler
+faulthandler.dump_traceback_later(240, exit=True)   # a hang shows where, and ends
+sys.path[:0] = [%(root)r, %(tests)r, %(tools)r]
+import numpy as np
+import frizbee_amd as F, oracle_lib as O, synth
+from frizbee_amd.distributed import RcclShardComm, shard_range, shard_ranges_by_bytes
+WORLD = int(sys.argv[1])
+T0 = time.time()
+def shards_of(data, ends, ranges):
+    out = []
+    for lo, hi in ranges:
+        b0 = int(ends[lo - 1]) if lo else 0
+        b1 = int(ends[hi - 1]) if hi else 0
+        out.append(F.Corpus(packed=(data[b0:b1].copy(), (ends[lo:hi] - np.uint64(b0)).astype(np.uint64))))
+    return out
+def run_world(ranges, shards, needle, kw, all_ranks, uid):
+    res, errs = [None] * WORLD, []
+    def rank_main(r):
+        try:
+            comm = RcclShardComm(rank=r, world=WORLD, unique_id=uid)
+            m = F.Matcher(needle, F.Config(pf_lanes=64, sw_lanes=64, **kw))
+            for rep in range(2):  # the second query reuses the communicator's buffers
+                res[r] = (comm.match_list_parallel(m, shards[r], ranges[r][0], all_ranks=all_ranks), comm.last_exchange_bytes())
+            comm.close()
+        except BaseException as e:
+            errs.append((r, repr(e)))
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(WORLD)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    return res
+cases = 0
+# (a) the C2 shape cut by count, (b) a ragged list cut by bytes with one EMPTY shard in the middle when the world allows it
+n = 60_000
+rows, ends = synth.fixed_corpus(b"deadbe", n, 32)
+data = rows.numpy().reshape(-1)
+ranges_a = [shard_range(n, r, WORLD) for r in range(WORLD)]
+rag, rends = synth.ragged_corpus(b"deadbeef", 40_000, 8, 128, seed=5)
+ranges_b = shard_ranges_by_bytes(rends, WORLD)
+if WORLD >= 3:  # an empty shard: rank 1 gives its share to rank 2
+    ranges_b[2] = (ranges_b[1][0], ranges_b[2][1]); ranges_b[1] = (ranges_b[1][0], ranges_b[1][0])
+for (dat, en, ranges, needle) in ((data, ends, ranges_a, "deadbe"), (rag, rends, ranges_b, "deadbeef")):
+    shards = shards_of(dat, en, ranges)
+    odata = np.concatenate([dat, np.zeros(64, np.uint8)])
+    for kw, okw in (({}, {}), ({"max_typos": 1, "sort": F.SortStrategy.ScoreThenIndexDesc}, {"max_typos": 1, "sort": "ScoreThenIndexDesc"}), ({"sort": F.SortStrategy.IndexAsc}, {"sort": "IndexAsc"})):
+        want = O.Matcher(needle, lanes=(64, 64, 32), **okw).match_packed(odata, en)
+        for all_ranks in (False, True):
+            uid = RcclShardComm.unique_id()
+            res = run_world(ranges, shards, needle, kw, all_ranks, uid)
+            for r in range(WORLD):
+                got, (sent, recvd) = res[r]
+                if r == 0 or all_ranks:
+                    assert got.tolist() == want.tolist(), (needle, kw, all_ranks, r, len(got), len(want))
+                else:
+                    assert len(got) == 0
+            # exactly the records travel: every non-receiving rank sends its run once (to every other rank with all_ranks)
+            per_rank = [int(((want["index"] >= lo) & (want["index"] < hi)).sum()) * 8 for lo, hi in ranges]
+            for r in range(WORLD):
+                sent, recvd = res[r][1]
+                assert sent == per_rank[r] * ((WORLD - 1) if all_ranks else (1 if r else 0)), (r, sent, per_rank)
+                assert recvd == ((sum(per_rank) - per_rank[r]) if (all_ranks or r == 0) else 0), (r, recvd, per_rank)
+            cases += 1
+            print("case", cases, needle, okw, all_ranks, "%%.1f s" %% (time.time() - T0), flush=True)
+# the empty pattern (CompiledPatterns::Empty): every index of every share, score 0, reversed for the *Desc strategies
+shards = shards_of(rag, rends, ranges_b)
+for sort in (F.SortStrategy.ScoreThenIndexAsc, F.SortStrategy.IndexDesc):
+    res = run_world(ranges_b, shards, "", {"sort": sort}, True, RcclShardComm.unique_id())
+    idx = np.arange(len(rends), dtype=np.uint32)[::-1 if sort == F.SortStrategy.IndexDesc else 1]
+    for r in range(WORLD):
+        got = res[r][0]
+        assert got["index"].tolist() == idx.tolist() and not got["score"].any() and not got["exact"].any(), (sort, r)
+print("RCCL-CABI-OK", WORLD, cases)
+'''
+
+
+def _fake_rccl():
+    src = os.path.join(ROOT, "tests", "cpp", "fake_rccl.cpp")
+    so = os.path.join(ROOT, "tests", "cpp", "libfake_rccl.so")
+    if not os.path.exists(so) or os.path.getmtime(src) > os.path.getmtime(so):
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-shared", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", src, "-o", so, "-L/opt/rocm/lib", "-lamdhip64",
+                               "-lpthread", "-Wl,-rpath,/opt/rocm/lib"])
+    return so
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_c_abi_rccl_exchange_with_several_ranks_as_threads(world):
+    """fzb_match_list_parallel_rccl with a world of 2 / 3 / 8: the ranks are threads of ONE process on the one GPU and the nine RCCL entry
+    points are a test double (tests/cpp/fake_rccl.cpp, through FZB_RCCL_LIB) that fails on any send / receive without its exact
+    counterpart - everything of the exchange except RCCL itself: the count all-gather, who sends what to whom at which offset, empty shards,
+    gather-to-root and gather-to-all, the rank-order merge; every receiver's list must be the oracle's for the whole list."""
+    code = _RCCL_CODE % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "tools": os.path.join(ROOT, "tools")}
+    r = subprocess.run([sys.executable, "-c", code, str(world)], capture_output=True, text=True, timeout=400, env=dict(os.environ, FZB_RCCL_LIB=_fake_rccl()))
+    assert r.returncode == 0 and "RCCL-CABI-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_c_abi_rccl_exchange_with_the_real_library_and_one_rank():
+    """The same entry points on the REAL RCCL (dlopen of librccl.so.1) with the one rank a one-GPU box allows: ncclCommInitRank, the count
+    all-gather on the communicator's stream, the merge; result = fzb_match_list's."""
+    code = r'''
+import sys
+sys.path[:0] = [%(root)r, %(tests)r, %(tools)r]
+import numpy as np
+import frizbee_amd as F, synth
+from frizbee_amd.distributed import RcclShardComm
+rows, ends = synth.fixed_corpus(b"deadbe", 200_000, 32)
+cp = F.Corpus(packed=(rows.numpy().reshape(-1), ends))
+comm = RcclShardComm(rank=0, world=1)
+for kw in ({}, {"max_typos": 2}, {"sort": F.SortStrategy.IndexDesc}):
+    m = F.Matcher("deadbe", F.Config(pf_lanes=64, sw_lanes=64, **kw))
+    want = m.match_list(cp); want["index"] += 11   # (a constant offset moves no record in any of the orders)
+    for all_ranks in (False, True):
+        got = comm.match_list_parallel(m, cp, 11, all_ranks=all_ranks)
+        assert len(got) > 1000 and got.tolist() == want.tolist(), (kw, all_ranks, len(got), len(want))
+        assert comm.last_exchange_bytes() == (0, 0)
+empty = F.Corpus(packed=(np.zeros(0, np.uint8), np.zeros(0, np.uint64)))
+assert len(comm.match_list_parallel(F.Matcher("deadbe"), empty, 0)) == 0
+assert len(RcclShardComm(rank=0, world=1).match_list_parallel(F.Matcher("deadbe"), empty, 0)) == 0   # a fresh communicator: nothing allocated yet
+got = comm.match_list_parallel(F.Matcher("", F.Config(sort=F.SortStrategy.IndexDesc)), cp, 5)
+assert got["index"].tolist() == list(range(5 + len(cp) - 1, 4, -1)) and not got["score"].any()
+comm.close()
+print("RCCL-CABI-REAL-OK")
+''' % {"root": ROOT, "tests": os.path.join(ROOT, "tests"), "tools": os.path.join(ROOT, "tools")}
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("FZB_RCCL_LIB", None)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "RCCL-CABI-REAL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])

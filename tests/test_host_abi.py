@@ -367,3 +367,27 @@ def test_class_composite_automaton_equals_the_byte_automaton():
         seen.append((needle, kg[0], kg[1]))
     print("class-composite automata (needle, K, G):", seen)
     assert sum(1 for _, k, g in seen if g == 4) >= 3 and sum(1 for _, k, g in seen if g == 2) >= 1
+
+
+def test_shard_comm_argument_checks_and_loud_failure_without_a_gpu():
+    """fzb_shard_comm_* (csrc/host_rccl.hip), host side: bad arguments are FZB_ERR_INVALID before RCCL is touched; without a GPU the
+    communicator cannot exist and says why (FZB_ERR_HIP) - there is no other transport to fall back to."""
+    import ctypes as C
+    import torch
+    l = F.lib()
+    out = C.c_void_p()
+    uid = bytes(128)
+    assert l.fzb_rccl_unique_id(None) == 1
+    assert l.fzb_shard_comm_create(None, 0, 1, C.byref(out)) == 1 and l.fzb_shard_comm_create(C.c_char_p(uid), 0, 1, None) == 1
+    for rank, world in ((-1, 2), (2, 2), (0, 0)):
+        assert l.fzb_shard_comm_create(C.c_char_p(uid), rank, world, C.byref(out)) == 1 and not out.value
+        assert b"outside a world" in l.fzb_last_error()
+    assert l.fzb_shard_comm_rank(None) == -1 and l.fzb_shard_comm_world(None) == 0
+    l.fzb_shard_comm_free(None)
+    n, res = C.c_size_t(), C.c_void_p()
+    assert l.fzb_match_list_parallel_rccl(None, None, 0, None, 0, C.byref(res), C.byref(n)) == 1
+    b = (C.c_uint64 * 2)()
+    assert l.fzb_shard_comm_last_exchange(None, b) == 1
+    if not torch.cuda.is_available():
+        assert l.fzb_shard_comm_create(C.c_char_p(uid), 0, 1, C.byref(out)) == 4 and not out.value
+        assert l.fzb_last_error()
