@@ -14,6 +14,7 @@
 //   (the borrowed &[S: AsRef<str>])                                        frizbee::Corpus: the list packed once, resident in HBM
 #pragma once
 #include <cstdint>
+#include <array>
 #include <memory>
 #include <optional>
 #include <stdexcept>
@@ -200,6 +201,31 @@ class ShardedCorpus {
     std::unique_ptr<fzb_sharded_corpus, Del> h_;
 };
 
+// One process per GPU (fzb_shard_comm, csrc/host_rccl.hip): the ranks in the role of `match_list_parallel`'s worker threads, the runs moved by
+// RCCL below the C ABI.  `ShardComm::unique_id()` on rank 0, its 128 bytes to the other ranks by whatever started them, then the constructor
+// on every rank (collective) with the rank's GPU current.
+class ShardComm {
+  public:
+    using Id = std::array<uint8_t, FZB_RCCL_ID_BYTES>;
+    static Id unique_id() {
+        Id id{};
+        check(fzb_rccl_unique_id(id.data()));
+        return id;
+    }
+    ShardComm(const Id& id, int rank, int world) {
+        fzb_shard_comm* c = nullptr;
+        check(fzb_shard_comm_create(id.data(), rank, world, &c));
+        h_.reset(c);
+    }
+    int rank() const { return fzb_shard_comm_rank(h_.get()); }
+    int world() const { return fzb_shard_comm_world(h_.get()); }
+    fzb_shard_comm* raw() const { return h_.get(); }
+
+  private:
+    struct Del { void operator()(fzb_shard_comm* c) const { fzb_shard_comm_free(c); } };
+    std::unique_ptr<fzb_shard_comm, Del> h_;
+};
+
 class Matcher {  // src/matcher/mod.rs:77-222
   public:
     // `Matcher::new(pattern, &config)`
@@ -319,6 +345,15 @@ class Matcher {  // src/matcher/mod.rs:77-222
         fzb_match* out = nullptr;
         size_t n = 0;
         check(fzb_match_list_parallel_sharded(single_.get(), corpus.raw(), &out, &n));
+        return take(out, n);
+    }
+    // `match_list_parallel` with one PROCESS per worker (fzb_match_list_parallel_rccl, collective): this rank's share of the list (`shard`,
+    // first global index `index_offset`); the whole list's result on rank 0 (`to_all`: on every rank), empty elsewhere.
+    std::vector<Match> match_list_parallel(const Corpus& shard, uint32_t index_offset, ShardComm& comm, bool to_all = false) {
+        if (!single_) throw Error(FZB_ERR_INVALID, "match_list_parallel over a communicator needs a single-pattern matcher");
+        fzb_match* out = nullptr;
+        size_t n = 0;
+        check(fzb_match_list_parallel_rccl(single_.get(), shard.raw(), index_offset, comm.raw(), to_all ? FZB_GATHER_ALL : FZB_GATHER_ROOT, &out, &n));
         return take(out, n);
     }
     // how the runs of that call reached the root device (fzb_matcher_shard_report: gather form, peer access per shard)

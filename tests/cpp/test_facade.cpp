@@ -205,6 +205,15 @@ static void gpu_side() {
             Matcher byscore("deadbe");
             CHECK(byscore.match_list_parallel(sc) == b);
         }
+        // ... and with one PROCESS per worker: the library's own RCCL communicator, here a world of the one rank this box allows
+        {
+            ShardComm comm(ShardComm::unique_id(), 0, 1);
+            CHECK(comm.rank() == 0 && comm.world() == 1);
+            Matcher byscore("deadbe");
+            CHECK(byscore.match_list_parallel(corpus, 0, comm) == b && byscore.match_list_parallel(corpus, 0, comm, true) == b);
+            auto shifted = m.match_list_parallel(corpus, 100, comm);
+            CHECK(shifted.size() == d.size() && !shifted.empty() && shifted[0].index == d[0].index + 100);
+        }
     }
 }
 
