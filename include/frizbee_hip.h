@@ -229,7 +229,10 @@ int fzb_merge_shard_runs(fzb_matcher* m, const void* const* dev_runs, const uint
  *                            (src/matcher/mod.rs:215-221) and copies the list to its host: *out / *out_len = the list
  *                            `match_list_parallel` returns for the WHOLE list, to be freed with fzb_matches_free; on a rank that does
  *                            not receive, *out = NULL and *out_len = 0.  Every rank must pass a matcher of the same needle and config.
- *   fzb_shard_comm_last_exchange   out_bytes[0] / [1] = record bytes this rank sent / received in its last query. */
+ *   fzb_shard_comm_last_exchange   out_bytes[0] / [1] = record bytes this rank sent / received in its last query.
+ * As with any collective: a rank that fails BEFORE the exchange (a bad argument, no memory) leaves the others waiting inside RCCL - check arguments
+ * that can differ per rank before the call, and treat an error of a collective call as the end of that communicator.  One communicator per thread;
+ * a communicator and the matchers used with it belong to the device that was current in fzb_shard_comm_create. */
 #define FZB_RCCL_ID_BYTES 128
 typedef struct fzb_shard_comm fzb_shard_comm;
 enum { FZB_GATHER_ROOT = 0, FZB_GATHER_ALL = 1 };
