@@ -205,6 +205,9 @@ void fzb_launch_dp(const CorpusDev& c, u64 first, u32 index_offset, const u32* i
                    int sw_lanes, int mode, int wmode, int pad_ok, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, int grid, hipStream_t st,
                    const RejectOut* rejects = nullptr);
 bool fzb_dp_short_applies(const CorpusDev& c, int sw_lanes, int mode);
+void fzb_launch_compact1_classify(const CorpusDev& c, u64 first, const u64* bitmap, const u32* tile_counts, u32 n_items, u32* out_idx, u32* total_out, const NeedleDev& nd, int sw_lanes,
+                                  int wmode, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride, int grid, hipStream_t st,
+                                  int split_multi);
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,
                            int wmode, fzb_match_rec* out, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride,
                            int num_cus, hipStream_t st, int part = 0, int split_multi = 0);

@@ -175,6 +175,7 @@ FzbKnobs parse_knobs() {
     k.no_lcs_dfa = set("FZB_NO_LCS_DFA");
     k.no_cdfa = set("FZB_NO_CDFA");
     k.no_dp_classes = set("FZB_NO_DP_CLASSES");
+    k.no_fused_classify = set("FZB_NO_FUSED_CLASSIFY");
     k.no_dp_cfm = set("FZB_NO_DP_CFM");
     k.no_dp_cfu = set("FZB_NO_DP_CFU");
     k.unicode_multi = num("FZB_UNICODE_MULTI", -1);
@@ -1326,6 +1327,7 @@ struct Pipe {
     const u32* win = nullptr;
     const u32* n_items_ptr = nullptr;
     int wmode = 0;
+    bool classified = false;  // the compaction launch classified its survivors too (k_compact1_classify): pipe_score_ascii starts at the class scorers
 };
 #define FZB_STAGE(name)                                                                                        \
     do {                                                                                                       \
@@ -1403,6 +1405,8 @@ static int pipe_typo_fast_path(Pipe& p) {
 
 // Filter stage of every other fuzzy query: streaming filter (or its item-list form) -> compaction [-> lane-exact window kernel -> second
 // compaction when the stream stage was a superset].  Leaves p.items / p.win / p.n_items_ptr / p.wmode for the scorers.
+static bool ascii_split_classes(const fzb_matcher* m, const CorpusDev& cd);
+static u32 pipe_qcap(const Pipe& p);
 static int pipe_filter_stage(Pipe& p) {
     fzb_matcher* m = p.m;
     Workspace& w = m->ws;
@@ -1451,8 +1455,21 @@ static int pipe_filter_stage(Pipe& p) {
                               nullptr, nullptr, lc.pad_ok, -1, (lc.filter_mode == 1 && m->cdfa_src == 1) ? w.cdfa : nullptr, (u32)m->cdfa.size(), m->cdfa_K, m->cdfa_G);
         FZB_PEV(3);
         FZB_STAGE("filter");
-        fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st, uni_typo_exact ? &cnt_c[1] : nullptr);
-        FZB_STAGE("compact1");
+        // ragged ASCII list, exact filter (0 typos) or whole-haystack windows: compaction and classification in ONE launch (k_compact1's grid: its
+        // workgroups classify the survivors they have just listed).  Step, us, two launches -> one (profiles/r06_fused_classify.txt): lists of 100 k /
+        // 300 k paths 34.7 -> 27.7 / 41.1 -> 36.1, 1.4 M paths 89.0 -> 86.5, the C4 shard 384 -> 384 (2, 3 or 4 workgroups per CU alike; 8 per CU
+        // lose 10 us on the two large lists: more workgroups than are resident at once, and each is a chain of dependent round trips)
+        const bool fuse = !nd.unicode && !p.trace && lc.filter_exact && !uni_typo_exact && (p.wmode == 1 || p.wmode == 2) && !fzb_knobs().no_fused_classify && w.cls_win && w.cls_lists &&
+                          ascii_split_classes(m, p.cd);
+        if (fuse) {
+            fzb_launch_compact1_classify(p.cd, p.first, w.bitmap, w.tile_counts, p.cnt, w.surv_idx, &cnt_c[0], nd, lc.sw_lanes, p.wmode, p.cap32, p.dev_count, w.overflow, pipe_qcap(p), cnt_c,
+                                         w.cls_win, w.cls_lists, (u32)w.cap_cls, p.cus * 4, p.st, 1);
+            p.classified = true;
+            FZB_STAGE("compact1 + classify");
+        } else {
+            fzb_launch_compact1(w.bitmap, w.tile_counts, p.cnt, nullptr, nullptr, w.surv_idx, &cnt_c[0], p.cus * 4, p.st, uni_typo_exact ? &cnt_c[1] : nullptr);
+            FZB_STAGE("compact1");
+        }
         p.items = w.surv_idx;
         if (uni_typo_exact) exact_wmode = 3;
     }
@@ -1476,6 +1493,15 @@ static int pipe_filter_stage(Pipe& p) {
 // most once by its scorer (front + back <= cnt), and the thread-per-haystack unicode scorer may hand up to FZB_UNICODE_FWD_CAP of the front's
 // windows on to the back WHILE the front is still being read: the back gets that many entries of room of its own below the front's reach
 // (ensure_workspace: the allocation holds at least count + FZB_UNICODE_FWD_CAP entries)
+// Ragged ASCII list whose scorers are ONE launch over the classifier's lists (k2_classes_all: single-chunk classes + multi-chunk windows by the
+// width of their last chunk's tail): classified scoring, windows wider than a chunk possible, dp_cfm.h's form for them
+static bool ascii_split_classes(const fzb_matcher* m, const CorpusDev& cd) {
+    const LaunchCfg& lc = m->lc;
+    const FzbKnobs& kn = fzb_knobs();
+    const bool no_wide = cd.max_len != 0 && cd.max_len <= (u32)lc.sw_lanes;
+    const bool classes = lc.cf_ok && !kn.no_dp_classes && !fzb_dp_short_applies(cd, lc.sw_lanes, 2);
+    return classes && !no_wide && lc.cfm_ok && !kn.no_dp_cfm;
+}
 static u32 pipe_qcap(const Pipe& p) { return (u32)std::min<u64>((u64)p.cnt + FZB_UNICODE_FWD_CAP, 0xFFFFFFFFull); }
 
 // matched indices: one traced generic scorer for every window width, ASCII and unicode (kernels_generic.hip)
@@ -1588,15 +1614,17 @@ static int pipe_score_ascii(Pipe& p) {
     const int mgrid = cus * 4;  // multi-chunk scorer: 2 waves per SIMD (the kernel is capped at 256 VGPRs)
     const int mmode = (lc.cfm_ok && !kn.no_dp_cfm) ? 2 : lc.bias_ok ? 1 : 0;
     if (!no_wide && (rc = ensure_dp_scratch(m, mgrid))) return rc;  // first use only (or fzb_matcher_reserve)
-    const int split = classes && !no_wide && mmode == 2;  // multi-chunk windows as k2w_classify's tail-class lists (needs dp_cfm.h's form; cf_ok includes pad_ok)
+    const int split = classes && !no_wide && mmode == 2;  // multi-chunk windows as k2w_classify's tail-class lists (needs dp_cfm.h's form; cf_ok includes pad_ok) == ascii_split_classes()
+    if (p.classified && !split) return fail(FZB_ERR_INVALID, "internal: the compaction classified a list whose scorers do not take class lists");
     bool fork = classes && !no_wide && !split;
     if (fork && ensure_aux_stream(m) != FZB_OK) {  // no second stream: everything on the caller's stream (the error text is dropped with the fallback)
         fork = false;
         fzb_clear_error();
     }
     if (split) {
-        fzb_launch_dp_classes(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, p.wmode, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
-                              (u32)w.cap_cls, cus, p.st, 1, split);
+        if (!p.classified)
+            fzb_launch_dp_classes(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, p.wmode, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,
+                                  (u32)w.cap_cls, cus, p.st, 1, split);
         fzb_launch_classes_all(cd, p.first, p.index_offset, p.items, w.cls_win, w.cls_lists, (u32)w.cap_cls, cnt_c, nd, lc.sw_lanes, p.out, p.cap32, w.dp_scratch, mgrid, cus, p.st);
     } else if (classes)
         fzb_launch_dp_classes(cd, p.first, p.index_offset, p.items, p.win, p.n_items_ptr, nd, lc.sw_lanes, p.wmode, p.out, p.cap32, p.dev_count, w.overflow, qcap, cnt_c, w.cls_win, w.cls_lists,

@@ -16,6 +16,7 @@
 // (see DESIGN.md).  BIAS=false keeps the literal 3-op form for scorings where the bias could overflow u16.
 #include "dp_cfm.h"
 #include "dp_quad.h"
+#include "compact1.h"
 #include <cstdlib>
 
 // MODE 0: literal gap scan (the bias could overflow u16), 1: biased scan (dp_body.h).  (dp_cf.h's form of this per-wave kernel - rounds 2-5 -
@@ -281,6 +282,62 @@ __global__ __launch_bounds__(128, 4) void k2b_dp_short(const u8* __restrict__ by
 //                 It writes, per survivor, one 16-byte record (window start, window end | bit 31 = "the window is the whole haystack", the
 //                 64-bit address of the haystack's first byte).  The scorers read that record and nothing else: no end offsets.
 // ---------------------------------------------------------------------------------------------------------------
+// One tile of the classifier: the workgroup's 256 threads take the survivors j0 .. j0 + 256 * PER - 1 (those below j_end and capacity), PER per
+// thread.  Called by every thread of the workgroup (barriers inside); s_cnt / s_base: nine words of LDS each.
+template <int PER>
+__device__ __forceinline__ void classify_tile(u32 j0, u32 j_end, u32* s_cnt, u32* s_base, const u8* __restrict__ bytes, const EndsAny& ends, u64 first, const u32* __restrict__ items,
+                                              const u32* __restrict__ win_in, const NeedleDev& nd, int wmode, u32 swl, uint4* __restrict__ meta, u32* __restrict__ lists, u32 list_stride,
+                                              u32* __restrict__ overflow, u32 qcap, u32* __restrict__ counters, u32 capacity, u32 split_multi) {
+    if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    u32 cls[PER], rank[PER], li[PER], ws[PER], we[PER];
+    const u8* src[PER];
+#pragma unroll
+    for (int p = 0; p < PER; p++) {
+        const u32 j = j0 + p * 256 + threadIdx.x;
+        cls[p] = 9; rank[p] = 0; li[p] = 0; ws[p] = 0; we[p] = 0; src[p] = bytes;
+        if (j < j_end && j < capacity) {
+            li[p] = items ? items[j] : j;
+            u32 L = 0;
+            u64 s;
+            haystack_span(ends, first + li[p], s, L);
+            src[p] = bytes + s;
+            if (wmode == 0) { ws[p] = win_in[2 * j]; we[p] = win_in[2 * j + 1]; }
+            else if (wmode == 2) { ws[p] = 0; we[p] = L; }
+            else window_first_last(nd, src[p], L, ws[p], we[p]);
+            const u32 sp = ws[p] ? ws[p] - 1 : 0;
+            const u32 m = we[p] - sp;
+            if (sp == 0 && we[p] == L) we[p] |= 0x80000000u;  // include_exact (src/matcher/algo.rs:238-249): the window is the whole haystack
+            cls[p] = m <= swl / 2 ? 0u : m <= 3 * swl / 4 ? 1u : m <= swl ? 2u : m <= FZB_MAX_HAYSTACK_LEN ? 3u : 4u;
+            if (split_multi && cls[p] == 3) cls[p] = 5 + ((m - 1) % swl) / (swl / 4);  // tail of 1 ..= swl bytes -> 0 ..= 3
+            rank[p] = atomicAdd(&s_cnt[cls[p]], 1u);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 9 && s_cnt[threadIdx.x]) {
+        const u32 c = threadIdx.x;
+        s_base[c] = atomicAdd(c < 3 ? &counters[8 + c] : c == 3 ? &counters[3] : c == 4 ? &counters[4] : &counters[12 + (c - 5)], s_cnt[c]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PER; p++) {
+        const u32 j = j0 + p * 256 + threadIdx.x;
+        if (cls[p] < 3 || (cls[p] >= 5 && cls[p] < 9)) {
+            const u32 l = cls[p] < 3 ? cls[p] : cls[p] - 2;
+            lists[(size_t)l * list_stride + s_base[cls[p]] + rank[p]] = j;
+            meta[j] = make_uint4(ws[p], we[p], (u32)(uintptr_t)src[p], (u32)((uintptr_t)src[p] >> 32));
+        } else if (cls[p] < 5) {
+            const u32 slot = s_base[cls[p]] + rank[p];
+            u32* qe = cls[p] == 4 ? overflow + 4 * (size_t)(qcap - 1 - slot) : overflow + 4 * (size_t)slot;
+            qe[0] = j;  // (output position, window start, window end, local haystack index)
+            qe[1] = ws[p];
+            qe[2] = we[p] & 0x7FFFFFFFu;
+            qe[3] = li[p];
+        }
+    }
+    __syncthreads();
+}
+
 template <int PER>
 __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes, const EndsAny ends, u64 first, const u32* __restrict__ items,
                                                     const u32* __restrict__ win_in, const u32* __restrict__ n_items_ptr, const NeedleDev nd, int wmode, u32 swl,
@@ -294,56 +351,34 @@ __global__ __launch_bounds__(256) void k2w_classify(const u8* __restrict__ bytes
     // a workgroup takes 256 * PER survivors at a time (PER per thread) and appends its members of a class with ONE global atomic per class
     // and tile: atomics that return a value to the same address serialise in L2 (one per 256 survivors cost ~40 us on the 0.6 M
     // survivors of the ragged list)
-    for (u32 j0 = blockIdx.x * (256 * PER); j0 < M; j0 += gridDim.x * (256 * PER)) {  // uniform trip count per workgroup
-        if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
-        __syncthreads();
-        u32 cls[PER], rank[PER], li[PER], ws[PER], we[PER];
-        const u8* src[PER];
-#pragma unroll
-        for (int p = 0; p < PER; p++) {
-            const u32 j = j0 + p * 256 + threadIdx.x;
-            cls[p] = 9; rank[p] = 0; li[p] = 0; ws[p] = 0; we[p] = 0; src[p] = bytes;
-            if (j < M && j < capacity) {
-                li[p] = items ? items[j] : j;
-                u32 L = 0;
-                u64 s;
-                haystack_span(ends, first + li[p], s, L);
-                src[p] = bytes + s;
-                if (wmode == 0) { ws[p] = win_in[2 * j]; we[p] = win_in[2 * j + 1]; }
-                else if (wmode == 2) { ws[p] = 0; we[p] = L; }
-                else window_first_last(nd, src[p], L, ws[p], we[p]);
-                const u32 sp = ws[p] ? ws[p] - 1 : 0;
-                const u32 m = we[p] - sp;
-                if (sp == 0 && we[p] == L) we[p] |= 0x80000000u;  // include_exact (src/matcher/algo.rs:238-249): the window is the whole haystack
-                cls[p] = m <= swl / 2 ? 0u : m <= 3 * swl / 4 ? 1u : m <= swl ? 2u : m <= FZB_MAX_HAYSTACK_LEN ? 3u : 4u;
-                if (split_multi && cls[p] == 3) cls[p] = 5 + ((m - 1) % swl) / (swl / 4);  // tail of 1 ..= swl bytes -> 0 ..= 3
-                rank[p] = atomicAdd(&s_cnt[cls[p]], 1u);
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 9 && s_cnt[threadIdx.x]) {
-            const u32 c = threadIdx.x;
-            s_base[c] = atomicAdd(c < 3 ? &counters[8 + c] : c == 3 ? &counters[3] : c == 4 ? &counters[4] : &counters[12 + (c - 5)], s_cnt[c]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int p = 0; p < PER; p++) {
-            const u32 j = j0 + p * 256 + threadIdx.x;
-            if (cls[p] < 3 || (cls[p] >= 5 && cls[p] < 9)) {
-                const u32 l = cls[p] < 3 ? cls[p] : cls[p] - 2;
-                lists[(size_t)l * list_stride + s_base[cls[p]] + rank[p]] = j;
-                meta[j] = make_uint4(ws[p], we[p], (u32)(uintptr_t)src[p], (u32)((uintptr_t)src[p] >> 32));
-            } else if (cls[p] < 5) {
-                const u32 slot = s_base[cls[p]] + rank[p];
-                u32* qe = cls[p] == 4 ? overflow + 4 * (size_t)(qcap - 1 - slot) : overflow + 4 * (size_t)slot;
-                qe[0] = j;  // (output position, window start, window end, local haystack index)
-                qe[1] = ws[p];
-                qe[2] = we[p] & 0x7FFFFFFFu;
-                qe[3] = li[p];
-            }
-        }
-        __syncthreads();
-    }
+    for (u32 j0 = blockIdx.x * (256 * PER); j0 < M; j0 += gridDim.x * (256 * PER))  // uniform trip count per workgroup
+        classify_tile<PER>(j0, M, s_cnt, s_base, bytes, ends, first, items, win_in, nd, wmode, swl, meta, lists, list_stride, overflow, qcap, counters, capacity, split_multi);
+}
+
+// Compaction and classification of a ragged ASCII list in ONE launch (round 6): k_compact1's workgroups - each owns a contiguous run of tiles and
+// derives its survivors' output positions itself (compact1.h) - classify the survivors they have just listed, a batch of tiles at a time, instead
+// of a second, dependent launch finding them again through the list.  Same lists, records and counters as k_compact1 + k2w_classify.
+template <int PER>
+__global__ __launch_bounds__(256) void k_compact1_classify(const u64* __restrict__ bitmap, const u32* __restrict__ tile_counts, u32 n_items, u32* __restrict__ out_idx,
+                                                           u32* __restrict__ total_out, const u8* __restrict__ bytes, const EndsAny ends, u64 first, const NeedleDev nd, int wmode,
+                                                           u32 swl, uint4* __restrict__ meta, u32* __restrict__ lists, u32 list_stride, u32* __restrict__ overflow, u32 qcap,
+                                                           u32* __restrict__ counters, u32 capacity, u32* __restrict__ dev_count, u32 split_multi) {
+    __shared__ u32 s_cnt[9], s_base[9];
+    compact1_body(
+        bitmap, tile_counts, n_items, nullptr, nullptr, out_idx, total_out, nullptr,
+        [&](u32 pos0, u32 nsurv) {
+            __threadfence_block();  // the batch's indices, written by other waves of this workgroup, are read below
+            __syncthreads();
+            // (one survivor per thread when the batch has no more than that: a second survivor is a second, dependent walk through its haystack)
+            if (nsurv <= 256)
+                classify_tile<1>(pos0, pos0 + nsurv, s_cnt, s_base, bytes, ends, first, out_idx, nullptr, nd, wmode, swl, meta, lists, list_stride, overflow, qcap, counters, capacity, split_multi);
+            else
+                for (u32 j0 = pos0; j0 < pos0 + nsurv; j0 += 256 * PER)
+                    classify_tile<PER>(j0, pos0 + nsurv, s_cnt, s_base, bytes, ends, first, out_idx, nullptr, nd, wmode, swl, meta, lists, list_stride, overflow, qcap, counters, capacity, split_multi);
+        },
+        [&](u32 total) {
+            if (dev_count) { dev_count[0] = total < capacity ? total : capacity; dev_count[1] = total; }
+        });
 }
 
 // (vblock of vgrid: the workgroup's index among those that walk this list - blockIdx / gridDim in the class's own launch, a slice of the grid
@@ -435,6 +470,15 @@ __global__ __launch_bounds__(128, (REAL * 4 <= SWL ? 4 : REAL * 8 <= 3 * SWL ? 3
     cf_build_tables<UPPER>(nd, tab);
     __syncthreads();
     dp_class_body<SWL, UPPER, REAL>(tab, blockIdx.x, gridDim.x, index_offset, items, meta, list, n_list_ptr, nd, out);
+}
+
+// k_compact1 + k2w_classify in one launch (k_compact1_classify): the bitmap and tile counts of the streaming filter -> the survivor list, its length
+// (total_out), and the classifier's lists / records / queue entries / counters / dev_count.  0-typo and whole-haystack windows only (wmode 1 / 2).
+void fzb_launch_compact1_classify(const CorpusDev& c, u64 first, const u64* bitmap, const u32* tile_counts, u32 n_items, u32* out_idx, u32* total_out, const NeedleDev& nd, int sw_lanes,
+                                  int wmode, u32 capacity, u32* dev_count, u32* overflow, u32 qcap, u32* counters, u32* win_out, u32* lists, u32 list_stride, int grid, hipStream_t st,
+                                  int split_multi) {
+    hipLaunchKernelGGL((k_compact1_classify<3>), dim3(grid), dim3(256), 0, st, bitmap, tile_counts, n_items, out_idx, total_out, c.bytes, EndsAny{c.ends, c.ends_u64}, first, nd, wmode,
+                       (u32)sw_lanes, (uint4*)win_out, lists, list_stride, overflow, qcap, counters, capacity, dev_count, (u32)split_multi);
 }
 
 void fzb_launch_dp_classes(const CorpusDev& c, u64 first, u32 index_offset, const u32* items, const u32* win_in, const u32* n_items_ptr, const NeedleDev& nd, int sw_lanes,

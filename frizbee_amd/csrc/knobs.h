@@ -15,6 +15,7 @@ struct FzbKnobs {
     bool no_lcs_dfa = false;         // FZB_NO_LCS_DFA=1        typo filter: the bit-vector kernel k1_filter (needles whose LCS automaton has more than 226 states) instead of the automaton in k1_dfa
     bool no_cdfa = false;            // FZB_NO_CDFA=1           ragged filter: the byte automaton (automata whose class-composite table exceeds 16 KB) instead of the composite one
     bool no_dp_classes = false;      // FZB_NO_DP_CLASSES=1     ASCII scorer: per-wave choice of computed lanes (k2b_dp: scorings outside dp_cf.h) instead of classified scoring
+    bool no_fused_classify = false;  // FZB_NO_FUSED_CLASSIFY=1 ragged ASCII lists: k_compact1 + k2w_classify as two launches (the form typo queries and item lists take) instead of k_compact1_classify
     bool no_dp_cfm = false;          // FZB_NO_DP_CFM=1         multi-chunk scorer in its first form (dp_body.h: scorings outside dp_cfm.h)
     bool no_dp_cfu = false;          // FZB_NO_DP_CFU=1         unicode scorer in its first form (scorings outside dp_unicode.h's biased form)
     int unicode_multi = -1;          // FZB_UNICODE_MULTI=0|1   unicode windows of 65..1024 bytes: never / always thread per haystack (k2u_dp_unicode_multi); default: by the queue's length, on the device

@@ -61,6 +61,8 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_COOP_BELOW": "100000000"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict()), ("wide", "deadbeef", dict(max_typos=1)), ("ragged", "DeadBeef", dict())]),  # multi-chunk windows: four lanes per window (the default below 49 152 queued)
     ({"FZB_COOP_BELOW": "0"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict())]),                                # ... never
     ({"FZB_DEBUG_SYNC": "1"}, [("short", "deadbe", dict()), ("ragged", "deadbeef", dict()), ("uniwide", "éa", dict(max_typos=None))]),
+    ({"FZB_NO_FUSED_CLASSIFY": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=None))]),  # k_compact1 + k2w_classify as two launches
+    ({"FZB_NO_FUSED_CLASSIFY": "1", "FZB_COOP_BELOW": "0"}, [("ragged", "deadbeef", dict())]),
 ]
 
 
