@@ -1459,8 +1459,12 @@ static int pipe_filter_stage(Pipe& p) {
         // workgroups classify the survivors they have just listed).  Step, us, two launches -> one (profiles/r06_fused_classify.txt): lists of 100 k /
         // 300 k paths 34.7 -> 27.7 / 41.1 -> 36.1, 1.4 M paths 89.0 -> 86.5, the C4 shard 384 -> 384 (2, 3 or 4 workgroups per CU alike; 8 per CU
         // lose 10 us on the two large lists: more workgroups than are resident at once, and each is a chain of dependent round trips)
+        // ... for lists of up to two tiles per CU (~ 0.5 M items: where a launch is a fifth of the query).  Beyond, the fused form gains nothing (above) and has a
+        // failure mode the two-launch form does not: a workgroup classifies what ITS tiles hold, so survivors that cluster in a few tiles - every file below
+        // one directory - are classified by a few workgroups, round after round (12.5 M items, all survivors in one stretch: 16 rounds in 52 workgroups),
+        // whereas k2w_classify spreads any survivor list evenly.  On a small list the worst case is two rounds.
         const bool fuse = !nd.unicode && !p.trace && lc.filter_exact && !uni_typo_exact && (p.wmode == 1 || p.wmode == 2) && !fzb_knobs().no_fused_classify && w.cls_win && w.cls_lists &&
-                          ascii_split_classes(m, p.cd);
+                          p.cnt <= (u32)p.cus * 2u * FZB_TILE && ascii_split_classes(m, p.cd);
         if (fuse) {
             fzb_launch_compact1_classify(p.cd, p.first, w.bitmap, w.tile_counts, p.cnt, w.surv_idx, &cnt_c[0], nd, lc.sw_lanes, p.wmode, p.cap32, p.dev_count, w.overflow, pipe_qcap(p), cnt_c,
                                          w.cls_win, w.cls_lists, (u32)w.cap_cls, p.cus * 4, p.st, 1);

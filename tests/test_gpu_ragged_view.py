@@ -214,3 +214,35 @@ def test_a_list_of_more_tiles_than_the_short_list_form_takes():
     assert len(want) > 40_000
     assert fm.last_counters()["multi_chunk_scored"] > 10_000
     assert_same(got, want, "540 k ragged haystacks")
+
+
+@pytest.mark.parametrize("n", [40_000, 700_000])
+def test_survivors_that_cluster_in_a_few_tiles(n):
+    """Every match of the list inside ONE stretch of haystacks (all files below one directory): on a small list the compaction launch classifies its
+    workgroup's survivors itself (k_compact1_classify) - here whole tiles of them, several rounds per workgroup, windows of every class; a list beyond two
+    tiles per CU takes k_compact1 + k2w_classify, which spread any survivor list evenly.  Both against the oracle, with and without the fused form."""
+    import os
+    rng = random.Random(n)
+    alphabet = "ghijkxyz_/."
+    hs = []
+    lo, hi = n // 3, n // 3 + 5000  # ~ five tiles of survivors
+    for i in range(n):
+        L = rng.randint(8, 140)
+        s = [rng.choice(alphabet) for _ in range(L)]
+        if lo <= i < hi and rng.random() < 0.95:
+            for q, c in zip(sorted(rng.sample(range(L), 8)), "deadbeef"):
+                s[q] = c
+        hs.append("".join(s))
+    cp = F.Corpus(hs)
+    want = O.Matcher("deadbeef", lanes=(64, 64, 32)).match_list(hs)
+    assert 4000 < len(want) < 5000
+    for fused in (True, False):
+        if not fused:
+            os.environ["FZB_NO_FUSED_CLASSIFY"] = "1"
+        F.lib().fzb_debug_reload_knobs()
+        try:
+            got = F.Matcher("deadbeef", F.Config(pf_lanes=64, sw_lanes=64)).match_list(cp)
+        finally:
+            os.environ.pop("FZB_NO_FUSED_CLASSIFY", None)
+            F.lib().fzb_debug_reload_knobs()
+        assert got.tolist() == want.tolist(), (n, fused)
