@@ -107,8 +107,11 @@ ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcoun
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     w->ag_send[(size_t)comm->rank] = sendbuff;
     if (!w->barrier()) return ncclInvalidUsage;
+    // (on the CALLER's stream, then drained: a device-to-device hipMemcpy on the null stream may return before it has run and is not ordered with the
+    // communicator's non-blocking stream - the next thing host_rccl.hip does is read recvbuff on that stream)
     for (int r = 0; r < w->n; r++)
-        if (hipMemcpy((char*)recvbuff + (size_t)r * bytes, w->ag_send[(size_t)r], bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        if (hipMemcpyAsync((char*)recvbuff + (size_t)r * bytes, w->ag_send[(size_t)r], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) return ncclUnhandledCudaError;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     return w->barrier() ? ncclSuccess : ncclInvalidUsage;
 }
 
@@ -161,7 +164,7 @@ ncclResult_t ncclGroupEnd() {
         Op* m = nullptr;
         for (Op& s : box) if (!s.matched) { m = &s; break; }
         if (m->bytes != op.bytes) ok = false;
-        else if (hipMemcpy(op.rbuf, m->sbuf, op.bytes, hipMemcpyDeviceToDevice) != hipSuccess) ok = false;
+        else if (hipMemcpyAsync(op.rbuf, m->sbuf, op.bytes, hipMemcpyDeviceToDevice, t_group_stream) != hipSuccess || hipStreamSynchronize(t_group_stream) != hipSuccess) ok = false;
         m->matched = true;
         lk.unlock();
         w->cv.notify_all();
