@@ -276,7 +276,7 @@ def merge_shard_runs(runs, sort):
 
 class RcclShardComm:
     """The multi-process form BELOW the C ABI (fzb_shard_comm, csrc/host_rccl.hip): one process per GPU, the runs exchanged by RCCL
-    inside libfrizbee_hip.so itself - what a Rust host binds; torch.distributed is used here only to carry the
+    inside libfrizbee_hip.so itself - what a Rust host binds ("One process per GPU, below the boundary"); torch.distributed is used here only to carry the
     128-byte communicator id from rank 0 to the other ranks (any channel does).  `match_list_parallel(matcher, shard, index_offset)` is
     `Matcher::match_list_parallel` (src/matcher/parallel.rs:18-89) over the WHOLE list: the ordered result on rank 0 (every rank with
     all_ranks=True), an empty array elsewhere."""
