@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -183,6 +184,7 @@ FzbKnobs parse_knobs() {
     k.coop_below = num("FZB_COOP_BELOW", -1);
     k.shard_gather_copy = getenv("FZB_SHARD_GATHER") != nullptr && !strcmp(getenv("FZB_SHARD_GATHER"), "copy");
     k.shard_inline = num("FZB_SHARD_INLINE", -1);
+    k.spin_wait_us = num("FZB_SPIN_WAIT_US", 1000);
     return k;
 }
 FzbKnobs& knobs_storage() {
@@ -1854,6 +1856,23 @@ PinnedPool& pinned_pool() {
     return *pool;
 }
 }  // namespace
+// The wait of a synchronous entry point: a query's results arrive tens to hundreds of microseconds after the call, and a thread that went to sleep in
+// hipStreamSynchronize wakes 10-20 us after the stream has drained; so the stream is POLLED first (hipStreamQuery, for at most FZB_SPIN_WAIT_US, default
+// 1 ms - a cold 8 ms upload-and-query ends up blocking as before), then blocked on.
+hipError_t fzb_stream_wait(hipStream_t st) {
+    const int budget_us = fzb_knobs().spin_wait_us;
+    if (budget_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e != hipErrorNotReady) return e;
+            if (std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= budget_us) break;
+            __builtin_ia32_pause();
+        }
+        (void)hipGetLastError();  // (hipErrorNotReady is not an error of the caller's)
+    }
+    return hipStreamSynchronize(st);
+}
 // (dev_words: eight u32 in device memory, all copied to h.count_host; the record count is word `n_word`)
 int fzb_fetch_records(FetchHint& h, const void* dev_records, const u32* dev_words, int n_word, size_t capacity, hipStream_t st, fzb_match** out, size_t* out_len) {
     if (!h.count_host) HIPCHK(hipHostMalloc((void**)&h.count_host, 32, hipHostMallocDefault));
@@ -1866,7 +1885,7 @@ int fzb_fetch_records(FetchHint& h, const void* dev_records, const u32* dev_word
     if (!r) return fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list");
     hipError_t e = hipMemcpyAsync(h.count_host, dev_words, 32, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && guess) e = hipMemcpyAsync(r, dev_records, guess * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = fzb_stream_wait(st);
     const size_t n = e == hipSuccess ? (size_t)h.count_host[n_word] : 0;
     if (e == hipSuccess && n > guess) {  // the result outgrew the guess (or there was none): the rest in a second copy
         size_t have = guess;
@@ -1877,7 +1896,7 @@ int fzb_fetch_records(FetchHint& h, const void* dev_records, const u32* dev_word
             have = 0;
         }
         e = hipMemcpyAsync(r + have, (const fzb_match*)dev_records + have, (n - have) * sizeof(fzb_match), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = fzb_stream_wait(st);
     }
     if (e != hipSuccess) {
         pinned_pool().put(r);

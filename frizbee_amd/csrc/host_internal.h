@@ -114,6 +114,8 @@ bool fzb_pinned_put(void* p);
 int fzb_bind_device(fzb_matcher* m);
 // count + records of a result in device memory -> a pooled pinned host buffer, with ONE synchronisation when the previous result's size
 // was a good guess (host.hip); dev_words = 8 u32, the record count is word n_word, the others stay readable in h.count_host
+// the wait of a synchronous entry point: polls the stream for up to FZB_SPIN_WAIT_US (default 1 ms), then blocks (host.hip)
+hipError_t fzb_stream_wait(hipStream_t st);
 int fzb_fetch_records(FetchHint& h, const void* dev_records, const u32* dev_words, int n_word, size_t capacity, hipStream_t st, fzb_match** out, size_t* out_len);
 int fzb_ensure_out_staging(fzb_matcher* m, size_t count);
 // the ordering post-step of `match_list` on the device (host.hip, next to fzb_sorted_range_device)

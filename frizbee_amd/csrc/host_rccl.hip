@@ -231,7 +231,7 @@ int fzb_match_list_parallel_rccl(fzb_matcher* m, const fzb_corpus* shard, uint32
     u32* all_words = c->words + 2;
     NCCLCHK(api, api->AllGather(c->words, all_words, 2, ncclUint32, c->comm, c->stream));
     HIPCHK(hipMemcpyAsync(c->words_host, all_words, 2 * (size_t)c->world * sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(fzb_stream_wait(c->stream));
     size_t others = 0, total = 0;
     for (int r = 0; r < c->world; r++) {
         const u32 written = c->words_host[2 * r], found = c->words_host[2 * r + 1];

@@ -491,7 +491,7 @@ int fzb_match_list_parallel_sharded(fzb_matcher* m, const fzb_sharded_corpus* sc
     if (!r) return drained(fzb_fail(FZB_ERR_HIP, "hipHostMalloc failed for the result list"));
     const fzb_match_rec* final_dev = (plan.reversed || plan.by_score) ? m->out_dev : gather;
     hipError_t e = hipMemcpyAsync(r, final_dev, total * sizeof(fzb_match), hipMemcpyDeviceToHost, m->shard_stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->shard_stream);
+    if (e == hipSuccess) e = fzb_stream_wait(m->shard_stream);
     if (e != hipSuccess) {
         fzb_pinned_put(r);
         return fzb_fail(FZB_ERR_HIP, std::string("device to host: ") + hipGetErrorString(e));

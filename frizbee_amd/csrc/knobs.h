@@ -21,6 +21,7 @@ struct FzbKnobs {
     int unicode_multi = -1;          // FZB_UNICODE_MULTI=0|1   unicode windows of 65..1024 bytes: never / always thread per haystack (k2u_dp_unicode_multi); default: by the queue's length, on the device
     int coop_below = -1;             // FZB_COOP_BELOW=n        multi-chunk ASCII windows of a ragged list: four lanes per window (dp_quad.h) when fewer than n are queued (0: never; default: 48 per workgroup of the slice = 49 152 on 256 CUs; below 32 768 windows of any kind the single-chunk ones too)
     int park_lds_kb = 37;            // FZB_PARK_LDS_KB         multi-chunk scorer: parked rows in LDS when they fit this many KB per workgroup (0: always the global slab, as for needles of many rows)
+    int spin_wait_us = 1000;         // FZB_SPIN_WAIT_US=n      synchronous entry points poll the stream for up to n us before they block (0: block at once, as hipStreamSynchronize does)
     // --- multi-device form ---
     bool shard_gather_copy = false;  // FZB_SHARD_GATHER=copy   counts to the host + hipMemcpyPeerAsync even when every shard shares the root device (the form shards on other devices take)
     int shard_inline = -1;           // FZB_SHARD_INLINE=0|1    shards on the root device: 0 = through the worker threads, 1 = enqueued by the caller

@@ -63,6 +63,7 @@ CASES = [  # (environment, [(list, needle, oracle config)])
     ({"FZB_DEBUG_SYNC": "1"}, [("short", "deadbe", dict()), ("ragged", "deadbeef", dict()), ("uniwide", "éa", dict(max_typos=None))]),
     ({"FZB_NO_FUSED_CLASSIFY": "1"}, [("ragged", "deadbeef", dict()), ("wide", "deadbeef", dict()), ("ragged", "deadbeef", dict(max_typos=None))]),  # k_compact1 + k2w_classify as two launches
     ({"FZB_NO_FUSED_CLASSIFY": "1", "FZB_COOP_BELOW": "0"}, [("ragged", "deadbeef", dict())]),
+    ({"FZB_SPIN_WAIT_US": "0"}, [("short", "deadbe", dict()), ("ragged", "deadbeef", dict())]),   # synchronous entry points block at once instead of polling first
 ]
 
 
